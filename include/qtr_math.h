@@ -1,0 +1,147 @@
+// qtr_math.h — deterministic scalar math shared by the CPU oracle (g++) and the gfx950 kernels (hipcc).
+//
+// Why this exists: the hot path's float outputs (FPFH histograms, normals) feed integer decisions
+// (histogram bins, nearest-neighbour indices, inlier sets).  libm (glibc) and ROCm's ocml round
+// atan2f/acosf/sinf/cosf differently, so "inlier index sets bit-exact" is only achievable if both
+// sides evaluate the SAME sequence of IEEE-754 basic operations.  Everything here uses only
+// + - * / sqrt on binary64 (correctly rounded on both x86-64 and gfx950) and must be compiled with
+// -ffp-contract=off (no FMA contraction) on both compilers.
+//
+// The functions replace, at the call sites the reference reaches through PCL 1.8.1 (not vendored
+// under /root/reference):
+//   qm_atan2f  <- atan2f in pcl::computePairFeatures (f1) and std::atan2 in pcl::computeRoots
+//   qm_acosf   <- acos(fabs(angle)) role-swap test in pcl::computePairFeatures
+//   qm_sincosf <- std::cos/std::sin(theta) in pcl::computeRoots
+// Results are the binary64-accurate value rounded once to binary32, i.e. equal to a correctly rounded
+// libm result except for ~1e-9 of inputs.
+//
+// Also: the counter-based RNG that replaces srand(time(NULL))/rand() in the tuple test
+// (reference src/teaser_utils/feature_matcher.cc:189-201) and the fixed-shape 64-lane summation
+// order used by the GNC-TLS rotation loop (reference include/quatro.hpp:488-531).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define QM_HD __host__ __device__ inline
+#else
+#define QM_HD inline
+#endif
+
+#define QM_PI 3.14159265358979323846
+#define QM_PI_2 1.57079632679489661923
+#define QM_PI_4 0.78539816339744830962
+
+// atan(x) for finite or +inf x >= 0, binary64, |err| ~ 1e-16.
+// Range reduction: x>1 -> pi/2 - atan(1/x); then three half-angle steps
+// t <- t / (1 + sqrt(1 + t^2)) bring t below tan(pi/32) ~ 0.0985; odd Taylor series to t^19.
+QM_HD double qm_atan_pos(double x) {
+  const bool inv = x > 1.0;
+  double t = inv ? 1.0 / x : x;
+  t = t / (1.0 + sqrt(1.0 + t * t));
+  t = t / (1.0 + sqrt(1.0 + t * t));
+  t = t / (1.0 + sqrt(1.0 + t * t));
+  const double t2 = t * t;
+  double s = 1.0 / 19.0;
+  s = 1.0 / 17.0 - t2 * s;
+  s = 1.0 / 15.0 - t2 * s;
+  s = 1.0 / 13.0 - t2 * s;
+  s = 1.0 / 11.0 - t2 * s;
+  s = 1.0 / 9.0 - t2 * s;
+  s = 1.0 / 7.0 - t2 * s;
+  s = 1.0 / 5.0 - t2 * s;
+  s = 1.0 / 3.0 - t2 * s;
+  s = 1.0 - t2 * s;
+  const double r = 8.0 * (t * s);
+  return inv ? (QM_PI_2 - r) : r;
+}
+
+QM_HD double qm_copysign(double mag, double sgn) {
+  return signbit(sgn) ? -mag : mag;
+}
+
+// C99 atan2 semantics, float in / float out, evaluated in binary64.
+QM_HD float qm_atan2f(float yf, float xf) {
+  const double y = (double)yf, x = (double)xf;
+  if (x != x || y != y) return yf + xf;  // NaN
+  if (y == 0.0) return (float)(signbit(x) ? qm_copysign(QM_PI, y) : qm_copysign(0.0, y));
+  if (x == 0.0) return (float)qm_copysign(QM_PI_2, y);
+  const bool xinf = (x - x) != 0.0, yinf = (y - y) != 0.0;
+  if (xinf) {
+    if (yinf) return (float)qm_copysign(x > 0 ? QM_PI_4 : 3.0 * QM_PI_4, y);
+    return (float)(x > 0 ? qm_copysign(0.0, y) : qm_copysign(QM_PI, y));
+  }
+  if (yinf) return (float)qm_copysign(QM_PI_2, y);
+  double a = qm_atan_pos(fabs(y) / fabs(x));
+  if (x < 0) a = QM_PI - a;
+  return (float)qm_copysign(a, y);
+}
+
+// acosf on [-1,1]; NaN outside (as libm). acos(x) = 2*atan(sqrt((1-x)/(1+x))).
+QM_HD float qm_acosf(float xf) {
+  const double x = (double)xf;
+  if (x != x) return xf;
+  if (x > 1.0 || x < -1.0) return (float)((x - x) / (x - x) + NAN);
+  if (x == -1.0) return (float)QM_PI;
+  return (float)(2.0 * qm_atan_pos(sqrt((1.0 - x) / (1.0 + x))));
+}
+
+// sin and cos of theta in [0, ~1.2] (computeRoots only produces theta in [0, pi/3]); Taylor series in
+// binary64 (degree 25/24), rounded once to float.
+QM_HD void qm_sincosf(float thetaf, float* s_out, float* c_out) {
+  const double t = (double)thetaf, t2 = t * t;
+  // sin: t * (1 - t2/(2*3) * (1 - t2/(4*5) * (...)))
+  double s = 1.0;
+  s = 1.0 - t2 / (24.0 * 25.0) * s;
+  s = 1.0 - t2 / (22.0 * 23.0) * s;
+  s = 1.0 - t2 / (20.0 * 21.0) * s;
+  s = 1.0 - t2 / (18.0 * 19.0) * s;
+  s = 1.0 - t2 / (16.0 * 17.0) * s;
+  s = 1.0 - t2 / (14.0 * 15.0) * s;
+  s = 1.0 - t2 / (12.0 * 13.0) * s;
+  s = 1.0 - t2 / (10.0 * 11.0) * s;
+  s = 1.0 - t2 / (8.0 * 9.0) * s;
+  s = 1.0 - t2 / (6.0 * 7.0) * s;
+  s = 1.0 - t2 / (4.0 * 5.0) * s;
+  s = 1.0 - t2 / (2.0 * 3.0) * s;
+  double c = 1.0;
+  c = 1.0 - t2 / (23.0 * 24.0) * c;
+  c = 1.0 - t2 / (21.0 * 22.0) * c;
+  c = 1.0 - t2 / (19.0 * 20.0) * c;
+  c = 1.0 - t2 / (17.0 * 18.0) * c;
+  c = 1.0 - t2 / (15.0 * 16.0) * c;
+  c = 1.0 - t2 / (13.0 * 14.0) * c;
+  c = 1.0 - t2 / (11.0 * 12.0) * c;
+  c = 1.0 - t2 / (9.0 * 10.0) * c;
+  c = 1.0 - t2 / (7.0 * 8.0) * c;
+  c = 1.0 - t2 / (5.0 * 6.0) * c;
+  c = 1.0 - t2 / (3.0 * 4.0) * c;
+  c = 1.0 - t2 / (1.0 * 2.0) * c;
+  *s_out = (float)(t * s);
+  *c_out = (float)c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG (SplitMix64 finaliser over seed + counter).  Replaces srand(time(NULL))/rand()
+// in the tuple test: trial t draws r_k = qm_rand_u32(seed, 3*t + k) % ncorr, k = 0,1,2.
+QM_HD uint64_t qm_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+QM_HD uint32_t qm_rand_u32(uint64_t seed, uint64_t counter) {
+  return (uint32_t)(qm_mix64(qm_mix64(seed) ^ (counter * 0xD1342543DE82EF95ULL)) >> 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-shape summation ("sum64"): the order in which the GNC-TLS loop's reductions are evaluated
+// on both sides.  Element j is accumulated sequentially into partial[j & 63] (ascending j), then the
+// 64 partials are folded by the shfl_down butterfly: for off = 32,16,...,1: p[l] += p[l+off], l<off.
+// qm_sum64_fold performs the fold on a 64-entry array (host oracle); the kernels do the same fold
+// with __shfl_down across one wavefront.
+QM_HD double qm_sum64_fold(double* p /*[64], clobbered*/) {
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int l = 0; l < off; ++l) p[l] = p[l] + p[l + off];
+  return p[0];
+}

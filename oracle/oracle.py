@@ -1,0 +1,253 @@
+"""ctypes binding of oracle/libquatro_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED (see quatro_oracle.cpp header): the reference has no golden vectors and cannot be built
+here, so this oracle defines the deterministic semantics the HIP path is compared against.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libquatro_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "quatro_oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "qtr_math.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("noise_bound", C.c_double), ("cbar2", C.c_double), ("rotation_gnc_factor", C.c_double),
+        ("rotation_cost_threshold", C.c_double), ("kcore_heuristic_threshold", C.c_double),
+        ("cote_noise_bound", C.c_double), ("ryrx", C.c_double * 9),
+        ("rotation_max_iterations", C.c_int), ("inlier_selection_mode", C.c_int), ("cote_median", C.c_int),
+        ("using_rot_inliers_when_estimating_cote", C.c_int), ("using_pre_estimated_ryrx", C.c_int),
+        ("clique_order", C.c_int),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("valid", C.c_int), ("T", C.c_double * 16), ("cost", C.c_double),
+        ("gnc_iters", C.c_int), ("n_clique", C.c_int), ("n_rot_inliers", C.c_int), ("n_final", C.c_int),
+        ("max_core", C.c_int), ("n_edges", C.c_int), ("n_card", C.c_int * 3),
+    ]
+
+
+def default_params(**kw) -> Params:
+    """Demo defaults actually run by the reference (config/params.yaml:22-44)."""
+    p = Params()
+    p.noise_bound = 0.3
+    p.cbar2 = 1.0
+    p.rotation_gnc_factor = 1.4
+    p.rotation_cost_threshold = 1.1e-4
+    p.kcore_heuristic_threshold = 0.5
+    p.cote_noise_bound = 0.3
+    for i, v in enumerate([1, 0, 0, 0, 1, 0, 0, 0, 1]):
+        p.ryrx[i] = float(v)
+    p.rotation_max_iterations = 50
+    p.inlier_selection_mode = 1
+    p.cote_median = 1
+    p.using_rot_inliers_when_estimating_cote = 0
+    p.using_pre_estimated_ryrx = 0
+    p.clique_order = 0
+    for k, v in kw.items():
+        if k == "ryrx":
+            for i, x in enumerate(np.asarray(v, dtype=np.float64).reshape(-1)):
+                p.ryrx[i] = float(x)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.qo_radius_neighbors.restype = C.c_longlong
+        _lib.qo_cote_estimate.restype = C.c_double
+    return _lib
+
+
+def _f4(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def set_threads(n: int) -> None:
+    lib().qo_set_threads(int(n))
+
+
+def max_threads() -> int:
+    return int(lib().qo_get_max_threads())
+
+
+def voxelize(xyz4, leaf: float):
+    xyz4 = _f4(xyz4)
+    out = np.zeros_like(xyz4)
+    n = lib().qo_voxelize(_p(xyz4, C.c_float), xyz4.shape[0], C.c_float(leaf), _p(out, C.c_float), xyz4.shape[0])
+    if n < 0:
+        return xyz4.copy()
+    return out[:n].copy()
+
+
+def radius_neighbors(xyz4, radius: float):
+    xyz4 = _f4(xyz4)
+    n = xyz4.shape[0]
+    off = np.zeros(n + 1, dtype=np.int64)
+    tot = lib().qo_radius_neighbors(_p(xyz4, C.c_float), n, C.c_double(radius), _p(off, C.c_longlong), None, None,
+                                    C.c_longlong(0))
+    idx = np.zeros(max(tot, 1), dtype=np.int32)
+    d2 = np.zeros(max(tot, 1), dtype=np.float32)
+    lib().qo_radius_neighbors(_p(xyz4, C.c_float), n, C.c_double(radius), _p(off, C.c_longlong), _p(idx, C.c_int),
+                              _p(d2, C.c_float), C.c_longlong(tot))
+    return off, idx[:tot], d2[:tot]
+
+
+def fpfh(xyz4, r_normal: float, r_fpfh: float):
+    """returns (normals4 [n,4] = nx,ny,nz,curvature ; spfh [n,33] ; fpfh [n,33])"""
+    xyz4 = _f4(xyz4)
+    n = xyz4.shape[0]
+    nrm = np.zeros((n, 4), dtype=np.float32)
+    sp = np.zeros((n, 33), dtype=np.float32)
+    de = np.zeros((n, 33), dtype=np.float32)
+    lib().qo_fpfh(_p(xyz4, C.c_float), n, C.c_double(r_normal), C.c_double(r_fpfh), _p(nrm, C.c_float),
+                  _p(sp, C.c_float), _p(de, C.c_float))
+    return nrm, sp, de
+
+
+def nn33(query, data):
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    out = np.zeros(query.shape[0], dtype=np.int32)
+    lib().qo_nn33(_p(query, C.c_float), query.shape[0], _p(data, C.c_float), data.shape[0], _p(out, C.c_int))
+    return out
+
+
+def match(xyz_s, desc_s, xyz_t, desc_t, crosscheck=True, tuple_test=True, tuple_scale=0.95, seed=0, debug=False):
+    xyz_s, xyz_t = _f4(xyz_s), _f4(xyz_t)
+    desc_s = np.ascontiguousarray(desc_s, dtype=np.float32)
+    desc_t = np.ascontiguousarray(desc_t, dtype=np.float32)
+    ns, nt = xyz_s.shape[0], xyz_t.shape[0]
+    cap = 3 * 100 * (ns + nt) if not crosscheck else ns + nt
+    corr = np.zeros((cap, 2), dtype=np.int32)
+    nn_ij = np.zeros(max(min(ns, nt), 1), dtype=np.int32)
+    nn_ji = np.zeros(max(max(ns, nt), 1), dtype=np.int32)
+    L = lib().qo_match(_p(xyz_s, C.c_float), ns, _p(desc_s, C.c_float), _p(xyz_t, C.c_float), nt,
+                       _p(desc_t, C.c_float), int(crosscheck), int(tuple_test), C.c_float(tuple_scale),
+                       C.c_ulonglong(seed), _p(corr, C.c_int), cap, _p(nn_ij, C.c_int), _p(nn_ji, C.c_int))
+    if debug:
+        return corr[:L].copy(), nn_ij, nn_ji
+    return corr[:L].copy()
+
+
+def graph_words(L: int) -> int:
+    return (L + 63) // 64
+
+
+def build_graph(src4, tgt4, noise_bound=0.3, cbar2=1.0):
+    src4, tgt4 = _f4(src4), _f4(tgt4)
+    L = src4.shape[0]
+    bm = np.zeros((L, graph_words(L)), dtype=np.uint64)
+    lib().qo_build_graph(_p(src4, C.c_float), _p(tgt4, C.c_float), L, C.c_double(noise_bound), C.c_double(cbar2),
+                         _p(bm, C.c_ulonglong))
+    return bm
+
+
+def kcore(bitmap):
+    bitmap = np.ascontiguousarray(bitmap, dtype=np.uint64)
+    L = bitmap.shape[0]
+    core = np.zeros(L, dtype=np.int32)
+    order = np.zeros(L, dtype=np.int32)
+    mc = lib().qo_kcore(_p(bitmap, C.c_ulonglong), L, _p(core, C.c_int), _p(order, C.c_int))
+    return core, order, mc
+
+
+def max_clique(bitmap, mode=1, kcore_thr=0.5, order_mode=0):
+    bitmap = np.ascontiguousarray(bitmap, dtype=np.uint64)
+    L = bitmap.shape[0]
+    cl = np.zeros(max(L, 1), dtype=np.int32)
+    m = lib().qo_max_clique(_p(bitmap, C.c_ulonglong), L, mode, C.c_double(kcore_thr), order_mode, _p(cl, C.c_int))
+    return cl[:m].copy()
+
+
+def gnc_rotation2d(src2, dst2, noise_bound, gnc_factor=1.4, max_iter=50, cost_thr=1.1e-4):
+    src2 = np.ascontiguousarray(src2, dtype=np.float64)
+    dst2 = np.ascontiguousarray(dst2, dtype=np.float64)
+    M = src2.shape[0]
+    R = np.zeros(4)
+    cost = C.c_double()
+    iters = C.c_int()
+    inl = np.zeros(M, dtype=np.uint8)
+    lib().qo_gnc_rotation2d(_p(src2, C.c_double), _p(dst2, C.c_double), M, C.c_double(noise_bound),
+                            C.c_double(gnc_factor), max_iter, C.c_double(cost_thr), _p(R, C.c_double),
+                            C.byref(cost), C.byref(iters), _p(inl, C.c_ubyte))
+    return R.reshape(2, 2), cost.value, iters.value, inl.astype(bool)
+
+
+def cote_estimate(X, rng, median=True):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    inl = np.zeros(X.shape[0], dtype=np.uint8)
+    nc = C.c_int()
+    e = lib().qo_cote_estimate(_p(X, C.c_double), X.shape[0], C.c_double(rng), int(median), _p(inl, C.c_ubyte),
+                               C.byref(nc))
+    return e, inl.astype(bool), nc.value
+
+
+def solve(src4, tgt4, params: Params | None = None):
+    src4, tgt4 = _f4(src4), _f4(tgt4)
+    L = src4.shape[0]
+    prm = params or default_params()
+    res = Result()
+    cl = np.zeros(max(L, 1), dtype=np.int32)
+    rot = np.zeros(max(L, 1), dtype=np.int32)
+    fin = np.zeros(max(L, 1), dtype=np.int32)
+    lib().qo_solve(_p(src4, C.c_float), _p(tgt4, C.c_float), L, C.byref(prm), C.byref(res), _p(cl, C.c_int),
+                   _p(rot, C.c_int), _p(fin, C.c_int))
+    return {
+        "status": res.status, "valid": bool(res.valid), "T": np.array(res.T[:]).reshape(4, 4), "cost": res.cost,
+        "gnc_iters": res.gnc_iters, "clique": cl[:res.n_clique].copy(), "rot_inliers": rot[:res.n_rot_inliers].copy(),
+        "final_inliers": fin[:res.n_final].copy(), "max_core": res.max_core, "n_edges": res.n_edges,
+        "n_card": list(res.n_card),
+    }
+
+
+def register_pair(src_raw4, tgt_raw4, leaf=0.3, r_normal=0.5, r_fpfh=0.75, tuple_scale=0.95, seed=0,
+                  params: Params | None = None):
+    src_raw4, tgt_raw4 = _f4(src_raw4), _f4(tgt_raw4)
+    prm = params or default_params()
+    res = Result()
+    cap = max(src_raw4.shape[0], tgt_raw4.shape[0])
+    counts = np.zeros(3, dtype=np.int32)
+    cl = np.zeros(cap, dtype=np.int32)
+    fin = np.zeros(cap, dtype=np.int32)
+    lib().qo_register_pair(_p(src_raw4, C.c_float), src_raw4.shape[0], _p(tgt_raw4, C.c_float), tgt_raw4.shape[0],
+                           C.c_float(leaf), C.c_double(r_normal), C.c_double(r_fpfh), C.c_float(tuple_scale),
+                           C.c_ulonglong(seed), C.byref(prm), C.byref(res), _p(counts, C.c_int), _p(cl, C.c_int),
+                           _p(fin, C.c_int), cap)
+    return {
+        "status": res.status, "valid": bool(res.valid), "T": np.array(res.T[:]).reshape(4, 4), "cost": res.cost,
+        "gnc_iters": res.gnc_iters, "clique": cl[:res.n_clique].copy(), "final_inliers": fin[:res.n_final].copy(),
+        "n_src": int(counts[0]), "n_tgt": int(counts[1]), "L": int(counts[2]), "max_core": res.max_core,
+        "n_edges": res.n_edges,
+    }

@@ -1,0 +1,1239 @@
+// quatro_oracle.cpp — CPU restatement ("oracle") of url-kaist/Quatro's registration hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may build, load or call it.  The product path (quatro_amd/ +
+// libquatro_hip.so) never links or calls anything in oracle/.
+//
+// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures, cannot be
+// compiled here (PCL / FLANN / Eigen / PMC absent) and is itself non-deterministic
+// (time-seeded tuple test, 12-thread racy clique heuristic, unstable sorts).  This file
+// therefore DEFINES the deterministic semantics the GPU path is compared against.  It follows the
+// reference's in-tree code line by line where that exists and restates the published algorithms of
+// the un-vendored dependencies (PCL 1.8.1, FLANN 1.9.1, Eigen 3.3, PMC tag `libpmc`) at the
+// reference's call sites.  Each function cites what it follows.  Declared divergences:
+//   D1 tuple-test RNG: counter-based qm_rand_u32(seed, 3*trial+k) instead of srand(time)/rand()
+//      (reference src/teaser_utils/feature_matcher.cc:189,199-201).
+//   D2 clique heuristic: single-thread sequential semantics instead of 12 OpenMP threads with a
+//      dynamic schedule (reference src/graph.cc:39).  Outer vertex order: by default the canonical
+//      (core number, vertex id) ascending order traversed from the back ("canonical"); the
+//      Batagelj-Zaversnik bucket order PMC produces is available as order=1 ("bz") for comparison.
+//      Within-core order is racy in the reference itself, so no order is "the" reference order.
+//   D3 ties: NN search -> lowest index; std::sort sites -> stable by (key, original position).
+//   D4 COTE median with n_card<=1 (UB in reference include/quatro.hpp:714-730) -> defined.
+//   D5 GNC rotation noise bound taken from the current params, not a function-local static
+//      (reference include/quatro.hpp:469-470); identical in the single-call demo flow.
+//   D6 2x2 weighted rotation in closed form instead of Eigen::JacobiSVD (utils.h:151-166); the
+//      H and cost reductions use the fixed 64-lane order of qtr_math.h (Eigen's GEMM order is
+//      build-dependent).  Agreement with an SVD evaluation is checked in tests to 1e-12.
+//   D7 libm atan2f/acosf/sinf/cosf replaced by the binary64 evaluations of qtr_math.h.
+//   D8 stdout prints removed.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/qtr_math.h"
+
+namespace {
+
+int g_threads = 1;
+
+struct P3 {
+  float x, y, z;
+};
+inline P3 ld4(const float* a, int i) { return P3{a[4 * i], a[4 * i + 1], a[4 * i + 2]}; }
+
+// ================================================================================================
+// K1  voxel-grid down-sampling.  Follows pcl::VoxelGrid<PointXYZ>::applyFilter (PCL 1.8.1) as called
+// from voxelize(), reference include/quatro.hpp:49-68 (leaf given as double, stored as float).
+// Within-voxel accumulation order: ascending original point index (PCL's std::sort is unstable; D3).
+// Returns n (voxels), or -1 if the grid would overflow int32 (PCL then passes the input through).
+int voxelize(const float* xyz4, int P, float leaf, float* out4, int cap) {
+  if (P <= 0) return 0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < P; ++i)
+    for (int a = 0; a < 3; ++a) {
+      float v = xyz4[4 * i + a];
+      mn[a] = v < mn[a] ? v : mn[a];
+      mx[a] = v > mx[a] ? v : mx[a];
+    }
+  const float inv = 1.0f / leaf;  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
+  int64_t d[3];
+  for (int a = 0; a < 3; ++a) d[a] = (int64_t)((mx[a] - mn[a]) * inv) + 1;
+  if (d[0] * d[1] * d[2] > (int64_t)std::numeric_limits<int32_t>::max()) return -1;
+  int minb[3], maxb[3], divb[3];
+  for (int a = 0; a < 3; ++a) {
+    minb[a] = (int)floorf(mn[a] * inv);
+    maxb[a] = (int)floorf(mx[a] * inv);
+    divb[a] = maxb[a] - minb[a] + 1;
+  }
+  const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+  std::vector<std::pair<uint32_t, int>> iv(P);
+  for (int i = 0; i < P; ++i) {
+    int i0 = (int)(floorf(xyz4[4 * i] * inv) - (float)minb[0]);
+    int i1 = (int)(floorf(xyz4[4 * i + 1] * inv) - (float)minb[1]);
+    int i2 = (int)(floorf(xyz4[4 * i + 2] * inv) - (float)minb[2]);
+    iv[i] = {(uint32_t)(i0 + i1 * mul1 + i2 * mul2), i};
+  }
+  std::sort(iv.begin(), iv.end());  // (idx, point) lexicographic == stable by idx
+  int n = 0;
+  for (int s = 0; s < P;) {
+    int e = s;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    while (e < P && iv[e].first == iv[s].first) {
+      cx += xyz4[4 * iv[e].second];
+      cy += xyz4[4 * iv[e].second + 1];
+      cz += xyz4[4 * iv[e].second + 2];
+      ++e;
+    }
+    const float cnt = (float)(e - s);
+    if (n < cap) {
+      out4[4 * n] = cx / cnt;
+      out4[4 * n + 1] = cy / cnt;
+      out4[4 * n + 2] = cz / cnt;
+      out4[4 * n + 3] = 0.f;
+    }
+    ++n;
+    s = e;
+  }
+  return n;
+}
+
+// ================================================================================================
+// Radius search.  Semantics of pcl::search::KdTree -> KdTreeFLANN::radiusSearch -> FLANN
+// KDTreeSingleIndex + RadiusResultSet (sorted): squared distance by flann::L2_Simple<float>
+// (((0+dx^2)+dy^2)+dz^2), kept iff d2 < float(double(r)*double(r)), results sorted ascending by
+// (d2, index) (FLANN DistanceIndex::operator<).  The query point itself is included.
+// Implementation: uniform hash grid (cell = r); exact, order-independent because of the final sort.
+struct Neighbors {
+  std::vector<int64_t> off;  // n+1
+  std::vector<int> idx;
+  std::vector<float> d2;
+};
+
+inline float l2_simple3(const P3& a, const P3& b) {
+  float r = 0.f, d;
+  d = a.x - b.x;
+  r += d * d;
+  d = a.y - b.y;
+  r += d * d;
+  d = a.z - b.z;
+  r += d * d;
+  return r;
+}
+
+void radius_neighbors(const float* xyz4, int n, double radius, Neighbors& nb) {
+  const float r2 = (float)(radius * radius);
+  const float cell = (float)radius * 1.001f;  // margin: float cell rounding can never hide a d2 < r2 pair
+  float mn[3] = {INFINITY, INFINITY, INFINITY};
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], xyz4[4 * i + a]);
+  auto cellof = [&](const P3& p, int* c) {
+    c[0] = (int)floorf((p.x - mn[0]) / cell);
+    c[1] = (int)floorf((p.y - mn[1]) / cell);
+    c[2] = (int)floorf((p.z - mn[2]) / cell);
+  };
+  auto keyof = [](int a, int b, int c) {
+    return ((uint64_t)(uint32_t)(a + 1) << 42) ^ ((uint64_t)(uint32_t)(b + 1) << 21) ^ (uint64_t)(uint32_t)(c + 1);
+  };
+  std::unordered_map<uint64_t, std::vector<int>> grid;
+  grid.reserve((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    int c[3];
+    cellof(ld4(xyz4, i), c);
+    grid[keyof(c[0], c[1], c[2])].push_back(i);
+  }
+  std::vector<std::vector<std::pair<uint64_t, int>>> lists((size_t)n);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+  for (int i = 0; i < n; ++i) {
+    const P3 p = ld4(xyz4, i);
+    int c[3];
+    cellof(p, c);
+    auto& L = lists[i];
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          auto it = grid.find(keyof(c[0] + dx, c[1] + dy, c[2] + dz));
+          if (it == grid.end()) continue;
+          for (int j : it->second) {
+            const float d2 = l2_simple3(p, ld4(xyz4, j));  // query first, as FLANN distance_(vec, point)
+            if (d2 < r2) {
+              uint32_t bits;
+              memcpy(&bits, &d2, 4);
+              L.push_back({((uint64_t)bits << 32) | (uint32_t)j, j});
+            }
+          }
+        }
+    std::sort(L.begin(), L.end());
+  }
+  nb.off.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) nb.off[i + 1] = nb.off[i] + (int64_t)lists[i].size();
+  nb.idx.resize((size_t)nb.off[n]);
+  nb.d2.resize((size_t)nb.off[n]);
+  for (int i = 0; i < n; ++i) {
+    int64_t o = nb.off[i];
+    for (auto& e : lists[i]) {
+      uint32_t bits = (uint32_t)(e.first >> 32);
+      float d2;
+      memcpy(&d2, &bits, 4);
+      nb.idx[o] = e.second;
+      nb.d2[o] = d2;
+      ++o;
+    }
+  }
+}
+
+// ================================================================================================
+// K2  surface normals.  Follows pcl::NormalEstimation<PointXYZ,Normal>::computeFeature (single
+// thread class chosen at reference src/teaser_utils/fpfh.cc:58-63) -> computePointNormal ->
+// computeMeanAndCovarianceMatrix (single-pass float, 9 accumulators) -> solvePlaneParameters ->
+// pcl::eigen33 (smallest eigenpair) -> flipNormalTowardsViewpoint(vp = 0,0,0).
+void compute_roots2(float b, float c, float* roots) {
+  roots[0] = 0.f;
+  float d = (float)((double)(b * b) - 4.0 * (double)c);
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+void compute_roots(const float m[9], float* roots) {
+  // characteristic polynomial x^3 - c2 x^2 + c1 x - c0
+  const float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] -
+                   m[8] * m[1] * m[1];
+  const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+  const float c2 = m[0] + m[4] + m[8];
+  if (fabsf(c0) < std::numeric_limits<float>::epsilon()) {
+    compute_roots2(c2, c1, roots);
+    return;
+  }
+  const float s_inv3 = (float)(1.0 / 3.0);
+  const float s_sqrt3 = sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.f) a_over_3 = 0.f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.f) q = 0.f;
+  const float rho = sqrtf(-a_over_3);
+  const float theta = qm_atan2f(sqrtf(-q), half_b) * s_inv3;
+  float sin_theta, cos_theta;
+  qm_sincosf(theta, &sin_theta, &cos_theta);
+  roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+  if (roots[1] >= roots[2]) {
+    std::swap(roots[1], roots[2]);
+    if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+  }
+  if (roots[0] <= 0.f) compute_roots2(c2, c1, roots);
+}
+
+inline void cross3(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// Eigen fixed-size-3 reduction order (redux_novec_unroller): e0 + (e1 + e2).
+inline float sum3_tree(float a, float b, float c) { return a + (b + c); }
+
+void eigen33_smallest(const float cov[9], float* eval, float* evec) {
+  float scale = 0.f;
+  for (int i = 0; i < 9; ++i) scale = std::max(scale, fabsf(cov[i]));
+  if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+  float s[9];
+  for (int i = 0; i < 9; ++i) s[i] = cov[i] / scale;
+  float roots[3];
+  compute_roots(s, roots);
+  *eval = roots[0] * scale;
+  s[0] -= roots[0];
+  s[4] -= roots[0];
+  s[8] -= roots[0];
+  float v1[3], v2[3], v3[3];
+  cross3(&s[0], &s[3], v1);
+  cross3(&s[0], &s[6], v2);
+  cross3(&s[3], &s[6], v3);
+  const float l1 = sum3_tree(v1[0] * v1[0], v1[1] * v1[1], v1[2] * v1[2]);
+  const float l2 = sum3_tree(v2[0] * v2[0], v2[1] * v2[1], v2[2] * v2[2]);
+  const float l3 = sum3_tree(v3[0] * v3[0], v3[1] * v3[1], v3[2] * v3[2]);
+  const float* v;
+  float l;
+  if (l1 >= l2 && l1 >= l3) {
+    v = v1;
+    l = l1;
+  } else if (l2 >= l1 && l2 >= l3) {
+    v = v2;
+    l = l2;
+  } else {
+    v = v3;
+    l = l3;
+  }
+  const float sl = sqrtf(l);
+  evec[0] = v[0] / sl;
+  evec[1] = v[1] / sl;
+  evec[2] = v[2] / sl;
+}
+
+// normals4: nx, ny, nz, curvature per point.  nbf = neighbours for the FPFH radius (sorted by d2);
+// the normal-radius neighbourhood is its prefix with d2 < rn2 (rn <= rf is enforced by the caller,
+// reference include/fpfh_manager.hpp:99-102).
+void normals_from_neighbors(const float* xyz4, int n, const Neighbors& nbf, float rn2, float* normals4) {
+  const float qnan = std::numeric_limits<float>::quiet_NaN();
+  for (int i = 0; i < n; ++i) {  // single-threaded in the reference (pcl::NormalEstimation)
+    int64_t b = nbf.off[i], e = nbf.off[i + 1];
+    int k = 0;
+    while (b + k < e && nbf.d2[b + k] < rn2) ++k;
+    float* o = normals4 + 4 * i;
+    if (k < 3) {
+      o[0] = o[1] = o[2] = o[3] = qnan;
+      continue;
+    }
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < k; ++t) {
+      const P3 q = ld4(xyz4, nbf.idx[b + t]);
+      acc[0] += q.x * q.x;
+      acc[1] += q.x * q.y;
+      acc[2] += q.x * q.z;
+      acc[3] += q.y * q.y;
+      acc[4] += q.y * q.z;
+      acc[5] += q.z * q.z;
+      acc[6] += q.x;
+      acc[7] += q.y;
+      acc[8] += q.z;
+    }
+    const float kf = (float)k;
+    for (int t = 0; t < 9; ++t) acc[t] /= kf;
+    float cov[9];
+    cov[0] = acc[0] - acc[6] * acc[6];
+    cov[1] = acc[1] - acc[6] * acc[7];
+    cov[2] = acc[2] - acc[6] * acc[8];
+    cov[4] = acc[3] - acc[7] * acc[7];
+    cov[5] = acc[4] - acc[7] * acc[8];
+    cov[8] = acc[5] - acc[8] * acc[8];
+    cov[3] = cov[1];
+    cov[6] = cov[2];
+    cov[7] = cov[5];
+    float ev, vec[3];
+    eigen33_smallest(cov, &ev, vec);
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    float curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
+    // flipNormalTowardsViewpoint, viewpoint (0,0,0)
+    const P3 p = ld4(xyz4, i);
+    const float vx = 0.f - p.x, vy = 0.f - p.y, vz = 0.f - p.z;
+    const float cos_theta = (vx * vec[0] + vy * vec[1] + vz * vec[2]);
+    if (cos_theta < 0) {
+      vec[0] *= -1;
+      vec[1] *= -1;
+      vec[2] *= -1;
+    }
+    o[0] = vec[0];
+    o[1] = vec[1];
+    o[2] = vec[2];
+    o[3] = curv;
+  }
+}
+
+// ================================================================================================
+// K3  SPFH.  Follows pcl::computePairFeatures + FPFHEstimation::computePointSPFHSignature (PCL 1.8.1)
+// as reached from FPFHEstimationOMP::computeFeature (reference src/teaser_utils/fpfh.cc:68-72).
+// Eigen Vector4f dot/norm reductions use the SSE packet order (e0+e2)+(e1+e3) with e3 = 0.
+inline float dot4_sse(const float* a, const float* b) { return (a[0] * b[0] + a[2] * b[2]) + (a[1] * b[1] + 0.0f); }
+
+// returns false when the pair is skipped; f[0..2] = f1,f2,f3
+bool pair_features(const P3& p1, const float* n1, const P3& p2, const float* n2, float* f) {
+  float dp[3] = {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
+  const float f4 = sqrtf(dot4_sse(dp, dp));
+  if (f4 == 0.0f) return false;
+  float n1c[3] = {n1[0], n1[1], n1[2]}, n2c[3] = {n2[0], n2[1], n2[2]};
+  const float angle1 = dot4_sse(n1c, dp) / f4;
+  const float angle2 = dot4_sse(n2c, dp) / f4;
+  float f3;
+  if (qm_acosf(fabsf(angle1)) > qm_acosf(fabsf(angle2))) {
+    for (int a = 0; a < 3; ++a) {
+      n1c[a] = n2[a];
+      n2c[a] = n1[a];
+      dp[a] *= -1.f;
+    }
+    f3 = -angle2;
+  } else
+    f3 = angle1;
+  float v[3];
+  cross3(dp, n1c, v);
+  const float v_norm = sqrtf(dot4_sse(v, v));
+  if (v_norm == 0.0f) return false;
+  v[0] /= v_norm;
+  v[1] /= v_norm;
+  v[2] /= v_norm;
+  float w[3];
+  cross3(n1c, v, w);
+  f[1] = dot4_sse(v, n2c);
+  f[0] = qm_atan2f(dot4_sse(w, n2c), dot4_sse(n1c, n2c));
+  f[2] = f3;
+  return true;
+}
+
+inline int bin11(double x) {  // static_cast<int>(floor(x)) with NaN -> 0 (x86 cvttsd2si gives INT_MIN, clamped to 0)
+  if (x != x) return 0;
+  double fl = floor(x);
+  if (fl < 0.0) return 0;
+  if (fl >= 11.0) return 10;
+  return (int)fl;
+}
+
+void spfh_from_neighbors(const float* xyz4, const float* normals4, int n, const Neighbors& nb, float* spfh33) {
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
+  memset(spfh33, 0, sizeof(float) * 33 * (size_t)n);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+  for (int i = 0; i < n; ++i) {
+    const int64_t b = nb.off[i], e = nb.off[i + 1];
+    const int k = (int)(e - b);
+    float* h = spfh33 + 33 * (size_t)i;
+    const float hist_incr = 100.0f / (float)(k - 1);
+    const P3 p = ld4(xyz4, i);
+    for (int64_t t = b; t < e; ++t) {
+      const int j = nb.idx[t];
+      if (j == i) continue;
+      float f[3];
+      if (!pair_features(p, normals4 + 4 * i, ld4(xyz4, j), normals4 + 4 * j, f)) continue;
+      h[bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))] += hist_incr;
+      h[11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))] += hist_incr;
+      h[22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))] += hist_incr;
+    }
+  }
+}
+
+// K4  FPFH weighting.  Follows FPFHEstimation::weightPointSPFHSignature (PCL 1.8.1).
+void fpfh_from_spfh(const float* spfh33, int n, const Neighbors& nb, float* desc33) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+  for (int i = 0; i < n; ++i) {
+    float* o = desc33 + 33 * (size_t)i;
+    for (int t = 0; t < 33; ++t) o[t] = 0.f;
+    double sum[3] = {0.0, 0.0, 0.0};
+    for (int64_t t = nb.off[i]; t < nb.off[i + 1]; ++t) {
+      if (nb.d2[t] == 0) continue;
+      const float weight = 1.0f / nb.d2[t];
+      const float* s = spfh33 + 33 * (size_t)nb.idx[t];
+      for (int blk = 0; blk < 3; ++blk)
+        for (int c = 0; c < 11; ++c) {
+          const float val = s[11 * blk + c] * weight;
+          sum[blk] += val;
+          o[11 * blk + c] += val;
+        }
+    }
+    for (int blk = 0; blk < 3; ++blk) {
+      if (sum[blk] != 0) sum[blk] = 100.0 / sum[blk];
+      for (int c = 0; c < 11; ++c) o[11 * blk + c] *= (float)sum[blk];
+    }
+  }
+}
+
+// ================================================================================================
+// K5  33-D nearest neighbour.  flann::L2<float>: groups of four, result += ((d0^2+d1^2)+d2^2)+d3^2,
+// then the 1-element tail (dim 33).  Exact (KDTreeSingleIndex, eps = 0); ties -> lowest index (D3).
+inline float l2_flann33(const float* a, const float* b) {
+  float result = 0.f;
+  for (int g = 0; g < 8; ++g) {
+    const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
+                d3 = a[4 * g + 3] - b[4 * g + 3];
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  const float d = a[32] - b[32];
+  result += d * d;
+  return result;
+}
+
+int nn33(const float* query, const float* data, int n) {
+  int best = -1;
+  float bd = INFINITY;
+  for (int i = 0; i < n; ++i) {
+    const float d = l2_flann33(query, data + 33 * (size_t)i);
+    if (d < bd) {  // KNNSimpleResultSet::addPoint: strict improvement only
+      bd = d;
+      best = i;
+    }
+  }
+  return best < 0 ? 0 : best;
+}
+
+// K5-K8  Follows teaser::Matcher::calculateCorrespondences (reference
+// include/teaser_utils/feature_matcher.h:42-74) -> normalizePoints (feature_matcher.cc:18-76,
+// use_absolute_scale = true) -> advancedMatching (feature_matcher.cc:77-265).
+// nn_large_of_small / nn_small_of_large (optional, sized n_small / n_large) expose the raw NN tables.
+int match(const float* xyz_s, int ns, const float* desc_s, const float* xyz_t, int nt, const float* desc_t,
+          int use_crosscheck, int use_tuple, float tuple_scale, uint64_t seed, int* corr, int cap, int* dbg_nn_i_of_j,
+          int* dbg_nn_j_of_i) {
+  // --- normalizePoints: mean-centred float copies (sequential float sums)
+  const float* xyz[2] = {xyz_s, xyz_t};
+  const int np[2] = {ns, nt};
+  std::vector<P3> pc[2];
+  for (int c = 0; c < 2; ++c) {
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    for (int i = 0; i < np[c]; ++i) {
+      mx = mx + xyz[c][4 * i];
+      my = my + xyz[c][4 * i + 1];
+      mz = mz + xyz[c][4 * i + 2];
+    }
+    const float inv_n = (float)np[c];
+    mx = mx / inv_n;
+    my = my / inv_n;
+    mz = mz / inv_n;
+    pc[c].resize((size_t)np[c]);
+    for (int i = 0; i < np[c]; ++i) pc[c][i] = P3{xyz[c][4 * i] - mx, xyz[c][4 * i + 1] - my, xyz[c][4 * i + 2] - mz};
+  }
+  const float* feat[2] = {desc_s, desc_t};
+  int fi = 0, fj = 1;
+  bool swapped = false;
+  if (np[fj] > np[fi]) {
+    std::swap(fi, fj);
+    swapped = true;
+  }
+  const int nPti = np[fi], nPtj = np[fj];
+  if (nPti == 0 || nPtj == 0) return 0;
+  // --- initial matching: i = NN_i(f_j) for every j; j' = NN_j(f_i) for every hit i
+  std::vector<int> nn_i_of_j((size_t)nPtj), i_to_j((size_t)nPti, -1);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+  for (int j = 0; j < nPtj; ++j) nn_i_of_j[j] = nn33(feat[fj] + 33 * (size_t)j, feat[fi], nPti);
+  std::vector<char> hit((size_t)nPti, 0);
+  for (int j = 0; j < nPtj; ++j) hit[nn_i_of_j[j]] = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+  for (int i = 0; i < nPti; ++i)
+    if (hit[i]) i_to_j[i] = nn33(feat[fi] + 33 * (size_t)i, feat[fj], nPtj);
+  if (dbg_nn_i_of_j) memcpy(dbg_nn_i_of_j, nn_i_of_j.data(), sizeof(int) * (size_t)nPtj);
+  if (dbg_nn_j_of_i) memcpy(dbg_nn_j_of_i, i_to_j.data(), sizeof(int) * (size_t)nPti);
+  std::vector<std::pair<int, int>> corres;
+  if (use_crosscheck) {
+    // (i, j) kept iff i_to_j[i] == j and nn_i_of_j[j] == i; emitted in ascending i
+    for (int i = 0; i < nPti; ++i) {
+      const int j = i_to_j[i];
+      if (j >= 0 && nn_i_of_j[j] == i) corres.push_back({i, j});
+    }
+  } else {
+    for (int i = 0; i < nPti; ++i)
+      if (i_to_j[i] != -1) corres.push_back({i, i_to_j[i]});
+    for (int j = 0; j < nPtj; ++j) corres.push_back({nn_i_of_j[j], j});
+  }
+  // --- tuple constraint (feature_matcher.cc:187-247), RNG per D1
+  if (use_tuple && tuple_scale != 0) {
+    const int ncorr = (int)corres.size();
+    const int64_t trials = (int64_t)ncorr * 100;
+    const float scale = tuple_scale;
+    std::vector<std::pair<int, int>> tup;
+    auto norm3 = [](const P3& a, const P3& b) {
+      const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+      return sqrtf(sum3_tree(dx * dx, dy * dy, dz * dz));
+    };
+    for (int64_t t = 0; t < trials; ++t) {
+      const int r0 = (int)(qm_rand_u32(seed, 3 * (uint64_t)t) % (uint32_t)ncorr);
+      const int r1 = (int)(qm_rand_u32(seed, 3 * (uint64_t)t + 1) % (uint32_t)ncorr);
+      const int r2 = (int)(qm_rand_u32(seed, 3 * (uint64_t)t + 2) % (uint32_t)ncorr);
+      const int idi0 = corres[r0].first, idj0 = corres[r0].second;
+      const int idi1 = corres[r1].first, idj1 = corres[r1].second;
+      const int idi2 = corres[r2].first, idj2 = corres[r2].second;
+      const float li0 = norm3(pc[fi][idi0], pc[fi][idi1]);
+      const float li1 = norm3(pc[fi][idi1], pc[fi][idi2]);
+      const float li2 = norm3(pc[fi][idi2], pc[fi][idi0]);
+      const float lj0 = norm3(pc[fj][idj0], pc[fj][idj1]);
+      const float lj1 = norm3(pc[fj][idj1], pc[fj][idj2]);
+      const float lj2 = norm3(pc[fj][idj2], pc[fj][idj0]);
+      if ((li0 * scale < lj0) && (lj0 < li0 / scale) && (li1 * scale < lj1) && (lj1 < li1 / scale) &&
+          (li2 * scale < lj2) && (lj2 < li2 / scale)) {
+        tup.push_back({idi0, idj0});
+        tup.push_back({idi1, idj1});
+        tup.push_back({idi2, idj2});
+      }
+    }
+    corres.swap(tup);
+  }
+  if (swapped)
+    for (auto& c : corres) std::swap(c.first, c.second);
+  std::sort(corres.begin(), corres.end());
+  corres.erase(std::unique(corres.begin(), corres.end()), corres.end());
+  const int L = (int)corres.size();
+  for (int i = 0; i < L && i < cap; ++i) {
+    corr[2 * i] = corres[i].first;
+    corr[2 * i + 1] = corres[i].second;
+  }
+  return L;
+}
+
+// ================================================================================================
+// K9-K11  pairwise-consistency graph as a bit matrix.  Follows Quatro::computeTIMs
+// (reference include/quatro.hpp:307-344), solveForScale (:355-386) and the addEdge loop (:784-789).
+// Points are float at the API (pcl::PointXYZ) and widened to double by pcl2eigen
+// (reference include/conversion.hpp:38-44).  Column norms: Eigen fixed-3 reduction e0+(e1+e2).
+inline double tim_norm(const double* a, const double* b) {  // || b - a ||
+  const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+  return sqrt(dx * dx + (dy * dy + dz * dz));
+}
+inline bool scale_consistent(double v1, double v2, double beta) {
+  const bool fwd = fabs(v2 / v1 - 1.0) <= beta * (1.0 / v1);  // beta * v1_dist.cwiseInverse()
+  const bool rev = fabs(v1 / v2 - 1.0) <= beta * (1.0 / v2);
+  return fwd && rev;
+}
+
+int graph_words(int L) { return (L + 63) / 64; }
+
+void build_graph(const double* src3, const double* tgt3, int L, double noise_bound, double cbar2, uint64_t* bm) {
+  const int W = graph_words(L);
+  memset(bm, 0, sizeof(uint64_t) * (size_t)W * (size_t)L);
+  const double beta = 2 * noise_bound * sqrt(cbar2);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+  for (int i = 0; i < L; ++i)
+    for (int j = 0; j < L; ++j) {
+      if (i == j) continue;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;  // TIM is v_hi - v_lo
+      const double a = tim_norm(src3 + 3 * lo, src3 + 3 * hi);
+      const double b = tim_norm(tgt3 + 3 * lo, tgt3 + 3 * hi);
+      if (scale_consistent(a, b, beta)) bm[(size_t)i * W + (j >> 6)] |= (1ULL << (j & 63));
+    }
+}
+
+// ================================================================================================
+// K12  max-clique heuristic.  Restates teaser::MaxCliqueSolver::findMaxClique (reference
+// src/graph.cc:12-104) over PMC (tag `libpmc`, not vendored): pmc_graph::compute_cores
+// (Batagelj-Zaversnik, 1-shifted ids, kcore = core+1) and pmc_heu::search_bounds / branch with
+// heu_strat "kcore", single thread (D2).
+struct Csr {
+  std::vector<long long> off;
+  std::vector<int> adj;
+};
+void bitmap_to_csr(const uint64_t* bm, int L, Csr& g) {
+  const int W = graph_words(L);
+  g.off.assign((size_t)L + 1, 0);
+  g.adj.clear();
+  for (int i = 0; i < L; ++i) {
+    for (int w = 0; w < W; ++w) {
+      uint64_t x = bm[(size_t)i * W + w];
+      while (x) {
+        const int b = __builtin_ctzll(x);
+        g.adj.push_back(w * 64 + b);
+        x &= x - 1;
+      }
+    }
+    g.off[i + 1] = (long long)g.adj.size();
+  }
+}
+
+// returns max_core; kcore[v] = core(v)+1 for v in [0,V); order[] = BZ removal order (0-based ids)
+int compute_cores_bz(const Csr& g, std::vector<int>& kcore, std::vector<int>& order) {
+  const int V = (int)g.off.size() - 1;
+  const int n = V + 1;
+  std::vector<int> pos((size_t)n), kc((size_t)n, 0), ko((size_t)n, 0);
+  int md = 0;
+  for (int v = 1; v < n; ++v) {
+    kc[v] = (int)(g.off[v] - g.off[v - 1]);
+    if (kc[v] > md) md = kc[v];
+  }
+  const int md_end = md + 1;
+  std::vector<int> bin((size_t)md_end, 0);
+  for (int v = 1; v < n; ++v) bin[kc[v]]++;
+  int start = 1;
+  for (int d = 0; d < md_end; ++d) {
+    const int num = bin[d];
+    bin[d] = start;
+    start += num;
+  }
+  for (int v = 1; v < n; ++v) {
+    pos[v] = bin[kc[v]];
+    ko[pos[v]] = v;
+    bin[kc[v]]++;
+  }
+  for (int d = md; d > 1; --d) bin[d] = bin[d - 1];
+  bin[0] = 1;
+  for (int i = 1; i < n; ++i) {
+    const int v = ko[i];
+    for (long long j = g.off[v - 1]; j < g.off[v]; ++j) {
+      const int u = g.adj[j] + 1;
+      if (kc[u] > kc[v]) {
+        const int du = kc[u], pu = pos[u], pw = bin[du], w = ko[pw];
+        if (u != w) {
+          pos[u] = pw;
+          ko[pu] = w;
+          pos[w] = pu;
+          ko[pw] = u;
+        }
+        bin[du]++;
+        kc[u]--;
+      }
+    }
+  }
+  kcore.assign((size_t)V, 0);
+  order.assign((size_t)V, 0);
+  for (int v = 0; v < V; ++v) {
+    kcore[v] = kc[v + 1] + 1;
+    order[v] = ko[v + 1] - 1;
+  }
+  if (V == 0) return 0;
+  return kcore[order[V - 1]] - 1;
+}
+
+struct HeuVertex {
+  int id, bound;
+};
+
+void heu_branch(const Csr& g, const std::vector<int>& K, std::vector<HeuVertex>& P, int sz, int& mc, std::vector<int>& C,
+                std::vector<short>& ind) {
+  if (!P.empty()) {
+    const int u = P.back().id;
+    P.pop_back();
+    for (long long j = g.off[u]; j < g.off[u + 1]; ++j) ind[g.adj[j]] = 1;
+    std::vector<HeuVertex> R;
+    R.reserve(P.size());
+    for (size_t i = 0; i < P.size(); ++i)
+      if (ind[P[i].id])
+        if (K[P[i].id] > mc) R.push_back(P[i]);
+    for (long long j = g.off[u]; j < g.off[u + 1]; ++j) ind[g.adj[j]] = 0;
+    const int mc_prev = mc;
+    heu_branch(g, K, R, sz + 1, mc, C, ind);
+    if (mc > mc_prev) C.push_back(u);
+  } else if (sz > mc)
+    mc = sz;
+}
+
+// order_mode 0: canonical (K, id) ascending, traversed from the back; 1: BZ order from compute_cores.
+int heu_search(const Csr& g, const std::vector<int>& K, const std::vector<int>& bz_order, int ub, int order_mode,
+               std::vector<int>& C_max) {
+  const int V = (int)g.off.size() - 1;
+  std::vector<int> order;
+  if (order_mode == 1)
+    order = bz_order;
+  else {
+    order.resize((size_t)V);
+    for (int v = 0; v < V; ++v) order[v] = v;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return K[a] < K[b]; });
+  }
+  std::vector<short> ind((size_t)V, 0);
+  std::vector<int> C;
+  std::vector<HeuVertex> P;
+  int mc = 0;
+  bool found_ub = false;
+  C_max.clear();
+  for (int i = V - 1; i >= 0; --i) {
+    if (found_ub) continue;
+    const int v = order[i];
+    const int mc_prev = mc;
+    int mc_cur = mc;
+    if (K[v] > mc) {
+      for (long long j = g.off[v]; j < g.off[v + 1]; ++j)
+        if (K[g.adj[j]] > mc) P.push_back(HeuVertex{g.adj[j], K[g.adj[j]]});
+      if ((int)P.size() > mc_cur) {
+        // std::sort(incr_heur) is unstable in PMC; defined here as stable -> (K, id) ascending (D3)
+        std::stable_sort(P.begin(), P.end(), [](const HeuVertex& a, const HeuVertex& b) { return a.bound < b.bound; });
+        heu_branch(g, K, P, 1, mc_cur, C, ind);
+        if (mc_cur > mc_prev) {
+          if (mc < mc_cur) {
+            mc = mc_cur;
+            C.push_back(v);
+            C_max = C;
+            if (mc >= ub) found_ub = true;
+          }
+        }
+      }
+      C.clear();
+      P.clear();
+    }
+  }
+  return (int)C_max.size();
+}
+
+// mode: 0 PMC_EXACT (unsupported here: falls back to heuristic result, flagged by caller), 1 PMC_HEU,
+// 2 KCORE_HEU.  Returns clique (unsorted, as PMC returns it).
+int find_max_clique(const uint64_t* bm, int L, int mode, double kcore_thr, int order_mode, std::vector<int>& C,
+                    int* max_core_out, std::vector<int>* core_out) {
+  Csr g;
+  bitmap_to_csr(bm, L, g);
+  std::vector<int> K, order;
+  const int max_core = compute_cores_bz(g, K, order);
+  if (max_core_out) *max_core_out = max_core;
+  if (core_out) {
+    core_out->resize((size_t)L);
+    for (int v = 0; v < L; ++v) (*core_out)[v] = K[v] - 1;
+  }
+  C.clear();
+  if (mode == 2 && kcore_thr != 1 && max_core > (int)(kcore_thr * (double)L)) {
+    // reference src/graph.cc:67-82 incl. its shifted indexing: k_cores has V+1 entries in PMC
+    // (entry V is a stale leftover of the shift); entry i (1..V) is tested, vertex i-1 is pushed.
+    std::vector<int> kc_shift((size_t)L + 1, 0);
+    for (int v = 0; v < L; ++v) kc_shift[v] = K[v];
+    kc_shift[L] = K[L - 1] - 1;  // PMC leaves kcore[n-1] at its pre-shift value = core(V-1)
+    for (int i = 1; i <= L; ++i)
+      if (kc_shift[i] >= max_core) C.push_back(i - 1);
+    return (int)C.size();
+  }
+  const int ub = max_core + 1;
+  heu_search(g, K, order, ub, order_mode, C);
+  return (int)C.size();
+}
+
+// ================================================================================================
+// K14  GNC-TLS 2-D rotation.  Follows Quatro::solveForRotation2D (reference include/quatro.hpp:
+// 430-572) with svdRot2d (include/teaser/utils.h:151-166) in closed form (D6).
+struct GncOut {
+  double R[4];
+  double cost;
+  int iters;
+};
+
+double sum64_strided(const std::vector<double>& v) {
+  double p[64];
+  for (int l = 0; l < 64; ++l) p[l] = 0.0;
+  for (size_t j = 0; j < v.size(); ++j) p[j & 63] = p[j & 63] + v[j];
+  return qm_sum64_fold(p);
+}
+
+void rot2d_closed_form(double h00, double h01, double h10, double h11, double* R) {
+  const double a = h00 + h11, b = h01 - h10;
+  const double nrm = sqrt(a * a + b * b);
+  double c = 1.0, s = 0.0;
+  if (nrm > 0.0) {
+    c = a / nrm;
+    s = b / nrm;
+  }
+  R[0] = c;
+  R[1] = -s;
+  R[2] = s;
+  R[3] = c;
+}
+
+void gnc_rotation2d(const double* src2, const double* dst2, int M, double noise_bound, double gnc_factor, int max_iter,
+                    double cost_thr, GncOut& out, std::vector<char>& inliers) {
+  double mu = 1, prev_cost = INFINITY;
+  out.cost = INFINITY;
+  out.iters = 0;
+  double nb_sq = noise_bound * noise_bound;
+  if (nb_sq < 1e-16) nb_sq = 1e-2;
+  std::vector<double> w((size_t)M, 1.0), r2((size_t)M), t0((size_t)M), t1((size_t)M), t2((size_t)M), t3((size_t)M);
+  out.R[0] = out.R[3] = 1;
+  out.R[1] = out.R[2] = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    out.iters = it + 1;
+    for (int j = 0; j < M; ++j) {
+      const double x0 = src2[2 * j], x1 = src2[2 * j + 1], y0 = dst2[2 * j], y1 = dst2[2 * j + 1];
+      const double wx0 = w[j] * x0, wx1 = w[j] * x1;
+      t0[j] = wx0 * y0;
+      t1[j] = wx0 * y1;
+      t2[j] = wx1 * y0;
+      t3[j] = wx1 * y1;
+    }
+    rot2d_closed_form(sum64_strided(t0), sum64_strided(t1), sum64_strided(t2), sum64_strided(t3), out.R);
+    double max_r = -INFINITY;
+    for (int j = 0; j < M; ++j) {
+      const double x0 = src2[2 * j], x1 = src2[2 * j + 1], y0 = dst2[2 * j], y1 = dst2[2 * j + 1];
+      const double e0 = y0 - (out.R[0] * x0 + out.R[1] * x1), e1 = y1 - (out.R[2] * x0 + out.R[3] * x1);
+      r2[j] = e0 * e0 + e1 * e1;
+      if (r2[j] > max_r) max_r = r2[j];
+    }
+    if (it == 0) {
+      mu = 1 / (2 * max_r / nb_sq - 1);
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
+    for (int j = 0; j < M; ++j) t0[j] = w[j] * r2[j];
+    out.cost = sum64_strided(t0);
+    for (int j = 0; j < M; ++j) {
+      if (r2[j] >= th1)
+        w[j] = 0;
+      else if (r2[j] <= th2)
+        w[j] = 1;
+      else
+        w[j] = sqrt(nb_sq * mu * (mu + 1) / r2[j]) - mu;
+    }
+    const double cost_diff = fabs(out.cost - prev_cost);
+    mu = mu * gnc_factor;
+    prev_cost = out.cost;
+    if (cost_diff < cost_thr) break;
+  }
+  inliers.resize((size_t)M);
+  for (int j = 0; j < M; ++j) inliers[j] = w[j] >= 0.4;
+}
+
+// ================================================================================================
+// K15  COTE (component-wise translation estimate).  Follows Quatro::estimate (reference
+// include/quatro.hpp:618-747): adaptive-voting sweep over 2N interval endpoints.  Sort is stable by
+// (value, insertion position) (D3); median of the last n_card sweep members (quirk kept), n_card<=1
+// defined (D4).
+double cote_estimate(const std::vector<double>& X, double range, bool median_sel, std::vector<char>& inl,
+                     int* n_card_out) {
+  const int N = (int)X.size();
+  struct Ev {
+    double v;
+    int id;  // +(i+1) lower, -(i+1) upper
+    int pos;
+  };
+  std::vector<Ev> h((size_t)(2 * N));
+  for (int i = 0; i < N; ++i) {
+    h[2 * i] = Ev{X[i] - range, i + 1, 2 * i};
+    h[2 * i + 1] = Ev{X[i] + range, -i - 1, 2 * i + 1};
+  }
+  std::sort(h.begin(), h.end(), [](const Ev& a, const Ev& b) { return a.v < b.v || (a.v == b.v && a.pos < b.pos); });
+  const double weight = 1.0 / (range * range);  // weights = ranges.square().inverse()
+  const int nc = 2 * N;
+  std::vector<double> x_hat((size_t)nc), x_cost((size_t)nc);
+  std::vector<int> card((size_t)nc);
+  double ranges_inverse_sum = 0;  // ranges.sum(): sequential add of N equal values
+  for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
+  double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
+  int consensus = 0;
+  for (int i = 0; i < nc; ++i) {
+    const int idx = std::abs(h[i].id) - 1;
+    const int eps = h[i].id > 0 ? 1 : -1;
+    consensus += eps;
+    dot_weights_consensus += eps * weight;
+    dot_X_weights += eps * weight * X[idx];
+    ranges_inverse_sum -= eps * range;
+    sum_xi += eps * X[idx];
+    sum_xi_square += eps * X[idx] * X[idx];
+    card[i] = consensus;
+    x_hat[i] = dot_X_weights / dot_weights_consensus;
+    const double residual = consensus * x_hat[i] * x_hat[i] + sum_xi_square - 2 * sum_xi * x_hat[i];
+    x_cost[i] = residual + ranges_inverse_sum;
+  }
+  int min_idx = 0;  // Eigen minCoeff(&idx): first strict minimum, NaN never selected unless first
+  for (int i = 1; i < nc; ++i)
+    if (x_cost[i] < x_cost[min_idx]) min_idx = i;
+  double est = x_hat[min_idx];
+  const int n_card = card[min_idx];
+  if (n_card_out) *n_card_out = n_card;
+  if (median_sel) {
+    if (n_card >= 2) {
+      std::vector<double> cand;
+      for (int j = 0; j < n_card; ++j) cand.push_back(X[std::abs(h[min_idx - j].id) - 1]);
+      std::sort(cand.begin(), cand.end());
+      est = (cand[cand.size() / 2 - 1] + cand[cand.size() / 2]) / 2.0;
+    } else if (n_card == 1) {
+      est = X[std::abs(h[min_idx].id) - 1];
+    }
+  }
+  inl.resize((size_t)N);
+  for (int i = 0; i < N; ++i) inl[i] = fabs(X[i] - est) <= range;
+  return est;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C API (ctypes-friendly)
+extern "C" {
+
+struct qo_params {
+  double noise_bound;         // Params::noise_bound (0.3)
+  double cbar2;               // Params::cbar2 (1.0)
+  double rotation_gnc_factor; // 1.4
+  double rotation_cost_threshold;
+  double kcore_heuristic_threshold;
+  double cote_noise_bound;    // Quatro::noise_bound_ member (0.3), reference quatro.hpp:115,601
+  double ryrx[9];             // estimated_RyRx_ (row-major)
+  int rotation_max_iterations;
+  int inlier_selection_mode;  // 0 PMC_EXACT, 1 PMC_HEU, 2 KCORE_HEU, 3 NONE
+  int cote_median;            // 1 = "median", 0 = "weighted_mean"
+  int using_rot_inliers_when_estimating_cote;
+  int using_pre_estimated_ryrx;
+  int clique_order;           // 0 canonical, 1 bz  (oracle-only knob, D2)
+};
+
+struct qo_result {
+  int status;  // 0 ok, 1 clique too small (solution invalid), 2 unsupported mode
+  int valid;
+  double T[16];  // row-major 4x4
+  double cost;
+  int gnc_iters;
+  int n_clique;
+  int n_rot_inliers;
+  int n_final;
+  int max_core;
+  int n_edges;  // undirected edge count of the consistency graph
+  int n_card[3];
+};
+
+void qo_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int qo_get_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int qo_voxelize(const float* xyz4, int P, float leaf, float* out4, int cap) { return voxelize(xyz4, P, leaf, out4, cap); }
+
+// neighbour lists for tests: returns total count; off has n+1 entries; idx/d2 filled up to cap
+long long qo_radius_neighbors(const float* xyz4, int n, double radius, long long* off, int* idx, float* d2,
+                              long long cap) {
+  Neighbors nb;
+  radius_neighbors(xyz4, n, radius, nb);
+  for (int i = 0; i <= n; ++i) off[i] = nb.off[i];
+  const long long tot = nb.off[n];
+  for (long long t = 0; t < tot && t < cap; ++t) {
+    idx[t] = nb.idx[t];
+    d2[t] = nb.d2[t];
+  }
+  return tot;
+}
+
+// reference src/teaser_utils/fpfh.cc:44-75 (4-argument overload used by FPFHManager)
+int qo_fpfh(const float* xyz4, int n, double r_normal, double r_fpfh, float* normals4, float* spfh33, float* desc33) {
+  if (n <= 0) return 0;
+  Neighbors nb;
+  radius_neighbors(xyz4, n, r_fpfh, nb);
+  normals_from_neighbors(xyz4, n, nb, (float)(r_normal * r_normal), normals4);
+  std::vector<float> spfh_local;
+  float* sp = spfh33;
+  if (!sp) {
+    spfh_local.resize(33 * (size_t)n);
+    sp = spfh_local.data();
+  }
+  spfh_from_neighbors(xyz4, normals4, n, nb, sp);
+  fpfh_from_spfh(sp, n, nb, desc33);
+  return 0;
+}
+
+int qo_nn33(const float* query, int nq, const float* data, int n, int* out) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+  for (int q = 0; q < nq; ++q) out[q] = nn33(query + 33 * (size_t)q, data, n);
+  return 0;
+}
+
+int qo_match(const float* xyz_s, int ns, const float* desc_s, const float* xyz_t, int nt, const float* desc_t,
+             int use_crosscheck, int use_tuple, float tuple_scale, unsigned long long seed, int* corr, int cap,
+             int* dbg_nn_i_of_j, int* dbg_nn_j_of_i) {
+  return match(xyz_s, ns, desc_s, xyz_t, nt, desc_t, use_crosscheck, use_tuple, tuple_scale, seed, corr, cap,
+               dbg_nn_i_of_j, dbg_nn_j_of_i);
+}
+
+int qo_graph_words(int L) { return graph_words(L); }
+
+// src4/tgt4: float xyz(+pad) as pcl::PointXYZ; bitmap: L * words uint64
+int qo_build_graph(const float* src4, const float* tgt4, int L, double noise_bound, double cbar2,
+                   unsigned long long* bitmap) {
+  std::vector<double> s(3 * (size_t)L), t(3 * (size_t)L);
+  for (int i = 0; i < L; ++i)
+    for (int a = 0; a < 3; ++a) {
+      s[3 * i + a] = (double)src4[4 * i + a];
+      t[3 * i + a] = (double)tgt4[4 * i + a];
+    }
+  build_graph(s.data(), t.data(), L, noise_bound, cbar2, (uint64_t*)bitmap);
+  return 0;
+}
+
+// core numbers (not shifted) + BZ order; returns max core
+int qo_kcore(const unsigned long long* bitmap, int L, int* core, int* bz_order) {
+  Csr g;
+  bitmap_to_csr((const uint64_t*)bitmap, L, g);
+  std::vector<int> K, order;
+  const int mc = compute_cores_bz(g, K, order);
+  for (int v = 0; v < L; ++v) {
+    if (core) core[v] = K[v] - 1;
+    if (bz_order) bz_order[v] = order[v];
+  }
+  return mc;
+}
+
+// returns clique size; clique[] sorted ascending
+int qo_max_clique(const unsigned long long* bitmap, int L, int mode, double kcore_thr, int order_mode, int* clique) {
+  std::vector<int> C;
+  find_max_clique((const uint64_t*)bitmap, L, mode, kcore_thr, order_mode, C, nullptr, nullptr);
+  std::sort(C.begin(), C.end());
+  for (size_t i = 0; i < C.size(); ++i) clique[i] = C[i];
+  return (int)C.size();
+}
+
+int qo_gnc_rotation2d(const double* src2, const double* dst2, int M, double noise_bound, double gnc_factor, int max_iter,
+                      double cost_thr, double* R4, double* cost, int* iters, unsigned char* inliers) {
+  GncOut o;
+  std::vector<char> inl;
+  gnc_rotation2d(src2, dst2, M, noise_bound, gnc_factor, max_iter, cost_thr, o, inl);
+  for (int i = 0; i < 4; ++i) R4[i] = o.R[i];
+  *cost = o.cost;
+  *iters = o.iters;
+  for (int j = 0; j < M; ++j) inliers[j] = (unsigned char)inl[j];
+  return 0;
+}
+
+double qo_cote_estimate(const double* X, int N, double range, int median_sel, unsigned char* inliers, int* n_card) {
+  std::vector<double> x(X, X + N);
+  std::vector<char> inl;
+  const double e = cote_estimate(x, range, median_sel != 0, inl, n_card);
+  for (int i = 0; i < N; ++i) inliers[i] = (unsigned char)inl[i];
+  return e;
+}
+
+// Back end: Quatro::computeTransformation(Eigen::Matrix4d&) (reference include/quatro.hpp:769-936).
+// clique / rot_inliers / final_inliers: caller buffers of capacity L.
+int qo_solve(const float* src4, const float* tgt4, int L, const qo_params* prm, qo_result* res, int* clique,
+             int* rot_inliers, int* final_inliers) {
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 4; ++i) res->T[5 * i] = 1.0;
+  res->cost = INFINITY;
+  if (prm->inlier_selection_mode == 3 || prm->inlier_selection_mode == 0) {
+    // NONE leaves max_clique_ empty in the reference (chain TIMs over an empty clique, then UB);
+    // PMC_EXACT needs PMC's exact branch-and-bound: both outside this restatement.
+    res->status = 2;
+    return 2;
+  }
+  std::vector<double> s(3 * (size_t)L), t(3 * (size_t)L);
+  for (int i = 0; i < L; ++i)
+    for (int a = 0; a < 3; ++a) {
+      s[3 * i + a] = (double)src4[4 * i + a];
+      t[3 * i + a] = (double)tgt4[4 * i + a];
+    }
+  const int W = graph_words(L);
+  std::vector<uint64_t> bm((size_t)W * (size_t)L);
+  build_graph(s.data(), t.data(), L, prm->noise_bound, prm->cbar2, bm.data());
+  long long deg_sum = 0;
+  for (uint64_t x : bm) deg_sum += __builtin_popcountll(x);
+  res->n_edges = (int)(deg_sum / 2);
+  std::vector<int> C;
+  find_max_clique(bm.data(), L, prm->inlier_selection_mode, prm->kcore_heuristic_threshold, prm->clique_order, C,
+                  &res->max_core, nullptr);
+  std::sort(C.begin(), C.end());
+  const int M = (int)C.size();
+  res->n_clique = M;
+  for (int i = 0; i < M; ++i) clique[i] = C[i];
+  if (M <= 1) {
+    res->valid = 0;
+    res->status = 1;
+    return 1;
+  }
+  // chain TIMs (quatro.hpp:817-844), XY rows only for the 2-D solver (:396-402)
+  std::vector<double> ps(2 * (size_t)M), pd(2 * (size_t)M);
+  for (int i = 0; i < M; ++i) {
+    const int root = C[i], leaf = (i != M - 1) ? C[i + 1] : C[0];
+    for (int a = 0; a < 2; ++a) {
+      ps[2 * i + a] = s[3 * leaf + a] - s[3 * root + a];
+      pd[2 * i + a] = (t[3 * leaf + a] - t[3 * root + a]) * (1 / 1.0);  // pruned_dst_tims_ *= 1/scale, scale = 1
+    }
+  }
+  const double rot_nb = prm->noise_bound * (2 / 1.0);  // params.noise_bound *= 2/scale (:850-852)
+  GncOut g;
+  std::vector<char> rmask;
+  gnc_rotation2d(ps.data(), pd.data(), M, rot_nb, prm->rotation_gnc_factor, prm->rotation_max_iterations,
+                 prm->rotation_cost_threshold, g, rmask);
+  res->cost = g.cost;
+  res->gnc_iters = g.iters;
+  double R[9] = {g.R[0], g.R[1], 0, g.R[2], g.R[3], 0, 0, 0, 1};
+  if (prm->using_pre_estimated_ryrx) {  // solution_.rotation * estimated_RyRx_ (:419-423)
+    double Rn[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        Rn[3 * r + c] = (R[3 * r] * prm->ryrx[c] + R[3 * r + 1] * prm->ryrx[3 + c]) + R[3 * r + 2] * prm->ryrx[6 + c];
+    memcpy(R, Rn, sizeof(R));
+  }
+  // rotation inliers, cyclic chain rule (:857-874)
+  std::vector<int> rot;
+  for (int i = 0; i < M; ++i) {
+    const int prev = (i == 0) ? M - 1 : i - 1;
+    if (rmask[prev] && rmask[i]) rot.push_back(i);
+  }
+  res->n_rot_inliers = (int)rot.size();
+  for (size_t i = 0; i < rot.size(); ++i) rot_inliers[i] = rot[i];
+  const int NR = (int)rot.size();
+  // points for COTE (:879-899)
+  std::vector<int> sel;
+  const bool use_rot = prm->using_rot_inliers_when_estimating_cote && NR > 0;
+  std::vector<double> cs, cd;
+  if (use_rot) {
+    for (int i = 0; i < NR; ++i) sel.push_back(C[rot[i]]);
+    for (int v : sel)
+      for (int a = 0; a < 3; ++a) {
+        cs.push_back(s[3 * v + a]);
+        cd.push_back(t[3 * v + a]);
+      }
+  } else {
+    sel = C;
+    const double* Y = prm->ryrx;
+    for (int v : sel) {
+      const double x = s[3 * v], y = s[3 * v + 1], z = s[3 * v + 2];
+      if (prm->using_pre_estimated_ryrx) {
+        cs.push_back((Y[0] * x + Y[1] * y) + Y[2] * z);
+        cs.push_back((Y[3] * x + Y[4] * y) + Y[5] * z);
+        cs.push_back((Y[6] * x + Y[7] * y) + Y[8] * z);
+      } else {
+        cs.push_back(x);
+        cs.push_back(y);
+        cs.push_back(z);
+      }
+      for (int a = 0; a < 3; ++a) cd.push_back(t[3 * v + a]);
+    }
+  }
+  const int N = (int)sel.size();
+  // raw_translation = dst - scale * R * src (:597, :906)
+  std::vector<double> raw[3];
+  for (int a = 0; a < 3; ++a) raw[a].resize((size_t)N);
+  for (int i = 0; i < N; ++i) {
+    const double x = cs[3 * i], y = cs[3 * i + 1], z = cs[3 * i + 2];
+    for (int a = 0; a < 3; ++a) raw[a][i] = cd[3 * i + a] - ((R[3 * a] * x + R[3 * a + 1] * y) + R[3 * a + 2] * z);
+  }
+  const double beta = prm->cote_noise_bound * sqrt(prm->cbar2);
+  std::vector<char> inl((size_t)N, 1), tmp;
+  double tr[3];
+  for (int a = 0; a < 3; ++a) {
+    tr[a] = cote_estimate(raw[a], beta, prm->cote_median != 0, tmp, &res->n_card[a]);
+    for (int i = 0; i < N; ++i) inl[i] = inl[i] && tmp[i];
+  }
+  int nf = 0;
+  for (int i = 0; i < N; ++i)
+    if (inl[i]) final_inliers[nf++] = sel[i];
+  res->n_final = nf;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) res->T[4 * r + c] = R[3 * r + c];
+    res->T[4 * r + 3] = tr[r];
+  }
+  res->T[12] = res->T[13] = res->T[14] = 0;
+  res->T[15] = 1;
+  res->valid = 1;
+  res->status = 0;
+  return 0;
+}
+
+// Full path as driven by the reference demo (examples/run_global_registration.cpp:206-246):
+// voxelize x2 -> FPFHManager::setFeaturePair -> Quatro::computeTransformation.
+// counts_out: [n_src_vox, n_tgt_vox, L].  Work buffers are internal.
+int qo_register_pair(const float* src_raw4, int Ps, const float* tgt_raw4, int Pt, float leaf, double r_normal,
+                     double r_fpfh, float tuple_scale, unsigned long long seed, const qo_params* prm, qo_result* res,
+                     int* counts_out, int* clique, int* final_inliers, int cap) {
+  std::vector<float> sv(4 * (size_t)Ps), tv(4 * (size_t)Pt);
+  int ns = voxelize(src_raw4, Ps, leaf, sv.data(), Ps);
+  int nt = voxelize(tgt_raw4, Pt, leaf, tv.data(), Pt);
+  if (ns < 0) {
+    memcpy(sv.data(), src_raw4, sizeof(float) * 4 * (size_t)Ps);
+    ns = Ps;
+  }
+  if (nt < 0) {
+    memcpy(tv.data(), tgt_raw4, sizeof(float) * 4 * (size_t)Pt);
+    nt = Pt;
+  }
+  std::vector<float> nrm_s(4 * (size_t)ns), nrm_t(4 * (size_t)nt), d_s(33 * (size_t)ns), d_t(33 * (size_t)nt);
+  qo_fpfh(sv.data(), ns, r_normal, r_fpfh, nrm_s.data(), nullptr, d_s.data());
+  qo_fpfh(tv.data(), nt, r_normal, r_fpfh, nrm_t.data(), nullptr, d_t.data());
+  const int ccap = std::min(ns, nt);
+  std::vector<int> corr(2 * (size_t)std::max(ccap, 1));
+  const int L = match(sv.data(), ns, d_s.data(), tv.data(), nt, d_t.data(), 1, 1, tuple_scale, seed, corr.data(), ccap,
+                      nullptr, nullptr);
+  counts_out[0] = ns;
+  counts_out[1] = nt;
+  counts_out[2] = L;
+  std::vector<float> ms(4 * (size_t)std::max(L, 1)), mt(4 * (size_t)std::max(L, 1));
+  for (int i = 0; i < L; ++i)
+    for (int a = 0; a < 4; ++a) {
+      ms[4 * i + a] = a < 3 ? sv[4 * corr[2 * i] + a] : 0.f;
+      mt[4 * i + a] = a < 3 ? tv[4 * corr[2 * i + 1] + a] : 0.f;
+    }
+  std::vector<int> cl((size_t)std::max(L, 1)), rot((size_t)std::max(L, 1)), fin((size_t)std::max(L, 1));
+  const int st = qo_solve(ms.data(), mt.data(), L, prm, res, cl.data(), rot.data(), fin.data());
+  for (int i = 0; i < res->n_clique && i < cap; ++i) clique[i] = cl[i];
+  for (int i = 0; i < res->n_final && i < cap; ++i) final_inliers[i] = fin[i];
+  return st;
+}
+
+}  // extern "C"
