@@ -1,0 +1,180 @@
+/* quatro_hip.h — C ABI of libquatro_hip.so, the MI355X (gfx950) back end behind the Quatro API.
+ *
+ * Plain C types only (no STL / Eigen / PCL / torch), never throws across the boundary: every call
+ * returns an int status and the handle keeps a human-readable message (qtr_last_error).
+ *
+ * Each entry point replaces one call site of the reference (url-kaist/Quatro, cited as file:line):
+ *   qtr_voxelize       <- voxelize<T>()                    include/quatro.hpp:49-68 (pcl::VoxelGrid)
+ *   qtr_fpfh           <- teaser::FPFHEstimation::computeFPFHFeatures (4-arg)
+ *                                                          src/teaser_utils/fpfh.cc:44-75
+ *   qtr_match          <- teaser::Matcher::calculateCorrespondences
+ *                                                          include/teaser_utils/feature_matcher.h:42-74,
+ *                                                          src/teaser_utils/feature_matcher.cc:18-265
+ *   qtr_solve          <- Quatro::computeTransformation(Eigen::Matrix4d&)
+ *                                                          include/quatro.hpp:769-936
+ *                         (computeTIMs :307, solveForScale :355, teaser::Graph + MaxCliqueSolver
+ *                          include/teaser/graph.h:29-274 + src/graph.cc:12-104, solveForRotation2D :430,
+ *                          solveForTranslation/estimate :585-747)
+ *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
+ *                         (voxelize x2, FPFHManager::setFeaturePair include/fpfh_manager.hpp:98-153,
+ *                          setInputSource/setInputTarget/computeTransformation)
+ *
+ * Point layout everywhere: float32 x,y,z,pad — 16 bytes per point, i.e. pcl::PointXYZ and the KITTI
+ * .bin record (x,y,z,intensity; reference examples/run_global_registration.cpp:377-402) can be passed
+ * without repacking.  The 4th float is ignored on input and written as 0 on output.
+ *
+ * Memory: `mem` selects where caller buffers live — QTR_MEM_HOST (pageable/pinned host memory; the
+ * library stages through its own device arenas) or QTR_MEM_DEVICE (HBM pointers valid on the handle's
+ * device; nothing is staged, results are written to the device buffers and the small qtr_result
+ * record to host).  The caller owns all buffers; the library owns only its arenas inside the handle.
+ *
+ * Threading: one handle = one device + n_slots independent stream slots.  Calls on different slots
+ * may be issued from different host threads; calls on the same slot must be externally serialised.
+ */
+#ifndef QUATRO_HIP_H
+#define QUATRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTR_OK 0
+#define QTR_ERR_BAD_ARG 1          /* std::invalid_argument in the reference */
+#define QTR_ERR_CLIQUE_TOO_SMALL 2 /* reference: solution_.valid = false, output untouched (quatro.hpp:809-813) */
+#define QTR_ERR_CAPACITY 3         /* a qtr_limits bound or a caller buffer capacity was exceeded */
+#define QTR_ERR_HIP 4              /* HIP runtime error (message in qtr_last_error) */
+#define QTR_ERR_UNSUPPORTED 5      /* mode accepted by the reference's API but not built here */
+
+#define QTR_MEM_HOST 0
+#define QTR_MEM_DEVICE 1
+
+/* INLIER_SELECTION_MODE, reference include/quatro.hpp:184-189 */
+#define QTR_INLIER_PMC_EXACT 0
+#define QTR_INLIER_PMC_HEU 1
+#define QTR_INLIER_KCORE_HEU 2
+#define QTR_INLIER_NONE 3
+
+typedef struct qtr_handle qtr_handle;
+
+typedef struct qtr_limits {
+  int max_points; /* raw points per cloud            (default 262144; reference loader caps at 250000) */
+  int max_voxels; /* down-sampled points per cloud   (default 65536) */
+  int max_corr;   /* correspondences into the solver (default 24576) */
+  int n_slots;    /* independent stream slots        (default 1) */
+} qtr_limits;
+
+/* The fields of Quatro::Params that the path consumes (reference include/quatro.hpp:202-268), plus the
+ * public member noise_bound_ (:269, used by COTE :600-601) and estimated_RyRx_ (:159). */
+typedef struct qtr_params {
+  double noise_bound;               /* 0.3 */
+  double cbar2;                     /* 1.0 */
+  double rotation_gnc_factor;       /* 1.4 */
+  double rotation_cost_threshold;   /* 1e-6 (Params default); demo yaml 1.1e-4 */
+  double kcore_heuristic_threshold; /* 0.5 */
+  double cote_noise_bound;          /* Quatro::noise_bound_ = 0.3 */
+  double ryrx[9];                   /* row-major estimated_RyRx_, identity */
+  int rotation_max_iterations;      /* 100 (Params default); demo yaml 50 */
+  int inlier_selection_mode;        /* QTR_INLIER_PMC_HEU */
+  int cote_median;                  /* 1 = cote_mode "median", 0 = "weighted_mean" */
+  int using_rot_inliers_when_estimating_cote; /* 0 */
+  int using_pre_estimated_ryrx;     /* 0 */
+  int reserved;
+} qtr_params;
+
+/* Front-end knobs of the demo (reference examples/run_global_registration.cpp:37-55, config/params.yaml:22-25)
+ * and of FPFHManager::setFeaturePair's matcher call (include/fpfh_manager.hpp:126-127). */
+typedef struct qtr_frontend_params {
+  float voxel_size;      /* 0.3 */
+  float normal_radius;   /* 0.5 */
+  float fpfh_radius;     /* 0.75 */
+  float tuple_scale;     /* 0.95 */
+  int use_crosscheck;    /* 1 */
+  int use_tuple_test;    /* 1 */
+  unsigned long long seed; /* tuple-test RNG seed (the reference seeds with time(NULL)) */
+} qtr_frontend_params;
+
+typedef struct qtr_result {
+  int status;        /* same value the call returned */
+  int valid;         /* solution_.valid */
+  double T[16];      /* row-major 4x4 [R t; 0 1] */
+  double cost;       /* Quatro::cost_ */
+  int gnc_iters;
+  int n_clique;      /* getNumMaxCliqueInliers() */
+  int n_rot_inliers; /* getNumRotaionInliers() */
+  int n_final;       /* getFinalInliersIndices().size() */
+  int max_core;
+  int n_edges;       /* undirected edges of the consistency graph */
+  int n_card[3];     /* COTE consensus-set cardinality per axis */
+  int n_src, n_tgt;  /* voxelised cloud sizes (qtr_register_pair) */
+  int n_corr;        /* correspondences handed to the solver */
+} qtr_result;
+
+/* Per-stage GPU time of the last call on a slot, milliseconds (hipEvent based). */
+typedef struct qtr_stage_times {
+  float voxelize, fpfh, match, graph, clique, solve, total;
+} qtr_stage_times;
+
+int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);
+void qtr_destroy(qtr_handle* h);
+const char* qtr_last_error(const qtr_handle* h);
+void qtr_default_limits(qtr_limits* l);
+void qtr_default_params(qtr_params* p);                   /* Quatro::Params defaults */
+void qtr_demo_params(qtr_params* p);                      /* config/params.yaml values */
+void qtr_default_frontend_params(qtr_frontend_params* p);
+int qtr_num_slots(const qtr_handle* h);
+void* qtr_slot_stream(qtr_handle* h, int slot); /* hipStream_t of a slot */
+
+/* K1.  out_xyz4 capacity `cap` points; *n_out receives the voxel count (output order = ascending
+ * linear voxel index, as PCL).  If the grid would overflow int32 PCL passes the input through; so
+ * does this call (then *n_out == P). */
+int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, float* out_xyz4, int cap, int* n_out,
+                 int mem);
+
+/* K2-K4.  normals4 (nx,ny,nz,curvature; may be NULL) and desc33 (n x 33 floats) */
+int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, float r_fpfh, float* normals4,
+             float* desc33, int mem);
+
+/* K5-K8.  corr2 = L x (src index, tgt index), sorted lexicographically, capacity `cap` pairs. */
+int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float* desc33_s, const float* xyz4_t,
+              int n_t, const float* desc33_t, const qtr_frontend_params* fp, int* corr2, int cap, int* L_out, int mem);
+
+/* K9-K16.  src4/tgt4: the two equal-length matched keypoint clouds (setInputSource / setInputTarget).
+ * clique / rot_inliers / final_inliers: optional int buffers of capacity `cap` (counts in *res). */
+int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int L, const qtr_params* prm,
+              qtr_result* res, int* clique, int* rot_inliers, int* final_inliers, int cap, int mem);
+
+/* Whole path on one slot: raw scans -> transform. */
+int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                      const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
+                      int* final_inliers, int cap, int mem);
+
+int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
+
+/* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to
+ * `bytes` bytes to host memory `dst`; returns the number of bytes the item holds, or <0 on error. */
+#define QTR_DBG_GRAPH_BITMAP 1   /* uint64[L][ceil(L/64)] adjacency, original labels */
+#define QTR_DBG_CORE 2           /* int32[L] core numbers */
+#define QTR_DBG_PERM 3           /* int32[L] vertex id at each rank of the (core,id) order */
+#define QTR_DBG_NBR_OFFSETS 4    /* int32[n+1] CSR offsets of the sorted radius-neighbour lists (last qtr_fpfh) */
+#define QTR_DBG_NBR_INDEX 5      /* int32[...] neighbour indices */
+#define QTR_DBG_NBR_DIST2 6      /* float[...] squared distances */
+#define QTR_DBG_SPFH 7           /* float[n][33] */
+#define QTR_DBG_NN_LARGE_OF_SMALL 8 /* int32[n_small] */
+#define QTR_DBG_NN_SMALL_OF_LARGE 9 /* int32[n_large] (-1 where not queried) */
+#define QTR_DBG_VOX_SRC 10       /* float4[n_src] voxelised source of the last qtr_register_pair */
+#define QTR_DBG_VOX_TGT 11
+#define QTR_DBG_CORR 12          /* int32[L][2] */
+#define QTR_DBG_MATCH_STATS 13   /* int32[4]: rows needing exact re-check (dir 0, dir 1), n_cross, n_tuple_pass */
+long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
+
+/* Evaluates the shared deterministic math (include/qtr_math.h) ON THE DEVICE, for the test that pins
+ * host/device bit-equality: fn 0 atan2f(a,b), 1 acosf(a), 2 sinf(a) (theta in [0,1.2]), 3 cosf(a). */
+int qtr_debug_math(qtr_handle* h, int fn, const float* a, const float* b, float* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUATRO_HIP_H */

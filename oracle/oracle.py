@@ -102,6 +102,14 @@ def max_threads() -> int:
     return int(lib().qo_get_max_threads())
 
 
+def math_fn(fn: int, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b if b is not None else a, dtype=np.float32)
+    out = np.zeros_like(a)
+    lib().qo_math(int(fn), _p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float), a.size)
+    return out
+
+
 def voxelize(xyz4, leaf: float):
     xyz4 = _f4(xyz4)
     out = np.zeros_like(xyz4)

@@ -957,6 +957,21 @@ struct qo_result {
 };
 
 void qo_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+
+// host evaluation of include/qtr_math.h (pins host/device bit-equality in tests):
+// fn 0 atan2f(a,b), 1 acosf(a), 2 sinf(a), 3 cosf(a)
+void qo_math(int fn, const float* a, const float* b, float* out, int n) {
+  for (int i = 0; i < n; ++i) {
+    float s, c;
+    switch (fn) {
+      case 0: out[i] = qm_atan2f(a[i], b[i]); break;
+      case 1: out[i] = qm_acosf(a[i]); break;
+      case 2: qm_sincosf(a[i], &s, &c); out[i] = s; break;
+      default: qm_sincosf(a[i], &s, &c); out[i] = c; break;
+    }
+  }
+}
+unsigned int qo_rand_u32(unsigned long long seed, unsigned long long counter) { return qm_rand_u32(seed, counter); }
 int qo_get_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -1,0 +1,566 @@
+// capi.hip — implementation of the C ABI declared in include/quatro_hip.h.
+// Host-side orchestration only: arenas, stream slots, staging copies, kernel sequencing.
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "frontend.h"
+#include "solver.h"
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // second cloud's front end runs concurrently
+  hipEvent_t ev[8] = {};
+  void* solver_arena = nullptr;
+  void* front_arena = nullptr;
+  SolverBufs sb;
+  FrontBufs fb;
+  float4* in_src = nullptr;  // staging for host-resident inputs (max_points each)
+  float4* in_tgt = nullptr;
+  float4* m_src = nullptr;  // matched keypoints (max_corr each)
+  float4* m_tgt = nullptr;
+  int* pinned_i32 = nullptr;     // >= 64 ints
+  qtr_result* pinned_res = nullptr;
+  qtr_stage_times times = {};
+  int last_L = 0;  // correspondences of the last solve
+  int last_n = 0;  // points of the last qtr_fpfh
+  int last_ns = 0, last_nt = 0;
+};
+
+struct qtr_handle {
+  int device = 0;
+  qtr_limits lim;
+  std::vector<Slot> slots;
+  char err[512];
+};
+
+extern "C" {
+
+void qtr_default_limits(qtr_limits* l) {
+  l->max_points = 262144;
+  l->max_voxels = 65536;
+  l->max_corr = 24576;
+  l->n_slots = 1;
+}
+
+void qtr_default_params(qtr_params* p) {  // Quatro::Params defaults, reference include/quatro.hpp:202-268
+  memset(p, 0, sizeof(*p));
+  p->noise_bound = 0.3;
+  p->cbar2 = 1.0;
+  p->rotation_gnc_factor = 1.4;
+  p->rotation_cost_threshold = 1e-6;
+  p->kcore_heuristic_threshold = 0.5;
+  p->cote_noise_bound = 0.3;
+  p->ryrx[0] = p->ryrx[4] = p->ryrx[8] = 1.0;
+  p->rotation_max_iterations = 100;
+  p->inlier_selection_mode = QTR_INLIER_PMC_HEU;
+  p->cote_median = 1;
+}
+
+void qtr_demo_params(qtr_params* p) {  // reference config/params.yaml:22-44
+  qtr_default_params(p);
+  p->rotation_cost_threshold = 1.1e-4;
+  p->rotation_max_iterations = 50;
+}
+
+void qtr_default_frontend_params(qtr_frontend_params* p) {
+  p->voxel_size = 0.3f;
+  p->normal_radius = 0.5f;
+  p->fpfh_radius = 0.75f;
+  p->tuple_scale = 0.95f;
+  p->use_crosscheck = 1;
+  p->use_tuple_test = 1;
+  p->seed = 0;
+}
+
+const char* qtr_last_error(const qtr_handle* h) { return h ? h->err : "null handle"; }
+int qtr_num_slots(const qtr_handle* h) { return h ? (int)h->slots.size() : 0; }
+void* qtr_slot_stream(qtr_handle* h, int slot) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size()) return nullptr;
+  return (void*)h->slots[slot].stream;
+}
+
+void qtr_destroy(qtr_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (auto& s : h->slots) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.stream2) (void)hipStreamSynchronize(s.stream2);
+    for (auto& e : s.ev)
+      if (e) (void)hipEventDestroy(e);
+    if (s.solver_arena) (void)hipFree(s.solver_arena);
+    if (s.front_arena) (void)hipFree(s.front_arena);
+    if (s.in_src) (void)hipFree(s.in_src);
+    if (s.in_tgt) (void)hipFree(s.in_tgt);
+    if (s.m_src) (void)hipFree(s.m_src);
+    if (s.m_tgt) (void)hipFree(s.m_tgt);
+    if (s.pinned_i32) (void)hipHostFree(s.pinned_i32);
+    if (s.pinned_res) (void)hipHostFree(s.pinned_res);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.stream2) (void)hipStreamDestroy(s.stream2);
+  }
+  delete h;
+}
+
+static int create_impl(qtr_handle* h) {
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  QTR_HIP_TRY(h, solver_init_attributes());
+  QTR_HIP_TRY(h, frontend_init_attributes());
+  for (auto& s : h->slots) {
+    QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    for (auto& e : s.ev) QTR_HIP_TRY(h, hipEventCreate(&e));
+    const size_t sbytes = solver_scratch_bytes(h->lim.max_corr) + 65536;
+    QTR_HIP_TRY(h, hipMalloc(&s.solver_arena, sbytes));
+    solver_carve(s.sb, s.solver_arena, h->lim.max_corr);
+    const size_t fbytes = frontend_scratch_bytes(h->lim.max_points, h->lim.max_voxels) + 65536;
+    QTR_HIP_TRY(h, hipMalloc(&s.front_arena, fbytes));
+    frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
+    QTR_HIP_TRY(h, hipMalloc((void**)&s.in_src, (size_t)h->lim.max_points * 16));
+    QTR_HIP_TRY(h, hipMalloc((void**)&s.in_tgt, (size_t)h->lim.max_points * 16));
+    QTR_HIP_TRY(h, hipMalloc((void**)&s.m_src, (size_t)h->lim.max_corr * 16));
+    QTR_HIP_TRY(h, hipMalloc((void**)&s.m_tgt, (size_t)h->lim.max_corr * 16));
+    QTR_HIP_TRY(h, hipHostMalloc((void**)&s.pinned_i32, 256 * sizeof(int)));
+    QTR_HIP_TRY(h, hipHostMalloc((void**)&s.pinned_res, sizeof(qtr_result)));
+  }
+  return QTR_OK;
+}
+
+int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
+  if (!out) return QTR_ERR_BAD_ARG;
+  *out = nullptr;
+  qtr_handle* h = new (std::nothrow) qtr_handle();
+  if (!h) return QTR_ERR_CAPACITY;
+  h->err[0] = 0;
+  h->device = device;
+  if (limits)
+    h->lim = *limits;
+  else
+    qtr_default_limits(&h->lim);
+  if (h->lim.max_points < 64 || h->lim.max_voxels < 64 || h->lim.max_corr < 64 || h->lim.n_slots < 1 ||
+      h->lim.max_corr > 32768 || h->lim.max_voxels > h->lim.max_points) {
+    delete h;
+    return QTR_ERR_BAD_ARG;
+  }
+  h->slots.resize((size_t)h->lim.n_slots);
+  const int rc = create_impl(h);
+  *out = h;  // returned even on failure so that qtr_last_error can be read; caller destroys it
+  return rc;
+}
+
+static Slot* get_slot(qtr_handle* h, int slot) {
+  if (!h) return nullptr;
+  if (slot < 0 || slot >= (int)h->slots.size()) {
+    snprintf(h->err, sizeof(h->err), "slot %d out of range", slot);
+    return nullptr;
+  }
+  return &h->slots[slot];
+}
+
+static int check_params(qtr_handle* h, const qtr_params* prm) {
+  if (!prm) {
+    snprintf(h->err, sizeof(h->err), "params is NULL");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (prm->inlier_selection_mode == QTR_INLIER_NONE || prm->inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
+    snprintf(h->err, sizeof(h->err),
+             "inlier_selection_mode %d not supported (NONE is undefined behaviour in the reference, PMC_EXACT "
+             "is a 'next' row)",
+             prm->inlier_selection_mode);
+    return QTR_ERR_UNSUPPORTED;
+  }
+  if (prm->inlier_selection_mode < 0 || prm->inlier_selection_mode > 3 || !(prm->noise_bound > 0) ||
+      !(prm->rotation_gnc_factor > 1) || prm->rotation_max_iterations < 1) {
+    snprintf(h->err, sizeof(h->err), "invalid solver parameter");
+    return QTR_ERR_BAD_ARG;
+  }
+  return QTR_OK;
+}
+
+// Runs the back end on device-resident matched clouds and brings the result record to the host.
+static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float4* d_tgt, int L, const qtr_params* prm,
+                        qtr_result* res) {
+  s.last_L = L;
+  QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, s.ev[2], s.ev[3]));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  const int keep_ns = res->n_src, keep_nt = res->n_tgt, keep_nc = res->n_corr;
+  *res = *s.pinned_res;
+  res->n_src = keep_ns;
+  res->n_tgt = keep_nt;
+  res->n_corr = keep_nc;
+  return res->status;
+}
+
+static int copy_out_lists(qtr_handle* h, Slot& s, const qtr_result* res, int* clique, int* rot_inliers,
+                          int* final_inliers, int cap, int mem) {
+  const hipMemcpyKind kind = (mem == QTR_MEM_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (clique && res->n_clique > 0) {
+    if (res->n_clique > cap) return QTR_ERR_CAPACITY;
+    QTR_HIP_TRY(h, hipMemcpyAsync(clique, s.sb.clique, sizeof(int) * (size_t)res->n_clique, kind, s.stream));
+  }
+  if (rot_inliers && res->n_rot_inliers > 0) {
+    if (res->n_rot_inliers > cap) return QTR_ERR_CAPACITY;
+    QTR_HIP_TRY(h, hipMemcpyAsync(rot_inliers, s.sb.rot_inl, sizeof(int) * (size_t)res->n_rot_inliers, kind, s.stream));
+  }
+  if (final_inliers && res->n_final > 0) {
+    if (res->n_final > cap) return QTR_ERR_CAPACITY;
+    QTR_HIP_TRY(h, hipMemcpyAsync(final_inliers, s.sb.final_inl, sizeof(int) * (size_t)res->n_final, kind, s.stream));
+  }
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  return QTR_OK;
+}
+
+int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int L, const qtr_params* prm,
+              qtr_result* res, int* clique, int* rot_inliers, int* final_inliers, int cap, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !res) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  memset(res, 0, sizeof(*res));
+  int rc = check_params(h, prm);
+  if (rc != QTR_OK) return res->status = rc;
+  if (L < 0 || (L > 0 && (!src4 || !tgt4))) {
+    snprintf(h->err, sizeof(h->err), "bad input clouds");
+    return res->status = QTR_ERR_BAD_ARG;
+  }
+  if (L > h->lim.max_corr) {
+    snprintf(h->err, sizeof(h->err), "L=%d exceeds max_corr=%d", L, h->lim.max_corr);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const float4 *d_src = (const float4*)src4, *d_tgt = (const float4*)tgt4;
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  if (mem == QTR_MEM_HOST && L > 0) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, src4, (size_t)L * 16, hipMemcpyHostToDevice, s.stream));
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, tgt4, (size_t)L * 16, hipMemcpyHostToDevice, s.stream));
+    d_src = s.m_src;
+    d_tgt = s.m_tgt;
+  }
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  res->n_corr = L;
+  rc = solve_device(h, s, d_src, d_tgt, L, prm, res);
+  if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) s.times.graph = ms;
+  if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
+  if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
+  const int rc2 = copy_out_lists(h, s, res, clique, rot_inliers, final_inliers, cap, mem);
+  if (rc2 != QTR_OK) return res->status = rc2;
+  return rc;
+}
+
+int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !out) return QTR_ERR_BAD_ARG;
+  *out = sp->times;
+  return QTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// front end
+int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, float* out_xyz4, int cap, int* n_out,
+                 int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !n_out || P < 0 || (P > 0 && (!xyz4 || !out_xyz4)) || !(leaf > 0)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_out = 0;
+  if (P == 0) return QTR_OK;
+  if (P > h->lim.max_points) {
+    snprintf(h->err, sizeof(h->err), "P=%d exceeds max_points=%d", P, h->lim.max_points);
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const float4* d_in = (const float4*)xyz4;
+  if (mem == QTR_MEM_HOST) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, xyz4, (size_t)P * 16, hipMemcpyHostToDevice, s.stream));
+    d_in = s.in_src;
+  }
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  CloudBufs& cb = s.fb.cloud[0];
+  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, cb, d_in, P, leaf, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  int n = s.pinned_i32[CNT_NVOX];
+  const bool passthrough = s.pinned_i32[CNT_VOX_OVERFLOW] != 0;
+  const float4* d_out = cb.vox;
+  if (passthrough) {  // PCL: "Leaf size is too small" -> output = input
+    n = P;
+    d_out = d_in;
+  }
+  if (n > h->lim.max_voxels && !passthrough) {
+    snprintf(h->err, sizeof(h->err), "voxel count %d exceeds max_voxels=%d", n, h->lim.max_voxels);
+    return QTR_ERR_CAPACITY;
+  }
+  if (n > cap) {
+    snprintf(h->err, sizeof(h->err), "voxel count %d exceeds output capacity %d", n, cap);
+    *n_out = n;
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipMemcpyAsync(out_xyz4, d_out, (size_t)n * 16,
+                                mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  *n_out = n;
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = s.times.total = ms;
+  return QTR_OK;
+}
+
+int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, float r_fpfh, float* normals4,
+             float* desc33, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || n < 0 || (n > 0 && (!xyz4 || !desc33))) return QTR_ERR_BAD_ARG;
+  if (r_normal > r_fpfh || !(r_normal > 0)) {  // reference include/fpfh_manager.hpp:99-102
+    snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
+    return QTR_ERR_BAD_ARG;
+  }
+  Slot& s = *sp;
+  s.last_n = n;
+  if (n == 0) return QTR_OK;
+  if (n > h->lim.max_voxels) {
+    snprintf(h->err, sizeof(h->err), "n=%d exceeds max_voxels=%d", n, h->lim.max_voxels);
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  CloudBufs& cb = s.fb.cloud[0];
+  const hipMemcpyKind kin = mem == QTR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const hipMemcpyKind kout = mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  QTR_HIP_TRY(h, hipMemcpyAsync(cb.vox, xyz4, (size_t)n * 16, kin, s.stream));
+  QTR_HIP_TRY(h, hipMemsetAsync(cb.counts, 0, 16 * sizeof(int), s.stream));
+  QTR_HIP_TRY(h, set_count_enqueue(cb, CNT_NVOX, n, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, cb, n, r_normal, r_fpfh, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if (s.pinned_i32[CNT_NBR_OVERFLOW]) {
+    snprintf(h->err, sizeof(h->err), "neighbour list capacity exceeded (total %d)", s.pinned_i32[CNT_NBR_TOTAL]);
+    return QTR_ERR_CAPACITY;
+  }
+  if (normals4) QTR_HIP_TRY(h, hipMemcpyAsync(normals4, cb.normals, (size_t)n * 16, kout, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(desc33, cb.fpfh, (size_t)n * 33 * 4, kout, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.fpfh = s.times.total = ms;
+  return QTR_OK;
+}
+
+// Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
+static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out) {
+  QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, s.fb.mcounts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  *L_out = s.pinned_i32[MC_NCORR];
+  return QTR_OK;
+}
+
+int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float* desc33_s, const float* xyz4_t,
+              int n_t, const float* desc33_t, const qtr_frontend_params* fp, int* corr2, int cap, int* L_out, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !fp || !L_out || n_s < 0 || n_t < 0) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *L_out = 0;
+  s.last_ns = n_s;
+  s.last_nt = n_t;
+  if (n_s == 0 || n_t == 0) return QTR_OK;
+  if (!xyz4_s || !xyz4_t || !desc33_s || !desc33_t || !corr2) return QTR_ERR_BAD_ARG;
+  if (n_s > h->lim.max_voxels || n_t > h->lim.max_voxels) {
+    snprintf(h->err, sizeof(h->err), "cloud size exceeds max_voxels=%d", h->lim.max_voxels);
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const hipMemcpyKind kin = mem == QTR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const hipMemcpyKind kout = mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[0].vox, xyz4_s, (size_t)n_s * 16, kin, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[1].vox, xyz4_t, (size_t)n_t * 16, kin, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[0].fpfh, desc33_s, (size_t)n_s * 132, kin, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[1].fpfh, desc33_t, (size_t)n_t * 132, kin, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  int L = 0;
+  int rc = match_device(h, s, n_s, n_t, fp, &L);
+  if (rc != QTR_OK) return rc;
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  *L_out = L;
+  if (L > cap) {
+    snprintf(h->err, sizeof(h->err), "L=%d exceeds output capacity %d", L, cap);
+    return QTR_ERR_CAPACITY;
+  }
+  if (L > 0) QTR_HIP_TRY(h, hipMemcpyAsync(corr2, s.fb.corr, (size_t)L * 8, kout, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.match = s.times.total = ms;
+  return QTR_OK;
+}
+
+int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                      const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
+                      int* final_inliers, int cap, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !res || !fp) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  memset(res, 0, sizeof(*res));
+  int rc = check_params(h, prm);
+  if (rc != QTR_OK) return res->status = rc;
+  if (fp->normal_radius > fp->fpfh_radius) {
+    snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
+    return res->status = QTR_ERR_BAD_ARG;
+  }
+  if (Ps <= 0 || Pt <= 0 || !src_raw4 || !tgt_raw4) {
+    snprintf(h->err, sizeof(h->err), "Invalid or empty point cloud dataset given!");
+    return res->status = QTR_ERR_BAD_ARG;
+  }
+  if (Ps > h->lim.max_points || Pt > h->lim.max_points) {
+    snprintf(h->err, sizeof(h->err), "cloud exceeds max_points=%d", h->lim.max_points);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const float4 *d_s = (const float4*)src_raw4, *d_t = (const float4*)tgt_raw4;
+  if (mem == QTR_MEM_HOST) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, src_raw4, (size_t)Ps * 16, hipMemcpyHostToDevice, s.stream));
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.in_tgt, tgt_raw4, (size_t)Pt * 16, hipMemcpyHostToDevice, s.stream));
+    d_s = s.in_src;
+    d_t = s.in_tgt;
+  }
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  // the target cloud's front end runs on the slot's second stream, concurrently with the source's
+  QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev[0], 0));
+  CloudBufs& cs = s.fb.cloud[0];
+  CloudBufs& ct = s.fb.cloud[1];
+  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, cs, d_s, Ps, fp->voxel_size, s.stream));
+  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, ct, d_t, Pt, fp->voxel_size, s.stream2));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cs.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 16, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream2));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream2));
+  int ns = s.pinned_i32[CNT_NVOX], nt = s.pinned_i32[16 + CNT_NVOX];
+  if (s.pinned_i32[CNT_VOX_OVERFLOW] || s.pinned_i32[16 + CNT_VOX_OVERFLOW]) {
+    snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  if (ns > h->lim.max_voxels || nt > h->lim.max_voxels) {
+    snprintf(h->err, sizeof(h->err), "voxel count (%d,%d) exceeds max_voxels=%d", ns, nt, h->lim.max_voxels);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  res->n_src = ns;
+  res->n_tgt = nt;
+  s.last_ns = ns;
+  s.last_nt = nt;
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, cs, ns, fp->normal_radius, fp->fpfh_radius, s.stream));
+  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, ct, nt, fp->normal_radius, fp->fpfh_radius, s.stream2));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
+  QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
+  int L = 0;
+  rc = match_device(h, s, ns, nt, fp, &L);
+  if (rc != QTR_OK) return res->status = rc;
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 32, cs.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 48, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if (s.pinned_i32[32 + CNT_NBR_OVERFLOW] || s.pinned_i32[48 + CNT_NBR_OVERFLOW]) {
+    snprintf(h->err, sizeof(h->err), "neighbour list capacity (%d per point) exceeded: max k = %d / %d", QTR_KMAX,
+             s.pinned_i32[32 + CNT_KMAX], s.pinned_i32[48 + CNT_KMAX]);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  res->n_corr = L;
+  if (L > h->lim.max_corr) {
+    snprintf(h->err, sizeof(h->err), "L=%d exceeds max_corr=%d", L, h->lim.max_corr);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
+  rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res);
+  if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = ms;
+  if (hipEventElapsedTime(&ms, s.ev[1], s.ev[6]) == hipSuccess) s.times.fpfh = ms;
+  if (hipEventElapsedTime(&ms, s.ev[6], s.ev[7]) == hipSuccess) s.times.match = ms;
+  if (hipEventElapsedTime(&ms, s.ev[7], s.ev[2]) == hipSuccess) s.times.graph = ms;
+  if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
+  if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
+  const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
+  if (rc2 != QTR_OK) return res->status = rc2;
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp) return -1;
+  Slot& s = *sp;
+  if (hipSetDevice(h->device) != hipSuccess) return -1;
+  const void* src = nullptr;
+  size_t have = 0;
+  const int L = s.last_L, W = (L + 63) / 64;
+  CloudBufs& c0 = s.fb.cloud[0];
+  switch (what) {
+    case QTR_DBG_GRAPH_BITMAP: src = s.sb.bm; have = (size_t)L * W * 8; break;
+    case QTR_DBG_CORE: src = s.sb.core; have = (size_t)L * 4; break;
+    case QTR_DBG_PERM: src = s.sb.perm; have = (size_t)L * 4; break;
+    case QTR_DBG_NBR_OFFSETS: src = c0.nbr_off; have = (size_t)(s.last_n + 1) * 4; break;
+    case QTR_DBG_NBR_INDEX:
+    case QTR_DBG_NBR_DIST2: {
+      int tot = 0;
+      if (hipMemcpy(&tot, c0.nbr_off + s.last_n, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      src = (what == QTR_DBG_NBR_INDEX) ? (const void*)c0.nbr_idx : (const void*)c0.nbr_d2;
+      have = (size_t)tot * 4;
+      break;
+    }
+    case QTR_DBG_SPFH: src = c0.spfh; have = (size_t)s.last_n * 132; break;
+    case QTR_DBG_NN_LARGE_OF_SMALL: src = s.fb.nn_of_small; have = (size_t)(s.last_ns < s.last_nt ? s.last_ns : s.last_nt) * 4; break;
+    case QTR_DBG_NN_SMALL_OF_LARGE: src = s.fb.nn_of_large; have = (size_t)(s.last_ns < s.last_nt ? s.last_nt : s.last_ns) * 4; break;
+    case QTR_DBG_VOX_SRC: src = s.fb.cloud[0].vox; have = (size_t)s.last_ns * 16; break;
+    case QTR_DBG_VOX_TGT: src = s.fb.cloud[1].vox; have = (size_t)s.last_nt * 16; break;
+    case QTR_DBG_CORR: src = s.fb.corr; have = (size_t)s.last_L * 8; break;
+    case QTR_DBG_MATCH_STATS: src = s.fb.mcounts; have = 16 * 4; break;
+    default: return -1;
+  }
+  const size_t n = have < bytes ? have : bytes;
+  if (dst && n > 0) {
+    if (hipStreamSynchronize(s.stream) != hipSuccess) return -1;
+    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  }
+  return (long long)have;
+}
+
+__global__ void k_debug_math(int fn, const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = 0.f, s, c;
+  switch (fn) {
+    case 0: r = qm_atan2f(a[i], b[i]); break;
+    case 1: r = qm_acosf(a[i]); break;
+    case 2: qm_sincosf(a[i], &s, &c); r = s; break;
+    case 3: qm_sincosf(a[i], &s, &c); r = c; break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+int qtr_debug_math(qtr_handle* h, int fn, const float* a, const float* b, float* out, int n) {
+  if (!h || !a || !out || n <= 0) return QTR_ERR_BAD_ARG;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  QTR_HIP_TRY(h, hipMalloc((void**)&da, (size_t)n * 4));
+  QTR_HIP_TRY(h, hipMalloc((void**)&db, (size_t)n * 4));
+  QTR_HIP_TRY(h, hipMalloc((void**)&dout, (size_t)n * 4));
+  QTR_HIP_TRY(h, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+  QTR_HIP_TRY(h, hipMemcpy(db, b ? b : a, (size_t)n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, fn, da, db, dout, n);
+  QTR_HIP_TRY(h, hipGetLastError());
+  QTR_HIP_TRY(h, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  return QTR_OK;
+}
+
+}  // extern "C"

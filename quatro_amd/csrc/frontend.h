@@ -1,0 +1,59 @@
+// frontend.h — buffers and launchers of the front-end kernels (frontend.hip, match.hip).
+#pragma once
+#include "common.h"
+
+#define QTR_KMAX 256        // capacity of one point's radius-neighbour list (entries)
+#define RADIX_TILE 1024     // elements per radix-sort workgroup (one wavefront)
+
+// per-cloud device counters (CloudBufs::counts, 16 ints)
+enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
+// matcher device counters (FrontBufs::mcounts, 16 ints)
+enum { MC_NCORR = 0, MC_RECHECK0 = 1, MC_RECHECK1 = 2, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5 };
+
+struct CloudBufs {
+  int* counts = nullptr;       // 16
+  u32* mm = nullptr;           // 8: order-preserving encodings of min x,y,z / max x,y,z
+  float4* vox = nullptr;       // [max_voxels] down-sampled cloud (or the qtr_fpfh input)
+  float4* normals = nullptr;   // [max_voxels] nx,ny,nz,curvature
+  float* spfh = nullptr;       // [max_voxels][33]
+  float* fpfh = nullptr;       // [max_voxels][33]
+  u64* keys_a = nullptr;       // [max_points] sort ping
+  u64* keys_b = nullptr;       // [max_points] sort pong
+  u32* hist = nullptr;         // radix histograms / block counters
+  int* nbr_cnt = nullptr;      // [max_voxels]
+  int* nbr_off = nullptr;      // [max_voxels+1] CSR view (exclusive scan of nbr_cnt) for inspection
+  int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
+  float* nbr_d2 = nullptr;     // [max_voxels][QTR_KMAX]
+  float* mean = nullptr;       // 4 floats: sequential float mean of the cloud (Matcher::normalizePoints)
+};
+
+struct FrontBufs {
+  int max_points = 0, max_voxels = 0;
+  CloudBufs cloud[2];
+  u64* best_small = nullptr;   // [max_voxels] packed (dist bits << 32 | index) running minima
+  u64* best_large = nullptr;
+  int* nn_of_small = nullptr;  // [n_small] index into the larger cloud
+  int* nn_of_large = nullptr;  // [n_large] index into the smaller cloud
+  int* cross_i = nullptr;      // cross-checked pairs in ascending i (index into larger cloud)
+  int* cross_j = nullptr;
+  int* flags = nullptr;        // [max_voxels] scratch flags
+  int* scan = nullptr;         // [max_voxels+1] scratch scan
+  int* passed = nullptr;       // [max_voxels] tuple-test pass flags
+  int* tgt_of_src = nullptr;   // [max_voxels]
+  int* corr = nullptr;         // [max_voxels][2]
+  int* mcounts = nullptr;      // 16
+};
+
+size_t frontend_scratch_bytes(int max_points, int max_voxels);
+void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels);
+hipError_t frontend_init_attributes();
+
+hipError_t voxelize_enqueue(FrontBufs& F, CloudBufs& C, const float4* in, int P, float leaf, hipStream_t st);
+hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st);
+hipError_t fpfh_enqueue(FrontBufs& F, CloudBufs& C, int n, float r_normal, float r_fpfh, hipStream_t st);
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
+hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
+
+// shared small kernels (defined in frontend.hip)
+hipError_t radix_sort_u64_hi(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st, u64** sorted_out);
+hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st);  // out has n+1 entries

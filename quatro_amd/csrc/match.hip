@@ -1,0 +1,264 @@
+// match.hip — 33-D reciprocal nearest-neighbour matching, cross-check, tuple test, compaction.
+//
+// Replaces teaser::Matcher::calculateCorrespondences (reference include/teaser_utils/feature_matcher.h:
+// 42-74) / advancedMatching (src/teaser_utils/feature_matcher.cc:77-265) and its two FLANN kd-trees.
+// The exact distance is flann::L2<float>'s: groups of four, result += ((d0^2+d1^2)+d2^2)+d3^2, then the
+// tail term; ties go to the lowest index.
+//
+// Two nearest-neighbour engines produce bit-identical tables:
+//  * k_nn_exact : VALU evaluation of the exact distance for every pair (LDS-tiled, broadcast reads);
+//  * k_nn_mfma  : the dense form |a|^2+|b|^2-2ab through v_mfma_f32_32x32x2_f32 with per-row best /
+//                 second-best tracking; rows whose two best candidates are closer than a rigorous
+//                 rounding bound are re-decided by k_nn_exact_rows.  (Selected by match_enqueue.)
+#include "common.h"
+#include "frontend.h"
+
+#define NN_TILE 64
+#define NN_STRIDE 36  // floats per staged descriptor row (33 + 3 zero pad; 16-byte aligned rows)
+
+__device__ __forceinline__ float l2_flann33(const float* a, const float* b /* LDS row, stride-36 */) {
+  float result = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const float4 bv = *(const float4*)(b + 4 * g);
+    const float d0 = a[4 * g] - bv.x, d1 = a[4 * g + 1] - bv.y, d2 = a[4 * g + 2] - bv.z, d3 = a[4 * g + 3] - bv.w;
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  const float d = a[32] - b[32];
+  result += d * d;
+  return result;
+}
+
+__global__ void k_fill_u64(u64* p, int n, u64 v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill_i32(int* p, int n, int v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+// grid (ceil(nA/256), nsplit): thread = one query of A, blockIdx.y = slice of B
+__global__ __launch_bounds__(256) void k_nn_exact(const float* __restrict__ A, int nA, const float* __restrict__ B,
+                                                  int nB, u64* __restrict__ best, const int* __restrict__ rows,
+                                                  int nrows) {
+  __shared__ __attribute__((aligned(16))) float tile[NN_TILE * NN_STRIDE];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  // optional indirection: only the listed rows of A are (re)computed
+  const int nq = rows ? nrows : nA;
+  const int a_idx = (q < nq) ? (rows ? rows[q] : q) : -1;
+  float a[33];
+#pragma unroll
+  for (int t = 0; t < 33; ++t) a[t] = (a_idx >= 0) ? A[(size_t)a_idx * 33 + t] : 0.f;
+  const int per = (nB + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nB, b0 + per);
+  float bd = INFINITY;
+  int bi = -1;
+  for (int base = b0; base < b1; base += NN_TILE) {
+    const int m = min(NN_TILE, b1 - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < NN_TILE * NN_STRIDE; e += 256) {
+      const int r = e / NN_STRIDE, c = e - r * NN_STRIDE;
+      tile[e] = (r < m && c < 33) ? B[(size_t)(base + r) * 33 + c] : 0.f;
+    }
+    __syncthreads();
+    if (a_idx >= 0) {
+      for (int r = 0; r < m; ++r) {
+        const float d = l2_flann33(a, tile + r * NN_STRIDE);
+        if (d < bd) {
+          bd = d;
+          bi = base + r;
+        }
+      }
+    }
+  }
+  if (a_idx >= 0 && bi >= 0) atomicMin(&best[a_idx], ((u64)__float_as_uint(bd) << 32) | (u32)bi);
+}
+
+__global__ void k_nn_unpack(const u64* __restrict__ best, int n, int* __restrict__ nn) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u64 b = best[i];
+    nn[i] = (b == ~0ULL) ? 0 : (int)(u32)b;
+  }
+}
+
+// cross-check flags over the larger cloud (index i): keep iff NN_small(i) = j and NN_large(j) = i
+__global__ void k_cross_flags(const int* __restrict__ nn_of_large, const int* __restrict__ nn_of_small, int n_large,
+                              int* __restrict__ flags) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_large; i += gridDim.x * blockDim.x) {
+    const int j = nn_of_large[i];
+    flags[i] = (nn_of_small[j] == i) ? 1 : 0;
+  }
+}
+
+__global__ void k_cross_compact(const int* __restrict__ flags, const int* __restrict__ scan,
+                                const int* __restrict__ nn_of_large, int n_large, int* __restrict__ cross_i,
+                                int* __restrict__ cross_j, int* __restrict__ mcounts) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_large; i += gridDim.x * blockDim.x) {
+    if (flags[i]) {
+      cross_i[scan[i]] = i;
+      cross_j[scan[i]] = nn_of_large[i];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) mcounts[MC_NCROSS] = scan[n_large];
+}
+
+// tuple test (reference feature_matcher.cc:187-247); trial t draws qm_rand_u32(seed, 3t+k) % ncorr
+__global__ __launch_bounds__(256) void k_tuple(const float4* __restrict__ pts_i, const float* __restrict__ mean_i,
+                                               const float4* __restrict__ pts_j, const float* __restrict__ mean_j,
+                                               const int* __restrict__ cross_i, const int* __restrict__ cross_j,
+                                               const int* __restrict__ mcounts, float scale, u64 seed,
+                                               int* __restrict__ passed) {
+  const int ncorr = mcounts[MC_NCROSS];
+  if (ncorr <= 0) return;
+  const long long trials = (long long)ncorr * 100;
+  const float mix = mean_i[0], miy = mean_i[1], miz = mean_i[2];
+  const float mjx = mean_j[0], mjy = mean_j[1], mjz = mean_j[2];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < trials;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int r0 = (int)(qm_rand_u32(seed, 3ULL * (u64)t) % (u32)ncorr);
+    const int r1 = (int)(qm_rand_u32(seed, 3ULL * (u64)t + 1ULL) % (u32)ncorr);
+    const int r2 = (int)(qm_rand_u32(seed, 3ULL * (u64)t + 2ULL) % (u32)ncorr);
+    float pi[3][3], pj[3][3];
+    const int rr[3] = {r0, r1, r2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 a = pts_i[cross_i[rr[k]]], b = pts_j[cross_j[rr[k]]];
+      pi[k][0] = a.x - mix;
+      pi[k][1] = a.y - miy;
+      pi[k][2] = a.z - miz;
+      pj[k][0] = b.x - mjx;
+      pj[k][1] = b.y - mjy;
+      pj[k][2] = b.z - mjz;
+    }
+    float li[3], lj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int k2 = (k + 1) % 3;
+      // edges: (0,1), (1,2), (2,0)
+      float dx = pi[k][0] - pi[k2][0], dy = pi[k][1] - pi[k2][1], dz = pi[k][2] - pi[k2][2];
+      li[k] = sqrtf(dx * dx + (dy * dy + dz * dz));
+      dx = pj[k][0] - pj[k2][0];
+      dy = pj[k][1] - pj[k2][1];
+      dz = pj[k][2] - pj[k2][2];
+      lj[k] = sqrtf(dx * dx + (dy * dy + dz * dz));
+    }
+    if ((li[0] * scale < lj[0]) && (lj[0] < li[0] / scale) && (li[1] * scale < lj[1]) && (lj[1] < li[1] / scale) &&
+        (li[2] * scale < lj[2]) && (lj[2] < li[2] / scale)) {
+      passed[r0] = 1;
+      passed[r1] = 1;
+      passed[r2] = 1;
+    }
+  }
+}
+
+// passed cross pairs -> tgt_of_src (each source index occurs at most once after the cross-check)
+__global__ void k_scatter_pairs(const int* __restrict__ cross_i, const int* __restrict__ cross_j,
+                                const int* __restrict__ passed, const int* mcounts, int swapped,
+                                int* __restrict__ tgt_of_src, int* mc_out) {
+  const int nc = mcounts[MC_NCROSS];
+  int local = 0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    if (passed[c]) {
+      const int i = cross_i[c], j = cross_j[c];
+      const int s = swapped ? j : i, t = swapped ? i : j;
+      tgt_of_src[s] = t;
+      ++local;
+    }
+  }
+  local = wave_sum_i32(local);
+  if (qk_lane() == 0 && local) atomicAdd(&mc_out[MC_NTUPLE], local);
+}
+
+__global__ void k_src_flags(const int* __restrict__ tgt_of_src, int ns, int* __restrict__ flags) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x)
+    flags[s] = tgt_of_src[s] >= 0 ? 1 : 0;
+}
+
+__global__ void k_corr_compact(const int* __restrict__ flags, const int* __restrict__ scan,
+                               const int* __restrict__ tgt_of_src, int ns, int* __restrict__ corr,
+                               int* __restrict__ mcounts) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    if (flags[s]) {
+      corr[2 * scan[s]] = s;
+      corr[2 * scan[s] + 1] = tgt_of_src[s];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) mcounts[MC_NCORR] = scan[ns];
+}
+
+__global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __restrict__ vt,
+                                 const int* __restrict__ corr, int L, float4* __restrict__ ms, float4* __restrict__ mt) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < L; c += gridDim.x * blockDim.x) {
+    float4 a = vs[corr[2 * c]], b = vt[corr[2 * c + 1]];
+    a.w = 0.f;
+    b.w = 0.f;
+    ms[c] = a;
+    mt[c] = b;
+  }
+}
+
+static inline int grid_for(int n) {
+  int g = (n + 255) / 256;
+  return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
+  // fi = larger cloud, fj = smaller (reference feature_matcher.cc:84-92)
+  const int swapped = nt > ns ? 1 : 0;
+  CloudBufs& Ci = F.cloud[swapped ? 1 : 0];
+  CloudBufs& Cj = F.cloud[swapped ? 0 : 1];
+  const int n_large = swapped ? nt : ns, n_small = swapped ? ns : nt;
+  hipError_t e;
+  if ((e = hipMemsetAsync(F.mcounts, 0, 16 * sizeof(int), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, F.mcounts + MC_SWAPPED, 1, swapped);
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, ~0ULL);
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, ~0ULL);
+  // K5: NN of every small-cloud descriptor in the large cloud, and of every large-cloud descriptor in
+  // the small cloud (the reference queries the latter lazily for hit rows only; the mutual test below
+  // only ever reads hit rows, so the result is the same)
+  auto nsplit = [](int nq, int nb) {
+    int blocks_x = (nq + 255) / 256;
+    int s = (1024 + blocks_x - 1) / blocks_x;
+    int maxs = (nb + NN_TILE - 1) / NN_TILE;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return s;
+  };
+  hipLaunchKernelGGL(k_nn_exact, dim3((n_small + 255) / 256, nsplit(n_small, n_large)), dim3(256), 0, st, Cj.fpfh,
+                     n_small, Ci.fpfh, n_large, F.best_small, (const int*)nullptr, 0);
+  hipLaunchKernelGGL(k_nn_exact, dim3((n_large + 255) / 256, nsplit(n_large, n_small)), dim3(256), 0, st, Ci.fpfh,
+                     n_large, Cj.fpfh, n_small, F.best_large, (const int*)nullptr, 0);
+  hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, F.nn_of_small);
+  hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, F.nn_of_large);
+  // K6 cross-check -> pairs in ascending i
+  hipLaunchKernelGGL(k_cross_flags, dim3(grid_for(n_large)), dim3(256), 0, st, F.nn_of_large, F.nn_of_small, n_large,
+                     F.flags);
+  if ((e = exclusive_scan_i32(F.flags, F.scan, n_large, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cross_compact, dim3(grid_for(n_large)), dim3(256), 0, st, F.flags, F.scan, F.nn_of_large,
+                     n_large, F.cross_i, F.cross_j, F.mcounts);
+  // K7 tuple test
+  const int maxc = n_small;  // cross-checked pairs <= n_small
+  if (fp.use_tuple_test && fp.tuple_scale != 0) {
+    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(maxc)), dim3(256), 0, st, F.passed, maxc, 0);
+    hipLaunchKernelGGL(k_tuple, dim3(2048), dim3(256), 0, st, Ci.vox, Ci.mean, Cj.vox, Cj.mean, F.cross_i, F.cross_j,
+                       F.mcounts, fp.tuple_scale, (u64)fp.seed, F.passed);
+  } else {
+    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(maxc)), dim3(256), 0, st, F.passed, maxc, 1);
+  }
+  // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(ns)), dim3(256), 0, st, F.tgt_of_src, ns, -1);
+  hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(maxc)), dim3(256), 0, st, F.cross_i, F.cross_j, F.passed,
+                     F.mcounts, swapped, F.tgt_of_src, F.mcounts);
+  hipLaunchKernelGGL(k_src_flags, dim3(grid_for(ns)), dim3(256), 0, st, F.tgt_of_src, ns, F.flags);
+  if ((e = exclusive_scan_i32(F.flags, F.scan, ns, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_corr_compact, dim3(grid_for(ns)), dim3(256), 0, st, F.flags, F.scan, F.tgt_of_src, ns, F.corr,
+                     F.mcounts);
+  return hipGetLastError();
+}
+
+hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st) {
+  if (L <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_matched, dim3(grid_for(L)), dim3(256), 0, st, F.cloud[0].vox, F.cloud[1].vox, F.corr, L,
+                     m_src, m_tgt);
+  return hipGetLastError();
+}

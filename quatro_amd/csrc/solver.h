@@ -1,0 +1,37 @@
+// solver.h — device state and buffer carving for the back-end kernels (solver.hip).
+#pragma once
+#include "common.h"
+
+struct SolverState {  // device resident; mirrored to pinned host memory between clique rounds
+  int mc;        // best clique size so far (pmc_heu's `mc`)
+  int best_r;    // rank of the start vertex that produced it (-1 none, -2 member bitset prebuilt)
+  int pos;       // rank of the next start vertex (descending)
+  int done;
+  int t0;        // lowest rank whose Kp exceeds mc
+  int ub;        // max_core + 1  (reference src/graph.cc:84-86)
+  int batch;     // starts evaluated by the current k_clique_batch
+  int max_core;
+  int n_edges2;  // sum of degrees
+  int rounds;
+  int pad[6];
+};
+
+struct SolverBufs {
+  int Lcap = 0;
+  u64* bm = nullptr;    // adjacency, original labels  [L][W]
+  u64* adjP = nullptr;  // adjacency, rank labels      [L][W]
+  int *deg = nullptr, *core = nullptr, *perm = nullptr, *rankof = nullptr, *Kp = nullptr, *picks = nullptr,
+      *gsz = nullptr;
+  int *clique = nullptr, *rot_inl = nullptr, *final_inl = nullptr;
+  double* f64 = nullptr;
+  int* i32 = nullptr;
+  u64* member_bits = nullptr;
+  SolverState* st = nullptr;
+  qtr_result* res = nullptr;
+};
+
+size_t solver_scratch_bytes(int Lcap);
+void solver_carve(SolverBufs& B, void* base, int Lcap);
+hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                          hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique);
+hipError_t solver_init_attributes();

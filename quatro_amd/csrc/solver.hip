@@ -1,0 +1,941 @@
+// solver.hip — back-end kernels: pairwise-consistency bit-matrix, k-core, max-clique heuristic,
+// GNC-TLS yaw rotation and component-wise translation (COTE).  gfx950 / wave64 only.
+//
+// Replaces Quatro::computeTransformation (reference include/quatro.hpp:769-936) and everything it
+// reaches: computeTIMs (:307-344), solveForScale (:355-386), teaser::Graph::addEdge
+// (include/teaser/graph.h:96-104), teaser::MaxCliqueSolver::findMaxClique + PMC (src/graph.cc:12-104),
+// solveForRotation2D (:430-572) + svdRot2d (include/teaser/utils.h:151-166), solveForTranslation /
+// estimate (:585-747).  No TIM is ever materialised: the L x L predicate is evaluated tile-wise and
+// ballot-packed into a bit matrix (L^2/8 bytes instead of the reference's ~32.5 L^2 bytes).
+#include "common.h"
+#include "solver.h"
+
+// =================================================================================================
+// K9+K10+K11: consistency graph.  One wavefront per row; lane l evaluates column w*64+l and the 64
+// predicate bits are packed with __ballot.  Every lane keeps "its" word of a 64-word group so the row
+// is written back as coalesced 512-byte segments.
+//
+// Predicate (reference :372-385): |b/a - 1| <= beta/a  AND  |a/b - 1| <= beta/b, a=|src TIM|, b=|tgt TIM|.
+// In exact arithmetic both sides are |b - a| <= beta, i.e. (a^2+b^2-beta^2)^2 <= 4 a^2 b^2 when the
+// left base is positive.  That division/sqrt-free form decides every pair whose margin is > 1e-9
+// relative; the remaining (borderline) pairs run the reference expression verbatim, so the result is
+// bit-identical to evaluating the reference expression everywhere.
+__device__ __forceinline__ bool pair_consistent(double s, double t, double beta, double beta2) {
+  if (s > 0.0 && t > 0.0) {
+    const double u = s + t - beta2;
+    if (u > 0.0) {
+      const double lhs = u * u, rhs = 4.0 * s * t;
+      if (lhs > rhs * (1.0 + 1e-9)) return false;
+      if (lhs < rhs * (1.0 - 1e-9)) return true;
+    }
+  }
+  const double a = sqrt(s), b = sqrt(t);
+  const bool fwd = fabs(b / a - 1.0) <= beta * (1.0 / a);
+  const bool rev = fabs(a / b - 1.0) <= beta * (1.0 / b);
+  return fwd && rev;
+}
+
+__global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ src, const float4* __restrict__ tgt,
+                                                     int L, int W, double beta, u64* __restrict__ bm,
+                                                     int* __restrict__ deg, int* __restrict__ n_edges2) {
+  const int lane = qk_lane();
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= L) return;
+  const float4 si = src[row], ti = tgt[row];
+  const double six = si.x, siy = si.y, siz = si.z, tix = ti.x, tiy = ti.y, tiz = ti.z;
+  const double beta2 = beta * beta;
+  int degacc = 0;
+  for (int w0 = 0; w0 < W; w0 += 64) {
+    u64 myword = 0;
+    const int wend = min(64, W - w0);
+    for (int ww = 0; ww < wend; ++ww) {
+      const int j = (w0 + ww) * 64 + lane;
+      bool e = false;
+      if (j < L && j != row) {
+        const float4 sj = src[j], tj = tgt[j];
+        const double dx = (double)sj.x - six, dy = (double)sj.y - siy, dz = (double)sj.z - siz;
+        const double ex = (double)tj.x - tix, ey = (double)tj.y - tiy, ez = (double)tj.z - tiz;
+        const double s = dx * dx + (dy * dy + dz * dz);
+        const double t = ex * ex + (ey * ey + ez * ez);
+        e = pair_consistent(s, t, beta, beta2);
+      }
+      const u64 b = __ballot(e);
+      if (lane == ww) myword = b;
+    }
+    if (lane < wend) {
+      bm[(size_t)row * W + w0 + lane] = myword;
+      degacc += __popcll(myword);
+    }
+  }
+  const int d = wave_sum_i32(degacc);
+  if (lane == 0) {
+    deg[row] = d;
+    atomicAdd(n_edges2, d);
+  }
+}
+
+// =================================================================================================
+// K12a: exact core numbers by level-synchronous peeling, one workgroup (the graph of one registration
+// is small: L <= ~24k vertices).  Degrees and the frontier queue live in LDS; adjacency rows are read
+// from the bit matrix (L2 / Infinity-Cache resident).  Core numbers equal pmc_graph::compute_cores'
+// (Batagelj-Zaversnik) by uniqueness of the k-core decomposition.
+#define KC_REMOVED (-(1 << 30))
+__global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int L, int W, const int* __restrict__ deg_in,
+                                                int* __restrict__ core_out, SolverState* __restrict__ st,
+                                                int* __restrict__ gqueue /* used when the queue does not fit LDS */) {
+  extern __shared__ int kc_lds[];
+  int* deg = kc_lds;
+  int* queue = gqueue ? gqueue : kc_lds + L;
+  __shared__ int s_qn, s_min;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  for (int v = tid; v < L; v += nthr) deg[v] = deg_in[v];
+  if (tid == 0) s_min = 0x7fffffff;
+  __syncthreads();
+  {
+    int m = 0x7fffffff;
+    for (int v = tid; v < L; v += nthr) m = min(m, deg[v]);
+    m = wave_min_i32(m);
+    if (lane == 0) atomicMin(&s_min, m);
+  }
+  __syncthreads();
+  int k = s_min;
+  int maxcore = 0;
+  if (L == 0) k = 0;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+    for (int v = tid; v < L; v += nthr) {
+      const int d = deg[v];
+      if (d > KC_REMOVED / 2 && d <= k) {
+        deg[v] = 2 * KC_REMOVED + 1024;  // stays far below KC_REMOVED/2 under any number of decrements
+        core_out[v] = k;
+        queue[atomicAdd(&s_qn, 1)] = v;
+      }
+    }
+    __syncthreads();
+    const int n = s_qn;
+    if (n == 0) {
+      // level exhausted: jump to the smallest remaining degree
+      if (tid == 0) s_min = 0x7fffffff;
+      __syncthreads();
+      int m = 0x7fffffff;
+      for (int v = tid; v < L; v += nthr) {
+        const int d = deg[v];
+        if (d > KC_REMOVED / 2) m = min(m, d);
+      }
+      m = wave_min_i32(m);
+      if (lane == 0 && m != 0x7fffffff) atomicMin(&s_min, m);
+      __syncthreads();
+      if (s_min == 0x7fffffff) break;
+      k = s_min;
+      continue;
+    }
+    maxcore = k;
+    for (int q = wave; q < n; q += nwaves) {
+      const int v = queue[q];
+      for (int w = lane; w < W; w += 64) {
+        u64 x = bm[(size_t)v * W + w];
+        while (x) {
+          const int b = __ffsll((long long)x) - 1;
+          x &= x - 1;
+          atomicSub(&deg[w * 64 + b], 1);
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    st->max_core = maxcore;
+    st->ub = maxcore + 1;
+  }
+}
+
+// K12b: rank of every vertex in the (core, id) ascending order; perm[rank] = vertex; Kp[rank] = core+1
+// (PMC's "kcore" value).  This single order serves both as the outer start order of the heuristic
+// (traversed from the back) and as the greedy pick order (highest rank = max (K, id)).
+__global__ __launch_bounds__(256) void k_rank(const int* __restrict__ core, int L, int* __restrict__ perm,
+                                               int* __restrict__ rankof, int* __restrict__ Kp) {
+  __shared__ int tile[1024];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int c = v < L ? core[v] : 0;
+  int r = 0;
+  for (int base = 0; base < L; base += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (base + t < L) ? core[base + t] : 0x7fffffff;
+    __syncthreads();
+    const int lim = min(1024, L - base);
+    for (int t = 0; t < lim; ++t) {
+      const int cu = tile[t], u = base + t;
+      r += (cu < c) || (cu == c && u < v);
+    }
+  }
+  if (v < L) {
+    perm[r] = v;
+    rankof[v] = r;
+    Kp[r] = c + 1;
+  }
+}
+
+// K12c: adjacency in rank labels: adjP[r][s] = adj[perm[r]][perm[s]].  One workgroup per output row:
+// the source row is staged in LDS, each wave builds output words with one LDS bit probe per lane and
+// a ballot.
+__global__ __launch_bounds__(256) void k_permute(const u64* __restrict__ bm, const int* __restrict__ perm, int L, int W,
+                                                  u64* __restrict__ adjP) {
+  extern __shared__ u64 prow[];
+  const int r = blockIdx.x;
+  const int v = perm[r];
+  for (int w = threadIdx.x; w < W; w += 256) prow[w] = bm[(size_t)v * W + w];
+  __syncthreads();
+  const int lane = qk_lane(), wave = threadIdx.x >> 6;
+  for (int w = wave; w < W; w += 4) {
+    const int s = w * 64 + lane;
+    bool bit = false;
+    if (s < L) {
+      const int u = perm[s];
+      bit = (prow[u >> 6] >> (u & 63)) & 1ULL;
+    }
+    const u64 word = __ballot(bit);
+    if (lane == 0) adjP[(size_t)r * W + w] = word;
+  }
+}
+
+// K12d: greedy clique growth (pmc_heu::branch) for a batch of start vertices, one wavefront each.
+// The candidate set is a bitset spread over the wave (word w lives in lane w%64, slot w/64); a pick is
+// the highest set bit (= max (K, id)), an intersection is a coalesced row AND.  Starts are speculated
+// with the clique bound mc0 known at batch start; k_clique_scan then replays PMC's sequential
+// acceptance rules over the batch, which makes the outcome identical to a single-threaded run.
+template <int WPL>
+__device__ __forceinline__ int greedy_descent(const u64* __restrict__ adjP, int W, int r, int t0, int lane,
+                                              int* __restrict__ picks /* may be null */) {
+  u64 cur[WPL];
+#pragma unroll
+  for (int s = 0; s < WPL; ++s) {
+    const int w = s * 64 + lane;
+    u64 x = (w < W) ? adjP[(size_t)r * W + w] : 0ULL;
+    const int lo = w * 64;
+    if (lo + 63 < t0)
+      x = 0;
+    else if (lo < t0)
+      x &= ~((1ULL << (t0 - lo)) - 1ULL);
+    cur[s] = x;
+  }
+  int depth = 1;
+  while (true) {
+    int hb = -1;
+#pragma unroll
+    for (int s = WPL - 1; s >= 0; --s)
+      if (hb < 0 && cur[s]) hb = (s * 64 + lane) * 64 + 63 - __clzll((long long)cur[s]);
+    const int u = wave_max_i32(hb);
+    if (u < 0) break;
+    if (picks && lane == 0) picks[depth - 1] = u;
+    ++depth;
+#pragma unroll
+    for (int s = 0; s < WPL; ++s) {
+      const int w = s * 64 + lane;
+      if (w < W) cur[s] &= adjP[(size_t)u * W + w];
+    }
+  }
+  return depth;
+}
+
+__device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, int t0, int lane, int* picks) {
+  if (W <= 128) return greedy_descent<2>(adjP, W, r, t0, lane, picks);
+  if (W <= 256) return greedy_descent<4>(adjP, W, r, t0, lane, picks);
+  return greedy_descent<8>(adjP, W, r, t0, lane, picks);  // W <= 512  (L <= 32768)
+}
+
+__global__ __launch_bounds__(256) void k_clique_init(const int* __restrict__ Kp, int L, SolverState* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->mc = 0;
+    st->best_r = -1;
+    st->pos = L - 1;
+    st->done = (L <= 0) ? 1 : 0;
+    st->batch = 1;
+    // t0 = first rank with Kp > 0: every vertex has K >= 1
+    st->t0 = 0;
+    st->rounds = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
+                                                      int W, const SolverState* __restrict__ st,
+                                                      int* __restrict__ gsz) {
+  const int lane = qk_lane();
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (st->done || wid >= st->batch) return;
+  const int r = st->pos - wid;
+  int g = 0;
+  if (r >= 0 && Kp[r] > st->mc) g = greedy_dispatch(adjP, W, r, st->t0, lane, nullptr);
+  if (lane == 0) gsz[wid] = g;
+}
+
+// Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
+__global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
+                                                    int W, SolverState* __restrict__ st, const int* __restrict__ gsz,
+                                                    int next_batch) {
+  if (st->done) return;
+  const int lane = qk_lane();
+  const int B = st->batch, pos = st->pos, ub = st->ub;
+  int mc = st->mc, t = st->t0, best = st->best_r, done = 0;
+  int cursor = 0;
+  while (cursor < B) {
+    const int wid = cursor + lane;
+    const int r = pos - wid;
+    const bool cand = (wid < B) && (r >= 0) && (Kp[r] > mc) && (gsz[wid] > mc);
+    const u64 bal = __ballot(cand);
+    if (!bal) {
+      cursor += 64;
+      continue;
+    }
+    const int first = __ffsll((long long)bal) - 1;
+    const int wsel = cursor + first;
+    const int rsel = pos - wsel;
+    // |P| = #{u in N(v) : K[u] > mc} = popcount of row bits at ranks >= t
+    int cnt = 0;
+    for (int w = lane; w < W; w += 64) {
+      u64 x = adjP[(size_t)rsel * W + w];
+      const int lo = w * 64;
+      if (lo + 63 < t)
+        x = 0;
+      else if (lo < t)
+        x &= ~((1ULL << (t - lo)) - 1ULL);
+      cnt += __popcll(x);
+    }
+    cnt = wave_sum_i32(cnt);
+    if (cnt > mc) {
+      mc = gsz[wsel];
+      best = rsel;
+      // t = first rank with Kp > mc (Kp is non-decreasing in rank)
+      int lo = 0, hi = L;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (Kp[mid] > mc)
+          hi = mid;
+        else
+          lo = mid + 1;
+      }
+      t = lo;
+      if (mc >= ub) {
+        done = 1;
+        break;
+      }
+    }
+    cursor = wsel + 1;
+  }
+  const int newpos = pos - B;
+  if (newpos < 0 || Kp[newpos] <= mc) done = 1;
+  if (lane == 0) {
+    st->mc = mc;
+    st->best_r = best;
+    st->t0 = t;
+    st->pos = newpos;
+    st->done = done;
+    st->batch = next_batch;
+    st->rounds += 1;
+  }
+}
+
+// KCORE_HEU shortcut (reference src/graph.cc:67-82, including its shifted indexing): decided on device.
+// Writes the member bitset directly; st->mc = clique size, st->best_r = -2 marks "bitset already built".
+__global__ __launch_bounds__(256) void k_kcore_heu(const int* __restrict__ core, int L, double thr, SolverState* st,
+                                                   u64* __restrict__ member_bits, int W) {
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int max_core = st->max_core;
+  const bool take = (thr != 1.0) && (max_core > (int)(thr * (double)L));
+  if (!take) return;  // falls through to the PMC heuristic
+  for (int w = threadIdx.x; w < W; w += 256) member_bits[w] = 0;
+  __syncthreads();
+  for (int i = 1 + threadIdx.x; i <= L; i += 256) {
+    const int kc = (i < L) ? core[i] + 1 : core[L - 1];  // PMC's k_cores[] has V+1 entries; last one is unshifted
+    if (kc >= max_core) {
+      atomicOr(&member_bits[(i - 1) >> 6], 1ULL << ((i - 1) & 63));
+      atomicAdd(&s_cnt, 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->mc = s_cnt;
+    st->best_r = -2;
+    st->done = 1;
+  }
+}
+
+// =================================================================================================
+// K13-K16: chain TIMs, GNC-TLS yaw, rotation-inlier chain rule, COTE, final inliers.  One workgroup
+// of 256 threads; wavefront 0 runs the GNC loop with the fixed-shape sum64 reductions.
+#define FIN_LDS_BYTES (96 * 1024)
+struct FinalizeArgs {
+  const float4* src;
+  const float4* tgt;
+  const u64* adjP;
+  const int* perm;
+  int L, W;
+  qtr_params prm;
+  SolverState* st;
+  // global scratch (capacity >= L each unless noted)
+  u64* member_bits;  // W words
+  int* picks;        // L
+  int* clique;       // L  (sorted vertex ids)  -- also an output
+  int* rot_inl;      // L  output
+  int* final_inl;    // L  output
+  double* f64;       // 12 * L doubles
+  int* i32;          // 8 * L ints
+  qtr_result* res;   // device copy of the result record
+};
+
+__device__ void bitonic_sort_events(double* key, int* pos, int n2, int tid, int nthr) {
+  // ascending by (key, pos); n2 power of two; +inf padding sorts last
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n2; i += nthr) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const double a = key[i], b = key[ixj];
+          const int pa = pos[i], pb = pos[ixj];
+          const bool a_gt_b = (a > b) || (a == b && pa > pb);
+          const bool up = ((i & k) == 0);
+          if (a_gt_b == up) {
+            key[i] = b;
+            key[ixj] = a;
+            pos[i] = pb;
+            pos[ixj] = pa;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double fin_lds[];
+  __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
+  __shared__ double s_R[4], s_cost, s_est, s_bestcost;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int L = A.L, W = A.W;
+  SolverState* st = A.st;
+  qtr_result* res = A.res;
+  const int mc = st->mc;
+
+  // ---- clique members -> bitset in ORIGINAL labels -> sorted id list
+  if (st->best_r != -2) {
+    for (int w = tid; w < W; w += nthr) A.member_bits[w] = 0;
+    __syncthreads();
+    if (tid == 0) s_M = 0;
+    __syncthreads();
+    if (wave == 0 && st->best_r >= 0) {
+      const int depth = greedy_dispatch(A.adjP, W, st->best_r, 0, lane, A.picks);
+      if (lane == 0) s_M = depth;
+    }
+    __syncthreads();
+    {
+      // depth-1 picks + the start vertex itself
+      const int depth = s_M;
+      for (int i = tid; i < depth; i += nthr) {
+        const int rr = (i == depth - 1) ? st->best_r : A.picks[i];
+        const int v = A.perm[rr];
+        atomicOr(&A.member_bits[v >> 6], 1ULL << (v & 63));
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) s_M = 0;
+  __syncthreads();
+  if (wave == 0) {
+    int base = 0;
+    for (int w0 = 0; w0 < W; w0 += 64) {
+      const int w = w0 + lane;
+      u64 x = (w < W) ? A.member_bits[w] : 0ULL;
+      int tot;
+      int off = wave_excl_scan_i32(__popcll(x), &tot);
+      int o = base + off;
+      while (x) {
+        const int b = __ffsll((long long)x) - 1;
+        x &= x - 1;
+        A.clique[o++] = w * 64 + b;
+      }
+      base += tot;
+    }
+    if (lane == 0) s_M = base;
+  }
+  __syncthreads();
+  const int M = s_M;
+  if (tid == 0) {
+    res->n_clique = M;
+    res->max_core = st->max_core;
+    res->n_edges = st->n_edges2 / 2;
+    res->valid = 0;
+    res->cost = INFINITY;
+    res->gnc_iters = 0;
+    res->n_rot_inliers = 0;
+    res->n_final = 0;
+    for (int i = 0; i < 16; ++i) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    res->n_card[0] = res->n_card[1] = res->n_card[2] = 0;
+    res->status = QTR_OK;
+  }
+  __syncthreads();
+  (void)mc;
+  if (M <= 1) {  // reference :809-813
+    if (tid == 0) res->status = QTR_ERR_CLIQUE_TOO_SMALL;
+    return;
+  }
+
+  // ---- scratch layout: LDS when it fits (5 arrays of M doubles), else global
+  double* X0;
+  double* X1;
+  double* Y0;
+  double* Y1;
+  double* Wt;
+  const bool use_lds = ((size_t)M * 5 * sizeof(double) <= (size_t)FIN_LDS_BYTES);
+  if (use_lds) {
+    X0 = fin_lds;
+    X1 = X0 + M;
+    Y0 = X1 + M;
+    Y1 = Y0 + M;
+    Wt = Y1 + M;
+  } else {
+    X0 = A.f64;
+    X1 = X0 + L;
+    Y0 = X1 + L;
+    Y1 = Y0 + L;
+    Wt = Y1 + L;
+  }
+  // chain TIMs over the sorted clique, XY rows (:817-844, :396-402); scale == 1
+  for (int i = tid; i < M; i += nthr) {
+    const int root = A.clique[i], leaf = (i != M - 1) ? A.clique[i + 1] : A.clique[0];
+    const float4 sr = A.src[root], sl = A.src[leaf], tr = A.tgt[root], tl = A.tgt[leaf];
+    X0[i] = (double)sl.x - (double)sr.x;
+    X1[i] = (double)sl.y - (double)sr.y;
+    Y0[i] = ((double)tl.x - (double)tr.x) * (1 / 1.0);
+    Y1[i] = ((double)tl.y - (double)tr.y) * (1 / 1.0);
+    Wt[i] = 1.0;
+  }
+  __syncthreads();
+
+  // ---- GNC-TLS (wavefront 0), reference :430-572
+  if (wave == 0) {
+    const double rot_nb = A.prm.noise_bound * (2 / 1.0);
+    double nb_sq = rot_nb * rot_nb;
+    if (nb_sq < 1e-16) nb_sq = 1e-2;
+    double mu = 1.0, prev_cost = INFINITY, cost = INFINITY;
+    double R0 = 1, R1 = 0, R2 = 0, R3 = 1;
+    int iters = 0;
+    const int max_it = A.prm.rotation_max_iterations;
+    for (int it = 0; it < max_it; ++it) {
+      iters = it + 1;
+      double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+      for (int j = lane; j < M; j += 64) {
+        const double wx0 = Wt[j] * X0[j], wx1 = Wt[j] * X1[j];
+        h0 = h0 + wx0 * Y0[j];
+        h1 = h1 + wx0 * Y1[j];
+        h2 = h2 + wx1 * Y0[j];
+        h3 = h3 + wx1 * Y1[j];
+      }
+      h0 = wave_sum64_f64(h0);
+      h1 = wave_sum64_f64(h1);
+      h2 = wave_sum64_f64(h2);
+      h3 = wave_sum64_f64(h3);
+      {
+        const double a = h0 + h3, b = h1 - h2;
+        const double nrm = sqrt(a * a + b * b);
+        double c = 1.0, s = 0.0;
+        if (nrm > 0.0) {
+          c = a / nrm;
+          s = b / nrm;
+        }
+        R0 = c;
+        R1 = -s;
+        R2 = s;
+        R3 = c;
+      }
+      double max_r = -INFINITY;
+      for (int j = lane; j < M; j += 64) {
+        const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
+        const double r2 = e0 * e0 + e1 * e1;
+        max_r = fmax(max_r, r2);
+      }
+      max_r = wave_max_f64(max_r);
+      if (it == 0) {
+        mu = 1 / (2 * max_r / nb_sq - 1);
+        if (mu <= 0) break;
+      }
+      const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
+      double cpart = 0;
+      for (int j = lane; j < M; j += 64) {
+        const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
+        const double r2 = e0 * e0 + e1 * e1;
+        cpart = cpart + Wt[j] * r2;
+        double w;
+        if (r2 >= th1)
+          w = 0;
+        else if (r2 <= th2)
+          w = 1;
+        else
+          w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
+        Wt[j] = w;
+      }
+      cost = wave_sum64_f64(cpart);
+      const double cost_diff = fabs(cost - prev_cost);
+      mu = mu * A.prm.rotation_gnc_factor;
+      prev_cost = cost;
+      if (cost_diff < A.prm.rotation_cost_threshold) break;
+    }
+    if (lane == 0) {
+      s_R[0] = R0;
+      s_R[1] = R1;
+      s_R[2] = R2;
+      s_R[3] = R3;
+      s_cost = cost;
+      s_iters = iters;
+    }
+  }
+  __syncthreads();
+
+  // ---- rotation (yaw block, optional R * RyRx :419-423), rotation inliers (:857-874)
+  double R[9] = {s_R[0], s_R[1], 0, s_R[2], s_R[3], 0, 0, 0, 1};
+  if (A.prm.using_pre_estimated_ryrx) {
+    double Rn[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        Rn[3 * r + c] =
+            (R[3 * r] * A.prm.ryrx[c] + R[3 * r + 1] * A.prm.ryrx[3 + c]) + R[3 * r + 2] * A.prm.ryrx[6 + c];
+    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+  }
+  if (tid == 0) s_nrot = 0;
+  __syncthreads();
+  if (wave == 0) {
+    int base = 0;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+      const int i = i0 + lane;
+      bool in = false;
+      if (i < M) {
+        const int prev = (i == 0) ? M - 1 : i - 1;
+        in = (Wt[prev] >= 0.4) && (Wt[i] >= 0.4);
+      }
+      const u64 bal = __ballot(in);
+      if (in) A.rot_inl[base + __popcll(bal & lanemask_lt())] = i;
+      base += __popcll(bal);
+    }
+    if (lane == 0) s_nrot = base;
+  }
+  __syncthreads();
+  const int NR = s_nrot;
+  const bool use_rot = A.prm.using_rot_inliers_when_estimating_cote && NR > 0;
+  const int N = use_rot ? NR : M;
+  int* sel = A.i32;  // N selected vertex ids
+  for (int i = tid; i < N; i += nthr) sel[i] = use_rot ? A.clique[A.rot_inl[i]] : A.clique[i];
+  __syncthreads();
+
+  // raw_translation = dst - R * src'  (src' = RyRx*src only in the non-rot-inlier branch, :879-899)
+  double* RAW = A.f64 + 5 * (size_t)L;  // 3 arrays of L
+  for (int i = tid; i < N; i += nthr) {
+    const float4 s4 = A.src[sel[i]], t4 = A.tgt[sel[i]];
+    double x = s4.x, y = s4.y, z = s4.z;
+    if (!use_rot && A.prm.using_pre_estimated_ryrx) {
+      const double* Y = A.prm.ryrx;
+      const double nx = (Y[0] * x + Y[1] * y) + Y[2] * z, ny = (Y[3] * x + Y[4] * y) + Y[5] * z,
+                   nz = (Y[6] * x + Y[7] * y) + Y[8] * z;
+      x = nx;
+      y = ny;
+      z = nz;
+    }
+    RAW[i] = (double)t4.x - ((R[0] * x + R[1] * y) + R[2] * z);
+    RAW[L + i] = (double)t4.y - ((R[3] * x + R[4] * y) + R[5] * z);
+    RAW[2 * (size_t)L + i] = (double)t4.z - ((R[6] * x + R[7] * y) + R[8] * z);
+  }
+  __syncthreads();
+
+  // ---- COTE per axis (reference estimate(), :618-747)
+  // Per axis: (1) bitonic sort of the 2N interval endpoints by (value, insertion position) in LDS,
+  // (2) ONE lane walks the events accumulating the five running sums in the reference's order (binary64
+  // addition is not associative, so this part stays sequential; it only touches LDS and issues
+  // fire-and-forget stores), (3) all lanes evaluate x_hat / cost per event, (4) block arg-min with
+  // Eigen's minCoeff tie rule, (5) median of the consensus window by parallel rank counting.
+  const double range = A.prm.cote_noise_bound * sqrt(A.prm.cbar2);
+  const int nc = 2 * N;
+  int n2 = 1;
+  while (n2 < nc) n2 <<= 1;
+  double* ekey;  // n2
+  double* exv;   // nc : X of the event's measurement, in sorted event order
+  int* epos;     // n2
+  if ((size_t)n2 * 12 + (size_t)nc * 8 <= (size_t)FIN_LDS_BYTES) {
+    ekey = fin_lds;
+    exv = fin_lds + n2;
+    epos = (int*)(fin_lds + n2 + nc);
+  } else {
+    ekey = A.f64 + 8 * (size_t)L;  // needs n2 <= 4L: n2 < 2*nc = 4N <= 4L
+    exv = A.f64 + 12 * (size_t)L;  // 2L
+    epos = A.i32 + 2 * (size_t)L;  // 4L
+  }
+  double* rs_w = A.f64 + 14 * (size_t)L;    // running dot_weights_consensus   [2L]
+  double* rs_xw = A.f64 + 16 * (size_t)L;   // running dot_X_weights           [2L]
+  double* rs_rng = A.f64 + 18 * (size_t)L;  // running ranges_inverse_sum      [2L]
+  double* rs_x = A.f64 + 20 * (size_t)L;    // running sum_xi                  [2L]
+  double* rs_xx = A.f64 + 22 * (size_t)L;   // running sum_xi_square           [2L]
+  double* xhat = A.f64 + 24 * (size_t)L;    // [2L]
+  double* xcost = A.f64 + 26 * (size_t)L;   // [2L]
+  int* card = A.i32 + 6 * (size_t)L;        // [2L]
+  unsigned char* inl = (unsigned char*)(A.i32 + 1 * (size_t)L);  // N bytes
+  __shared__ double s_red_c[4];
+  __shared__ int s_red_i[4];
+  __shared__ double s_va, s_vb;
+  for (int i = tid; i < N; i += nthr) inl[i] = 1;
+  double tr[3] = {0, 0, 0};
+  for (int axis = 0; axis < 3; ++axis) {
+    const double* X = RAW + (size_t)axis * L;
+    __syncthreads();
+    for (int i = tid; i < n2; i += nthr) {
+      if (i < nc) {
+        const int p = i >> 1;
+        ekey[i] = (i & 1) ? X[p] + range : X[p] - range;
+        epos[i] = i;
+      } else {
+        ekey[i] = INFINITY;
+        epos[i] = i;
+      }
+    }
+    bitonic_sort_events(ekey, epos, n2, tid, nthr);
+    for (int i = tid; i < nc; i += nthr) exv[i] = X[epos[i] >> 1];
+    __syncthreads();
+    if (tid == 0) {
+      const double weight = 1.0 / (range * range);
+      double ranges_inverse_sum = 0;
+      for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
+      double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
+      int consensus = 0;
+      for (int i = 0; i < nc; ++i) {
+        const int eps = (epos[i] & 1) ? -1 : 1;
+        const double xv = exv[i];
+        consensus += eps;
+        dot_weights_consensus += eps * weight;
+        dot_X_weights += eps * weight * xv;
+        ranges_inverse_sum -= eps * range;
+        sum_xi += eps * xv;
+        sum_xi_square += eps * xv * xv;
+        card[i] = consensus;
+        rs_w[i] = dot_weights_consensus;
+        rs_xw[i] = dot_X_weights;
+        rs_rng[i] = ranges_inverse_sum;
+        rs_x[i] = sum_xi;
+        rs_xx[i] = sum_xi_square;
+      }
+    }
+    __syncthreads();
+    // per-event estimate and cost, then arg-min (first strict minimum; NaN is never selected unless first)
+    double bc = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < nc; i += nthr) {
+      const double xh = rs_xw[i] / rs_w[i];
+      xhat[i] = xh;
+      const double residual = card[i] * xh * xh + rs_xx[i] - 2 * rs_x[i] * xh;
+      const double c = residual + rs_rng[i];
+      xcost[i] = c;
+      if (c < bc || (c == bc && i < bi)) {
+        bc = c;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double oc = __shfl_xor(bc, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (oc < bc || (oc == bc && oi < bi)) {
+        bc = oc;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_red_c[wave] = bc;
+      s_red_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double c = s_red_c[0];
+      int mi = s_red_i[0];
+      for (int w = 1; w < 4; ++w)
+        if (s_red_c[w] < c || (s_red_c[w] == c && s_red_i[w] < mi)) {
+          c = s_red_c[w];
+          mi = s_red_i[w];
+        }
+      if (mi == 0x7fffffff || xcost[0] != xcost[0]) mi = 0;
+      s_minidx = mi;
+      s_ncard = card[mi];
+      s_est = xhat[mi];
+      s_va = 0;
+      s_vb = 0;
+    }
+    __syncthreads();
+    const int mi = s_minidx, ncard = s_ncard;
+    if (A.prm.cote_median && ncard >= 2) {
+      // the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}
+      const int ra = ncard / 2 - 1, rb = ncard / 2;
+      for (int j = tid; j < ncard; j += nthr) {
+        const double vj = exv[mi - j];
+        int rk = 0;
+        for (int q = 0; q < ncard; ++q) {
+          const double vq = exv[mi - q];
+          rk += (vq < vj) || (vq == vj && q < j);
+        }
+        if (rk == ra) s_va = vj;
+        if (rk == rb) s_vb = vj;
+      }
+      __syncthreads();
+      if (tid == 0) s_est = (s_va + s_vb) / 2.0;
+    } else if (A.prm.cote_median && ncard == 1) {
+      if (tid == 0) s_est = exv[mi];
+    }
+    __syncthreads();
+    const double est = s_est;
+    tr[axis] = est;
+    for (int i = tid; i < N; i += nthr) inl[i] = inl[i] && (fabs(X[i] - est) <= range);
+    if (tid == 0) res->n_card[axis] = ncard;
+  }
+  __syncthreads();
+  // ---- final inliers (:914-930) and the 4x4
+  if (wave == 0) {
+    int base = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+      const int i = i0 + lane;
+      const bool in = (i < N) && inl[i];
+      const u64 bal = __ballot(in);
+      if (in) A.final_inl[base + __popcll(bal & lanemask_lt())] = sel[i];
+      base += __popcll(bal);
+    }
+    if (lane == 0) s_nfinal = base;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) res->T[4 * r + c] = R[3 * r + c];
+      res->T[4 * r + 3] = tr[r];
+    }
+    res->T[12] = res->T[13] = res->T[14] = 0;
+    res->T[15] = 1;
+    res->cost = s_cost;
+    res->gnc_iters = s_iters;
+    res->n_rot_inliers = NR;
+    res->n_final = s_nfinal;
+    res->valid = 1;
+    res->status = QTR_OK;
+  }
+}
+
+// =================================================================================================
+// host-side launcher (called from capi.hip)
+hipError_t solver_init_attributes() {
+  hipError_t e = hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
+size_t solver_scratch_bytes(int Lcap) {
+  const size_t W = (size_t)(Lcap + 63) / 64;
+  size_t b = 0;
+  b += 2 * (size_t)Lcap * W * 8;        // bm, adjP
+  b += 8 * (size_t)Lcap * 4;            // deg, core, perm, rankof, Kp, picks, gsz, (spare)
+  b += 3 * (size_t)Lcap * 4;            // clique, rot_inl, final_inl
+  b += 28 * (size_t)Lcap * 8;           // f64
+  b += 8 * (size_t)Lcap * 4;            // i32
+  b += W * 8 + 4096;
+  return b;
+}
+
+void solver_carve(SolverBufs& B, void* base, int Lcap) {
+  char* p = (char*)base;
+  const size_t W = (size_t)(Lcap + 63) / 64;
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += (bytes + 255) & ~(size_t)255;
+    return (void*)r;
+  };
+  B.Lcap = Lcap;
+  B.bm = (u64*)take((size_t)Lcap * W * 8);
+  B.adjP = (u64*)take((size_t)Lcap * W * 8);
+  B.deg = (int*)take((size_t)Lcap * 4);
+  B.core = (int*)take((size_t)Lcap * 4);
+  B.perm = (int*)take((size_t)Lcap * 4);
+  B.rankof = (int*)take((size_t)Lcap * 4);
+  B.Kp = (int*)take((size_t)Lcap * 4);
+  B.picks = (int*)take((size_t)Lcap * 4);
+  B.gsz = (int*)take((size_t)Lcap * 4);
+  B.clique = (int*)take((size_t)Lcap * 4);
+  B.rot_inl = (int*)take((size_t)Lcap * 4);
+  B.final_inl = (int*)take((size_t)Lcap * 4);
+  B.f64 = (double*)take(28 * (size_t)Lcap * 8);
+  B.i32 = (int*)take(8 * (size_t)Lcap * 4);
+  B.member_bits = (u64*)take(W * 8);
+  B.st = (SolverState*)take(sizeof(SolverState));
+  B.res = (qtr_result*)take(sizeof(qtr_result));
+}
+
+// Enqueues the whole back end on `stream`.  L is known on the host.  Returns a HIP error code.
+// The clique heuristic normally terminates after the first two batches (see header comment of
+// k_clique_batch); `*host_done` (pinned) is polled between further rounds.
+hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                          hipStream_t stream, int* pinned_state /* >= 16 ints, host pinned */,
+                          hipEvent_t ev_graph, hipEvent_t ev_clique) {
+  const int W = (L + 63) / 64;
+  hipError_t e;
+  if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
+  if (L > 0) {
+    const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
+    hipLaunchKernelGGL(k_graph_build, dim3((L + 3) / 4), dim3(256), 0, stream, src, tgt, L, W, beta, B.bm, B.deg,
+                       &B.st->n_edges2);
+    if (ev_graph) hipEventRecord(ev_graph, stream);
+    const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
+    const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
+    hipLaunchKernelGGL(k_kcore, dim3(1), dim3(1024), kc_lds, stream, B.bm, L, W, B.deg, B.core, B.st,
+                       q_in_lds ? (int*)nullptr : B.picks);
+    hipLaunchKernelGGL(k_rank, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.perm, B.rankof, B.Kp);
+    hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
+    hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
+    bool heuristic = true;
+    if (prm.inlier_selection_mode == QTR_INLIER_KCORE_HEU) {
+      hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, prm.kcore_heuristic_threshold, B.st,
+                         B.member_bits, W);
+    }
+    if (heuristic) {
+      const int BATCH = 256;
+      // round 0: the single top-ranked start; round 1..: BATCH starts each
+      hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz);
+      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH);
+      int guard = 0;
+      while (true) {
+        hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz);
+        hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH);
+        if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) !=
+            hipSuccess)
+          return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const SolverState* hs = (const SolverState*)pinned_state;
+        if (hs->done) break;
+        if (++guard > (L / BATCH) + 4) break;  // cannot happen: pos decreases by BATCH per round
+      }
+    }
+  }
+  if (ev_clique) hipEventRecord(ev_clique, stream);
+  FinalizeArgs A;
+  A.src = src;
+  A.tgt = tgt;
+  A.adjP = B.adjP;
+  A.perm = B.perm;
+  A.L = L;
+  A.W = W;
+  A.prm = prm;
+  A.st = B.st;
+  A.member_bits = B.member_bits;
+  A.picks = B.picks;
+  A.clique = B.clique;
+  A.rot_inl = B.rot_inl;
+  A.final_inl = B.final_inl;
+  A.f64 = B.f64;
+  A.i32 = B.i32;
+  A.res = B.res;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), (size_t)FIN_LDS_BYTES, stream, A);
+  return hipGetLastError();
+}

@@ -1,0 +1,5 @@
+// unity.hip — single translation unit of libquatro_hip.so (all kernels + the C ABI).
+#include "solver.hip"
+#include "frontend.hip"
+#include "match.hip"
+#include "capi.hip"

@@ -1,0 +1,296 @@
+"""ctypes binding of libquatro_hip.so (the C ABI in include/quatro_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises, loudly.
+Build it with ``python -m quatro_amd.build`` (hipcc cross-compiles for gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquatro_hip.so")
+
+QTR_OK, QTR_ERR_BAD_ARG, QTR_ERR_CLIQUE_TOO_SMALL, QTR_ERR_CAPACITY, QTR_ERR_HIP, QTR_ERR_UNSUPPORTED = range(6)
+MEM_HOST, MEM_DEVICE = 0, 1
+INLIER_PMC_EXACT, INLIER_PMC_HEU, INLIER_KCORE_HEU, INLIER_NONE = range(4)
+
+DBG_GRAPH_BITMAP, DBG_CORE, DBG_PERM, DBG_NBR_OFFSETS, DBG_NBR_INDEX, DBG_NBR_DIST2, DBG_SPFH = 1, 2, 3, 4, 5, 6, 7
+DBG_NN_LARGE_OF_SMALL, DBG_NN_SMALL_OF_LARGE, DBG_VOX_SRC, DBG_VOX_TGT, DBG_CORR, DBG_MATCH_STATS = 8, 9, 10, 11, 12, 13
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_points", C.c_int), ("max_voxels", C.c_int), ("max_corr", C.c_int), ("n_slots", C.c_int)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("noise_bound", C.c_double), ("cbar2", C.c_double), ("rotation_gnc_factor", C.c_double),
+        ("rotation_cost_threshold", C.c_double), ("kcore_heuristic_threshold", C.c_double),
+        ("cote_noise_bound", C.c_double), ("ryrx", C.c_double * 9),
+        ("rotation_max_iterations", C.c_int), ("inlier_selection_mode", C.c_int), ("cote_median", C.c_int),
+        ("using_rot_inliers_when_estimating_cote", C.c_int), ("using_pre_estimated_ryrx", C.c_int),
+        ("reserved", C.c_int),
+    ]
+
+
+class FrontendParams(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("normal_radius", C.c_float), ("fpfh_radius", C.c_float),
+                ("tuple_scale", C.c_float), ("use_crosscheck", C.c_int), ("use_tuple_test", C.c_int),
+                ("seed", C.c_ulonglong)]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("valid", C.c_int), ("T", C.c_double * 16), ("cost", C.c_double),
+        ("gnc_iters", C.c_int), ("n_clique", C.c_int), ("n_rot_inliers", C.c_int), ("n_final", C.c_int),
+        ("max_core", C.c_int), ("n_edges", C.c_int), ("n_card", C.c_int * 3),
+        ("n_src", C.c_int), ("n_tgt", C.c_int), ("n_corr", C.c_int),
+    ]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total")]
+
+
+EXPORTS = [
+    "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
+    "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
+    "qtr_solve", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+]
+
+_lib = None
+
+
+class QuatroHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libquatro_hip status {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Loads libquatro_hip.so.  Raises if it has not been built — there is no software fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m quatro_amd.build` "
+            "(or __graft_entry__.build()). quatro_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; importing it first makes both share ONE HIP runtime.
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    lib.qtr_last_error.restype = C.c_char_p
+    lib.qtr_slot_stream.restype = C.c_void_p
+    lib.qtr_debug_fetch.restype = C.c_longlong
+    lib.qtr_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.qtr_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.qtr_destroy.argtypes = [C.c_void_p]
+    lib.qtr_last_error.argtypes = [C.c_void_p]
+    lib.qtr_slot_stream.argtypes = [C.c_void_p, C.c_int]
+    lib.qtr_num_slots.argtypes = [C.c_void_p]
+    lib.qtr_voxelize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                 C.POINTER(C.c_int), C.c_int]
+    lib.qtr_fpfh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                             C.c_int]
+    lib.qtr_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                              C.POINTER(FrontendParams), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+    lib.qtr_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params),
+                              C.POINTER(Result), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_register_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.POINTER(FrontendParams), C.POINTER(Params), C.POINTER(Result), C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
+    lib.qtr_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    _lib = lib
+    return lib
+
+
+def default_params() -> Params:
+    p = Params()
+    load().qtr_default_params(C.byref(p))
+    return p
+
+
+def demo_params(**kw) -> Params:
+    """config/params.yaml values (what the reference demo actually runs)."""
+    p = Params()
+    load().qtr_demo_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "ryrx":
+            for i, x in enumerate(np.asarray(v, dtype=np.float64).reshape(-1)):
+                p.ryrx[i] = float(x)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def default_frontend_params(**kw) -> FrontendParams:
+    p = FrontendParams()
+    load().qtr_default_frontend_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    """numpy array -> (host pointer, MEM_HOST); torch CUDA tensor -> (device pointer, MEM_DEVICE)."""
+    if a is None:
+        return None, None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data, MEM_HOST
+    # torch tensor
+    assert a.is_contiguous()
+    return a.data_ptr(), (MEM_DEVICE if a.is_cuda else MEM_HOST)
+
+
+def _f4(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4, "points must be [N,4] float32 (x,y,z,pad)"
+    return a
+
+
+class Handle:
+    """One device + n_slots stream slots (qtr_handle)."""
+
+    def __init__(self, device: int = 0, max_points: int = 262144, max_voxels: int = 65536, max_corr: int = 24576,
+                 n_slots: int = 1):
+        self._lib = load()
+        lim = Limits(max_points, max_voxels, max_corr, n_slots)
+        self._h = C.c_void_p()
+        rc = self._lib.qtr_create(device, C.byref(lim), C.byref(self._h))
+        if rc != QTR_OK:
+            msg = self._lib.qtr_last_error(self._h).decode() if self._h else "qtr_create failed"
+            if self._h:
+                self._lib.qtr_destroy(self._h)
+                self._h = C.c_void_p()
+            raise QuatroHipError(rc, msg)
+        self.limits = lim
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.qtr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        return self._lib.qtr_last_error(self._h).decode()
+
+    def _check(self, rc: int, ok=(QTR_OK,)):
+        if rc not in ok:
+            raise QuatroHipError(rc, self.last_error())
+        return rc
+
+    def stream_ptr(self, slot: int = 0) -> int:
+        return int(self._lib.qtr_slot_stream(self._h, slot) or 0)
+
+    # ---- host-array convenience wrappers (numpy in / numpy out) ---------------------------------
+    def voxelize(self, xyz4, leaf: float, slot: int = 0):
+        xyz4 = _f4(xyz4)
+        out = np.zeros_like(xyz4)
+        n = C.c_int()
+        self._check(self._lib.qtr_voxelize(self._h, slot, xyz4.ctypes.data, xyz4.shape[0], leaf, out.ctypes.data,
+                                           out.shape[0], C.byref(n), MEM_HOST))
+        return out[: n.value].copy()
+
+    def fpfh(self, xyz4, r_normal: float, r_fpfh: float, slot: int = 0):
+        xyz4 = _f4(xyz4)
+        n = xyz4.shape[0]
+        nrm = np.zeros((n, 4), dtype=np.float32)
+        desc = np.zeros((n, 33), dtype=np.float32)
+        self._check(self._lib.qtr_fpfh(self._h, slot, xyz4.ctypes.data, n, r_normal, r_fpfh, nrm.ctypes.data,
+                                       desc.ctypes.data, MEM_HOST))
+        return nrm, desc
+
+    def match(self, xyz_s, desc_s, xyz_t, desc_t, fp: FrontendParams | None = None, slot: int = 0):
+        xyz_s, xyz_t = _f4(xyz_s), _f4(xyz_t)
+        desc_s = np.ascontiguousarray(desc_s, dtype=np.float32)
+        desc_t = np.ascontiguousarray(desc_t, dtype=np.float32)
+        fp = fp or default_frontend_params()
+        cap = max(min(xyz_s.shape[0], xyz_t.shape[0]), 1)
+        corr = np.zeros((cap, 2), dtype=np.int32)
+        L = C.c_int()
+        self._check(self._lib.qtr_match(self._h, slot, xyz_s.ctypes.data, xyz_s.shape[0], desc_s.ctypes.data,
+                                        xyz_t.ctypes.data, xyz_t.shape[0], desc_t.ctypes.data, C.byref(fp),
+                                        corr.ctypes.data, cap, C.byref(L), MEM_HOST))
+        return corr[: L.value].copy()
+
+    def solve(self, src4, tgt4, params: Params | None = None, slot: int = 0):
+        src4, tgt4 = _f4(src4), _f4(tgt4)
+        L = src4.shape[0]
+        assert tgt4.shape[0] == L
+        prm = params or demo_params()
+        res = Result()
+        cap = max(L, 1)
+        cl = np.zeros(cap, dtype=np.int32)
+        rot = np.zeros(cap, dtype=np.int32)
+        fin = np.zeros(cap, dtype=np.int32)
+        rc = self._lib.qtr_solve(self._h, slot, src4.ctypes.data, tgt4.ctypes.data, L, C.byref(prm), C.byref(res),
+                                 cl.ctypes.data, rot.ctypes.data, fin.ctypes.data, cap, MEM_HOST)
+        self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
+        return _result_dict(res, cl, rot, fin)
+
+    def register_pair(self, src_raw4, tgt_raw4, fp: FrontendParams | None = None, params: Params | None = None,
+                      slot: int = 0):
+        src_raw4, tgt_raw4 = _f4(src_raw4), _f4(tgt_raw4)
+        fp = fp or default_frontend_params()
+        prm = params or demo_params()
+        res = Result()
+        cap = int(self.limits.max_corr)
+        cl = np.zeros(cap, dtype=np.int32)
+        fin = np.zeros(cap, dtype=np.int32)
+        rc = self._lib.qtr_register_pair(self._h, slot, src_raw4.ctypes.data, src_raw4.shape[0], tgt_raw4.ctypes.data,
+                                         tgt_raw4.shape[0], C.byref(fp), C.byref(prm), C.byref(res), cl.ctypes.data,
+                                         fin.ctypes.data, cap, MEM_HOST)
+        self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
+        return _result_dict(res, cl, None, fin)
+
+    # ---- device-resident entry points (torch CUDA tensors or raw pointers) -----------------------
+    def register_pair_dev(self, src_ptr: int, Ps: int, tgt_ptr: int, Pt: int, fp: FrontendParams, prm: Params,
+                          res: Result, slot: int = 0) -> int:
+        return self._lib.qtr_register_pair(self._h, slot, src_ptr, Ps, tgt_ptr, Pt, C.byref(fp), C.byref(prm),
+                                           C.byref(res), None, None, 0, MEM_DEVICE)
+
+    def solve_dev(self, src_ptr: int, tgt_ptr: int, L: int, prm: Params, res: Result, slot: int = 0) -> int:
+        return self._lib.qtr_solve(self._h, slot, src_ptr, tgt_ptr, L, C.byref(prm), C.byref(res), None, None, None,
+                                   0, MEM_DEVICE)
+
+    def stage_times(self, slot: int = 0) -> dict:
+        t = StageTimes()
+        self._lib.qtr_get_stage_times(self._h, slot, C.byref(t))
+        return {n: getattr(t, n) for n, _ in StageTimes._fields_}
+
+    def debug_fetch(self, what: int, dtype, slot: int = 0) -> np.ndarray:
+        nbytes = self._lib.qtr_debug_fetch(self._h, slot, what, None, 0)
+        if nbytes < 0:
+            raise QuatroHipError(-1, "qtr_debug_fetch failed")
+        out = np.zeros(max(nbytes // np.dtype(dtype).itemsize, 0), dtype=dtype)
+        if nbytes:
+            self._lib.qtr_debug_fetch(self._h, slot, what, out.ctypes.data, nbytes)
+        return out
+
+    def debug_math(self, fn: int, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b if b is not None else a, dtype=np.float32)
+        out = np.zeros_like(a)
+        self._check(self._lib.qtr_debug_math(self._h, fn, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
+        return out
+
+
+def _result_dict(res: Result, cl, rot, fin) -> dict:
+    return {
+        "status": res.status, "valid": bool(res.valid), "T": np.array(res.T[:]).reshape(4, 4), "cost": res.cost,
+        "gnc_iters": res.gnc_iters, "clique": cl[: res.n_clique].copy(),
+        "rot_inliers": None if rot is None else rot[: res.n_rot_inliers].copy(),
+        "final_inliers": fin[: res.n_final].copy(), "max_core": res.max_core, "n_edges": res.n_edges,
+        "n_card": list(res.n_card), "n_src": res.n_src, "n_tgt": res.n_tgt, "L": res.n_corr,
+        "n_rot_inliers": res.n_rot_inliers,
+    }
