@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — registrations/sec of the whole hot path (voxel-FPFH -> matching -> consistency graph ->
+max-clique -> GNC-TLS -> COTE) on synthetic KITTI-64-shaped scan pairs resident in HBM.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run, one rank per GPU.  A step = one registration of one scan pair (BASELINE.json
+configs[1]); pairs are independent, so ranks shard pairs with no data-path collective and the only
+exchange is the final gather of fixed-size result records over RCCL ("weak" scaling: per-GPU work
+fixed).  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline     — dominant kernel (33-D nearest-neighbour contraction): algorithmic FLOP per launch
+                 (66 * n_small * n_large) / mean launch duration from HIP events recorded by the library on
+                 the launch stream, against the FP32 matrix/vector peak of MI355X.
+  cpu_baseline — the CPU oracle (a port; the reference cannot be built here) timed on this box's host cores
+                 on a bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="kitti64_pair", choices=["kitti64_pair", "solver5k"])
+    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through per rank")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    from quatro_amd import dist as qdist
+    from quatro_amd import lib as ql
+    from quatro_amd import synth
+
+    h = ql.Handle(local_rank)
+    prm = ql.demo_params()
+    res = ql.Result()
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    pool = []
+    for i in range(args.pairs):
+        pid = rank * args.pairs + i
+        if args.workload == "kitti64_pair":
+            s, t, Tgt = synth.kitti64_pair(pid)
+        else:
+            s, t, Tgt, _ = synth.correspondences(5000, 0.05, seed=pid, noise=0.1)
+        pool.append({"id": pid, "src_h": s, "tgt_h": t, "Tgt": Tgt, "src": torch.from_numpy(s).to(dev),
+                     "tgt": torch.from_numpy(t).to(dev), "fp": ql.default_frontend_params(seed=pid)})
+    torch.cuda.synchronize()
+
+    def step(p):
+        if args.workload == "kitti64_pair":
+            rc = h.register_pair_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
+                                     p["fp"], prm, res)
+        else:
+            rc = h.solve_dev(p["src"].data_ptr(), p["tgt"].data_ptr(), p["src"].shape[0], prm, res)
+        if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+            raise ql.QuatroHipError(rc, h.last_error())
+
+    for w in range(args.warmup):
+        step(pool[w % len(pool)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    nn_ms, nn_launches, stage_acc = 0.0, 0, {}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(pool[k % len(pool)])
+        st = h.stage_times()
+        nn_ms += st["nn_kernel"]
+        nn_launches += st["nn_launches"]
+        for key, v in st.items():
+            stage_acc[key] = stage_acc.get(key, 0.0) + float(v)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = qdist.max_over_ranks(elapsed, dev)
+
+    # ---- result records of the pool, gathered on rank 0 (the path's only collective)
+    recs = []
+    for p in pool:
+        if args.workload == "kitti64_pair":
+            r = h.register_pair(p["src_h"], p["tgt_h"], p["fp"], prm)
+        else:
+            r = h.solve(p["src_h"], p["tgt_h"], prm)
+        p["result"] = r
+        recs.append(qdist.pack_record(p["id"], r))
+    gathered = qdist.gather_records(np.stack(recs), dev)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    p0 = pool[0]
+    r0 = p0["result"]
+    value = world * args.steps / elapsed
+    out = {
+        "metric": "scan-pair registrations/sec (KITTI 64-ch) + rot/trans err vs ref",
+        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (front end) / f64 (solver)", "data": "synthetic",
+        "config": {
+            "workload": ("synthetic KITTI-64-shaped single pair, voxel 0.3 m, whole path on GPU (BASELINE configs[1])"
+                         if args.workload == "kitti64_pair" else "solver only, 5000 synthetic correspondences"),
+            "raw_points": [int(p0["src_h"].shape[0]), int(p0["tgt_h"].shape[0])],
+            "n_src": int(r0.get("n_src", 0)), "n_tgt": int(r0.get("n_tgt", 0)), "n_corr": int(r0["L"]),
+            "n_clique": int(r0["clique"].size), "n_final_inliers": int(r0["final_inliers"].size),
+            "pairs_per_rank": len(pool), "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
+            "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, RCCL gather of result records",
+        },
+        "stage_ms": {k: round(v / args.steps, 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
+    }
+    yaw_gt = float(np.arctan2(p0["Tgt"][1, 0], p0["Tgt"][0, 0]))
+    yaw = float(np.arctan2(r0["T"][1, 0], r0["T"][0, 0]))
+    out["accuracy_vs_ground_truth"] = {
+        "rot_err_rad": abs(float(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt)))),
+        "trans_err_m": float(np.linalg.norm(r0["T"][:3, 3] - p0["Tgt"][:3, 3])), "valid": bool(r0["valid"])}
+
+    # ---- roofline of the dominant kernel
+    if args.workload == "kitti64_pair" and nn_launches > 0:
+        ns, nt = int(r0["n_src"]), int(r0["n_tgt"])
+        flop_per_launch = 66.0 * ns * nt
+        mean_launch_s = 1e-3 * nn_ms / nn_launches
+        achieved = flop_per_launch / mean_launch_s / 1e12
+        out["roofline"] = {"kernel": "k_nn (33-D reciprocal nearest neighbour, one launch per direction)",
+                           "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                           "flop_per_launch": flop_per_launch, "mean_launch_ms": 1e3 * mean_launch_s}
+    else:
+        L = int(r0["L"])
+        gk = stage_acc.get("graph", 0.0) / max(args.steps, 1)
+        alg_bytes = 32.0 * L + L * L / 8.0  # 2 x 16 B per correspondence in + bit matrix out
+        achieved = alg_bytes / (1e-3 * gk) / 1e9 if gk > 0 else 0.0
+        out["roofline"] = {"kernel": "k_graph_build (stage time)", "bound": "hbm", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+
+    # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample; also the parity check
+    if world == 1 and args.cpu_seconds > 0:
+        from oracle import oracle as qo  # cpu_baseline leg: the only place bench.py touches oracle/
+        cores = os.cpu_count() or 1
+        qo.set_threads(cores)
+
+        def cpu_once():
+            if args.workload == "kitti64_pair":
+                return qo.register_pair(p0["src_h"], p0["tgt_h"], seed=p0["id"])
+            return qo.solve(p0["src_h"], p0["tgt_h"])
+
+        t1 = time.perf_counter()
+        o = cpu_once()  # warm-up, also the parity reference
+        first = time.perf_counter() - t1
+        runs = int(max(1, min(5, args.cpu_seconds / max(first, 1e-3) - 1)))
+        ts = []
+        for _ in range(runs):
+            t1 = time.perf_counter()
+            cpu_once()
+            ts.append(time.perf_counter() - t1)
+        med = float(np.median(ts))
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
+                               "sample": f"pair {p0['id']} of the same workload: 1 warm-up + {runs} timed runs of the "
+                                         f"OpenMP CPU oracle (median {med:.3f} s)"}
+        yaw_o = float(np.arctan2(o["T"][1, 0], o["T"][0, 0]))
+        out["parity_vs_oracle"] = {
+            "rot_err_rad": abs(float(np.arctan2(np.sin(yaw - yaw_o), np.cos(yaw - yaw_o)))),
+            "trans_err_m": float(np.linalg.norm(r0["T"][:3, 3] - o["T"][:3, 3])),
+            "clique_bit_exact": bool(np.array_equal(r0["clique"], o["clique"])),
+            "final_inliers_bit_exact": bool(np.array_equal(r0["final_inliers"], o["final_inliers"])),
+            "counts_equal": bool(args.workload != "kitti64_pair" or
+                                 (r0["n_src"], r0["n_tgt"], r0["L"]) == (o["n_src"], o["n_tgt"], o["L"]))}
+        out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

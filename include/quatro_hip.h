@@ -115,6 +115,9 @@ typedef struct qtr_result {
 /* Per-stage GPU time of the last call on a slot, milliseconds (hipEvent based). */
 typedef struct qtr_stage_times {
   float voxelize, fpfh, match, graph, clique, solve, total;
+  float nn_kernel;  /* sum of the nearest-neighbour kernel launches of the last match (events on the launch stream) */
+  int nn_launches;
+  float graph_kernel; /* k_graph_build alone */
 } qtr_stage_times;
 
 int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);

@@ -1,0 +1,286 @@
+"""Host-side mirror of the reference's interface for this path, in Python, above the C ABI.
+
+Same names, argument meaning and error behaviour as the reference so that tests read like the
+reference's demo (examples/run_global_registration.cpp:103-108, 206-221, 243-246):
+
+    quatro = Quatro(); quatro.reset(params)
+    src_feat, tgt_feat = voxelize(src, 0.3), voxelize(tgt, 0.3)
+    fm = FPFHManager(normal_radius, fpfh_radius); fm.flushAllFeatures(); fm.setFeaturePair(src_feat, tgt_feat)
+    quatro.setInputSource(fm.getSrcKps()); quatro.setInputTarget(fm.getTgtKps())
+    T = quatro.computeTransformation()
+
+Clouds are numpy [N,4] float32 (x,y,z,pad) — the layout of pcl::PointXYZ.  Everything numerical happens
+in libquatro_hip.so; this module holds state and argument checks only.
+"""
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import lib as _ql
+
+
+class INLIER_SELECTION_MODE(enum.IntEnum):  # reference include/quatro.hpp:184-189
+    PMC_EXACT = 0
+    PMC_HEU = 1
+    KCORE_HEU = 2
+    NONE = 3
+
+
+class ROTATION_ESTIMATION_ALGORITHM(enum.IntEnum):  # :172-175
+    GNC_TLS = 0
+    FGR = 1
+
+
+class INLIER_GRAPH_FORMULATION(enum.IntEnum):  # :197-200
+    CHAIN = 0
+    COMPLETE = 1
+
+
+@dataclass
+class Params:
+    """Quatro::Params (reference include/quatro.hpp:202-268), same field names and defaults."""
+    reg_name: str = "Quatro"
+    cote_mode: str = "median"
+    using_rot_inliers_when_estimating_cote: bool = False
+    noise_bound: float = 0.3
+    cbar2: float = 1.0
+    estimate_scaling: bool = True            # accepted, ignored (reference :361 forces scale = 1)
+    rotation_estimation_algorithm: ROTATION_ESTIMATION_ALGORITHM = ROTATION_ESTIMATION_ALGORITHM.GNC_TLS
+    rotation_gnc_factor: float = 1.4
+    rotation_max_iterations: int = 100
+    rotation_cost_threshold: float = 1e-6
+    rotation_tim_graph: INLIER_GRAPH_FORMULATION = INLIER_GRAPH_FORMULATION.CHAIN
+    inlier_selection_mode: INLIER_SELECTION_MODE = INLIER_SELECTION_MODE.PMC_HEU
+    kcore_heuristic_threshold: float = 0.5
+    use_max_clique: bool = True              # deprecated in the reference, unused
+    max_clique_exact_solution: bool = True   # deprecated in the reference, unused
+    max_clique_time_limit: float = 3600.0
+
+
+@dataclass
+class RegistrationSolution:  # reference include/quatro.hpp:161-168
+    valid: bool = True
+    scale: float = 1.0
+    translation: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    rotation: np.ndarray = field(default_factory=lambda: np.eye(3))
+
+
+_shared_handle = None
+
+
+def _handle() -> "_ql.Handle":
+    global _shared_handle
+    if _shared_handle is None:
+        _shared_handle = _ql.Handle(0)
+    return _shared_handle
+
+
+def _as_cloud(c) -> np.ndarray:
+    a = np.asarray(c, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (3, 4):
+        raise ValueError("cloud must be [N,3] or [N,4]")
+    if a.shape[1] == 3:
+        a = np.concatenate([a, np.zeros((a.shape[0], 1), dtype=np.float32)], axis=1)
+    return np.ascontiguousarray(a)
+
+
+def voxelize(src, voxelSize: float, handle=None) -> np.ndarray:
+    """voxelize<T>() (reference include/quatro.hpp:49-68): pcl::VoxelGrid centroid down-sampling."""
+    return (handle or _handle()).voxelize(_as_cloud(src), float(voxelSize))
+
+
+class FPFHManager:
+    """Reference include/fpfh_manager.hpp:25-238 (front-end orchestrator)."""
+
+    def __init__(self, normal_radius: float = 0.5, fpfh_radius: float = 0.6, interval: int = 1, handle=None,
+                 seed: int = 0):
+        self.normal_radius_ = float(normal_radius)
+        self.fpfh_radius_ = float(fpfh_radius)
+        self.interval_ = interval
+        self.is_initial_ = True
+        self.is_odometry_test_ = False
+        self.corr = np.zeros((0, 2), dtype=np.int32)
+        self.src_cloud = self.tgt_cloud = None
+        self._obj = self._scene = None
+        self._src_normals = self._tgt_normals = None
+        self.src_matched = self.tgt_matched = None
+        self.tgt_normals = None
+        self._h = handle
+        self.seed = seed  # tuple-test RNG seed (the reference seeds from the clock)
+
+    def flushAllFeatures(self):
+        self.is_initial_ = True
+
+    def setParams(self, normal_radius, fpfh_radius, interval):
+        self.normal_radius_, self.fpfh_radius_, self.interval_ = float(normal_radius), float(fpfh_radius), interval
+
+    def clearInputs(self):
+        self.is_initial_ = True
+        self.src_cloud = self.tgt_cloud = self._obj = self._scene = None
+
+    def swapTgt2Src(self):
+        self.src_cloud, self._obj, self._src_normals = self.tgt_cloud, self._scene, self._tgt_normals
+
+    def setFeaturePair(self, src, target):
+        if self.normal_radius_ > self.fpfh_radius_:  # reference :99-102
+            raise ValueError("[FPFHManager]: Normal should be lower than fpfh_radius!!!!")
+        h = self._h or _handle()
+        if self.is_initial_ and not self.is_odometry_test_:
+            self.src_cloud = _as_cloud(src)
+            self._src_normals, self._obj = h.fpfh(self.src_cloud, self.normal_radius_, self.fpfh_radius_)
+            self.is_initial_ = False
+        else:
+            self.swapTgt2Src()
+        self.tgt_cloud = _as_cloud(target)
+        self._tgt_normals, self._scene = h.fpfh(self.tgt_cloud, self.normal_radius_, self.fpfh_radius_)
+        fp = _ql.default_frontend_params(normal_radius=self.normal_radius_, fpfh_radius=self.fpfh_radius_,
+                                         tuple_scale=0.95, use_crosscheck=1, use_tuple_test=1, seed=self.seed)
+        self.corr = h.match(self.src_cloud, self._obj, self.tgt_cloud, self._scene, fp)
+        self.src_matched = self.src_cloud[self.corr[:, 0], :3].astype(np.float64).T.copy()  # 3 x L, as Eigen
+        self.tgt_matched = self.tgt_cloud[self.corr[:, 1], :3].astype(np.float64).T.copy()
+        self.tgt_normals = self._tgt_normals[self.corr[:, 1], :3].astype(np.float64).T.copy()
+
+    def getSrcMatched(self):
+        return self.src_matched
+
+    def getTgtMatched(self):
+        return self.tgt_matched
+
+    def getTgtNormals(self):
+        return self.tgt_normals
+
+    def getObjDescriptor(self):
+        return self._obj
+
+    def getSceneDescriptor(self):
+        return self._scene
+
+    def getSrcKps(self) -> np.ndarray:
+        return _as_cloud(self.src_cloud[self.corr[:, 0], :3])
+
+    def getTgtKps(self) -> np.ndarray:
+        return _as_cloud(self.tgt_cloud[self.corr[:, 1], :3])
+
+    def getCorrespondences(self):
+        return [(int(a), int(b)) for a, b in self.corr]
+
+
+class Quatro:
+    """Reference include/quatro.hpp:70-1061 — the PCL-Registration-derived back-end surface."""
+
+    def __init__(self, handle=None):
+        self.reg_name_ = "Quatro"
+        self.noise_bound_ = 0.3                       # public member, used by COTE (reference :115, :601)
+        self.cost_ = float("inf")
+        self.using_pre_estimated_RyRx_ = False
+        self.estimated_RyRx_ = np.eye(3)
+        self.solution_ = RegistrationSolution()
+        self.params_ = Params()
+        self.input_ = None
+        self.target_ = None
+        self.max_iterations_ = 0
+        self._h = handle
+        self._clear()
+
+    def _clear(self):
+        self.max_clique_ = np.zeros(0, dtype=np.int32)
+        self.rotation_inliers_ = np.zeros(0, dtype=np.int32)
+        self.final_inliers_ = np.zeros(0, dtype=np.int32)
+        self.num_rot_inliers_ = 0
+        self.num_maxclique_ = 0
+
+    def getParams(self) -> Params:
+        return self.params_
+
+    def setParams(self, params: Params):
+        self.params_ = params
+
+    def setPreEstaimatedRyRx(self, estimated_RyRx):  # sic (reference :276-279)
+        self.estimated_RyRx_ = np.asarray(estimated_RyRx, dtype=np.float64)[:3, :3].copy()
+        self.using_pre_estimated_RyRx_ = True
+
+    def setInputSource(self, cloud):
+        self.input_ = _as_cloud(cloud)
+
+    def setInputTarget(self, cloud):
+        c = _as_cloud(cloud)
+        if c.shape[0] == 0:  # reference :298-302: PCL_ERROR + return
+            print("[pcl::Quatro::setInputSource] Invalid or empty point cloud dataset given!")
+            return
+        self.target_ = c
+
+    def reset(self, params: Params):
+        self.reg_name_ = params.reg_name
+        self.params_ = params
+        self._clear()
+
+    def setMaximumIterations(self, nr_iterations: int):
+        self.max_iterations_ = nr_iterations
+
+    def _c_params(self) -> "_ql.Params":
+        p = self.params_
+        if p.cote_mode not in ("median", "weighted_mean"):
+            raise ValueError("[COTE]: Wrong parameter comes!")  # reference :911
+        if self.reg_name_ != "Quatro":
+            raise ValueError("[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'")  # :410
+        cp = _ql.default_params()
+        cp.noise_bound = p.noise_bound
+        cp.cbar2 = p.cbar2
+        cp.rotation_gnc_factor = p.rotation_gnc_factor
+        cp.rotation_cost_threshold = p.rotation_cost_threshold
+        cp.kcore_heuristic_threshold = p.kcore_heuristic_threshold
+        cp.cote_noise_bound = self.noise_bound_
+        for i, v in enumerate(np.asarray(self.estimated_RyRx_, dtype=np.float64).reshape(-1)):
+            cp.ryrx[i] = float(v)
+        cp.rotation_max_iterations = int(p.rotation_max_iterations)
+        cp.inlier_selection_mode = int(p.inlier_selection_mode)
+        cp.cote_median = 1 if p.cote_mode == "median" else 0
+        cp.using_rot_inliers_when_estimating_cote = int(bool(p.using_rot_inliers_when_estimating_cote))
+        cp.using_pre_estimated_ryrx = int(bool(self.using_pre_estimated_RyRx_))
+        return cp
+
+    def computeTransformation(self, output=None):
+        """computeTransformation(Eigen::Matrix4d& output) (reference :769-936).  Returns the 4x4; when a
+        numpy array is passed it is overwritten in place — and left untouched if the clique is too small,
+        as in the reference (:809-813)."""
+        if self.input_ is None or self.target_ is None:
+            raise ValueError("input clouds not set")
+        if self.input_.shape[0] != self.target_.shape[0]:
+            raise ValueError("source and target keypoint clouds must have equal length")
+        h = self._h or _handle()
+        cp = self._c_params()
+        r = h.solve(self.input_, self.target_, cp)
+        # the reference persists params_.noise_bound *= 2/scale for later calls (:850-852)
+        self.params_.noise_bound = self.params_.noise_bound * 2.0
+        self.max_clique_ = r["clique"]
+        self.num_maxclique_ = int(r["clique"].size)
+        if not r["valid"]:
+            self.solution_.valid = False
+            return output
+        self.rotation_inliers_ = r["rot_inliers"]
+        self.num_rot_inliers_ = int(r["rot_inliers"].size)
+        self.final_inliers_ = r["final_inliers"]
+        self.cost_ = r["cost"]
+        self.solution_ = RegistrationSolution(True, 1.0, r["T"][:3, 3].copy(), r["T"][:3, :3].copy())
+        if output is None:
+            return r["T"].copy()
+        output[...] = r["T"]
+        return output
+
+    def getMaxCliques(self):
+        return self.input_[self.max_clique_], self.target_[self.max_clique_]
+
+    def getFinalInliers(self):
+        return self.input_[self.final_inliers_], self.target_[self.final_inliers_]
+
+    def getFinalInliersIndices(self):
+        return [int(i) for i in self.final_inliers_]
+
+    def getNumRotaionInliers(self) -> int:  # sic
+        return self.num_rot_inliers_
+
+    def getNumMaxCliqueInliers(self) -> int:
+        return self.num_maxclique_

@@ -88,6 +88,8 @@ void qtr_destroy(qtr_handle* h) {
     if (s.stream2) (void)hipStreamSynchronize(s.stream2);
     for (auto& e : s.ev)
       if (e) (void)hipEventDestroy(e);
+    for (auto& e : s.fb.ev_nn)
+      if (e) (void)hipEventDestroy(e);
     if (s.solver_arena) (void)hipFree(s.solver_arena);
     if (s.front_arena) (void)hipFree(s.front_arena);
     if (s.in_src) (void)hipFree(s.in_src);
@@ -110,12 +112,17 @@ static int create_impl(qtr_handle* h) {
     QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
     for (auto& e : s.ev) QTR_HIP_TRY(h, hipEventCreate(&e));
+    for (auto& e : s.fb.ev_nn) QTR_HIP_TRY(h, hipEventCreate(&e));
     const size_t sbytes = solver_scratch_bytes(h->lim.max_corr) + 65536;
     QTR_HIP_TRY(h, hipMalloc(&s.solver_arena, sbytes));
     solver_carve(s.sb, s.solver_arena, h->lim.max_corr);
     const size_t fbytes = frontend_scratch_bytes(h->lim.max_points, h->lim.max_voxels) + 65536;
     QTR_HIP_TRY(h, hipMalloc(&s.front_arena, fbytes));
-    frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
+    {
+      hipEvent_t keep[4] = {s.fb.ev_nn[0], s.fb.ev_nn[1], s.fb.ev_nn[2], s.fb.ev_nn[3]};
+      frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
+      for (int q = 0; q < 4; ++q) s.fb.ev_nn[q] = keep[q];
+    }
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_src, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_tgt, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.m_src, (size_t)h->lim.max_corr * 16));
@@ -146,6 +153,15 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   const int rc = create_impl(h);
   *out = h;  // returned even on failure so that qtr_last_error can be read; caller destroys it
   return rc;
+}
+
+static void fill_nn_times(Slot& s) {
+  float a = 0, b = 0;
+  if (hipEventElapsedTime(&a, s.fb.ev_nn[0], s.fb.ev_nn[1]) == hipSuccess &&
+      hipEventElapsedTime(&b, s.fb.ev_nn[1], s.fb.ev_nn[2]) == hipSuccess) {
+    s.times.nn_kernel = a + b;
+    s.times.nn_launches = 2;
+  }
 }
 
 static Slot* get_slot(qtr_handle* h, int slot) {
@@ -395,6 +411,7 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   float ms = 0;
   s.times = qtr_stage_times{};
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.match = s.times.total = ms;
+  fill_nn_times(s);
   return QTR_OK;
 }
 
@@ -486,6 +503,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
   if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
+  fill_nn_times(s);
   const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
   return rc;

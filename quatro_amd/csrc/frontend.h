@@ -42,6 +42,7 @@ struct FrontBufs {
   int* tgt_of_src = nullptr;   // [max_voxels]
   int* corr = nullptr;         // [max_voxels][2]
   int* mcounts = nullptr;      // 16
+  hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)
 };
 
 size_t frontend_scratch_bytes(int max_points, int max_voxels);

@@ -224,10 +224,13 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     if (s > 256) s = 256;
     return s;
   };
+  if (F.ev_nn[0]) (void)hipEventRecord(F.ev_nn[0], st);
   hipLaunchKernelGGL(k_nn_exact, dim3((n_small + 255) / 256, nsplit(n_small, n_large)), dim3(256), 0, st, Cj.fpfh,
                      n_small, Ci.fpfh, n_large, F.best_small, (const int*)nullptr, 0);
+  if (F.ev_nn[1]) (void)hipEventRecord(F.ev_nn[1], st);
   hipLaunchKernelGGL(k_nn_exact, dim3((n_large + 255) / 256, nsplit(n_large, n_small)), dim3(256), 0, st, Ci.fpfh,
                      n_large, Cj.fpfh, n_small, F.best_large, (const int*)nullptr, 0);
+  if (F.ev_nn[2]) (void)hipEventRecord(F.ev_nn[2], st);
   hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, F.nn_of_small);
   hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, F.nn_of_large);
   // K6 cross-check -> pairs in ascending i

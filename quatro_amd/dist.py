@@ -1,0 +1,65 @@
+"""Multi-GPU plumbing: independent scan pairs shard across ranks; there is no data-path collective.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).  The only
+exchange is the final gather of fixed-size result records (north_star: "RCCL over xGMI used only for the
+final gather") plus the barrier / max-over-ranks timing reduction of the bench contract.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RECORD_DOUBLES = 24  # T[16], cost, valid, n_clique, n_rot_inliers, n_final, n_corr, pair_id, pad
+
+
+def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block partition [lo, hi) of range(n_items) for `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_record(pair_id: int, res: dict) -> np.ndarray:
+    r = np.zeros(RECORD_DOUBLES, dtype=np.float64)
+    r[:16] = np.asarray(res["T"], dtype=np.float64).reshape(-1)
+    r[16] = res["cost"] if np.isfinite(res["cost"]) else -1.0
+    r[17] = float(bool(res["valid"]))
+    r[18] = len(res["clique"])
+    r[19] = res.get("n_rot_inliers", 0) or 0
+    r[20] = len(res["final_inliers"])
+    r[21] = res.get("L", 0)
+    r[22] = pair_id
+    return r
+
+
+def gather_records(local: "np.ndarray", device=None):
+    """Gathers [n_local, RECORD_DOUBLES] records from every rank onto rank 0 (all ranks must hold the same
+    n_local).  Returns the [world * n_local, RECORD_DOUBLES] array on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.cpu().numpy()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo":
+        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, out, dst=0)
+    else:  # RCCL: all_gather is the portable fixed-size collective
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+    if rank != 0:
+        return None
+    return torch.cat([o.cpu() for o in out], dim=0).numpy()
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -52,7 +52,8 @@ class Result(C.Structure):
 
 
 class StageTimes(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total")]
+    _fields_ = ([(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total",
+                                          "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
 
 
 EXPORTS = [

@@ -1,0 +1,51 @@
+"""Generates the committed fixtures under tests/golden/ from the CPU oracle (the reference itself has no
+golden vectors and cannot run here — see oracle/quatro_oracle.cpp header).  They pin the oracle against
+accidental drift and give the GPU tests inputs/outputs that do not depend on the oracle being rebuilt.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+from oracle import oracle as qo  # noqa: E402
+from quatro_amd import synth  # noqa: E402
+
+
+def main():
+    qo.set_threads(1)
+    # --- back end: 300 correspondences, 20 % inliers
+    src, tgt, T, inl = synth.correspondences(300, 0.2, seed=42, noise=0.3)
+    r = qo.solve(src, tgt)
+    bm = qo.build_graph(src, tgt)
+    core, _, mc = qo.kcore(bm)
+    np.savez_compressed(os.path.join(HERE, "solver_L300.npz"), src=src, tgt=tgt, T_gt=T, planted=inl, T=r["T"],
+                        clique=r["clique"], rot_inliers=r["rot_inliers"], final_inliers=r["final_inliers"],
+                        cost=r["cost"], gnc_iters=r["gnc_iters"], bitmap=bm, core=core, max_core=mc)
+    # --- front end: a 700-point patch of a synthetic scan
+    s, t, _ = synth.kitti64_pair(7)
+    v = qo.voxelize(s, 0.3)
+    sel = v[np.argsort(np.linalg.norm(v[:, :2] - v[100, :2], axis=1))[:700]]
+    sel = sel[np.lexsort((sel[:, 0], sel[:, 1], sel[:, 2]))].copy()
+    nrm, sp, de = qo.fpfh(sel, 0.5, 0.75)
+    raw = s[:6000].copy()
+    vox = qo.voxelize(raw, 0.3)
+    np.savez_compressed(os.path.join(HERE, "frontend_patch.npz"), cloud=sel, normals=nrm, spfh=sp, fpfh=de, raw=raw,
+                        vox=vox)
+    # --- matcher: descriptors of two overlapping patches
+    v2 = qo.voxelize(t, 0.3)
+    a = v[:900].copy()
+    b = v2[:800].copy()
+    _, _, da = qo.fpfh(a, 0.5, 0.75)
+    _, _, db = qo.fpfh(b, 0.5, 0.75)
+    corr, nn_ij, nn_ji = qo.match(a, da, b, db, seed=5, debug=True)
+    np.savez_compressed(os.path.join(HERE, "matcher_small.npz"), xyz_s=a, desc_s=da, xyz_t=b, desc_t=db, corr=corr,
+                        nn_large_of_small=nn_ij, nn_small_of_large=nn_ji, seed=5)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

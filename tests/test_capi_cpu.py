@@ -1,0 +1,112 @@
+"""No-GPU checks of the boundary: the C-ABI library builds, loads and exports every symbol that
+include/quatro_hip.h declares; the host-side mirror validates arguments like the reference; the product
+has no CPU fallback."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from quatro_amd import build as qbuild
+    return qbuild.build(force=False, verbose=False)
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    hdr = open(os.path.join(ROOT, "include", "quatro_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(qtr_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(libpath)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    from quatro_amd import lib as ql
+    assert set(ql.EXPORTS) == set(declared)
+
+
+def test_struct_layouts_match_header(libpath):
+    """ctypes mirrors must have the C sizes (checked by compiling a tiny C program against the header)."""
+    src = r'''
+#include <stdio.h>
+#include "quatro_hip.h"
+int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(qtr_limits), sizeof(qtr_params), sizeof(qtr_frontend_params),
+ sizeof(qtr_result), sizeof(qtr_stage_times)); return 0;}
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = list(map(int, subprocess.check_output([exe]).split()))
+    from quatro_amd import lib as ql
+    assert sizes == [ctypes.sizeof(ql.Limits), ctypes.sizeof(ql.Params), ctypes.sizeof(ql.FrontendParams),
+                     ctypes.sizeof(ql.Result), ctypes.sizeof(ql.StageTimes)]
+
+
+def test_defaults_match_reference_params(libpath):
+    from quatro_amd import lib as ql
+    p = ql.default_params()  # Quatro::Params defaults (reference include/quatro.hpp:202-268)
+    assert (p.noise_bound, p.cbar2, p.rotation_gnc_factor, p.rotation_max_iterations) == (0.3, 1.0, 1.4, 100)
+    assert p.rotation_cost_threshold == 1e-6 and p.inlier_selection_mode == ql.INLIER_PMC_HEU and p.cote_median == 1
+    d = ql.demo_params()  # config/params.yaml:22-44
+    assert (d.rotation_max_iterations, d.rotation_cost_threshold) == (50, 1.1e-4)
+    f = ql.default_frontend_params()
+    assert (round(f.voxel_size, 3), round(f.normal_radius, 3), round(f.fpfh_radius, 3), round(f.tuple_scale, 3)) == \
+        (0.3, 0.5, 0.75, 0.95)
+
+
+def test_no_cpu_fallback_when_library_missing(tmp_path, monkeypatch):
+    from quatro_amd import lib as ql
+    monkeypatch.setattr(ql, "_lib", None)
+    monkeypatch.setattr(ql, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ql.load()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "quatro_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"libquatro_oracle", r"\bqo_[a-z]", r"oracle[/\\]",
+                            r"#include\s+\".*oracle"):
+                    assert not re.search(pat, txt, flags=re.M), f"{f} reaches into oracle/: {pat}"
+
+
+def test_host_mirror_argument_checks():
+    from quatro_amd import api
+    fm = api.FPFHManager(0.9, 0.5)
+    with pytest.raises(ValueError, match="Normal should be lower than fpfh_radius"):
+        fm.setFeaturePair(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+    q = api.Quatro()
+    p = api.Params()
+    assert p.inlier_selection_mode == api.INLIER_SELECTION_MODE.PMC_HEU and p.cote_mode == "median"
+    q.reset(p)
+    with pytest.raises(ValueError):
+        q.computeTransformation()
+    q.setInputSource(np.zeros((5, 3), np.float32))
+    q.setInputTarget(np.zeros((0, 3), np.float32))  # prints the PCL error, keeps target unset
+    assert q.target_ is None
+    q.params_.cote_mode = "bogus"
+    with pytest.raises(ValueError, match="COTE"):
+        q._c_params()
+
+
+def test_cpp_dropin_header_compiles_against_c_abi(libpath, tmp_path):
+    """include/quatro.hpp + include/fpfh_manager.hpp (the reference's class surface over the C ABI) build with
+    plain g++ and link against libquatro_hip.so; no GPU is touched."""
+    src = os.path.join(ROOT, "tests", "cpp", "dropin_demo.cpp")
+    if not os.path.exists(src):
+        pytest.skip("C++ drop-in demo not present")
+    exe = tmp_path / "dropin_demo"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", str(exe),
+                           "-L", os.path.dirname(libpath), "-lquatro_hip", "-Wl,-rpath," + os.path.dirname(libpath),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    assert exe.exists()

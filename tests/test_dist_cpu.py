@@ -1,0 +1,62 @@
+"""The N>1 path on CPU: pair sharding, the final gather of result records and the max-over-ranks timing,
+exercised with world_size 2 over gloo (the same code runs over RCCL on the GPUs)."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_shard_range_partitions_everything():
+    from quatro_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quatro_amd import dist as qd
+    lo, hi = qd.shard_range(6, rank, world)
+    recs = []
+    for pid in range(lo, hi):
+        T = np.eye(4)
+        T[0, 3] = pid
+        recs.append(qd.pack_record(pid, {"T": T, "cost": 0.5 * pid, "valid": True, "clique": np.arange(pid + 2),
+                                         "final_inliers": np.arange(pid + 1), "L": 100 + pid, "n_rot_inliers": pid}))
+    g = qd.gather_records(np.stack(recs))
+    tmax = qd.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        q.put((g, tmax))
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_and_max_over_ranks_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert g.shape == (6, 24)
+    assert g[:, 22].tolist() == [0, 1, 2, 3, 4, 5]          # pair ids in rank order
+    assert g[:, 3].tolist() == [0, 1, 2, 3, 4, 5]           # T[0,3]
+    assert g[:, 18].tolist() == [2, 3, 4, 5, 6, 7]          # clique sizes
+    assert tmax == 2.0

@@ -1,0 +1,237 @@
+"""Parity tests proper: the HIP path (called ONLY through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed fixtures, and — at full BASELINE sizes — through size-independent
+properties.  Bar: bit-exact for integer/index outputs (inlier sets, cliques, correspondences, neighbour
+lists) and, since both sides evaluate identical IEEE operation sequences, bit-exact floats as well; the
+stated tolerance of the north star (1e-4 rad / 1e-3 m) is asserted explicitly on the transforms."""
+import os
+
+import numpy as np
+import pytest
+
+from quatro_amd import lib as ql
+from quatro_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+
+
+def _b(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _yaw(T):
+    return float(np.arctan2(T[1, 0], T[0, 0]))
+
+
+def _assert_same_solution(r, o):
+    assert r["valid"] == o["valid"]
+    assert np.array_equal(r["clique"], o["clique"])
+    assert np.array_equal(r["final_inliers"], o["final_inliers"])
+    if r["rot_inliers"] is not None and "rot_inliers" in o:
+        assert np.array_equal(r["rot_inliers"], o["rot_inliers"])
+    if r["valid"]:
+        d = _yaw(r["T"]) - _yaw(o["T"])
+        assert abs(np.arctan2(np.sin(d), np.cos(d))) <= ROT_TOL
+        assert np.abs(r["T"][:3, 3] - o["T"][:3, 3]).max() <= TRANS_TOL
+        assert np.array_equal(r["T"], o["T"])  # identical operation sequences -> identical bits
+
+
+# ---------------------------------------------------------------------------------------------- shared math
+def test_device_math_is_bit_identical_to_host(hip, qo):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.uniform(-1.2, 1.2, 300000), rng.uniform(-1e-6, 1e-6, 1000),
+                        [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    b = np.concatenate([rng.uniform(-1.2, 1.2, 300000), rng.uniform(-1e-6, 1e-6, 1000),
+                        [0.0, -0.0, -0.0, 0.0, np.inf, 1.0, 1.0]]).astype(np.float32)
+    for fn in (0, 1):
+        d, o = hip.debug_math(fn, a, b), qo.math_fn(fn, a, b)
+        assert np.all((_b(d) == _b(o)) | (np.isnan(d) & np.isnan(o)))
+    th = rng.uniform(0, 1.2, 300000).astype(np.float32)
+    for fn in (2, 3):
+        assert np.array_equal(_b(hip.debug_math(fn, th)), _b(qo.math_fn(fn, th)))
+
+
+# ---------------------------------------------------------------------------------------------- back end
+@pytest.mark.parametrize("L,frac,seed,noise", [
+    (2, 1.0, 0, 0.1), (3, 0.0, 1, 0.1), (50, 0.3, 1, 0.1), (64, 0.5, 2, 0.2), (65, 0.5, 3, 0.2), (300, 0.2, 2, 0.3),
+    (1000, 0.1, 3, 0.35), (3000, 0.0, 6, 0.1), (5000, 0.05, 4, 0.1), (5000, 0.05, 7, 0.3), (5000, 0.02, 5, 0.4),
+    (8192, 0.1, 8, 0.3), (8193, 0.03, 9, 0.3)])
+def test_solver_matches_oracle(hip, qo, L, frac, seed, noise):
+    src, tgt, T, inl = synth.correspondences(L, frac, seed, noise=noise)
+    r, o = hip.solve(src, tgt), qo.solve(src, tgt)
+    bm_g = hip.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(L, -1)
+    bm_o = qo.build_graph(src, tgt, 0.3, 1.0)
+    assert np.array_equal(bm_g, bm_o)
+    assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32), qo.kcore(bm_o)[0])
+    assert r["max_core"] == o["max_core"] and r["n_edges"] == o["n_edges"]
+    _assert_same_solution(r, o)
+    assert r["gnc_iters"] == o["gnc_iters"] and r["n_card"] == o["n_card"]
+    assert r["cost"] == o["cost"] or (np.isinf(r["cost"]) and np.isinf(o["cost"]))
+
+
+def test_solver_edge_cases(hip, qo):
+    e = np.zeros((0, 4), dtype=np.float32)
+    r = hip.solve(e, e)
+    assert not r["valid"] and r["status"] == ql.QTR_ERR_CLIQUE_TOO_SMALL
+    one, one_t, _, _ = synth.correspondences(1, 1.0, 0)
+    assert not hip.solve(one, one_t)["valid"]
+    # identical duplicated correspondences: zero-length TIMs (0/0 in the reference predicate)
+    src, tgt, _, _ = synth.correspondences(40, 0.5, 3)
+    src[5], tgt[5] = src[4], tgt[4]
+    _assert_same_solution(hip.solve(src, tgt), qo.solve(src, tgt))
+    # unsupported / invalid modes are reported, not silently changed
+    with pytest.raises(ql.QuatroHipError) as ei:
+        hip.solve(src, tgt, ql.demo_params(inlier_selection_mode=ql.INLIER_NONE))
+    assert ei.value.code == ql.QTR_ERR_UNSUPPORTED
+    with pytest.raises(ql.QuatroHipError) as ei:
+        hip.solve(src, tgt, ql.demo_params(noise_bound=-1.0))
+    assert ei.value.code == ql.QTR_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("kw", [dict(inlier_selection_mode=2, kcore_heuristic_threshold=0.05), dict(cote_median=0),
+                                dict(using_rot_inliers_when_estimating_cote=1), dict(noise_bound=0.1, cbar2=2.0),
+                                dict(rotation_max_iterations=3), dict(cote_noise_bound=0.15),
+                                dict(using_pre_estimated_ryrx=1, ryrx=[0.9998, 0, 0.02, 0, 1, 0, -0.02, 0, 0.9998])])
+def test_solver_parameter_variants(hip, qo, kw):
+    src, tgt, _, _ = synth.correspondences(800, 0.15, seed=21, noise=0.3)
+    _assert_same_solution(hip.solve(src, tgt, ql.demo_params(**kw)), qo.solve(src, tgt, qo.default_params(**kw)))
+
+
+def test_solver_fixture(hip):
+    g = np.load(os.path.join(G, "solver_L300.npz"))
+    r = hip.solve(g["src"], g["tgt"])
+    assert np.array_equal(r["clique"], g["clique"]) and np.array_equal(r["final_inliers"], g["final_inliers"])
+    assert np.array_equal(r["T"], g["T"]) and r["gnc_iters"] == int(g["gnc_iters"])
+    assert np.array_equal(hip.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(300, -1), g["bitmap"])
+    assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32), g["core"])
+
+
+def test_solver_properties_at_full_size(hip):
+    """BASELINE sizes (L = 5000 and the dense-mode L = 20000) through properties that need no oracle."""
+    for L, frac in ((5000, 0.05), (20000, 0.02)):
+        src, tgt, T, inl = synth.correspondences(L, frac, seed=77, noise=0.1)
+        r = hip.solve(src, tgt)
+        assert r["valid"]
+        bm = hip.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(L, -1)
+        C = r["clique"]
+        rows = np.unpackbits(bm[C].view(np.uint8), axis=1, bitorder="little")[:, :L][:, C]
+        assert rows.sum() == len(C) * (len(C) - 1)           # the clique is a clique of the device bitmap
+        assert set(inl).issubset(set(C))                      # planted mutually-consistent inliers recovered
+        assert set(r["final_inliers"]).issubset(set(C))
+        d = _yaw(r["T"]) - _yaw(T)
+        assert abs(np.arctan2(np.sin(d), np.cos(d))) < 5e-3 and np.linalg.norm(r["T"][:3, 3] - T[:3, 3]) < 0.15
+        # idempotence: the same call again returns the same answer
+        r2 = hip.solve(src, tgt)
+        assert np.array_equal(r2["clique"], C) and np.array_equal(r2["T"], r["T"])
+        # linearity: a rigid motion of the target composes with the estimate
+        R2 = synth.yaw_matrix(0.4)
+        tgt2 = tgt.copy()
+        tgt2[:, :3] = (tgt[:, :3].astype(np.float64) @ R2.T + np.array([1.0, -2.0, 0.5])).astype(np.float32)
+        r3 = hip.solve(src, tgt2)
+        d = _yaw(r3["T"]) - (_yaw(r["T"]) + 0.4)
+        assert abs(np.arctan2(np.sin(d), np.cos(d))) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- front end
+def test_voxelize_matches_oracle(hip, qo, small_pair):
+    s, t, _ = small_pair
+    for cloud, leaf in ((s, 0.3), (t, 0.3), (s[:777], 0.5), (s[:1], 0.3), (np.repeat(s[:1], 50, axis=0), 0.3)):
+        g, o = hip.voxelize(cloud, leaf), qo.voxelize(cloud, leaf)
+        assert g.shape == o.shape and np.array_equal(_b(g), _b(o))
+
+
+def test_voxelize_properties_full_size(hip):
+    s, t, _ = synth.kitti64_pair(11)
+    v = hip.voxelize(s, 0.3)
+    inv = np.float32(1.0) / np.float32(0.3)
+    key = np.floor(v[:, :3] * inv).astype(np.int64)
+    assert len(np.unique(key, axis=0)) == v.shape[0]       # one centroid per occupied voxel
+    mn = np.floor(s[:, :3].min(0) * inv).astype(np.int64)
+    dv = np.floor(s[:, :3].max(0) * inv).astype(np.int64) - mn + 1
+    lin = (key - mn) @ np.array([1, dv[0], dv[0] * dv[1]])
+    assert np.all(np.diff(lin) > 0)                         # ascending linear voxel index (PCL output order)
+    assert np.array_equal(_b(hip.voxelize(v, 0.3)), _b(v))  # idempotent on its own output
+
+
+def test_fpfh_matches_oracle(hip, qo, small_pair):
+    s, t, _ = small_pair
+    v = qo.voxelize(s, 0.3)
+    nrm_o, sp_o, de_o = qo.fpfh(v, 0.5, 0.75)
+    nrm_g, de_g = hip.fpfh(v, 0.5, 0.75)
+    n = v.shape[0]
+    off_o, idx_o, d2_o = qo.radius_neighbors(v, 0.75)
+    off_g = hip.debug_fetch(ql.DBG_NBR_OFFSETS, np.int32)
+    assert np.array_equal(off_g.astype(np.int64), off_o)
+    sp_g = hip.debug_fetch(ql.DBG_SPFH, np.float32).reshape(n, 33)
+    assert np.all((_b(nrm_g) == _b(nrm_o)) | (np.isnan(nrm_g) & np.isnan(nrm_o)))
+    assert np.isnan(nrm_o[:, 0]).sum() > 0                  # the NaN-normal branch is exercised
+    assert np.array_equal(_b(sp_g), _b(sp_o))
+    assert np.array_equal(_b(de_g), _b(de_o))
+
+
+def test_fpfh_fixture_and_argument_check(hip):
+    g = np.load(os.path.join(G, "frontend_patch.npz"))
+    nrm, de = hip.fpfh(g["cloud"], 0.5, 0.75)
+    assert np.all((_b(nrm) == _b(g["normals"])) | (np.isnan(nrm) & np.isnan(g["normals"])))
+    assert np.array_equal(_b(de), _b(g["fpfh"]))
+    assert np.array_equal(_b(hip.voxelize(g["raw"], 0.3)), _b(g["vox"]))
+    with pytest.raises(ql.QuatroHipError) as ei:            # reference include/fpfh_manager.hpp:99-102
+        hip.fpfh(g["cloud"], 0.9, 0.5)
+    assert ei.value.code == ql.QTR_ERR_BAD_ARG
+
+
+def test_match_matches_oracle(hip, qo, small_pair):
+    s, t, _ = small_pair
+    vs, vt = qo.voxelize(s, 0.3), qo.voxelize(t, 0.3)
+    _, _, ds = qo.fpfh(vs, 0.5, 0.75)
+    _, _, dt = qo.fpfh(vt, 0.5, 0.75)
+    for (a, da, b, db, seed) in ((vs, ds, vt, dt, 7), (vt, dt, vs, ds, 8), (vs[:500], ds[:500], vt[:2000], dt[:2000], 9)):
+        corr_g = hip.match(a, da, b, db, ql.default_frontend_params(seed=seed))
+        corr_o, nn_ij, nn_ji = qo.match(a, da, b, db, seed=seed, debug=True)
+        assert np.array_equal(hip.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32), nn_ij)
+        hit = nn_ji >= 0
+        assert np.array_equal(hip.debug_fetch(ql.DBG_NN_SMALL_OF_LARGE, np.int32)[hit], nn_ji[hit])
+        assert np.array_equal(corr_g, corr_o)
+        nt = hip.match(a, da, b, db, ql.default_frontend_params(seed=seed, use_tuple_test=0))
+        assert np.array_equal(nt, qo.match(a, da, b, db, tuple_test=False))
+
+
+def test_match_fixture(hip):
+    g = np.load(os.path.join(G, "matcher_small.npz"))
+    corr = hip.match(g["xyz_s"], g["desc_s"], g["xyz_t"], g["desc_t"], ql.default_frontend_params(seed=int(g["seed"])))
+    assert np.array_equal(corr, g["corr"])
+
+
+# ---------------------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("pair_id", [0, 1, 2])
+def test_register_pair_matches_oracle(hip, qo, pair_id):
+    s, t, Tgt = synth.kitti64_pair(pair_id)
+    r = hip.register_pair(s, t, ql.default_frontend_params(seed=pair_id))
+    o = qo.register_pair(s, t, seed=pair_id)
+    assert (r["n_src"], r["n_tgt"], r["L"]) == (o["n_src"], o["n_tgt"], o["L"])
+    _assert_same_solution(r, o)
+    d = _yaw(r["T"]) - _yaw(Tgt)
+    assert abs(np.arctan2(np.sin(d), np.cos(d))) < 0.02 and np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) < 0.3
+
+
+def test_host_mirror_reads_like_the_reference_demo(hip, qo, small_pair):
+    """examples/run_global_registration.cpp:103-108, 206-221, 243-246 through quatro_amd.api."""
+    from quatro_amd import api
+    s, t, Tgt = small_pair
+    quatro = api.Quatro(handle=hip)
+    params = api.Params(rotation_max_iterations=50, rotation_cost_threshold=1.1e-4)
+    quatro.reset(params)
+    src_feat, tgt_feat = api.voxelize(s, 0.3, handle=hip), api.voxelize(t, 0.3, handle=hip)
+    fm = api.FPFHManager(0.5, 0.75, handle=hip, seed=2)
+    fm.flushAllFeatures()
+    fm.setFeaturePair(src_feat, tgt_feat)
+    quatro.setInputSource(fm.getSrcKps())
+    quatro.setInputTarget(fm.getTgtKps())
+    out = np.eye(4)
+    quatro.computeTransformation(out)
+    o = qo.register_pair(s, t, seed=2)
+    assert quatro.solution_.valid and np.array_equal(out, o["T"])
+    assert quatro.getFinalInliersIndices() == o["final_inliers"].tolist()
+    assert quatro.getNumMaxCliqueInliers() == o["clique"].size
+    assert len(fm.getCorrespondences()) == o["L"]

@@ -1,0 +1,344 @@
+"""The oracle restates un-vendored third-party algorithms (PCL / FLANN / PMC / Eigen) and the reference has
+no golden vectors (PARITY UNPINNED).  These tests pin the oracle against INDEPENDENT
+implementations and closed-form properties instead (SURVEY.md §8c "what stands in for golden vectors")."""
+import networkx as nx
+import numpy as np
+import pytest
+
+from quatro_amd import synth
+
+
+def _cloud(n, seed, extent=6.0):
+    rng = np.random.default_rng(seed)
+    c = np.zeros((n, 4), dtype=np.float32)
+    c[:, :3] = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    c[:, 2] *= 0.2
+    return c
+
+
+def _bitmap_to_dense(bm, L):
+    bits = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :L]
+    return bits.astype(bool)
+
+
+# ------------------------------------------------------------------------------------------- K1
+def test_voxelize_matches_independent_numpy(qo):
+    rng = np.random.default_rng(0)
+    pts = np.zeros((3000, 4), dtype=np.float32)
+    pts[:, :3] = rng.normal(0, 3, (3000, 3)).astype(np.float32)
+    leaf = np.float32(0.3)
+    out = qo.voxelize(pts, float(leaf))
+    inv = np.float32(1.0) / leaf
+    mn, mx = pts[:, :3].min(0), pts[:, :3].max(0)
+    minb = np.floor(mn * inv).astype(np.int64)
+    maxb = np.floor(mx * inv).astype(np.int64)
+    div = maxb - minb + 1
+    ijk = (np.floor(pts[:, :3] * inv) - minb.astype(np.float32)).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    order = np.lexsort((np.arange(len(idx)), idx))
+    exp = []
+    i = 0
+    while i < len(order):
+        j = i
+        acc = np.zeros(3, dtype=np.float32)
+        while j < len(order) and idx[order[j]] == idx[order[i]]:
+            acc = acc + pts[order[j], :3]
+            j += 1
+        exp.append(acc / np.float32(j - i))
+        i = j
+    exp = np.array(exp, dtype=np.float32)
+    assert out.shape[0] == exp.shape[0]
+    assert np.array_equal(out[:, :3].view(np.uint32), exp.view(np.uint32))
+    # output order = ascending voxel index; every centroid lies in its voxel
+    assert np.all(out[:, 3] == 0)
+
+
+def test_voxelize_edge_cases(qo):
+    one = np.array([[1.0, 2.0, 3.0, 9.0]], dtype=np.float32)
+    assert np.array_equal(qo.voxelize(one, 0.3)[:, :3], one[:, :3])
+    dup = np.repeat(one, 7, axis=0)
+    assert qo.voxelize(dup, 0.3).shape[0] == 1
+    # leaf far too small for the extent -> PCL passes the input through
+    far = np.array([[0, 0, 0, 0], [1e5, 1e5, 1e5, 0]], dtype=np.float32)
+    assert qo.voxelize(far, 0.001).shape[0] == 2
+
+
+# ------------------------------------------------------------------------------------------- radius search
+def test_radius_neighbors_vs_bruteforce(qo):
+    c = _cloud(1200, 1)
+    off, idx, d2 = qo.radius_neighbors(c, 0.75)
+    r2 = np.float32(0.75 * 0.75)
+    p = c[:, :3]
+    for i in range(0, 1200, 37):
+        dx = p[i, 0] - p[:, 0]
+        dy = p[i, 1] - p[:, 1]
+        dz = p[i, 2] - p[:, 2]
+        dd = ((dx * dx) + dy * dy) + dz * dz  # float32, L2_Simple order
+        sel = np.nonzero(dd < r2)[0]
+        order = sel[np.lexsort((sel, dd[sel]))]
+        got = idx[off[i]:off[i + 1]]
+        assert np.array_equal(got, order)
+        assert np.array_equal(d2[off[i]:off[i + 1]].view(np.uint32), dd[order].view(np.uint32))
+        assert got[0] == i  # the query itself, distance 0
+
+
+# ------------------------------------------------------------------------------------------- K2-K4
+def test_normals_close_to_eigh_and_oriented(qo):
+    rng = np.random.default_rng(2)
+    n = 1500
+    c = np.zeros((n, 4), dtype=np.float32)
+    c[:, 0] = rng.uniform(2, 8, n)
+    c[:, 1] = rng.uniform(-3, 3, n)
+    c[:, 2] = 0.3 * c[:, 0] + 0.02 * rng.normal(size=n)  # a tilted plane
+    nrm, sp, de = qo.fpfh(c, 0.5, 0.75)
+    ok = ~np.isnan(nrm[:, 0])
+    assert ok.sum() > 0.5 * n
+    v = nrm[ok, :3]
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-4)
+    true_n = np.array([-0.3, 0, 1.0]) / np.linalg.norm([-0.3, 0, 1.0])
+    cosang = np.abs(v @ true_n)
+    assert np.median(cosang) > 0.98
+    # flipped toward the viewpoint (origin): n . (0 - p) >= 0
+    assert np.all(np.einsum("ij,ij->i", v, -c[ok, :3]) >= -1e-5)
+    # curvature = lambda0 / trace in [0, 1/3]
+    assert np.all((nrm[ok, 3] >= 0) & (nrm[ok, 3] <= 1.0 / 3 + 1e-3))
+
+
+def test_fpfh_blocks_sum_to_100(qo):
+    s, t, _ = synth.kitti64_pair(5)
+    v = qo.voxelize(s, 0.3)[:2500]
+    nrm, sp, de = qo.fpfh(v, 0.5, 0.75)
+    assert np.all(de >= 0) and np.all(np.isfinite(de))
+    blocks = de.reshape(-1, 3, 11).sum(axis=2)
+    nz = blocks > 0
+    assert np.allclose(blocks[nz], 100.0, atol=1e-2)
+    # SPFH rows: each block sums to 100 when the point has >= 1 usable neighbour
+    sb = sp.reshape(-1, 3, 11).sum(axis=2)
+    assert np.all((np.abs(sb - 100.0) < 0.05) | (sb == 0))
+
+
+def test_fpfh_rigid_motion_invariance(qo):
+    """FPFH is built from relative angles: descriptors of a rotated+translated copy stay close (float
+    rounding and the viewpoint flip aside)."""
+    rng = np.random.default_rng(3)
+    n = 800
+    c = np.zeros((n, 4), dtype=np.float32)
+    c[:, 0] = rng.uniform(10, 14, n)
+    c[:, 1] = rng.uniform(-2, 2, n)
+    c[:, 2] = 0.2 * np.sin(c[:, 0]) + 0.1 * np.cos(2 * c[:, 1])
+    _, _, d0 = qo.fpfh(c, 0.5, 0.75)
+    R = synth.yaw_matrix(0.3)
+    c2 = c.copy()
+    c2[:, :3] = (c[:, :3].astype(np.float64) @ R.T + np.array([1.0, 0.5, 0.0])).astype(np.float32)
+    _, _, d1 = qo.fpfh(c2, 0.5, 0.75)
+    assert np.median(np.abs(d0 - d1).sum(axis=1)) < 20.0  # out of 300 total mass
+
+
+# ------------------------------------------------------------------------------------------- K5-K8
+def test_nn33_vs_sklearn_and_exact_order(qo):
+    from sklearn.neighbors import NearestNeighbors
+    rng = np.random.default_rng(4)
+    A = rng.uniform(0, 100, (400, 33)).astype(np.float32)
+    B = rng.uniform(0, 100, (900, 33)).astype(np.float32)
+    got = qo.nn33(A, B)
+    ref = NearestNeighbors(n_neighbors=1, algorithm="brute").fit(B.astype(np.float64)).kneighbors(
+        A.astype(np.float64), return_distance=False)[:, 0]
+    assert (got == ref).mean() > 0.995
+    # exact flann::L2 accumulation order, float32
+    for q in range(0, 400, 41):
+        d = np.zeros(900, dtype=np.float32)
+        for g in range(8):
+            df = A[q, 4 * g:4 * g + 4][None, :] - B[:, 4 * g:4 * g + 4]
+            sq = df * df
+            d = d + (((sq[:, 0] + sq[:, 1]) + sq[:, 2]) + sq[:, 3])
+        t = A[q, 32] - B[:, 32]
+        d = d + t * t
+        assert got[q] == int(np.argmin(d))
+
+
+def test_nn33_tie_goes_to_lowest_index(qo):
+    B = np.zeros((5, 33), dtype=np.float32)
+    B[1] = 1.0
+    B[3] = 1.0  # duplicates of row 1
+    A = np.ones((1, 33), dtype=np.float32)
+    assert qo.nn33(A, B)[0] == 1
+
+
+def test_match_properties(qo):
+    s, t, _ = synth.kitti64_pair(6)
+    vs, vt = qo.voxelize(s, 0.3)[:3000], qo.voxelize(t, 0.3)[:2600]
+    _, _, ds = qo.fpfh(vs, 0.5, 0.75)
+    _, _, dt = qo.fpfh(vt, 0.5, 0.75)
+    cross = qo.match(vs, ds, vt, dt, tuple_test=False)
+    full = qo.match(vs, ds, vt, dt, seed=9)
+    full2 = qo.match(vs, ds, vt, dt, seed=9)
+    assert np.array_equal(full, full2)  # deterministic given the seed
+    # sorted lexicographically, unique, each index used at most once
+    assert np.all(np.diff(cross[:, 0]) > 0) and len(set(cross[:, 1])) == len(cross)
+    # mutual nearest neighbours
+    nn_t = qo.nn33(ds, dt)
+    nn_s = qo.nn33(dt, ds)
+    for a, b in cross[::17]:
+        assert nn_t[a] == b and nn_s[b] == a
+    # the tuple test only removes pairs
+    cs = set(map(tuple, cross))
+    assert all(tuple(p) in cs for p in full)
+    # swapped roles (larger cloud second) give the transposed answer without the tuple test
+    crossT = qo.match(vt, dt, vs, ds, tuple_test=False)
+    assert set(map(tuple, crossT[:, ::-1])) == cs
+
+
+def test_match_empty_inputs(qo):
+    e4 = np.zeros((0, 4), dtype=np.float32)
+    e33 = np.zeros((0, 33), dtype=np.float32)
+    c = _cloud(10, 0)
+    d = np.ones((10, 33), dtype=np.float32)
+    assert qo.match(e4, e33, c, d).shape[0] == 0
+
+
+# ------------------------------------------------------------------------------------------- K9-K12
+def test_graph_predicate_vs_numpy(qo):
+    src, tgt, T, inl = synth.correspondences(400, 0.2, seed=1, noise=0.3)
+    bm = qo.build_graph(src, tgt, 0.3, 1.0)
+    A = _bitmap_to_dense(bm, 400)
+    s = src[:, :3].astype(np.float64)
+    t = tgt[:, :3].astype(np.float64)
+    ds = s[None, :, :] - s[:, None, :]
+    dt = t[None, :, :] - t[:, None, :]
+    a = np.sqrt(ds[..., 0] ** 2 + (ds[..., 1] ** 2 + ds[..., 2] ** 2))
+    b = np.sqrt(dt[..., 0] ** 2 + (dt[..., 1] ** 2 + dt[..., 2] ** 2))
+    beta = 2 * 0.3 * np.sqrt(1.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fwd = np.abs(b / a - 1.0) <= beta * (1.0 / a)
+        rev = np.abs(a / b - 1.0) <= beta * (1.0 / b)
+    exp = fwd & rev
+    np.fill_diagonal(exp, False)
+    assert np.array_equal(A, exp)
+    assert np.array_equal(A, A.T)
+
+
+def test_kcore_vs_networkx(qo):
+    for seed in range(4):
+        src, tgt, _, _ = synth.correspondences(300, 0.15, seed=seed, noise=0.3)
+        bm = qo.build_graph(src, tgt)
+        A = _bitmap_to_dense(bm, 300)
+        core, order, mc = qo.kcore(bm)
+        G = nx.from_numpy_array(A.astype(int))
+        ref = nx.core_number(G)
+        assert all(core[v] == ref[v] for v in range(300))
+        assert mc == max(ref.values())
+        assert sorted(order.tolist()) == list(range(300))
+        # BZ order is a valid degeneracy order: core numbers are non-decreasing along it
+        assert np.all(np.diff(core[order]) >= 0)
+
+
+def test_clique_invariants_and_planted_recovery(qo):
+    for seed in range(5):
+        src, tgt, _, inl = synth.correspondences(600, 0.1, seed=seed, noise=0.05)
+        bm = qo.build_graph(src, tgt)
+        A = _bitmap_to_dense(bm, 600)
+        core, _, mc = qo.kcore(bm)
+        for order_mode in (0, 1):
+            C = qo.max_clique(bm, 1, 0.5, order_mode)
+            assert len(C) >= 2 and np.all(np.diff(C) > 0)
+            sub = A[np.ix_(C, C)]
+            assert sub.sum() == len(C) * (len(C) - 1)  # a clique
+            assert len(C) <= mc + 1
+            assert np.all(core[C] >= len(C) - 1)
+            # planted inliers with noise << noise bound are mutually consistent and must be found
+            assert len(set(inl) - set(C)) == 0
+        assert len(qo.max_clique(bm, 1, 0.5, 0)) == len(qo.max_clique(bm, 1, 0.5, 1))
+
+
+def test_clique_degenerate_graphs(qo):
+    # no edges -> empty clique
+    bm = np.zeros((10, 1), dtype=np.uint64)
+    assert qo.max_clique(bm).size == 0
+    # a single edge
+    bm[2, 0] = 1 << 7
+    bm[7, 0] = 1 << 2
+    assert qo.max_clique(bm).tolist() == [2, 7]
+
+
+# ------------------------------------------------------------------------------------------- K14-K15
+def test_rotation_closed_form_matches_svd(qo):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        M = 64
+        X = rng.normal(size=(M, 2))
+        th = rng.uniform(-np.pi, np.pi)
+        Rt = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        Y = X @ Rt.T + 0.01 * rng.normal(size=(M, 2))
+        R, cost, iters, inl = qo.gnc_rotation2d(X, Y, 10.0, max_iter=1)  # one iteration = plain weighted fit
+        H = X.T @ Y  # X W Y^T with W = I (2 x 2)
+        U, S, Vt = np.linalg.svd(H)
+        V = Vt.T
+        if np.linalg.det(U) * np.linalg.det(V) < 0:
+            V[:, 1] *= -1
+        Rs = V @ U.T  # svdRot2d, reference include/teaser/utils.h:151-166
+        assert np.abs(R - Rs).max() < 1e-12
+        assert abs(np.arctan2(R[1, 0], R[0, 0]) - th) < 0.01
+
+
+def test_gnc_rejects_outliers(qo):
+    rng = np.random.default_rng(6)
+    M = 200
+    X = rng.uniform(-20, 20, (M, 2))
+    th = 0.7
+    Rt = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    Y = X @ Rt.T + rng.uniform(-0.05, 0.05, (M, 2))
+    out = rng.choice(M, 60, replace=False)
+    Y[out] = rng.uniform(-20, 20, (60, 2))
+    R, cost, iters, inl = qo.gnc_rotation2d(X, Y, 0.6)
+    assert abs(np.arctan2(R[1, 0], R[0, 0]) - th) < 2e-3
+    assert inl.sum() >= M - 60 - 2 and not inl[out].all()
+    assert 1 < iters <= 50 and np.isfinite(cost)
+
+
+def test_cote_majority_and_median(qo):
+    rng = np.random.default_rng(7)
+    X = np.concatenate([3.0 + rng.uniform(-0.2, 0.2, 80), rng.uniform(-30, 30, 40)])
+    est, inl, ncard = qo.cote_estimate(X, 0.3, True)
+    assert abs(est - 3.0) < 0.1 and inl[:80].all() and ncard >= 80
+    est_w, inl_w, _ = qo.cote_estimate(X, 0.3, False)
+    assert abs(est_w - 3.0) < 0.1
+    # two measurements: defined behaviour (reference indexes out of range for n_card == 1)
+    est2, inl2, nc2 = qo.cote_estimate(np.array([0.0, 10.0]), 0.3, True)
+    assert np.isfinite(est2) and nc2 == 1
+
+
+# ------------------------------------------------------------------------------------------- whole back end
+@pytest.mark.parametrize("L,frac,noise", [(200, 0.3, 0.1), (1000, 0.1, 0.3), (2000, 0.05, 0.2)])
+def test_solve_recovers_planted_transform(qo, L, frac, noise):
+    src, tgt, T, inl = synth.correspondences(L, frac, seed=L, noise=noise)
+    r = qo.solve(src, tgt)
+    assert r["valid"] and r["status"] == 0
+    yaw = np.arctan2(r["T"][1, 0], r["T"][0, 0])
+    yaw_gt = np.arctan2(T[1, 0], T[0, 0])
+    assert abs(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt))) < 0.02
+    assert np.linalg.norm(r["T"][:3, 3] - T[:3, 3]) < 0.35
+    assert set(r["final_inliers"]).issubset(set(r["clique"]))
+    assert np.allclose(r["T"][2, :3], [0, 0, 1]) and np.allclose(r["T"][3], [0, 0, 0, 1])
+    assert abs(np.linalg.det(r["T"][:3, :3]) - 1) < 1e-12
+
+
+def test_solve_soft_failure_and_modes(qo):
+    src, tgt, _, _ = synth.correspondences(1, 1.0, seed=0)
+    r = qo.solve(src, tgt)
+    assert not r["valid"] and r["status"] == 1
+    src, tgt, _, _ = synth.correspondences(300, 0.2, seed=3)
+    assert qo.solve(src, tgt, qo.default_params(inlier_selection_mode=3))["status"] == 2
+    rk = qo.solve(src, tgt, qo.default_params(inlier_selection_mode=2, kcore_heuristic_threshold=0.1))
+    assert rk["valid"]
+    rw = qo.solve(src, tgt, qo.default_params(cote_median=0))
+    assert rw["valid"]
+
+
+def test_register_pair_end_to_end(qo, small_pair):
+    s, t, Tgt = small_pair
+    r = qo.register_pair(s, t, seed=2)
+    assert r["valid"] and r["L"] > 50
+    yaw = np.arctan2(r["T"][1, 0], r["T"][0, 0])
+    yaw_gt = np.arctan2(Tgt[1, 0], Tgt[0, 0])
+    assert abs(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt))) < 0.02
+    assert np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) < 0.3
