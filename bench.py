@@ -144,6 +144,11 @@ def main() -> None:
         },
         "stage_ms": {k: round(v / args.steps, 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
     }
+    if args.workload == "kitti64_pair":
+        ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
+        out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]
+        out["config"]["nn_rows_pair_compare"] = [int(ms[10]), int(ms[11])]
+        out["config"]["n_cross_checked"] = int(ms[3])
     yaw_gt = float(np.arctan2(p0["Tgt"][1, 0], p0["Tgt"][0, 0]))
     yaw = float(np.arctan2(r0["T"][1, 0], r0["T"][0, 0]))
     out["accuracy_vs_ground_truth"] = {

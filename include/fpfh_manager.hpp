@@ -1,0 +1,108 @@
+// fpfh_manager.hpp — drop-in for url-kaist/Quatro's include/fpfh_manager.hpp (class FPFHManager, :25-238):
+// normals + FPFH for both clouds, reciprocal matching, matched key-point clouds — all on the GPU through
+// the C ABI (qtr_fpfh, qtr_match).  The ROS / PCD-cache members of the reference class (saveFeaturePair,
+// loadFeaturePair) are I/O around the path and are not part of this back end.
+#ifndef FPFH_MANAGER_H
+#define FPFH_MANAGER_H
+
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "quatro.hpp"
+
+#ifndef QUATRO_POINT_TYPE_DEFINED
+#define QUATRO_POINT_TYPE_DEFINED
+typedef pcl::PointXYZ PointType;  // reference include/utility.h:50
+#endif
+
+class FPFHManager {
+ public:
+  double normal_radius_ = 0.5;
+  double fpfh_radius_ = 0.6;
+  bool is_initial_ = true;
+  bool is_odometry_test_ = false;
+  int interval_ = 1;
+  unsigned long long seed_ = 0;              // tuple-test RNG seed (the reference seeds with time(NULL))
+  std::vector<std::pair<int, int>> corr;     // correspondences (src index, tgt index)
+  pcl::PointCloud<PointType> src_matched_pcl, tgt_matched_pcl;
+
+  FPFHManager(double normal_radius, double fpfh_radius, int interval = 1)
+      : normal_radius_(normal_radius), fpfh_radius_(fpfh_radius), interval_(interval) {}
+  FPFHManager() {}
+
+  void flushAllFeatures() { is_initial_ = true; }
+  void setParams(float normal_radius, float fpfh_radius, int interval) {
+    normal_radius_ = normal_radius;
+    fpfh_radius_ = fpfh_radius;
+    interval_ = interval;
+  }
+  void clearInputs() {
+    is_initial_ = true;
+    src_cloud_.clear();
+    tgt_cloud_.clear();
+    obj_desc_.clear();
+    scene_desc_.clear();
+  }
+  void swapTgt2Src() {
+    src_cloud_ = tgt_cloud_;
+    obj_desc_ = scene_desc_;
+  }
+
+  // reference :98-153
+  void setFeaturePair(QUATRO_SHARED_PTR<pcl::PointCloud<PointType>> src,
+                      QUATRO_SHARED_PTR<pcl::PointCloud<PointType>> target) {
+    if (normal_radius_ > fpfh_radius_)
+      throw std::invalid_argument("[FPFHManager]: Normal should be lower than fpfh_radius!!!!");  // :99-102
+    qtr_handle* h = quatro_hip::default_handle();
+    if (is_initial_ && !is_odometry_test_) {
+      src_cloud_ = src->points;
+      compute(h, src_cloud_, obj_desc_);
+      is_initial_ = false;
+    } else {
+      swapTgt2Src();
+    }
+    tgt_cloud_ = target->points;
+    compute(h, tgt_cloud_, scene_desc_);
+    qtr_frontend_params fp;
+    qtr_default_frontend_params(&fp);
+    fp.normal_radius = static_cast<float>(normal_radius_);
+    fp.fpfh_radius = static_cast<float>(fpfh_radius_);
+    fp.tuple_scale = 0.95f;  // calculateCorrespondences(..., true, true, true, 0.95), reference :126-127
+    fp.seed = seed_;
+    const int ns = static_cast<int>(src_cloud_.size()), nt = static_cast<int>(tgt_cloud_.size());
+    std::vector<int> c2(2 * static_cast<size_t>(ns < nt ? ns : nt) + 2);
+    int L = 0;
+    quatro_hip::check(h, qtr_match(h, 0, quatro_hip::xyz4(src_cloud_), ns, obj_desc_.data(), quatro_hip::xyz4(tgt_cloud_),
+                                   nt, scene_desc_.data(), &fp, c2.data(), static_cast<int>(c2.size() / 2), &L,
+                                   QTR_MEM_HOST));
+    corr.clear();
+    src_matched_pcl.clear();
+    tgt_matched_pcl.clear();
+    for (int i = 0; i < L; ++i) {
+      corr.emplace_back(c2[2 * i], c2[2 * i + 1]);
+      const PointType& a = src_cloud_[static_cast<size_t>(c2[2 * i])];
+      const PointType& b = tgt_cloud_[static_cast<size_t>(c2[2 * i + 1])];
+      src_matched_pcl.push_back(PointType(a.x, a.y, a.z));
+      tgt_matched_pcl.push_back(PointType(b.x, b.y, b.z));
+    }
+  }
+
+  pcl::PointCloud<PointType> getSrcKps() { return src_matched_pcl; }          // :172-174
+  pcl::PointCloud<PointType> getTgtKps() { return tgt_matched_pcl; }          // :175-177
+  std::vector<std::pair<int, int>> getCorrespondences() { return corr; }      // :234
+  const std::vector<float>& getObjDescriptor() const { return obj_desc_; }    // n x 33, row-major
+  const std::vector<float>& getSceneDescriptor() const { return scene_desc_; }
+
+ private:
+  void compute(qtr_handle* h, const std::vector<PointType>& cloud, std::vector<float>& desc) {
+    desc.assign(33 * cloud.size(), 0.f);
+    quatro_hip::check(h, qtr_fpfh(h, 0, quatro_hip::xyz4(cloud), static_cast<int>(cloud.size()),
+                                  static_cast<float>(normal_radius_), static_cast<float>(fpfh_radius_), nullptr,
+                                  desc.data(), QTR_MEM_HOST));
+  }
+  std::vector<PointType> src_cloud_, tgt_cloud_;
+  std::vector<float> obj_desc_, scene_desc_;
+};
+
+#endif  // FPFH_MANAGER_H

@@ -170,7 +170,9 @@ int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 #define QTR_DBG_VOX_SRC 10       /* float4[n_src] voxelised source of the last qtr_register_pair */
 #define QTR_DBG_VOX_TGT 11
 #define QTR_DBG_CORR 12          /* int32[L][2] */
-#define QTR_DBG_MATCH_STATS 13   /* int32[4]: rows needing exact re-check (dir 0, dir 1), n_cross, n_tuple_pass */
+#define QTR_DBG_MATCH_STATS 13   /* int32[16]: [0] L, [3] cross-checked pairs, [4] tuple-test survivors, [5] swapped,
+                                    [8],[9] rows sent to the exact NN re-check (dir 0/1), [10],[11] rows settled by the
+                                    two-candidate exact compare */
 long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
 
 /* Evaluates the shared deterministic math (include/qtr_math.h) ON THE DEVICE, for the test that pins

@@ -158,7 +158,7 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
 static void fill_nn_times(Slot& s) {
   float a = 0, b = 0;
   if (hipEventElapsedTime(&a, s.fb.ev_nn[0], s.fb.ev_nn[1]) == hipSuccess &&
-      hipEventElapsedTime(&b, s.fb.ev_nn[1], s.fb.ev_nn[2]) == hipSuccess) {
+      hipEventElapsedTime(&b, s.fb.ev_nn[2], s.fb.ev_nn[3]) == hipSuccess) {
     s.times.nn_kernel = a + b;
     s.times.nn_launches = 2;
   }

@@ -8,7 +8,8 @@
 // per-cloud device counters (CloudBufs::counts, 16 ints)
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
 // matcher device counters (FrontBufs::mcounts, 16 ints)
-enum { MC_NCORR = 0, MC_RECHECK0 = 1, MC_RECHECK1 = 2, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5 };
+// MC_RECHECKx: rows sent to the exact re-check; MC_RECHECKx + 2: rows settled by the two-candidate exact compare
+enum { MC_NCORR = 0, MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5 };
 
 struct CloudBufs {
   int* counts = nullptr;       // 16
@@ -24,7 +25,13 @@ struct CloudBufs {
   int* nbr_off = nullptr;      // [max_voxels+1] CSR view (exclusive scan of nbr_cnt) for inspection
   int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
   float* nbr_d2 = nullptr;     // [max_voxels][QTR_KMAX]
+  float4* spts = nullptr;      // [max_voxels] points in cell-sorted order, w = original index
+  int* ranges = nullptr;       // [max_voxels][9][2] candidate key ranges
   float* mean = nullptr;       // 4 floats: sequential float mean of the cloud (Matcher::normalizePoints)
+  float* baseT = nullptr;      // [34][n_pad] k-major descriptors + |b|^2 row   (MFMA streamed operand)
+  float* queryT = nullptr;     // [34][n_pad] -2*descriptor + ones row            (MFMA stationary operand)
+  float* norms = nullptr;      // [max_voxels] |desc|^2
+  u32* max_norm = nullptr;     // 1: bits of the largest |desc|^2
 };
 
 struct FrontBufs {
@@ -42,6 +49,9 @@ struct FrontBufs {
   int* tgt_of_src = nullptr;   // [max_voxels]
   int* corr = nullptr;         // [max_voxels][2]
   int* mcounts = nullptr;      // 16
+  void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
+  int* recheck_rows = nullptr; // [max_voxels]
+  int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
   hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)
 };
 

@@ -8,6 +8,8 @@
 // organised around coalesced 16-byte point loads, LDS staging and wave-level (ballot / shuffle)
 // compaction.  kd-trees are replaced by a sort-based uniform grid (cell = search radius): points are
 // sorted by packed cell key and a query scans 9 contiguous key ranges.
+#include <stdlib.h>
+
 #include "common.h"
 #include "frontend.h"
 
@@ -51,12 +53,24 @@ __global__ __launch_bounds__(256) void k_minmax(const float4* __restrict__ pts, 
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
     }
   }
+  __shared__ float red[4][6];
+  const int wave = threadIdx.x >> 6;
   if (qk_lane() == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(&mm[a], enc_f32(mn[a]));
-      atomicMax(&mm[3 + a], enc_f32(mx[a]));
+      red[wave][a] = mn[a];
+      red[wave][3 + a] = mx[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int w = 1; w < 4; ++w) v = (a < 3) ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    if (a < 3)
+      atomicMin(&mm[a], enc_f32(v));
+    else
+      atomicMax(&mm[a], enc_f32(v));
   }
 }
 
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256) void k_vox_centroids(const u64* __restrict__ k
 hipError_t voxelize_enqueue(FrontBufs& F, CloudBufs& C, const float4* in, int P, float leaf, hipStream_t st) {
   hipLaunchKernelGGL(k_cloud_init, dim3(1), dim3(64), 0, st, C.counts, C.mm);
   const int g = min(1024, (P + 255) / 256);
-  hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, st, in, P, C.mm);
+  hipLaunchKernelGGL(k_minmax, dim3(min(g, 128)), dim3(256), 0, st, in, P, C.mm);
   hipLaunchKernelGGL(k_vox_keys, dim3(g), dim3(256), 0, st, in, P, leaf, C.mm, C.keys_a, C.counts);
   u64* sorted = nullptr;
   hipError_t e = radix_sort_u64_hi(C.keys_a, C.keys_b, C.hist, P, 32, st, &sorted);
@@ -351,66 +365,97 @@ __device__ __forceinline__ int lower_bound_hi(const u64* keys, int n, u32 k) {  
   return lo;
 }
 
+// points gathered into cell-sorted order (w carries the original index) so that candidate loads are
+// contiguous 16-byte reads instead of a dependent key -> point gather
+__global__ __launch_bounds__(256) void k_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted,
+                                                       int n, float4* __restrict__ spts) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const u32 j = (u32)sorted[t];
+    float4 p = pts[j];
+    p.w = __uint_as_float(j);
+    spts[t] = p;
+  }
+}
+
+// the nine contiguous key ranges (rows cy-1..cy+1 x cz-1..cz+1, cells cx-1..cx+1) of every query point:
+// one thread per (point, range) so the binary searches of the whole cloud overlap
+__global__ __launch_bounds__(256) void k_ranges(const float4* __restrict__ pts, int n, const u64* __restrict__ sorted,
+                                                const u32* __restrict__ mm, float cell, int* __restrict__ ranges) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * 9) return;
+  const int i = g / 9, r = g - i * 9;
+  CellGrid cg;
+  cg.mn[0] = dec_f32(mm[0]);
+  cg.mn[1] = dec_f32(mm[1]);
+  cg.mn[2] = dec_f32(mm[2]);
+  cg.cell = cell;
+  int c[3];
+  cell_of(cg, pts[i], c);
+  const int cy = c[1] + (r % 3) - 1, cz = c[2] + (r / 3) - 1;
+  int s = 0, e = 0;
+  if (cy >= 0 && cy <= 255 && cz >= 0 && cz <= 255) {
+    const u32 klo = cell_key(max(c[0] - 1, 0), cy, cz), khi = cell_key(min(c[0] + 1, 255), cy, cz);
+    s = lower_bound_hi(sorted, n, klo);
+    e = lower_bound_hi(sorted, n, khi + 1u);
+  }
+  ranges[2 * g] = s;
+  ranges[2 * g + 1] = e;
+}
+
 // one wavefront (= one workgroup) per query point
-__global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts, int n, const u64* __restrict__ sorted,
-                                                  const u32* __restrict__ mm, float cell, float r2,
+__global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts, int n, const float4* __restrict__ spts,
+                                                  const int* __restrict__ ranges, float r2,
                                                   int* __restrict__ nbr_cnt, int* __restrict__ nbr_idx,
                                                   float* __restrict__ nbr_d2, int* __restrict__ counts) {
   __shared__ u64 buf[QTR_KMAX];
-  __shared__ int rs[9], re[9];
+  __shared__ int rs[9], pre[10];
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
   const float4 p = pts[i];
-  CellGrid g;
-  g.mn[0] = dec_f32(mm[0]);
-  g.mn[1] = dec_f32(mm[1]);
-  g.mn[2] = dec_f32(mm[2]);
-  g.cell = cell;
-  int c[3];
-  cell_of(g, p, c);
-  if (lane < 9) {
-    const int cy = c[1] + (lane % 3) - 1, cz = c[2] + (lane / 3) - 1;
-    int s = 0, e = 0;
-    if (cy >= 0 && cy <= 255 && cz >= 0 && cz <= 255) {
-      const u32 klo = cell_key(max(c[0] - 1, 0), cy, cz), khi = cell_key(min(c[0] + 1, 255), cy, cz);
-      s = lower_bound_hi(sorted, n, klo);
-      e = lower_bound_hi(sorted, n, khi + 1u);
+  {
+    int len = 0, s = 0;
+    if (lane < 9) {
+      s = ranges[18 * i + 2 * lane];
+      len = ranges[18 * i + 2 * lane + 1] - s;
+      rs[lane] = s;
     }
-    rs[lane] = s;
-    re[lane] = e;
+    int tot;
+    const int ex = wave_excl_scan_i32(len, &tot);
+    if (lane < 9) pre[lane] = ex;
+    if (lane == 9) pre[9] = tot;
   }
   __syncthreads();
+  const int total = pre[9];
   int k = 0;
   bool overflow = false;
-  for (int r = 0; r < 9; ++r) {
-    const int s = rs[r], e = re[r];
-    for (int t0 = s; t0 < e; t0 += 64) {
-      const int t = t0 + lane;
-      bool ok = false;
-      u64 key = 0;
-      if (t < e) {
-        const u32 j = (u32)sorted[t];
-        const float4 q = pts[j];
-        float d2 = 0.f, d;
-        d = p.x - q.x;
-        d2 += d * d;
-        d = p.y - q.y;
-        d2 += d * d;
-        d = p.z - q.z;
-        d2 += d * d;
-        ok = d2 < r2;
-        key = ((u64)__float_as_uint(d2) << 32) | j;
-      }
-      const u64 bal = __ballot(ok);
-      if (ok) {
-        const int pos = k + __popcll(bal & lanemask_lt());
-        if (pos < QTR_KMAX)
-          buf[pos] = key;
-        else
-          overflow = true;
-      }
-      k += __popcll(bal);
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    bool ok = false;
+    u64 key = 0;
+    if (c < total) {
+      int r = 0;
+#pragma unroll
+      for (int q = 1; q < 9; ++q) r += (c >= pre[q]);
+      const float4 qp = spts[rs[r] + (c - pre[r])];
+      float d2 = 0.f, d;
+      d = p.x - qp.x;
+      d2 += d * d;
+      d = p.y - qp.y;
+      d2 += d * d;
+      d = p.z - qp.z;
+      d2 += d * d;
+      ok = d2 < r2;
+      key = ((u64)__float_as_uint(d2) << 32) | __float_as_uint(qp.w);
     }
+    const u64 bal = __ballot(ok);
+    if (ok) {
+      const int pos = k + __popcll(bal & lanemask_lt());
+      if (pos < QTR_KMAX)
+        buf[pos] = key;
+      else
+        overflow = true;
+    }
+    k += __popcll(bal);
   }
   if (__ballot(overflow) || k > QTR_KMAX) {
     if (lane == 0) {
@@ -422,7 +467,7 @@ __global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts
   int n2 = 64;
   while (n2 < k) n2 <<= 1;
   for (int t = k + lane; t < n2; t += 64) buf[t] = ~0ULL;
-  // bitonic sort of n2 (<= 256) packed keys in LDS
+  // bitonic sort of n2 (<= 256) packed keys in LDS: ascending (d2, index)
   for (int kk = 2; kk <= n2; kk <<= 1) {
     for (int j = kk >> 1; j > 0; j >>= 1) {
       __syncthreads();
@@ -445,11 +490,7 @@ __global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts
     nbr_idx[(size_t)i * QTR_KMAX + t] = (int)(u32)key;
     nbr_d2[(size_t)i * QTR_KMAX + t] = __uint_as_float((u32)(key >> 32));
   }
-  if (lane == 0) {
-    nbr_cnt[i] = k;
-    atomicAdd(&counts[CNT_NBR_TOTAL], k);
-    atomicMax(&counts[CNT_KMAX], k);
-  }
+  if (lane == 0) nbr_cnt[i] = k;  // (no per-point global atomics: one hot address caps at ~90 updates/us)
 }
 
 // =================================================================================================
@@ -735,34 +776,62 @@ __global__ __launch_bounds__(64) void k_fpfh(const float* __restrict__ spfh, int
 }
 
 // Matcher::normalizePoints mean (reference src/teaser_utils/feature_matcher.cc:27-36): a plain
-// sequential float sum over the cloud, one lane per component.
-__global__ __launch_bounds__(64) void k_seq_mean(const float4* __restrict__ pts, int n, float* __restrict__ mean) {
-  const int lane = threadIdx.x;
-  if (lane >= 3) return;
-  const float* base = (const float*)pts + lane;
+// sequential float sum over the cloud.  The additions form one dependent chain per component (float
+// addition is not associative, and the oracle defines the sequential order), so three lanes do them —
+// but out of LDS: the other waves of the workgroup stream the cloud into a double-buffered SoA tile
+// with coalesced 16-byte loads while the chain runs, which removes the HBM/L2 latency from the chain.
+#define MEAN_CHUNK 2048
+__global__ __launch_bounds__(256) void k_seq_mean(const float4* __restrict__ pts, int n, float* __restrict__ mean) {
+  __shared__ float buf[2][3][MEAN_CHUNK];
+  const int tid = threadIdx.x;
+  const int nchunks = (n + MEAN_CHUNK - 1) / MEAN_CHUNK;
+  // loaders: `nld` threads starting at `first` cover one chunk with coalesced float4 loads
+  auto load_chunk = [&](int c, int slot, int first, int nld) {
+    const int base = c * MEAN_CHUNK;
+    for (int t = tid - first; t < MEAN_CHUNK; t += nld) {
+      const int i = base + t;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n) p = pts[i];
+      buf[slot][0][t] = p.x;
+      buf[slot][1][t] = p.y;
+      buf[slot][2][t] = p.z;
+    }
+  };
   float m = 0.f;
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    const float a0 = base[4 * (i + 0)], a1 = base[4 * (i + 1)], a2 = base[4 * (i + 2)], a3 = base[4 * (i + 3)];
-    const float a4 = base[4 * (i + 4)], a5 = base[4 * (i + 5)], a6 = base[4 * (i + 6)], a7 = base[4 * (i + 7)];
-    m = m + a0;
-    m = m + a1;
-    m = m + a2;
-    m = m + a3;
-    m = m + a4;
-    m = m + a5;
-    m = m + a6;
-    m = m + a7;
+  if (nchunks > 0) load_chunk(0, 0, 0, 256);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int slot = c & 1;
+    if (tid >= 64) {  // waves 1..3 prefetch the next chunk while wave 0 runs the chain
+      if (c + 1 < nchunks) load_chunk(c + 1, slot ^ 1, 64, 192);
+    } else if (tid < 3) {
+      const int cnt = min(MEAN_CHUNK, n - c * MEAN_CHUNK);
+      const float* b = buf[slot][tid];
+      int t = 0;
+      for (; t + 8 <= cnt; t += 8) {
+        const float a0 = b[t], a1 = b[t + 1], a2 = b[t + 2], a3 = b[t + 3];
+        const float a4 = b[t + 4], a5 = b[t + 5], a6 = b[t + 6], a7 = b[t + 7];
+        m = m + a0;
+        m = m + a1;
+        m = m + a2;
+        m = m + a3;
+        m = m + a4;
+        m = m + a5;
+        m = m + a6;
+        m = m + a7;
+      }
+      for (; t < cnt; ++t) m = m + b[t];
+    }
+    __syncthreads();
   }
-  for (; i < n; ++i) m = m + base[4 * i];
-  mean[lane] = m / (float)n;
+  if (tid < 3) mean[tid] = m / (float)n;
 }
 
 hipError_t fpfh_enqueue(FrontBufs& F, CloudBufs& C, int n, float r_normal, float r_fpfh, hipStream_t st) {
   // grid over the cloud (bounding box, cell keys, sort)
   hipLaunchKernelGGL(k_cloud_init, dim3(1), dim3(64), 0, st, C.counts + 8, C.mm);  // keeps counts[0..7]
   const int g = min(1024, (n + 255) / 256);
-  hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, st, C.vox, n, C.mm);
+  hipLaunchKernelGGL(k_minmax, dim3(min(g, 128)), dim3(256), 0, st, C.vox, n, C.mm);
   const float cell = r_fpfh * 1.001f;
   hipLaunchKernelGGL(k_cell_keys, dim3(g), dim3(256), 0, st, C.vox, n, C.mm, cell, C.keys_a);
   u64* sorted = nullptr;
@@ -770,14 +839,17 @@ hipError_t fpfh_enqueue(FrontBufs& F, CloudBufs& C, int n, float r_normal, float
   if (e != hipSuccess) return e;
   const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
   const float rn2 = (float)((double)r_normal * (double)r_normal);
-  hipLaunchKernelGGL(k_neighbors, dim3(n), dim3(64), 0, st, C.vox, n, sorted, C.mm, cell, r2, C.nbr_cnt, C.nbr_idx,
+  int* ranges = C.ranges;
+  hipLaunchKernelGGL(k_sorted_points, dim3(g), dim3(256), 0, st, C.vox, sorted, n, C.spts);
+  hipLaunchKernelGGL(k_ranges, dim3((9 * n + 255) / 256), dim3(256), 0, st, C.vox, n, sorted, C.mm, cell, ranges);
+  hipLaunchKernelGGL(k_neighbors, dim3(n), dim3(64), 0, st, C.vox, n, C.spts, ranges, r2, C.nbr_cnt, C.nbr_idx,
                      C.nbr_d2, C.counts);
   hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, C.nbr_cnt, C.nbr_off, n);
   hipLaunchKernelGGL(k_normals, dim3((n + 255) / 256), dim3(256), 0, st, C.vox, n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2,
                      C.normals);
   hipLaunchKernelGGL(k_spfh, dim3(n), dim3(64), 0, st, C.vox, C.normals, n, C.nbr_cnt, C.nbr_idx, C.spfh);
   hipLaunchKernelGGL(k_fpfh, dim3(n), dim3(64), 0, st, C.spfh, n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
-  hipLaunchKernelGGL(k_seq_mean, dim3(1), dim3(64), 0, st, C.vox, n, C.mean);
+  hipLaunchKernelGGL(k_seq_mean, dim3(1), dim3(256), 0, st, C.vox, n, C.mean);
   return hipGetLastError();
 }
 
@@ -790,7 +862,11 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)(256 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 4096) * 4 + 65536;  // hist
   per_cloud += (size_t)max_voxels * 4 * 2 + 64;              // nbr_cnt, nbr_off
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
+  per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
   size_t shared = (size_t)max_voxels * 64 + 16384;
+  const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
+  per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
+  shared += vpad * 32 * 16 + (size_t)max_voxels * 4 + 1024;           // nn_partial, recheck_rows
   return 2 * per_cloud + shared + 64 * 256;
 }
 
@@ -819,6 +895,13 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);
     C.nbr_d2 = (float*)take((size_t)max_voxels * QTR_KMAX * 4);
+    C.spts = (float4*)take((size_t)max_voxels * 16);
+    C.ranges = (int*)take((size_t)max_voxels * 18 * 4);
+    const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
+    C.baseT = (float*)take(34 * vpad * 4);
+    C.queryT = (float*)take(34 * vpad * 4);
+    C.norms = (float*)take((size_t)max_voxels * 4);
+    C.max_norm = (u32*)take(64);
   }
   F.best_small = (u64*)take((size_t)max_voxels * 8);
   F.best_large = (u64*)take((size_t)max_voxels * 8);
@@ -832,6 +915,12 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.tgt_of_src = (int*)take((size_t)max_voxels * 4);
   F.corr = (int*)take((size_t)max_voxels * 8);
   F.mcounts = (int*)take(16 * 4);
+  F.nn_partial = take((((size_t)max_voxels + 511) / 512 * 512) * 32 * 16);
+  F.recheck_rows = (int*)take((size_t)max_voxels * 4);
+  {
+    const char* e = getenv("QTR_NN_ENGINE");
+    F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : 1;
+  }
 }
 
 hipError_t frontend_init_attributes() { return hipSuccess; }

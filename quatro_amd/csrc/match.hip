@@ -29,6 +29,19 @@ __device__ __forceinline__ float l2_flann33(const float* a, const float* b /* LD
   return result;
 }
 
+__device__ __forceinline__ float l2_flann33_g(const float* a, const float* __restrict__ b /* global row */) {
+  float result = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
+                d3 = a[4 * g + 3] - b[4 * g + 3];
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  const float d = a[32] - b[32];
+  result += d * d;
+  return result;
+}
+
 __global__ void k_fill_u64(u64* p, int n, u64 v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
@@ -77,6 +90,222 @@ __global__ void k_nn_unpack(const u64* __restrict__ best, int n, int* __restrict
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u64 b = best[i];
     nn[i] = (b == ~0ULL) ? 0 : (int)(u32)b;
+  }
+}
+
+// =================================================================================================
+// MFMA engine.  d~(a,b) = |a|^2 + (|b|^2 - 2 a.b): the bracket is ONE f32 MFMA chain over K = 34
+// (33 descriptor bins + one slot carrying |b|^2 against a constant 1), issued as 17 x
+// v_mfma_f32_32x32x2_f32.  The streamed operand is the BASE cloud (M side, 32 rows per tile), the
+// stationary operand the QUERIES (N side): in the 32x32 accumulator layout a lane owns ONE query column
+// (col = lane & 31) and 16 base rows, so the running best / second-best per query live in that lane's
+// registers and no cross-lane reduction is needed until the very end.  Descriptors are pre-transposed
+// to k-major ([34][n_pad]) so every fragment load is two coalesced 128-byte segments; no LDS at all.
+// A query's approximate winner is accepted only when second-best - best exceeds twice a rigorous
+// rounding bound; otherwise the row is re-decided by k_nn_exact (bit-identical tables either way).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define NN_K2 17      // k pairs: K = 34
+#define NN_QPW 128    // queries per wave (4 accumulators of 32 columns)
+#define NN_QPB 512    // queries per workgroup (4 waves)
+
+// desc[n][33] -> baseT[34][n_pad] (row 33 = |b|^2; pad rows get 1e30 so they never win) and
+// queryT[34][n_pad] (-2 * desc, row 33 = 1); also the norms (binary64 sum rounded once) and the
+// largest norm (as ordered bits).
+__global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ desc, int n, int n_pad,
+                                                   float* __restrict__ baseT, float* __restrict__ queryT,
+                                                   float* __restrict__ norms, u32* __restrict__ max_norm_bits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float nrm = 0.f;
+  if (i < n_pad) {
+    if (i < n) {
+      double acc = 0.0;
+      for (int k = 0; k < 33; ++k) {
+        const float v = desc[(size_t)i * 33 + k];
+        acc += (double)v * (double)v;
+        baseT[(size_t)k * n_pad + i] = v;
+        queryT[(size_t)k * n_pad + i] = -2.0f * v;
+      }
+      nrm = (float)acc;
+      baseT[(size_t)33 * n_pad + i] = nrm;
+      queryT[(size_t)33 * n_pad + i] = 1.0f;
+      norms[i] = nrm;
+    } else {
+      for (int k = 0; k < 33; ++k) {
+        baseT[(size_t)k * n_pad + i] = 0.f;
+        queryT[(size_t)k * n_pad + i] = 0.f;
+      }
+      baseT[(size_t)33 * n_pad + i] = 1e30f;
+      queryT[(size_t)33 * n_pad + i] = 1.0f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
+  if (qk_lane() == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
+}
+
+// best and second-best approximate distance of a query over one base slice (index of the best only)
+struct NnPartial {
+  float b1, b2;
+  int i1;
+  int pad;
+};
+
+// grid.x = nq_pad / 512 query groups, grid.y = base slices.  Each wave keeps 4 x 32 query columns
+// stationary (68 VGPRs), streams 32-row base tiles (17 coalesced dword loads per lane, software
+// prefetched one tile ahead in a second register set) and issues 68 MFMAs per tile.  The epilogue is
+// five branch-free VALU ops per accumulator value (cmp / max / min / min / cndmask), i.e. ~0.15 of the
+// MFMA issue time, so the kernel is matrix-pipe bound.
+__global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ baseT, int nb_pad,
+                                                    const float* __restrict__ queryT, int nq_pad,
+                                                    int tiles_per_split, NnPartial* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int qbase = (blockIdx.x * 4 + wave) * NN_QPW + col;
+  float q[4][NN_K2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int kk = 0; kk < NN_K2; ++kk) q[a][kk] = queryT[(size_t)(2 * kk + half) * nq_pad + qbase + 32 * a];
+  float b1[4], b2[4];
+  int i1[4];  // code of the best: (tile << 4) | accumulator register
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    b1[a] = b2[a] = INFINITY;
+    i1[a] = -1;
+  }
+  const int ntiles = nb_pad / 32;
+  const int t_begin = blockIdx.y * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+  const float* bp = baseT + (size_t)half * nb_pad + col;
+  float m0[NN_K2], m1[NN_K2];
+  auto load_tile = [&](float* m, int t) {
+    const float* p = bp + (size_t)t * 32;
+#pragma unroll
+    for (int kk = 0; kk < NN_K2; ++kk) m[kk] = p[(size_t)(2 * kk) * nb_pad];
+  };
+  auto compute_tile = [&](const float* m, int t) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < NN_K2; ++kk)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(m[kk], q[a][kk], acc[a], 0, 0, 0);
+    const int tcode = t << 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[a][r];
+        const bool lt = v < b1[a];
+        const float loser = fmaxf(b1[a], v);
+        b1[a] = fminf(b1[a], v);
+        b2[a] = fminf(b2[a], loser);
+        i1[a] = lt ? (tcode | r) : i1[a];
+      }
+  };
+  if (t_begin < t_end) load_tile(m0, t_begin);
+  for (int t = t_begin; t < t_end; t += 2) {
+    if (t + 1 < t_end) load_tile(m1, t + 1);
+    compute_tile(m0, t);
+    if (t + 1 < t_end) {
+      if (t + 2 < t_end) load_tile(m0, t + 2);
+      compute_tile(m1, t + 1);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    // decode the best's row, then merge the two lanes (half 0 / half 1) that own the same query column
+    const int r = i1[a] & 15;
+    int row = (i1[a] < 0) ? -1 : ((i1[a] >> 4) * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
+    const float ob1 = __shfl_xor(b1[a], 32, 64), ob2 = __shfl_xor(b2[a], 32, 64);
+    const int orow = __shfl_xor(row, 32, 64);
+    const bool take = (ob1 < b1[a]) || (ob1 == b1[a] && orow >= 0 && (row < 0 || orow < row));
+    const float nb2 = fminf(fminf(b2[a], ob2), take ? b1[a] : ob1);
+    const float nb1 = take ? ob1 : b1[a];
+    row = take ? orow : row;
+    if (half == 0) {
+      NnPartial p;
+      p.b1 = nb1;
+      p.b2 = nb2;
+      p.i1 = row;
+      p.pad = 0;
+      partial[(size_t)(qbase + 32 * a) * gridDim.y + blockIdx.y] = p;
+    }
+  }
+}
+
+// Merge the per-slice partials and decide each query row: if best + 2 eps < second-best the approximate
+// winner IS the exact arg-min; otherwise the row goes to the exact re-check list.
+// eps bounds |d~ - d_exact-order| for every pair of the row: with u = 2^-24, the 35-term fma chain
+// contributes 35u(|b|^2 + 2 a.b) <= 35u(|a|^2 + 2|b|^2), the final addition and the two once-rounded
+// norms u(|a|^2 + |b|^2 + d~), and the exact-order evaluation itself 35u d; rounded up to the
+// constants below (a.b <= (|a|^2+|b|^2)/2, d <= d~ + eps).
+__global__ __launch_bounds__(256) void k_nn_mfma_finish(const NnPartial* __restrict__ partial, int nsplit, int nq,
+                                                        const float* __restrict__ qnorm,
+                                                        const u32* __restrict__ base_max_norm_bits,
+                                                        u64* __restrict__ best, int* __restrict__ recheck_rows,
+                                                        int* __restrict__ recheck_count) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  float b1 = INFINITY, b2 = INFINITY;
+  int i1 = -1;
+  for (int sidx = 0; sidx < nsplit; ++sidx) {
+    const NnPartial p = partial[(size_t)q * nsplit + sidx];
+    const bool take = (p.b1 < b1) || (p.b1 == b1 && p.i1 >= 0 && (i1 < 0 || p.i1 < i1));
+    const float nb2 = fminf(fminf(b2, p.b2), take ? b1 : p.b1);
+    b1 = take ? p.b1 : b1;
+    i1 = take ? p.i1 : i1;
+    b2 = nb2;
+  }
+  const float na = qnorm[q], nbmax = __uint_as_float(*base_max_norm_bits);
+  const float u = 5.9604645e-08f;
+  const float dmax = fmaxf(na + b1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
+  const float eps = u * (40.0f * na + 76.0f * nbmax + 40.0f * dmax) * 1.01f;
+  if (i1 >= 0 && b2 - b1 > 2.0f * eps) {
+    best[q] = (u64)(u32)i1;
+  } else {
+    best[q] = ~0ULL;
+    recheck_rows[atomicAdd(recheck_count, 1)] = q;
+  }
+}
+
+// exact re-decision of the listed rows: workgroup (x, y) scans base slice y for row x (grid-strided over
+// the list, whose length is read on the device); thread t evaluates base rows t, t+256, ... with the
+// exact flann::L2 arithmetic; a block arg-min feeds one packed 64-bit atomicMin per (row, slice).
+__global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__ A, const float* __restrict__ B, int nB,
+                                                       u64* __restrict__ best, const int* __restrict__ rows,
+                                                       const int* __restrict__ nrows_p) {
+  __shared__ float a_s[36];
+  __shared__ u64 wbest[4];
+  const int nrows = *nrows_p;
+  const int per = (nB + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nB, b0 + per);
+  for (int ri = blockIdx.x; ri < nrows; ri += gridDim.x) {
+    const int a_idx = rows[ri];
+    __syncthreads();
+    if (threadIdx.x < 33) a_s[threadIdx.x] = A[(size_t)a_idx * 33 + threadIdx.x];
+    __syncthreads();
+    float a[33];
+#pragma unroll
+    for (int t = 0; t < 33; ++t) a[t] = a_s[t];
+    u64 mine = ~0ULL;
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) {
+      const float d = l2_flann33_g(a, B + (size_t)b * 33);
+      const u64 key = ((u64)__float_as_uint(d) << 32) | (u32)b;
+      mine = key < mine ? key : mine;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const u64 o = __shfl_xor(mine, off, 64);
+      mine = o < mine ? o : mine;
+    }
+    if (qk_lane() == 0) wbest[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u64 m = wbest[0];
+      for (int w = 1; w < 4; ++w) m = wbest[w] < m ? wbest[w] : m;
+      if (m != ~0ULL) atomicMin(&best[a_idx], m);
+    }
   }
 }
 
@@ -224,13 +453,47 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     if (s > 256) s = 256;
     return s;
   };
-  if (F.ev_nn[0]) (void)hipEventRecord(F.ev_nn[0], st);
-  hipLaunchKernelGGL(k_nn_exact, dim3((n_small + 255) / 256, nsplit(n_small, n_large)), dim3(256), 0, st, Cj.fpfh,
-                     n_small, Ci.fpfh, n_large, F.best_small, (const int*)nullptr, 0);
-  if (F.ev_nn[1]) (void)hipEventRecord(F.ev_nn[1], st);
-  hipLaunchKernelGGL(k_nn_exact, dim3((n_large + 255) / 256, nsplit(n_large, n_small)), dim3(256), 0, st, Ci.fpfh,
-                     n_large, Cj.fpfh, n_small, F.best_large, (const int*)nullptr, 0);
-  if (F.ev_nn[2]) (void)hipEventRecord(F.ev_nn[2], st);
+  if (F.nn_engine == 0) {
+    if (F.ev_nn[0]) (void)hipEventRecord(F.ev_nn[0], st);
+    hipLaunchKernelGGL(k_nn_exact, dim3((n_small + 255) / 256, nsplit(n_small, n_large)), dim3(256), 0, st, Cj.fpfh,
+                       n_small, Ci.fpfh, n_large, F.best_small, (const int*)nullptr, 0);
+    if (F.ev_nn[1]) (void)hipEventRecord(F.ev_nn[1], st);
+    if (F.ev_nn[2]) (void)hipEventRecord(F.ev_nn[2], st);
+    hipLaunchKernelGGL(k_nn_exact, dim3((n_large + 255) / 256, nsplit(n_large, n_small)), dim3(256), 0, st, Ci.fpfh,
+                       n_large, Cj.fpfh, n_small, F.best_large, (const int*)nullptr, 0);
+    if (F.ev_nn[3]) (void)hipEventRecord(F.ev_nn[3], st);
+  } else {
+    const int pad_small = (n_small + NN_QPB - 1) / NN_QPB * NN_QPB, pad_large = (n_large + NN_QPB - 1) / NN_QPB * NN_QPB;
+    if ((e = hipMemsetAsync(Ci.max_norm, 0, 4, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(Cj.max_norm, 0, 4, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_desc_prep, dim3(pad_large / 256), dim3(256), 0, st, Ci.fpfh, n_large, pad_large, Ci.baseT,
+                       Ci.queryT, Ci.norms, Ci.max_norm);
+    hipLaunchKernelGGL(k_desc_prep, dim3(pad_small / 256), dim3(256), 0, st, Cj.fpfh, n_small, pad_small, Cj.baseT,
+                       Cj.queryT, Cj.norms, Cj.max_norm);
+    auto run_dir = [&](CloudBufs& Q, int nq, int nq_pad, CloudBufs& Bc, int nb, int nb_pad, u64* best, int mc_slot,
+                       hipEvent_t ev0, hipEvent_t ev1) {
+      const int ntiles = nb_pad / 32;
+      int ns = (2048 + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
+      if (ns > 32) ns = 32;
+      if (ns > ntiles) ns = ntiles;
+      if (ns < 1) ns = 1;
+      const int tps = (ntiles + ns - 1) / ns;
+      ns = (ntiles + tps - 1) / tps;
+      if (ev0) (void)hipEventRecord(ev0, st);
+      hipLaunchKernelGGL(k_nn_mfma, dim3(nq_pad / NN_QPB, ns), dim3(256), 0, st, Bc.baseT, nb_pad, Q.queryT, nq_pad, tps,
+                         (NnPartial*)F.nn_partial);
+      if (ev1) (void)hipEventRecord(ev1, st);
+      hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns,
+                         nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.mcounts + mc_slot);
+      int ey = (nb + 1023) / 1024;  // >= 4 base rows per thread and slice
+      if (ey > 16) ey = 16;
+      if (ey < 1) ey = 1;
+      hipLaunchKernelGGL(k_nn_exact_rows, dim3(256, ey), dim3(256), 0, st, Q.fpfh, Bc.fpfh, nb, best, F.recheck_rows,
+                         F.mcounts + mc_slot);
+    };
+    run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, F.ev_nn[0], F.ev_nn[1]);
+    run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, F.ev_nn[2], F.ev_nn[3]);
+  }
   hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, F.nn_of_small);
   hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, F.nn_of_large);
   // K6 cross-check -> pairs in ascending i

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#define CLIQUE_BATCH 256
+
 struct SolverState {  // device resident; mirrored to pinned host memory between clique rounds
   int mc;        // best clique size so far (pmc_heu's `mc`)
   int best_r;    // rank of the start vertex that produced it (-1 none, -2 member bitset prebuilt)
@@ -26,6 +28,7 @@ struct SolverBufs {
   double* f64 = nullptr;
   int* i32 = nullptr;
   u64* member_bits = nullptr;
+  int* picks_buf = nullptr;  // [CLIQUE_BATCH][L] greedy picks of every start of the current batch
   SolverState* st = nullptr;
   qtr_result* res = nullptr;
 };

@@ -68,10 +68,7 @@ __global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ 
     }
   }
   const int d = wave_sum_i32(degacc);
-  if (lane == 0) {
-    deg[row] = d;
-    atomicAdd(n_edges2, d);
-  }
+  if (lane == 0) deg[row] = d;  // the edge total is reduced in k_kcore (no hot-address atomics here)
 }
 
 // =================================================================================================
@@ -82,61 +79,76 @@ __global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ 
 #define KC_REMOVED (-(1 << 30))
 __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int L, int W, const int* __restrict__ deg_in,
                                                 int* __restrict__ core_out, SolverState* __restrict__ st,
-                                                int* __restrict__ gqueue /* used when the queue does not fit LDS */) {
-  extern __shared__ int kc_lds[];
+                                                int* __restrict__ gqueue /* used when the queue does not fit LDS */,
+                                                int lds_bitmap) {
+  extern __shared__ __attribute__((aligned(16))) int kc_lds[];
   int* deg = kc_lds;
   int* queue = gqueue ? gqueue : kc_lds + L;
-  __shared__ int s_qn, s_min;
+  __shared__ int s_qn[2], s_min[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-  for (int v = tid; v < L; v += nthr) deg[v] = deg_in[v];
-  if (tid == 0) s_min = 0x7fffffff;
-  __syncthreads();
-  {
-    int m = 0x7fffffff;
-    for (int v = tid; v < L; v += nthr) m = min(m, deg[v]);
-    m = wave_min_i32(m);
-    if (lane == 0) atomicMin(&s_min, m);
+  const int lane = tid & 63;
+  __shared__ int s_edges2;
+  if (tid == 0) {
+    s_qn[0] = s_qn[1] = 0;
+    s_min[0] = s_min[1] = 0x7fffffff;
+    s_edges2 = 0;
   }
   __syncthreads();
-  int k = s_min;
+  {
+    int esum = 0;
+    for (int v = tid; v < L; v += nthr) {
+      const int d = deg_in[v];
+      deg[v] = d;
+      esum += d;
+    }
+    esum = wave_sum_i32(esum);
+    if (lane == 0 && esum) atomicAdd(&s_edges2, esum);
+  }
+  // adjacency rows: from LDS when the whole bit matrix fits behind the degree/queue arrays
+  const u64* rows = bm;
+  if (lds_bitmap) {
+    u64* lb = (u64*)(kc_lds + ((2 * L + 1) & ~1));
+    for (size_t e = tid; e < (size_t)L * W; e += nthr) lb[e] = bm[e];
+    rows = lb;
+  }
+  __syncthreads();
+  if (tid == 0) st->n_edges2 = s_edges2;
+  int k = -1;  // first round: nothing has degree <= -1, so it only computes the minimum degree
   int maxcore = 0;
-  if (L == 0) k = 0;
-  while (true) {
-    __syncthreads();
-    if (tid == 0) s_qn = 0;
-    __syncthreads();
+  for (int round = 0;; ++round) {
+    const int p = round & 1;
+    // detection: vertices with degree <= k leave the graph at core k; the rest vote for the next level
+    int m = 0x7fffffff;
     for (int v = tid; v < L; v += nthr) {
       const int d = deg[v];
-      if (d > KC_REMOVED / 2 && d <= k) {
-        deg[v] = 2 * KC_REMOVED + 1024;  // stays far below KC_REMOVED/2 under any number of decrements
-        core_out[v] = k;
-        queue[atomicAdd(&s_qn, 1)] = v;
+      if (d > KC_REMOVED / 2) {
+        if (d <= k) {
+          deg[v] = 2 * KC_REMOVED + 1024;  // stays far below KC_REMOVED/2 under any number of decrements
+          core_out[v] = k;
+          queue[atomicAdd(&s_qn[p], 1)] = v;
+        } else {
+          m = min(m, d);
+        }
       }
     }
+    m = wave_min_i32(m);
+    if (lane == 0 && m != 0x7fffffff) atomicMin(&s_min[p], m);
     __syncthreads();
-    const int n = s_qn;
-    if (n == 0) {
-      // level exhausted: jump to the smallest remaining degree
-      if (tid == 0) s_min = 0x7fffffff;
-      __syncthreads();
-      int m = 0x7fffffff;
-      for (int v = tid; v < L; v += nthr) {
-        const int d = deg[v];
-        if (d > KC_REMOVED / 2) m = min(m, d);
-      }
-      m = wave_min_i32(m);
-      if (lane == 0 && m != 0x7fffffff) atomicMin(&s_min, m);
-      __syncthreads();
-      if (s_min == 0x7fffffff) break;
-      k = s_min;
-      continue;
+    const int n = s_qn[p], mn = s_min[p];
+    if (tid == 0) {
+      s_qn[p ^ 1] = 0;
+      s_min[p ^ 1] = 0x7fffffff;
     }
-    maxcore = k;
-    for (int q = wave; q < n; q += nwaves) {
-      const int v = queue[q];
-      for (int w = lane; w < W; w += 64) {
-        u64 x = bm[(size_t)v * W + w];
+    if (n == 0) {
+      if (mn == 0x7fffffff) break;  // nothing left
+      k = mn;                       // level exhausted: jump to the smallest remaining degree
+    } else {
+      maxcore = k;
+      // (frontier vertex, word) items are independent: flattened over all threads so that the row loads
+      // of a round overlap instead of forming one latency chain per wave
+      for (int item = tid; item < n * W; item += nthr) {
+        const int v = queue[item / W], w = item - (item / W) * W;
+        u64 x = rows[(size_t)v * W + w];
         while (x) {
           const int b = __ffsll((long long)x) - 1;
           x &= x - 1;
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
         }
       }
     }
+    __syncthreads();
   }
   if (tid == 0) {
     st->max_core = maxcore;
@@ -260,20 +273,21 @@ __global__ __launch_bounds__(256) void k_clique_init(const int* __restrict__ Kp,
 
 __global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
                                                       int W, const SolverState* __restrict__ st,
-                                                      int* __restrict__ gsz) {
+                                                      int* __restrict__ gsz, int* __restrict__ picks_buf) {
   const int lane = qk_lane();
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (st->done || wid >= st->batch) return;
   const int r = st->pos - wid;
   int g = 0;
-  if (r >= 0 && Kp[r] > st->mc) g = greedy_dispatch(adjP, W, r, st->t0, lane, nullptr);
+  if (r >= 0 && Kp[r] > st->mc) g = greedy_dispatch(adjP, W, r, st->t0, lane, picks_buf + (size_t)wid * L);
   if (lane == 0) gsz[wid] = g;
 }
 
 // Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
 __global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
                                                     int W, SolverState* __restrict__ st, const int* __restrict__ gsz,
-                                                    int next_batch) {
+                                                    int next_batch, const int* __restrict__ picks_buf,
+                                                    int* __restrict__ best_picks) {
   if (st->done) return;
   const int lane = qk_lane();
   const int B = st->batch, pos = st->pos, ub = st->ub;
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP
     if (cnt > mc) {
       mc = gsz[wsel];
       best = rsel;
+      for (int i = lane; i < mc - 1; i += 64) best_picks[i] = picks_buf[(size_t)wsel * L + i];
       // t = first rank with Kp > mc (Kp is non-decreasing in rank)
       int lo = 0, hi = L;
       while (lo < hi) {
@@ -425,16 +440,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   if (st->best_r != -2) {
     for (int w = tid; w < W; w += nthr) A.member_bits[w] = 0;
     __syncthreads();
-    if (tid == 0) s_M = 0;
-    __syncthreads();
-    if (wave == 0 && st->best_r >= 0) {
-      const int depth = greedy_dispatch(A.adjP, W, st->best_r, 0, lane, A.picks);
-      if (lane == 0) s_M = depth;
-    }
-    __syncthreads();
     {
-      // depth-1 picks + the start vertex itself
-      const int depth = s_M;
+      // the winning start's picks were saved by k_clique_scan: depth-1 picks + the start vertex itself
+      const int depth = (st->best_r >= 0) ? mc : 0;
       for (int i = tid; i < depth; i += nthr) {
         const int rr = (i == depth - 1) ? st->best_r : A.picks[i];
         const int v = A.perm[rr];
@@ -659,26 +667,28 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   const int nc = 2 * N;
   int n2 = 1;
   while (n2 < nc) n2 <<= 1;
-  double* ekey;  // n2
-  double* exv;   // nc : X of the event's measurement, in sorted event order
-  int* epos;     // n2
-  if ((size_t)n2 * 12 + (size_t)nc * 8 <= (size_t)FIN_LDS_BYTES) {
-    ekey = fin_lds;
-    exv = fin_lds + n2;
-    epos = (int*)(fin_lds + n2 + nc);
-  } else {
-    ekey = A.f64 + 8 * (size_t)L;  // needs n2 <= 4L: n2 < 2*nc = 4N <= 4L
-    exv = A.f64 + 12 * (size_t)L;  // 2L
-    epos = A.i32 + 2 * (size_t)L;  // 4L
-  }
-  double* rs_w = A.f64 + 14 * (size_t)L;    // running dot_weights_consensus   [2L]
-  double* rs_xw = A.f64 + 16 * (size_t)L;   // running dot_X_weights           [2L]
-  double* rs_rng = A.f64 + 18 * (size_t)L;  // running ranges_inverse_sum      [2L]
-  double* rs_x = A.f64 + 20 * (size_t)L;    // running sum_xi                  [2L]
-  double* rs_xx = A.f64 + 22 * (size_t)L;   // running sum_xi_square           [2L]
-  double* xhat = A.f64 + 24 * (size_t)L;    // [2L]
-  double* xcost = A.f64 + 26 * (size_t)L;   // [2L]
-  int* card = A.i32 + 6 * (size_t)L;        // [2L]
+  // working arrays: carved from LDS while it lasts, global scratch (L2-resident) otherwise
+  size_t lds_used = 0;
+  auto carve = [&](size_t bytes, void* global_fallback) -> void* {
+    const size_t aligned = (bytes + 15) & ~(size_t)15;
+    if (lds_used + aligned <= (size_t)FIN_LDS_BYTES) {
+      void* p = (char*)fin_lds + lds_used;
+      lds_used += aligned;
+      return p;
+    }
+    return global_fallback;
+  };
+  double* ekey = (double*)carve((size_t)n2 * 8, A.f64 + 8 * (size_t)L);   // n2 <= 4L
+  int* epos = (int*)carve((size_t)n2 * 4, A.i32 + 2 * (size_t)L);          // n2 <= 4L
+  double* exv = (double*)carve((size_t)nc * 8, A.f64 + 12 * (size_t)L);   // X of the event, sorted order
+  double* rs_w = (double*)carve((size_t)nc * 8, A.f64 + 14 * (size_t)L);    // running dot_weights_consensus
+  double* rs_xw = (double*)carve((size_t)nc * 8, A.f64 + 16 * (size_t)L);   // running dot_X_weights
+  double* rs_rng = (double*)carve((size_t)nc * 8, A.f64 + 18 * (size_t)L);  // running ranges_inverse_sum
+  double* rs_x = (double*)carve((size_t)nc * 8, A.f64 + 20 * (size_t)L);    // running sum_xi
+  double* rs_xx = (double*)carve((size_t)nc * 8, A.f64 + 22 * (size_t)L);   // running sum_xi_square
+  double* xhat = (double*)carve((size_t)nc * 8, A.f64 + 24 * (size_t)L);
+  double* xcost = (double*)carve((size_t)nc * 8, A.f64 + 26 * (size_t)L);
+  int* card = (int*)carve((size_t)nc * 4, A.i32 + 6 * (size_t)L);
   unsigned char* inl = (unsigned char*)(A.i32 + 1 * (size_t)L);  // N bytes
   __shared__ double s_red_c[4];
   __shared__ int s_red_i[4];
@@ -842,6 +852,7 @@ size_t solver_scratch_bytes(int Lcap) {
   b += 28 * (size_t)Lcap * 8;           // f64
   b += 8 * (size_t)Lcap * 4;            // i32
   b += W * 8 + 4096;
+  b += (size_t)CLIQUE_BATCH * Lcap * 4;  // picks_buf
   return b;
 }
 
@@ -869,6 +880,7 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
   B.f64 = (double*)take(28 * (size_t)Lcap * 8);
   B.i32 = (int*)take(8 * (size_t)Lcap * 4);
   B.member_bits = (u64*)take(W * 8);
+  B.picks_buf = (int*)take((size_t)CLIQUE_BATCH * Lcap * 4);
   B.st = (SolverState*)take(sizeof(SolverState));
   B.res = (qtr_result*)take(sizeof(qtr_result));
 }
@@ -889,8 +901,11 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     if (ev_graph) hipEventRecord(ev_graph, stream);
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
-    hipLaunchKernelGGL(k_kcore, dim3(1), dim3(1024), kc_lds, stream, B.bm, L, W, B.deg, B.core, B.st,
-                       q_in_lds ? (int*)nullptr : B.picks);
+    const size_t bm_bytes = (size_t)L * W * 8;
+    const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
+    const int kc_threads = 1024;
+    hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
+                       B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
     hipLaunchKernelGGL(k_rank, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.perm, B.rankof, B.Kp);
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
     hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
@@ -900,14 +915,17 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
                          B.member_bits, W);
     }
     if (heuristic) {
-      const int BATCH = 256;
+      const int BATCH = CLIQUE_BATCH;
       // round 0: the single top-ranked start; round 1..: BATCH starts each
-      hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz);
-      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH);
+      hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
+      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
+                         B.picks);
       int guard = 0;
       while (true) {
-        hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz);
-        hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH);
+        hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
+                           B.picks_buf);
+        hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
+                         B.picks);
         if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) !=
             hipSuccess)
           return e;

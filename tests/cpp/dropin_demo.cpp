@@ -1,0 +1,67 @@
+// dropin_demo.cpp — the reference demo's call sequence (examples/run_global_registration.cpp:92-108,
+// 206-221, 243-246) written against include/quatro.hpp + include/fpfh_manager.hpp of THIS repository.
+// usage: dropin_demo src.bin tgt.bin [seed]     (.bin = float32 x,y,z,intensity records, as KITTI)
+// Prints the 4x4 transform (17 significant digits), clique size and final inlier indices.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+
+#include "fpfh_manager.hpp"
+#include "quatro.hpp"
+
+static std::shared_ptr<pcl::PointCloud<PointType>> getCloud(const char* path) {  // reference :377-402
+  auto cloud = std::make_shared<pcl::PointCloud<PointType>>();
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  float rec[4];
+  while (f.read(reinterpret_cast<char*>(rec), sizeof(rec)) && cloud->size() < 250000)
+    cloud->push_back(PointType(rec[0], rec[1], rec[2]));
+  return cloud;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s src.bin tgt.bin [seed]\n", argv[0]);
+    return 2;
+  }
+  auto srcRaw = getCloud(argv[1]);
+  auto tgtRaw = getCloud(argv[2]);
+  using QuatroT = Quatro<PointType, PointType>;
+  QuatroT quatro;
+  QuatroT::Params params;  // setParams(...) of the demo, config/params.yaml values
+  params.noise_bound = 0.3;
+  params.cbar2 = 1.0;
+  params.rotation_gnc_factor = 1.4;
+  params.rotation_max_iterations = 50;
+  params.rotation_cost_threshold = 1.1e-4;
+  params.estimate_scaling = false;
+  params.inlier_selection_mode = QuatroT::INLIER_SELECTION_MODE::PMC_HEU;
+  quatro.reset(params);
+
+  auto srcFeat = std::make_shared<pcl::PointCloud<PointType>>();
+  auto tgtFeat = std::make_shared<pcl::PointCloud<PointType>>();
+  voxelize(srcRaw, srcFeat, 0.3);
+  voxelize(tgtRaw, tgtFeat, 0.3);
+  FPFHManager fpfhmanager(0.5, 0.75);
+  fpfhmanager.seed_ = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0;
+  fpfhmanager.flushAllFeatures();
+  fpfhmanager.setFeaturePair(srcFeat, tgtFeat);
+  auto srcMatched = std::make_shared<pcl::PointCloud<PointType>>(fpfhmanager.getSrcKps());
+  auto tgtMatched = std::make_shared<pcl::PointCloud<PointType>>(fpfhmanager.getTgtKps());
+
+  quatro.setInputSource(srcMatched);
+  quatro.setInputTarget(tgtMatched);
+  Eigen::Matrix4d output = Eigen::Matrix4d::Identity();
+  quatro.computeTransformation(output);
+
+  std::printf("n_src %zu n_tgt %zu L %zu valid %d clique %d rot_inliers %d\n", srcFeat->size(), tgtFeat->size(),
+              srcMatched->size(), quatro.solution_.valid ? 1 : 0, quatro.getNumMaxCliqueInliers(),
+              quatro.getNumRotaionInliers());
+  for (int r = 0; r < 4; ++r)
+    std::printf("T %.17g %.17g %.17g %.17g\n", output(r, 0), output(r, 1), output(r, 2), output(r, 3));
+  std::printf("final");
+  for (int i : quatro.getFinalInliersIndices()) std::printf(" %d", i);
+  std::printf("\n");
+  return 0;
+}

@@ -235,3 +235,65 @@ def test_host_mirror_reads_like_the_reference_demo(hip, qo, small_pair):
     assert quatro.getFinalInliersIndices() == o["final_inliers"].tolist()
     assert quatro.getNumMaxCliqueInliers() == o["clique"].size
     assert len(fm.getCorrespondences()) == o["L"]
+
+
+def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path):
+    """The reference demo's call sequence compiled against include/quatro.hpp + include/fpfh_manager.hpp
+    (tests/cpp/dropin_demo.cpp) gives the oracle's answer, digit for digit."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    s, t, _ = small_pair
+    synth.save_kitti_bin(str(tmp_path / "src.bin"), s)
+    synth.save_kitti_bin(str(tmp_path / "tgt.bin"), t)
+    exe = str(tmp_path / "dropin_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):  # system HIP runtime, else torch's copy
+        env = dict(os.environ)
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe, str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin"), "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            out = p.stdout
+            break
+    assert out is not None, p.stderr[-500:]
+    o = qo.register_pair(s, t, seed=2)
+    lines = out.strip().splitlines()
+    head = dict(zip(lines[0].split()[0::2], lines[0].split()[1::2]))
+    assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (o["n_src"], o["n_tgt"], o["L"])
+    assert int(head["clique"]) == o["clique"].size and int(head["valid"]) == 1
+    T = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[1:5]])
+    assert np.array_equal(T, o["T"])
+    final = [int(x) for x in lines[5].split()[1:]]
+    assert final == o["final_inliers"].tolist()
+
+
+def test_nn_engines_produce_identical_tables(qo, small_pair):
+    """MFMA engine (+ exact re-check of uncertified rows) vs the all-exact VALU engine: same tables, and the
+    re-check fraction stays small."""
+    s, t, _ = small_pair
+    vs, vt = qo.voxelize(s, 0.3), qo.voxelize(t, 0.3)
+    _, _, ds = qo.fpfh(vs, 0.5, 0.75)
+    _, _, dt = qo.fpfh(vt, 0.5, 0.75)
+    tables = {}
+    for engine in ("exact", "mfma"):
+        os.environ["QTR_NN_ENGINE"] = engine
+        try:
+            h = ql.Handle(0)
+        finally:
+            os.environ.pop("QTR_NN_ENGINE", None)
+        corr = h.match(vs, ds, vt, dt, ql.default_frontend_params(seed=4))
+        tables[engine] = (corr, h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32),
+                          h.debug_fetch(ql.DBG_NN_SMALL_OF_LARGE, np.int32),
+                          h.debug_fetch(ql.DBG_MATCH_STATS, np.int32))
+        h.close()
+    for a, b in zip(tables["exact"][:3], tables["mfma"][:3]):
+        assert np.array_equal(a, b)
+    stats = tables["mfma"][3]
+    assert stats[8] + stats[9] < 0.2 * (vs.shape[0] + vt.shape[0])  # rows that needed the exact re-check
