@@ -539,6 +539,7 @@ long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t b
     case QTR_DBG_VOX_TGT: src = s.fb.cloud[1].vox; have = (size_t)s.last_nt * 16; break;
     case QTR_DBG_CORR: src = s.fb.corr; have = (size_t)s.last_L * 8; break;
     case QTR_DBG_MATCH_STATS: src = s.fb.mcounts; have = 16 * 4; break;
+    case QTR_DBG_SOLVER_STATE: src = s.sb.st; have = sizeof(SolverState); break;
     default: return -1;
   }
   const size_t n = have < bytes ? have : bytes;

@@ -26,6 +26,7 @@ struct CloudBufs {
   int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
   float* nbr_d2 = nullptr;     // [max_voxels][QTR_KMAX]
   float4* spts = nullptr;      // [max_voxels] points in cell-sorted order, w = original index
+  float4* raw_sorted = nullptr; // [max_points] raw scan gathered into voxel-sorted order
   int* ranges = nullptr;       // [max_voxels][9][2] candidate key ranges
   float* mean = nullptr;       // 4 floats: sequential float mean of the cloud (Matcher::normalizePoints)
   float* baseT = nullptr;      // [34][n_pad] k-major descriptors + |b|^2 row   (MFMA streamed operand)

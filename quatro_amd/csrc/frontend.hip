@@ -80,19 +80,21 @@ __global__ __launch_bounds__(256) void k_minmax(const float4* __restrict__ pts, 
 // ballot match masks and in-order LDS updates (no barriers).  Used with key = (cell index << 32) |
 // point index on inputs that are already in ascending point-index order, so equal cells keep ascending
 // point order — the accumulation order the oracle defines for pcl::VoxelGrid centroids.
+template <int BITS, int TILE>
 __global__ __launch_bounds__(64) void k_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
                                                    int nblk) {
-  __shared__ u32 cnt[256];
+  constexpr int NB = 1 << BITS;
+  __shared__ u32 cnt[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
-  for (int d = lane; d < 256; d += 64) cnt[d] = 0;
+  for (int d = lane; d < NB; d += 64) cnt[d] = 0;
   __syncthreads();
-  const int base = blk * RADIX_TILE;
-  for (int s = 0; s < RADIX_TILE; s += 64) {
+  const int base = blk * TILE;
+  for (int s = 0; s < TILE; s += 64) {
     const int i = base + s + lane;
-    if (i < n) atomicAdd(&cnt[(u32)(in[i] >> shift) & 255u], 1u);
+    if (i < n) atomicAdd(&cnt[(u32)(in[i] >> shift) & (u32)(NB - 1)], 1u);
   }
   __syncthreads();
-  for (int d = lane; d < 256; d += 64) hist[d * nblk + blk] = cnt[d];
+  for (int d = lane; d < NB; d += 64) hist[d * nblk + blk] = cnt[d];
 }
 
 // exclusive scan of m 32-bit counters by one workgroup (m up to a few hundred thousand)
@@ -131,21 +133,23 @@ __global__ __launch_bounds__(1024) void k_scan_u32(u32* __restrict__ data, int m
   if (tid == 0 && total_out) *total_out = carry_s;
 }
 
+template <int BITS, int TILE>
 __global__ __launch_bounds__(64) void k_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
                                                       int shift, const u32* __restrict__ hist, int nblk) {
-  __shared__ u32 base[256];
+  constexpr int NB = 1 << BITS;
+  __shared__ u32 base[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
-  for (int d = lane; d < 256; d += 64) base[d] = hist[d * nblk + blk];
+  for (int d = lane; d < NB; d += 64) base[d] = hist[d * nblk + blk];
   __syncthreads();
-  const int tbase = blk * RADIX_TILE;
-  for (int s = 0; s < RADIX_TILE; s += 64) {
+  const int tbase = blk * TILE;
+  for (int s = 0; s < TILE; s += 64) {
     const int i = tbase + s + lane;
     const bool valid = i < n;
     const u64 key = valid ? in[i] : 0ULL;
-    const u32 d = (u32)(key >> shift) & 255u;
+    const u32 d = (u32)(key >> shift) & (u32)(NB - 1);
     u64 m = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < BITS; ++bit) {
       const bool one = (d >> bit) & 1u;
       const u64 b = __ballot(valid && one);
       m &= one ? b : ~b;
@@ -160,20 +164,30 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const u64* __restrict__ in
   }
 }
 
-hipError_t radix_sort_u64_hi(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st,
-                             u64** sorted_out) {
-  const int nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
+template <int BITS, int TILE>
+static hipError_t radix_sort_impl(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st,
+                                  u64** sorted_out) {
+  const int nblk = (n + TILE - 1) / TILE;
   u64 *src = keys_a, *dst = keys_b;
-  for (int shift = 32; shift < 32 + key_bits; shift += 8) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(64), 0, st, src, n, shift, hist, nblk);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, hist, 256 * nblk, (u32*)nullptr);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(64), 0, st, src, dst, n, shift, hist, nblk);
+  for (int shift = 32; shift < 32 + key_bits; shift += BITS) {
+    hipLaunchKernelGGL((k_radix_hist<BITS, TILE>), dim3(nblk), dim3(64), 0, st, src, n, shift, hist, nblk);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, hist, (1 << BITS) * nblk, (u32*)nullptr);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, TILE>), dim3(nblk), dim3(64), 0, st, src, dst, n, shift, hist, nblk);
     u64* t = src;
     src = dst;
     dst = t;
   }
   *sorted_out = src;
   return hipGetLastError();
+}
+
+// key_bits = 32: four 8-bit passes (voxel indices); key_bits = 24: three (cell keys)
+hipError_t radix_sort_u64_hi(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st,
+                             u64** sorted_out) {
+  // 8-bit digits on 1024-element single-wave tiles measured fastest on MI355X for 10^4..10^5 keys: wider
+  // digits (11/12 bits) need fewer passes but their 4096-element tiles serialise 4x more steps per wave
+  // and were 2x slower overall (profiles/r1e_kernel_stats.txt).
+  return radix_sort_impl<8, RADIX_TILE>(keys_a, keys_b, hist, n, key_bits <= 24 ? 24 : 32, st, sorted_out);
 }
 
 __global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
@@ -204,6 +218,9 @@ hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, in, out, n);
   return hipGetLastError();
 }
+
+__global__ void k_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted, int n,
+                                float4* __restrict__ spts);
 
 // =================================================================================================
 // K1  pcl::VoxelGrid::applyFilter restated
@@ -263,18 +280,42 @@ __global__ __launch_bounds__(256) void k_vox_headcount(const u64* __restrict__ k
   if (threadIdx.x == 0) blkcnt[blockIdx.x] = s;
 }
 
-// centroid per voxel: the head element of each run sums its run sequentially (float, sorted order)
+// centroid per voxel: the head element of each run sums its run sequentially (float, sorted order).
+// A workgroup stages its 1024 sorted elements plus a 512-element halo (cell id + xyz, gathered through
+// the sorted index) in LDS with coalesced loads, so the dependent float additions of a run are fed from
+// LDS instead of one HBM/L2 round trip per element; only runs longer than the halo touch global memory.
+#define VOX_TILE 1024
+#define VOX_HALO 512
 __global__ __launch_bounds__(256) void k_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
                                                        int P, const int* __restrict__ blkoff, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts) {
+  __shared__ u32 s_cell[VOX_TILE + VOX_HALO + 1];
+  __shared__ float s_x[VOX_TILE + VOX_HALO], s_y[VOX_TILE + VOX_HALO], s_z[VOX_TILE + VOX_HALO];
   __shared__ int wtot[4];
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
-  const int base = blockIdx.x * 1024;
+  const int base = blockIdx.x * VOX_TILE;
   int running = blkoff[blockIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
-  for (int t0 = 0; t0 < 1024; t0 += 256) {
-    const int i = base + t0 + threadIdx.x;
-    const bool head = (i < P) && ((i == 0) || ((u32)(keys[i] >> 32) != (u32)(keys[i - 1] >> 32)));
+  for (int t = threadIdx.x; t < VOX_TILE + VOX_HALO; t += 256) {
+    const int i = base + t;
+    if (i < P) {
+      const u64 k = keys[i];
+      const float4 p = pts[(u32)k];
+      s_cell[t + 1] = (u32)(k >> 32);
+      s_x[t] = p.x;
+      s_y[t] = p.y;
+      s_z[t] = p.z;
+    } else {
+      s_cell[t + 1] = 0xffffffffu;
+    }
+  }
+  if (threadIdx.x == 0) s_cell[0] = (base > 0) ? (u32)(keys[base - 1] >> 32) : 0xffffffffu;
+  __syncthreads();
+  for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const int i = base + t;
+    const u32 cell = s_cell[t + 1];
+    const bool head = (i < P) && (i == 0 || cell != s_cell[t]);
     const u64 bal = __ballot(head);
     if (lane == 0) wtot[wave] = __popcll(bal);
     __syncthreads();
@@ -283,17 +324,25 @@ __global__ __launch_bounds__(256) void k_vox_centroids(const u64* __restrict__ k
     const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (head) {
       const int slot = running + woff + __popcll(bal & lanemask_lt());
-      const u32 cell = (u32)(keys[i] >> 32);
       float cx = 0.f, cy = 0.f, cz = 0.f;
-      int e = i;
-      while (e < P && (u32)(keys[e] >> 32) == cell) {
-        const float4 p = pts[(u32)keys[e]];
-        cx += p.x;
-        cy += p.y;
-        cz += p.z;
+      int e = t;
+      while (e < VOX_TILE + VOX_HALO && s_cell[e + 1] == cell) {
+        cx += s_x[e];
+        cy += s_y[e];
+        cz += s_z[e];
         ++e;
       }
-      const float cnt = (float)(e - i);
+      int g = base + e;
+      if (e == VOX_TILE + VOX_HALO) {  // run longer than the halo: continue from global memory
+        while (g < P && (u32)(keys[g] >> 32) == cell) {
+          const float4 p = pts[(u32)keys[g]];
+          cx += p.x;
+          cy += p.y;
+          cz += p.z;
+          ++g;
+        }
+      }
+      const float cnt = (float)(g - i);
       if (slot < cap) out[slot] = make_float4(cx / cnt, cy / cnt, cz / cnt, 0.f);
     }
     running += tot;
@@ -782,7 +831,7 @@ __global__ __launch_bounds__(64) void k_fpfh(const float* __restrict__ spfh, int
 // with coalesced 16-byte loads while the chain runs, which removes the HBM/L2 latency from the chain.
 #define MEAN_CHUNK 2048
 __global__ __launch_bounds__(256) void k_seq_mean(const float4* __restrict__ pts, int n, float* __restrict__ mean) {
-  __shared__ float buf[2][3][MEAN_CHUNK];
+  __shared__ __attribute__((aligned(16))) float buf[2][3][MEAN_CHUNK];
   const int tid = threadIdx.x;
   const int nchunks = (n + MEAN_CHUNK - 1) / MEAN_CHUNK;
   // loaders: `nld` threads starting at `first` cover one chunk with coalesced float4 loads
@@ -807,18 +856,19 @@ __global__ __launch_bounds__(256) void k_seq_mean(const float4* __restrict__ pts
     } else if (tid < 3) {
       const int cnt = min(MEAN_CHUNK, n - c * MEAN_CHUNK);
       const float* b = buf[slot][tid];
+      const float4* b4 = (const float4*)b;
       int t = 0;
-      for (; t + 8 <= cnt; t += 8) {
-        const float a0 = b[t], a1 = b[t + 1], a2 = b[t + 2], a3 = b[t + 3];
-        const float a4 = b[t + 4], a5 = b[t + 5], a6 = b[t + 6], a7 = b[t + 7];
-        m = m + a0;
-        m = m + a1;
-        m = m + a2;
-        m = m + a3;
-        m = m + a4;
-        m = m + a5;
-        m = m + a6;
-        m = m + a7;
+      for (; t + 32 <= cnt; t += 32) {  // eight 16-byte LDS reads in flight ahead of 32 dependent additions
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = b4[(t >> 2) + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          m = m + v[q].x;
+          m = m + v[q].y;
+          m = m + v[q].z;
+          m = m + v[q].w;
+        }
       }
       for (; t < cnt; ++t) m = m + b[t];
     }
@@ -859,10 +909,11 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += 4096;                                         // counts, mm, mean
   per_cloud += (size_t)max_voxels * (16 + 16 + 132 + 132);   // vox, normals, spfh, fpfh
   per_cloud += 2 * (size_t)max_points * 8;                   // keys
-  per_cloud += (size_t)(256 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 4096) * 4 + 65536;  // hist
+  per_cloud += (size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4 + 65536;  // hist
   per_cloud += (size_t)max_voxels * 4 * 2 + 64;              // nbr_cnt, nbr_off
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
+  per_cloud += (size_t)max_points * 16 + 256;                // raw_sorted
   size_t shared = (size_t)max_voxels * 64 + 16384;
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
@@ -890,12 +941,13 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.fpfh = (float*)take((size_t)max_voxels * 132);
     C.keys_a = (u64*)take((size_t)max_points * 8);
     C.keys_b = (u64*)take((size_t)max_points * 8);
-    C.hist = (u32*)take((size_t)(256 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 4096) * 4);
+    C.hist = (u32*)take((size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4);
     C.nbr_cnt = (int*)take((size_t)max_voxels * 4);
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);
     C.nbr_d2 = (float*)take((size_t)max_voxels * QTR_KMAX * 4);
     C.spts = (float4*)take((size_t)max_voxels * 16);
+    C.raw_sorted = (float4*)take((size_t)max_points * 16);
     C.ranges = (int*)take((size_t)max_voxels * 18 * 4);
     const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
     C.baseT = (float*)take(34 * vpad * 4);

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ 
 // from the bit matrix (L2 / Infinity-Cache resident).  Core numbers equal pmc_graph::compute_cores'
 // (Batagelj-Zaversnik) by uniqueness of the k-core decomposition.
 #define KC_REMOVED (-(1 << 30))
+// workgroup barrier that orders LDS traffic only: the core_out stores issued inside the peeling loop are
+// never read by this kernel, and waiting for their HBM acknowledgement would cost ~1.5 us per round
+#define KC_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
 __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int L, int W, const int* __restrict__ deg_in,
                                                 int* __restrict__ core_out, SolverState* __restrict__ st,
                                                 int* __restrict__ gqueue /* used when the queue does not fit LDS */,
@@ -115,8 +118,10 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
   if (tid == 0) st->n_edges2 = s_edges2;
   int k = -1;  // first round: nothing has degree <= -1, so it only computes the minimum degree
   int maxcore = 0;
+  int kc_rounds = 0;
   for (int round = 0;; ++round) {
     const int p = round & 1;
+    kc_rounds = round + 1;
     // detection: vertices with degree <= k leave the graph at core k; the rest vote for the next level
     int m = 0x7fffffff;
     for (int v = tid; v < L; v += nthr) {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
     }
     m = wave_min_i32(m);
     if (lane == 0 && m != 0x7fffffff) atomicMin(&s_min[p], m);
-    __syncthreads();
+    if (gqueue) __syncthreads(); else KC_BARRIER_LDS();  // a global queue needs the full fence
     const int n = s_qn[p], mn = s_min[p];
     if (tid == 0) {
       s_qn[p ^ 1] = 0;
@@ -146,21 +151,132 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
       maxcore = k;
       // (frontier vertex, word) items are independent: flattened over all threads so that the row loads
       // of a round overlap instead of forming one latency chain per wave
-      for (int item = tid; item < n * W; item += nthr) {
-        const int v = queue[item / W], w = item - (item / W) * W;
-        u64 x = rows[(size_t)v * W + w];
-        while (x) {
-          const int b = __ffsll((long long)x) - 1;
-          x &= x - 1;
-          atomicSub(&deg[w * 64 + b], 1);
+      // each wave fetches 64 (frontier vertex, word) items at once (64 independent loads in flight), then
+      // walks the non-zero words with one lane per bit: conflict-free LDS atomics
+      const int nwaves = nthr >> 6, wave = tid >> 6;
+      for (int base = wave * 64; base < n * W; base += nwaves * 64) {
+        const int item = base + lane;
+        u64 xs = 0;
+        int wj = 0;
+        if (item < n * W) {
+          const int qi = item / W;
+          wj = item - qi * W;
+          xs = rows[(size_t)queue[qi] * W + wj];
+        }
+        u64 nz = __ballot(xs != 0);
+        while (nz) {
+          const int t = __ffsll((long long)nz) - 1;
+          nz &= nz - 1;
+          const u64 x = __shfl(xs, t, 64);
+          const int w = __shfl(wj, t, 64);
+          if ((x >> lane) & 1ULL) atomicSub(&deg[w * 64 + lane], 1);
         }
       }
     }
-    __syncthreads();
+    if (gqueue) __syncthreads(); else KC_BARRIER_LDS();  // a global queue needs the full fence
   }
   if (tid == 0) {
     st->max_core = maxcore;
     st->ub = maxcore + 1;
+    st->pad[0] = kc_rounds;  // statistics
+  }
+}
+
+// Single-wavefront variant for graphs whose bit matrix fits in LDS (L up to 1152): the peeling of a
+// dense consistency graph takes hundreds of rounds (one per occupied level), so the cost per round is
+// what matters.  Lane l owns vertices j*64+l and keeps their degrees in REGISTERS; removing vertex v is
+// "for every word j of row v: my degree[j] -= bit l of that word" — a broadcast LDS read and three VALU
+// ops per word, no atomics, no barriers, no per-round memory round trips.
+#define KCW_JMAX 18  // 64 * 18 = 1152 vertices
+#define KCW_GONE 0x3fffffff  // degree of a removed (or non-existent) vertex
+__global__ __launch_bounds__(64) void k_kcore_wave(const u64* __restrict__ bm, int L, int W,
+                                                   const int* __restrict__ deg_in, int* __restrict__ core_out,
+                                                   SolverState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) u64 kcw_rows[];
+  const int lane = threadIdx.x;
+#pragma unroll 8
+  for (int e = lane; e < L * W; e += 64) kcw_rows[e] = bm[e];
+  int dreg[KCW_JMAX], creg[KCW_JMAX];
+  int esum = 0;
+#pragma unroll
+  for (int j = 0; j < KCW_JMAX; ++j) {
+    const int v = j * 64 + lane;
+    dreg[j] = (v < L) ? deg_in[v] : KCW_GONE;
+    creg[j] = 0;
+    if (v < L) esum += dreg[j];
+  }
+  esum = wave_sum_i32(esum);
+  __syncthreads();
+  int k = -1, maxcore = 0, rounds = 0;
+  const u32* rows32 = (const u32*)kcw_rows;
+  const int halfsel = lane >> 5, bitsel = lane & 31;
+  while (true) {
+    ++rounds;
+    // frontier of level k: removed vertices carry a huge positive degree and never hit
+    u32 hitbits = 0;
+#pragma unroll
+    for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+    u64 hl = __ballot(hitbits != 0);
+    if (hl == 0) {
+      // level exhausted: the next occupied level is usually k+1; probe a few, then jump to the minimum
+      int tries = 0;
+      while (hl == 0 && tries < 4) {
+        ++k;
+        ++tries;
+        hitbits = 0;
+#pragma unroll
+        for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+        hl = __ballot(hitbits != 0);
+      }
+      if (hl == 0) {
+        int m = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < KCW_JMAX; ++j) m = min(m, dreg[j]);
+        m = wave_min_i32(m);
+        if (m >= KCW_GONE / 2) break;
+        k = m;
+        hitbits = 0;
+#pragma unroll
+        for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+        hl = __ballot(hitbits != 0);
+      }
+    }
+    maxcore = k;
+    // mark this round's frontier as removed ...
+#pragma unroll
+    for (int j = 0; j < KCW_JMAX; ++j) {
+      const bool hit = (hitbits >> j) & 1u;
+      dreg[j] = hit ? KCW_GONE : dreg[j];
+      creg[j] = hit ? k : creg[j];
+    }
+    // ... then subtract each frontier vertex's row from everybody's degrees: lanes 0-31 read the low
+    // half-word of word w, lanes 32-63 the high one (two broadcast addresses), one v_bfe per word
+    while (hl) {
+      const int l = __ffsll((long long)hl) - 1;
+      hl &= hl - 1;
+      u32 hb = (u32)__builtin_amdgcn_readlane((int)hitbits, l);
+      while (hb) {
+        const int j = __ffs((int)hb) - 1;
+        hb &= hb - 1;
+        const u32* row = rows32 + (size_t)(j * 64 + l) * W * 2 + halfsel;
+        u32 x[KCW_JMAX];
+#pragma unroll
+        for (int w = 0; w < KCW_JMAX; ++w) x[w] = row[2 * (w < W ? w : W - 1)];
+#pragma unroll
+        for (int w = 0; w < KCW_JMAX; ++w) dreg[w] -= (w < W) ? (int)((x[w] >> bitsel) & 1u) : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KCW_JMAX; ++j) {
+    const int v = j * 64 + lane;
+    if (v < L) core_out[v] = creg[j];
+  }
+  if (lane == 0) {
+    st->max_core = maxcore;
+    st->ub = maxcore + 1;
+    st->n_edges2 = esum;
+    st->pad[0] = rounds;
   }
 }
 
@@ -283,6 +399,25 @@ __global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ ad
   if (lane == 0) gsz[wid] = g;
 }
 
+// Round 0 of the heuristic is a single start (the top-ranked vertex) whose greedy descent is one long
+// dependent chain (one row AND per clique member).  When the rank-labelled bit matrix fits in LDS the
+// chain runs out of LDS (~100 cycles per step instead of an L2 round trip).
+__global__ __launch_bounds__(256) void k_clique_first_lds(const u64* __restrict__ adjP, const int* __restrict__ Kp,
+                                                          int L, int W, const SolverState* __restrict__ st,
+                                                          int* __restrict__ gsz, int* __restrict__ picks_buf) {
+  extern __shared__ __attribute__((aligned(16))) u64 cl_rows[];
+  if (st->done) return;
+#pragma unroll 4
+  for (int e = threadIdx.x; e < L * W; e += 256) cl_rows[e] = adjP[e];
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int r = st->pos;
+  int g = 0;
+  if (r >= 0 && Kp[r] > st->mc) g = greedy_dispatch(cl_rows, W, r, st->t0, lane, picks_buf);
+  if (lane == 0) gsz[0] = g;
+}
+
 // Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
 __global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
                                                     int W, SolverState* __restrict__ st, const int* __restrict__ gsz,
@@ -381,7 +516,7 @@ __global__ __launch_bounds__(256) void k_kcore_heu(const int* __restrict__ core,
 // =================================================================================================
 // K13-K16: chain TIMs, GNC-TLS yaw, rotation-inlier chain rule, COTE, final inliers.  One workgroup
 // of 256 threads; wavefront 0 runs the GNC loop with the fixed-shape sum64 reductions.
-#define FIN_LDS_BYTES (96 * 1024)
+#define FIN_LDS_BYTES (144 * 1024)
 struct FinalizeArgs {
   const float4* src;
   const float4* tgt;
@@ -657,88 +792,116 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
 
-  // ---- COTE per axis (reference estimate(), :618-747)
-  // Per axis: (1) bitonic sort of the 2N interval endpoints by (value, insertion position) in LDS,
-  // (2) ONE lane walks the events accumulating the five running sums in the reference's order (binary64
-  // addition is not associative, so this part stays sequential; it only touches LDS and issues
-  // fire-and-forget stores), (3) all lanes evaluate x_hat / cost per event, (4) block arg-min with
-  // Eigen's minCoeff tie rule, (5) median of the consensus window by parallel rank counting.
+  // ---- COTE (reference estimate(), :618-747).  The three axes are independent: wavefront a handles axis a
+  // (wave 3 only joins the barriers).  Per axis: (1) bitonic sort of the 2N interval endpoints by
+  // (value, insertion position), (2) ONE lane walks the events accumulating the five running sums in the
+  // reference's order (binary64 addition is not associative, so this part stays sequential; it touches
+  // LDS only), (3) the wave evaluates x_hat / cost per event and takes the arg-min with Eigen's
+  // minCoeff tie rule, (4) median of the consensus window by rank counting.
   const double range = A.prm.cote_noise_bound * sqrt(A.prm.cbar2);
   const int nc = 2 * N;
   int n2 = 1;
   while (n2 < nc) n2 <<= 1;
-  // working arrays: carved from LDS while it lasts, global scratch (L2-resident) otherwise
+  const int ax = wave;
+  const bool act = ax < 3;
+  // working arrays of this wave's axis: carved from its third of the LDS while it lasts, global otherwise
+  const size_t lds_per_axis = ((size_t)FIN_LDS_BYTES / 3) & ~(size_t)15;
   size_t lds_used = 0;
+  const int axc = act ? ax : 0;
+  char* lds_base = (char*)fin_lds + (size_t)axc * lds_per_axis;
+  double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
+  int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
   auto carve = [&](size_t bytes, void* global_fallback) -> void* {
     const size_t aligned = (bytes + 15) & ~(size_t)15;
-    if (lds_used + aligned <= (size_t)FIN_LDS_BYTES) {
-      void* p = (char*)fin_lds + lds_used;
+    if (lds_used + aligned <= lds_per_axis) {
+      void* p = lds_base + lds_used;
       lds_used += aligned;
       return p;
     }
     return global_fallback;
   };
-  double* ekey = (double*)carve((size_t)n2 * 8, A.f64 + 8 * (size_t)L);   // n2 <= 4L
-  int* epos = (int*)carve((size_t)n2 * 4, A.i32 + 2 * (size_t)L);          // n2 <= 4L
-  double* exv = (double*)carve((size_t)nc * 8, A.f64 + 12 * (size_t)L);   // X of the event, sorted order
-  double* rs_w = (double*)carve((size_t)nc * 8, A.f64 + 14 * (size_t)L);    // running dot_weights_consensus
-  double* rs_xw = (double*)carve((size_t)nc * 8, A.f64 + 16 * (size_t)L);   // running dot_X_weights
-  double* rs_rng = (double*)carve((size_t)nc * 8, A.f64 + 18 * (size_t)L);  // running ranges_inverse_sum
-  double* rs_x = (double*)carve((size_t)nc * 8, A.f64 + 20 * (size_t)L);    // running sum_xi
-  double* rs_xx = (double*)carve((size_t)nc * 8, A.f64 + 22 * (size_t)L);   // running sum_xi_square
-  double* xhat = (double*)carve((size_t)nc * 8, A.f64 + 24 * (size_t)L);
-  double* xcost = (double*)carve((size_t)nc * 8, A.f64 + 26 * (size_t)L);
-  int* card = (int*)carve((size_t)nc * 4, A.i32 + 6 * (size_t)L);
-  unsigned char* inl = (unsigned char*)(A.i32 + 1 * (size_t)L);  // N bytes
-  __shared__ double s_red_c[4];
-  __shared__ int s_red_i[4];
-  __shared__ double s_va, s_vb;
-  for (int i = tid; i < N; i += nthr) inl[i] = 1;
-  double tr[3] = {0, 0, 0};
-  for (int axis = 0; axis < 3; ++axis) {
-    const double* X = RAW + (size_t)axis * L;
-    __syncthreads();
-    for (int i = tid; i < n2; i += nthr) {
+  double* ekey = (double*)carve((size_t)n2 * 8, gf);                      // n2 <= 4L
+  int* epos = (int*)carve((size_t)n2 * 4, gi);                            // n2 <= 4L
+  double* exv = (double*)carve((size_t)nc * 8, gf + 4 * (size_t)L);     // X of the event, sorted order
+  double* rs_w = (double*)carve((size_t)nc * 8, gf + 6 * (size_t)L);    // running dot_weights_consensus
+  double* rs_xw = (double*)carve((size_t)nc * 8, gf + 8 * (size_t)L);   // running dot_X_weights
+  double* rs_rng = (double*)carve((size_t)nc * 8, gf + 10 * (size_t)L); // running ranges_inverse_sum
+  double* rs_x = (double*)carve((size_t)nc * 8, gf + 12 * (size_t)L);   // running sum_xi
+  double* rs_xx = (double*)carve((size_t)nc * 8, gf + 14 * (size_t)L);  // running sum_xi_square
+  double* xhat = (double*)carve((size_t)nc * 8, gf + 16 * (size_t)L);
+  double* xcost = (double*)carve((size_t)nc * 8, gf + 18 * (size_t)L);
+  int* card = (int*)carve((size_t)nc * 4, gi + 4 * (size_t)L);
+  __shared__ double s_axis_est[3], s_va[3], s_vb[3];
+  __shared__ int s_axis_ncard[3], s_axis_mi[3];
+  const double* X = RAW + (size_t)axc * L;
+  __syncthreads();  // GNC arrays in LDS are dead from here on
+  if (act) {
+    for (int i = lane; i < n2; i += 64) {
       if (i < nc) {
         const int p = i >> 1;
         ekey[i] = (i & 1) ? X[p] + range : X[p] - range;
-        epos[i] = i;
       } else {
         ekey[i] = INFINITY;
-        epos[i] = i;
+      }
+      epos[i] = i;
+    }
+  }
+  // bitonic sort, ascending by (key, pos); every wave runs the same barrier sequence
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      if (act) {
+        for (int i = lane; i < n2; i += 64) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const double ka = ekey[i], kb = ekey[ixj];
+            const int pa = epos[i], pb = epos[ixj];
+            const bool a_gt_b = (ka > kb) || (ka == kb && pa > pb);
+            const bool up = ((i & k) == 0);
+            if (a_gt_b == up) {
+              ekey[i] = kb;
+              ekey[ixj] = ka;
+              epos[i] = pb;
+              epos[ixj] = pa;
+            }
+          }
+        }
       }
     }
-    bitonic_sort_events(ekey, epos, n2, tid, nthr);
-    for (int i = tid; i < nc; i += nthr) exv[i] = X[epos[i] >> 1];
-    __syncthreads();
-    if (tid == 0) {
-      const double weight = 1.0 / (range * range);
-      double ranges_inverse_sum = 0;
-      for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
-      double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
-      int consensus = 0;
-      for (int i = 0; i < nc; ++i) {
-        const int eps = (epos[i] & 1) ? -1 : 1;
-        const double xv = exv[i];
-        consensus += eps;
-        dot_weights_consensus += eps * weight;
-        dot_X_weights += eps * weight * xv;
-        ranges_inverse_sum -= eps * range;
-        sum_xi += eps * xv;
-        sum_xi_square += eps * xv * xv;
-        card[i] = consensus;
-        rs_w[i] = dot_weights_consensus;
-        rs_xw[i] = dot_X_weights;
-        rs_rng[i] = ranges_inverse_sum;
-        rs_x[i] = sum_xi;
-        rs_xx[i] = sum_xi_square;
-      }
+  }
+  __syncthreads();
+  if (act)
+    for (int i = lane; i < nc; i += 64) exv[i] = X[epos[i] >> 1];
+  __syncthreads();
+  if (act && lane == 0) {
+    const double weight = 1.0 / (range * range);
+    double ranges_inverse_sum = 0;
+    for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
+    double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
+    int consensus = 0;
+    for (int i = 0; i < nc; ++i) {
+      const int eps = (epos[i] & 1) ? -1 : 1;
+      const double xv = exv[i];
+      consensus += eps;
+      dot_weights_consensus += eps * weight;
+      dot_X_weights += eps * weight * xv;
+      ranges_inverse_sum -= eps * range;
+      sum_xi += eps * xv;
+      sum_xi_square += eps * xv * xv;
+      card[i] = consensus;
+      rs_w[i] = dot_weights_consensus;
+      rs_xw[i] = dot_X_weights;
+      rs_rng[i] = ranges_inverse_sum;
+      rs_x[i] = sum_xi;
+      rs_xx[i] = sum_xi_square;
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (act) {
     // per-event estimate and cost, then arg-min (first strict minimum; NaN is never selected unless first)
     double bc = INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < nc; i += nthr) {
+    for (int i = lane; i < nc; i += 64) {
       const double xh = rs_xw[i] / rs_w[i];
       xhat[i] = xh;
       const double residual = card[i] * xh * xh + rs_xx[i] - 2 * rs_x[i] * xh;
@@ -759,50 +922,50 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
       }
     }
     if (lane == 0) {
-      s_red_c[wave] = bc;
-      s_red_i[wave] = bi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double c = s_red_c[0];
-      int mi = s_red_i[0];
-      for (int w = 1; w < 4; ++w)
-        if (s_red_c[w] < c || (s_red_c[w] == c && s_red_i[w] < mi)) {
-          c = s_red_c[w];
-          mi = s_red_i[w];
-        }
+      int mi = bi;
       if (mi == 0x7fffffff || xcost[0] != xcost[0]) mi = 0;
-      s_minidx = mi;
-      s_ncard = card[mi];
-      s_est = xhat[mi];
-      s_va = 0;
-      s_vb = 0;
+      s_axis_mi[ax] = mi;
+      s_axis_ncard[ax] = card[mi];
+      s_axis_est[ax] = xhat[mi];
+      s_va[ax] = 0;
+      s_vb[ax] = 0;
     }
-    __syncthreads();
-    const int mi = s_minidx, ncard = s_ncard;
+  }
+  __syncthreads();
+  if (act) {
+    const int mi = s_axis_mi[ax], ncard = s_axis_ncard[ax];
     if (A.prm.cote_median && ncard >= 2) {
       // the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}
       const int ra = ncard / 2 - 1, rb = ncard / 2;
-      for (int j = tid; j < ncard; j += nthr) {
+      for (int j = lane; j < ncard; j += 64) {
         const double vj = exv[mi - j];
         int rk = 0;
         for (int q = 0; q < ncard; ++q) {
           const double vq = exv[mi - q];
           rk += (vq < vj) || (vq == vj && q < j);
         }
-        if (rk == ra) s_va = vj;
-        if (rk == rb) s_vb = vj;
+        if (rk == ra) s_va[ax] = vj;
+        if (rk == rb) s_vb[ax] = vj;
       }
-      __syncthreads();
-      if (tid == 0) s_est = (s_va + s_vb) / 2.0;
-    } else if (A.prm.cote_median && ncard == 1) {
-      if (tid == 0) s_est = exv[mi];
     }
-    __syncthreads();
-    const double est = s_est;
-    tr[axis] = est;
-    for (int i = tid; i < N; i += nthr) inl[i] = inl[i] && (fabs(X[i] - est) <= range);
-    if (tid == 0) res->n_card[axis] = ncard;
+  }
+  __syncthreads();
+  if (act && lane == 0) {
+    const int ncard = s_axis_ncard[ax];
+    if (A.prm.cote_median && ncard >= 2)
+      s_axis_est[ax] = (s_va[ax] + s_vb[ax]) / 2.0;
+    else if (A.prm.cote_median && ncard == 1)
+      s_axis_est[ax] = exv[s_axis_mi[ax]];
+    res->n_card[ax] = ncard;
+  }
+  __syncthreads();
+  double tr[3] = {s_axis_est[0], s_axis_est[1], s_axis_est[2]};
+  unsigned char* inl = (unsigned char*)(A.i32 + 1 * (size_t)L);  // N bytes
+  for (int i = tid; i < N; i += nthr) {
+    bool in = true;
+#pragma unroll
+    for (int a3 = 0; a3 < 3; ++a3) in = in && (fabs(RAW[(size_t)a3 * L + i] - tr[a3]) <= range);
+    inl[i] = in ? 1 : 0;
   }
   __syncthreads();
   // ---- final inliers (:914-930) and the 4x4
@@ -841,6 +1004,10 @@ hipError_t solver_init_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_kcore_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_clique_first_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 size_t solver_scratch_bytes(int Lcap) {
@@ -849,8 +1016,8 @@ size_t solver_scratch_bytes(int Lcap) {
   b += 2 * (size_t)Lcap * W * 8;        // bm, adjP
   b += 8 * (size_t)Lcap * 4;            // deg, core, perm, rankof, Kp, picks, gsz, (spare)
   b += 3 * (size_t)Lcap * 4;            // clique, rot_inl, final_inl
-  b += 28 * (size_t)Lcap * 8;           // f64
-  b += 8 * (size_t)Lcap * 4;            // i32
+  b += 72 * (size_t)Lcap * 8;           // f64
+  b += 24 * (size_t)Lcap * 4;           // i32
   b += W * 8 + 4096;
   b += (size_t)CLIQUE_BATCH * Lcap * 4;  // picks_buf
   return b;
@@ -877,8 +1044,8 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
   B.clique = (int*)take((size_t)Lcap * 4);
   B.rot_inl = (int*)take((size_t)Lcap * 4);
   B.final_inl = (int*)take((size_t)Lcap * 4);
-  B.f64 = (double*)take(28 * (size_t)Lcap * 8);
-  B.i32 = (int*)take(8 * (size_t)Lcap * 4);
+  B.f64 = (double*)take(72 * (size_t)Lcap * 8);
+  B.i32 = (int*)take(24 * (size_t)Lcap * 4);
   B.member_bits = (u64*)take(W * 8);
   B.picks_buf = (int*)take((size_t)CLIQUE_BATCH * Lcap * 4);
   B.st = (SolverState*)take(sizeof(SolverState));
@@ -902,10 +1069,16 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
+    const bool kc_single_wave = (L <= 64 * KCW_JMAX) && (bm_bytes + 64 <= (size_t)150 * 1024);
+    if (kc_single_wave) {
+      hipLaunchKernelGGL(k_kcore_wave, dim3(1), dim3(64), bm_bytes + 64, stream, B.bm, L, W, B.deg, B.core,
+                         B.st);
+    } else {
     const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
     const int kc_threads = 1024;
     hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
                        B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
+    }
     hipLaunchKernelGGL(k_rank, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.perm, B.rankof, B.Kp);
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
     hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
@@ -917,7 +1090,11 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     if (heuristic) {
       const int BATCH = CLIQUE_BATCH;
       // round 0: the single top-ranked start; round 1..: BATCH starts each
-      hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
+      if ((size_t)L * W * 8 <= (size_t)150 * 1024)
+        hipLaunchKernelGGL(k_clique_first_lds, dim3(1), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W, B.st,
+                           B.gsz, B.picks_buf);
+      else
+        hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
       hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
       int guard = 0;

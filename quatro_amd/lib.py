@@ -19,6 +19,7 @@ INLIER_PMC_EXACT, INLIER_PMC_HEU, INLIER_KCORE_HEU, INLIER_NONE = range(4)
 
 DBG_GRAPH_BITMAP, DBG_CORE, DBG_PERM, DBG_NBR_OFFSETS, DBG_NBR_INDEX, DBG_NBR_DIST2, DBG_SPFH = 1, 2, 3, 4, 5, 6, 7
 DBG_NN_LARGE_OF_SMALL, DBG_NN_SMALL_OF_LARGE, DBG_VOX_SRC, DBG_VOX_TGT, DBG_CORR, DBG_MATCH_STATS = 8, 9, 10, 11, 12, 13
+DBG_SOLVER_STATE = 14
 
 
 class Limits(C.Structure):
