@@ -200,7 +200,14 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, s.ev[2], s.ev[3]));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 128, s.sb.st, sizeof(SolverState), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if (L > 0 && !((const SolverState*)(s.pinned_i32 + 128))->done) {  // rare: more clique rounds needed
+    QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
+    QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
+    QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  }
   const int keep_ns = res->n_src, keep_nt = res->n_tgt, keep_nc = res->n_corr;
   *res = *s.pinned_res;
   res->n_src = keep_ns;
@@ -296,7 +303,11 @@ int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, 
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   CloudBufs& cb = s.fb.cloud[0];
-  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, cb, d_in, P, leaf, s.stream));
+  {
+    const float4* raws[1] = {d_in};
+    const int Ps[1] = {P};
+    QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 1, raws, Ps, leaf, s.stream));
+  }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -349,7 +360,10 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   QTR_HIP_TRY(h, hipMemsetAsync(cb.counts, 0, 16 * sizeof(int), s.stream));
   QTR_HIP_TRY(h, set_count_enqueue(cb, CNT_NVOX, n, s.stream));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
-  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, cb, n, r_normal, r_fpfh, s.stream));
+  {
+    const int ns1[1] = {n};
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream));
+  }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -445,16 +459,17 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     d_t = s.in_tgt;
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
-  // the target cloud's front end runs on the slot's second stream, concurrently with the source's
-  QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev[0], 0));
+  // both clouds go through every front-end kernel together (blockIdx.y = cloud)
   CloudBufs& cs = s.fb.cloud[0];
   CloudBufs& ct = s.fb.cloud[1];
-  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, cs, d_s, Ps, fp->voxel_size, s.stream));
-  QTR_HIP_TRY(h, voxelize_enqueue(s.fb, ct, d_t, Pt, fp->voxel_size, s.stream2));
+  {
+    const float4* raws[2] = {d_s, d_t};
+    const int Ps2[2] = {Ps, Pt};
+    QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream));
+  }
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cs.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 16, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream2));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 16, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream2));
   int ns = s.pinned_i32[CNT_NVOX], nt = s.pinned_i32[16 + CNT_NVOX];
   if (s.pinned_i32[CNT_VOX_OVERFLOW] || s.pinned_i32[16 + CNT_VOX_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
@@ -469,10 +484,10 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   s.last_ns = ns;
   s.last_nt = nt;
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
-  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, cs, ns, fp->normal_radius, fp->fpfh_radius, s.stream));
-  QTR_HIP_TRY(h, fpfh_enqueue(s.fb, ct, nt, fp->normal_radius, fp->fpfh_radius, s.stream2));
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
-  QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
+  {
+    const int n2[2] = {ns, nt};
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream));
+  }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L);

@@ -60,12 +60,11 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels);
 void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels);
 hipError_t frontend_init_attributes();
 
-hipError_t voxelize_enqueue(FrontBufs& F, CloudBufs& C, const float4* in, int P, float leaf, hipStream_t st);
+hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st);
 hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st);
-hipError_t fpfh_enqueue(FrontBufs& F, CloudBufs& C, int n, float r_normal, float r_fpfh, hipStream_t st);
+hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st);
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
 
 // shared small kernels (defined in frontend.hip)
-hipError_t radix_sort_u64_hi(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st, u64** sorted_out);
 hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st);  // out has n+1 entries

@@ -34,7 +34,7 @@ __global__ void k_set_count(int* counts, int which, int value) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counts[which] = value;
 }
 
-__global__ __launch_bounds__(256) void k_minmax(const float4* __restrict__ pts, int n, u32* __restrict__ mm) {
+__device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, u32* __restrict__ mm) {
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 p = pts[i];
@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void k_minmax(const float4* __restrict__ pts, 
 // point index on inputs that are already in ascending point-index order, so equal cells keep ascending
 // point order — the accumulation order the oracle defines for pcl::VoxelGrid centroids.
 template <int BITS, int TILE>
-__global__ __launch_bounds__(64) void k_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
+__device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
                                                    int nblk) {
   constexpr int NB = 1 << BITS;
   __shared__ u32 cnt[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
+  if (blk >= nblk) return;
   for (int d = lane; d < NB; d += 64) cnt[d] = 0;
   __syncthreads();
   const int base = blk * TILE;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64) void k_radix_hist(const u64* __restrict__ in, i
 }
 
 // exclusive scan of m 32-bit counters by one workgroup (m up to a few hundred thousand)
-__global__ __launch_bounds__(1024) void k_scan_u32(u32* __restrict__ data, int m, u32* __restrict__ total_out) {
+__device__ __forceinline__ void d_scan_u32(u32* __restrict__ data, int m, u32* __restrict__ total_out) {
   __shared__ u32 wsum[16];
   __shared__ u32 carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,11 +135,12 @@ __global__ __launch_bounds__(1024) void k_scan_u32(u32* __restrict__ data, int m
 }
 
 template <int BITS, int TILE>
-__global__ __launch_bounds__(64) void k_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
+__device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
                                                       int shift, const u32* __restrict__ hist, int nblk) {
   constexpr int NB = 1 << BITS;
   __shared__ u32 base[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
+  if (blk >= nblk) return;
   for (int d = lane; d < NB; d += 64) base[d] = hist[d * nblk + blk];
   __syncthreads();
   const int tbase = blk * TILE;
@@ -164,33 +166,7 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const u64* __restrict__ in
   }
 }
 
-template <int BITS, int TILE>
-static hipError_t radix_sort_impl(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st,
-                                  u64** sorted_out) {
-  const int nblk = (n + TILE - 1) / TILE;
-  u64 *src = keys_a, *dst = keys_b;
-  for (int shift = 32; shift < 32 + key_bits; shift += BITS) {
-    hipLaunchKernelGGL((k_radix_hist<BITS, TILE>), dim3(nblk), dim3(64), 0, st, src, n, shift, hist, nblk);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, hist, (1 << BITS) * nblk, (u32*)nullptr);
-    hipLaunchKernelGGL((k_radix_scatter<BITS, TILE>), dim3(nblk), dim3(64), 0, st, src, dst, n, shift, hist, nblk);
-    u64* t = src;
-    src = dst;
-    dst = t;
-  }
-  *sorted_out = src;
-  return hipGetLastError();
-}
-
-// key_bits = 32: four 8-bit passes (voxel indices); key_bits = 24: three (cell keys)
-hipError_t radix_sort_u64_hi(u64* keys_a, u64* keys_b, u32* hist, int n, int key_bits, hipStream_t st,
-                             u64** sorted_out) {
-  // 8-bit digits on 1024-element single-wave tiles measured fastest on MI355X for 10^4..10^5 keys: wider
-  // digits (11/12 bits) need fewer passes but their 4096-element tiles serialise 4x more steps per wave
-  // and were 2x slower overall (profiles/r1e_kernel_stats.txt).
-  return radix_sort_impl<8, RADIX_TILE>(keys_a, keys_b, hist, n, key_bits <= 24 ? 24 : 32, st, sorted_out);
-}
-
-__global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
+__device__ __forceinline__ void d_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
   // out[0..n] = exclusive scan of in[0..n) ; single workgroup
   __shared__ int wsum[16];
   __shared__ int carry_s;
@@ -213,14 +189,6 @@ __global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ 
   }
   if (tid == 0) out[n] = carry_s;
 }
-
-hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st) {
-  hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, in, out, n);
-  return hipGetLastError();
-}
-
-__global__ void k_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted, int n,
-                                float4* __restrict__ spts);
 
 // =================================================================================================
 // K1  pcl::VoxelGrid::applyFilter restated
@@ -247,7 +215,7 @@ __device__ __forceinline__ VoxGrid vox_grid(const u32* mm, float leaf) {
   return g;
 }
 
-__global__ __launch_bounds__(256) void k_vox_keys(const float4* __restrict__ pts, int P, float leaf,
+__device__ __forceinline__ void d_vox_keys(const float4* __restrict__ pts, int P, float leaf,
                                                   const u32* __restrict__ mm, u64* __restrict__ keys,
                                                   int* __restrict__ counts) {
   const VoxGrid g = vox_grid(mm, leaf);
@@ -264,8 +232,9 @@ __global__ __launch_bounds__(256) void k_vox_keys(const float4* __restrict__ pts
 }
 
 // heads per 1024-element block
-__global__ __launch_bounds__(256) void k_vox_headcount(const u64* __restrict__ keys, int P, int* __restrict__ blkcnt) {
+__device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, int P, int* __restrict__ blkcnt) {
   __shared__ int s;
+  if ((long long)blockIdx.x * 1024 >= P) return;
   if (threadIdx.x == 0) s = 0;
   __syncthreads();
   int c = 0;
@@ -286,12 +255,13 @@ __global__ __launch_bounds__(256) void k_vox_headcount(const u64* __restrict__ k
 // LDS instead of one HBM/L2 round trip per element; only runs longer than the halo touch global memory.
 #define VOX_TILE 1024
 #define VOX_HALO 512
-__global__ __launch_bounds__(256) void k_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
+__device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
                                                        int P, const int* __restrict__ blkoff, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts) {
   __shared__ u32 s_cell[VOX_TILE + VOX_HALO + 1];
   __shared__ float s_x[VOX_TILE + VOX_HALO], s_y[VOX_TILE + VOX_HALO], s_z[VOX_TILE + VOX_HALO];
   __shared__ int wtot[4];
+  if (blockIdx.x >= nblk) return;
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * VOX_TILE;
   int running = blkoff[blockIdx.x];
@@ -350,29 +320,6 @@ __global__ __launch_bounds__(256) void k_vox_centroids(const u64* __restrict__ k
   }
 }
 
-hipError_t voxelize_enqueue(FrontBufs& F, CloudBufs& C, const float4* in, int P, float leaf, hipStream_t st) {
-  hipLaunchKernelGGL(k_cloud_init, dim3(1), dim3(64), 0, st, C.counts, C.mm);
-  const int g = min(1024, (P + 255) / 256);
-  hipLaunchKernelGGL(k_minmax, dim3(min(g, 128)), dim3(256), 0, st, in, P, C.mm);
-  hipLaunchKernelGGL(k_vox_keys, dim3(g), dim3(256), 0, st, in, P, leaf, C.mm, C.keys_a, C.counts);
-  u64* sorted = nullptr;
-  hipError_t e = radix_sort_u64_hi(C.keys_a, C.keys_b, C.hist, P, 32, st, &sorted);
-  if (e != hipSuccess) return e;
-  const int nblk = (P + 1023) / 1024;
-  int* blkcnt = (int*)C.hist;            // radix histograms are dead now
-  int* blkoff = blkcnt + nblk + 8;
-  hipLaunchKernelGGL(k_vox_headcount, dim3(nblk), dim3(256), 0, st, sorted, P, blkcnt);
-  hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, blkcnt, blkoff, nblk);
-  hipLaunchKernelGGL(k_vox_centroids, dim3(nblk), dim3(256), 0, st, sorted, in, P, blkoff, C.vox, F.max_voxels, nblk,
-                     C.counts);
-  return hipGetLastError();
-}
-
-hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st) {
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, st, C.counts, which, value);
-  return hipGetLastError();
-}
-
 // =================================================================================================
 // Radius-neighbour lists.  Semantics of pcl::search::KdTree::radiusSearch (FLANN RadiusResultSet,
 // sorted): d2 = ((dx^2)+dy^2)+dz^2 in float with the query first, kept iff d2 < float(r*r), sorted by
@@ -388,7 +335,7 @@ __device__ __forceinline__ void cell_of(const CellGrid& g, const float4& p, int*
 }
 __device__ __forceinline__ u32 cell_key(int cx, int cy, int cz) { return ((u32)cz << 16) | ((u32)cy << 8) | (u32)cx; }
 
-__global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pts, int n, const u32* __restrict__ mm,
+__device__ __forceinline__ void d_cell_keys(const float4* __restrict__ pts, int n, const u32* __restrict__ mm,
                                                    float cell, u64* __restrict__ keys) {
   CellGrid g;
   g.mn[0] = dec_f32(mm[0]);
@@ -416,7 +363,7 @@ __device__ __forceinline__ int lower_bound_hi(const u64* keys, int n, u32 k) {  
 
 // points gathered into cell-sorted order (w carries the original index) so that candidate loads are
 // contiguous 16-byte reads instead of a dependent key -> point gather
-__global__ __launch_bounds__(256) void k_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted,
+__device__ __forceinline__ void d_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted,
                                                        int n, float4* __restrict__ spts) {
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const u32 j = (u32)sorted[t];
@@ -428,7 +375,7 @@ __global__ __launch_bounds__(256) void k_sorted_points(const float4* __restrict_
 
 // the nine contiguous key ranges (rows cy-1..cy+1 x cz-1..cz+1, cells cx-1..cx+1) of every query point:
 // one thread per (point, range) so the binary searches of the whole cloud overlap
-__global__ __launch_bounds__(256) void k_ranges(const float4* __restrict__ pts, int n, const u64* __restrict__ sorted,
+__device__ __forceinline__ void d_ranges(const float4* __restrict__ pts, int n, const u64* __restrict__ sorted,
                                                 const u32* __restrict__ mm, float cell, int* __restrict__ ranges) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * 9) return;
@@ -452,7 +399,7 @@ __global__ __launch_bounds__(256) void k_ranges(const float4* __restrict__ pts, 
 }
 
 // one wavefront (= one workgroup) per query point
-__global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts, int n, const float4* __restrict__ spts,
+__device__ __forceinline__ void d_neighbors(const float4* __restrict__ pts, int n, const float4* __restrict__ spts,
                                                   const int* __restrict__ ranges, float r2,
                                                   int* __restrict__ nbr_cnt, int* __restrict__ nbr_idx,
                                                   float* __restrict__ nbr_d2, int* __restrict__ counts) {
@@ -460,6 +407,7 @@ __global__ __launch_bounds__(64) void k_neighbors(const float4* __restrict__ pts
   __shared__ int rs[9], pre[10];
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
+  if (i >= n) return;
   const float4 p = pts[i];
   {
     int len = 0, s = 0;
@@ -595,7 +543,7 @@ __device__ __forceinline__ void dev_cross(const float* a, const float* b, float*
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-__global__ __launch_bounds__(256) void k_normals(const float4* __restrict__ pts, int n, const int* __restrict__ nbr_cnt,
+__device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n, const int* __restrict__ nbr_cnt,
                                                  const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
                                                  float rn2, float4* __restrict__ normals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -742,11 +690,12 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   return true;
 }
 
-__global__ __launch_bounds__(64) void k_spfh(const float4* __restrict__ pts, const float4* __restrict__ normals, int n,
+__device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const float4* __restrict__ normals, int n,
                                              const int* __restrict__ nbr_cnt, const int* __restrict__ nbr_idx,
                                              float* __restrict__ spfh) {
   __shared__ int cnt[33];
   const int lane = threadIdx.x, i = blockIdx.x;
+  if (i >= n) return;
   if (lane < 33) cnt[lane] = 0;
   __syncthreads();
   const int k = nbr_cnt[i];
@@ -775,13 +724,14 @@ __global__ __launch_bounds__(64) void k_spfh(const float4* __restrict__ pts, con
 // neighbours' contributions in list order; lanes 33..35 own the three binary64 normalisation sums,
 // each adding its 11 per-neighbour terms in the reference's nested (neighbour, bin) order.
 #define FPFH_CHUNK 16
-__global__ __launch_bounds__(64) void k_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
+__device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
                                              const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
                                              float* __restrict__ fpfh) {
   __shared__ float rows[FPFH_CHUNK][33];
   __shared__ float wts[FPFH_CHUNK];
   __shared__ double sums[3];
   const int lane = threadIdx.x, i = blockIdx.x;
+  if (i >= n) return;
   const int k = nbr_cnt[i];
   float h = 0.f;
   double sum = 0.0;
@@ -830,7 +780,7 @@ __global__ __launch_bounds__(64) void k_fpfh(const float* __restrict__ spfh, int
 // but out of LDS: the other waves of the workgroup stream the cloud into a double-buffered SoA tile
 // with coalesced 16-byte loads while the chain runs, which removes the HBM/L2 latency from the chain.
 #define MEAN_CHUNK 2048
-__global__ __launch_bounds__(256) void k_seq_mean(const float4* __restrict__ pts, int n, float* __restrict__ mean) {
+__device__ __forceinline__ void d_seq_mean(const float4* __restrict__ pts, int n, float* __restrict__ mean) {
   __shared__ __attribute__((aligned(16))) float buf[2][3][MEAN_CHUNK];
   const int tid = threadIdx.x;
   const int nchunks = (n + MEAN_CHUNK - 1) / MEAN_CHUNK;
@@ -877,29 +827,231 @@ __global__ __launch_bounds__(256) void k_seq_mean(const float4* __restrict__ pts
   if (tid < 3) mean[tid] = m / (float)n;
 }
 
-hipError_t fpfh_enqueue(FrontBufs& F, CloudBufs& C, int n, float r_normal, float r_fpfh, hipStream_t st) {
-  // grid over the cloud (bounding box, cell keys, sort)
-  hipLaunchKernelGGL(k_cloud_init, dim3(1), dim3(64), 0, st, C.counts + 8, C.mm);  // keeps counts[0..7]
-  const int g = min(1024, (n + 255) / 256);
-  hipLaunchKernelGGL(k_minmax, dim3(min(g, 128)), dim3(256), 0, st, C.vox, n, C.mm);
+// =================================================================================================
+// Two-cloud batched launches.  The front end always has two clouds (source, target) of similar size and a
+// chain of ~35 small dependent kernels each; one launch serves both (blockIdx.y = cloud), which halves the
+// dispatch count on the critical path and doubles the work per dispatch.  A CloudView carries one cloud's
+// pointers and sizes; kernels pick theirs with blockIdx.y.
+struct CloudView {
+  const float4* raw;   // raw scan (voxelise)
+  int P;               // raw points
+  int n;               // voxel count (known on the host after the voxelise read-back)
+  int nblk;            // radix tiles of the array being sorted
+  int nblk_vox;        // 1024-element tiles of the sorted raw scan
+  int* counts;
+  u32* mm;
+  float4* vox;
+  float4* normals;
+  float* spfh;
+  float* fpfh;
+  const u64* keys_in;  // ping-pong roles of the current radix pass
+  u64* keys_out;
+  u32* hist;
+  int* blkcnt;
+  int* blkoff;
+  int* nbr_cnt;
+  int* nbr_off;
+  int* nbr_idx;
+  float* nbr_d2;
+  float4* spts;
+  int* ranges;
+  float* mean;
+};
+struct Clouds2 {
+  CloudView c[2];
+};
+
+__global__ void k2_cloud_init(Clouds2 a, int keep_counts) {
+  const CloudView& C = a.c[blockIdx.y];
+  const int t = threadIdx.x;
+  if (!keep_counts && t < 16) C.counts[t] = 0;
+  if (t < 3) C.mm[t] = 0xffffffffu;
+  if (t >= 3 && t < 6) C.mm[t] = 0u;
+}
+__global__ __launch_bounds__(256) void k2_minmax(Clouds2 a, int use_vox) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm);
+}
+__global__ __launch_bounds__(256) void k2_vox_keys(Clouds2 a, float leaf) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_vox_keys(C.raw, C.P, leaf, C.mm, C.keys_out, C.counts);
+}
+__global__ __launch_bounds__(256) void k2_cell_keys(Clouds2 a, float cell) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_cell_keys(C.vox, C.n, C.mm, cell, C.keys_out);
+}
+__global__ __launch_bounds__(64) void k2_radix_hist(Clouds2 a, int use_vox, int shift) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_radix_hist<8, RADIX_TILE>(C.keys_in, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
+}
+__global__ __launch_bounds__(1024) void k2_radix_scan(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_scan_u32(C.hist, 256 * C.nblk, (u32*)nullptr);
+}
+__global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_radix_scatter<8, RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
+}
+__global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_vox_headcount(C.keys_in, C.P, C.blkcnt);
+}
+__global__ __launch_bounds__(1024) void k2_vox_blockscan(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_scan_i32_copy(C.blkcnt, C.blkoff, C.nblk_vox);
+}
+__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts);
+}
+__global__ __launch_bounds__(256) void k2_sorted_points(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_sorted_points(C.vox, C.keys_in, C.n, C.spts);
+}
+__global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_ranges(C.vox, C.n, C.keys_in, C.mm, cell, C.ranges);
+}
+__global__ __launch_bounds__(64) void k2_neighbors(Clouds2 a, float r2) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_neighbors(C.vox, C.n, C.spts, C.ranges, r2, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.counts);
+}
+__global__ __launch_bounds__(1024) void k2_nbr_scan(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_scan_i32_copy(C.nbr_cnt, C.nbr_off, C.n);
+}
+__global__ __launch_bounds__(256) void k2_normals(Clouds2 a, float rn2) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_normals(C.vox, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2, C.normals);
+}
+__global__ __launch_bounds__(64) void k2_spfh(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, C.nbr_idx, C.spfh);
+}
+__global__ __launch_bounds__(64) void k2_fpfh(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_fpfh(C.spfh, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
+}
+__global__ __launch_bounds__(256) void k2_seq_mean(Clouds2 a) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_seq_mean(C.vox, C.n, C.mean);
+}
+__global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
+  d_scan_i32_copy(in, out, n);
+}
+
+hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, in, out, n);
+  return hipGetLastError();
+}
+
+static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
+  CloudView v;
+  memset(&v, 0, sizeof(v));
+  v.raw = raw;
+  v.P = P;
+  v.n = n;
+  v.counts = C.counts;
+  v.mm = C.mm;
+  v.vox = C.vox;
+  v.normals = C.normals;
+  v.spfh = C.spfh;
+  v.fpfh = C.fpfh;
+  v.hist = C.hist;
+  v.nbr_cnt = C.nbr_cnt;
+  v.nbr_off = C.nbr_off;
+  v.nbr_idx = C.nbr_idx;
+  v.nbr_d2 = C.nbr_d2;
+  v.spts = C.spts;
+  v.ranges = C.ranges;
+  v.mean = C.mean;
+  return v;
+}
+
+// stable LSD radix sort of keys_a (both clouds) by bits [32, 32+key_bits); returns which buffer holds the result
+static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st) {
+  int maxblk = 1;
+  for (int c = 0; c < nc; ++c) {
+    const int n = use_vox ? a.c[c].n : a.c[c].P;
+    a.c[c].nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
+    if (a.c[c].nblk > maxblk) maxblk = a.c[c].nblk;
+  }
+  int src = 0;  // 0: keys_a holds the input
+  for (int shift = 32; shift < 32 + key_bits; shift += 8) {
+    for (int c = 0; c < nc; ++c) {
+      a.c[c].keys_in = src == 0 ? C[c]->keys_a : C[c]->keys_b;
+      a.c[c].keys_out = src == 0 ? C[c]->keys_b : C[c]->keys_a;
+    }
+    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    hipLaunchKernelGGL(k2_radix_scan, dim3(1, nc), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    src ^= 1;
+  }
+  return src;
+}
+
+// voxel-grid down-sampling of nc (1 or 2) raw clouds
+hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st) {
+  Clouds2 a;
+  CloudBufs* C[2] = {&F.cloud[0], &F.cloud[nc > 1 ? 1 : 0]};
+  int maxP = 1;
+  for (int c = 0; c < nc; ++c) {
+    a.c[c] = make_view(*C[c], raw[c], P[c], 0);
+    a.c[c].keys_out = C[c]->keys_a;
+    a.c[c].nblk_vox = (P[c] + 1023) / 1024;
+    a.c[c].blkcnt = (int*)C[c]->hist;
+    a.c[c].blkoff = a.c[c].blkcnt + a.c[c].nblk_vox + 8;
+    if (P[c] > maxP) maxP = P[c];
+  }
+  if (nc == 1) a.c[1] = a.c[0];
+  const int g = min(1024, (maxP + 255) / 256);
+  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 0);
+  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, a, leaf);
+  const int where = radix_sort2(a, C, nc, 0, 32, st);
+  for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
+  if (nc == 1) a.c[1] = a.c[0];
+  const int nblk = (maxP + 1023) / 1024;
+  hipLaunchKernelGGL(k2_vox_headcount, dim3(nblk, nc), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k2_vox_blockscan, dim3(1, nc), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, a, F.max_voxels);
+  return hipGetLastError();
+}
+
+hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st) {
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, st, C.counts, which, value);
+  return hipGetLastError();
+}
+
+// normals + SPFH + FPFH (+ the matcher's sequential mean) of nc (1 or 2) clouds held in F.cloud[first + c]
+hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st) {
+  Clouds2 a;
+  CloudBufs* C[2] = {&F.cloud[first], &F.cloud[nc > 1 ? first + 1 : first]};
+  int maxn = 1;
+  for (int c = 0; c < nc; ++c) {
+    a.c[c] = make_view(*C[c], nullptr, 0, n[c]);
+    a.c[c].keys_out = C[c]->keys_a;
+    if (n[c] > maxn) maxn = n[c];
+  }
+  if (nc == 1) a.c[1] = a.c[0];
+  const int g = min(1024, (maxn + 255) / 256);
   const float cell = r_fpfh * 1.001f;
-  hipLaunchKernelGGL(k_cell_keys, dim3(g), dim3(256), 0, st, C.vox, n, C.mm, cell, C.keys_a);
-  u64* sorted = nullptr;
-  hipError_t e = radix_sort_u64_hi(C.keys_a, C.keys_b, C.hist, n, 24, st, &sorted);
-  if (e != hipSuccess) return e;
   const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
   const float rn2 = (float)((double)r_normal * (double)r_normal);
-  int* ranges = C.ranges;
-  hipLaunchKernelGGL(k_sorted_points, dim3(g), dim3(256), 0, st, C.vox, sorted, n, C.spts);
-  hipLaunchKernelGGL(k_ranges, dim3((9 * n + 255) / 256), dim3(256), 0, st, C.vox, n, sorted, C.mm, cell, ranges);
-  hipLaunchKernelGGL(k_neighbors, dim3(n), dim3(64), 0, st, C.vox, n, C.spts, ranges, r2, C.nbr_cnt, C.nbr_idx,
-                     C.nbr_d2, C.counts);
-  hipLaunchKernelGGL(k_scan_i32_copy, dim3(1), dim3(1024), 0, st, C.nbr_cnt, C.nbr_off, n);
-  hipLaunchKernelGGL(k_normals, dim3((n + 255) / 256), dim3(256), 0, st, C.vox, n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2,
-                     C.normals);
-  hipLaunchKernelGGL(k_spfh, dim3(n), dim3(64), 0, st, C.vox, C.normals, n, C.nbr_cnt, C.nbr_idx, C.spfh);
-  hipLaunchKernelGGL(k_fpfh, dim3(n), dim3(64), 0, st, C.spfh, n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
-  hipLaunchKernelGGL(k_seq_mean, dim3(1), dim3(256), 0, st, C.vox, n, C.mean);
+  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 1);  // keeps the counters of the voxel stage
+  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 1);
+  hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, a, cell);
+  const int where = radix_sort2(a, C, nc, 1, 24, st);
+  for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
+  if (nc == 1) a.c[1] = a.c[0];
+  hipLaunchKernelGGL(k2_sorted_points, dim3(g, nc), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, a, cell);
+  hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, a, r2);
+  hipLaunchKernelGGL(k2_nbr_scan, dim3(1, nc), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, a, rn2);
+  hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k2_fpfh, dim3(maxn, nc), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -111,7 +111,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // desc[n][33] -> baseT[34][n_pad] (row 33 = |b|^2; pad rows get 1e30 so they never win) and
 // queryT[34][n_pad] (-2 * desc, row 33 = 1); also the norms (binary64 sum rounded once) and the
 // largest norm (as ordered bits).
-__global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ desc, int n, int n_pad,
+__device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int n, int n_pad,
                                                    float* __restrict__ baseT, float* __restrict__ queryT,
                                                    float* __restrict__ norms, u32* __restrict__ max_norm_bits) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -141,6 +141,15 @@ __global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ des
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, off, 64));
   if (qk_lane() == 0 && nrm > 0.f) atomicMax(max_norm_bits, __float_as_uint(nrm));
+}
+
+__global__ __launch_bounds__(256) void k_desc_prep2(const float* d0, int n0, int p0, float* bT0, float* qT0, float* nr0,
+                                                    u32* mx0, const float* d1, int n1, int p1, float* bT1, float* qT1,
+                                                    float* nr1, u32* mx1) {
+  if (blockIdx.y == 0)
+    d_desc_prep(d0, n0, p0, bT0, qT0, nr0, mx0);
+  else
+    d_desc_prep(d1, n1, p1, bT1, qT1, nr1, mx1);
 }
 
 // best and second-best approximate distance of a query over one base slice (index of the best only)
@@ -309,6 +318,80 @@ __global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__
   }
 }
 
+// one launch instead of six memsets/fills: counters, norm maxima, tuple-test flags, source->target table
+__global__ __launch_bounds__(256) void k_match_init(int* __restrict__ mcounts, int swapped, u32* __restrict__ mx0,
+                                                    u32* __restrict__ mx1, int* __restrict__ passed, int n_passed,
+                                                    int passed_value, int* __restrict__ tgt_of_src, int ns,
+                                                    u64* __restrict__ best_small, int n_small,
+                                                    u64* __restrict__ best_large, int n_large, int fill_best) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  if (gid < 16) mcounts[gid] = (gid == MC_SWAPPED) ? swapped : 0;
+  if (gid == 16) *mx0 = 0u;
+  if (gid == 17) *mx1 = 0u;
+  for (int i = gid; i < n_passed; i += gsz) passed[i] = passed_value;
+  for (int i = gid; i < ns; i += gsz) tgt_of_src[i] = -1;
+  if (fill_best) {
+    for (int i = gid; i < n_small; i += gsz) best_small[i] = ~0ULL;
+    for (int i = gid; i < n_large; i += gsz) best_large[i] = ~0ULL;
+  }
+}
+
+// unpack both NN tables and evaluate the mutual-NN test in one pass
+__global__ __launch_bounds__(256) void k_cross_flags2(const u64* __restrict__ best_large,
+                                                      const u64* __restrict__ best_small, int n_large, int n_small,
+                                                      int* __restrict__ nn_of_large, int* __restrict__ nn_of_small,
+                                                      int* __restrict__ flags) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  for (int j = gid; j < n_small; j += gsz) {
+    const u64 b = best_small[j];
+    nn_of_small[j] = (b == ~0ULL) ? 0 : (int)(u32)b;
+  }
+  for (int i = gid; i < n_large; i += gsz) {
+    const u64 b = best_large[i];
+    const int j = (b == ~0ULL) ? 0 : (int)(u32)b;
+    nn_of_large[i] = j;
+    const u64 bs = best_small[j];
+    const int back = (bs == ~0ULL) ? 0 : (int)(u32)bs;
+    flags[i] = (back == i) ? 1 : 0;
+  }
+}
+
+// exclusive scan of the predicate (in[i] >= 0), one workgroup; out has n+1 entries
+__global__ __launch_bounds__(1024) void k_scan_nonneg(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < n && in[i] >= 0) ? 1 : 0;
+    int tot;
+    const int ex = wave_excl_scan_i32(v, &tot);
+    if (lane == 63) wsum[wave] = tot;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (i < n) out[i] = carry_s + woff + ex;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry_s + woff + ex + v;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+__global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restrict__ tgt_of_src, int ns,
+                                int* __restrict__ corr, int* __restrict__ mcounts) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    const int t = tgt_of_src[s];
+    if (t >= 0) {
+      corr[2 * scan[s]] = s;
+      corr[2 * scan[s] + 1] = t;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) mcounts[MC_NCORR] = scan[ns];
+}
+
 // cross-check flags over the larger cloud (index i): keep iff NN_small(i) = j and NN_large(j) = i
 __global__ void k_cross_flags(const int* __restrict__ nn_of_large, const int* __restrict__ nn_of_small, int n_large,
                               int* __restrict__ flags) {
@@ -436,24 +519,24 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
   CloudBufs& Ci = F.cloud[swapped ? 1 : 0];
   CloudBufs& Cj = F.cloud[swapped ? 0 : 1];
   const int n_large = swapped ? nt : ns, n_small = swapped ? ns : nt;
-  hipError_t e;
-  if ((e = hipMemsetAsync(F.mcounts, 0, 16 * sizeof(int), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, F.mcounts + MC_SWAPPED, 1, swapped);
-  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, ~0ULL);
-  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, ~0ULL);
+  const int maxc = n_small;  // cross-checked pairs <= n_small
+  const bool tuple = fp.use_tuple_test && fp.tuple_scale != 0;
+  hipLaunchKernelGGL(k_match_init, dim3(grid_for(n_large)), dim3(256), 0, st, F.mcounts, swapped, Ci.max_norm,
+                     Cj.max_norm, F.passed, maxc, tuple ? 0 : 1, F.tgt_of_src, ns, F.best_small, n_small, F.best_large,
+                     n_large, F.nn_engine == 0 ? 1 : 0);
   // K5: NN of every small-cloud descriptor in the large cloud, and of every large-cloud descriptor in
   // the small cloud (the reference queries the latter lazily for hit rows only; the mutual test below
   // only ever reads hit rows, so the result is the same)
-  auto nsplit = [](int nq, int nb) {
-    int blocks_x = (nq + 255) / 256;
-    int s = (1024 + blocks_x - 1) / blocks_x;
-    int maxs = (nb + NN_TILE - 1) / NN_TILE;
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
-    return s;
-  };
   if (F.nn_engine == 0) {
+    auto nsplit = [](int nq, int nb) {
+      int blocks_x = (nq + 255) / 256;
+      int s = (1024 + blocks_x - 1) / blocks_x;
+      int maxs = (nb + NN_TILE - 1) / NN_TILE;
+      if (s > maxs) s = maxs;
+      if (s < 1) s = 1;
+      if (s > 256) s = 256;
+      return s;
+    };
     if (F.ev_nn[0]) (void)hipEventRecord(F.ev_nn[0], st);
     hipLaunchKernelGGL(k_nn_exact, dim3((n_small + 255) / 256, nsplit(n_small, n_large)), dim3(256), 0, st, Cj.fpfh,
                        n_small, Ci.fpfh, n_large, F.best_small, (const int*)nullptr, 0);
@@ -464,26 +547,23 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     if (F.ev_nn[3]) (void)hipEventRecord(F.ev_nn[3], st);
   } else {
     const int pad_small = (n_small + NN_QPB - 1) / NN_QPB * NN_QPB, pad_large = (n_large + NN_QPB - 1) / NN_QPB * NN_QPB;
-    if ((e = hipMemsetAsync(Ci.max_norm, 0, 4, st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(Cj.max_norm, 0, 4, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_desc_prep, dim3(pad_large / 256), dim3(256), 0, st, Ci.fpfh, n_large, pad_large, Ci.baseT,
-                       Ci.queryT, Ci.norms, Ci.max_norm);
-    hipLaunchKernelGGL(k_desc_prep, dim3(pad_small / 256), dim3(256), 0, st, Cj.fpfh, n_small, pad_small, Cj.baseT,
-                       Cj.queryT, Cj.norms, Cj.max_norm);
+    hipLaunchKernelGGL(k_desc_prep2, dim3(pad_large / 256, 2), dim3(256), 0, st, Ci.fpfh, n_large, pad_large, Ci.baseT,
+                       Ci.queryT, Ci.norms, Ci.max_norm, Cj.fpfh, n_small, pad_small, Cj.baseT, Cj.queryT, Cj.norms,
+                       Cj.max_norm);
     auto run_dir = [&](CloudBufs& Q, int nq, int nq_pad, CloudBufs& Bc, int nb, int nb_pad, u64* best, int mc_slot,
                        hipEvent_t ev0, hipEvent_t ev1) {
       const int ntiles = nb_pad / 32;
-      int ns = (2048 + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
-      if (ns > 32) ns = 32;
-      if (ns > ntiles) ns = ntiles;
-      if (ns < 1) ns = 1;
-      const int tps = (ntiles + ns - 1) / ns;
-      ns = (ntiles + tps - 1) / tps;
+      int ns_ = (2048 + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
+      if (ns_ > 32) ns_ = 32;
+      if (ns_ > ntiles) ns_ = ntiles;
+      if (ns_ < 1) ns_ = 1;
+      const int tps = (ntiles + ns_ - 1) / ns_;
+      ns_ = (ntiles + tps - 1) / tps;
       if (ev0) (void)hipEventRecord(ev0, st);
-      hipLaunchKernelGGL(k_nn_mfma, dim3(nq_pad / NN_QPB, ns), dim3(256), 0, st, Bc.baseT, nb_pad, Q.queryT, nq_pad, tps,
+      hipLaunchKernelGGL(k_nn_mfma, dim3(nq_pad / NN_QPB, ns_), dim3(256), 0, st, Bc.baseT, nb_pad, Q.queryT, nq_pad, tps,
                          (NnPartial*)F.nn_partial);
       if (ev1) (void)hipEventRecord(ev1, st);
-      hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns,
+      hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns_,
                          nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.mcounts + mc_slot);
       int ey = (nb + 1023) / 1024;  // >= 4 base rows per thread and slice
       if (ey > 16) ey = 16;
@@ -494,31 +574,22 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, F.ev_nn[0], F.ev_nn[1]);
     run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, F.ev_nn[2], F.ev_nn[3]);
   }
-  hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_small)), dim3(256), 0, st, F.best_small, n_small, F.nn_of_small);
-  hipLaunchKernelGGL(k_nn_unpack, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, n_large, F.nn_of_large);
   // K6 cross-check -> pairs in ascending i
-  hipLaunchKernelGGL(k_cross_flags, dim3(grid_for(n_large)), dim3(256), 0, st, F.nn_of_large, F.nn_of_small, n_large,
-                     F.flags);
+  hipError_t e;
+  hipLaunchKernelGGL(k_cross_flags2, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, F.best_small, n_large,
+                     n_small, F.nn_of_large, F.nn_of_small, F.flags);
   if ((e = exclusive_scan_i32(F.flags, F.scan, n_large, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_cross_compact, dim3(grid_for(n_large)), dim3(256), 0, st, F.flags, F.scan, F.nn_of_large,
                      n_large, F.cross_i, F.cross_j, F.mcounts);
   // K7 tuple test
-  const int maxc = n_small;  // cross-checked pairs <= n_small
-  if (fp.use_tuple_test && fp.tuple_scale != 0) {
-    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(maxc)), dim3(256), 0, st, F.passed, maxc, 0);
+  if (tuple)
     hipLaunchKernelGGL(k_tuple, dim3(2048), dim3(256), 0, st, Ci.vox, Ci.mean, Cj.vox, Cj.mean, F.cross_i, F.cross_j,
                        F.mcounts, fp.tuple_scale, (u64)fp.seed, F.passed);
-  } else {
-    hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(maxc)), dim3(256), 0, st, F.passed, maxc, 1);
-  }
   // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
-  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(ns)), dim3(256), 0, st, F.tgt_of_src, ns, -1);
   hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(maxc)), dim3(256), 0, st, F.cross_i, F.cross_j, F.passed,
                      F.mcounts, swapped, F.tgt_of_src, F.mcounts);
-  hipLaunchKernelGGL(k_src_flags, dim3(grid_for(ns)), dim3(256), 0, st, F.tgt_of_src, ns, F.flags);
-  if ((e = exclusive_scan_i32(F.flags, F.scan, ns, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_corr_compact, dim3(grid_for(ns)), dim3(256), 0, st, F.flags, F.scan, F.tgt_of_src, ns, F.corr,
-                     F.mcounts);
+  hipLaunchKernelGGL(k_scan_nonneg, dim3(1), dim3(1024), 0, st, F.tgt_of_src, F.scan, ns);
+  hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr, F.mcounts);
   return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-#define CLIQUE_BATCH 256
+#define CLIQUE_BATCH 1024
 
 struct SolverState {  // device resident; mirrored to pinned host memory between clique rounds
   int mc;        // best clique size so far (pmc_heu's `mc`)
@@ -38,3 +38,5 @@ void solver_carve(SolverBufs& B, void* base, int Lcap);
 hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                           hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique);
 hipError_t solver_init_attributes();
+hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                           hipStream_t stream, int* pinned_state);

@@ -402,20 +402,28 @@ __global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ ad
 // Round 0 of the heuristic is a single start (the top-ranked vertex) whose greedy descent is one long
 // dependent chain (one row AND per clique member).  When the rank-labelled bit matrix fits in LDS the
 // chain runs out of LDS (~100 cycles per step instead of an L2 round trip).
-__global__ __launch_bounds__(256) void k_clique_first_lds(const u64* __restrict__ adjP, const int* __restrict__ Kp,
+__global__ __launch_bounds__(256) void k_clique_batch_lds(const u64* __restrict__ adjP, const int* __restrict__ Kp,
                                                           int L, int W, const SolverState* __restrict__ st,
                                                           int* __restrict__ gsz, int* __restrict__ picks_buf) {
   extern __shared__ __attribute__((aligned(16))) u64 cl_rows[];
   if (st->done) return;
+  const int lane = qk_lane();
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int batch = st->batch;
+  if (blockIdx.x * 4 >= batch) return;
+  // any start of this workgroup worth descending from?  (uniform per block after the vote below)
+  const int r = st->pos - wid;
+  const bool want = (wid < batch) && (r >= 0) && (Kp[r] > st->mc);
+  if (!__syncthreads_or(want ? 1 : 0)) {
+    if (lane == 0 && wid < batch) gsz[wid] = 0;
+    return;
+  }
 #pragma unroll 4
   for (int e = threadIdx.x; e < L * W; e += 256) cl_rows[e] = adjP[e];
   __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  const int r = st->pos;
   int g = 0;
-  if (r >= 0 && Kp[r] > st->mc) g = greedy_dispatch(cl_rows, W, r, st->t0, lane, picks_buf);
-  if (lane == 0) gsz[0] = g;
+  if (want) g = greedy_dispatch(cl_rows, W, r, st->t0, lane, picks_buf + (size_t)wid * L);
+  if (lane == 0 && wid < batch) gsz[wid] = g;
 }
 
 // Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
@@ -1006,7 +1014,7 @@ hipError_t solver_init_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_kcore_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_clique_first_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  e = hipFuncSetAttribute((const void*)k_clique_batch_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
@@ -1052,6 +1060,51 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
   B.res = (qtr_result*)take(sizeof(qtr_result));
 }
 
+static void launch_finalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                            hipStream_t stream) {
+  const int W = (L + 63) / 64;
+  FinalizeArgs A;
+  A.src = src;
+  A.tgt = tgt;
+  A.adjP = B.adjP;
+  A.perm = B.perm;
+  A.L = L;
+  A.W = W;
+  A.prm = prm;
+  A.st = B.st;
+  A.member_bits = B.member_bits;
+  A.picks = B.picks;
+  A.clique = B.clique;
+  A.rot_inl = B.rot_inl;
+  A.final_inl = B.final_inl;
+  A.f64 = B.f64;
+  A.i32 = B.i32;
+  A.res = B.res;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), (size_t)FIN_LDS_BYTES, stream, A);
+}
+
+// Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host
+// check per round) and the finalisation again.
+hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                           hipStream_t stream, int* pinned_state) {
+  const int W = (L + 63) / 64;
+  hipError_t e;
+  int guard = 0;
+  while (true) {
+    hipLaunchKernelGGL(k_clique_batch, dim3(CLIQUE_BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
+                       B.picks_buf);
+    hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, CLIQUE_BATCH,
+                       B.picks_buf, B.picks);
+    if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+      return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if (((const SolverState*)pinned_state)->done) break;
+    if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
+  }
+  launch_finalize(B, src, tgt, L, prm, stream);
+  return hipGetLastError();
+}
+
 // Enqueues the whole back end on `stream`.  L is known on the host.  Returns a HIP error code.
 // The clique heuristic normally terminates after the first two batches (see header comment of
 // k_clique_batch); `*host_done` (pinned) is polled between further rounds.
@@ -1090,47 +1143,28 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     if (heuristic) {
       const int BATCH = CLIQUE_BATCH;
       // round 0: the single top-ranked start; round 1..: BATCH starts each
-      if ((size_t)L * W * 8 <= (size_t)150 * 1024)
-        hipLaunchKernelGGL(k_clique_first_lds, dim3(1), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W, B.st,
+      const bool lds_rows = (size_t)L * W * 8 <= (size_t)150 * 1024;
+      if (lds_rows)
+        hipLaunchKernelGGL(k_clique_batch_lds, dim3(1), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W, B.st,
                            B.gsz, B.picks_buf);
       else
         hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
       hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
-      int guard = 0;
-      while (true) {
+      // Rounds 0 and 1 are enqueued unconditionally: the heuristic nearly always terminates within them (the
+      // first start finds the large clique, the second batch only confirms that no start can beat it).  The
+      // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
+      if (lds_rows)
+        hipLaunchKernelGGL(k_clique_batch_lds, dim3(BATCH / 4), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W,
+                           B.st, B.gsz, B.picks_buf);
+      else
         hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
                            B.picks_buf);
-        hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
+      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
-        if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) !=
-            hipSuccess)
-          return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const SolverState* hs = (const SolverState*)pinned_state;
-        if (hs->done) break;
-        if (++guard > (L / BATCH) + 4) break;  // cannot happen: pos decreases by BATCH per round
-      }
     }
   }
   if (ev_clique) hipEventRecord(ev_clique, stream);
-  FinalizeArgs A;
-  A.src = src;
-  A.tgt = tgt;
-  A.adjP = B.adjP;
-  A.perm = B.perm;
-  A.L = L;
-  A.W = W;
-  A.prm = prm;
-  A.st = B.st;
-  A.member_bits = B.member_bits;
-  A.picks = B.picks;
-  A.clique = B.clique;
-  A.rot_inl = B.rot_inl;
-  A.final_inl = B.final_inl;
-  A.f64 = B.f64;
-  A.i32 = B.i32;
-  A.res = B.res;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), (size_t)FIN_LDS_BYTES, stream, A);
+  launch_finalize(B, src, tgt, L, prm, stream);
   return hipGetLastError();
 }
