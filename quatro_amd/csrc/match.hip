@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256) void k_nn_mfma_finish(const NnPartial* __restr
 // exact re-decision of the listed rows: workgroup (x, y) scans base slice y for row x (grid-strided over
 // the list, whose length is read on the device); thread t evaluates base rows t, t+256, ... with the
 // exact flann::L2 arithmetic; a block arg-min feeds one packed 64-bit atomicMin per (row, slice).
-__global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__ A, const float* __restrict__ B, int nB,
-                                                       u64* __restrict__ best, const int* __restrict__ rows,
-                                                       const int* __restrict__ nrows_p) {
+__global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__ A, const float* __restrict__ BT,
+                                                       int nB, int nb_pad, u64* __restrict__ best,
+                                                       const int* __restrict__ rows, const int* __restrict__ nrows_p) {
   __shared__ float a_s[36];
   __shared__ u64 wbest[4];
   const int nrows = *nrows_p;
@@ -299,7 +299,18 @@ __global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__
     for (int t = 0; t < 33; ++t) a[t] = a_s[t];
     u64 mine = ~0ULL;
     for (int b = b0 + threadIdx.x; b < b1; b += 256) {
-      const float d = l2_flann33_g(a, B + (size_t)b * 33);
+      // base descriptors come from the k-major table: consecutive threads read consecutive addresses
+      float result = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float d0 = a[4 * g] - BT[(size_t)(4 * g) * nb_pad + b], d1 = a[4 * g + 1] - BT[(size_t)(4 * g + 1) * nb_pad + b],
+                    d2 = a[4 * g + 2] - BT[(size_t)(4 * g + 2) * nb_pad + b],
+                    d3 = a[4 * g + 3] - BT[(size_t)(4 * g + 3) * nb_pad + b];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+      const float dt = a[32] - BT[(size_t)32 * nb_pad + b];
+      result += dt * dt;
+      const float d = result;
       const u64 key = ((u64)__float_as_uint(d) << 32) | (u32)b;
       mine = key < mine ? key : mine;
     }
@@ -565,11 +576,11 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
       if (ev1) (void)hipEventRecord(ev1, st);
       hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns_,
                          nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.mcounts + mc_slot);
-      int ey = (nb + 1023) / 1024;  // >= 4 base rows per thread and slice
-      if (ey > 16) ey = 16;
+      int ey = (nb + 511) / 512;  // 2 base rows per thread and slice
+      if (ey > 32) ey = 32;
       if (ey < 1) ey = 1;
-      hipLaunchKernelGGL(k_nn_exact_rows, dim3(256, ey), dim3(256), 0, st, Q.fpfh, Bc.fpfh, nb, best, F.recheck_rows,
-                         F.mcounts + mc_slot);
+      hipLaunchKernelGGL(k_nn_exact_rows, dim3(256, ey), dim3(256), 0, st, Q.fpfh, Bc.baseT, nb, nb_pad, best,
+                         F.recheck_rows, F.mcounts + mc_slot);
     };
     run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, F.ev_nn[0], F.ev_nn[1]);
     run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, F.ev_nn[2], F.ev_nn[3]);

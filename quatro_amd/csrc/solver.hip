@@ -189,24 +189,31 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
 // ops per word, no atomics, no barriers, no per-round memory round trips.
 #define KCW_JMAX 18  // 64 * 18 = 1152 vertices
 #define KCW_GONE 0x3fffffff  // degree of a removed (or non-existent) vertex
-__global__ __launch_bounds__(64) void k_kcore_wave(const u64* __restrict__ bm, int L, int W,
+__global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, int L, int W,
                                                    const int* __restrict__ deg_in, int* __restrict__ core_out,
                                                    SolverState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) u64 kcw_rows[];
-  const int lane = threadIdx.x;
+  // all four waves stage the bit matrix; wave 0 alone runs the peeling
 #pragma unroll 8
-  for (int e = lane; e < L * W; e += 64) kcw_rows[e] = bm[e];
+  for (int e = threadIdx.x; e < L * W; e += 256) kcw_rows[e] = bm[e];
+  const int lane = threadIdx.x & 63;
   int dreg[KCW_JMAX], creg[KCW_JMAX];
   int esum = 0;
+  if (threadIdx.x < 64) {
+    int dl[KCW_JMAX];
 #pragma unroll
-  for (int j = 0; j < KCW_JMAX; ++j) {
-    const int v = j * 64 + lane;
-    dreg[j] = (v < L) ? deg_in[v] : KCW_GONE;
-    creg[j] = 0;
-    if (v < L) esum += dreg[j];
+    for (int j = 0; j < KCW_JMAX; ++j) dl[j] = deg_in[min(j * 64 + lane, L - 1)];  // one burst of independent loads
+#pragma unroll
+    for (int j = 0; j < KCW_JMAX; ++j) {
+      const bool in = j * 64 + lane < L;
+      dreg[j] = in ? dl[j] : KCW_GONE;
+      creg[j] = 0;
+      esum += in ? dl[j] : 0;
+    }
+    esum = wave_sum_i32(esum);
   }
-  esum = wave_sum_i32(esum);
   __syncthreads();
+  if (threadIdx.x >= 64) return;
   int k = -1, maxcore = 0, rounds = 0;
   const u32* rows32 = (const u32*)kcw_rows;
   const int halfsel = lane >> 5, bitsel = lane & 31;
@@ -351,11 +358,22 @@ __device__ __forceinline__ int greedy_descent(const u64* __restrict__ adjP, int 
   }
   int depth = 1;
   while (true) {
-    int hb = -1;
+    // highest set bit of the wave-distributed bitset: ballot per slot (highest slot first), then scalar
+    // reads of the winning lane's word — no cross-lane reduction network on the dependent chain
+    int u = -1;
 #pragma unroll
-    for (int s = WPL - 1; s >= 0; --s)
-      if (hb < 0 && cur[s]) hb = (s * 64 + lane) * 64 + 63 - __clzll((long long)cur[s]);
-    const int u = wave_max_i32(hb);
+    for (int s = WPL - 1; s >= 0; --s) {
+      if (u < 0) {
+        const u64 nz = __ballot(cur[s] != 0);
+        if (nz) {
+          const int l = 63 - __clzll((long long)nz);
+          const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)cur[s], l);
+          const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(cur[s] >> 32), l);
+          const u64 word = ((u64)hi << 32) | lo;
+          u = (s * 64 + l) * 64 + 63 - __clzll((long long)word);
+        }
+      }
+    }
     if (u < 0) break;
     if (picks && lane == 0) picks[depth - 1] = u;
     ++depth;
@@ -578,6 +596,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   SolverState* st = A.st;
   qtr_result* res = A.res;
   const int mc = st->mc;
+  const long long t_fin0 = clock64();
 
   // ---- clique members -> bitset in ORIGINAL labels -> sorted id list
   if (st->best_r != -2) {
@@ -667,6 +686,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
 
+  const long long t_fin1 = clock64();
   // ---- GNC-TLS (wavefront 0), reference :430-572
   if (wave == 0) {
     const double rot_nb = A.prm.noise_bound * (2 / 1.0);
@@ -746,6 +766,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
 
+  const long long t_fin2 = clock64();
   // ---- rotation (yaw block, optional R * RyRx :419-423), rotation inliers (:857-874)
   double R[9] = {s_R[0], s_R[1], 0, s_R[2], s_R[3], 0, 0, 0, 1};
   if (A.prm.using_pre_estimated_ryrx) {
@@ -800,6 +821,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
 
+  const long long t_fin3 = clock64();
   // ---- COTE (reference estimate(), :618-747).  The three axes are independent: wavefront a handles axis a
   // (wave 3 only joins the barriers).  Per axis: (1) bitonic sort of the 2N interval endpoints by
   // (value, insertion position), (2) ONE lane walks the events accumulating the five running sums in the
@@ -990,6 +1012,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
   if (tid == 0) {
+    const long long t_fin4 = clock64();
+    st->pad[1] = (int)((t_fin1 - t_fin0) >> 4);
+    st->pad[2] = (int)((t_fin2 - t_fin1) >> 4);
+    st->pad[3] = (int)((t_fin3 - t_fin2) >> 4);
+    st->pad[4] = (int)((t_fin4 - t_fin3) >> 4);
     for (int r = 0; r < 3; ++r) {
       for (int c = 0; c < 3; ++c) res->T[4 * r + c] = R[3 * r + c];
       res->T[4 * r + 3] = tr[r];
@@ -1124,7 +1151,7 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     const size_t bm_bytes = (size_t)L * W * 8;
     const bool kc_single_wave = (L <= 64 * KCW_JMAX) && (bm_bytes + 64 <= (size_t)150 * 1024);
     if (kc_single_wave) {
-      hipLaunchKernelGGL(k_kcore_wave, dim3(1), dim3(64), bm_bytes + 64, stream, B.bm, L, W, B.deg, B.core,
+      hipLaunchKernelGGL(k_kcore_wave, dim3(1), dim3(256), bm_bytes + 64, stream, B.bm, L, W, B.deg, B.core,
                          B.st);
     } else {
     const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
