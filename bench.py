@@ -41,6 +41,9 @@ def main() -> None:
     ap.add_argument("--workload", default="kitti64_pair", choices=["kitti64_pair", "solver5k"])
     ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through per rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--stream-slots", type=int, default=4,
+                    help="extra (untimed-for-`value`) leg: the same K steps with this many pairs in flight on "
+                         "independent stream slots of one GPU (BASELINE configs[2] style); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -109,6 +112,45 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     elapsed = qdist.max_over_ranks(elapsed, dev)
 
+    # ---- extra leg: several pairs in flight per GPU (one host thread + one stream slot each).  Reported next to
+    # `value`, never as `value`: configs[1] is the single-pair workload.
+    multi = None
+    if args.stream_slots > 1 and args.workload == "kitti64_pair":
+        import threading
+        S = args.stream_slots
+        hm = ql.Handle(local_rank, n_slots=S)
+        results = [ql.Result() for _ in range(S)]
+
+        def worker(slot, count):
+            for k in range(count):
+                p = pool[(slot + k * S) % len(pool)]
+                rc = hm.register_pair_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
+                                          p["fp"], prm, results[slot], slot)
+                if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+                    raise ql.QuatroHipError(rc, hm.last_error())
+
+        def run(total):
+            per = [(total + S - 1 - i) // S for i in range(S)]
+            th = [threading.Thread(target=worker, args=(i, per[i])) for i in range(S)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+
+        run(max(S, args.warmup))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tm0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tm = qdist.max_over_ranks(time.perf_counter() - tm0, dev)
+        multi = {"stream_slots": S, "steps": args.steps, "value": world * args.steps / tm, "unit": "registrations/s",
+                 "ms_per_step": 1e3 * tm / args.steps}
+        hm.close()
+
     # ---- result records of the pool, gathered on rank 0 (the path's only collective)
     recs = []
     for p in pool:
@@ -144,6 +186,8 @@ def main() -> None:
         },
         "stage_ms": {k: round(v / args.steps, 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
     }
+    if multi is not None:
+        out["pairs_in_flight_leg"] = multi
     if args.workload == "kitti64_pair":
         ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
         out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]

@@ -151,25 +151,16 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
       maxcore = k;
       // (frontier vertex, word) items are independent: flattened over all threads so that the row loads
       // of a round overlap instead of forming one latency chain per wave
-      // each wave fetches 64 (frontier vertex, word) items at once (64 independent loads in flight), then
-      // walks the non-zero words with one lane per bit: conflict-free LDS atomics
-      const int nwaves = nthr >> 6, wave = tid >> 6;
-      for (int base = wave * 64; base < n * W; base += nwaves * 64) {
-        const int item = base + lane;
-        u64 xs = 0;
-        int wj = 0;
-        if (item < n * W) {
-          const int qi = item / W;
-          wj = item - qi * W;
-          xs = rows[(size_t)queue[qi] * W + wj];
-        }
-        u64 nz = __ballot(xs != 0);
-        while (nz) {
-          const int t = __ffsll((long long)nz) - 1;
-          nz &= nz - 1;
-          const u64 x = __shfl(xs, t, 64);
-          const int w = __shfl(wj, t, 64);
-          if ((x >> lane) & 1ULL) atomicSub(&deg[w * 64 + lane], 1);
+      // (frontier vertex, word) items are independent: flattened over all threads so that the row loads of
+      // a round overlap; each lane walks the set bits of its word (up to 64 conflict-tolerant LDS atomics per
+      // step across the wave, whatever the density)
+      for (int item = tid; item < n * W; item += nthr) {
+        const int qi = item / W, w = item - qi * W;
+        u64 x = rows[(size_t)queue[qi] * W + w];
+        while (x) {
+          const int b = __ffsll((long long)x) - 1;
+          x &= x - 1;
+          atomicSub(&deg[w * 64 + b], 1);
         }
       }
     }
@@ -290,26 +281,33 @@ __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, 
 // K12b: rank of every vertex in the (core, id) ascending order; perm[rank] = vertex; Kp[rank] = core+1
 // (PMC's "kcore" value).  This single order serves both as the outer start order of the heuristic
 // (traversed from the back) and as the greedy pick order (highest rank = max (K, id)).
-__global__ __launch_bounds__(256) void k_rank(const int* __restrict__ core, int L, int* __restrict__ perm,
-                                               int* __restrict__ rankof, int* __restrict__ Kp) {
+__global__ __launch_bounds__(256) void k_rank_partial(const int* __restrict__ core, int L, int* __restrict__ rankof) {
+  // grid (ceil(L/256), slices): thread = vertex v, blockIdx.y = slice of the comparison range
   __shared__ int tile[1024];
   const int v = blockIdx.x * 256 + threadIdx.x;
   const int c = v < L ? core[v] : 0;
+  const int per = ((L + gridDim.y - 1) / gridDim.y + 1023) / 1024 * 1024;
+  const int u0 = blockIdx.y * per, u1 = min(L, u0 + per);
   int r = 0;
-  for (int base = 0; base < L; base += 1024) {
+  for (int base = u0; base < u1; base += 1024) {
     __syncthreads();
-    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (base + t < L) ? core[base + t] : 0x7fffffff;
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (base + t < u1) ? core[base + t] : 0x7fffffff;
     __syncthreads();
-    const int lim = min(1024, L - base);
+    const int lim = min(1024, u1 - base);
     for (int t = 0; t < lim; ++t) {
       const int cu = tile[t], u = base + t;
       r += (cu < c) || (cu == c && u < v);
     }
   }
+  if (v < L && r) atomicAdd(&rankof[v], r);
+}
+__global__ __launch_bounds__(256) void k_rank_finish(const int* __restrict__ core, int L, const int* __restrict__ rankof,
+                                                      int* __restrict__ perm, int* __restrict__ Kp) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
   if (v < L) {
+    const int r = rankof[v];
     perm[r] = v;
-    rankof[v] = r;
-    Kp[r] = c + 1;
+    Kp[r] = core[v] + 1;
   }
 }
 
@@ -562,29 +560,176 @@ struct FinalizeArgs {
   qtr_result* res;   // device copy of the result record
 };
 
-__device__ void bitonic_sort_events(double* key, int* pos, int n2, int tid, int nthr) {
-  // ascending by (key, pos); n2 power of two; +inf padding sorts last
+// One COTE axis on one wavefront (reference estimate(), include/quatro.hpp:618-747).  Called by all four
+// waves of the workgroup with identical N / n2 so that the barriers match; `act` is false for the wave
+// that only keeps the barriers company.  __forceinline__ on purpose: at the LDS call site the pointers
+// derive directly from the dynamic shared array, so address-space inference turns every access into a
+// ds_* instruction (the generic-pointer version ran ~10x slower through the flat path).
+struct CoteOut {
+  double est;
+  int ncard;
+};
+__device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* __restrict__ X, int N, int nc, int n2,
+                                             double range, int median_sel, double* ekey, int* epos, double* exv,
+                                             double* rs_w /* may alias ekey: dead after the sort */, double* rs_xw,
+                                             double* rs_rng, double* rs_x, double* rs_xx, int* card,
+                                             double* s_bcast /* [4] per axis */) {
+  if (act) {
+    for (int i = lane; i < n2; i += 64) {
+      if (i < nc) {
+        const int p = i >> 1;
+        ekey[i] = (i & 1) ? X[p] + range : X[p] - range;
+      } else {
+        ekey[i] = INFINITY;
+      }
+      epos[i] = i;
+    }
+  }
+  // bitonic sort, ascending by (key, pos); every wave runs the same barrier sequence
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      for (int i = tid; i < n2; i += nthr) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const double a = key[i], b = key[ixj];
-          const int pa = pos[i], pb = pos[ixj];
-          const bool a_gt_b = (a > b) || (a == b && pa > pb);
-          const bool up = ((i & k) == 0);
-          if (a_gt_b == up) {
-            key[i] = b;
-            key[ixj] = a;
-            pos[i] = pb;
-            pos[ixj] = pa;
+      if (act) {
+        for (int i = lane; i < n2; i += 64) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const double ka = ekey[i], kb = ekey[ixj];
+            const int pa = epos[i], pb = epos[ixj];
+            const bool a_gt_b = (ka > kb) || (ka == kb && pa > pb);
+            const bool up = ((i & k) == 0);
+            if (a_gt_b == up) {
+              ekey[i] = kb;
+              ekey[ixj] = ka;
+              epos[i] = pb;
+              epos[ixj] = pa;
+            }
           }
         }
       }
     }
   }
   __syncthreads();
+  if (act)
+    for (int i = lane; i < nc; i += 64) {
+      const int p = epos[i];
+      // signed event value: the sweep needs eps and X only through eps*w, eps*w*X, eps*range, eps*X, eps*X*X
+      exv[i] = X[p >> 1];
+    }
+  __syncthreads();
+  if (act && lane == 0) {
+    // ONE lane walks the events accumulating the running sums in the reference's order (binary64 addition
+    // is not associative); loads are issued four events ahead of the dependent additions
+    const double weight = 1.0 / (range * range);
+    double ranges_inverse_sum = 0;
+    for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
+    double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
+    int consensus = 0;
+    int i = 0;
+    for (; i + 4 <= nc; i += 4) {
+      int ep[4];
+      double xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ep[q] = epos[i + q];
+        xv[q] = exv[i + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int eps = (ep[q] & 1) ? -1 : 1;
+        consensus += eps;
+        dot_weights_consensus += eps * weight;
+        dot_X_weights += eps * weight * xv[q];
+        ranges_inverse_sum -= eps * range;
+        sum_xi += eps * xv[q];
+        sum_xi_square += eps * xv[q] * xv[q];
+        card[i + q] = consensus;
+        rs_w[i + q] = dot_weights_consensus;
+        rs_xw[i + q] = dot_X_weights;
+        rs_rng[i + q] = ranges_inverse_sum;
+        rs_x[i + q] = sum_xi;
+        rs_xx[i + q] = sum_xi_square;
+      }
+    }
+    for (; i < nc; ++i) {
+      const int eps = (epos[i] & 1) ? -1 : 1;
+      const double xv = exv[i];
+      consensus += eps;
+      dot_weights_consensus += eps * weight;
+      dot_X_weights += eps * weight * xv;
+      ranges_inverse_sum -= eps * range;
+      sum_xi += eps * xv;
+      sum_xi_square += eps * xv * xv;
+      card[i] = consensus;
+      rs_w[i] = dot_weights_consensus;
+      rs_xw[i] = dot_X_weights;
+      rs_rng[i] = ranges_inverse_sum;
+      rs_x[i] = sum_xi;
+      rs_xx[i] = sum_xi_square;
+    }
+  }
+  __syncthreads();
+  int mi = 0, ncard = 0;
+  double est = 0;
+  if (act) {
+    // per-event estimate and cost, then arg-min (first strict minimum; NaN is never selected unless first)
+    double bc = INFINITY;
+    int bi = 0x7fffffff;
+    double c0 = 0;
+    for (int i = lane; i < nc; i += 64) {
+      const double xh = rs_xw[i] / rs_w[i];
+      const double residual = card[i] * xh * xh + rs_xx[i] - 2 * rs_x[i] * xh;
+      const double c = residual + rs_rng[i];
+      if (i == 0) c0 = c;
+      if (c < bc || (c == bc && i < bi)) {
+        bc = c;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double oc = __shfl_xor(bc, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (oc < bc || (oc == bc && oi < bi)) {
+        bc = oc;
+        bi = oi;
+      }
+    }
+    mi = bi;
+    c0 = __shfl(c0, 0, 64);
+    if (mi == 0x7fffffff || c0 != c0) mi = 0;
+    ncard = card[mi];
+    est = rs_xw[mi] / rs_w[mi];
+    if (lane == 0) {
+      s_bcast[0] = 0;
+      s_bcast[1] = 0;
+    }
+  }
+  __syncthreads();
+  if (act && median_sel && ncard >= 2) {
+    // the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}, by rank counting
+    const int ra = ncard / 2 - 1, rb = ncard / 2;
+    for (int j = lane; j < ncard; j += 64) {
+      const double vj = exv[mi - j];
+      int rk = 0;
+      for (int q = 0; q < ncard; ++q) {
+        const double vq = exv[mi - q];
+        rk += (vq < vj) || (vq == vj && q < j);
+      }
+      if (rk == ra) s_bcast[0] = vj;
+      if (rk == rb) s_bcast[1] = vj;
+    }
+  }
+  __syncthreads();
+  if (act && median_sel) {
+    if (ncard >= 2)
+      est = (s_bcast[0] + s_bcast[1]) / 2.0;
+    else if (ncard == 1)
+      est = exv[mi];
+  }
+  CoteOut o;
+  o.est = est;
+  o.ncard = ncard;
+  return o;
 }
 
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
@@ -824,9 +969,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   const long long t_fin3 = clock64();
   // ---- COTE (reference estimate(), :618-747).  The three axes are independent: wavefront a handles axis a
   // (wave 3 only joins the barriers).  Per axis: (1) bitonic sort of the 2N interval endpoints by
-  // (value, insertion position), (2) ONE lane walks the events accumulating the five running sums in the
-  // reference's order (binary64 addition is not associative, so this part stays sequential; it touches
-  // LDS only), (3) the wave evaluates x_hat / cost per event and takes the arg-min with Eigen's
+  // (value, insertion position), (2) one lane walks the events accumulating the five running sums in the
+  // reference's order, (3) the wave evaluates x_hat / cost per event and takes the arg-min with Eigen's
   // minCoeff tie rule, (4) median of the consensus window by rank counting.
   const double range = A.prm.cote_noise_bound * sqrt(A.prm.cbar2);
   const int nc = 2 * N;
@@ -834,159 +978,34 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   while (n2 < nc) n2 <<= 1;
   const int ax = wave;
   const bool act = ax < 3;
-  // working arrays of this wave's axis: carved from its third of the LDS while it lasts, global otherwise
-  const size_t lds_per_axis = ((size_t)FIN_LDS_BYTES / 3) & ~(size_t)15;
-  size_t lds_used = 0;
   const int axc = act ? ax : 0;
-  char* lds_base = (char*)fin_lds + (size_t)axc * lds_per_axis;
-  double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
-  int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
-  auto carve = [&](size_t bytes, void* global_fallback) -> void* {
-    const size_t aligned = (bytes + 15) & ~(size_t)15;
-    if (lds_used + aligned <= lds_per_axis) {
-      void* p = lds_base + lds_used;
-      lds_used += aligned;
-      return p;
-    }
-    return global_fallback;
-  };
-  double* ekey = (double*)carve((size_t)n2 * 8, gf);                      // n2 <= 4L
-  int* epos = (int*)carve((size_t)n2 * 4, gi);                            // n2 <= 4L
-  double* exv = (double*)carve((size_t)nc * 8, gf + 4 * (size_t)L);     // X of the event, sorted order
-  double* rs_w = (double*)carve((size_t)nc * 8, gf + 6 * (size_t)L);    // running dot_weights_consensus
-  double* rs_xw = (double*)carve((size_t)nc * 8, gf + 8 * (size_t)L);   // running dot_X_weights
-  double* rs_rng = (double*)carve((size_t)nc * 8, gf + 10 * (size_t)L); // running ranges_inverse_sum
-  double* rs_x = (double*)carve((size_t)nc * 8, gf + 12 * (size_t)L);   // running sum_xi
-  double* rs_xx = (double*)carve((size_t)nc * 8, gf + 14 * (size_t)L);  // running sum_xi_square
-  double* xhat = (double*)carve((size_t)nc * 8, gf + 16 * (size_t)L);
-  double* xcost = (double*)carve((size_t)nc * 8, gf + 18 * (size_t)L);
-  int* card = (int*)carve((size_t)nc * 4, gi + 4 * (size_t)L);
-  __shared__ double s_axis_est[3], s_va[3], s_vb[3];
-  __shared__ int s_axis_ncard[3], s_axis_mi[3];
+  __shared__ double s_axis_est[3], s_bc[3][4];
+  __shared__ int s_axis_ncard[3];
   const double* X = RAW + (size_t)axc * L;
+  // bytes one axis needs: ekey n2*8 (re-used for the first running sum), epos n2*4, then 5 arrays of nc
+  // doubles and card nc*4 (16-byte aligned)
+  const size_t a_ekey = 0, a_epos = a_ekey + (((size_t)n2 * 8 + 15) & ~(size_t)15),
+               a_exv = a_epos + (((size_t)n2 * 4 + 15) & ~(size_t)15), a_arr = (((size_t)nc * 8 + 15) & ~(size_t)15),
+               a_card = a_exv + 5 * a_arr, a_total = a_card + (((size_t)nc * 4 + 15) & ~(size_t)15);
   __syncthreads();  // GNC arrays in LDS are dead from here on
-  if (act) {
-    for (int i = lane; i < n2; i += 64) {
-      if (i < nc) {
-        const int p = i >> 1;
-        ekey[i] = (i & 1) ? X[p] + range : X[p] - range;
-      } else {
-        ekey[i] = INFINITY;
-      }
-      epos[i] = i;
-    }
+  CoteOut co;
+  if (3 * a_total <= (size_t)FIN_LDS_BYTES) {
+    char* base = (char*)fin_lds + (size_t)axc * a_total;  // LDS: pointers derive from the shared array
+    co = cote_axis(act, lane, X, N, nc, n2, range, A.prm.cote_median, (double*)(base + a_ekey), (int*)(base + a_epos),
+                   (double*)(base + a_exv), (double*)(base + a_ekey), (double*)(base + a_exv + 1 * a_arr),
+                   (double*)(base + a_exv + 2 * a_arr), (double*)(base + a_exv + 3 * a_arr),
+                   (double*)(base + a_exv + 4 * a_arr), (int*)(base + a_card), s_bc[axc]);
+  } else {
+    double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
+    int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
+    co = cote_axis(act, lane, X, N, nc, n2, range, A.prm.cote_median, gf, gi, gf + 4 * (size_t)L, gf + 6 * (size_t)L,
+                   gf + 8 * (size_t)L, gf + 10 * (size_t)L, gf + 12 * (size_t)L, gf + 14 * (size_t)L, gi + 4 * (size_t)L,
+                   s_bc[axc]);
   }
-  // bitonic sort, ascending by (key, pos); every wave runs the same barrier sequence
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      if (act) {
-        for (int i = lane; i < n2; i += 64) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const double ka = ekey[i], kb = ekey[ixj];
-            const int pa = epos[i], pb = epos[ixj];
-            const bool a_gt_b = (ka > kb) || (ka == kb && pa > pb);
-            const bool up = ((i & k) == 0);
-            if (a_gt_b == up) {
-              ekey[i] = kb;
-              ekey[ixj] = ka;
-              epos[i] = pb;
-              epos[ixj] = pa;
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (act)
-    for (int i = lane; i < nc; i += 64) exv[i] = X[epos[i] >> 1];
-  __syncthreads();
   if (act && lane == 0) {
-    const double weight = 1.0 / (range * range);
-    double ranges_inverse_sum = 0;
-    for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
-    double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
-    int consensus = 0;
-    for (int i = 0; i < nc; ++i) {
-      const int eps = (epos[i] & 1) ? -1 : 1;
-      const double xv = exv[i];
-      consensus += eps;
-      dot_weights_consensus += eps * weight;
-      dot_X_weights += eps * weight * xv;
-      ranges_inverse_sum -= eps * range;
-      sum_xi += eps * xv;
-      sum_xi_square += eps * xv * xv;
-      card[i] = consensus;
-      rs_w[i] = dot_weights_consensus;
-      rs_xw[i] = dot_X_weights;
-      rs_rng[i] = ranges_inverse_sum;
-      rs_x[i] = sum_xi;
-      rs_xx[i] = sum_xi_square;
-    }
-  }
-  __syncthreads();
-  if (act) {
-    // per-event estimate and cost, then arg-min (first strict minimum; NaN is never selected unless first)
-    double bc = INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = lane; i < nc; i += 64) {
-      const double xh = rs_xw[i] / rs_w[i];
-      xhat[i] = xh;
-      const double residual = card[i] * xh * xh + rs_xx[i] - 2 * rs_x[i] * xh;
-      const double c = residual + rs_rng[i];
-      xcost[i] = c;
-      if (c < bc || (c == bc && i < bi)) {
-        bc = c;
-        bi = i;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double oc = __shfl_xor(bc, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (oc < bc || (oc == bc && oi < bi)) {
-        bc = oc;
-        bi = oi;
-      }
-    }
-    if (lane == 0) {
-      int mi = bi;
-      if (mi == 0x7fffffff || xcost[0] != xcost[0]) mi = 0;
-      s_axis_mi[ax] = mi;
-      s_axis_ncard[ax] = card[mi];
-      s_axis_est[ax] = xhat[mi];
-      s_va[ax] = 0;
-      s_vb[ax] = 0;
-    }
-  }
-  __syncthreads();
-  if (act) {
-    const int mi = s_axis_mi[ax], ncard = s_axis_ncard[ax];
-    if (A.prm.cote_median && ncard >= 2) {
-      // the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}
-      const int ra = ncard / 2 - 1, rb = ncard / 2;
-      for (int j = lane; j < ncard; j += 64) {
-        const double vj = exv[mi - j];
-        int rk = 0;
-        for (int q = 0; q < ncard; ++q) {
-          const double vq = exv[mi - q];
-          rk += (vq < vj) || (vq == vj && q < j);
-        }
-        if (rk == ra) s_va[ax] = vj;
-        if (rk == rb) s_vb[ax] = vj;
-      }
-    }
-  }
-  __syncthreads();
-  if (act && lane == 0) {
-    const int ncard = s_axis_ncard[ax];
-    if (A.prm.cote_median && ncard >= 2)
-      s_axis_est[ax] = (s_va[ax] + s_vb[ax]) / 2.0;
-    else if (A.prm.cote_median && ncard == 1)
-      s_axis_est[ax] = exv[s_axis_mi[ax]];
-    res->n_card[ax] = ncard;
+    s_axis_est[ax] = co.est;
+    s_axis_ncard[ax] = co.ncard;
+    res->n_card[ax] = co.ncard;
   }
   __syncthreads();
   double tr[3] = {s_axis_est[0], s_axis_est[1], s_axis_est[2]};
@@ -1159,7 +1178,13 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
                        B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
     }
-    hipLaunchKernelGGL(k_rank, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.perm, B.rankof, B.Kp);
+    {
+      int slices = (L + 1023) / 1024;
+      if (slices > 32) slices = 32;
+      (void)hipMemsetAsync(B.rankof, 0, sizeof(int) * (size_t)L, stream);
+      hipLaunchKernelGGL(k_rank_partial, dim3((L + 255) / 256, slices), dim3(256), 0, stream, B.core, L, B.rankof);
+      hipLaunchKernelGGL(k_rank_finish, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.rankof, B.perm, B.Kp);
+    }
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
     hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
     bool heuristic = true;

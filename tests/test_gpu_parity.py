@@ -297,3 +297,27 @@ def test_nn_engines_produce_identical_tables(qo, small_pair):
         assert np.array_equal(a, b)
     stats = tables["mfma"][3]
     assert stats[8] + stats[9] < 0.2 * (vs.shape[0] + vt.shape[0])  # rows that needed the exact re-check
+
+
+def test_stream_slots_run_concurrently_and_agree(qo):
+    """Three pairs in flight on three stream slots (one host thread each) give the answers of sequential runs."""
+    import threading
+    h = ql.Handle(0, n_slots=3)
+    pairs = [synth.kitti64_pair(i) for i in range(3)]
+    seq = [h.register_pair(s, t, ql.default_frontend_params(seed=i), slot=0) for i, (s, t, _) in enumerate(pairs)]
+    out = [None] * 3
+
+    def work(i):
+        s, t, _ = pairs[i]
+        for _ in range(3):
+            out[i] = h.register_pair(s, t, ql.default_frontend_params(seed=i), slot=i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    for a, b in zip(seq, out):
+        assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["final_inliers"], b["final_inliers"])
+        assert np.array_equal(a["clique"], b["clique"]) and a["L"] == b["L"]
+    h.close()
