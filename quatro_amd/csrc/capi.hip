@@ -362,7 +362,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   {
     const int ns1[1] = {n};
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -411,6 +411,10 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[0].fpfh, desc33_s, (size_t)n_s * 132, kin, s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[1].fpfh, desc33_t, (size_t)n_t * 132, kin, s.stream));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  {
+    const int n2[2] = {n_s, n_t};  // Matcher::normalizePoints means of the two clouds handed in
+    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream));
+  }
   int L = 0;
   int rc = match_device(h, s, n_s, n_t, fp, &L);
   if (rc != QTR_OK) return rc;
@@ -486,7 +490,10 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream));
+    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain (stream is idle-synced here)
+    QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false));
+    QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
@@ -538,10 +545,17 @@ long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t b
     case QTR_DBG_GRAPH_BITMAP: src = s.sb.bm; have = (size_t)L * W * 8; break;
     case QTR_DBG_CORE: src = s.sb.core; have = (size_t)L * 4; break;
     case QTR_DBG_PERM: src = s.sb.perm; have = (size_t)L * 4; break;
-    case QTR_DBG_NBR_OFFSETS: src = c0.nbr_off; have = (size_t)(s.last_n + 1) * 4; break;
+    case QTR_DBG_NBR_OFFSETS:
+      // the CSR view is only built for inspection
+      if (exclusive_scan_i32(c0.nbr_cnt, c0.nbr_off, s.last_n, s.stream) != hipSuccess) return -1;
+      src = c0.nbr_off;
+      have = (size_t)(s.last_n + 1) * 4;
+      break;
     case QTR_DBG_NBR_INDEX:
     case QTR_DBG_NBR_DIST2: {
       int tot = 0;
+      if (exclusive_scan_i32(c0.nbr_cnt, c0.nbr_off, s.last_n, s.stream) != hipSuccess) return -1;
+      if (hipStreamSynchronize(s.stream) != hipSuccess) return -1;
       if (hipMemcpy(&tot, c0.nbr_off + s.last_n, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
       src = (what == QTR_DBG_NBR_INDEX) ? (const void*)c0.nbr_idx : (const void*)c0.nbr_d2;
       have = (size_t)tot * 4;

@@ -53,6 +53,7 @@ struct FrontBufs {
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
+  int nn_target_waves = 2048;  // waves per k_nn_mfma launch aimed at when slicing the base cloud (QTR_NN_WAVES)
   hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)
 };
 
@@ -62,7 +63,9 @@ hipError_t frontend_init_attributes();
 
 hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st);
 hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st);
-hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st);
+hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
+                        bool with_mean);
+hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
 

@@ -141,7 +141,32 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   __shared__ u32 base[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
   if (blk >= nblk) return;
-  for (int d = lane; d < NB; d += 64) base[d] = hist[d * nblk + blk];
+  // offsets from the RAW per-tile histograms (no separate scan launch): digit d of this tile starts at
+  //   sum_{d'<d} total[d'] + sum_{b<blk} hist[d][b]
+  {
+    static_assert(NB == 256, "offset computation below assumes 4 digits per lane");
+    u32 tot[4], before[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = lane * 4 + q;
+      u32 t = 0, bf = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const u32 h = hist[d * nblk + b];
+        bf += (b < blk) ? h : 0u;
+        t += h;
+      }
+      tot[q] = t;
+      before[q] = bf;
+    }
+    int wtot;
+    const int ex = wave_excl_scan_i32((int)(tot[0] + tot[1] + tot[2] + tot[3]), &wtot);
+    u32 run = (u32)ex;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      base[lane * 4 + q] = run + before[q];
+      run += tot[q];
+    }
+  }
   __syncthreads();
   const int tbase = blk * TILE;
   for (int s = 0; s < TILE; s += 64) {
@@ -983,7 +1008,6 @@ static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int
       a.c[c].keys_out = src == 0 ? C[c]->keys_b : C[c]->keys_a;
     }
     hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
-    hipLaunchKernelGGL(k2_radix_scan, dim3(1, nc), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
     src ^= 1;
   }
@@ -1024,7 +1048,18 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 }
 
 // normals + SPFH + FPFH (+ the matcher's sequential mean) of nc (1 or 2) clouds held in F.cloud[first + c]
-hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st) {
+// Matcher::normalizePoints means of nc clouds; independent of the FPFH chain, so the whole-path driver runs it
+// on the slot's second stream
+hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st) {
+  Clouds2 a;
+  for (int c = 0; c < nc; ++c) a.c[c] = make_view(F.cloud[first + c], nullptr, 0, n[c]);
+  if (nc == 1) a.c[1] = a.c[0];
+  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
+                        bool with_mean) {
   Clouds2 a;
   CloudBufs* C[2] = {&F.cloud[first], &F.cloud[nc > 1 ? first + 1 : first]};
   int maxn = 1;
@@ -1047,11 +1082,10 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   hipLaunchKernelGGL(k2_sorted_points, dim3(g, nc), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, a, cell);
   hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, a, r2);
-  hipLaunchKernelGGL(k2_nbr_scan, dim3(1, nc), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, a, rn2);
   hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k2_fpfh, dim3(maxn, nc), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
+  if (with_mean) hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1124,6 +1158,8 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   {
     const char* e = getenv("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : 1;
+    const char* w = getenv("QTR_NN_WAVES");
+    F.nn_target_waves = (w && atoi(w) > 0) ? atoi(w) : 2048;
   }
 }
 

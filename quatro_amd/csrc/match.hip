@@ -564,7 +564,7 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     auto run_dir = [&](CloudBufs& Q, int nq, int nq_pad, CloudBufs& Bc, int nb, int nb_pad, u64* best, int mc_slot,
                        hipEvent_t ev0, hipEvent_t ev1) {
       const int ntiles = nb_pad / 32;
-      int ns_ = (2048 + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
+      int ns_ = (F.nn_target_waves + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
       if (ns_ > 32) ns_ = 32;
       if (ns_ > ntiles) ns_ = ntiles;
       if (ns_ < 1) ns_ = 1;
