@@ -1016,6 +1016,7 @@ static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int
 
 // voxel-grid down-sampling of nc (1 or 2) raw clouds
 hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st) {
+  (void)hipGetLastError();
   Clouds2 a;
   CloudBufs* C[2] = {&F.cloud[0], &F.cloud[nc > 1 ? 1 : 0]};
   int maxP = 1;
@@ -1060,6 +1061,7 @@ hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream
 
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
                         bool with_mean) {
+  (void)hipGetLastError();
   Clouds2 a;
   CloudBufs* C[2] = {&F.cloud[first], &F.cloud[nc > 1 ? first + 1 : first]};
   int maxn = 1;

@@ -525,6 +525,7 @@ static inline int grid_for(int n) {
 }
 
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
+  (void)hipGetLastError();
   // fi = larger cloud, fj = smaller (reference feature_matcher.cc:84-92)
   const int swapped = nt > ns ? 1 : 0;
   CloudBufs& Ci = F.cloud[swapped ? 1 : 0];

@@ -1159,7 +1159,9 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
                           hipEvent_t ev_graph, hipEvent_t ev_clique) {
   const int W = (L + 63) / 64;
   hipError_t e;
+  (void)hipGetLastError();  // a stale sticky error (e.g. timing query on an unrecorded event) is not ours
   if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
+  if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
     hipLaunchKernelGGL(k_graph_build, dim3((L + 3) / 4), dim3(256), 0, stream, src, tgt, L, W, beta, B.bm, B.deg,

@@ -321,3 +321,85 @@ def test_stream_slots_run_concurrently_and_agree(qo):
         assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["final_inliers"], b["final_inliers"])
         assert np.array_equal(a["clique"], b["clique"]) and a["L"] == b["L"]
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def test_edge_cases_through_the_abi(hip, qo):
+    rng = np.random.default_rng(0)
+    # empty and tiny clouds
+    e4 = np.zeros((0, 4), dtype=np.float32)
+    assert hip.voxelize(e4, 0.3).shape == (0, 4)
+    for n in (1, 2, 3, 5):
+        c = np.zeros((n, 4), dtype=np.float32)
+        c[:, :3] = rng.uniform(-1, 1, (n, 3))
+        nrm_g, de_g = hip.fpfh(c, 0.5, 0.75)
+        nrm_o, _, de_o = qo.fpfh(c, 0.5, 0.75)
+        assert np.all((_b(nrm_g) == _b(nrm_o)) | (np.isnan(nrm_g) & np.isnan(nrm_o)))
+        assert np.array_equal(_b(de_g), _b(de_o))
+    # isolated points (no neighbour inside either radius): NaN normals, all-zero descriptors
+    far = np.zeros((6, 4), dtype=np.float32)
+    far[:, 0] = np.arange(6) * 10.0
+    nrm, de = hip.fpfh(far, 0.5, 0.75)
+    assert np.isnan(nrm[:, :3]).all() and not de.any()
+    # exact duplicates inside a cloud (d2 == 0 neighbours are skipped by the FPFH weighting)
+    dup = np.zeros((40, 4), dtype=np.float32)
+    dup[:, :3] = rng.uniform(-0.6, 0.6, (40, 3))
+    dup[7] = dup[3]
+    nrm_g, de_g = hip.fpfh(dup, 0.5, 0.75)
+    nrm_o, _, de_o = qo.fpfh(dup, 0.5, 0.75)
+    assert np.array_equal(_b(de_g), _b(de_o))
+    # matcher with very unequal / minimal sizes, and tuple test off
+    a = np.zeros((1, 4), dtype=np.float32)
+    da = rng.uniform(0, 50, (1, 33)).astype(np.float32)
+    b = np.zeros((700, 4), dtype=np.float32)
+    b[:, :3] = rng.uniform(-5, 5, (700, 3))
+    db = rng.uniform(0, 50, (700, 33)).astype(np.float32)
+    for (x, dx, y, dy) in ((a, da, b, db), (b, db, a, da)):
+        for tup in (0, 1):
+            fp = ql.default_frontend_params(seed=3, use_tuple_test=tup)
+            assert np.array_equal(hip.match(x, dx, y, dy, fp), qo.match(x, dx, y, dy, seed=3, tuple_test=bool(tup)))
+    assert hip.match(e4, np.zeros((0, 33), np.float32), b, db).shape[0] == 0
+    # identical descriptors everywhere: every NN is a tie -> lowest index, through the exact re-check path
+    same = np.tile(da, (300, 1))
+    pts = np.zeros((300, 4), dtype=np.float32)
+    pts[:, :3] = rng.uniform(-5, 5, (300, 3))
+    assert np.array_equal(hip.match(pts, same, b[:200], np.tile(da, (200, 1)), ql.default_frontend_params(seed=1)),
+                          qo.match(pts, same, b[:200], np.tile(da, (200, 1)), seed=1))
+    # whole path on clouds too small / too sparse to register: soft failure, not a crash
+    tiny = np.zeros((30, 4), dtype=np.float32)
+    tiny[:, :3] = rng.uniform(-20, 20, (30, 3))
+    r = hip.register_pair(tiny, tiny[::-1].copy(), ql.default_frontend_params(seed=0))
+    o = qo.register_pair(tiny, tiny[::-1].copy(), seed=0)
+    assert r["valid"] == o["valid"] and r["L"] == o["L"] and np.array_equal(r["clique"], o["clique"])
+    # capacity errors are reported as such
+    small = ql.Handle(0, max_points=4096, max_voxels=1024, max_corr=64)
+    big = np.zeros((5000, 4), dtype=np.float32)
+    with pytest.raises(ql.QuatroHipError) as ei:
+        small.voxelize(big, 0.3)
+    assert ei.value.code == ql.QTR_ERR_CAPACITY
+    s100, t100, _, _ = synth.correspondences(100, 0.5, 1)
+    with pytest.raises(ql.QuatroHipError) as ei:
+        small.solve(s100, t100)
+    assert ei.value.code == ql.QTR_ERR_CAPACITY
+    small.close()
+
+
+def test_full_size_raw_cloud_and_voxel_grid_extremes(qo):
+    """Loader-cap sized scan (250 000 points) and degenerate grids."""
+    hip = ql.Handle(0, max_points=262144, max_voxels=262144, max_corr=1024)
+    rng = np.random.default_rng(5)
+    P = 250000
+    c = np.zeros((P, 4), dtype=np.float32)
+    c[:, :3] = rng.normal(0, 12, (P, 3)).astype(np.float32)
+    c[:, 2] *= 0.1
+    g, o = hip.voxelize(c, 0.3), qo.voxelize(c, 0.3)
+    assert g.shape == o.shape and np.array_equal(_b(g), _b(o))
+    # all points in one voxel (a 60 000-point run: exercises the long-run path of the centroid kernel)
+    one = np.zeros((60000, 4), dtype=np.float32)
+    one[:, :3] = rng.uniform(0.01, 0.29, (60000, 3)).astype(np.float32)
+    g, o = hip.voxelize(one, 0.3), qo.voxelize(one, 0.3)
+    assert g.shape == (1, 4) and np.array_equal(_b(g), _b(o))
+    # leaf too small for the extent: PCL passes the input through
+    far = np.array([[0, 0, 0, 0], [1e5, 1e5, 1e5, 0], [5, 5, 5, 0]], dtype=np.float32)
+    assert np.array_equal(hip.voxelize(far, 0.001), far) and qo.voxelize(far, 0.001).shape[0] == 3
+    hip.close()
