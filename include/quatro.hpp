@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "quatro_hip.h"
+#include "quatro_hip_cxx.hpp"
 
 #if defined(__has_include)
 #if __has_include(<pcl/registration/registration.h>) && __has_include(<Eigen/Core>) && !defined(QUATRO_FORCE_SHIM)
@@ -100,30 +101,11 @@ class Registration {
 #endif  // QUATRO_HAVE_PCL
 
 namespace quatro_hip {
-// One process-wide handle (device 0) shared by every Quatro / FPFHManager object; created on first use.
-inline qtr_handle* default_handle() {
-  static qtr_handle* h = nullptr;
-  if (!h) {
-    const int rc = qtr_create(0, nullptr, &h);
-    if (rc != QTR_OK) {
-      std::string msg = h ? qtr_last_error(h) : "qtr_create failed";
-      if (h) qtr_destroy(h);
-      h = nullptr;
-      throw std::runtime_error("[quatro_hip] " + msg);
-    }
-  }
-  return h;
-}
 // pcl::PointXYZ and friends are 16-byte records starting with float x,y,z: passed through as xyz4.
 template <typename PointT>
 inline const float* xyz4(const std::vector<PointT>& pts) {
   static_assert(sizeof(PointT) == 16, "point type must be a 16-byte x,y,z,pad record (pcl::PointXYZ)");
   return reinterpret_cast<const float*>(pts.data());
-}
-inline void check(qtr_handle* h, int rc) {
-  if (rc == QTR_OK || rc == QTR_ERR_CLIQUE_TOO_SMALL) return;
-  if (rc == QTR_ERR_BAD_ARG || rc == QTR_ERR_UNSUPPORTED) throw std::invalid_argument(qtr_last_error(h));
-  throw std::runtime_error(qtr_last_error(h));
 }
 }  // namespace quatro_hip
 

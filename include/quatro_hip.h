@@ -15,6 +15,8 @@
  *                         (computeTIMs :307, solveForScale :355, teaser::Graph + MaxCliqueSolver
  *                          include/teaser/graph.h:29-274 + src/graph.cc:12-104, solveForRotation2D :430,
  *                          solveForTranslation/estimate :585-747)
+ *   qtr_max_clique     <- teaser::MaxCliqueSolver::findMaxClique(teaser::Graph)
+ *                                                          include/teaser/graph.h:219-274, src/graph.cc:12-104
  *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
  *                         (voxelize x2, FPFHManager::setFeaturePair include/fpfh_manager.hpp:98-153,
  *                          setInputSource/setInputTarget/computeTransformation)
@@ -148,6 +150,14 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
  * clique / rot_inliers / final_inliers: optional int buffers of capacity `cap` (counts in *res). */
 int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int L, const qtr_params* prm,
               qtr_result* res, int* clique, int* rot_inliers, int* final_inliers, int cap, int mem);
+
+/* K10-K12 alone: the clique search on a caller-supplied graph.  adj = symmetric bit matrix, L rows of
+ * ceil(L/64) uint64 words (bit j of row i set <=> edge i-j; the diagonal and bits >= L are ignored).
+ * mode: QTR_INLIER_PMC_HEU or QTR_INLIER_KCORE_HEU (teaser CLIQUE_SOLVER_MODE 1 / 2).  clique receives
+ * the member ids in ascending order (capacity cap); *n_out their count; *max_core_out (may be NULL) the
+ * largest core number. */
+int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
+                   int* clique, int cap, int* n_out, int* max_core_out, int mem);
 
 /* Whole path on one slot: raw scans -> transform. */
 int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,

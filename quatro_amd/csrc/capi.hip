@@ -275,6 +275,53 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
   return rc;
 }
 
+int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
+                   int* clique, int cap, int* n_out, int* max_core_out, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !n_out || L < 0 || (L > 0 && (!adj || !clique))) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_out = 0;
+  if (max_core_out) *max_core_out = 0;
+  if (mode != QTR_INLIER_PMC_HEU && mode != QTR_INLIER_KCORE_HEU) {
+    snprintf(h->err, sizeof(h->err), "clique solver mode %d not supported (PMC_EXACT is a 'next' row)", mode);
+    return QTR_ERR_UNSUPPORTED;
+  }
+  if (L > h->lim.max_corr) {
+    snprintf(h->err, sizeof(h->err), "L=%d exceeds max_corr=%d", L, h->lim.max_corr);
+    return QTR_ERR_CAPACITY;
+  }
+  if (L == 0) return QTR_OK;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const int W = (L + 63) / 64;
+  const u64* d_adj = (const u64*)adj;
+  if (mem == QTR_MEM_HOST) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.sb.bm, adj, (size_t)L * W * 8, hipMemcpyHostToDevice, s.stream));
+    d_adj = s.sb.bm;
+  }
+  s.last_L = L;
+  QTR_HIP_TRY(h, clique_only_enqueue(s.sb, d_adj, L, mode, kcore_thr, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 128, s.sb.st, sizeof(SolverState), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if (!((const SolverState*)(s.pinned_i32 + 128))->done) {
+    qtr_params dummy;
+    qtr_default_params(&dummy);
+    QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128));
+  }
+  QTR_HIP_TRY(h, clique_only_finish(s.sb, L, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  const int M = s.pinned_res->n_clique;
+  if (max_core_out) *max_core_out = s.pinned_res->max_core;
+  *n_out = M;
+  if (M > cap) return QTR_ERR_CAPACITY;
+  if (M > 0) {
+    const hipMemcpyKind kind = (mem == QTR_MEM_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    QTR_HIP_TRY(h, hipMemcpyAsync(clique, s.sb.clique, sizeof(int) * (size_t)M, kind, s.stream));
+    QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  }
+  return QTR_OK;
+}
+
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !out) return QTR_ERR_BAD_ARG;

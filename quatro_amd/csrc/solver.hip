@@ -732,6 +732,80 @@ __device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* _
   return o;
 }
 
+// Clique members of the finished search -> bitset in ORIGINAL labels -> ascending id list in `clique`;
+// *s_M (LDS) receives the member count.  Called by every thread of a 256-thread workgroup.
+__device__ __forceinline__ void clique_members(const SolverState* st, u64* member_bits, const int* picks,
+                                               const int* perm, int* clique, int W, int* s_M) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int mc = st->mc;
+  if (st->best_r != -2) {
+    for (int w = tid; w < W; w += nthr) member_bits[w] = 0;
+    __syncthreads();
+    {
+      // the winning start's picks were saved by k_clique_scan: depth-1 picks + the start vertex itself
+      const int depth = (st->best_r >= 0) ? mc : 0;
+      for (int i = tid; i < depth; i += nthr) {
+        const int rr = (i == depth - 1) ? st->best_r : picks[i];
+        const int v = perm[rr];
+        atomicOr(&member_bits[v >> 6], 1ULL << (v & 63));
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *s_M = 0;
+  __syncthreads();
+  if (wave == 0) {
+    int base = 0;
+    for (int w0 = 0; w0 < W; w0 += 64) {
+      const int w = w0 + lane;
+      u64 x = (w < W) ? member_bits[w] : 0ULL;
+      int tot;
+      int off = wave_excl_scan_i32(__popcll(x), &tot);
+      int o = base + off;
+      while (x) {
+        const int b = __ffsll((long long)x) - 1;
+        x &= x - 1;
+        clique[o++] = w * 64 + b;
+      }
+      base += tot;
+    }
+    if (lane == 0) *s_M = base;
+  }
+  __syncthreads();
+}
+
+// Stand-alone clique extraction for qtr_max_clique (teaser::MaxCliqueSolver::findMaxClique boundary,
+// reference src/graph.cc:15-98): res->n_clique / max_core / n_edges are filled, nothing else is estimated.
+__global__ __launch_bounds__(256) void k_clique_only(SolverState* st, u64* member_bits, const int* picks,
+                                                     const int* perm, int* clique, int W, qtr_result* res) {
+  __shared__ int s_M;
+  clique_members(st, member_bits, picks, perm, clique, W, &s_M);
+  if (threadIdx.x == 0) {
+    res->n_clique = s_M;
+    res->max_core = st->max_core;
+    res->n_edges = st->n_edges2 / 2;
+    res->status = QTR_OK;
+  }
+}
+
+// qtr_max_clique input hygiene + degrees, one wavefront per row: the diagonal bit and the bits past L are
+// cleared in our copy of the matrix (a teaser::Graph has no self loops, include/teaser/graph.h:96-105), then
+// deg[i] = popcount(row i).  Symmetry is the caller's contract.
+__global__ __launch_bounds__(256) void k_row_degrees(u64* __restrict__ bm, int L, int W, int* __restrict__ deg) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= L) return;
+  int c = 0;
+  for (int w = lane; w < W; w += 64) {
+    u64 x = bm[(size_t)row * W + w], y = x;
+    if (w == (row >> 6)) y &= ~(1ULL << (row & 63));
+    if (w == W - 1 && (L & 63)) y &= (1ULL << (L & 63)) - 1;
+    if (y != x) bm[(size_t)row * W + w] = y;
+    c += __popcll(y);
+  }
+  c = wave_sum_i32(c);
+  if (lane == 0) deg[row] = c;
+}
+
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   extern __shared__ __attribute__((aligned(16))) double fin_lds[];
   __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
@@ -743,41 +817,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   const int mc = st->mc;
   const long long t_fin0 = clock64();
 
-  // ---- clique members -> bitset in ORIGINAL labels -> sorted id list
-  if (st->best_r != -2) {
-    for (int w = tid; w < W; w += nthr) A.member_bits[w] = 0;
-    __syncthreads();
-    {
-      // the winning start's picks were saved by k_clique_scan: depth-1 picks + the start vertex itself
-      const int depth = (st->best_r >= 0) ? mc : 0;
-      for (int i = tid; i < depth; i += nthr) {
-        const int rr = (i == depth - 1) ? st->best_r : A.picks[i];
-        const int v = A.perm[rr];
-        atomicOr(&A.member_bits[v >> 6], 1ULL << (v & 63));
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) s_M = 0;
-  __syncthreads();
-  if (wave == 0) {
-    int base = 0;
-    for (int w0 = 0; w0 < W; w0 += 64) {
-      const int w = w0 + lane;
-      u64 x = (w < W) ? A.member_bits[w] : 0ULL;
-      int tot;
-      int off = wave_excl_scan_i32(__popcll(x), &tot);
-      int o = base + off;
-      while (x) {
-        const int b = __ffsll((long long)x) - 1;
-        x &= x - 1;
-        A.clique[o++] = w * 64 + b;
-      }
-      base += tot;
-    }
-    if (lane == 0) s_M = base;
-  }
-  __syncthreads();
+  clique_members(st, A.member_bits, A.picks, A.perm, A.clique, W, &s_M);
   const int M = s_M;
   if (tid == 0) {
     res->n_clique = M;
@@ -1129,44 +1169,11 @@ static void launch_finalize(const SolverBufs& B, const float4* src, const float4
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), (size_t)FIN_LDS_BYTES, stream, A);
 }
 
-// Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host
-// check per round) and the finalisation again.
-hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                           hipStream_t stream, int* pinned_state) {
+// K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds.  Expects the bit matrix in
+// B.bm and the degrees in B.deg; everything stays on `stream`.
+static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kcore_thr, hipStream_t stream) {
   const int W = (L + 63) / 64;
-  hipError_t e;
-  int guard = 0;
-  while (true) {
-    hipLaunchKernelGGL(k_clique_batch, dim3(CLIQUE_BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
-                       B.picks_buf);
-    hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, CLIQUE_BATCH,
-                       B.picks_buf, B.picks);
-    if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-      return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-    if (((const SolverState*)pinned_state)->done) break;
-    if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
-  }
-  launch_finalize(B, src, tgt, L, prm, stream);
-  return hipGetLastError();
-}
-
-// Enqueues the whole back end on `stream`.  L is known on the host.  Returns a HIP error code.
-// The clique heuristic normally terminates after the first two batches (see header comment of
-// k_clique_batch); `*host_done` (pinned) is polled between further rounds.
-hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                          hipStream_t stream, int* pinned_state /* >= 16 ints, host pinned */,
-                          hipEvent_t ev_graph, hipEvent_t ev_clique) {
-  const int W = (L + 63) / 64;
-  hipError_t e;
-  (void)hipGetLastError();  // a stale sticky error (e.g. timing query on an unrecorded event) is not ours
-  if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
-  if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
-  if (L > 0) {
-    const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
-    hipLaunchKernelGGL(k_graph_build, dim3((L + 3) / 4), dim3(256), 0, stream, src, tgt, L, W, beta, B.bm, B.deg,
-                       &B.st->n_edges2);
-    if (ev_graph) hipEventRecord(ev_graph, stream);
+  {
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
@@ -1190,8 +1197,8 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
     hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
     bool heuristic = true;
-    if (prm.inlier_selection_mode == QTR_INLIER_KCORE_HEU) {
-      hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, prm.kcore_heuristic_threshold, B.st,
+    if (mode == QTR_INLIER_KCORE_HEU) {
+      hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, kcore_thr, B.st,
                          B.member_bits, W);
     }
     if (heuristic) {
@@ -1217,6 +1224,73 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
       hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
     }
+  }
+}
+
+// Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host
+// check per round) and the finalisation again.
+hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                           hipStream_t stream, int* pinned_state) {
+  const int W = (L + 63) / 64;
+  hipError_t e;
+  int guard = 0;
+  while (true) {
+    hipLaunchKernelGGL(k_clique_batch, dim3(CLIQUE_BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
+                       B.picks_buf);
+    hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, CLIQUE_BATCH,
+                       B.picks_buf, B.picks);
+    if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+      return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if (((const SolverState*)pinned_state)->done) break;
+    if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
+  }
+  if (src) launch_finalize(B, src, tgt, L, prm, stream);
+  return hipGetLastError();
+}
+
+// qtr_max_clique: bit matrix (device, L x ceil(L/64) words) -> degrees -> clique search.
+hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int mode, double kcore_thr,
+                               hipStream_t stream) {
+  const int W = (L + 63) / 64;
+  hipError_t e;
+  (void)hipGetLastError();
+  if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(B.res, 0, sizeof(qtr_result), stream)) != hipSuccess) return e;
+  if (L > 0) {
+    if (d_adj != B.bm &&
+        (e = hipMemcpyAsync(B.bm, d_adj, (size_t)L * W * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(k_row_degrees, dim3((L + 3) / 4), dim3(256), 0, stream, B.bm, L, W, B.deg);
+    clique_stage_enqueue(B, L, mode, kcore_thr, stream);
+  }
+  return hipGetLastError();
+}
+
+hipError_t clique_only_finish(const SolverBufs& B, int L, hipStream_t stream) {
+  const int W = (L + 63) / 64;
+  hipLaunchKernelGGL(k_clique_only, dim3(1), dim3(256), 0, stream, B.st, B.member_bits, B.picks, B.perm, B.clique, W,
+                     B.res);
+  return hipGetLastError();
+}
+
+// Enqueues the whole back end on `stream`.  L is known on the host.  Returns a HIP error code.
+// The clique heuristic normally terminates after the first two batches (see header comment of
+// k_clique_batch); `*host_done` (pinned) is polled between further rounds.
+hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                          hipStream_t stream, int* pinned_state /* >= 16 ints, host pinned */,
+                          hipEvent_t ev_graph, hipEvent_t ev_clique) {
+  const int W = (L + 63) / 64;
+  hipError_t e;
+  (void)hipGetLastError();  // a stale sticky error (e.g. timing query on an unrecorded event) is not ours
+  if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
+  if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
+  if (L > 0) {
+    const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
+    hipLaunchKernelGGL(k_graph_build, dim3((L + 3) / 4), dim3(256), 0, stream, src, tgt, L, W, beta, B.bm, B.deg,
+                       &B.st->n_edges2);
+    if (ev_graph) hipEventRecord(ev_graph, stream);
+    clique_stage_enqueue(B, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream);
   }
   if (ev_clique) hipEventRecord(ev_clique, stream);
   launch_finalize(B, src, tgt, L, prm, stream);

@@ -60,7 +60,7 @@ class StageTimes(C.Structure):
 EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
-    "qtr_solve", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_solve", "qtr_max_clique", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
@@ -105,6 +105,8 @@ def load():
                                       C.POINTER(FrontendParams), C.POINTER(Params), C.POINTER(Result), C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
+    lib.qtr_max_clique.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     lib.qtr_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = lib
     return lib
@@ -239,6 +241,17 @@ class Handle:
                                  cl.ctypes.data, rot.ctypes.data, fin.ctypes.data, cap, MEM_HOST)
         self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
         return _result_dict(res, cl, rot, fin)
+
+    def max_clique(self, bitmap, mode: int = 1, kcore_thr: float = 0.5, slot: int = 0):
+        """teaser::MaxCliqueSolver::findMaxClique on a bit-matrix graph [L][ceil(L/64)] uint64 -> (ids, max_core)."""
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint64)
+        L = bitmap.shape[0]
+        assert bitmap.ndim == 2 and (L == 0 or bitmap.shape[1] == (L + 63) // 64)
+        cl = np.zeros(max(L, 1), dtype=np.int32)
+        n, mcore = C.c_int(), C.c_int()
+        self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
+                                             cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
+        return cl[: n.value].copy(), mcore.value
 
     def register_pair(self, src_raw4, tgt_raw4, fp: FrontendParams | None = None, params: Params | None = None,
                       slot: int = 0):

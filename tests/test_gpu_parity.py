@@ -403,3 +403,96 @@ def test_full_size_raw_cloud_and_voxel_grid_extremes(qo):
     far = np.array([[0, 0, 0, 0], [1e5, 1e5, 1e5, 0], [5, 5, 5, 0]], dtype=np.float32)
     assert np.array_equal(hip.voxelize(far, 0.001), far) and qo.voxelize(far, 0.001).shape[0] == 3
     hip.close()
+
+
+# ------------------------------------------------------------------------- teaser::Graph / MaxCliqueSolver
+def _random_graph_bitmap(L, p, seed, planted=0):
+    rng = np.random.default_rng(seed)
+    A = np.triu(rng.random((L, L)) < p, 1)
+    if planted:
+        mem = rng.choice(L, planted, replace=False)
+        A[np.ix_(mem, mem)] = True
+    A = np.triu(A, 1)
+    A = A | A.T
+    W = (L + 63) // 64
+    bits = np.zeros((L, W * 64), dtype=np.uint8)
+    bits[:, :L] = A
+    return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W), A
+
+
+@pytest.mark.parametrize("L,p,planted,seed", [(1, 0.0, 0, 0), (2, 1.0, 0, 0), (65, 0.3, 0, 1), (200, 0.05, 12, 2),
+                                              (777, 0.02, 25, 3), (1500, 0.3, 40, 4), (3000, 0.01, 30, 5)])
+def test_max_clique_entry_matches_oracle(hip, qo, L, p, planted, seed):
+    """qtr_max_clique (the teaser::MaxCliqueSolver boundary) on arbitrary graphs, both heuristic modes."""
+    bm, A = _random_graph_bitmap(L, p, seed, planted)
+    core, _, mc = qo.kcore(bm)
+    for mode, thr in ((1, 0.5), (2, 0.5), (2, 0.0), (2, 1.0)):
+        ref = qo.max_clique(bm, mode, thr)
+        got, max_core = hip.max_clique(bm, mode, thr)
+        assert np.array_equal(got, ref), (mode, thr)
+        assert max_core == mc
+        if got.size:
+            sub = A[np.ix_(got, got)]
+            assert sub.sum() == got.size * (got.size - 1) or (mode == 2)  # KCORE_HEU returns the top core, not a clique
+    assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32)[:L], core)
+
+
+def test_max_clique_entry_hygiene_and_errors(hip, qo):
+    bm, _ = _random_graph_bitmap(130, 0.2, 9, 10)
+    ref, _ = hip.max_clique(bm, 1)
+    dirty = bm.copy()
+    for i in range(130):  # self loops and garbage past column L must be ignored
+        dirty[i, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+        dirty[i, 2] |= np.uint64(0xFFFF) << np.uint64(40)
+    got, _ = hip.max_clique(dirty, 1)
+    assert np.array_equal(got, ref)
+    with pytest.raises(ql.QuatroHipError) as e:
+        hip.max_clique(bm, 0)  # PMC_EXACT
+    assert e.value.code == ql.QTR_ERR_UNSUPPORTED
+    empty, mcore = hip.max_clique(np.zeros((0, 0), dtype=np.uint64), 1)
+    assert empty.size == 0 and mcore == 0
+    none, _ = hip.max_clique(np.zeros((10, 1), dtype=np.uint64), 1)
+    assert none.size == 0 and qo.max_clique(np.zeros((10, 1), dtype=np.uint64)).size == 0
+    # the solver still works on the slot afterwards (shared arenas)
+    src, tgt, _, _ = synth.correspondences(300, 0.2, seed=1, noise=0.05)
+    _assert_same_solution(hip.solve(src, tgt), qo.solve(src, tgt))
+
+
+def test_cpp_teaser_graph_dropin(hip, qo, tmp_path):
+    """teaser::Graph + teaser::MaxCliqueSolver from include/teaser/graph.h (tests/cpp/graph_demo.cpp)."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    bm, A = _random_graph_bitmap(400, 0.05, 11, 18)
+    ii, jj = np.nonzero(np.triu(A, 1))
+    with open(tmp_path / "edges.txt", "w") as f:
+        f.write("400\n")
+        for a, b in zip(ii, jj):
+            f.write(f"{a} {b}\n")
+            if (a + b) % 7 == 0:
+                f.write(f"{b} {a}\n")  # duplicate: Graph::addEdge must refuse it
+    exe = str(tmp_path / "graph_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "graph_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+    def run(mode, thr):
+        for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+            env = dict(os.environ)
+            if extra:
+                env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+            p = subprocess.run([exe, str(tmp_path / "edges.txt"), str(mode), str(thr)], env=env, capture_output=True,
+                               text=True, timeout=300)
+            if p.returncode == 0:
+                return p.stdout.strip()
+        raise AssertionError(p.stderr[-500:])
+
+    out = run(1, 0.5).split()
+    assert out[:2] == ["vertices", "400"] and int(out[3]) == ii.size
+    assert [int(x) for x in out[7:]] == qo.max_clique(bm, 1, 0.5).tolist()
+    assert int(out[5]) == qo.kcore(bm)[2]
+    out = run(2, 0.0).split()
+    assert [int(x) for x in out[7:]] == qo.max_clique(bm, 2, 0.0).tolist()
+    assert run(0, 0.5).startswith("invalid_argument")
