@@ -183,7 +183,7 @@ int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 #define QTR_DBG_MATCH_STATS 13   /* int32[16]: [0] L, [3] cross-checked pairs, [4] tuple-test survivors, [5] swapped,
                                     [8],[9] rows sent to the exact NN re-check (dir 0/1), [10],[11] rows settled by the
                                     two-candidate exact compare */
-#define QTR_DBG_SOLVER_STATE 14  /* int32[16]: mc, best_r, pos, done, t0, ub, batch, max_core, n_edges2, clique rounds,
+#define QTR_DBG_SOLVER_STATE 14  /* int32[32]: mc, best_r, pos, done, t0, ub, batch, max_core, n_edges2, clique rounds,
                                     [10] k-core peeling rounds */
 long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
 

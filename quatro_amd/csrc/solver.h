@@ -15,7 +15,7 @@ struct SolverState {  // device resident; mirrored to pinned host memory between
   int max_core;
   int n_edges2;  // sum of degrees
   int rounds;
-  int pad[6];
+  int pad[22];   // [0] k-core peeling rounds, [1..4] k_finalize phase clocks / 16, [6..11] COTE step clocks / 16
 };
 
 struct SolverBufs {

@@ -180,6 +180,34 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
 // ops per word, no atomics, no barriers, no per-round memory round trips.
 #define KCW_JMAX 18  // 64 * 18 = 1152 vertices
 #define KCW_GONE 0x3fffffff  // degree of a removed (or non-existent) vertex
+// JM = words per row rounded up to an even count (template: every per-round loop is fully unrolled over
+// the words the graph really has).  LDS holds L+1 rows: row L is all zero and stands in for the unused
+// slots of a batch of four frontier vertices.
+template <int JM>
+__device__ __forceinline__ void kcw_subtract4(const u32* __restrict__ rows32, int W, int halfsel, int bitsel, int v0,
+                                              int v1, int v2, int v3, int (&dreg)[JM]) {
+  const u32* r0 = rows32 + (size_t)v0 * W * 2 + halfsel;
+  const u32* r1 = rows32 + (size_t)v1 * W * 2 + halfsel;
+  const u32* r2 = rows32 + (size_t)v2 * W * 2 + halfsel;
+  const u32* r3 = rows32 + (size_t)v3 * W * 2 + halfsel;
+  u32 x0[JM], x1[JM], x2[JM], x3[JM];
+#pragma unroll
+  for (int w = 0; w < JM; ++w) {
+    const int ww = 2 * (w < W ? w : W - 1);
+    x0[w] = r0[ww];
+    x1[w] = r1[ww];
+    x2[w] = r2[ww];
+    x3[w] = r3[ww];
+  }
+#pragma unroll
+  for (int w = 0; w < JM; ++w) {
+    const int s = (int)((x0[w] >> bitsel) & 1u) + (int)((x1[w] >> bitsel) & 1u) + (int)((x2[w] >> bitsel) & 1u) +
+                  (int)((x3[w] >> bitsel) & 1u);
+    dreg[w] -= (w < W) ? s : 0;
+  }
+}
+
+template <int JM>
 __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, int L, int W,
                                                    const int* __restrict__ deg_in, int* __restrict__ core_out,
                                                    SolverState* __restrict__ st) {
@@ -187,15 +215,16 @@ __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, 
   // all four waves stage the bit matrix; wave 0 alone runs the peeling
 #pragma unroll 8
   for (int e = threadIdx.x; e < L * W; e += 256) kcw_rows[e] = bm[e];
+  for (int e = threadIdx.x; e < W; e += 256) kcw_rows[(size_t)L * W + e] = 0;
   const int lane = threadIdx.x & 63;
-  int dreg[KCW_JMAX], creg[KCW_JMAX];
+  int dreg[JM], creg[JM];
   int esum = 0;
   if (threadIdx.x < 64) {
-    int dl[KCW_JMAX];
+    int dl[JM];
 #pragma unroll
-    for (int j = 0; j < KCW_JMAX; ++j) dl[j] = deg_in[min(j * 64 + lane, L - 1)];  // one burst of independent loads
+    for (int j = 0; j < JM; ++j) dl[j] = deg_in[min(j * 64 + lane, L - 1)];  // one burst of independent loads
 #pragma unroll
-    for (int j = 0; j < KCW_JMAX; ++j) {
+    for (int j = 0; j < JM; ++j) {
       const bool in = j * 64 + lane < L;
       dreg[j] = in ? dl[j] : KCW_GONE;
       creg[j] = 0;
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, 
     // frontier of level k: removed vertices carry a huge positive degree and never hit
     u32 hitbits = 0;
 #pragma unroll
-    for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+    for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
     u64 hl = __ballot(hitbits != 0);
     if (hl == 0) {
       // level exhausted: the next occupied level is usually k+1; probe a few, then jump to the minimum
@@ -223,32 +252,37 @@ __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, 
         ++tries;
         hitbits = 0;
 #pragma unroll
-        for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+        for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
         hl = __ballot(hitbits != 0);
       }
       if (hl == 0) {
         int m = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < KCW_JMAX; ++j) m = min(m, dreg[j]);
+        for (int j = 0; j < JM; ++j) m = min(m, dreg[j]);
         m = wave_min_i32(m);
         if (m >= KCW_GONE / 2) break;
         k = m;
         hitbits = 0;
 #pragma unroll
-        for (int j = 0; j < KCW_JMAX; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
+        for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
         hl = __ballot(hitbits != 0);
       }
     }
     maxcore = k;
     // mark this round's frontier as removed ...
+    int alive_min = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < KCW_JMAX; ++j) {
+    for (int j = 0; j < JM; ++j) {
       const bool hit = (hitbits >> j) & 1u;
       dreg[j] = hit ? KCW_GONE : dreg[j];
       creg[j] = hit ? k : creg[j];
+      alive_min = min(alive_min, dreg[j]);
     }
-    // ... then subtract each frontier vertex's row from everybody's degrees: lanes 0-31 read the low
-    // half-word of word w, lanes 32-63 the high one (two broadcast addresses), one v_bfe per word
+    // ... if that emptied the graph (the top core leaves all at once) nobody is left to update
+    if (__ballot(alive_min < KCW_GONE / 2) == 0) break;
+    // ... then subtract the frontier vertices' rows from everybody's degrees, four rows per batch: lanes
+    // 0-31 read the low half-word of word w, lanes 32-63 the high one (two broadcast addresses)
+    int v0 = L, v1 = L, v2 = L, nq = 0;
     while (hl) {
       const int l = __ffsll((long long)hl) - 1;
       hl &= hl - 1;
@@ -256,17 +290,27 @@ __global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, 
       while (hb) {
         const int j = __ffs((int)hb) - 1;
         hb &= hb - 1;
-        const u32* row = rows32 + (size_t)(j * 64 + l) * W * 2 + halfsel;
-        u32 x[KCW_JMAX];
-#pragma unroll
-        for (int w = 0; w < KCW_JMAX; ++w) x[w] = row[2 * (w < W ? w : W - 1)];
-#pragma unroll
-        for (int w = 0; w < KCW_JMAX; ++w) dreg[w] -= (w < W) ? (int)((x[w] >> bitsel) & 1u) : 0;
+        const int v = j * 64 + l;
+        if (nq == 0) {
+          v0 = v;
+          nq = 1;
+        } else if (nq == 1) {
+          v1 = v;
+          nq = 2;
+        } else if (nq == 2) {
+          v2 = v;
+          nq = 3;
+        } else {
+          kcw_subtract4<JM>(rows32, W, halfsel, bitsel, v0, v1, v2, v, dreg);
+          v0 = v1 = v2 = L;
+          nq = 0;
+        }
       }
     }
+    if (nq) kcw_subtract4<JM>(rows32, W, halfsel, bitsel, v0, v1, v2, L, dreg);
   }
 #pragma unroll
-  for (int j = 0; j < KCW_JMAX; ++j) {
+  for (int j = 0; j < JM; ++j) {
     const int v = j * 64 + lane;
     if (v < L) core_out[v] = creg[j];
   }
@@ -540,7 +584,8 @@ __global__ __launch_bounds__(256) void k_kcore_heu(const int* __restrict__ core,
 // =================================================================================================
 // K13-K16: chain TIMs, GNC-TLS yaw, rotation-inlier chain rule, COTE, final inliers.  One workgroup
 // of 256 threads; wavefront 0 runs the GNC loop with the fixed-shape sum64 reductions.
-#define FIN_LDS_BYTES (144 * 1024)
+#define FIN_LDS_BYTES (152 * 1024)
+#define FIN_THREADS 768  // three groups of four wavefronts: one COTE axis each
 struct FinalizeArgs {
   const float4* src;
   const float4* tgt;
@@ -560,49 +605,63 @@ struct FinalizeArgs {
   qtr_result* res;   // device copy of the result record
 };
 
-// One COTE axis on one wavefront (reference estimate(), include/quatro.hpp:618-747).  Called by all four
-// waves of the workgroup with identical N / n2 so that the barriers match; `act` is false for the wave
-// that only keeps the barriers company.  __forceinline__ on purpose: at the LDS call site the pointers
-// derive directly from the dynamic shared array, so address-space inference turns every access into a
-// ds_* instruction (the generic-pointer version ran ~10x slower through the flat path).
+// One COTE axis on one GROUP of four wavefronts (256 threads; reference estimate(), include/quatro.hpp:618-747).
+// Every thread of the workgroup calls it with identical N so that the barriers match; `act` is false for
+// threads that only keep the barriers company.  Steps:
+//   1. the 2N interval endpoints, key = X -/+ range, insertion position = 2p / 2p+1
+//   2. bitonic sort by (key, position) across the 256 threads (O(n log^2 n) compare-exchanges: a rank-counting
+//      sort was VALU-bound, all three axes share ONE compute unit)
+//   3. the signed per-event terms of the six running sums, in parallel
+//   4. six lanes of one wave, one running sum each, add the terms in the reference's sequential order
+//      (binary64 addition is not associative, so the order is part of the result); loads run one batch of
+//      eight ahead of the dependent additions
+//   5. x_hat / cost per event and the arg-min with Eigen's minCoeff tie rule (first strict minimum)
+//   6. median of the consensus window by rank counting
+// __forceinline__ on purpose: at the LDS call site the pointers derive directly from the dynamic shared
+// array, so address-space inference turns every access into a ds_* instruction (generic pointers ran ~10x
+// slower through the flat path).
 struct CoteOut {
   double est;
   int ncard;
 };
-__device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* __restrict__ X, int N, int nc, int n2,
-                                             double range, int median_sel, double* ekey, int* epos, double* exv,
-                                             double* rs_w /* may alias ekey: dead after the sort */, double* rs_xw,
-                                             double* rs_rng, double* rs_x, double* rs_xx, int* card,
-                                             double* s_bcast /* [4] per axis */) {
-  if (act) {
-    for (int i = lane; i < n2; i += 64) {
-      if (i < nc) {
-        const int p = i >> 1;
-        ekey[i] = (i & 1) ? X[p] + range : X[p] - range;
-      } else {
-        ekey[i] = INFINITY;
-      }
+__device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __restrict__ X, int N, int nc,
+                                              double range, int median_sel, double* sxv, int* spos,
+                                              double* T /* 6 arrays of nc; first holds the sort keys/positions */,
+                                              double* s_bcast /* [4] per axis */, double* s_redc /* [4] */,
+                                              int* s_redi /* [4] */, int* dbg) {
+  const int lane = tl & 63, gw = tl >> 6;
+  long long tc0 = clock64(), tc1;
+#define COTE_TICK(slot)                                  \
+  if (dbg && tl == 0) {                                  \
+    tc1 = clock64();                                     \
+    dbg[slot] = (int)((tc1 - tc0) >> 4);                 \
+    tc0 = tc1;                                           \
+  }
+  // ---- 1./2. bitonic sort of (key, position), ascending; keys/positions live in the (still unused) T area
+  int n2 = 1;
+  while (n2 < nc) n2 <<= 1;
+  double* ekey = T;
+  int* epos = (int*)(T + n2);
+  if (act)
+    for (int i = tl; i < n2; i += 256) {
+      ekey[i] = (i < nc) ? ((i & 1) ? X[i >> 1] + range : X[i >> 1] - range) : INFINITY;
       epos[i] = i;
     }
-  }
-  // bitonic sort, ascending by (key, pos); every wave runs the same barrier sequence
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
       if (act) {
-        for (int i = lane; i < n2; i += 64) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const double ka = ekey[i], kb = ekey[ixj];
-            const int pa = epos[i], pb = epos[ixj];
-            const bool a_gt_b = (ka > kb) || (ka == kb && pa > pb);
-            const bool up = ((i & k) == 0);
-            if (a_gt_b == up) {
-              ekey[i] = kb;
-              ekey[ixj] = ka;
-              epos[i] = pb;
-              epos[ixj] = pa;
-            }
+        for (int t = tl; t < (n2 >> 1); t += 256) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+          const double ka = ekey[i], kb = ekey[ixj];
+          const int pa = epos[i], pb = epos[ixj];
+          const bool a_gt_b = (ka > kb) | ((ka == kb) & (pa > pb));
+          const bool up = ((i & k) == 0);
+          if (a_gt_b == up) {
+            ekey[i] = kb;
+            ekey[ixj] = ka;
+            epos[i] = pb;
+            epos[ixj] = pa;
           }
         }
       }
@@ -610,81 +669,87 @@ __device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* _
   }
   __syncthreads();
   if (act)
-    for (int i = lane; i < nc; i += 64) {
+    for (int i = tl; i < nc; i += 256) {
       const int p = epos[i];
-      // signed event value: the sweep needs eps and X only through eps*w, eps*w*X, eps*range, eps*X, eps*X*X
-      exv[i] = X[p >> 1];
+      spos[i] = p;
+      sxv[i] = X[p >> 1];
     }
+  COTE_TICK(0)
+  if (act && tl == 64) {  // sum of N ranges in the reference's order (:660), off the serial wave
+    double r = 0;
+    for (int i = 0; i < N; ++i) r += range;
+    s_bcast[2] = r;
+  }
   __syncthreads();
-  if (act && lane == 0) {
-    // ONE lane walks the events accumulating the running sums in the reference's order (binary64 addition
-    // is not associative); loads are issued four events ahead of the dependent additions
+  // ---- 3. per-event terms (sort keys are dead: T takes their place)
+  if (act) {
     const double weight = 1.0 / (range * range);
-    double ranges_inverse_sum = 0;
-    for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
-    double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
-    int consensus = 0;
-    int i = 0;
-    for (; i + 4 <= nc; i += 4) {
-      int ep[4];
-      double xv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ep[q] = epos[i + q];
-        xv[q] = exv[i + q];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int eps = (ep[q] & 1) ? -1 : 1;
-        consensus += eps;
-        dot_weights_consensus += eps * weight;
-        dot_X_weights += eps * weight * xv[q];
-        ranges_inverse_sum -= eps * range;
-        sum_xi += eps * xv[q];
-        sum_xi_square += eps * xv[q] * xv[q];
-        card[i + q] = consensus;
-        rs_w[i + q] = dot_weights_consensus;
-        rs_xw[i + q] = dot_X_weights;
-        rs_rng[i + q] = ranges_inverse_sum;
-        rs_x[i + q] = sum_xi;
-        rs_xx[i + q] = sum_xi_square;
-      }
-    }
-    for (; i < nc; ++i) {
-      const int eps = (epos[i] & 1) ? -1 : 1;
-      const double xv = exv[i];
-      consensus += eps;
-      dot_weights_consensus += eps * weight;
-      dot_X_weights += eps * weight * xv;
-      ranges_inverse_sum -= eps * range;
-      sum_xi += eps * xv;
-      sum_xi_square += eps * xv * xv;
-      card[i] = consensus;
-      rs_w[i] = dot_weights_consensus;
-      rs_xw[i] = dot_X_weights;
-      rs_rng[i] = ranges_inverse_sum;
-      rs_x[i] = sum_xi;
-      rs_xx[i] = sum_xi_square;
+    for (int i = tl; i < nc; i += 256) {
+      const int eps = (spos[i] & 1) ? -1 : 1;
+      const double xv = sxv[i];
+      T[i] = eps * weight;
+      T[(size_t)nc + i] = eps * weight * xv;
+      T[2 * (size_t)nc + i] = -(eps * range);
+      T[3 * (size_t)nc + i] = eps * xv;
+      T[4 * (size_t)nc + i] = eps * xv * xv;
+      T[5 * (size_t)nc + i] = (double)eps;
     }
   }
   __syncthreads();
+  COTE_TICK(1)
+  // ---- 4. running sums, in place: lane c of wave 0 owns array c
+  if (act && gw == 0 && lane < 6) {
+    double* t = T + (size_t)lane * nc;
+    double acc = (lane == 2) ? s_bcast[2] : 0.0;
+    int i = 0;
+    if (nc >= 8) {
+      double v[8], nx[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = t[q];
+      for (; i + 16 <= nc; i += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = t[i + 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc += v[q];
+          v[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[i + q] = v[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = nx[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc += v[q];
+        t[i + q] = acc;
+      }
+      i += 8;
+    }
+    for (; i < nc; ++i) {
+      acc += t[i];
+      t[i] = acc;
+    }
+  }
+  __syncthreads();
+  COTE_TICK(2)
+  // ---- 5. per-event estimate and cost, arg-min (first strict minimum; NaN is never selected unless first)
   int mi = 0, ncard = 0;
   double est = 0;
-  if (act) {
-    // per-event estimate and cost, then arg-min (first strict minimum; NaN is never selected unless first)
+  {
     double bc = INFINITY;
     int bi = 0x7fffffff;
-    double c0 = 0;
-    for (int i = lane; i < nc; i += 64) {
-      const double xh = rs_xw[i] / rs_w[i];
-      const double residual = card[i] * xh * xh + rs_xx[i] - 2 * rs_x[i] * xh;
-      const double c = residual + rs_rng[i];
-      if (i == 0) c0 = c;
-      if (c < bc || (c == bc && i < bi)) {
-        bc = c;
-        bi = i;
+    if (act)
+      for (int i = tl; i < nc; i += 256) {
+        const double xh = T[(size_t)nc + i] / T[i];
+        const double residual = T[5 * (size_t)nc + i] * xh * xh + T[4 * (size_t)nc + i] - 2 * T[3 * (size_t)nc + i] * xh;
+        const double c = residual + T[2 * (size_t)nc + i];
+        if (i == 0) s_bcast[3] = c;
+        if (c < bc || (c == bc && i < bi)) {
+          bc = c;
+          bi = i;
+        }
       }
-    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const double oc = __shfl_xor(bc, off, 64);
@@ -694,26 +759,45 @@ __device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* _
         bi = oi;
       }
     }
-    mi = bi;
-    c0 = __shfl(c0, 0, 64);
-    if (mi == 0x7fffffff || c0 != c0) mi = 0;
-    ncard = card[mi];
-    est = rs_xw[mi] / rs_w[mi];
-    if (lane == 0) {
+    if (act && lane == 0) {
+      s_redc[gw] = bc;
+      s_redi[gw] = bi;
+    }
+    if (act && tl == 0) {
       s_bcast[0] = 0;
       s_bcast[1] = 0;
     }
+    __syncthreads();
+    if (act) {
+      bc = s_redc[0];
+      bi = s_redi[0];
+#pragma unroll
+      for (int g = 1; g < 4; ++g) {
+        const double oc = s_redc[g];
+        const int oi = s_redi[g];
+        if (oc < bc || (oc == bc && oi < bi)) {
+          bc = oc;
+          bi = oi;
+        }
+      }
+      mi = bi;
+      const double c0 = s_bcast[3];
+      if (mi == 0x7fffffff || c0 != c0) mi = 0;
+      ncard = (int)T[5 * (size_t)nc + mi];
+      est = T[(size_t)nc + mi] / T[mi];
+    }
   }
   __syncthreads();
+  COTE_TICK(3)
+  // ---- 6. the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}
   if (act && median_sel && ncard >= 2) {
-    // the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}, by rank counting
     const int ra = ncard / 2 - 1, rb = ncard / 2;
-    for (int j = lane; j < ncard; j += 64) {
-      const double vj = exv[mi - j];
+    for (int j = tl; j < ncard; j += 256) {
+      const double vj = sxv[mi - j];
       int rk = 0;
       for (int q = 0; q < ncard; ++q) {
-        const double vq = exv[mi - q];
-        rk += (vq < vj) || (vq == vj && q < j);
+        const double vq = sxv[mi - q];
+        rk += ((vq < vj) | ((vq == vj) & (q < j))) ? 1 : 0;
       }
       if (rk == ra) s_bcast[0] = vj;
       if (rk == rb) s_bcast[1] = vj;
@@ -724,8 +808,10 @@ __device__ __forceinline__ CoteOut cote_axis(bool act, int lane, const double* _
     if (ncard >= 2)
       est = (s_bcast[0] + s_bcast[1]) / 2.0;
     else if (ncard == 1)
-      est = exv[mi];
+      est = sxv[mi];
   }
+  COTE_TICK(4)
+#undef COTE_TICK
   CoteOut o;
   o.est = est;
   o.ncard = ncard;
@@ -806,7 +892,7 @@ __global__ __launch_bounds__(256) void k_row_degrees(u64* __restrict__ bm, int L
   if (lane == 0) deg[row] = c;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   extern __shared__ __attribute__((aligned(16))) double fin_lds[];
   __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
   __shared__ double s_R[4], s_cost, s_est, s_bestcost;
@@ -1007,42 +1093,32 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
   __syncthreads();
 
   const long long t_fin3 = clock64();
-  // ---- COTE (reference estimate(), :618-747).  The three axes are independent: wavefront a handles axis a
-  // (wave 3 only joins the barriers).  Per axis: (1) bitonic sort of the 2N interval endpoints by
-  // (value, insertion position), (2) one lane walks the events accumulating the five running sums in the
-  // reference's order, (3) the wave evaluates x_hat / cost per event and takes the arg-min with Eigen's
-  // minCoeff tie rule, (4) median of the consensus window by rank counting.
+  // ---- COTE (reference estimate(), :618-747).  The three axes are independent: threads 256a..256a+255
+  // handle axis a (see cote_axis4).
   const double range = A.prm.cote_noise_bound * sqrt(A.prm.cbar2);
   const int nc = 2 * N;
-  int n2 = 1;
-  while (n2 < nc) n2 <<= 1;
-  const int ax = wave;
+  const int ax = tid >> 8, tl = tid & 255;
   const bool act = ax < 3;
   const int axc = act ? ax : 0;
-  __shared__ double s_axis_est[3], s_bc[3][4];
-  __shared__ int s_axis_ncard[3];
+  __shared__ double s_axis_est[3], s_bc[3][4], s_redc[3][4];
+  __shared__ int s_axis_ncard[3], s_redi[3][4];
   const double* X = RAW + (size_t)axc * L;
-  // bytes one axis needs: ekey n2*8 (re-used for the first running sum), epos n2*4, then 5 arrays of nc
-  // doubles and card nc*4 (16-byte aligned)
-  const size_t a_ekey = 0, a_epos = a_ekey + (((size_t)n2 * 8 + 15) & ~(size_t)15),
-               a_exv = a_epos + (((size_t)n2 * 4 + 15) & ~(size_t)15), a_arr = (((size_t)nc * 8 + 15) & ~(size_t)15),
-               a_card = a_exv + 5 * a_arr, a_total = a_card + (((size_t)nc * 4 + 15) & ~(size_t)15);
+  // bytes one axis needs: sorted X nc*8, sorted positions nc*4, six term / running-sum arrays of nc doubles
+  const size_t a_arr = (((size_t)nc * 8 + 15) & ~(size_t)15), a_spos = a_arr,
+               a_T = a_spos + (((size_t)nc * 4 + 15) & ~(size_t)15), a_total = a_T + 6 * a_arr;
   __syncthreads();  // GNC arrays in LDS are dead from here on
   CoteOut co;
   if (3 * a_total <= (size_t)FIN_LDS_BYTES) {
     char* base = (char*)fin_lds + (size_t)axc * a_total;  // LDS: pointers derive from the shared array
-    co = cote_axis(act, lane, X, N, nc, n2, range, A.prm.cote_median, (double*)(base + a_ekey), (int*)(base + a_epos),
-                   (double*)(base + a_exv), (double*)(base + a_ekey), (double*)(base + a_exv + 1 * a_arr),
-                   (double*)(base + a_exv + 2 * a_arr), (double*)(base + a_exv + 3 * a_arr),
-                   (double*)(base + a_exv + 4 * a_arr), (int*)(base + a_card), s_bc[axc]);
+    co = cote_axis4(act, tl, X, N, nc, range, A.prm.cote_median, (double*)base, (int*)(base + a_spos),
+                    (double*)(base + a_T), s_bc[axc], s_redc[axc], s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   } else {
     double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
     int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
-    co = cote_axis(act, lane, X, N, nc, n2, range, A.prm.cote_median, gf, gi, gf + 4 * (size_t)L, gf + 6 * (size_t)L,
-                   gf + 8 * (size_t)L, gf + 10 * (size_t)L, gf + 12 * (size_t)L, gf + 14 * (size_t)L, gi + 4 * (size_t)L,
-                   s_bc[axc]);
+    co = cote_axis4(act, tl, X, N, nc, range, A.prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
+                    s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   }
-  if (act && lane == 0) {
+  if (act && tl == 0) {
     s_axis_est[ax] = co.est;
     s_axis_ncard[ax] = co.ncard;
     res->n_card[ax] = co.ncard;
@@ -1098,8 +1174,11 @@ hipError_t solver_init_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_kcore_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+#define KCW_ATTR(JM)                                                                                                  \
+  e = hipFuncSetAttribute((const void*)k_kcore_wave<JM>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);     \
   if (e != hipSuccess) return e;
+  KCW_ATTR(4) KCW_ATTR(6) KCW_ATTR(8) KCW_ATTR(10) KCW_ATTR(12) KCW_ATTR(14) KCW_ATTR(16) KCW_ATTR(18)
+#undef KCW_ATTR
   e = hipFuncSetAttribute((const void*)k_clique_batch_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1166,7 +1245,7 @@ static void launch_finalize(const SolverBufs& B, const float4* src, const float4
   A.f64 = B.f64;
   A.i32 = B.i32;
   A.res = B.res;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), (size_t)FIN_LDS_BYTES, stream, A);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, A);
 }
 
 // K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds.  Expects the bit matrix in
@@ -1177,10 +1256,20 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
-    const bool kc_single_wave = (L <= 64 * KCW_JMAX) && (bm_bytes + 64 <= (size_t)150 * 1024);
+    const bool kc_single_wave = (L <= 64 * KCW_JMAX) && (bm_bytes + (size_t)W * 8 + 64 <= (size_t)150 * 1024);
     if (kc_single_wave) {
-      hipLaunchKernelGGL(k_kcore_wave, dim3(1), dim3(256), bm_bytes + 64, stream, B.bm, L, W, B.deg, B.core,
-                         B.st);
+      const size_t kcw_lds = bm_bytes + (size_t)W * 8 + 64;
+#define KCW_LAUNCH(JM)                                                                                          \
+  hipLaunchKernelGGL(k_kcore_wave<JM>, dim3(1), dim3(256), kcw_lds, stream, B.bm, L, W, B.deg, B.core, B.st)
+      if (W <= 4) KCW_LAUNCH(4);
+      else if (W <= 6) KCW_LAUNCH(6);
+      else if (W <= 8) KCW_LAUNCH(8);
+      else if (W <= 10) KCW_LAUNCH(10);
+      else if (W <= 12) KCW_LAUNCH(12);
+      else if (W <= 14) KCW_LAUNCH(14);
+      else if (W <= 16) KCW_LAUNCH(16);
+      else KCW_LAUNCH(18);
+#undef KCW_LAUNCH
     } else {
     const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
     const int kc_threads = 1024;
