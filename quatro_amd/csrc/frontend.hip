@@ -191,6 +191,96 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   }
 }
 
+// One radix pass in ONE launch.  Every tile (a) counts its digits into LDS, keeping its 1024 keys in
+// registers, (b) publishes the 256 counters (tile-major, one coalesced 1 KB row) and raises its flag to
+// this launch's epoch, (c) waits until every tile of the cloud has done so — all tiles of a launch are
+// co-resident (single-wave workgroups, at most a few hundred of them), so the wait is a grid-wide barrier
+// that costs about one tile's counting time — then (d) turns the rows into its own digit offsets
+//   base[d] = sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d]
+// and (e) ranks and scatters exactly as d_radix_scatter does.  Epochs only grow, so flags never need clearing.
+template <int TILE>
+__device__ __forceinline__ void d_radix_pass(const u64* __restrict__ in, u64* __restrict__ out, int n, int shift,
+                                             u32* __restrict__ hist, u32* __restrict__ flags, int nblk, u32 epoch) {
+  constexpr int NB = 256, ITER = TILE / 64;
+  __shared__ u32 cnt[NB];
+  __shared__ u32 base[NB];
+  const int lane = threadIdx.x, blk = blockIdx.x;
+  if (blk >= nblk) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cnt[lane * 4 + q] = 0;
+  __syncthreads();
+  const int tbase = blk * TILE;
+  u64 key[ITER];
+#pragma unroll
+  for (int s = 0; s < ITER; ++s) {
+    const int i = tbase + s * 64 + lane;
+    key[s] = (i < n) ? in[i] : 0ULL;
+  }
+#pragma unroll
+  for (int s = 0; s < ITER; ++s) {
+    const int i = tbase + s * 64 + lane;
+    if (i < n) atomicAdd(&cnt[(u32)(key[s] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  uint4 mine;
+  mine.x = cnt[lane * 4 + 0];
+  mine.y = cnt[lane * 4 + 1];
+  mine.z = cnt[lane * 4 + 2];
+  mine.w = cnt[lane * 4 + 3];
+  ((uint4*)(hist + (size_t)blk * NB))[lane] = mine;
+  __threadfence();
+  __syncthreads();
+  if (lane == 0) __hip_atomic_store(&flags[blk], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  for (int b = lane; b < nblk; b += 64)
+    while (__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  __syncthreads();
+  {
+    u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblk; ++b) {
+      const uint4 h = ((const uint4*)(hist + (size_t)b * NB))[lane];
+      const u32 m = (b < blk) ? 0xffffffffu : 0u;
+      tot[0] += h.x;
+      tot[1] += h.y;
+      tot[2] += h.z;
+      tot[3] += h.w;
+      before[0] += h.x & m;
+      before[1] += h.y & m;
+      before[2] += h.z & m;
+      before[3] += h.w & m;
+    }
+    int wtot;
+    const int ex = wave_excl_scan_i32((int)(tot[0] + tot[1] + tot[2] + tot[3]), &wtot);
+    u32 run = (u32)ex;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      base[lane * 4 + q] = run + before[q];
+      run += tot[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < ITER; ++s) {
+    const int i = tbase + s * 64 + lane;
+    const bool valid = i < n;
+    const u32 d = (u32)(key[s] >> shift) & 255u;
+    u64 m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const u64 b = __ballot(valid && one);
+      m &= one ? b : ~b;
+    }
+    if (valid) {
+      const u32 pos = base[d] + (u32)__popcll(m & lanemask_lt());
+      out[pos] = key[s];
+    }
+    __syncthreads();  // single-wave workgroup: orders the LDS reads above before the updates below
+    if (valid && (m & lanemask_lt()) == 0) base[d] += (u32)__popcll(m);
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ void d_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
   // out[0..n] = exclusive scan of in[0..n) ; single workgroup
   __shared__ int wsum[16];
@@ -872,6 +962,7 @@ struct CloudView {
   const u64* keys_in;  // ping-pong roles of the current radix pass
   u64* keys_out;
   u32* hist;
+  u32* flags;         // per-tile epoch flags of the single-launch radix pass
   int* blkcnt;
   int* blkoff;
   int* nbr_cnt;
@@ -916,6 +1007,10 @@ __global__ __launch_bounds__(1024) void k2_radix_scan(Clouds2 a) {
 __global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift) {
   const CloudView& C = a.c[blockIdx.y];
   d_radix_scatter<8, RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
+}
+__global__ __launch_bounds__(64) void k2_radix_pass(Clouds2 a, int use_vox, int shift, u32 epoch) {
+  const CloudView& C = a.c[blockIdx.y];
+  d_radix_pass<RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.flags, C.nblk, epoch);
 }
 __global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a) {
   const CloudView& C = a.c[blockIdx.y];
@@ -983,6 +1078,7 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
   v.spfh = C.spfh;
   v.fpfh = C.fpfh;
   v.hist = C.hist;
+  v.flags = C.flags;
   v.nbr_cnt = C.nbr_cnt;
   v.nbr_off = C.nbr_off;
   v.nbr_idx = C.nbr_idx;
@@ -994,7 +1090,8 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
 }
 
 // stable LSD radix sort of keys_a (both clouds) by bits [32, 32+key_bits); returns which buffer holds the result
-static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st) {
+static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st,
+                       u32* epoch) {
   int maxblk = 1;
   for (int c = 0; c < nc; ++c) {
     const int n = use_vox ? a.c[c].n : a.c[c].P;
@@ -1007,8 +1104,12 @@ static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int
       a.c[c].keys_in = src == 0 ? C[c]->keys_a : C[c]->keys_b;
       a.c[c].keys_out = src == 0 ? C[c]->keys_b : C[c]->keys_a;
     }
-    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
-    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    if (maxblk * nc <= RADIX_ONEPASS_MAX_TILES) {
+      hipLaunchKernelGGL(k2_radix_pass, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift, ++*epoch);
+    } else {  // too many tiles to rely on co-residency: two launches per pass
+      hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+      hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    }
     src ^= 1;
   }
   return src;
@@ -1033,7 +1134,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 0);
   hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 0);
   hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, a, leaf);
-  const int where = radix_sort2(a, C, nc, 0, 32, st);
+  const int where = radix_sort2(a, C, nc, 0, 32, st, &F.radix_epoch);
   for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
   if (nc == 1) a.c[1] = a.c[0];
   const int nblk = (maxP + 1023) / 1024;
@@ -1078,7 +1179,7 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 1);  // keeps the counters of the voxel stage
   hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 1);
   hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, a, cell);
-  const int where = radix_sort2(a, C, nc, 1, 24, st);
+  const int where = radix_sort2(a, C, nc, 1, 24, st, &F.radix_epoch);
   for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
   if (nc == 1) a.c[1] = a.c[0];
   hipLaunchKernelGGL(k2_sorted_points, dim3(g, nc), dim3(256), 0, st, a);
@@ -1130,6 +1231,8 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.keys_a = (u64*)take((size_t)max_points * 8);
     C.keys_b = (u64*)take((size_t)max_points * 8);
     C.hist = (u32*)take((size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4);
+    C.flags = C.hist + (size_t)3072 * ((max_points + RADIX_TILE - 1) / RADIX_TILE);  // unused tail of the hist area
+    (void)hipMemset(C.flags, 0, (size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE) * 4);
     C.nbr_cnt = (int*)take((size_t)max_voxels * 4);
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);
