@@ -173,152 +173,122 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
   }
 }
 
-// Single-wavefront variant for graphs whose bit matrix fits in LDS (L up to 1152): the peeling of a
-// dense consistency graph takes hundreds of rounds (one per occupied level), so the cost per round is
-// what matters.  Lane l owns vertices j*64+l and keeps their degrees in REGISTERS; removing vertex v is
-// "for every word j of row v: my degree[j] -= bit l of that word" — a broadcast LDS read and three VALU
-// ops per word, no atomics, no barriers, no per-round memory round trips.
-#define KCW_JMAX 18  // 64 * 18 = 1152 vertices
-#define KCW_GONE 0x3fffffff  // degree of a removed (or non-existent) vertex
-// JM = words per row rounded up to an even count (template: every per-round loop is fully unrolled over
-// the words the graph really has).  LDS holds L+1 rows: row L is all zero and stands in for the unused
-// slots of a batch of four frontier vertices.
-template <int JM>
-__device__ __forceinline__ void kcw_subtract4(const u32* __restrict__ rows32, int W, int halfsel, int bitsel, int v0,
-                                              int v1, int v2, int v3, int (&dreg)[JM]) {
-  const u32* r0 = rows32 + (size_t)v0 * W * 2 + halfsel;
-  const u32* r1 = rows32 + (size_t)v1 * W * 2 + halfsel;
-  const u32* r2 = rows32 + (size_t)v2 * W * 2 + halfsel;
-  const u32* r3 = rows32 + (size_t)v3 * W * 2 + halfsel;
-  u32 x0[JM], x1[JM], x2[JM], x3[JM];
+// Level-parallel variant for graphs whose bit matrix fits in LDS (L up to ~1100): peeling is a chain of
+// hundreds of dependent rounds (one per occupied level, ~1 us each however few lanes they keep busy), but
+// the k-cores themselves are independent of one another.  Workgroup k computes the k-core directly:
+//     alive = {deg >= k};  repeat  alive = {v in alive : |N(v) & alive| >= k}  until nothing changes
+// (a handful of sweeps, each one popcount per row word), and writes its membership mask M[k].  The cores are
+// nested, so core(v) = max{k : v in M[k]}; the workgroup that finishes last gathers the masks into LDS and
+// binary-searches every vertex's column.  Core numbers are unique, so this equals compute_cores' result.
+// LDS layout is word-major (rowsT[w][v]): lane = vertex makes every read conflict free.
+#define KCL_VPT 5  // vertices per thread: 256 * 5 = 1280 >= any L whose matrix fits in LDS
+__global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm, int L, int W,
+                                                     const int* __restrict__ deg_in, u64* __restrict__ M,
+                                                     int* __restrict__ core_out, SolverState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) u64 kcl_rows[];  // [W][L]
+  __shared__ u64 s_alive[2][4 * KCL_VPT];
+  __shared__ int s_cnt, s_last, s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x + 1;
+  const int vpt = (L + 255) >> 8;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  u32 amask = 0;  // bit i: my vertex i*256+tid is alive
+  int mydeg[KCL_VPT];
+  {
+    int c = 0;
 #pragma unroll
-  for (int w = 0; w < JM; ++w) {
-    const int ww = 2 * (w < W ? w : W - 1);
-    x0[w] = r0[ww];
-    x1[w] = r1[ww];
-    x2[w] = r2[ww];
-    x3[w] = r3[ww];
-  }
-#pragma unroll
-  for (int w = 0; w < JM; ++w) {
-    const int s = (int)((x0[w] >> bitsel) & 1u) + (int)((x1[w] >> bitsel) & 1u) + (int)((x2[w] >> bitsel) & 1u) +
-                  (int)((x3[w] >> bitsel) & 1u);
-    dreg[w] -= (w < W) ? s : 0;
-  }
-}
-
-template <int JM>
-__global__ __launch_bounds__(256) void k_kcore_wave(const u64* __restrict__ bm, int L, int W,
-                                                   const int* __restrict__ deg_in, int* __restrict__ core_out,
-                                                   SolverState* __restrict__ st) {
-  extern __shared__ __attribute__((aligned(16))) u64 kcw_rows[];
-  // all four waves stage the bit matrix; wave 0 alone runs the peeling
-#pragma unroll 8
-  for (int e = threadIdx.x; e < L * W; e += 256) kcw_rows[e] = bm[e];
-  for (int e = threadIdx.x; e < W; e += 256) kcw_rows[(size_t)L * W + e] = 0;
-  const int lane = threadIdx.x & 63;
-  int dreg[JM], creg[JM];
-  int esum = 0;
-  if (threadIdx.x < 64) {
-    int dl[JM];
-#pragma unroll
-    for (int j = 0; j < JM; ++j) dl[j] = deg_in[min(j * 64 + lane, L - 1)];  // one burst of independent loads
-#pragma unroll
-    for (int j = 0; j < JM; ++j) {
-      const bool in = j * 64 + lane < L;
-      dreg[j] = in ? dl[j] : KCW_GONE;
-      creg[j] = 0;
-      esum += in ? dl[j] : 0;
+    for (int i = 0; i < KCL_VPT; ++i) {
+      const int v = i * 256 + tid;
+      mydeg[i] = (i < vpt && v < L) ? deg_in[v] : -1;
+      const bool a = mydeg[i] >= k;
+      amask |= a ? (1u << i) : 0u;
+      const u64 mk = __ballot(a);
+      if (lane == 0) s_alive[0][i * 4 + wave] = mk;
+      c += (lane == 0) ? __popcll(mk) : 0;
     }
-    esum = wave_sum_i32(esum);
+    if (lane == 0 && c) atomicAdd(&s_cnt, c);
   }
   __syncthreads();
-  if (threadIdx.x >= 64) return;
-  int k = -1, maxcore = 0, rounds = 0;
-  const u32* rows32 = (const u32*)kcw_rows;
-  const int halfsel = lane >> 5, bitsel = lane & 31;
-  while (true) {
-    ++rounds;
-    // frontier of level k: removed vertices carry a huge positive degree and never hit
-    u32 hitbits = 0;
-#pragma unroll
-    for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
-    u64 hl = __ballot(hitbits != 0);
-    if (hl == 0) {
-      // level exhausted: the next occupied level is usually k+1; probe a few, then jump to the minimum
-      int tries = 0;
-      while (hl == 0 && tries < 4) {
-        ++k;
-        ++tries;
-        hitbits = 0;
-#pragma unroll
-        for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
-        hl = __ballot(hitbits != 0);
-      }
-      if (hl == 0) {
-        int m = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < JM; ++j) m = min(m, dreg[j]);
-        m = wave_min_i32(m);
-        if (m >= KCW_GONE / 2) break;
-        k = m;
-        hitbits = 0;
-#pragma unroll
-        for (int j = 0; j < JM; ++j) hitbits |= (dreg[j] <= k ? 1u : 0u) << j;
-        hl = __ballot(hitbits != 0);
-      }
+  int par = 0, sweeps = 0;
+  if (s_cnt > k) {  // a k-core needs k+1 vertices
+    for (int e = tid; e < L * W; e += 256) {
+      const int r = e / W, c = e - r * W;
+      kcl_rows[(size_t)c * L + r] = bm[e];
     }
-    maxcore = k;
-    // mark this round's frontier as removed ...
-    int alive_min = 0x7fffffff;
+    __syncthreads();
+    while (true) {
+      ++sweeps;
+      int changed = 0;
 #pragma unroll
-    for (int j = 0; j < JM; ++j) {
-      const bool hit = (hitbits >> j) & 1u;
-      dreg[j] = hit ? KCW_GONE : dreg[j];
-      creg[j] = hit ? k : creg[j];
-      alive_min = min(alive_min, dreg[j]);
-    }
-    // ... if that emptied the graph (the top core leaves all at once) nobody is left to update
-    if (__ballot(alive_min < KCW_GONE / 2) == 0) break;
-    // ... then subtract the frontier vertices' rows from everybody's degrees, four rows per batch: lanes
-    // 0-31 read the low half-word of word w, lanes 32-63 the high one (two broadcast addresses)
-    int v0 = L, v1 = L, v2 = L, nq = 0;
-    while (hl) {
-      const int l = __ffsll((long long)hl) - 1;
-      hl &= hl - 1;
-      u32 hb = (u32)__builtin_amdgcn_readlane((int)hitbits, l);
-      while (hb) {
-        const int j = __ffs((int)hb) - 1;
-        hb &= hb - 1;
-        const int v = j * 64 + l;
-        if (nq == 0) {
-          v0 = v;
-          nq = 1;
-        } else if (nq == 1) {
-          v1 = v;
-          nq = 2;
-        } else if (nq == 2) {
-          v2 = v;
-          nq = 3;
-        } else {
-          kcw_subtract4<JM>(rows32, W, halfsel, bitsel, v0, v1, v2, v, dreg);
-          v0 = v1 = v2 = L;
-          nq = 0;
+      for (int i = 0; i < KCL_VPT; ++i) {
+        if (i < vpt) {
+          const int v = i * 256 + tid;
+          if ((amask >> i) & 1u) {
+            int d = 0;
+            for (int w = 0; w < W; ++w) d += __popcll(kcl_rows[(size_t)w * L + v] & s_alive[par][w]);
+            if (d < k) {
+              amask &= ~(1u << i);
+              changed = 1;
+            }
+          }
+          const u64 mk = __ballot((amask >> i) & 1u);
+          if (lane == 0) s_alive[par ^ 1][i * 4 + wave] = mk;
         }
       }
+      par ^= 1;
+      if (!__syncthreads_or(changed)) break;
     }
-    if (nq) kcw_subtract4<JM>(rows32, W, halfsel, bitsel, v0, v1, v2, L, dreg);
-  }
+  } else {
+    amask = 0;
 #pragma unroll
-  for (int j = 0; j < JM; ++j) {
-    const int v = j * 64 + lane;
-    if (v < L) core_out[v] = creg[j];
+    for (int i = 0; i < KCL_VPT; ++i)
+      if (lane == 0) s_alive[0][i * 4 + wave] = 0;
+    __syncthreads();
   }
+  if (tid < W) M[(size_t)k * W + tid] = s_alive[par][tid];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(&st->pad[5], 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  // ---- last workgroup: gather the masks and read every vertex's core number off its column
+  __threadfence();
+  const int K = (int)gridDim.x;  // masks exist for k = 1..K
+  for (int e = tid; e < K * W; e += 256) kcl_rows[e] = M[(size_t)W + e];  // kcl_rows[(k-1)*W + w]
+  __syncthreads();
+  int esum = 0, cmax = 0;
+#pragma unroll
+  for (int i = 0; i < KCL_VPT; ++i) {
+    const int v = i * 256 + tid;
+    if (i < vpt && v < L) {
+      int lo = 0, hi = min(mydeg[i], K);
+      const int wv = v >> 6, bv = v & 63;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((kcl_rows[(size_t)(mid - 1) * W + wv] >> bv) & 1ULL)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      core_out[v] = lo;
+      cmax = max(cmax, lo);
+      esum += mydeg[i];
+    }
+  }
+  cmax = wave_max_i32(cmax);
+  esum = wave_sum_i32(esum);
   if (lane == 0) {
-    st->max_core = maxcore;
-    st->ub = maxcore + 1;
-    st->n_edges2 = esum;
-    st->pad[0] = rounds;
+    s_red[wave] = cmax;
+    s_red[4 + wave] = esum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int mc = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    st->max_core = mc;
+    st->ub = mc + 1;
+    st->n_edges2 = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    st->pad[0] = sweeps;
   }
 }
 
@@ -1174,11 +1144,8 @@ hipError_t solver_init_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
-#define KCW_ATTR(JM)                                                                                                  \
-  e = hipFuncSetAttribute((const void*)k_kcore_wave<JM>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);     \
+  e = hipFuncSetAttribute((const void*)k_kcore_levels, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
-  KCW_ATTR(4) KCW_ATTR(6) KCW_ATTR(8) KCW_ATTR(10) KCW_ATTR(12) KCW_ATTR(14) KCW_ATTR(16) KCW_ATTR(18)
-#undef KCW_ATTR
   e = hipFuncSetAttribute((const void*)k_clique_batch_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1256,20 +1223,10 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
-    const bool kc_single_wave = (L <= 64 * KCW_JMAX) && (bm_bytes + (size_t)W * 8 + 64 <= (size_t)150 * 1024);
+    const bool kc_single_wave = (L <= 256 * KCL_VPT) && (bm_bytes <= (size_t)150 * 1024);
     if (kc_single_wave) {
-      const size_t kcw_lds = bm_bytes + (size_t)W * 8 + 64;
-#define KCW_LAUNCH(JM)                                                                                          \
-  hipLaunchKernelGGL(k_kcore_wave<JM>, dim3(1), dim3(256), kcw_lds, stream, B.bm, L, W, B.deg, B.core, B.st)
-      if (W <= 4) KCW_LAUNCH(4);
-      else if (W <= 6) KCW_LAUNCH(6);
-      else if (W <= 8) KCW_LAUNCH(8);
-      else if (W <= 10) KCW_LAUNCH(10);
-      else if (W <= 12) KCW_LAUNCH(12);
-      else if (W <= 14) KCW_LAUNCH(14);
-      else if (W <= 16) KCW_LAUNCH(16);
-      else KCW_LAUNCH(18);
-#undef KCW_LAUNCH
+      hipLaunchKernelGGL(k_kcore_levels, dim3(L > 1 ? L - 1 : 1), dim3(256), bm_bytes, stream, B.bm, L, W, B.deg, B.adjP,
+                         B.core, B.st);
     } else {
     const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
     const int kc_threads = 1024;
