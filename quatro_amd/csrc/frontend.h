@@ -4,7 +4,6 @@
 
 #define QTR_KMAX 256        // capacity of one point's radius-neighbour list (entries)
 #define RADIX_TILE 1024     // elements per radix-sort workgroup (one wavefront)
-#define RADIX_ONEPASS_MAX_TILES 2048  // single-launch passes need all tiles co-resident (256 CUs x 8+ waves)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
@@ -22,7 +21,6 @@ struct CloudBufs {
   u64* keys_a = nullptr;       // [max_points] sort ping
   u64* keys_b = nullptr;       // [max_points] sort pong
   u32* hist = nullptr;         // radix histograms / block counters
-  u32* flags = nullptr;        // per-tile epoch flags of the single-launch radix pass (zeroed at carve time)
   int* nbr_cnt = nullptr;      // [max_voxels]
   int* nbr_off = nullptr;      // [max_voxels+1] CSR view (exclusive scan of nbr_cnt) for inspection
   int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
@@ -54,7 +52,6 @@ struct FrontBufs {
   int* mcounts = nullptr;      // 16
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
-  u32 radix_epoch = 0;         // launch counter of k2_radix_pass (flags hold the epoch of their last pass)
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
   int nn_target_waves = 2048;  // waves per k_nn_mfma launch aimed at when slicing the base cloud (QTR_NN_WAVES)
   hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)

@@ -90,12 +90,25 @@ __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, 
   for (int d = lane; d < NB; d += 64) cnt[d] = 0;
   __syncthreads();
   const int base = blk * TILE;
-  for (int s = 0; s < TILE; s += 64) {
-    const int i = base + s + lane;
-    if (i < n) atomicAdd(&cnt[(u32)(in[i] >> shift) & (u32)(NB - 1)], 1u);
+  u64 keys[TILE / 64];
+#pragma unroll
+  for (int s = 0; s < TILE / 64; ++s) {
+    const int i = base + s * 64 + lane;
+    keys[s] = (i < n) ? in[i] : 0ULL;
+  }
+#pragma unroll
+  for (int s = 0; s < TILE / 64; ++s) {
+    const int i = base + s * 64 + lane;
+    if (i < n) atomicAdd(&cnt[(u32)(keys[s] >> shift) & (u32)(NB - 1)], 1u);
   }
   __syncthreads();
-  for (int d = lane; d < NB; d += 64) hist[d * nblk + blk] = cnt[d];
+  static_assert(NB == 256, "tile-major rows of 256 counters, four per lane");
+  uint4 mine;
+  mine.x = cnt[lane * 4 + 0];
+  mine.y = cnt[lane * 4 + 1];
+  mine.z = cnt[lane * 4 + 2];
+  mine.w = cnt[lane * 4 + 3];
+  ((uint4*)(hist + (size_t)blk * NB))[lane] = mine;  // hist[blk][digit]: one coalesced 1 KB row per tile
 }
 
 // exclusive scan of m 32-bit counters by one workgroup (m up to a few hundred thousand)
@@ -142,21 +155,27 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   const int lane = threadIdx.x, blk = blockIdx.x;
   if (blk >= nblk) return;
   // offsets from the RAW per-tile histograms (no separate scan launch): digit d of this tile starts at
-  //   sum_{d'<d} total[d'] + sum_{b<blk} hist[d][b]
+  //   sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d]        (rows are tile-major: one 16-byte load per tile)
   {
     static_assert(NB == 256, "offset computation below assumes 4 digits per lane");
-    u32 tot[4], before[4];
+    u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+    for (int b0 = 0; b0 < nblk; b0 += 16) {  // 16 rows in flight per round trip
+      uint4 h[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int d = lane * 4 + q;
-      u32 t = 0, bf = 0;
-      for (int b = 0; b < nblk; ++b) {
-        const u32 h = hist[d * nblk + b];
-        bf += (b < blk) ? h : 0u;
-        t += h;
+      for (int q = 0; q < 16; ++q) h[q] = ((const uint4*)(hist + (size_t)min(b0 + q, nblk - 1) * NB))[lane];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int b = b0 + q;
+        const u32 live = (b < nblk) ? 0xffffffffu : 0u, m = (b < blk) ? 0xffffffffu : 0u;
+        tot[0] += h[q].x & live;
+        tot[1] += h[q].y & live;
+        tot[2] += h[q].z & live;
+        tot[3] += h[q].w & live;
+        before[0] += h[q].x & m;
+        before[1] += h[q].y & m;
+        before[2] += h[q].z & m;
+        before[3] += h[q].w & m;
       }
-      tot[q] = t;
-      before[q] = bf;
     }
     int wtot;
     const int ex = wave_excl_scan_i32((int)(tot[0] + tot[1] + tot[2] + tot[3]), &wtot);
@@ -169,10 +188,18 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   }
   __syncthreads();
   const int tbase = blk * TILE;
-  for (int s = 0; s < TILE; s += 64) {
-    const int i = tbase + s + lane;
+  constexpr int ITER = TILE / 64;
+  u64 keys[ITER];  // the whole tile in registers: the barriers below would otherwise serialise 16 global loads
+#pragma unroll
+  for (int s = 0; s < ITER; ++s) {
+    const int i = tbase + s * 64 + lane;
+    keys[s] = (i < n) ? in[i] : 0ULL;
+  }
+#pragma unroll
+  for (int s = 0; s < ITER; ++s) {
+    const int i = tbase + s * 64 + lane;
     const bool valid = i < n;
-    const u64 key = valid ? in[i] : 0ULL;
+    const u64 key = keys[s];
     const u32 d = (u32)(key >> shift) & (u32)(NB - 1);
     u64 m = __ballot(valid);
 #pragma unroll
@@ -184,96 +211,6 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
     if (valid) {
       const u32 pos = base[d] + (u32)__popcll(m & lanemask_lt());
       out[pos] = key;
-    }
-    __syncthreads();  // single-wave workgroup: orders the LDS reads above before the updates below
-    if (valid && (m & lanemask_lt()) == 0) base[d] += (u32)__popcll(m);
-    __syncthreads();
-  }
-}
-
-// One radix pass in ONE launch.  Every tile (a) counts its digits into LDS, keeping its 1024 keys in
-// registers, (b) publishes the 256 counters (tile-major, one coalesced 1 KB row) and raises its flag to
-// this launch's epoch, (c) waits until every tile of the cloud has done so — all tiles of a launch are
-// co-resident (single-wave workgroups, at most a few hundred of them), so the wait is a grid-wide barrier
-// that costs about one tile's counting time — then (d) turns the rows into its own digit offsets
-//   base[d] = sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d]
-// and (e) ranks and scatters exactly as d_radix_scatter does.  Epochs only grow, so flags never need clearing.
-template <int TILE>
-__device__ __forceinline__ void d_radix_pass(const u64* __restrict__ in, u64* __restrict__ out, int n, int shift,
-                                             u32* __restrict__ hist, u32* __restrict__ flags, int nblk, u32 epoch) {
-  constexpr int NB = 256, ITER = TILE / 64;
-  __shared__ u32 cnt[NB];
-  __shared__ u32 base[NB];
-  const int lane = threadIdx.x, blk = blockIdx.x;
-  if (blk >= nblk) return;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) cnt[lane * 4 + q] = 0;
-  __syncthreads();
-  const int tbase = blk * TILE;
-  u64 key[ITER];
-#pragma unroll
-  for (int s = 0; s < ITER; ++s) {
-    const int i = tbase + s * 64 + lane;
-    key[s] = (i < n) ? in[i] : 0ULL;
-  }
-#pragma unroll
-  for (int s = 0; s < ITER; ++s) {
-    const int i = tbase + s * 64 + lane;
-    if (i < n) atomicAdd(&cnt[(u32)(key[s] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  uint4 mine;
-  mine.x = cnt[lane * 4 + 0];
-  mine.y = cnt[lane * 4 + 1];
-  mine.z = cnt[lane * 4 + 2];
-  mine.w = cnt[lane * 4 + 3];
-  ((uint4*)(hist + (size_t)blk * NB))[lane] = mine;
-  __threadfence();
-  __syncthreads();
-  if (lane == 0) __hip_atomic_store(&flags[blk], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  for (int b = lane; b < nblk; b += 64)
-    while (__hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  __syncthreads();
-  {
-    u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
-    for (int b = 0; b < nblk; ++b) {
-      const uint4 h = ((const uint4*)(hist + (size_t)b * NB))[lane];
-      const u32 m = (b < blk) ? 0xffffffffu : 0u;
-      tot[0] += h.x;
-      tot[1] += h.y;
-      tot[2] += h.z;
-      tot[3] += h.w;
-      before[0] += h.x & m;
-      before[1] += h.y & m;
-      before[2] += h.z & m;
-      before[3] += h.w & m;
-    }
-    int wtot;
-    const int ex = wave_excl_scan_i32((int)(tot[0] + tot[1] + tot[2] + tot[3]), &wtot);
-    u32 run = (u32)ex;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      base[lane * 4 + q] = run + before[q];
-      run += tot[q];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < ITER; ++s) {
-    const int i = tbase + s * 64 + lane;
-    const bool valid = i < n;
-    const u32 d = (u32)(key[s] >> shift) & 255u;
-    u64 m = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      const bool one = (d >> bit) & 1u;
-      const u64 b = __ballot(valid && one);
-      m &= one ? b : ~b;
-    }
-    if (valid) {
-      const u32 pos = base[d] + (u32)__popcll(m & lanemask_lt());
-      out[pos] = key[s];
     }
     __syncthreads();  // single-wave workgroup: orders the LDS reads above before the updates below
     if (valid && (m & lanemask_lt()) == 0) base[d] += (u32)__popcll(m);
@@ -962,7 +899,6 @@ struct CloudView {
   const u64* keys_in;  // ping-pong roles of the current radix pass
   u64* keys_out;
   u32* hist;
-  u32* flags;         // per-tile epoch flags of the single-launch radix pass
   int* blkcnt;
   int* blkoff;
   int* nbr_cnt;
@@ -1007,10 +943,6 @@ __global__ __launch_bounds__(1024) void k2_radix_scan(Clouds2 a) {
 __global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift) {
   const CloudView& C = a.c[blockIdx.y];
   d_radix_scatter<8, RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
-}
-__global__ __launch_bounds__(64) void k2_radix_pass(Clouds2 a, int use_vox, int shift, u32 epoch) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_radix_pass<RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.flags, C.nblk, epoch);
 }
 __global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a) {
   const CloudView& C = a.c[blockIdx.y];
@@ -1078,7 +1010,6 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
   v.spfh = C.spfh;
   v.fpfh = C.fpfh;
   v.hist = C.hist;
-  v.flags = C.flags;
   v.nbr_cnt = C.nbr_cnt;
   v.nbr_off = C.nbr_off;
   v.nbr_idx = C.nbr_idx;
@@ -1090,8 +1021,7 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
 }
 
 // stable LSD radix sort of keys_a (both clouds) by bits [32, 32+key_bits); returns which buffer holds the result
-static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st,
-                       u32* epoch) {
+static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st) {
   int maxblk = 1;
   for (int c = 0; c < nc; ++c) {
     const int n = use_vox ? a.c[c].n : a.c[c].P;
@@ -1104,12 +1034,10 @@ static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int
       a.c[c].keys_in = src == 0 ? C[c]->keys_a : C[c]->keys_b;
       a.c[c].keys_out = src == 0 ? C[c]->keys_b : C[c]->keys_a;
     }
-    if (maxblk * nc <= RADIX_ONEPASS_MAX_TILES) {
-      hipLaunchKernelGGL(k2_radix_pass, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift, ++*epoch);
-    } else {  // too many tiles to rely on co-residency: two launches per pass
-      hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
-      hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
-    }
+    // two launches per pass: a single-launch pass (tiles exchanging histograms through flags) needs
+    // device-scope fences, which on this multi-XCD part cost more than the launch boundary
+    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
     src ^= 1;
   }
   return src;
@@ -1134,7 +1062,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 0);
   hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 0);
   hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, a, leaf);
-  const int where = radix_sort2(a, C, nc, 0, 32, st, &F.radix_epoch);
+  const int where = radix_sort2(a, C, nc, 0, 32, st);
   for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
   if (nc == 1) a.c[1] = a.c[0];
   const int nblk = (maxP + 1023) / 1024;
@@ -1179,7 +1107,7 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 1);  // keeps the counters of the voxel stage
   hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 1);
   hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, a, cell);
-  const int where = radix_sort2(a, C, nc, 1, 24, st, &F.radix_epoch);
+  const int where = radix_sort2(a, C, nc, 1, 24, st);
   for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
   if (nc == 1) a.c[1] = a.c[0];
   hipLaunchKernelGGL(k2_sorted_points, dim3(g, nc), dim3(256), 0, st, a);
@@ -1231,8 +1159,6 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.keys_a = (u64*)take((size_t)max_points * 8);
     C.keys_b = (u64*)take((size_t)max_points * 8);
     C.hist = (u32*)take((size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4);
-    C.flags = C.hist + (size_t)3072 * ((max_points + RADIX_TILE - 1) / RADIX_TILE);  // unused tail of the hist area
-    (void)hipMemset(C.flags, 0, (size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE) * 4);
     C.nbr_cnt = (int*)take((size_t)max_voxels * 4);
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);

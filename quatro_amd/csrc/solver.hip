@@ -173,34 +173,36 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
   }
 }
 
-// Level-parallel variant for graphs whose bit matrix fits in LDS (L up to ~1100): peeling is a chain of
-// hundreds of dependent rounds (one per occupied level, ~1 us each however few lanes they keep busy), but
-// the k-cores themselves are independent of one another.  Workgroup k computes the k-core directly:
+// Level-parallel variant for L <= 1280: peeling is a chain of hundreds of dependent rounds (one per occupied
+// level, ~1 us each however few lanes they keep busy), but the k-cores themselves are independent of one
+// another.  Workgroup k computes the k-core directly:
 //     alive = {deg >= k};  repeat  alive = {v in alive : |N(v) & alive| >= k}  until nothing changes
-// (a handful of sweeps, each one popcount per row word), and writes its membership mask M[k].  The cores are
-// nested, so core(v) = max{k : v in M[k]}; the workgroup that finishes last gathers the masks into LDS and
-// binary-searches every vertex's column.  Core numbers are unique, so this equals compute_cores' result.
-// LDS layout is word-major (rowsT[w][v]): lane = vertex makes every read conflict free.
-#define KCL_VPT 5  // vertices per thread: 256 * 5 = 1280 >= any L whose matrix fits in LDS
+// (a handful of sweeps) and writes its membership mask M[k].  Thread t owns vertices t, t+256, ... and keeps
+// THEIR ROWS IN REGISTERS (VT rows of 4*VT words), so a sweep is one broadcast LDS read of the alive word,
+// an AND, a popcount and an add per word — no staging of the matrix, no dynamic LDS, every workgroup of the
+// launch co-resident.  The cores are nested, so core(v) = max{k : v in M[k]}; the workgroup that finishes
+// last reads every vertex's core number off its column with an 8-ary search.  Core numbers are unique, so
+// this equals compute_cores' (Batagelj-Zaversnik) result.
+#define KCL_VPT 5  // most vertices per thread: 256 * 5 = 1280
+template <int VT>
 __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm, int L, int W,
-                                                     const int* __restrict__ deg_in, u64* __restrict__ M,
-                                                     int* __restrict__ core_out, SolverState* __restrict__ st) {
-  extern __shared__ __attribute__((aligned(16))) u64 kcl_rows[];  // [W][L]
+                                                     const int* __restrict__ deg_in, u64* __restrict__ M) {
+  constexpr int WT = 4 * VT;
   __shared__ u64 s_alive[2][4 * KCL_VPT];
-  __shared__ int s_cnt, s_last, s_red[8];
+  __shared__ int s_cnt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.x + 1;
-  const int vpt = (L + 255) >> 8;
   if (tid == 0) s_cnt = 0;
+  if (tid < 4 * KCL_VPT) s_alive[0][tid] = s_alive[1][tid] = 0;
   __syncthreads();
   u32 amask = 0;  // bit i: my vertex i*256+tid is alive
-  int mydeg[KCL_VPT];
+  int mydeg[VT];
   {
     int c = 0;
 #pragma unroll
-    for (int i = 0; i < KCL_VPT; ++i) {
+    for (int i = 0; i < VT; ++i) {
       const int v = i * 256 + tid;
-      mydeg[i] = (i < vpt && v < L) ? deg_in[v] : -1;
+      mydeg[i] = (v < L) ? deg_in[v] : -1;
       const bool a = mydeg[i] >= k;
       amask |= a ? (1u << i) : 0u;
       const u64 mk = __ballot(a);
@@ -212,69 +214,87 @@ __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm
   __syncthreads();
   int par = 0, sweeps = 0;
   if (s_cnt > k) {  // a k-core needs k+1 vertices
-    for (int e = tid; e < L * W; e += 256) {
-      const int r = e / W, c = e - r * W;
-      kcl_rows[(size_t)c * L + r] = bm[e];
+    u64 row[VT][WT];
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+      const u64* src = bm + (size_t)(i * 256 + tid) * W;
+      const bool a = (amask >> i) & 1u;
+#pragma unroll
+      for (int w = 0; w < WT; ++w) row[i][w] = (a && w < W) ? src[w] : 0ULL;
     }
-    __syncthreads();
     while (true) {
       ++sweeps;
       int changed = 0;
 #pragma unroll
-      for (int i = 0; i < KCL_VPT; ++i) {
-        if (i < vpt) {
-          const int v = i * 256 + tid;
-          if ((amask >> i) & 1u) {
-            int d = 0;
-            for (int w = 0; w < W; ++w) d += __popcll(kcl_rows[(size_t)w * L + v] & s_alive[par][w]);
-            if (d < k) {
-              amask &= ~(1u << i);
-              changed = 1;
-            }
+      for (int i = 0; i < VT; ++i) {
+        if ((amask >> i) & 1u) {
+          int d = 0;
+#pragma unroll
+          for (int w = 0; w < WT; ++w) d += __popcll(row[i][w] & s_alive[par][w]);
+          if (d < k) {
+            amask &= ~(1u << i);
+            changed = 1;
           }
-          const u64 mk = __ballot((amask >> i) & 1u);
-          if (lane == 0) s_alive[par ^ 1][i * 4 + wave] = mk;
         }
+        const u64 mk = __ballot((amask >> i) & 1u);
+        if (lane == 0) s_alive[par ^ 1][i * 4 + wave] = mk;
       }
       par ^= 1;
       if (!__syncthreads_or(changed)) break;
     }
   } else {
-    amask = 0;
-#pragma unroll
-    for (int i = 0; i < KCL_VPT; ++i)
-      if (lane == 0) s_alive[0][i * 4 + wave] = 0;
+    __syncthreads();
+    if (tid < 4 * KCL_VPT) s_alive[0][tid] = 0;
     __syncthreads();
   }
   if (tid < W) M[(size_t)k * W + tid] = s_alive[par][tid];
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_last = (atomicAdd(&st->pad[5], 1) == (int)gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  // ---- last workgroup: gather the masks and read every vertex's core number off its column
-  __threadfence();
-  const int K = (int)gridDim.x;  // masks exist for k = 1..K
-  for (int e = tid; e < K * W; e += 256) kcl_rows[e] = M[(size_t)W + e];  // kcl_rows[(k-1)*W + w]
-  __syncthreads();
+}
+
+// Second half: every vertex's core number = the largest k whose mask holds it (the masks are nested), found
+// with an 8-ary search over its column (7 independent probes per step).  A separate launch on purpose: on a
+// multi-XCD part a device-scope fence inside the kernel (last-workgroup-done pattern) writes back and
+// invalidates the L2s and cost more than the launch boundary that gives the same ordering for free.
+__global__ __launch_bounds__(256) void k_kcore_collect(const u64* __restrict__ M, int L, int W, int K,
+                                                      const int* __restrict__ deg_in, int* __restrict__ core_out,
+                                                      SolverState* __restrict__ st) {
+  __shared__ int s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v = blockIdx.x * 256 + tid;
   int esum = 0, cmax = 0;
+  if (v < L) {
+    const int dv = deg_in[v];
+    int lo = 0, hi = min(dv, K);  // invariant: member at lo (k = 0: everybody), not above hi
+    const u64* col = M + (v >> 6);
+    const int bv = v & 63;
+    while (lo < hi) {
+      const int span = hi - lo;
+      int probe[7];
+      u64 word[7];
 #pragma unroll
-  for (int i = 0; i < KCL_VPT; ++i) {
-    const int v = i * 256 + tid;
-    if (i < vpt && v < L) {
-      int lo = 0, hi = min(mydeg[i], K);
-      const int wv = v >> 6, bv = v & 63;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((kcl_rows[(size_t)(mid - 1) * W + wv] >> bv) & 1ULL)
-          lo = mid;
-        else
-          hi = mid - 1;
+      for (int q = 0; q < 7; ++q) {
+        probe[q] = min(lo + max(1, (int)(((long long)span * (q + 1)) >> 3)), hi);
+        word[q] = col[(size_t)probe[q] * W];
       }
-      core_out[v] = lo;
-      cmax = max(cmax, lo);
-      esum += mydeg[i];
+      int nlo = lo, nhi = hi;
+      bool cut = false;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const bool in = (word[q] >> bv) & 1ULL;
+        if (!cut) {
+          if (in)
+            nlo = probe[q];
+          else {
+            nhi = probe[q] - 1;
+            cut = true;
+          }
+        }
+      }
+      lo = nlo;
+      hi = nhi;
     }
+    core_out[v] = lo;
+    cmax = lo;
+    esum = dv;
   }
   cmax = wave_max_i32(cmax);
   esum = wave_sum_i32(esum);
@@ -285,10 +305,9 @@ __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm
   __syncthreads();
   if (tid == 0) {
     const int mc = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
-    st->max_core = mc;
-    st->ub = mc + 1;
-    st->n_edges2 = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-    st->pad[0] = sweeps;
+    atomicMax(&st->max_core, mc);
+    atomicMax(&st->ub, mc + 1);
+    atomicAdd(&st->n_edges2, s_red[4] + s_red[5] + s_red[6] + s_red[7]);
   }
 }
 
@@ -1144,8 +1163,6 @@ hipError_t solver_init_attributes() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_kcore_levels, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_clique_batch_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1223,9 +1240,18 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
-    const bool kc_single_wave = (L <= 256 * KCL_VPT) && (bm_bytes <= (size_t)150 * 1024);
+    const bool kc_single_wave = (L <= 256 * KCL_VPT);
     if (kc_single_wave) {
-      hipLaunchKernelGGL(k_kcore_levels, dim3(L > 1 ? L - 1 : 1), dim3(256), bm_bytes, stream, B.bm, L, W, B.deg, B.adjP,
+      const dim3 kgrid(L > 1 ? L - 1 : 1);
+#define KCL_LAUNCH(VT) \
+  hipLaunchKernelGGL(k_kcore_levels<VT>, kgrid, dim3(256), 0, stream, B.bm, L, W, B.deg, B.adjP)
+      if (W <= 4) KCL_LAUNCH(1);
+      else if (W <= 8) KCL_LAUNCH(2);
+      else if (W <= 12) KCL_LAUNCH(3);
+      else if (W <= 16) KCL_LAUNCH(4);
+      else KCL_LAUNCH(5);
+#undef KCL_LAUNCH
+      hipLaunchKernelGGL(k_kcore_collect, dim3((L + 255) / 256), dim3(256), 0, stream, B.adjP, L, W, (int)kgrid.x, B.deg,
                          B.core, B.st);
     } else {
     const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
