@@ -53,7 +53,9 @@ struct FrontBufs {
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
-  int nn_target_waves = 2048;  // waves per k_nn_mfma launch aimed at when slicing the base cloud (QTR_NN_WAVES)
+  int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit
+  int n_cu = 256;              // compute units of the device
+  int nn_trace = 0;            // QTR_NN_TRACE=1: k_nn_mfma (first direction) leaves clocks per tile / workgroup lives in mcounts[12..15]
   hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)
 };
 

@@ -166,8 +166,10 @@ struct NnPartial {
 // MFMA issue time, so the kernel is matrix-pipe bound.
 __global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ baseT, int nb_pad,
                                                     const float* __restrict__ queryT, int nq_pad,
-                                                    int tiles_per_split, NnPartial* __restrict__ partial) {
+                                                    int tiles_per_split, NnPartial* __restrict__ partial,
+                                                    int* __restrict__ dbg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
   const int col = lane & 31, half = lane >> 5;
   const int qbase = (blockIdx.x * 4 + wave) * NN_QPW + col;
   float q[4][NN_K2];
@@ -175,12 +177,16 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ ba
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int kk = 0; kk < NN_K2; ++kk) q[a][kk] = queryT[(size_t)(2 * kk + half) * nq_pad + qbase + 32 * a];
+  // running best / second best per query column.  The accumulator register r a value came from rides in the
+  // four low mantissa bits of the value itself (v_and_or_b32), so the update is three VALU ops per value —
+  // pack, second = med3(best, second, v), best = min(best, v) — and the winning TILE is found once per tile
+  // by noticing that best changed.  The <16 ulp perturbation is part of the rounding bound of the finish.
   float b1[4], b2[4];
-  int i1[4];  // code of the best: (tile << 4) | accumulator register
+  int it1[4];  // tile of the best
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     b1[a] = b2[a] = INFINITY;
-    i1[a] = -1;
+    it1[a] = -1;
   }
   const int ntiles = nb_pad / 32;
   const int t_begin = blockIdx.y * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
@@ -199,33 +205,34 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ ba
     for (int kk = 0; kk < NN_K2; ++kk)
 #pragma unroll
       for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(m[kk], q[a][kk], acc[a], 0, 0, 0);
-    const int tcode = t << 4;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      const float before = b1[a];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[a][r];
-        const bool lt = v < b1[a];
-        const float loser = fmaxf(b1[a], v);
-        b1[a] = fminf(b1[a], v);
-        b2[a] = fminf(b2[a], loser);
-        i1[a] = lt ? (tcode | r) : i1[a];
+        const float v = __uint_as_float((__float_as_uint(acc[a][r]) & 0xfffffff0u) | (u32)r);
+        b2[a] = __builtin_amdgcn_fmed3f(b1[a], b2[a], v);
+        b1[a] = __builtin_amdgcn_fmed3f(b1[a], v, -INFINITY);
       }
+      it1[a] = (b1[a] != before) ? t : it1[a];
+    }
   };
   if (t_begin < t_end) load_tile(m0, t_begin);
   for (int t = t_begin; t < t_end; t += 2) {
     if (t + 1 < t_end) load_tile(m1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sank it otherwise)
     compute_tile(m0, t);
     if (t + 1 < t_end) {
       if (t + 2 < t_end) load_tile(m0, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
       compute_tile(m1, t + 1);
     }
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     // decode the best's row, then merge the two lanes (half 0 / half 1) that own the same query column
-    const int r = i1[a] & 15;
-    int row = (i1[a] < 0) ? -1 : ((i1[a] >> 4) * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
+    const int r = (int)(__float_as_uint(b1[a]) & 15u);
+    int row = (it1[a] < 0) ? -1 : (it1[a] * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
     const float ob1 = __shfl_xor(b1[a], 32, 64), ob2 = __shfl_xor(b2[a], 32, 64);
     const int orow = __shfl_xor(row, 32, 64);
     const bool take = (ob1 < b1[a]) || (ob1 == b1[a] && orow >= 0 && (row < 0 || orow < row));
@@ -240,6 +247,13 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ ba
       p.pad = 0;
       partial[(size_t)(qbase + 32 * a) * gridDim.y + blockIdx.y] = p;
     }
+  }
+  if (dbg && threadIdx.x == 0) {
+    const u32 w0 = (u32)dbg_w0, w1 = (u32)wall_clock64();
+    if (blockIdx.x == 1 && blockIdx.y == 1) dbg[12] = (int)((clock64() - dbg_c0) / (t_end - t_begin));  // clk per tile
+    atomicMax((u32*)&dbg[13], (w1 - w0));  // longest workgroup life, 10 ns
+    atomicAdd((u32*)&dbg[14], (w1 - w0));  // sum of lives
+    atomicAdd((u32*)&dbg[15], 1u);
   }
 }
 
@@ -269,7 +283,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma_finish(const NnPartial* __restr
   const float na = qnorm[q], nbmax = __uint_as_float(*base_max_norm_bits);
   const float u = 5.9604645e-08f;
   const float dmax = fmaxf(na + b1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
-  const float eps = u * (40.0f * na + 76.0f * nbmax + 40.0f * dmax) * 1.01f;
+  // + 32u(|a|^2 + 2|b|^2): the index bits that replace the four low mantissa bits of every candidate
+  const float eps = u * (72.0f * na + 140.0f * nbmax + 40.0f * dmax) * 1.01f;
   if (i1 >= 0 && b2 - b1 > 2.0f * eps) {
     best[q] = (u64)(u32)i1;
   } else {
@@ -565,15 +580,35 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
     auto run_dir = [&](CloudBufs& Q, int nq, int nq_pad, CloudBufs& Bc, int nb, int nb_pad, u64* best, int mc_slot,
                        hipEvent_t ev0, hipEvent_t ev1) {
       const int ntiles = nb_pad / 32;
-      int ns_ = (F.nn_target_waves + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
-      if (ns_ > 32) ns_ = 32;
-      if (ns_ > ntiles) ns_ = ntiles;
-      if (ns_ < 1) ns_ = 1;
-      const int tps = (ntiles + ns_ - 1) / ns_;
-      ns_ = (ntiles + tps - 1) / tps;
+      // Slicing policy: ONE workgroup per compute unit and no more workgroups than compute units.  Measured
+      // on MI355X (tests/probe/nn_probe.hip): a lone workgroup runs a tile in ~6.0k clocks (68 MFMAs = 4.35k);
+      // two per CU share the matrix pipe AND lose ~40 % to each other's loads, and a grid of 270 workgroups on
+      // 256 CUs runs as long as 512 would (the doubled-up CUs finish last).
+      const int qblocks = nq_pad / NN_QPB;
+      int ns_ = 1, tps = ntiles;
+      if (F.nn_target_waves > 0) {  // QTR_NN_WAVES: aim at a wave count (experiments)
+        ns_ = (F.nn_target_waves + nq_pad / NN_QPW - 1) / (nq_pad / NN_QPW);
+        if (ns_ > 32) ns_ = 32;
+        if (ns_ > ntiles) ns_ = ntiles;
+        if (ns_ < 1) ns_ = 1;
+        tps = (ntiles + ns_ - 1) / ns_;
+        ns_ = (ntiles + tps - 1) / tps;
+      } else {  // fewest (rounds of n_cu workgroups) x (tiles per workgroup + ~1.5 tiles of prologue / epilogue)
+        double best_cost = 1e300;
+        for (int cand = 1; cand <= 32 && cand <= ntiles; ++cand) {
+          const int ctps = (ntiles + cand - 1) / cand, cns = (ntiles + ctps - 1) / ctps;
+          const int rounds = (qblocks * cns + F.n_cu - 1) / F.n_cu;
+          const double cost = (double)rounds * (ctps + 1.5);
+          if (cost < best_cost) {
+            best_cost = cost;
+            ns_ = cns;
+            tps = ctps;
+          }
+        }
+      }
       if (ev0) (void)hipEventRecord(ev0, st);
       hipLaunchKernelGGL(k_nn_mfma, dim3(nq_pad / NN_QPB, ns_), dim3(256), 0, st, Bc.baseT, nb_pad, Q.queryT, nq_pad, tps,
-                         (NnPartial*)F.nn_partial);
+                         (NnPartial*)F.nn_partial, (F.nn_trace && mc_slot == MC_RECHECK0) ? F.mcounts : (int*)nullptr);
       if (ev1) (void)hipEventRecord(ev1, st);
       hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns_,
                          nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.mcounts + mc_slot);
