@@ -21,6 +21,7 @@ struct Slot {
   float4* m_tgt = nullptr;
   int* pinned_i32 = nullptr;     // >= 64 ints
   qtr_result* pinned_res = nullptr;
+  int* mail = nullptr;           // pinned host mailbox the phase-ending kernels write into (frontend.h MAIL_*)
   qtr_stage_times times = {};
   int last_L = 0;  // correspondences of the last solve
   int last_n = 0;  // points of the last qtr_fpfh
@@ -98,6 +99,7 @@ void qtr_destroy(qtr_handle* h) {
     if (s.m_tgt) (void)hipFree(s.m_tgt);
     if (s.pinned_i32) (void)hipHostFree(s.pinned_i32);
     if (s.pinned_res) (void)hipHostFree(s.pinned_res);
+    if (s.mail) (void)hipHostFree(s.mail);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.stream2) (void)hipStreamDestroy(s.stream2);
   }
@@ -129,6 +131,14 @@ static int create_impl(qtr_handle* h) {
     QTR_HIP_TRY(h, hipMalloc((void**)&s.m_tgt, (size_t)h->lim.max_corr * 16));
     QTR_HIP_TRY(h, hipHostMalloc((void**)&s.pinned_i32, 256 * sizeof(int)));
     QTR_HIP_TRY(h, hipHostMalloc((void**)&s.pinned_res, sizeof(qtr_result)));
+    QTR_HIP_TRY(h, hipHostMalloc((void**)&s.mail, MAIL_INTS * sizeof(int), hipHostMallocMapped));
+    memset(s.mail, 0, MAIL_INTS * sizeof(int));
+    {
+      void* dv = nullptr;
+      QTR_HIP_TRY(h, hipHostGetDevicePointer(&dv, s.mail, 0));
+      s.fb.mail = (int*)dv;
+      s.sb.mail = (int*)dv;
+    }
   }
   return QTR_OK;
 }
@@ -199,15 +209,13 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
   s.last_L = L;
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, s.ev[2], s.ev[3]));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 128, s.sb.st, sizeof(SolverState), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  if (L > 0 && !((const SolverState*)(s.pinned_i32 + 128))->done) {  // rare: more clique rounds needed
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k_finalize left the record and the state in the mailbox
+  if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
     QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
-    QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
     QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   }
+  memcpy(s.pinned_res, s.mail + MAIL_SOLVER, sizeof(qtr_result));
   const int keep_ns = res->n_src, keep_nt = res->n_tgt, keep_nc = res->n_corr;
   *res = *s.pinned_res;
   res->n_src = keep_ns;
@@ -308,8 +316,8 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128));
   }
   QTR_HIP_TRY(h, clique_only_finish(s.sb, L, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_res, s.sb.res, sizeof(qtr_result), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  memcpy(s.pinned_res, s.mail + MAIL_SOLVER, sizeof(qtr_result));
   const int M = s.pinned_res->n_clique;
   if (max_core_out) *max_core_out = s.pinned_res->max_core;
   *n_out = M;
@@ -430,9 +438,8 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
 static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out) {
   QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, s.fb.mcounts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  *L_out = s.pinned_i32[MC_NCORR];
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k_corr_compact2 left the counters in the mailbox
+  *L_out = s.mail[MAIL_MATCH + MC_NCORR];
   return QTR_OK;
 }
 
@@ -511,18 +518,14 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   // both clouds go through every front-end kernel together (blockIdx.y = cloud)
-  CloudBufs& cs = s.fb.cloud[0];
-  CloudBufs& ct = s.fb.cloud[1];
   {
     const float4* raws[2] = {d_s, d_t};
     const int Ps2[2] = {Ps, Pt};
     QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream));
   }
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cs.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 16, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  int ns = s.pinned_i32[CNT_NVOX], nt = s.pinned_i32[16 + CNT_NVOX];
-  if (s.pinned_i32[CNT_VOX_OVERFLOW] || s.pinned_i32[16 + CNT_VOX_OVERFLOW]) {
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k2_vox_centroids left both clouds' counters in the mailbox
+  int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+  if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
     return res->status = QTR_ERR_CAPACITY;
   }
@@ -546,12 +549,9 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L);
   if (rc != QTR_OK) return res->status = rc;
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 32, cs.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 48, ct.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  if (s.pinned_i32[32 + CNT_NBR_OVERFLOW] || s.pinned_i32[48 + CNT_NBR_OVERFLOW]) {
+  if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "neighbour list capacity (%d per point) exceeded: max k = %d / %d", QTR_KMAX,
-             s.pinned_i32[32 + CNT_KMAX], s.pinned_i32[48 + CNT_KMAX]);
+             s.mail[MAIL_CNT0 + CNT_KMAX], s.mail[MAIL_CNT1 + CNT_KMAX]);
     return res->status = QTR_ERR_CAPACITY;
   }
   res->n_corr = L;

@@ -11,6 +11,10 @@ enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW =
 // MC_RECHECKx: rows sent to the exact re-check; MC_RECHECKx + 2: rows settled by the two-candidate exact compare
 enum { MC_NCORR = 0, MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5 };
 
+// Host mailbox (ints): the kernel that finishes a phase stores the few counters the host needs straight into
+// pinned host memory, so a phase boundary costs one stream synchronisation and no copy launches.
+enum { MAIL_VOX0 = 0, MAIL_VOX1 = 16, MAIL_MATCH = 32, MAIL_CNT0 = 48, MAIL_CNT1 = 64, MAIL_SOLVER = 128, MAIL_INTS = 512 };
+
 struct CloudBufs {
   int* counts = nullptr;       // 16
   u32* mm = nullptr;           // 8: order-preserving encodings of min x,y,z / max x,y,z
@@ -52,6 +56,7 @@ struct FrontBufs {
   int* mcounts = nullptr;      // 16
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
+  int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* below); may be null
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
   int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit
   int n_cu = 256;              // compute units of the device

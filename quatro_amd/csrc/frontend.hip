@@ -309,7 +309,8 @@ __device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, in
 #define VOX_HALO 512
 __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
                                                        int P, const int* __restrict__ blkoff, float4* __restrict__ out,
-                                                       int cap, int nblk, int* __restrict__ counts) {
+                                                       int cap, int nblk, int* __restrict__ counts,
+                                                       int* __restrict__ mail) {
   __shared__ u32 s_cell[VOX_TILE + VOX_HALO + 1];
   __shared__ float s_x[VOX_TILE + VOX_HALO], s_y[VOX_TILE + VOX_HALO], s_z[VOX_TILE + VOX_HALO];
   __shared__ int wtot[4];
@@ -318,6 +319,8 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   const int base = blockIdx.x * VOX_TILE;
   int running = blkoff[blockIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
+  if (mail && blockIdx.x == 0 && threadIdx.x < 16)  // this is the last voxelise kernel: hand the counters to the host
+    mail[threadIdx.x] = (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x];
   for (int t = threadIdx.x; t < VOX_TILE + VOX_HALO; t += 256) {
     const int i = base + t;
     if (i < P) {
@@ -899,6 +902,7 @@ struct CloudView {
   const u64* keys_in;  // ping-pong roles of the current radix pass
   u64* keys_out;
   u32* hist;
+  int* mail;           // host mailbox slot of this cloud's voxelise counters (or null)
   int* blkcnt;
   int* blkoff;
   int* nbr_cnt;
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(1024) void k2_vox_blockscan(Clouds2 a) {
 }
 __global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap) {
   const CloudView& C = a.c[blockIdx.y];
-  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts);
+  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts, C.mail);
 }
 __global__ __launch_bounds__(256) void k2_sorted_points(Clouds2 a) {
   const CloudView& C = a.c[blockIdx.y];
@@ -1052,6 +1056,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   for (int c = 0; c < nc; ++c) {
     a.c[c] = make_view(*C[c], raw[c], P[c], 0);
     a.c[c].keys_out = C[c]->keys_a;
+    a.c[c].mail = F.mail ? F.mail + (C[c] == &F.cloud[1] ? MAIL_VOX1 : MAIL_VOX0) : nullptr;
     a.c[c].nblk_vox = (P[c] + 1023) / 1024;
     a.c[c].blkcnt = (int*)C[c]->hist;
     a.c[c].blkoff = a.c[c].blkcnt + a.c[c].nblk_vox + 8;

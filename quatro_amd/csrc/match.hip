@@ -407,7 +407,8 @@ __global__ __launch_bounds__(1024) void k_scan_nonneg(const int* __restrict__ in
 }
 
 __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restrict__ tgt_of_src, int ns,
-                                int* __restrict__ corr, int* __restrict__ mcounts) {
+                                int* __restrict__ corr, int* __restrict__ mcounts, int* __restrict__ mail,
+                                const int* __restrict__ counts0, const int* __restrict__ counts1) {
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
     const int t = tgt_of_src[s];
     if (t >= 0) {
@@ -416,6 +417,15 @@ __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restr
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) mcounts[MC_NCORR] = scan[ns];
+  if (mail && blockIdx.x == 0 && threadIdx.x < 48) {  // last matcher kernel: counters for the host, no copy launches
+    const int t = threadIdx.x;
+    if (t < 16)
+      mail[MAIL_MATCH + t] = (t == MC_NCORR) ? scan[ns] : mcounts[t];
+    else if (t < 32)
+      mail[MAIL_CNT0 + (t - 16)] = counts0[t - 16];
+    else
+      mail[MAIL_CNT1 + (t - 32)] = counts1[t - 32];
+  }
 }
 
 // cross-check flags over the larger cloud (index i): keep iff NN_small(i) = j and NN_large(j) = i
@@ -504,23 +514,6 @@ __global__ void k_scatter_pairs(const int* __restrict__ cross_i, const int* __re
   }
   local = wave_sum_i32(local);
   if (qk_lane() == 0 && local) atomicAdd(&mc_out[MC_NTUPLE], local);
-}
-
-__global__ void k_src_flags(const int* __restrict__ tgt_of_src, int ns, int* __restrict__ flags) {
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x)
-    flags[s] = tgt_of_src[s] >= 0 ? 1 : 0;
-}
-
-__global__ void k_corr_compact(const int* __restrict__ flags, const int* __restrict__ scan,
-                               const int* __restrict__ tgt_of_src, int ns, int* __restrict__ corr,
-                               int* __restrict__ mcounts) {
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
-    if (flags[s]) {
-      corr[2 * scan[s]] = s;
-      corr[2 * scan[s] + 1] = tgt_of_src[s];
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) mcounts[MC_NCORR] = scan[ns];
 }
 
 __global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __restrict__ vt,
@@ -636,7 +629,8 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
   hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(maxc)), dim3(256), 0, st, F.cross_i, F.cross_j, F.passed,
                      F.mcounts, swapped, F.tgt_of_src, F.mcounts);
   hipLaunchKernelGGL(k_scan_nonneg, dim3(1), dim3(1024), 0, st, F.tgt_of_src, F.scan, ns);
-  hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr, F.mcounts);
+  hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr, F.mcounts,
+                     F.mail, F.cloud[0].counts, F.cloud[1].counts);
   return hipGetLastError();
 }
 

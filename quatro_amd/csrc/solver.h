@@ -1,6 +1,7 @@
 // solver.h — device state and buffer carving for the back-end kernels (solver.hip).
 #pragma once
 #include "common.h"
+#include "frontend.h"
 
 #define CLIQUE_BATCH 1024
 
@@ -31,6 +32,7 @@ struct SolverBufs {
   int* picks_buf = nullptr;  // [CLIQUE_BATCH][L] greedy picks of every start of the current batch
   SolverState* st = nullptr;
   qtr_result* res = nullptr;
+  int* mail = nullptr;  // device view of the slot's pinned host mailbox (frontend.h MAIL_*), or null
 };
 
 size_t solver_scratch_bytes(int Lcap);
