@@ -218,16 +218,47 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   }
 }
 
-__device__ __forceinline__ void d_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
-  // out[0..n] = exclusive scan of in[0..n) ; single workgroup
+// out[0..n] = exclusive scan of f(in[0..n)); single workgroup of 1024 threads.  Up to 16384 elements each
+// thread owns one contiguous run of K <= 16 values held in registers (one round of loads, two barriers);
+// longer inputs take the chunked path (three barriers and one load round trip per 1024 elements).
+template <typename F>
+__device__ __forceinline__ void d_block_scan(const int* __restrict__ in, int* __restrict__ out, int n, F f) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = (n + 1023) >> 10;
+  if (K <= 16) {
+    const int base = tid * K;
+    int v[16];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = (k < K && base + k < n) ? f(in[base + k]) : 0;
+      s += v[k];
+    }
+    int tot;
+    const int ex = wave_excl_scan_i32(s, &tot);
+    if (lane == 63) wsum[wave] = tot;
+    __syncthreads();
+    int run = ex, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      run += (w < wave) ? wsum[w] : 0;
+      total += wsum[w];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < K && base + k < n) out[base + k] = run;
+      run += v[k];
+    }
+    if (tid == 0) out[n] = total;
+    return;
+  }
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int i = base + tid;
-    const int v = i < n ? in[i] : 0;
+    const int v = i < n ? f(in[i]) : 0;
     int tot;
     const int ex = wave_excl_scan_i32(v, &tot);
     if (lane == 63) wsum[wave] = tot;
@@ -240,6 +271,9 @@ __device__ __forceinline__ void d_scan_i32_copy(const int* __restrict__ in, int*
     __syncthreads();
   }
   if (tid == 0) out[n] = carry_s;
+}
+__device__ __forceinline__ void d_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
+  d_block_scan(in, out, n, [](int x) { return x; });
 }
 
 // =================================================================================================
@@ -311,8 +345,8 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
                                                        int P, const int* __restrict__ blkoff, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts,
                                                        int* __restrict__ mail) {
-  __shared__ u32 s_cell[VOX_TILE + VOX_HALO + 1];
-  __shared__ float s_x[VOX_TILE + VOX_HALO], s_y[VOX_TILE + VOX_HALO], s_z[VOX_TILE + VOX_HALO];
+  // element t of the window lives in s_p[t + 1] as (x, y, z, cell id bits): one 16-byte LDS read per element
+  __shared__ float4 s_p[VOX_TILE + VOX_HALO + 1];
   __shared__ int wtot[4];
   if (blockIdx.x >= nblk) return;
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
@@ -321,26 +355,35 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
   if (mail && blockIdx.x == 0 && threadIdx.x < 16)  // this is the last voxelise kernel: hand the counters to the host
     mail[threadIdx.x] = (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x];
-  for (int t = threadIdx.x; t < VOX_TILE + VOX_HALO; t += 256) {
-    const int i = base + t;
-    if (i < P) {
-      const u64 k = keys[i];
-      const float4 p = pts[(u32)k];
-      s_cell[t + 1] = (u32)(k >> 32);
-      s_x[t] = p.x;
-      s_y[t] = p.y;
-      s_z[t] = p.z;
-    } else {
-      s_cell[t + 1] = 0xffffffffu;
+  {
+    // two rounds of independent loads (keys, then the gathered points) instead of six dependent pairs
+    constexpr int NLD = (VOX_TILE + VOX_HALO) / 256;
+    u64 kk[NLD];
+    float4 pp[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int i = base + q * 256 + threadIdx.x;
+      kk[q] = (i < P) ? keys[i] : ~0ULL;
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int i = base + q * 256 + threadIdx.x;
+      pp[q] = (i < P) ? pts[(u32)kk[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const int t = q * 256 + threadIdx.x;
+      pp[q].w = __uint_as_float((u32)(kk[q] >> 32));  // 0xffffffff past the end of the cloud
+      s_p[t + 1] = pp[q];
     }
   }
-  if (threadIdx.x == 0) s_cell[0] = (base > 0) ? (u32)(keys[base - 1] >> 32) : 0xffffffffu;
+  if (threadIdx.x == 0) s_p[0].w = __uint_as_float((base > 0) ? (u32)(keys[base - 1] >> 32) : 0xffffffffu);
   __syncthreads();
   for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
     const int t = t0 + threadIdx.x;
     const int i = base + t;
-    const u32 cell = s_cell[t + 1];
-    const bool head = (i < P) && (i == 0 || cell != s_cell[t]);
+    const u32 cell = __float_as_uint(s_p[t + 1].w);
+    const bool head = (i < P) && (i == 0 || cell != __float_as_uint(s_p[t].w));
     const u64 bal = __ballot(head);
     if (lane == 0) wtot[wave] = __popcll(bal);
     __syncthreads();
@@ -351,20 +394,53 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
       const int slot = running + woff + __popcll(bal & lanemask_lt());
       float cx = 0.f, cy = 0.f, cz = 0.f;
       int e = t;
-      while (e < VOX_TILE + VOX_HALO && s_cell[e + 1] == cell) {
-        cx += s_x[e];
-        cy += s_y[e];
-        cz += s_z[e];
+      // the additions of a run are sequential by definition (float, sorted order); what can overlap is the LDS
+      // traffic: fetch eight candidates at a time, then add the ones that still belong to the run
+      bool more = true;
+      while (more && e + 8 <= VOX_TILE + VOX_HALO) {
+        float4 c8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c8[q] = s_p[e + 1 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (more && __float_as_uint(c8[q].w) == cell) {
+            cx += c8[q].x;
+            cy += c8[q].y;
+            cz += c8[q].z;
+            ++e;
+          } else {
+            more = false;
+          }
+        }
+      }
+      while (more && e < VOX_TILE + VOX_HALO && __float_as_uint(s_p[e + 1].w) == cell) {
+        cx += s_p[e + 1].x;
+        cy += s_p[e + 1].y;
+        cz += s_p[e + 1].z;
         ++e;
       }
       int g = base + e;
       if (e == VOX_TILE + VOX_HALO) {  // run longer than the halo: continue from global memory
-        while (g < P && (u32)(keys[g] >> 32) == cell) {
-          const float4 p = pts[(u32)keys[g]];
-          cx += p.x;
-          cy += p.y;
-          cz += p.z;
-          ++g;
+        bool more = true;
+        while (more) {  // eight keys, then eight gathered points per round trip; additions stay in order
+          u64 k8[8];
+          float4 p8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) k8[q] = (g + q < P) ? keys[g + q] : ~0ULL;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            p8[q] = ((u32)(k8[q] >> 32) == cell) ? pts[(u32)k8[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (more && (u32)(k8[q] >> 32) == cell) {
+              cx += p8[q].x;
+              cy += p8[q].y;
+              cz += p8[q].z;
+              ++g;
+            } else {
+              more = false;
+            }
+          }
         }
       }
       const float cnt = (float)(g - i);

@@ -384,26 +384,7 @@ __global__ __launch_bounds__(256) void k_cross_flags2(const u64* __restrict__ be
 
 // exclusive scan of the predicate (in[i] >= 0), one workgroup; out has n+1 entries
 __global__ __launch_bounds__(1024) void k_scan_nonneg(const int* __restrict__ in, int* __restrict__ out, int n) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const int v = (i < n && in[i] >= 0) ? 1 : 0;
-    int tot;
-    const int ex = wave_excl_scan_i32(v, &tot);
-    if (lane == 63) wsum[wave] = tot;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    if (i < n) out[i] = carry_s + woff + ex;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry_s + woff + ex + v;
-    __syncthreads();
-  }
-  if (tid == 0) out[n] = carry_s;
+  d_block_scan(in, out, n, [](int x) { return x >= 0 ? 1 : 0; });
 }
 
 __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restrict__ tgt_of_src, int ns,
