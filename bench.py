@@ -209,6 +209,16 @@ def main() -> None:
                            "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
                            "flop_per_launch": flop_per_launch, "mean_launch_ms": 1e3 * mean_launch_s}
+        # HBM-side bytes per launch come from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
+        # this same command); counters cannot be read in-process, so the committed summary is quoted
+        import glob
+        pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_nn.json")))
+        if pmc:
+            with open(pmc[-1]) as f:
+                pj = json.load(f)
+            out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE + WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc[-1])
     else:
         L = int(r0["L"])
         gk = stage_acc.get("graph", 0.0) / max(args.steps, 1)
