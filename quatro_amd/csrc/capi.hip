@@ -22,6 +22,8 @@ struct Slot {
   int* pinned_i32 = nullptr;     // >= 64 ints
   qtr_result* pinned_res = nullptr;
   int* mail = nullptr;           // pinned host mailbox the phase-ending kernels write into (frontend.h MAIL_*)
+  int seq = 0;                   // last sequence number handed to a phase-ending kernel
+  int times_pending = 0;         // 1: qtr_solve, 2: qtr_register_pair — stage times are read off the events lazily
   qtr_stage_times times = {};
   int last_L = 0;  // correspondences of the last solve
   int last_n = 0;  // points of the last qtr_fpfh
@@ -32,6 +34,7 @@ struct qtr_handle {
   int device = 0;
   qtr_limits lim;
   std::vector<Slot> slots;
+  int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
   char err[512];
 };
 
@@ -150,6 +153,10 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   if (!h) return QTR_ERR_CAPACITY;
   h->err[0] = 0;
   h->device = device;
+  {
+    const char* hw = getenv("QTR_HOST_WAIT");
+    h->spin_wait = (hw && strcmp(hw, "block") == 0) ? 0 : 1;
+  }
   if (limits)
     h->lim = *limits;
   else
@@ -172,6 +179,59 @@ static void fill_nn_times(Slot& s) {
     s.times.nn_kernel = a + b;
     s.times.nn_launches = 2;
   }
+}
+
+// Waits until the phase-ending kernel has published `seq` in mailbox word `idx` (frontend.h MAIL_SEQ_*).  The
+// default is to WATCH the pinned word — the store crosses PCIe in ~1-2 us, the runtime's stream wait costs
+// 20-30 us per phase boundary (three per registration) — and to fall back to the runtime every 64k polls so
+// that a failed launch or a lost device ends the wait.  QTR_HOST_WAIT=block uses hipStreamSynchronize only.
+static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
+  volatile int* p = s.mail + idx;
+  if (!h->spin_wait) {
+    QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  } else {
+    for (unsigned long spins = 1;; ++spins) {
+      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return QTR_OK;
+      if ((spins & 0xffff) == 0) {
+        const hipError_t q = hipStreamQuery(s.stream);
+        if (q == hipSuccess) break;  // stream drained: the word must be there now (checked below)
+        if (q != hipErrorNotReady) QTR_HIP_TRY(h, q);
+        (void)hipGetLastError();  // hipErrorNotReady is not an error of ours
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  if (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
+    snprintf(h->err, sizeof(h->err), "mailbox word %d holds %d, expected %d (phase kernel did not run)", idx, (int)*p, seq);
+    return QTR_ERR_HIP;
+  }
+  return QTR_OK;
+}
+#define QTR_TRY(expr)                  \
+  do {                                 \
+    const int rc_ = (expr);            \
+    if (rc_ != QTR_OK) return rc_;     \
+  } while (0)
+
+static void compute_times(Slot& s) {
+  if (!s.times_pending) return;
+  (void)hipEventSynchronize(s.ev[4]);
+  float ms = 0;
+  s.times = qtr_stage_times{};
+  if (s.times_pending == 1) {
+    if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) s.times.graph = ms;
+  } else {
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = ms;
+    if (hipEventElapsedTime(&ms, s.ev[1], s.ev[6]) == hipSuccess) s.times.fpfh = ms;
+    if (hipEventElapsedTime(&ms, s.ev[6], s.ev[7]) == hipSuccess) s.times.match = ms;
+    if (hipEventElapsedTime(&ms, s.ev[7], s.ev[2]) == hipSuccess) s.times.graph = ms;
+    fill_nn_times(s);
+  }
+  if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
+  if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
+  (void)hipGetLastError();
+  s.times_pending = 0;
 }
 
 static Slot* get_slot(qtr_handle* h, int slot) {
@@ -207,13 +267,15 @@ static int check_params(qtr_handle* h, const qtr_params* prm) {
 static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float4* d_tgt, int L, const qtr_params* prm,
                         qtr_result* res) {
   s.last_L = L;
+  s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, s.ev[2], s.ev[3]));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k_finalize left the record and the state in the mailbox
+  QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));  // k_finalize left the record and the state in the mailbox
   if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
+    s.sb.mail_seq = ++s.seq;
     QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
-    QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+    QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
   }
   memcpy(s.pinned_res, s.mail + MAIL_SOLVER, sizeof(qtr_result));
   const int keep_ns = res->n_src, keep_nt = res->n_tgt, keep_nc = res->n_corr;
@@ -272,12 +334,7 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
   res->n_corr = L;
   rc = solve_device(h, s, d_src, d_tgt, L, prm, res);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
-  float ms = 0;
-  s.times = qtr_stage_times{};
-  if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) s.times.graph = ms;
-  if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
-  if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
-  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
+  s.times_pending = 1;
   const int rc2 = copy_out_lists(h, s, res, clique, rot_inliers, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
   return rc;
@@ -315,8 +372,9 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     qtr_default_params(&dummy);
     QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128));
   }
+  s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, clique_only_finish(s.sb, L, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
   memcpy(s.pinned_res, s.mail + MAIL_SOLVER, sizeof(qtr_result));
   const int M = s.pinned_res->n_clique;
   if (max_core_out) *max_core_out = s.pinned_res->max_core;
@@ -333,6 +391,7 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !out) return QTR_ERR_BAD_ARG;
+  compute_times(*sp);
   *out = sp->times;
   return QTR_OK;
 }
@@ -387,6 +446,7 @@ int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, 
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   *n_out = n;
   float ms = 0;
+  s.times_pending = 0;
   s.times = qtr_stage_times{};
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = s.times.total = ms;
   return QTR_OK;
@@ -430,6 +490,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   QTR_HIP_TRY(h, hipMemcpyAsync(desc33, cb.fpfh, (size_t)n * 33 * 4, kout, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   float ms = 0;
+  s.times_pending = 0;
   s.times = qtr_stage_times{};
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.fpfh = s.times.total = ms;
   return QTR_OK;
@@ -437,8 +498,9 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
 static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out) {
+  s.fb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream));
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k_corr_compact2 left the counters in the mailbox
+  QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
   *L_out = s.mail[MAIL_MATCH + MC_NCORR];
   return QTR_OK;
 }
@@ -481,6 +543,7 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   if (L > 0) QTR_HIP_TRY(h, hipMemcpyAsync(corr2, s.fb.corr, (size_t)L * 8, kout, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   float ms = 0;
+  s.times_pending = 0;
   s.times = qtr_stage_times{};
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.match = s.times.total = ms;
   fill_nn_times(s);
@@ -521,9 +584,12 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   {
     const float4* raws[2] = {d_s, d_t};
     const int Ps2[2] = {Ps, Pt};
+    s.fb.mail_seq = ++s.seq;
     QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream));
   }
-  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // k2_vox_centroids left both clouds' counters in the mailbox
+  // k2_vox_centroids leaves both clouds' counters in the mailbox
+  if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
+    return res->status = rc;
   int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
   if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
@@ -563,16 +629,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
   rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
-  float ms = 0;
-  s.times = qtr_stage_times{};
-  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = ms;
-  if (hipEventElapsedTime(&ms, s.ev[1], s.ev[6]) == hipSuccess) s.times.fpfh = ms;
-  if (hipEventElapsedTime(&ms, s.ev[6], s.ev[7]) == hipSuccess) s.times.match = ms;
-  if (hipEventElapsedTime(&ms, s.ev[7], s.ev[2]) == hipSuccess) s.times.graph = ms;
-  if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) s.times.clique = ms;
-  if (hipEventElapsedTime(&ms, s.ev[3], s.ev[4]) == hipSuccess) s.times.solve = ms;
-  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
-  fill_nn_times(s);
+  s.times_pending = 2;
   const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
   return rc;

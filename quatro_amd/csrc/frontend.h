@@ -13,7 +13,10 @@ enum { MC_NCORR = 0, MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIR
 
 // Host mailbox (ints): the kernel that finishes a phase stores the few counters the host needs straight into
 // pinned host memory, so a phase boundary costs one stream synchronisation and no copy launches.
-enum { MAIL_VOX0 = 0, MAIL_VOX1 = 16, MAIL_MATCH = 32, MAIL_CNT0 = 48, MAIL_CNT1 = 64, MAIL_SOLVER = 128, MAIL_INTS = 512 };
+// MAIL_SEQ_*: written LAST (after a system-scope fence) with the sequence number the host passed to the phase, so
+// the host can simply watch that word instead of going through the runtime's stream wait.
+enum { MAIL_VOX0 = 0, MAIL_VOX1 = 16, MAIL_MATCH = 32, MAIL_CNT0 = 48, MAIL_CNT1 = 64, MAIL_SEQ_VOX0 = 96, MAIL_SEQ_VOX1 = 97,
+       MAIL_SEQ_MATCH = 98, MAIL_SEQ_SOLVE = 99, MAIL_SOLVER = 128, MAIL_INTS = 512 };
 
 struct CloudBufs {
   int* counts = nullptr;       // 16
@@ -56,7 +59,8 @@ struct FrontBufs {
   int* mcounts = nullptr;      // 16
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
-  int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* below); may be null
+  int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
+  int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
   int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit
   int n_cu = 256;              // compute units of the device

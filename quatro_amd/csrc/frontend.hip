@@ -344,7 +344,8 @@ __device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, in
 __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
                                                        int P, const int* __restrict__ blkoff, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts,
-                                                       int* __restrict__ mail) {
+                                                       int* __restrict__ mail, int* __restrict__ mail_seq_slot,
+                                                       int seq) {
   // element t of the window lives in s_p[t + 1] as (x, y, z, cell id bits): one 16-byte LDS read per element
   __shared__ float4 s_p[VOX_TILE + VOX_HALO + 1];
   __shared__ int wtot[4];
@@ -353,8 +354,11 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   const int base = blockIdx.x * VOX_TILE;
   int running = blkoff[blockIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
-  if (mail && blockIdx.x == 0 && threadIdx.x < 16)  // this is the last voxelise kernel: hand the counters to the host
+  if (mail && blockIdx.x == 0 && threadIdx.x < 16) {  // this is the last voxelise kernel: hand the counters to the host
     mail[threadIdx.x] = (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) *mail_seq_slot = seq;
+  }
   {
     // two rounds of independent loads (keys, then the gathered points) instead of six dependent pairs
     constexpr int NLD = (VOX_TILE + VOX_HALO) / 256;
@@ -979,6 +983,7 @@ struct CloudView {
   u64* keys_out;
   u32* hist;
   int* mail;           // host mailbox slot of this cloud's voxelise counters (or null)
+  int* mail_seq_slot;  // ... and the word that receives the sequence number after them
   int* blkcnt;
   int* blkoff;
   int* nbr_cnt;
@@ -1032,9 +1037,9 @@ __global__ __launch_bounds__(1024) void k2_vox_blockscan(Clouds2 a) {
   const CloudView& C = a.c[blockIdx.y];
   d_scan_i32_copy(C.blkcnt, C.blkoff, C.nblk_vox);
 }
-__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap) {
+__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap, int seq) {
   const CloudView& C = a.c[blockIdx.y];
-  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts, C.mail);
+  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts, C.mail, C.mail_seq_slot, seq);
 }
 __global__ __launch_bounds__(256) void k2_sorted_points(Clouds2 a) {
   const CloudView& C = a.c[blockIdx.y];
@@ -1133,6 +1138,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
     a.c[c] = make_view(*C[c], raw[c], P[c], 0);
     a.c[c].keys_out = C[c]->keys_a;
     a.c[c].mail = F.mail ? F.mail + (C[c] == &F.cloud[1] ? MAIL_VOX1 : MAIL_VOX0) : nullptr;
+    a.c[c].mail_seq_slot = F.mail ? F.mail + (C[c] == &F.cloud[1] ? MAIL_SEQ_VOX1 : MAIL_SEQ_VOX0) : nullptr;
     a.c[c].nblk_vox = (P[c] + 1023) / 1024;
     a.c[c].blkcnt = (int*)C[c]->hist;
     a.c[c].blkoff = a.c[c].blkcnt + a.c[c].nblk_vox + 8;
@@ -1149,7 +1155,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   const int nblk = (maxP + 1023) / 1024;
   hipLaunchKernelGGL(k2_vox_headcount, dim3(nblk, nc), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k2_vox_blockscan, dim3(1, nc), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, a, F.max_voxels);
+  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, a, F.max_voxels, F.mail_seq);
   return hipGetLastError();
 }
 

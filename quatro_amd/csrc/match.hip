@@ -389,7 +389,7 @@ __global__ __launch_bounds__(1024) void k_scan_nonneg(const int* __restrict__ in
 
 __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restrict__ tgt_of_src, int ns,
                                 int* __restrict__ corr, int* __restrict__ mcounts, int* __restrict__ mail,
-                                const int* __restrict__ counts0, const int* __restrict__ counts1) {
+                                const int* __restrict__ counts0, const int* __restrict__ counts1, int seq) {
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
     const int t = tgt_of_src[s];
     if (t >= 0) {
@@ -406,6 +406,8 @@ __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restr
       mail[MAIL_CNT0 + (t - 16)] = counts0[t - 16];
     else
       mail[MAIL_CNT1 + (t - 32)] = counts1[t - 32];
+    __threadfence_system();  // threads 0..47 are one wavefront: the stores above are acknowledged before ...
+    if (t == 0) mail[MAIL_SEQ_MATCH] = seq;  // ... the word the host is watching changes
   }
 }
 
@@ -611,7 +613,7 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
                      F.mcounts, swapped, F.tgt_of_src, F.mcounts);
   hipLaunchKernelGGL(k_scan_nonneg, dim3(1), dim3(1024), 0, st, F.tgt_of_src, F.scan, ns);
   hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr, F.mcounts,
-                     F.mail, F.cloud[0].counts, F.cloud[1].counts);
+                     F.mail, F.cloud[0].counts, F.cloud[1].counts, F.mail_seq);
   return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct SolverBufs {
   SolverState* st = nullptr;
   qtr_result* res = nullptr;
   int* mail = nullptr;  // device view of the slot's pinned host mailbox (frontend.h MAIL_*), or null
+  int mail_seq = 0;     // sequence number the next k_finalize / k_clique_only publishes
 };
 
 size_t solver_scratch_bytes(int Lcap);

@@ -593,6 +593,7 @@ struct FinalizeArgs {
   int* i32;          // 8 * L ints
   qtr_result* res;   // device copy of the result record
   int* mail;         // host mailbox (pinned, device visible) for the result record + solver state, or null
+  int seq;           // sequence number published after them
 };
 
 // One COTE axis on one GROUP of four wavefronts (256 threads; reference estimate(), include/quatro.hpp:618-747).
@@ -852,20 +853,27 @@ __device__ __forceinline__ void clique_members(const SolverState* st, u64* membe
 
 // Result record and solver state straight into the slot's pinned host mailbox: the host needs one stream
 // synchronisation and no copy launches.  Called by every thread of the workgroup at kernel exit.
-__device__ __forceinline__ void export_result(int* __restrict__ mail, const qtr_result* res, const SolverState* st) {
+__device__ __forceinline__ void export_result(int* __restrict__ mail, const qtr_result* res, const SolverState* st,
+                                              int seq) {
   if (!mail) return;
   __syncthreads();
   constexpr int NR = (int)(sizeof(qtr_result) / 4), NS = (int)(sizeof(SolverState) / 4);
   const int t = threadIdx.x;
   if (t < NR) mail[MAIL_SOLVER + t] = ((const int*)res)[t];
   if (t >= 64 && t < 64 + NS) mail[MAIL_SOLVER + 64 + (t - 64)] = ((const int*)st)[t - 64];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) {
+    __threadfence_system();
+    mail[MAIL_SEQ_SOLVE] = seq;
+  }
 }
 
 // Stand-alone clique extraction for qtr_max_clique (teaser::MaxCliqueSolver::findMaxClique boundary,
 // reference src/graph.cc:15-98): res->n_clique / max_core / n_edges are filled, nothing else is estimated.
 __global__ __launch_bounds__(256) void k_clique_only(SolverState* st, u64* member_bits, const int* picks,
                                                      const int* perm, int* clique, int W, qtr_result* res,
-                                                     int* mail) {
+                                                     int* mail, int seq) {
   __shared__ int s_M;
   clique_members(st, member_bits, picks, perm, clique, W, &s_M);
   if (threadIdx.x == 0) {
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(256) void k_clique_only(SolverState* st, u64* membe
     res->n_edges = st->n_edges2 / 2;
     res->status = QTR_OK;
   }
-  export_result(mail, res, st);
+  export_result(mail, res, st, seq);
 }
 
 // qtr_max_clique input hygiene + degrees, one wavefront per row: the diagonal bit and the bits past L are
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   (void)mc;
   if (M <= 1) {  // reference :809-813
     if (tid == 0) res->status = QTR_ERR_CLIQUE_TOO_SMALL;
-    export_result(A.mail, res, st);
+    export_result(A.mail, res, st, A.seq);
     return;
   }
 
@@ -1169,7 +1177,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
     res->valid = 1;
     res->status = QTR_OK;
   }
-  export_result(A.mail, res, st);
+  export_result(A.mail, res, st, A.seq);
 }
 
 // =================================================================================================
@@ -1246,6 +1254,7 @@ static void launch_finalize(const SolverBufs& B, const float4* src, const float4
   A.i32 = B.i32;
   A.res = B.res;
   A.mail = B.mail;
+  A.seq = B.mail_seq;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, A);
 }
 
@@ -1359,7 +1368,7 @@ hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int
 hipError_t clique_only_finish(const SolverBufs& B, int L, hipStream_t stream) {
   const int W = (L + 63) / 64;
   hipLaunchKernelGGL(k_clique_only, dim3(1), dim3(256), 0, stream, B.st, B.member_bits, B.picks, B.perm, B.clique, W,
-                     B.res, B.mail);
+                     B.res, B.mail, B.mail_seq);
   return hipGetLastError();
 }
 
