@@ -59,6 +59,7 @@ struct FrontBufs {
   int* mcounts = nullptr;      // 16
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
+  float* recheck_thr = nullptr; // [max_voxels] per listed row: approximate best + 2 eps (candidates above it cannot win)
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)

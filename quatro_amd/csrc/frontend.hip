@@ -1221,7 +1221,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   size_t shared = (size_t)max_voxels * 64 + 16384;
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
-  shared += vpad * 32 * 16 + (size_t)max_voxels * 4 + 1024;           // nn_partial, recheck_rows
+  shared += vpad * 32 * 16 + 2 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr
   return 2 * per_cloud + shared + 64 * 256;
 }
 
@@ -1273,6 +1273,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.mcounts = (int*)take(16 * 4);
   F.nn_partial = take((((size_t)max_voxels + 511) / 512 * 512) * 32 * 16);
   F.recheck_rows = (int*)take((size_t)max_voxels * 4);
+  F.recheck_thr = (float*)take((size_t)max_voxels * 4);
   {
     const char* e = getenv("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : 1;

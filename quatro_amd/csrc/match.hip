@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void k_nn_mfma_finish(const NnPartial* __restr
                                                         const float* __restrict__ qnorm,
                                                         const u32* __restrict__ base_max_norm_bits,
                                                         u64* __restrict__ best, int* __restrict__ recheck_rows,
+                                                        float* __restrict__ recheck_thr,
                                                         int* __restrict__ recheck_count) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
@@ -289,58 +290,70 @@ __global__ __launch_bounds__(256) void k_nn_mfma_finish(const NnPartial* __restr
     best[q] = (u64)(u32)i1;
   } else {
     best[q] = ~0ULL;
-    recheck_rows[atomicAdd(recheck_count, 1)] = q;
+    const int slot = atomicAdd(recheck_count, 1);
+    recheck_rows[slot] = q;
+    // a base row whose approximate distance exceeds this cannot be the exact arg-min (both values are within eps
+    // of the exact one); +inf when the slice merge found nothing
+    recheck_thr[slot] = (i1 >= 0) ? b1 + 2.0f * eps : INFINITY;
   }
 }
 
-// exact re-decision of the listed rows: workgroup (x, y) scans base slice y for row x (grid-strided over
-// the list, whose length is read on the device); thread t evaluates base rows t, t+256, ... with the
-// exact flann::L2 arithmetic; a block arg-min feeds one packed 64-bit atomicMin per (row, slice).
-__global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__ A, const float* __restrict__ BT,
-                                                       int nB, int nb_pad, u64* __restrict__ best,
-                                                       const int* __restrict__ rows, const int* __restrict__ nrows_p) {
-  __shared__ float a_s[36];
-  __shared__ u64 wbest[4];
+// exact re-decision of the listed rows (list length read on the device).  One WAVEFRONT per (listed row, base
+// slice): the query row is wave-uniform, so its 33 values and their -2x counterparts (from the k-major query
+// table) live in SGPRs and every lane scans base descriptors (34 coalesced loads each from the k-major base
+// table) with ~60 VGPRs — many resident waves hide the load latency, there is no LDS staging and no barrier.
+// The test is two-staged: a 33-term fma chain gives the approximate distance (within eps of the exact-order
+// value, like the MFMA result), and only base rows under the row's threshold (approximate best + 2 eps, from the
+// finish kernel) can be the exact arg-min — those few are evaluated with the exact flann::L2 arithmetic.  The
+// exact winner always passes the filter, so the tables are unchanged; the VALU work per (row, base) pair drops
+// from ~100 to ~35 operations.  A wave arg-min feeds one packed 64-bit atomicMin per (row, slice).
+// (Tried and slower: eight rows per workgroup sharing the base loads through LDS-resident queries — 256 VGPRs +
+// spills; 8-byte base loads — 34.6 us against 21.4.)
+__global__ __launch_bounds__(256) void k_nn_exact_rows(const float* __restrict__ A, const float* __restrict__ QT,
+                                                       int nq_pad, const float* __restrict__ BT, int nB, int nb_pad,
+                                                       u64* __restrict__ best, const int* __restrict__ rows,
+                                                       const float* __restrict__ thr, const int* __restrict__ nrows_p) {
   const int nrows = *nrows_p;
   const int per = (nB + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nB, b0 + per);
-  for (int ri = blockIdx.x; ri < nrows; ri += gridDim.x) {
-    const int a_idx = rows[ri];
-    __syncthreads();
-    if (threadIdx.x < 33) a_s[threadIdx.x] = A[(size_t)a_idx * 33 + threadIdx.x];
-    __syncthreads();
-    float a[33];
+  const int lane = qk_lane(), wave = threadIdx.x >> 6;
+  for (int ri = blockIdx.x * 4 + wave; ri < nrows; ri += gridDim.x * 4) {
+    const int a_idx = __builtin_amdgcn_readfirstlane(rows[ri]);
+    const float tr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(thr[ri])));
+    float a[33], m2a[33];
 #pragma unroll
-    for (int t = 0; t < 33; ++t) a[t] = a_s[t];
+    for (int k = 0; k < 33; ++k) {
+      a[k] = A[(size_t)a_idx * 33 + k];                // uniform address -> scalar loads
+      m2a[k] = QT[(size_t)k * nq_pad + a_idx];         // -2 * a[k]
+    }
     u64 mine = ~0ULL;
-    for (int b = b0 + threadIdx.x; b < b1; b += 256) {
-      // base descriptors come from the k-major table: consecutive threads read consecutive addresses
-      float result = 0.f;
+    for (int b = b0 + lane; b < b1; b += 64) {
+      float v[34];
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const float d0 = a[4 * g] - BT[(size_t)(4 * g) * nb_pad + b], d1 = a[4 * g + 1] - BT[(size_t)(4 * g + 1) * nb_pad + b],
-                    d2 = a[4 * g + 2] - BT[(size_t)(4 * g + 2) * nb_pad + b],
-                    d3 = a[4 * g + 3] - BT[(size_t)(4 * g + 3) * nb_pad + b];
-        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      for (int k = 0; k < 34; ++k) v[k] = BT[(size_t)k * nb_pad + b];
+      float approx = v[33];  // |b|^2
+#pragma unroll
+      for (int k = 0; k < 33; ++k) approx = fmaf(m2a[k], v[k], approx);
+      if (approx <= tr) {  // rare: exact flann::L2 order
+        float result = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const float d0 = a[4 * g] - v[4 * g], d1 = a[4 * g + 1] - v[4 * g + 1], d2 = a[4 * g + 2] - v[4 * g + 2],
+                      d3 = a[4 * g + 3] - v[4 * g + 3];
+          result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        const float dt = a[32] - v[32];
+        result += dt * dt;
+        const u64 key = ((u64)__float_as_uint(result) << 32) | (u32)b;
+        mine = key < mine ? key : mine;
       }
-      const float dt = a[32] - BT[(size_t)32 * nb_pad + b];
-      result += dt * dt;
-      const float d = result;
-      const u64 key = ((u64)__float_as_uint(d) << 32) | (u32)b;
-      mine = key < mine ? key : mine;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const u64 o = __shfl_xor(mine, off, 64);
       mine = o < mine ? o : mine;
     }
-    if (qk_lane() == 0) wbest[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      u64 m = wbest[0];
-      for (int w = 1; w < 4; ++w) m = wbest[w] < m ? wbest[w] : m;
-      if (m != ~0ULL) atomicMin(&best[a_idx], m);
-    }
+    if (lane == 0 && mine != ~0ULL) atomicMin(&best[a_idx], mine);
   }
 }
 
@@ -587,12 +600,12 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
                          (NnPartial*)F.nn_partial, (F.nn_trace && mc_slot == MC_RECHECK0) ? F.mcounts : (int*)nullptr);
       if (ev1) (void)hipEventRecord(ev1, st);
       hipLaunchKernelGGL(k_nn_mfma_finish, dim3((nq + 255) / 256), dim3(256), 0, st, (const NnPartial*)F.nn_partial, ns_,
-                         nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.mcounts + mc_slot);
-      int ey = (nb + 511) / 512;  // 2 base rows per thread and slice
-      if (ey > 32) ey = 32;
+                         nq, Q.norms, Bc.max_norm, best, F.recheck_rows, F.recheck_thr, F.mcounts + mc_slot);
+      int ey = (nb + 255) / 256;  // ~4 base descriptors per lane and slice
+      if (ey > 64) ey = 64;
       if (ey < 1) ey = 1;
-      hipLaunchKernelGGL(k_nn_exact_rows, dim3(256, ey), dim3(256), 0, st, Q.fpfh, Bc.baseT, nb, nb_pad, best,
-                         F.recheck_rows, F.mcounts + mc_slot);
+      hipLaunchKernelGGL(k_nn_exact_rows, dim3(64, ey), dim3(256), 0, st, Q.fpfh, Q.queryT, nq_pad, Bc.baseT, nb, nb_pad, best,
+                         F.recheck_rows, F.recheck_thr, F.mcounts + mc_slot);
     };
     run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, F.ev_nn[0], F.ev_nn[1]);
     run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, F.ev_nn[2], F.ev_nn[3]);
