@@ -181,8 +181,8 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
 // THEIR ROWS IN REGISTERS (VT rows of 4*VT words), so a sweep is one broadcast LDS read of the alive word,
 // an AND, a popcount and an add per word — no staging of the matrix, no dynamic LDS, every workgroup of the
 // launch co-resident.  The cores are nested, so core(v) = max{k : v in M[k]}; the workgroup that finishes
-// last reads every vertex's core number off its column with an 8-ary search.  Core numbers are unique, so
-// this equals compute_cores' (Batagelj-Zaversnik) result.
+// next kernel reads every vertex's core number off its column.  Core numbers are unique, so this equals
+// compute_cores' (Batagelj-Zaversnik) result.
 #define KCL_VPT 5  // most vertices per thread: 256 * 5 = 1280
 template <int VT>
 __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm, int L, int W,
@@ -250,64 +250,141 @@ __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm
   if (tid < W) M[(size_t)k * W + tid] = s_alive[par][tid];
 }
 
-// Second half: every vertex's core number = the largest k whose mask holds it (the masks are nested), found
-// with an 8-ary search over its column (7 independent probes per step).  A separate launch on purpose: on a
-// multi-XCD part a device-scope fence inside the kernel (last-workgroup-done pattern) writes back and
-// invalidates the L2s and cost more than the launch boundary that gives the same ordering for free.
-__global__ __launch_bounds__(256) void k_kcore_collect(const u64* __restrict__ M, int L, int W, int K,
-                                                      const int* __restrict__ deg_in, int* __restrict__ core_out,
-                                                      SolverState* __restrict__ st) {
-  __shared__ int s_red[8];
+// Second half of the level-parallel path: every vertex's core number = the largest k whose mask holds it (the
+// masks are nested), found with an 8-ary search over its column (7 independent probes per step) — a separate
+// launch on purpose: on a multi-XCD part a device-scope fence inside the kernel (last-workgroup-done pattern)
+// writes back and invalidates the L2s and cost more than the launch boundary that gives the same ordering for
+// free.  The same workgroup then ranks the vertices and initialises the search: ONE workgroup of 1024 threads
+// (L <= 1280 <= 2 vertices per thread) (L <= 1280 <= 2 vertices per thread): the core numbers go to LDS, every thread counts how
+// many (core, id) pairs precede its own with broadcast LDS reads, and thread 0 initialises the clique search —
+// one launch instead of five (collect, memset, rank partial, rank finish, clique init).
+__global__ __launch_bounds__(1024) void k_kcore_collect_rank(const u64* __restrict__ M, int L, int W, int K,
+                                                            const int* __restrict__ deg_in, int* __restrict__ core_out,
+                                                            int* __restrict__ perm, int* __restrict__ Kp,
+                                                            SolverState* __restrict__ st) {
+  __shared__ __attribute__((aligned(16))) int s_core[2048 + 4];
+  __shared__ int s_bin[2048];
+  __shared__ int s_red[32], s_tot[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int v = blockIdx.x * 256 + tid;
   int esum = 0, cmax = 0;
-  if (v < L) {
-    const int dv = deg_in[v];
-    int lo = 0, hi = min(dv, K);  // invariant: member at lo (k = 0: everybody), not above hi
-    const u64* col = M + (v >> 6);
-    const int bv = v & 63;
-    while (lo < hi) {
-      const int span = hi - lo;
-      int probe[7];
-      u64 word[7];
+  int myc[2] = {0, 0};
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        probe[q] = min(lo + max(1, (int)(((long long)span * (q + 1)) >> 3)), hi);
-        word[q] = col[(size_t)probe[q] * W];
-      }
-      int nlo = lo, nhi = hi;
-      bool cut = false;
+  for (int i = 0; i < 2; ++i) {
+    const int v = i * 1024 + tid;
+    if (v < L) {
+      const int dv = deg_in[v];
+      int lo = 0, hi = min(dv, K);  // invariant: member at lo (k = 0: everybody), not above hi
+      const u64* col = M + (v >> 6);
+      const int bv = v & 63;
+      while (lo < hi) {
+        const int span = hi - lo;
+        int probe[7];
+        u64 word[7];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        const bool in = (word[q] >> bv) & 1ULL;
-        if (!cut) {
-          if (in)
-            nlo = probe[q];
-          else {
-            nhi = probe[q] - 1;
-            cut = true;
+        for (int q = 0; q < 7; ++q) {
+          probe[q] = min(lo + max(1, (int)(((long long)span * (q + 1)) >> 3)), hi);
+          word[q] = col[(size_t)probe[q] * W];
+        }
+        int nlo = lo, nhi = hi;
+        bool cut = false;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const bool in = (word[q] >> bv) & 1ULL;
+          if (!cut) {
+            if (in)
+              nlo = probe[q];
+            else {
+              nhi = probe[q] - 1;
+              cut = true;
+            }
           }
         }
+        lo = nlo;
+        hi = nhi;
       }
-      lo = nlo;
-      hi = nhi;
+      core_out[v] = lo;
+      myc[i] = lo;
+      cmax = max(cmax, lo);
+      esum += dv;
     }
-    core_out[v] = lo;
-    cmax = lo;
-    esum = dv;
+    if (v < 2048) s_core[v] = (v < L) ? myc[i] : 0x7fffffff;
   }
   cmax = wave_max_i32(cmax);
   esum = wave_sum_i32(esum);
   if (lane == 0) {
     s_red[wave] = cmax;
-    s_red[4 + wave] = esum;
+    s_red[16 + wave] = esum;
   }
   __syncthreads();
   if (tid == 0) {
-    const int mc = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
-    atomicMax(&st->max_core, mc);
-    atomicMax(&st->ub, mc + 1);
-    atomicAdd(&st->n_edges2, s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    int mc = 0, es = 0;
+    for (int w = 0; w < 16; ++w) {
+      mc = max(mc, s_red[w]);
+      es += s_red[16 + w];
+    }
+    s_tot[0] = mc;
+    s_tot[1] = es;
+  }
+  __syncthreads();
+  // ranks in the (core, id) order = one stable counting-sort pass keyed by the core number: histogram, exclusive
+  // scan over the (at most 2048) core values, then ONE wavefront walks the vertices in id order, 64 at a time,
+  // ranking equal keys inside a chunk with ballot match masks (as the radix scatter does)
+  for (int c = tid; c < 2048; c += 1024) s_bin[c] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = i * 1024 + tid;
+    if (v < L) atomicAdd(&s_bin[myc[i]], 1);
+  }
+  __syncthreads();
+  {
+    const int c0 = s_bin[2 * tid], c1 = s_bin[2 * tid + 1];
+    int tot;
+    const int ex = wave_excl_scan_i32(c0 + c1, &tot);
+    if (lane == 63) s_red[wave] = tot;  // (cmax / esum partials were consumed above)
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_red[w];
+    s_bin[2 * tid] = woff + ex;
+    s_bin[2 * tid + 1] = woff + ex + c0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int base = 0; base < L; base += 64) {
+      const int v = base + lane;
+      const bool valid = v < L;
+      const int c = valid ? s_core[v] : 0;
+      u64 m = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 11; ++bit) {
+        const bool one = (c >> bit) & 1;
+        const u64 bb = __ballot(valid && one);
+        m &= one ? bb : ~bb;
+      }
+      int r = 0;
+      if (valid) r = s_bin[c] + __popcll(m & lanemask_lt());
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above complete before the updates below
+      if (valid && (m & lanemask_lt()) == 0) s_bin[c] += __popcll(m);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (valid) {
+        perm[r] = v;
+        Kp[r] = c + 1;
+      }
+    }
+  }
+  if (tid == 0) {
+    const int mc = s_tot[0], es = s_tot[1];
+    st->max_core = mc;
+    st->ub = mc + 1;
+    st->n_edges2 = es;
+    // k_clique_init
+    st->mc = 0;
+    st->best_r = -1;
+    st->pos = L - 1;
+    st->done = (L <= 0) ? 1 : 0;
+    st->batch = 1;
+    st->t0 = 0;
+    st->rounds = 0;
   }
 }
 
@@ -1277,23 +1354,21 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
       else if (W <= 16) KCL_LAUNCH(4);
       else KCL_LAUNCH(5);
 #undef KCL_LAUNCH
-      hipLaunchKernelGGL(k_kcore_collect, dim3((L + 255) / 256), dim3(256), 0, stream, B.adjP, L, W, (int)kgrid.x, B.deg,
-                         B.core, B.st);
+      hipLaunchKernelGGL(k_kcore_collect_rank, dim3(1), dim3(1024), 0, stream, B.adjP, L, W, (int)kgrid.x, B.deg, B.core,
+                         B.perm, B.Kp, B.st);
     } else {
-    const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
-    const int kc_threads = 1024;
-    hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
-                       B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
-    }
-    {
+      const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
+      const int kc_threads = 1024;
+      hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
+                         B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
       (void)hipMemsetAsync(B.rankof, 0, sizeof(int) * (size_t)L, stream);
       hipLaunchKernelGGL(k_rank_partial, dim3((L + 255) / 256, slices), dim3(256), 0, stream, B.core, L, B.rankof);
       hipLaunchKernelGGL(k_rank_finish, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.rankof, B.perm, B.Kp);
+      hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
     }
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
-    hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
     bool heuristic = true;
     if (mode == QTR_INLIER_KCORE_HEU) {
       hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, kcore_thr, B.st,
