@@ -255,9 +255,9 @@ __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm
 // launch on purpose: on a multi-XCD part a device-scope fence inside the kernel (last-workgroup-done pattern)
 // writes back and invalidates the L2s and cost more than the launch boundary that gives the same ordering for
 // free.  The same workgroup then ranks the vertices and initialises the search: ONE workgroup of 1024 threads
-// (L <= 1280 <= 2 vertices per thread) (L <= 1280 <= 2 vertices per thread): the core numbers go to LDS, every thread counts how
-// many (core, id) pairs precede its own with broadcast LDS reads, and thread 0 initialises the clique search —
-// one launch instead of five (collect, memset, rank partial, rank finish, clique init).
+// (L <= 1280 <= 2 vertices per thread); the ranks come from one stable counting-sort pass keyed by the core
+// number, and thread 0 initialises the clique search — one launch instead of five (collect, memset, rank
+// partial, rank finish, clique init).
 __global__ __launch_bounds__(1024) void k_kcore_collect_rank(const u64* __restrict__ M, int L, int W, int K,
                                                             const int* __restrict__ deg_in, int* __restrict__ core_out,
                                                             int* __restrict__ perm, int* __restrict__ Kp,
