@@ -494,6 +494,40 @@ __device__ __forceinline__ int greedy_descent(const u64* __restrict__ adjP, int 
   return depth;
 }
 
+// W <= 64 (L <= 4096), matrix in LDS: the whole candidate set is one word per lane, so a pick is
+//   v_cmp (ballot) -> s_flbit -> 2 x v_readlane -> s_flbit -> address -> ds_read_b64 -> v_and
+// with nothing else on the dependent chain: no slot loop, and the picks are parked in LDS (every lane writes the
+// same word: no exec-mask switching) and copied out coalesced at the end.
+__device__ __forceinline__ int greedy_descent_lds1(const u64* __restrict__ rows, int W, int r, int t0, int lane,
+                                                   int* __restrict__ picks_lds, int* __restrict__ picks_out) {
+  const int wl = min(lane, W - 1);
+  u64 cur = (lane < W) ? rows[(size_t)r * W + lane] : 0ULL;
+  {
+    const int lo = lane * 64;
+    if (lo + 63 < t0)
+      cur = 0;
+    else if (lo < t0)
+      cur &= ~((1ULL << (t0 - lo)) - 1ULL);
+  }
+  const u64* col = rows + wl;
+  int depth = 1;
+  while (true) {
+    const u64 nz = __ballot(cur != 0);
+    if (nz == 0) break;
+    const int l = 63 - __clzll((long long)nz);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)cur, l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(cur >> 32), l);
+    const u64 word = ((u64)hi << 32) | lo;
+    const int u = l * 64 + 63 - __clzll((long long)word);
+    picks_lds[depth - 1] = u;
+    ++depth;
+    cur &= col[(size_t)u * W];  // lanes >= W hold 0 and stay 0
+  }
+  // depth - 1 picks, copied out coalesced
+  for (int i = lane; i < depth - 1; i += 64) picks_out[i] = picks_lds[i];
+  return depth;
+}
+
 __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, int t0, int lane, int* picks) {
   if (W <= 128) return greedy_descent<2>(adjP, W, r, t0, lane, picks);
   if (W <= 256) return greedy_descent<4>(adjP, W, r, t0, lane, picks);
@@ -548,7 +582,14 @@ __global__ __launch_bounds__(256) void k_clique_batch_lds(const u64* __restrict_
   for (int e = threadIdx.x; e < L * W; e += 256) cl_rows[e] = adjP[e];
   __syncthreads();
   int g = 0;
-  if (want) g = greedy_dispatch(cl_rows, W, r, st->t0, lane, picks_buf + (size_t)wid * L);
+  if (want) {
+    if (W <= 64) {
+      int* pk = (int*)(cl_rows + (size_t)L * W) + (size_t)(threadIdx.x >> 6) * L;  // per-wave pick list after the matrix
+      g = greedy_descent_lds1(cl_rows, W, r, st->t0, lane, pk, picks_buf + (size_t)wid * L);
+    } else {
+      g = greedy_dispatch(cl_rows, W, r, st->t0, lane, picks_buf + (size_t)wid * L);
+    }
+  }
   if (lane == 0 && wid < batch) gsz[wid] = g;
 }
 
@@ -1377,9 +1418,10 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
     if (heuristic) {
       const int BATCH = CLIQUE_BATCH;
       // round 0: the single top-ranked start; round 1..: BATCH starts each
-      const bool lds_rows = (size_t)L * W * 8 <= (size_t)150 * 1024;
+      const size_t cl_lds = (size_t)L * W * 8 + (size_t)4 * L * sizeof(int);  // matrix + four per-wave pick lists
+      const bool lds_rows = cl_lds <= (size_t)150 * 1024;
       if (lds_rows)
-        hipLaunchKernelGGL(k_clique_batch_lds, dim3(1), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W, B.st,
+        hipLaunchKernelGGL(k_clique_batch_lds, dim3(1), dim3(256), cl_lds, stream, B.adjP, B.Kp, L, W, B.st,
                            B.gsz, B.picks_buf);
       else
         hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
@@ -1389,7 +1431,7 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
       // first start finds the large clique, the second batch only confirms that no start can beat it).  The
       // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
       if (lds_rows)
-        hipLaunchKernelGGL(k_clique_batch_lds, dim3(BATCH / 4), dim3(256), (size_t)L * W * 8, stream, B.adjP, B.Kp, L, W,
+        hipLaunchKernelGGL(k_clique_batch_lds, dim3(BATCH / 4), dim3(256), cl_lds, stream, B.adjP, B.Kp, L, W,
                            B.st, B.gsz, B.picks_buf);
       else
         hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
