@@ -141,6 +141,8 @@ static int create_impl(qtr_handle* h) {
       QTR_HIP_TRY(h, hipHostGetDevicePointer(&dv, s.mail, 0));
       s.fb.mail = (int*)dv;
       s.sb.mail = (int*)dv;
+      s.fb.m_src = s.m_src;
+      s.fb.m_tgt = s.m_tgt;
     }
   }
   return QTR_OK;

@@ -61,6 +61,9 @@ struct FrontBufs {
   int* recheck_rows = nullptr; // [max_voxels]
   float* recheck_thr = nullptr; // [max_voxels] per listed row: approximate best + 2 eps (candidates above it cannot win)
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
+  float4* m_src = nullptr;     // where the matcher's last kernel should leave the matched keypoint clouds (or null)
+  float4* m_tgt = nullptr;
+  bool gathered = false;       // set by match_enqueue when it did
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
   int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit

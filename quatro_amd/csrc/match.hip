@@ -512,6 +512,148 @@ __global__ void k_scatter_pairs(const int* __restrict__ cross_i, const int* __re
   if (qk_lane() == 0 && local) atomicAdd(&mc_out[MC_NTUPLE], local);
 }
 
+// ---- fused tails for clouds of up to 16384 points: one workgroup of 1024 threads, every thread owning one
+// contiguous run of at most 16 indices, so flag -> exclusive scan -> compaction happens in registers and LDS
+// without the three-launch (flags, scan, compact) round trips.
+// K6: unpack both NN tables, mutual-NN test, cross pairs in ascending i.
+__global__ __launch_bounds__(1024) void k_cross_fused(const u64* __restrict__ best_large,
+                                                      const u64* __restrict__ best_small, int n_large, int n_small,
+                                                      int* __restrict__ nn_of_large, int* __restrict__ nn_of_small,
+                                                      int* __restrict__ cross_i, int* __restrict__ cross_j,
+                                                      int* __restrict__ mcounts) {
+  extern __shared__ int fl_s[];  // [n_large] nn index | keep flag << 31, staged with coalesced (striped) accesses
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < n_small; j += 1024) {
+    const u64 b = best_small[j];
+    nn_of_small[j] = (b == ~0ULL) ? 0 : (int)(u32)b;
+  }
+  for (int i = tid; i < n_large; i += 1024) {
+    const u64 b = best_large[i];
+    const int j = (b == ~0ULL) ? 0 : (int)(u32)b;
+    nn_of_large[i] = j;
+    const u64 bs = best_small[j];
+    const int back = (bs == ~0ULL) ? 0 : (int)(u32)bs;
+    fl_s[i] = j | ((back == i) ? (int)0x80000000 : 0);
+  }
+  __syncthreads();
+  const int K = (n_large + 1023) >> 10, base = tid * K;
+  int jj[16];
+  u32 keep = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = base + k;
+    jj[k] = 0;
+    if (k < K && i < n_large) {
+      const int v = fl_s[i];
+      jj[k] = v & 0x7fffffff;
+      if (v < 0) {
+        keep |= 1u << k;
+        ++cnt;
+      }
+    }
+  }
+  int tot;
+  const int ex = wave_excl_scan_i32(cnt, &tot);
+  if (lane == 63) wsum[wave] = tot;
+  __syncthreads();
+  int run = ex, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    run += (w < wave) ? wsum[w] : 0;
+    total += wsum[w];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if ((keep >> k) & 1u) {
+      cross_i[run] = base + k;
+      cross_j[run] = jj[k];
+      ++run;
+    }
+  if (tid == 0) mcounts[MC_NCROSS] = total;
+}
+
+// K8 + gather: passed cross pairs -> tgt_of_src, compaction in source order, the matched keypoint clouds
+// (when asked for) and the counters for the host.
+__global__ __launch_bounds__(1024) void k_pairs_fused(const int* __restrict__ cross_i, const int* __restrict__ cross_j,
+                                                      const int* __restrict__ passed, int swapped, int ns,
+                                                      int* __restrict__ tgt_of_src, int* __restrict__ corr,
+                                                      const float4* __restrict__ vs, const float4* __restrict__ vt,
+                                                      float4* __restrict__ m_src, float4* __restrict__ m_tgt,
+                                                      int* __restrict__ mcounts, int* __restrict__ mail,
+                                                      const int* __restrict__ counts0, const int* __restrict__ counts1,
+                                                      int seq) {
+  __shared__ int wsum[16];
+  __shared__ int s_ntuple;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_ntuple = 0;
+  __syncthreads();
+  const int nc = mcounts[MC_NCROSS];
+  int local = 0;
+  for (int c = tid; c < nc; c += 1024)
+    if (passed[c]) {
+      const int i = cross_i[c], j = cross_j[c];
+      tgt_of_src[swapped ? j : i] = swapped ? i : j;
+      ++local;
+    }
+  local = wave_sum_i32(local);
+  if (lane == 0 && local) atomicAdd(&s_ntuple, local);
+  __threadfence_block();
+  __syncthreads();  // the scattered targets are visible to the whole workgroup
+  extern __shared__ int tg_s[];  // [ns] staged with coalesced (striped) loads
+  for (int i = tid; i < ns; i += 1024) tg_s[i] = tgt_of_src[i];
+  __syncthreads();
+  const int K = (ns + 1023) >> 10, base = tid * K;
+  int tt[16];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int sidx = base + k;
+    tt[k] = (k < K && sidx < ns) ? tg_s[sidx] : -1;
+    cnt += tt[k] >= 0 ? 1 : 0;
+  }
+  int tot;
+  const int ex = wave_excl_scan_i32(cnt, &tot);
+  if (lane == 63) wsum[wave] = tot;
+  __syncthreads();
+  int run = ex, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    run += (w < wave) ? wsum[w] : 0;
+    total += wsum[w];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (tt[k] >= 0) {
+      corr[2 * run] = base + k;
+      corr[2 * run + 1] = tt[k];
+      if (m_src) {
+        float4 a = vs[base + k], b = vt[tt[k]];
+        a.w = 0.f;
+        b.w = 0.f;
+        m_src[run] = a;
+        m_tgt[run] = b;
+      }
+      ++run;
+    }
+  if (tid == 0) {
+    mcounts[MC_NCORR] = total;
+    mcounts[MC_NTUPLE] = s_ntuple;
+  }
+  if (mail && tid < 48) {  // last matcher kernel: counters for the host, no copy launches
+    const int t = tid;
+    if (t < 16)
+      mail[MAIL_MATCH + t] = (t == MC_NCORR) ? total : (t == MC_NTUPLE) ? s_ntuple : mcounts[t];
+    else if (t < 32)
+      mail[MAIL_CNT0 + (t - 16)] = counts0[t - 16];
+    else
+      mail[MAIL_CNT1 + (t - 32)] = counts1[t - 32];
+    __threadfence_system();  // threads 0..47 are one wavefront: the stores above are acknowledged before ...
+    if (t == 0) mail[MAIL_SEQ_MATCH] = seq;  // ... the word the host is watching changes
+  }
+}
+
 __global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __restrict__ vt,
                                  const int* __restrict__ corr, int L, float4* __restrict__ ms, float4* __restrict__ mt) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < L; c += gridDim.x * blockDim.x) {
@@ -612,26 +754,40 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
   }
   // K6 cross-check -> pairs in ascending i
   hipError_t e;
-  hipLaunchKernelGGL(k_cross_flags2, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, F.best_small, n_large,
-                     n_small, F.nn_of_large, F.nn_of_small, F.flags);
-  if ((e = exclusive_scan_i32(F.flags, F.scan, n_large, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cross_compact, dim3(grid_for(n_large)), dim3(256), 0, st, F.flags, F.scan, F.nn_of_large,
-                     n_large, F.cross_i, F.cross_j, F.mcounts);
+  const bool fused_tail = n_large <= 16384 && ns <= 16384;
+  F.gathered = false;
+  if (fused_tail) {
+    hipLaunchKernelGGL(k_cross_fused, dim3(1), dim3(1024), (size_t)n_large * 4, st, F.best_large, F.best_small, n_large, n_small,
+                       F.nn_of_large, F.nn_of_small, F.cross_i, F.cross_j, F.mcounts);
+  } else {
+    hipLaunchKernelGGL(k_cross_flags2, dim3(grid_for(n_large)), dim3(256), 0, st, F.best_large, F.best_small, n_large,
+                       n_small, F.nn_of_large, F.nn_of_small, F.flags);
+    if ((e = exclusive_scan_i32(F.flags, F.scan, n_large, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_cross_compact, dim3(grid_for(n_large)), dim3(256), 0, st, F.flags, F.scan, F.nn_of_large,
+                       n_large, F.cross_i, F.cross_j, F.mcounts);
+  }
   // K7 tuple test
   if (tuple)
     hipLaunchKernelGGL(k_tuple, dim3(2048), dim3(256), 0, st, Ci.vox, Ci.mean, Cj.vox, Cj.mean, F.cross_i, F.cross_j,
                        F.mcounts, fp.tuple_scale, (u64)fp.seed, F.passed);
   // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
-  hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(maxc)), dim3(256), 0, st, F.cross_i, F.cross_j, F.passed,
-                     F.mcounts, swapped, F.tgt_of_src, F.mcounts);
-  hipLaunchKernelGGL(k_scan_nonneg, dim3(1), dim3(1024), 0, st, F.tgt_of_src, F.scan, ns);
-  hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr, F.mcounts,
-                     F.mail, F.cloud[0].counts, F.cloud[1].counts, F.mail_seq);
+  if (fused_tail) {
+    hipLaunchKernelGGL(k_pairs_fused, dim3(1), dim3(1024), (size_t)ns * 4, st, F.cross_i, F.cross_j, F.passed, swapped, ns,
+                       F.tgt_of_src, F.corr, F.cloud[0].vox, F.cloud[1].vox, F.m_src, F.m_tgt, F.mcounts, F.mail,
+                       F.cloud[0].counts, F.cloud[1].counts, F.mail_seq);
+    F.gathered = F.m_src != nullptr;
+  } else {
+    hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(maxc)), dim3(256), 0, st, F.cross_i, F.cross_j, F.passed,
+                       F.mcounts, swapped, F.tgt_of_src, F.mcounts);
+    hipLaunchKernelGGL(k_scan_nonneg, dim3(1), dim3(1024), 0, st, F.tgt_of_src, F.scan, ns);
+    hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(ns)), dim3(256), 0, st, F.scan, F.tgt_of_src, ns, F.corr,
+                       F.mcounts, F.mail, F.cloud[0].counts, F.cloud[1].counts, F.mail_seq);
+  }
   return hipGetLastError();
 }
 
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st) {
-  if (L <= 0) return hipSuccess;
+  if (L <= 0 || (F.gathered && m_src == F.m_src && m_tgt == F.m_tgt)) return hipSuccess;  // k_pairs_fused did it
   hipLaunchKernelGGL(k_gather_matched, dim3(grid_for(L)), dim3(256), 0, st, F.cloud[0].vox, F.cloud[1].vox, F.corr, L,
                      m_src, m_tgt);
   return hipGetLastError();
