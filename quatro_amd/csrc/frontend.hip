@@ -678,34 +678,9 @@ __device__ __forceinline__ void dev_cross(const float* a, const float* b, float*
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-__device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n, const int* __restrict__ nbr_cnt,
-                                                 const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
-                                                 float rn2, float4* __restrict__ normals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int kf = nbr_cnt[i];
-  const int* idx = nbr_idx + (size_t)i * QTR_KMAX;
-  const float* d2 = nbr_d2 + (size_t)i * QTR_KMAX;
-  int k = 0;
-  while (k < kf && d2[k] < rn2) ++k;
-  const float qnan = __uint_as_float(0x7fc00000u);
-  if (k < 3) {
-    normals[i] = make_float4(qnan, qnan, qnan, qnan);
-    return;
-  }
-  float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < k; ++t) {
-    const float4 q = pts[idx[t]];
-    acc[0] += q.x * q.x;
-    acc[1] += q.x * q.y;
-    acc[2] += q.x * q.z;
-    acc[3] += q.y * q.y;
-    acc[4] += q.y * q.z;
-    acc[5] += q.z * q.z;
-    acc[6] += q.x;
-    acc[7] += q.y;
-    acc[8] += q.z;
-  }
+// pcl::NormalEstimation tail: the nine single-pass float sums of k neighbours -> covariance -> pcl::eigen33
+// smallest eigenpair -> viewpoint flip.  (nx, ny, nz, curvature)
+__device__ __forceinline__ float4 normal_from_sums(float (&acc)[9], int k, const float4 p) {
   const float kk = (float)k;
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] /= kk;
@@ -763,7 +738,6 @@ __device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n,
   vz = vz / sl;
   const float eig_sum = cov[0] + cov[4] + cov[8];
   const float curv = (eig_sum != 0.f) ? fabsf(ev / eig_sum) : 0.f;
-  const float4 p = pts[i];
   const float wx = 0.f - p.x, wy = 0.f - p.y, wz = 0.f - p.z;
   const float cos_theta = (wx * vx + wy * vy + wz * vz);
   if (cos_theta < 0) {
@@ -771,7 +745,37 @@ __device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n,
     vy *= -1;
     vz *= -1;
   }
-  normals[i] = make_float4(vx, vy, vz, curv);
+  return make_float4(vx, vy, vz, curv);
+}
+__device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n, const int* __restrict__ nbr_cnt,
+                                                 const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
+                                                 float rn2, float4* __restrict__ normals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int kf = nbr_cnt[i];
+  const int* idx = nbr_idx + (size_t)i * QTR_KMAX;
+  const float* d2 = nbr_d2 + (size_t)i * QTR_KMAX;
+  int k = 0;
+  while (k < kf && d2[k] < rn2) ++k;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (k < 3) {
+    normals[i] = make_float4(qnan, qnan, qnan, qnan);
+    return;
+  }
+  float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < k; ++t) {
+    const float4 q = pts[idx[t]];
+    acc[0] += q.x * q.x;
+    acc[1] += q.x * q.y;
+    acc[2] += q.x * q.z;
+    acc[3] += q.y * q.y;
+    acc[4] += q.y * q.z;
+    acc[5] += q.z * q.z;
+    acc[6] += q.x;
+    acc[7] += q.y;
+    acc[8] += q.z;
+  }
+  normals[i] = normal_from_sums(acc, k, pts[i]);
 }
 
 // =================================================================================================
@@ -1047,6 +1051,15 @@ __global__ __launch_bounds__(256) void k2_sorted_points(Clouds2 a) {
 }
 __global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell) {
   const CloudView& C = a.c[blockIdx.y];
+  {  // the first n threads of the launch also gather the points into cell-sorted order (was k2_sorted_points)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < C.n) {
+      const u32 j = (u32)C.keys_in[t];
+      float4 p = C.vox[j];
+      p.w = __uint_as_float(j);
+      C.spts[t] = p;
+    }
+  }
   d_ranges(C.vox, C.n, C.keys_in, C.mm, cell, C.ranges);
 }
 __global__ __launch_bounds__(64) void k2_neighbors(Clouds2 a, float r2) {
@@ -1197,8 +1210,10 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   const int where = radix_sort2(a, C, nc, 1, 24, st);
   for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
   if (nc == 1) a.c[1] = a.c[0];
-  hipLaunchKernelGGL(k2_sorted_points, dim3(g, nc), dim3(256), 0, st, a);
+  // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
   hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, a, cell);
+  // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
+  // thread and the launch went from 21 + 14 us to 51 us)
   hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, a, r2);
   hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, a, rn2);
   hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, a);

@@ -37,6 +37,31 @@ __global__ __launch_bounds__(256, 2) void k_nn(const float* __restrict__ baseT, 
     f32x16 acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (MODE & 8) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int kk = 0; kk < NN_K2; ++kk) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(m[kk], q[a][kk], acc[a], 0, 0, 0);
+        const float before = b1[a];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __uint_as_float((__float_as_uint(acc[a][r]) & 0xfffffff0u) | (u32)r);
+          b2[a] = __builtin_amdgcn_fmed3f(b1[a], b2[a], v);
+          b1[a] = __builtin_amdgcn_fmed3f(b1[a], v, -INFINITY);
+        }
+        it1[a] = (b1[a] != before) ? t : it1[a];
+      }
+      if (MODE & 16) {  // hand-placed interleave: epilogue of accumulator a-1 rides under the MFMA chain of a
+        __builtin_amdgcn_sched_group_barrier(0x008, 17, 0);
+#pragma unroll
+        for (int i = 0; i < 51; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < NN_K2; ++kk)
 #pragma unroll
@@ -216,10 +241,10 @@ int main() {
   for (int sl : {15}) {
     run_k(k_nn<0>, "mfma only (no loads, no epilogue)", 8525, 9027, sl);
     run_k(k_nn<7>, "loads+epilogue+schedbarrier", 8525, 9027, sl);
-    run_k(k_nn_pipe<0>, "pipelined, compiler schedule", 8525, 9027, sl);
-    run_k(k_nn_pipe<2>, "pipelined, 1 mfma : 2 valu", 8525, 9027, sl);
-    run_k(k_nn_pipe<3>, "pipelined, 1 mfma : 3 valu", 8525, 9027, sl);
-    run_k(k_nn_pipe<4>, "pipelined, 1 mfma : 4 valu", 8525, 9027, sl);
+    run_k(k_nn<15>, "a-outer order", 8525, 9027, sl);
+    run_k(k_nn<11>, "a-outer order, no schedbarrier", 8525, 9027, sl);
+    run_k(k_nn<27>, "a-outer + sched_group_barrier", 8525, 9027, sl);
+    run_k(k_nn<31>, "a-outer + sgb + schedbarrier", 8525, 9027, sl);
   }
   return 0;
 }
