@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "quatro_hip.h"
@@ -38,24 +39,50 @@
 #else
 // ------------------------------------------------------------------ minimal Eigen / PCL stand-ins
 namespace Eigen {
-template <int R, int C>
-struct FixedMatrixD {
-  double m[R][C];
-  FixedMatrixD() { std::memset(m, 0, sizeof(m)); }
-  double& operator()(int r, int c) { return m[r][c]; }
-  const double& operator()(int r, int c) const { return m[r][c]; }
-  double& operator()(int i) { return (&m[0][0])[i]; }
-  const double& operator()(int i) const { return (&m[0][0])[i]; }
-  static FixedMatrixD Identity() {
-    FixedMatrixD a;
-    for (int i = 0; i < (R < C ? R : C); ++i) a.m[i][i] = 1.0;
+// Just enough of Eigen::Matrix for the types on the reference's API: fixed or dynamic sizes, (r, c) / (i) access,
+// rows() / cols() / resize(), Identity / Zero / Ones.  Row-major storage; the wrappers below only use accessors,
+// so they compile unchanged against the real (column-major) Eigen.
+constexpr int Dynamic = -1;
+template <typename T, int R, int C>
+class Matrix {
+  using Store = typename std::conditional<std::is_same<T, bool>::value, unsigned char, T>::type;
+
+ public:
+  Matrix() : rows_(R == Dynamic ? 0 : R), cols_(C == Dynamic ? 0 : C), d_(static_cast<size_t>(rows_) * cols_, Store()) {}
+  Matrix(int r, int c) : rows_(r), cols_(c), d_(static_cast<size_t>(r) * c, Store()) {}
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  void resize(int r, int c) {
+    rows_ = r;
+    cols_ = c;
+    d_.assign(static_cast<size_t>(r) * c, Store());
+  }
+  Store& operator()(int r, int c) { return d_[static_cast<size_t>(r) * cols_ + c]; }
+  const Store& operator()(int r, int c) const { return d_[static_cast<size_t>(r) * cols_ + c]; }
+  Store& operator()(int i) { return d_[static_cast<size_t>(i)]; }
+  const Store& operator()(int i) const { return d_[static_cast<size_t>(i)]; }
+  static Matrix Zero() { return Matrix(); }
+  static Matrix Zero(int r, int c) { return Matrix(r, c); }
+  static Matrix Ones(int r, int c) {
+    Matrix a(r, c);
+    for (auto& x : a.d_) x = Store(1);
     return a;
   }
-  static FixedMatrixD Zero() { return FixedMatrixD(); }
+  static Matrix Identity() {
+    Matrix a;
+    for (int i = 0; i < (a.rows_ < a.cols_ ? a.rows_ : a.cols_); ++i) a(i, i) = Store(1);
+    return a;
+  }
+
+ private:
+  int rows_, cols_;
+  std::vector<Store> d_;
 };
-using Matrix4d = FixedMatrixD<4, 4>;
-using Matrix3d = FixedMatrixD<3, 3>;
-using Vector3d = FixedMatrixD<3, 1>;
+using Matrix4d = Matrix<double, 4, 4>;
+using Matrix3d = Matrix<double, 3, 3>;
+using Matrix2d = Matrix<double, 2, 2>;
+using Vector3d = Matrix<double, 3, 1>;
+using RowVectorXd = Matrix<double, 1, Dynamic>;
 }  // namespace Eigen
 namespace pcl {
 struct PointXYZ {
@@ -274,6 +301,161 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     }
   }
 
+  // ---- the individually callable stages of the reference class, served by the device (stages.hip).  The fused
+  // computeTransformation above never materialises TIMs and does not call them.
+  // computeTIMs :307-344
+  Eigen::Matrix<double, 3, Eigen::Dynamic> computeTIMs(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v,
+                                                       Eigen::Matrix<int, 2, Eigen::Dynamic>* map) {
+    const int N = static_cast<int>(v.cols());
+    const long long K = static_cast<long long>(N) * (N - 1) / 2;
+    Eigen::Matrix<double, 3, Eigen::Dynamic> vtilde(3, static_cast<int>(K));
+    if (map) map->resize(2, static_cast<int>(K));
+    if (K <= 0) return vtilde;
+    std::vector<double> in(static_cast<size_t>(3) * N), out(static_cast<size_t>(3) * K);
+    std::vector<int> mp(static_cast<size_t>(2) * K);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < N; ++c) in[static_cast<size_t>(r) * N + c] = v(r, c);
+    qtr_handle* h = quatro_hip::default_handle();
+    quatro_hip::check(h, qtr_compute_tims(h, 0, in.data(), N, out.data(), mp.data()));
+    for (int r = 0; r < 3; ++r)
+      for (long long c = 0; c < K; ++c) vtilde(r, static_cast<int>(c)) = out[static_cast<size_t>(r) * K + c];
+    if (map)
+      for (int r = 0; r < 2; ++r)
+        for (long long c = 0; c < K; ++c) (*map)(r, static_cast<int>(c)) = mp[static_cast<size_t>(r) * K + c];
+    return vtilde;
+  }
+
+  // solveForScale :346-386 (the reference forces scale = 1)
+  double solveForScale(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v1,
+                       const Eigen::Matrix<double, 3, Eigen::Dynamic>& v2) {
+    scale_inliers_mask_.resize(1, static_cast<int>(v1.cols()));
+    solveForScale(v1, v2, &solution_.scale, &scale_inliers_mask_);
+    return solution_.scale;
+  }
+  void solveForScale(const Eigen::Matrix<double, 3, Eigen::Dynamic>& src,
+                     const Eigen::Matrix<double, 3, Eigen::Dynamic>& dst, double* scale,
+                     Eigen::Matrix<bool, 1, Eigen::Dynamic>* inliers) {
+    if (src.cols() != dst.cols()) throw std::invalid_argument("[solveForScale] dimension mismatch");
+    if (scale) *scale = 1;
+    if (!inliers) return;
+    const long long K = src.cols();
+    inliers->resize(1, static_cast<int>(K));
+    if (K == 0) return;
+    std::vector<double> a(static_cast<size_t>(3) * K), b(a.size());
+    for (int r = 0; r < 3; ++r)
+      for (long long c = 0; c < K; ++c) {
+        a[static_cast<size_t>(r) * K + c] = src(r, static_cast<int>(c));
+        b[static_cast<size_t>(r) * K + c] = dst(r, static_cast<int>(c));
+      }
+    std::vector<unsigned char> mask(static_cast<size_t>(K));
+    qtr_handle* h = quatro_hip::default_handle();
+    quatro_hip::check(h, qtr_scale_mask(h, 0, a.data(), b.data(), K, params_.noise_bound, params_.cbar2, mask.data()));
+    for (long long c = 0; c < K; ++c) (*inliers)(0, static_cast<int>(c)) = mask[static_cast<size_t>(c)] != 0;
+  }
+
+  // solveForRotation :388-428, solveForRotation2D :430-572
+  Eigen::Matrix3d solveForRotation(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v1,
+                                   const Eigen::Matrix<double, 3, Eigen::Dynamic>& v2) {
+    rotation_inliers_mask_.resize(1, static_cast<int>(v1.cols()));
+    if (reg_name_ != "Quatro")
+      throw std::invalid_argument("[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'");
+    Eigen::Matrix<double, 2, Eigen::Dynamic> src_2d(2, static_cast<int>(v1.cols())), dst_2d(2, static_cast<int>(v2.cols()));
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < v1.cols(); ++c) src_2d(r, c) = v1(r, c);
+      for (int c = 0; c < v2.cols(); ++c) dst_2d(r, c) = v2(r, c);
+    }
+    Eigen::Matrix2d rotation_2d = Eigen::Matrix2d::Identity();
+    solveForRotation2D(src_2d, dst_2d, &rotation_2d, &rotation_inliers_mask_);
+    Eigen::Matrix3d rot_yaw = Eigen::Matrix3d::Identity();
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c) rot_yaw(r, c) = rotation_2d(r, c);
+    solution_.rotation = rot_yaw;
+    if (using_pre_estimated_RyRx_) {  // :419-423: Rz * RyRx
+      Eigen::Matrix3d prod;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          prod(r, c) = (rot_yaw(r, 0) * estimated_RyRx_(0, c) + rot_yaw(r, 1) * estimated_RyRx_(1, c)) +
+                       rot_yaw(r, 2) * estimated_RyRx_(2, c);
+      solution_.rotation = prod;
+    }
+    return solution_.rotation;
+  }
+  void solveForRotation2D(const Eigen::Matrix<double, 2, Eigen::Dynamic>& src,
+                          const Eigen::Matrix<double, 2, Eigen::Dynamic>& dst, Eigen::Matrix2d* rotation,
+                          Eigen::Matrix<bool, 1, Eigen::Dynamic>* inliers) {
+    if (!rotation || src.cols() != dst.cols() || !(params_.rotation_gnc_factor > 1))
+      throw std::invalid_argument("[solveForRotation2D] bad arguments");
+    const int M = static_cast<int>(src.cols());
+    if (inliers) inliers->resize(1, M);
+    if (M == 0) return;
+    std::vector<double> a(static_cast<size_t>(2) * M), b(a.size());
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < M; ++c) {
+        a[static_cast<size_t>(r) * M + c] = src(r, c);
+        b[static_cast<size_t>(r) * M + c] = dst(r, c);
+      }
+    double R4[4], cost = 0;
+    int iters = 0;
+    std::vector<unsigned char> inl(static_cast<size_t>(M));
+    qtr_handle* h = quatro_hip::default_handle();
+    quatro_hip::check(h, qtr_gnc_rotation2d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
+                                            static_cast<int>(params_.rotation_max_iterations),
+                                            params_.rotation_cost_threshold, R4, &cost, &iters, inl.data()));
+    cost_ = cost;
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c) (*rotation)(r, c) = R4[2 * r + c];
+    if (inliers)
+      for (int c = 0; c < M; ++c) (*inliers)(0, c) = inl[static_cast<size_t>(c)] != 0;
+  }
+
+  // solveForTranslation :574-615, estimate :618-747 (uniform ranges, as every call site of the class passes)
+  Eigen::Vector3d solveForTranslation(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v1,
+                                      const Eigen::Matrix<double, 3, Eigen::Dynamic>& v2,
+                                      bool using_median_selection = false) {
+    translation_inliers_mask_.resize(1, static_cast<int>(v1.cols()));
+    solveForTranslation(v1, v2, &solution_.translation, &translation_inliers_mask_, using_median_selection);
+    return solution_.translation;
+  }
+  void solveForTranslation(const Eigen::Matrix<double, 3, Eigen::Dynamic>& src,
+                           const Eigen::Matrix<double, 3, Eigen::Dynamic>& dst, Eigen::Vector3d* translation,
+                           Eigen::Matrix<bool, 1, Eigen::Dynamic>* inliers, bool using_median_selection) {
+    if (src.cols() != dst.cols() || !translation) throw std::invalid_argument("[solveForTranslation] bad arguments");
+    const int N = static_cast<int>(src.cols());
+    const double beta = noise_bound_ * std::sqrt(params_.cbar2);
+    Eigen::RowVectorXd row(1, N), alphas(1, N);
+    Eigen::Matrix<bool, 1, Eigen::Dynamic> all = Eigen::Matrix<bool, 1, Eigen::Dynamic>::Ones(1, N), tmp(1, N);
+    for (int c = 0; c < N; ++c) alphas(0, c) = beta;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < N; ++c) row(0, c) = dst(r, c) - src(r, c);
+      double e = 0;
+      estimate(row, alphas, &e, &tmp, using_median_selection);
+      (*translation)(r, 0) = e;
+      for (int c = 0; c < N; ++c) all(0, c) = all(0, c) && tmp(0, c);
+    }
+    if (inliers) *inliers = all;
+  }
+  void estimate(const Eigen::RowVectorXd& X, const Eigen::RowVectorXd& ranges, double* estimate_out,
+                Eigen::Matrix<bool, 1, Eigen::Dynamic>* inliers, bool using_median_selection = false) {
+    const int N = static_cast<int>(X.cols());
+    if (ranges.cols() != N || N < 2) throw std::invalid_argument("[estimate] dimension mismatch or a single element");
+    for (int c = 1; c < N; ++c)
+      if (ranges(0, c) != ranges(0, 0))
+        throw std::invalid_argument("[estimate] non-uniform ranges are not supported by the device path");
+    std::vector<double> x(static_cast<size_t>(N));
+    for (int c = 0; c < N; ++c) x[static_cast<size_t>(c)] = X(0, c);
+    std::vector<unsigned char> inl(static_cast<size_t>(N));
+    double e = 0;
+    int ncard = 0;
+    qtr_handle* h = quatro_hip::default_handle();
+    quatro_hip::check(h, qtr_cote_estimate(h, 0, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e, inl.data(),
+                                           &ncard));
+    if (estimate_out) *estimate_out = e;
+    if (inliers) {
+      inliers->resize(1, N);
+      for (int c = 0; c < N; ++c) (*inliers)(0, c) = inl[static_cast<size_t>(c)] != 0;
+    }
+  }
+
   void getMaxCliques(pcl::PointCloud<PointSource>& source_max_clique,
                      pcl::PointCloud<PointSource>& target_max_clique) {  // :949-953
     gather(*input_, source_max_clique, max_clique_);
@@ -300,6 +482,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
   std::vector<int> max_clique_;
   std::vector<int> rotation_inliers_;
   std::vector<int> final_inliers_;
+  Eigen::Matrix<bool, 1, Eigen::Dynamic> scale_inliers_mask_, rotation_inliers_mask_, translation_inliers_mask_;  // :1009-1015
 };
 
 #endif  // QUATRO_H

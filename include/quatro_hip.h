@@ -17,6 +17,9 @@
  *                          solveForTranslation/estimate :585-747)
  *   qtr_max_clique     <- teaser::MaxCliqueSolver::findMaxClique(teaser::Graph)
  *                                                          include/teaser/graph.h:219-274, src/graph.cc:12-104
+ *   qtr_compute_tims / qtr_scale_mask / qtr_gnc_rotation2d / qtr_cote_estimate
+ *                      <- the public stage methods computeTIMs :307-344, solveForScale :355-386,
+ *                         solveForRotation2D :430-572, estimate :618-747 of include/quatro.hpp
  *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
  *                         (voxelize x2, FPFHManager::setFeaturePair include/fpfh_manager.hpp:98-153,
  *                          setInputSource/setInputTarget/computeTransformation)
@@ -158,6 +161,21 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
  * largest core number. */
 int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
                    int* clique, int cap, int* n_out, int* max_core_out, int mem);
+
+/* The reference class keeps its stages individually callable (computeTIMs :307, solveForScale :355,
+ * solveForRotation2D :430, estimate :618); these entry points serve them from the same device code the fused
+ * path uses.  Host buffers only; matrices are ROW-major (3 x N means three rows of N doubles).
+ * Capacity: every call stages through the slot's solver arena — K (TIM columns) and M / N are limited to what
+ * max_corr provides (3 K doubles <= 36 * max_corr doubles per operand); QTR_ERR_CAPACITY otherwise. */
+int qtr_compute_tims(qtr_handle* h, int slot, const double* v3n, int N, double* tims3k /* 3 x N(N-1)/2 */,
+                     int* map2k /* 2 x N(N-1)/2: (i, j) of every column */);
+int qtr_scale_mask(qtr_handle* h, int slot, const double* tims_src3k, const double* tims_dst3k, long long K,
+                   double noise_bound, double cbar2, unsigned char* mask /* K */);
+int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const double* dst2m, int M, double noise_bound,
+                       double gnc_factor, int max_iterations, double cost_threshold, double* R4 /* row-major 2x2 */,
+                       double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
+int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
+                      double* estimate, unsigned char* inliers /* N */, int* n_card);
 
 /* Whole path on one slot: raw scans -> transform. */
 int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,

@@ -390,6 +390,107 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
   return QTR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// individually callable stages (stages.hip).  All staging goes through the slot's solver arena.
+static bool stage_fits(qtr_handle* h, Slot& s, size_t doubles, size_t ints) {
+  if (doubles <= (size_t)72 * s.sb.Lcap && ints <= (size_t)24 * s.sb.Lcap) return true;
+  snprintf(h->err, sizeof(h->err), "stage call needs %zu doubles / %zu ints of scratch; raise max_corr (now %d)",
+           doubles, ints, s.sb.Lcap);
+  return false;
+}
+
+int qtr_compute_tims(qtr_handle* h, int slot, const double* v3n, int N, double* tims3k, int* map2k) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || N < 0 || (N > 1 && (!v3n || !tims3k || !map2k))) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  const long long K = (long long)N * (N - 1) / 2;
+  if (K <= 0) return QTR_OK;
+  if (!stage_fits(h, s, (size_t)3 * N + (size_t)3 * K, (size_t)2 * K)) return QTR_ERR_CAPACITY;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  double* d_v = s.sb.f64;
+  double* d_t = d_v + (size_t)3 * N;
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_v, v3n, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_compute_tims, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s.stream, d_v, N, K, d_t, s.sb.i32);
+  QTR_HIP_TRY(h, hipGetLastError());
+  QTR_HIP_TRY(h, hipMemcpyAsync(tims3k, d_t, sizeof(double) * 3 * (size_t)K, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(map2k, s.sb.i32, sizeof(int) * 2 * (size_t)K, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  return QTR_OK;
+}
+
+int qtr_scale_mask(qtr_handle* h, int slot, const double* a, const double* b, long long K, double noise_bound,
+                   double cbar2, unsigned char* mask) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || K < 0 || (K > 0 && (!a || !b || !mask)) || !(noise_bound > 0)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  if (K == 0) return QTR_OK;
+  if (!stage_fits(h, s, (size_t)6 * K, (size_t)(K + 3) / 4)) return QTR_ERR_CAPACITY;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  double* d_a = s.sb.f64;
+  double* d_b = d_a + (size_t)3 * K;
+  unsigned char* d_m = (unsigned char*)s.sb.i32;
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_a, a, sizeof(double) * 3 * (size_t)K, hipMemcpyHostToDevice, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_b, b, sizeof(double) * 3 * (size_t)K, hipMemcpyHostToDevice, s.stream));
+  const double beta = 2 * noise_bound * sqrt(cbar2);
+  hipLaunchKernelGGL(k_scale_mask, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s.stream, d_a, d_b, K, beta, d_m);
+  QTR_HIP_TRY(h, hipGetLastError());
+  QTR_HIP_TRY(h, hipMemcpyAsync(mask, d_m, (size_t)K, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  return QTR_OK;
+}
+
+int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const double* dst2m, int M, double noise_bound,
+                       double gnc_factor, int max_iterations, double cost_threshold, double* R4, double* cost,
+                       int* iterations, unsigned char* inliers) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || M < 1 || !src2m || !dst2m || !R4 || !(gnc_factor > 1) || max_iterations < 1) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  if (!stage_fits(h, s, (size_t)5 * M + 8, (size_t)(M + 3) / 4)) return QTR_ERR_CAPACITY;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  double* d_s = s.sb.f64;
+  double* d_d = d_s + (size_t)2 * M;
+  double* d_w = d_d + (size_t)2 * M;
+  double* d_o = d_w + (size_t)M;
+  unsigned char* d_i = (unsigned char*)s.sb.i32;
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_s, src2m, sizeof(double) * 2 * (size_t)M, hipMemcpyHostToDevice, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_d, dst2m, sizeof(double) * 2 * (size_t)M, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_gnc_only, dim3(1), dim3(64), 0, s.stream, d_s, d_d, M, noise_bound, gnc_factor, max_iterations,
+                     cost_threshold, d_w, d_o, d_i);
+  QTR_HIP_TRY(h, hipGetLastError());
+  double out[6];
+  QTR_HIP_TRY(h, hipMemcpyAsync(out, d_o, sizeof(out), hipMemcpyDeviceToHost, s.stream));
+  if (inliers) QTR_HIP_TRY(h, hipMemcpyAsync(inliers, d_i, (size_t)M, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  for (int i = 0; i < 4; ++i) R4[i] = out[i];
+  if (cost) *cost = out[4];
+  if (iterations) *iterations = (int)out[5];
+  return QTR_OK;
+}
+
+int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range, int median_selection,
+                      double* estimate, unsigned char* inliers, int* n_card) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || N < 1 || !X || !(range > 0)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  if (!stage_fits(h, s, (size_t)15 * N + 8, (size_t)2 * N + (size_t)(N + 3) / 4)) return QTR_ERR_CAPACITY;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  double* d_x = s.sb.f64;
+  double* d_f = d_x + (size_t)N;
+  double* d_o = d_f + (size_t)14 * N;
+  int* d_si = s.sb.i32;
+  unsigned char* d_i = (unsigned char*)(d_si + (size_t)2 * N);
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_x, X, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_cote_only, dim3(1), dim3(256), 0, s.stream, d_x, N, range, median_selection ? 1 : 0, d_f, d_si, d_o, d_i);
+  QTR_HIP_TRY(h, hipGetLastError());
+  double out[2];
+  QTR_HIP_TRY(h, hipMemcpyAsync(out, d_o, sizeof(out), hipMemcpyDeviceToHost, s.stream));
+  if (inliers) QTR_HIP_TRY(h, hipMemcpyAsync(inliers, d_i, (size_t)N, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  if (estimate) *estimate = out[0];
+  if (n_card) *n_card = (int)out[1];
+  return QTR_OK;
+}
+
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !out) return QTR_ERR_BAD_ARG;
@@ -517,6 +618,10 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   s.last_nt = n_t;
   if (n_s == 0 || n_t == 0) return QTR_OK;
   if (!xyz4_s || !xyz4_t || !desc33_s || !desc33_t || !corr2) return QTR_ERR_BAD_ARG;
+  if (!fp->use_crosscheck) {  // the reference's only call site passes true (include/fpfh_manager.hpp:126-127)
+    snprintf(h->err, sizeof(h->err), "use_crosscheck = 0 is not supported (the one-directional pair list is a 'next' row)");
+    return QTR_ERR_UNSUPPORTED;
+  }
   if (n_s > h->lim.max_voxels || n_t > h->lim.max_voxels) {
     snprintf(h->err, sizeof(h->err), "cloud size exceeds max_voxels=%d", h->lim.max_voxels);
     return QTR_ERR_CAPACITY;

@@ -714,6 +714,85 @@ struct FinalizeArgs {
   int seq;           // sequence number published after them
 };
 
+// GNC-TLS yaw estimation on ONE wavefront (reference solveForRotation2D, include/quatro.hpp:430-572; closed-form
+// 2x2 rotation instead of JacobiSVD, fixed 64-lane summation order — oracle divergence D6).  X = source, Y =
+// destination chain TIMs (xy rows), Wt = weights (in: 1, out: final weights).  __forceinline__: at the LDS call
+// site the pointers derive from the dynamic shared array and every access becomes a ds_* instruction.
+__device__ __forceinline__ void gnc_wave(int lane, const double* X0, const double* X1, const double* Y0, const double* Y1,
+                                         double* Wt, int M, double rot_nb, double gnc_factor, int max_it, double cost_thr,
+                                         double (&Rout)[4], double* cost_out, int* iters_out) {
+  double nb_sq = rot_nb * rot_nb;
+  if (nb_sq < 1e-16) nb_sq = 1e-2;
+  double mu = 1.0, prev_cost = INFINITY, cost = INFINITY;
+  double R0 = 1, R1 = 0, R2 = 0, R3 = 1;
+  int iters = 0;
+  for (int it = 0; it < max_it; ++it) {
+    iters = it + 1;
+    double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    for (int j = lane; j < M; j += 64) {
+      const double wx0 = Wt[j] * X0[j], wx1 = Wt[j] * X1[j];
+      h0 = h0 + wx0 * Y0[j];
+      h1 = h1 + wx0 * Y1[j];
+      h2 = h2 + wx1 * Y0[j];
+      h3 = h3 + wx1 * Y1[j];
+    }
+    h0 = wave_sum64_f64(h0);
+    h1 = wave_sum64_f64(h1);
+    h2 = wave_sum64_f64(h2);
+    h3 = wave_sum64_f64(h3);
+    {
+      const double a = h0 + h3, b = h1 - h2;
+      const double nrm = sqrt(a * a + b * b);
+      double c = 1.0, s = 0.0;
+      if (nrm > 0.0) {
+        c = a / nrm;
+        s = b / nrm;
+      }
+      R0 = c;
+      R1 = -s;
+      R2 = s;
+      R3 = c;
+    }
+    double max_r = -INFINITY;
+    for (int j = lane; j < M; j += 64) {
+      const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
+      const double r2 = e0 * e0 + e1 * e1;
+      max_r = fmax(max_r, r2);
+    }
+    max_r = wave_max_f64(max_r);
+    if (it == 0) {
+      mu = 1 / (2 * max_r / nb_sq - 1);
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
+    double cpart = 0;
+    for (int j = lane; j < M; j += 64) {
+      const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
+      const double r2 = e0 * e0 + e1 * e1;
+      cpart = cpart + Wt[j] * r2;
+      double w;
+      if (r2 >= th1)
+        w = 0;
+      else if (r2 <= th2)
+        w = 1;
+      else
+        w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
+      Wt[j] = w;
+    }
+    cost = wave_sum64_f64(cpart);
+    const double cost_diff = fabs(cost - prev_cost);
+    mu = mu * gnc_factor;
+    prev_cost = cost;
+    if (cost_diff < cost_thr) break;
+  }
+  Rout[0] = R0;
+  Rout[1] = R1;
+  Rout[2] = R2;
+  Rout[3] = R3;
+  *cost_out = cost;
+  *iters_out = iters;
+}
+
 // One COTE axis on one GROUP of four wavefronts (256 threads; reference estimate(), include/quatro.hpp:618-747).
 // Every thread of the workgroup calls it with identical N so that the barriers match; `act` is false for
 // threads that only keep the barriers company.  Steps:
@@ -1090,79 +1169,17 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   const long long t_fin1 = clock64();
   // ---- GNC-TLS (wavefront 0), reference :430-572
   if (wave == 0) {
-    const double rot_nb = A.prm.noise_bound * (2 / 1.0);
-    double nb_sq = rot_nb * rot_nb;
-    if (nb_sq < 1e-16) nb_sq = 1e-2;
-    double mu = 1.0, prev_cost = INFINITY, cost = INFINITY;
-    double R0 = 1, R1 = 0, R2 = 0, R3 = 1;
-    int iters = 0;
-    const int max_it = A.prm.rotation_max_iterations;
-    for (int it = 0; it < max_it; ++it) {
-      iters = it + 1;
-      double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-      for (int j = lane; j < M; j += 64) {
-        const double wx0 = Wt[j] * X0[j], wx1 = Wt[j] * X1[j];
-        h0 = h0 + wx0 * Y0[j];
-        h1 = h1 + wx0 * Y1[j];
-        h2 = h2 + wx1 * Y0[j];
-        h3 = h3 + wx1 * Y1[j];
-      }
-      h0 = wave_sum64_f64(h0);
-      h1 = wave_sum64_f64(h1);
-      h2 = wave_sum64_f64(h2);
-      h3 = wave_sum64_f64(h3);
-      {
-        const double a = h0 + h3, b = h1 - h2;
-        const double nrm = sqrt(a * a + b * b);
-        double c = 1.0, s = 0.0;
-        if (nrm > 0.0) {
-          c = a / nrm;
-          s = b / nrm;
-        }
-        R0 = c;
-        R1 = -s;
-        R2 = s;
-        R3 = c;
-      }
-      double max_r = -INFINITY;
-      for (int j = lane; j < M; j += 64) {
-        const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
-        const double r2 = e0 * e0 + e1 * e1;
-        max_r = fmax(max_r, r2);
-      }
-      max_r = wave_max_f64(max_r);
-      if (it == 0) {
-        mu = 1 / (2 * max_r / nb_sq - 1);
-        if (mu <= 0) break;
-      }
-      const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
-      double cpart = 0;
-      for (int j = lane; j < M; j += 64) {
-        const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
-        const double r2 = e0 * e0 + e1 * e1;
-        cpart = cpart + Wt[j] * r2;
-        double w;
-        if (r2 >= th1)
-          w = 0;
-        else if (r2 <= th2)
-          w = 1;
-        else
-          w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
-        Wt[j] = w;
-      }
-      cost = wave_sum64_f64(cpart);
-      const double cost_diff = fabs(cost - prev_cost);
-      mu = mu * A.prm.rotation_gnc_factor;
-      prev_cost = cost;
-      if (cost_diff < A.prm.rotation_cost_threshold) break;
-    }
+    double Rg[4], costg;
+    int itersg;
+    gnc_wave(lane, X0, X1, Y0, Y1, Wt, M, A.prm.noise_bound * (2 / 1.0), A.prm.rotation_gnc_factor,
+             A.prm.rotation_max_iterations, A.prm.rotation_cost_threshold, Rg, &costg, &itersg);
     if (lane == 0) {
-      s_R[0] = R0;
-      s_R[1] = R1;
-      s_R[2] = R2;
-      s_R[3] = R3;
-      s_cost = cost;
-      s_iters = iters;
+      s_R[0] = Rg[0];
+      s_R[1] = Rg[1];
+      s_R[2] = Rg[2];
+      s_R[3] = Rg[3];
+      s_cost = costg;
+      s_iters = itersg;
     }
   }
   __syncthreads();

@@ -60,7 +60,8 @@ class StageTimes(C.Structure):
 EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
-    "qtr_solve", "qtr_max_clique", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
+    "qtr_cote_estimate", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
@@ -107,6 +108,14 @@ def load():
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
     lib.qtr_max_clique.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    lib.qtr_compute_tims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.qtr_scale_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_double, C.c_double,
+                                   C.c_void_p]
+    lib.qtr_gnc_rotation2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                       C.c_void_p]
+    lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                      C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
     lib.qtr_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = lib
     return lib
@@ -252,6 +261,47 @@ class Handle:
         self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
                                              cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
         return cl[: n.value].copy(), mcore.value
+
+    # ---- the reference class's individually callable stages (row-major matrices) -------------------
+    def compute_tims(self, v3n, slot: int = 0):
+        v = np.ascontiguousarray(v3n, dtype=np.float64)
+        N = v.shape[1]
+        K = N * (N - 1) // 2
+        tims = np.zeros((3, K), dtype=np.float64)
+        mp = np.zeros((2, K), dtype=np.int32)
+        self._check(self._lib.qtr_compute_tims(self._h, slot, v.ctypes.data, N, tims.ctypes.data, mp.ctypes.data))
+        return tims, mp
+
+    def scale_mask(self, tims_src, tims_dst, noise_bound: float, cbar2: float = 1.0, slot: int = 0):
+        a = np.ascontiguousarray(tims_src, dtype=np.float64)
+        b = np.ascontiguousarray(tims_dst, dtype=np.float64)
+        K = a.shape[1]
+        mask = np.zeros(K, dtype=np.uint8)
+        self._check(self._lib.qtr_scale_mask(self._h, slot, a.ctypes.data, b.ctypes.data, K, noise_bound, cbar2,
+                                             mask.ctypes.data))
+        return mask.astype(bool)
+
+    def gnc_rotation2d(self, src2, dst2, noise_bound: float, gnc_factor: float = 1.4, max_iter: int = 50,
+                       cost_thr: float = 1.1e-4, slot: int = 0):
+        """src2/dst2: (M, 2) arrays as the oracle's gnc_rotation2d takes them."""
+        s2 = np.ascontiguousarray(np.asarray(src2, dtype=np.float64).T)
+        d2 = np.ascontiguousarray(np.asarray(dst2, dtype=np.float64).T)
+        M = s2.shape[1]
+        R = np.zeros(4)
+        cost, iters = C.c_double(), C.c_int()
+        inl = np.zeros(M, dtype=np.uint8)
+        self._check(self._lib.qtr_gnc_rotation2d(self._h, slot, s2.ctypes.data, d2.ctypes.data, M, noise_bound,
+                                                 gnc_factor, max_iter, cost_thr, R.ctypes.data, C.byref(cost),
+                                                 C.byref(iters), inl.ctypes.data))
+        return R.reshape(2, 2), cost.value, iters.value, inl.astype(bool)
+
+    def cote_estimate(self, X, rng: float, median: bool = True, slot: int = 0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        inl = np.zeros(X.shape[0], dtype=np.uint8)
+        est, nc = C.c_double(), C.c_int()
+        self._check(self._lib.qtr_cote_estimate(self._h, slot, X.ctypes.data, X.shape[0], rng, 1 if median else 0,
+                                                C.byref(est), inl.ctypes.data, C.byref(nc)))
+        return est.value, inl.astype(bool), nc.value
 
     def register_pair(self, src_raw4, tgt_raw4, fp: FrontendParams | None = None, params: Params | None = None,
                       slot: int = 0):

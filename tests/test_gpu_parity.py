@@ -552,3 +552,98 @@ def test_dense_mode_front_end_at_50k_points(qo):
         assert np.array_equal(nn[qs], ref)
     finally:
         h.close()
+
+
+# ------------------------------------------------------------- individually callable stages (reference :307-747)
+def test_stage_entry_points_match_oracle_and_numpy(hip, qo):
+    """qtr_compute_tims / qtr_scale_mask / qtr_gnc_rotation2d / qtr_cote_estimate — the public stage methods of the
+    reference class served by the same device code as the fused path."""
+    rng = np.random.default_rng(5)
+    # computeTIMs: column order and index map of the reference (segment start i*N - i(i+1)/2)
+    N = 57
+    v = rng.standard_normal((3, N)) * 10
+    tims, mp = hip.compute_tims(v)
+    ii, jj = np.triu_indices(N, 1)
+    assert np.array_equal(mp[0], ii) and np.array_equal(mp[1], jj)
+    assert np.array_equal(tims, v[:, jj] - v[:, ii])
+    # solveForScale mask over TIMs == the consistency graph of the same points
+    src, tgt, _, _ = synth.correspondences(300, 0.2, seed=3, noise=0.05)
+    ts, _ = hip.compute_tims(src[:, :3].T.astype(np.float64))
+    tt, m2 = hip.compute_tims(tgt[:, :3].T.astype(np.float64))
+    mask = hip.scale_mask(ts, tt, 0.3, 1.0)
+    bm = qo.build_graph(src, tgt)
+    bits = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :300].astype(bool)
+    assert np.array_equal(mask, bits[m2[0], m2[1]])
+    # solveForRotation2D
+    for seed in range(4):
+        g = np.random.default_rng(seed)
+        M = [7, 64, 129, 500][seed]
+        th = g.uniform(-3, 3)
+        Rz = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        a = g.standard_normal((M, 2)) * 8
+        b = a @ Rz.T + 0.05 * g.standard_normal((M, 2))
+        out = g.random(M) < 0.4
+        b[out] = g.standard_normal((int(out.sum()), 2)) * 8
+        Ro, co, io, mo = qo.gnc_rotation2d(a, b, 0.6)
+        Rg, cg, ig, mg = hip.gnc_rotation2d(a, b, 0.6)
+        assert np.array_equal(Rg, Ro) and cg == co and ig == io and np.array_equal(mg, mo)
+    # estimate (COTE)
+    for seed, Nn in enumerate([2, 3, 50, 301, 700]):
+        g = np.random.default_rng(100 + seed)
+        X = np.concatenate([1.5 + 0.1 * g.standard_normal(Nn - Nn // 3), g.uniform(-20, 20, Nn // 3)])
+        for median in (True, False):
+            eo, mo, no = qo.cote_estimate(X, 0.3, median)
+            eg, mg, ng = hip.cote_estimate(X, 0.3, median)
+            assert eg == eo and ng == no and np.array_equal(mg, mo), (Nn, median)
+
+
+def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):
+    """tests/cpp/stages_demo.cpp: teaser::FPFHEstimation / teaser::Matcher and the public stage methods of class
+    Quatro from this repository's headers give the oracle's numbers, digit for digit."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    s, t, _ = small_pair
+    vs, vt = qo.voxelize(s, 0.3), qo.voxelize(t, 0.3)
+    synth.save_kitti_bin(str(tmp_path / "src.bin"), vs)
+    synth.save_kitti_bin(str(tmp_path / "tgt.bin"), vt)
+    exe = str(tmp_path / "stages_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "stages_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+        env = dict(os.environ)
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe, str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin"), "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            out = p.stdout
+            break
+    assert out is not None, p.stderr[-500:]
+    lines = out.strip().splitlines()
+    _, _, ds = qo.fpfh(vs, 0.5, 0.75)
+    _, _, dt = qo.fpfh(vt, 0.5, 0.75)
+    corr = qo.match(vs, ds, vt, dt, seed=2)
+    head = dict(zip(lines[0].split()[0::2], lines[0].split()[1::2]))
+    assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (vs.shape[0], vt.shape[0], corr.shape[0])
+    assert lines[1].split()[1:] == [f"{a}:{b}" for a, b in corr[:8]]
+    N = min(200, corr.shape[0])
+    a = vs[corr[:N, 0]]
+    b = vt[corr[:N, 1]]
+    bm = qo.build_graph(a, b)
+    n_pairs = int(np.unpackbits(bm.view(np.uint8), bitorder="little").sum()) // 2
+    l2 = lines[2].split()
+    assert int(l2[1]) == N * (N - 1) // 2 and float(l2[3]) == 1.0 and int(l2[5]) == n_pairs
+    assert (int(l2[7]), int(l2[8])) == (N - 2, N - 1)
+    R, _, _, _ = qo.gnc_rotation2d(a[:, :2].astype(np.float64), b[:, :2].astype(np.float64), 0.3)
+    assert [float(x) for x in lines[3].split()[1:]] == [R[0, 0], R[0, 1], R[1, 0], R[1, 1]]
+    R3 = np.eye(3)
+    R3[:2, :2] = R
+    a64 = a[:, :3].astype(np.float64)
+    ra = np.stack([(R3[r, 0] * a64[:, 0] + R3[r, 1] * a64[:, 1]) + R3[r, 2] * a64[:, 2] for r in range(3)], axis=1)
+    tt = [qo.cote_estimate(b[:, r].astype(np.float64) - ra[:, r], 0.3, True)[0] for r in range(3)]
+    assert [float(x) for x in lines[4].split()[1:]] == tt
