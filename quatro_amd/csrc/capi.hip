@@ -35,6 +35,7 @@ struct qtr_handle {
   qtr_limits lim;
   std::vector<Slot> slots;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
+  int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   char err[512];
 };
 
@@ -127,6 +128,7 @@ static int create_impl(qtr_handle* h) {
       hipEvent_t keep[4] = {s.fb.ev_nn[0], s.fb.ev_nn[1], s.fb.ev_nn[2], s.fb.ev_nn[3]};
       frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
       for (int q = 0; q < 4; ++q) s.fb.ev_nn[q] = keep[q];
+      s.fb.nn_events = h->stage_events;
     }
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_src, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_tgt, (size_t)h->lim.max_points * 16));
@@ -158,6 +160,8 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   {
     const char* hw = getenv("QTR_HOST_WAIT");
     h->spin_wait = (hw && strcmp(hw, "block") == 0) ? 0 : 1;
+    const char* se = getenv("QTR_STAGE_EVENTS");
+    h->stage_events = (se && atoi(se) == 0) ? 0 : 1;
   }
   if (limits)
     h->lim = *limits;
@@ -270,7 +274,8 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
                         qtr_result* res) {
   s.last_L = L;
   s.sb.mail_seq = ++s.seq;
-  QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, s.ev[2], s.ev[3]));
+  QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, h->stage_events ? s.ev[2] : nullptr,
+                                h->stage_events ? s.ev[3] : nullptr));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));  // k_finalize left the record and the state in the mailbox
   if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
@@ -710,7 +715,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   res->n_tgt = nt;
   s.last_ns = ns;
   s.last_nt = nt;
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
     QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain (stream is idle-synced here)
@@ -718,7 +723,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
+  if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L);
   if (rc != QTR_OK) return res->status = rc;
@@ -733,7 +738,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     return res->status = QTR_ERR_CAPACITY;
   }
   QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, s.stream));
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
+  if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
   rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
   s.times_pending = 2;

@@ -749,8 +749,11 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
       hipLaunchKernelGGL(k_nn_exact_rows, dim3(64, ey), dim3(256), 0, st, Q.fpfh, Q.queryT, nq_pad, Bc.baseT, nb, nb_pad, best,
                          F.recheck_rows, F.recheck_thr, F.mcounts + mc_slot);
     };
-    run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, F.ev_nn[0], F.ev_nn[1]);
-    run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, F.ev_nn[2], F.ev_nn[3]);
+    const bool evs = F.nn_events != 0;
+    run_dir(Cj, n_small, pad_small, Ci, n_large, pad_large, F.best_small, MC_RECHECK0, evs ? F.ev_nn[0] : nullptr,
+            evs ? F.ev_nn[1] : nullptr);
+    run_dir(Ci, n_large, pad_large, Cj, n_small, pad_small, F.best_large, MC_RECHECK1, evs ? F.ev_nn[2] : nullptr,
+            evs ? F.ev_nn[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
   hipError_t e;

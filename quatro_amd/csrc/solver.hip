@@ -753,14 +753,14 @@ __device__ __forceinline__ void gnc_wave(int lane, const double* X0, const doubl
       R2 = s;
       R3 = c;
     }
-    double max_r = -INFINITY;
-    for (int j = lane; j < M; j += 64) {
-      const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
-      const double r2 = e0 * e0 + e1 * e1;
-      max_r = fmax(max_r, r2);
-    }
-    max_r = wave_max_f64(max_r);
-    if (it == 0) {
+    if (it == 0) {  // the largest residual only seeds mu (reference :494-500); later iterations do not need it
+      double max_r = -INFINITY;
+      for (int j = lane; j < M; j += 64) {
+        const double e0 = Y0[j] - (R0 * X0[j] + R1 * X1[j]), e1 = Y1[j] - (R2 * X0[j] + R3 * X1[j]);
+        const double r2 = e0 * e0 + e1 * e1;
+        max_r = fmax(max_r, r2);
+      }
+      max_r = wave_max_f64(max_r);
       mu = 1 / (2 * max_r / nb_sq - 1);
       if (mu <= 0) break;
     }

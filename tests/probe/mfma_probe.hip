@@ -34,6 +34,81 @@ __global__ __launch_bounds__(256) void k_probe(float* out, long long* clk, int i
   }
 }
 
+// Does a top-2 epilogue that READS a finished accumulator overlap with MFMAs that write OTHER accumulators?
+// PATTERN 0: 8 accumulators, epilogue on the tuple finished in the previous group while 4 others are being written
+// PATTERN 1: same MFMAs, the epilogue works on plain registers (no accumulator reads)
+template <int PATTERN>
+__global__ __launch_bounds__(256) void k_probe2(float* out, long long* clk, int iters) {
+  f32x16 accA[4], accB[4];
+  for (int a = 0; a < 4; ++a) {
+    accA[a] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    accB[a] = accA[a];
+  }
+  float x = threadIdx.x * 0.001f, y = 1.0f + threadIdx.x * 0.002f;
+  float b1[4] = {1e30f, 1e30f, 1e30f, 1e30f}, b2[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+  float plain[16];
+  for (int q = 0; q < 16; ++q) plain[q] = x + q;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+    // group 1: MFMAs into accA, epilogue on accB
+#pragma unroll
+    for (int kk = 0; kk < 17; ++kk)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accA[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, accA[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float src = PATTERN == 0 ? accB[a][r] : plain[r];
+        const float v = __uint_as_float((__float_as_uint(src) & 0xfffffff0u) | (unsigned)r);
+        b2[a] = __builtin_amdgcn_fmed3f(b1[a], b2[a], v);
+        b1[a] = __builtin_amdgcn_fmed3f(b1[a], v, -INFINITY);
+      }
+    // group 2: MFMAs into accB, epilogue on accA
+#pragma unroll
+    for (int kk = 0; kk < 17; ++kk)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accB[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, accB[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float src = PATTERN == 0 ? accA[a][r] : plain[r];
+        const float v = __uint_as_float((__float_as_uint(src) & 0xfffffff0u) | (unsigned)r);
+        b2[a] = __builtin_amdgcn_fmed3f(b1[a], b2[a], v);
+        b1[a] = __builtin_amdgcn_fmed3f(b1[a], v, -INFINITY);
+      }
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  float s = 0;
+  for (int a = 0; a < 4; ++a) {
+    s += b1[a] + b2[a];
+    for (int r = 0; r < 16; ++r) s += accA[a][r] + accB[a][r];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+}
+template <int PATTERN>
+void run2(const char* name) {
+  float* out;
+  long long* clk;
+  hipMalloc(&out, (size_t)256 * 256 * 4);
+  hipMalloc(&clk, 16);
+  const int iters = 100;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipLaunchKernelGGL(k_probe2<PATTERN>, dim3(256), dim3(256), 0, 0, out, clk, iters);
+    hipDeviceSynchronize();
+  }
+  long long h[2];
+  hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  printf("%-50s clk per 68-MFMA tile %.0f (68 x 64 = 4352)\n", name, (double)h[0] / (2.0 * iters));
+  hipFree(out);
+  hipFree(clk);
+}
+
 template <int NACC, int VPM>
 void run(const char* name, int blocks, int threads) {
   float* out;
@@ -104,6 +179,8 @@ void occ(int blocks) {
 }
 
 int main() {
+  run2<0>("epilogue reads the other accumulator set");
+  run2<1>("epilogue on plain registers");
   occ<100>(512);
   occ<120>(512);
   occ<200>(512);
