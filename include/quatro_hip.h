@@ -20,6 +20,8 @@
  *   qtr_compute_tims / qtr_scale_mask / qtr_gnc_rotation2d / qtr_cote_estimate
  *                      <- the public stage methods computeTIMs :307-344, solveForScale :355-386,
  *                         solveForRotation2D :430-572, estimate :618-747 of include/quatro.hpp
+ *   qtr_segment_cloud  <- ImageProjection::segmentCloud ("Patchwork" mode) + getValidSegments / getOutliers
+ *                                                          include/imageProjection.hpp:244-258,273-581
  *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
  *                         (voxelize x2, FPFHManager::setFeaturePair include/fpfh_manager.hpp:98-153,
  *                          setInputSource/setInputTarget/computeTransformation)
@@ -176,6 +178,28 @@ int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const doubl
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
+
+/* "Next" row (f)1: range-image projection + sub-cluster rejection, the stage before voxelisation in the reference
+ * demo (ImageProjection::segmentCloud in "Patchwork" mode + getValidSegments / getOutliers,
+ * include/imageProjection.hpp:244-258,273-294).  Input: the non-ground points of one scan in sensor order.
+ * valid_xyzl: x,y,z,label of every pixel of a valid segment, row-major over the range image; outl_xyzi: the
+ * rejected sub-clusters (x, y, z, row + col/10000 as in the reference :345).  Capacities in points
+ * (n_scan * horizon_scan always suffices).  labelmat (optional, host only): n_scan x horizon_scan int32,
+ * -1 no return / 999999 rejected / label >= 1. */
+typedef struct qtr_ip_params {
+  int n_scan, horizon_scan;            /* 64, 1800 for "Velodyne-64-HDE" */
+  float ang_res_x, ang_res_y, ang_bottom;
+  int neighbor_mode;                   /* 0 "4Neighbor", 1 "8Neighbor", 2 "4CrossNeighbor" */
+  int num_min_pts;                     /* numMinPtsForSubclustering, 30 */
+  float segment_theta;                 /* 60 deg in rad */
+  int valid_point_num, valid_line_num; /* 5, 3 */
+} qtr_ip_params;
+/* lidar_type: "Velodyne-64-HDE", "VLP-16", "HDL-32E", "Ouster-OS1-16", "Ouster-OS1-64"; neighbor_mode: as above.
+ * Returns QTR_ERR_BAD_ARG for names the reference's constructor rejects (:131, :140). */
+int qtr_ip_default_params(const char* lidar_type, const char* neighbor_mode, qtr_ip_params* p);
+int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
+                      int cap_valid, int* n_valid, float* outl_xyzi, int cap_outl, int* n_outl, int* n_segments,
+                      int* labelmat, int mem);
 
 /* Whole path on one slot: raw scans -> transform. */
 int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,

@@ -222,6 +222,44 @@ def cote_estimate(X, rng, median=True):
     return e, inl.astype(bool), nc.value
 
 
+class IpParams(C.Structure):
+    _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("ang_res_x", C.c_float), ("ang_res_y", C.c_float),
+                ("ang_bottom", C.c_float), ("neighbor_mode", C.c_int), ("num_min_pts", C.c_int),
+                ("segment_theta", C.c_float), ("valid_point_num", C.c_int), ("valid_line_num", C.c_int)]
+
+
+def ip_params(lidar="Velodyne-64-HDE", neighbor_mode="4CrossNeighbor", num_min_pts=30):
+    """The reference's ImageProjection constructor table (include/imageProjection.hpp:85-133)."""
+    f32 = np.float32
+    table = {  # n_scan, horizon_scan, ang_res_x, ang_res_y, ang_bottom
+        "Velodyne-64-HDE": (64, 1800, f32(360.0) / f32(1800), f32(26.9) / f32(63), f32(25.0)),
+        "VLP-16": (16, 1800, f32(0.2), f32(2.0), f32(15.0 + 0.1)),
+        "HDL-32E": (32, 1800, f32(360.0) / f32(1800), f32(41.33) / f32(31), f32(30.67)),
+        "Ouster-OS1-16": (16, 1024, f32(360.0) / f32(1024), f32(33.2) / f32(15), f32(16.6 + 0.1)),
+        "Ouster-OS1-64": (64, 1024, f32(360.0) / f32(1024), f32(33.2) / f32(63), f32(16.6 + 0.1)),
+    }
+    ns, hs, rx, ry, ab = table[lidar]
+    mode = {"4Neighbor": 0, "8Neighbor": 1, "4CrossNeighbor": 2}[neighbor_mode]
+    return IpParams(ns, hs, float(rx), float(ry), float(ab), mode, num_min_pts,
+                    float(f32(60.0 / 180.0 * np.pi)), 5, 3)
+
+
+def segment_cloud(xyz4, ipp: IpParams | None = None):
+    """ImageProjection::segmentCloud ("Patchwork" mode) -> valid segments (x,y,z,label), outliers, label / range images."""
+    xyz4 = _f4(xyz4)
+    ipp = ipp or ip_params()
+    NP = ipp.n_scan * ipp.horizon_scan
+    out = np.zeros((NP, 4), dtype=np.float32)
+    outl = np.zeros((NP, 4), dtype=np.float32)
+    lab = np.zeros(NP, dtype=np.int32)
+    rng = np.zeros(NP, dtype=np.float32)
+    nv, no = C.c_int(), C.c_int()
+    lib().qo_segment_cloud(_p(xyz4, C.c_float), xyz4.shape[0], C.byref(ipp), _p(out, C.c_float), C.byref(nv),
+                           _p(outl, C.c_float), C.byref(no), _p(lab, C.c_int), _p(rng, C.c_float))
+    return dict(valid=out[:nv.value].copy(), outliers=outl[:no.value].copy(),
+                labels=lab.reshape(ipp.n_scan, ipp.horizon_scan), ranges=rng.reshape(ipp.n_scan, ipp.horizon_scan))
+
+
 def solve(src4, tgt4, params: Params | None = None):
     src4, tgt4 = _f4(src4), _f4(tgt4)
     L = src4.shape[0]

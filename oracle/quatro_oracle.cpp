@@ -30,6 +30,7 @@
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -924,6 +925,158 @@ double cote_estimate(const std::vector<double>& X, double range, bool median_sel
 
 // ================================================================================================
 // C API (ctypes-friendly)
+// =================================================================================================
+// "Next" row (f)1 of SURVEY.md section 8: range-image projection + sub-cluster rejection
+// (reference include/imageProjection.hpp: projectPointCloud :308-352, maskGround :354-364 in "Patchwork" mode,
+// cloudSegmentation :424-483, labelComponents :485-581; LeGO-LOAM lineage).  Restated as: last-writer-wins
+// projection, connected components of the symmetric angle criterion (what the BFS computes), the BFS's validity
+// rule (size >= num_min_pts, or size >= 5 and >= 3 rows holding a pixel other than the seed), labels numbered in
+// row-major order of the components' first pixels.  Declared divergences: atan2f / sin / cos come from qtr_math.h
+// (D7); the float -> size_t conversions of negative values (undefined behaviour in the reference) are defined as
+// truncation toward zero followed by the range check, which is what x86-64 does.
+struct IpParams {
+  int n_scan, horizon_scan;
+  float ang_res_x, ang_res_y, ang_bottom;
+  int neighbor_mode;  // 0: 4-neighbour, 1: 8-neighbour, 2: 4-cross-neighbour
+  int num_min_pts;    // numMinPtsForSubclustering (30)
+  float segment_theta;  // 60 deg in rad
+  int valid_point_num, valid_line_num;  // 5, 3
+};
+
+static bool ip_pixel_of(const IpParams& ip, float x, float y, float z, int* row, int* col, float* range) {
+  const float va = (float)((double)(qm_atan2f(z, sqrtf(x * x + y * y)) * 180) / M_PI);
+  const float rf = (va + ip.ang_bottom) / ip.ang_res_y;
+  const long long r = (long long)rf;  // size_t conversion in the reference; negative values wrap and fail the test
+  if (r < 0 || r >= ip.n_scan) return false;
+  const float ha = (float)((double)(qm_atan2f(x, y) * 180) / M_PI);
+  const double cd = -round(((double)ha - 90.0) / (double)ip.ang_res_x) + (double)(ip.horizon_scan / 2);
+  long long c = (long long)cd;
+  if (c < 0) return false;
+  if (c >= ip.horizon_scan) c -= ip.horizon_scan;
+  if (c < 0 || c >= ip.horizon_scan) return false;
+  const float rg = sqrtf(x * x + y * y + z * z);
+  if (rg < 0.1) return false;
+  *row = (int)r;
+  *col = (int)c;
+  *range = rg;
+  return true;
+}
+
+static void ip_alpha_trig(const IpParams& ip, float* sx, float* cx, float* sy, float* cy) {
+  const float ax = (float)((double)ip.ang_res_x / 180.0 * M_PI), ay = (float)((double)ip.ang_res_y / 180.0 * M_PI);
+  qm_sincosf(ax, sx, cx);
+  qm_sincosf(ay, sy, cy);
+}
+
+static inline bool ip_edge(float ra, float rb, float sn, float cs, float theta) {
+  const float d1 = ra > rb ? ra : rb, d2 = ra > rb ? rb : ra;
+  const float angle = qm_atan2f(d2 * sn, (d1 - d2 * cs));
+  return angle > theta;
+}
+
+static int ip_neighbors(int mode, int (*off)[2]) {
+  static const int n4[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
+  static const int n8[8][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}, {-1, -1}, {-1, 1}, {1, 1}, {1, -1}};
+  static const int nx[4][2] = {{-1, -1}, {-1, 1}, {1, 1}, {1, -1}};
+  const int cnt = mode == 1 ? 8 : 4;
+  for (int i = 0; i < cnt; ++i) {
+    const int* q = mode == 0 ? n4[i] : mode == 1 ? n8[i] : nx[i];
+    off[i][0] = q[0];
+    off[i][1] = q[1];
+  }
+  return cnt;
+}
+
+// labelmat: 0 never (every pixel ends up -1, 999999 or a label >= 1); out4: x,y,z,label; outl4: x,y,z,row+col/1e4
+static void segment_cloud(const float* xyz4, int P, const IpParams& ip, float* out4, int* n_valid, float* outl4,
+                          int* n_outl, int* labelmat, float* rangemat) {
+  const int H = ip.horizon_scan, NS = ip.n_scan, NP = NS * H;
+  std::vector<int> owner((size_t)NP, -1);
+  std::vector<float> range((size_t)NP, FLT_MAX);
+  for (int i = 0; i < P; ++i) {
+    int r, c;
+    float rg;
+    if (!ip_pixel_of(ip, xyz4[4 * i], xyz4[4 * i + 1], xyz4[4 * i + 2], &r, &c, &rg)) continue;
+    owner[(size_t)r * H + c] = i;  // later points overwrite earlier ones
+    range[(size_t)r * H + c] = rg;
+  }
+  float sx, cx, sy, cy;
+  ip_alpha_trig(ip, &sx, &cx, &sy, &cy);
+  int off[8][2];
+  const int nn = ip_neighbors(ip.neighbor_mode, off);
+  std::vector<int> label((size_t)NP, 0);
+  for (int p = 0; p < NP; ++p)
+    if (owner[p] < 0) label[p] = -1;
+  int label_count = 1;
+  std::vector<int> queue((size_t)NP), pushed((size_t)NP);
+  std::vector<char> line((size_t)NS);
+  for (int r0 = 0; r0 < NS; ++r0)
+    for (int c0 = 0; c0 < H; ++c0) {
+      if (label[(size_t)r0 * H + c0] != 0) continue;
+      // breadth-first labelling exactly as labelComponents does it
+      std::fill(line.begin(), line.end(), 0);
+      int qs = 0, qe = 1, np = 1;
+      queue[0] = r0 * H + c0;
+      pushed[0] = queue[0];
+      while (qs < qe) {
+        const int from = queue[qs++];
+        const int fr = from / H, fc = from % H;
+        label[from] = label_count;
+        for (int q = 0; q < nn; ++q) {
+          const int tr = fr + off[q][0];
+          int tc = fc + off[q][1];
+          if (tr < 0 || tr >= NS) continue;
+          if (tc < 0) tc = H - 1;
+          if (tc >= H) tc = 0;
+          const int to = tr * H + tc;
+          if (label[to] != 0) continue;
+          const bool horiz = off[q][0] == 0;
+          if (ip_edge(range[from], range[to], horiz ? sx : sy, horiz ? cx : cy, ip.segment_theta)) {
+            queue[qe++] = to;
+            label[to] = label_count;
+            line[tr] = 1;
+            pushed[np++] = to;
+          }
+        }
+      }
+      bool feasible = false;
+      if (np >= ip.num_min_pts)
+        feasible = true;
+      else if (np >= ip.valid_point_num) {
+        int lc = 0;
+        for (int r = 0; r < NS; ++r) lc += line[r];
+        if (lc >= ip.valid_line_num) feasible = true;
+      }
+      if (feasible)
+        ++label_count;
+      else
+        for (int i = 0; i < np; ++i) label[pushed[i]] = 999999;
+    }
+  int nv = 0, no = 0;
+  for (int p = 0; p < NP; ++p) {
+    if (label[p] > 0 && label[p] != 999999) {
+      const float* q = xyz4 + 4 * (size_t)owner[p];
+      out4[4 * nv] = q[0];
+      out4[4 * nv + 1] = q[1];
+      out4[4 * nv + 2] = q[2];
+      out4[4 * nv + 3] = (float)label[p];
+      ++nv;
+    } else if (label[p] == 999999) {
+      const float* q = xyz4 + 4 * (size_t)owner[p];
+      outl4[4 * no] = q[0];
+      outl4[4 * no + 1] = q[1];
+      outl4[4 * no + 2] = q[2];
+      outl4[4 * no + 3] = (float)(p / H) + (float)(p % H) / 10000.0f;
+      ++no;
+    }
+  }
+  *n_valid = nv;
+  *n_outl = no;
+  if (labelmat) std::copy(label.begin(), label.end(), labelmat);
+  if (rangemat) std::copy(range.begin(), range.end(), rangemat);
+}
+
+
 extern "C" {
 
 struct qo_params {
@@ -978,6 +1131,32 @@ int qo_get_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+struct qo_ip_params {
+  int n_scan, horizon_scan;
+  float ang_res_x, ang_res_y, ang_bottom;
+  int neighbor_mode, num_min_pts;
+  float segment_theta;
+  int valid_point_num, valid_line_num;
+};
+// ImageProjection::segmentCloud in "Patchwork" mode + getValidSegments / getOutliers (capacity of the outputs:
+// n_scan * horizon_scan points each)
+int qo_segment_cloud(const float* xyz4, int P, const qo_ip_params* ipp, float* out4, int* n_valid, float* outl4,
+                     int* n_outl, int* labelmat, float* rangemat) {
+  IpParams ip;
+  ip.n_scan = ipp->n_scan;
+  ip.horizon_scan = ipp->horizon_scan;
+  ip.ang_res_x = ipp->ang_res_x;
+  ip.ang_res_y = ipp->ang_res_y;
+  ip.ang_bottom = ipp->ang_bottom;
+  ip.neighbor_mode = ipp->neighbor_mode;
+  ip.num_min_pts = ipp->num_min_pts;
+  ip.segment_theta = ipp->segment_theta;
+  ip.valid_point_num = ipp->valid_point_num;
+  ip.valid_line_num = ipp->valid_line_num;
+  segment_cloud(xyz4, P, ip, out4, n_valid, outl4, n_outl, labelmat, rangemat);
+  return 0;
 }
 
 int qo_voxelize(const float* xyz4, int P, float leaf, float* out4, int cap) { return voxelize(xyz4, P, leaf, out4, cap); }

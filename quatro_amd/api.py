@@ -92,6 +92,44 @@ def voxelize(src, voxelSize: float, handle=None) -> np.ndarray:
     return (handle or _handle()).voxelize(_as_cloud(src), float(voxelSize))
 
 
+class ImageProjection:
+    """Reference include/imageProjection.hpp:31-581 (range-image projection + sub-cluster rejection, "Patchwork"
+    ground mode): segmentCloud then getValidSegments / getOutliers."""
+
+    def __init__(self, lidarType: str = "Velodyne-64-HDE", neighborSelectionMode: str = "4CrossNeighbor",
+                 groundSegmentationMode: str = "Patchwork", numSubclusteringCriteria: int = 30, handle=None):
+        try:
+            self.params = _ql.ip_params(lidarType, neighborSelectionMode, numSubclusteringCriteria)
+        except ValueError:
+            try:
+                _ql.ip_params(lidarType, "4Neighbor")
+            except ValueError:
+                raise ValueError("[ImageProjection]:Check your paramter. Lidar Type is wrong!") from None
+            raise ValueError("[ImageProjection]:Check your paramter. Neighbor selection mode is wrong!") from None
+        if groundSegmentationMode not in ("LeGO-LOAM", "Patchwork"):
+            raise ValueError("[ImageProjection]: Check your paramter. Ground Segmentation mode is wrong!")
+        if groundSegmentationMode == "LeGO-LOAM":
+            raise ValueError("[ImageProjection]: the LeGO-LOAM ground removal is not part of the device path")
+        self._h = handle
+        self._r = None
+
+    def segmentCloud(self, cloud):
+        self._r = (self._h or _handle()).segment_cloud(_as_cloud(cloud), self.params)
+
+    def getValidSegments(self) -> np.ndarray:
+        """(n, 4) float32: x, y, z, segment label (pcl::PointXYZI view; drop the last column for PointXYZ)."""
+        return self._r["valid"]
+
+    def getOutliers(self) -> np.ndarray:
+        return self._r["outliers"]
+
+    def getGround(self) -> np.ndarray:
+        return np.zeros((0, 4), dtype=np.float32)
+
+    def getLabelMat(self) -> np.ndarray:
+        return self._r["labels"]
+
+
 class FPFHManager:
     """Reference include/fpfh_manager.hpp:25-238 (front-end orchestrator)."""
 

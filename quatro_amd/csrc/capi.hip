@@ -21,6 +21,8 @@ struct Slot {
   float4* m_tgt = nullptr;
   int* pinned_i32 = nullptr;     // >= 64 ints
   qtr_result* pinned_res = nullptr;
+  SegBufs seg;                   // range-image segmentation arena (allocated on first use)
+  void* seg_arena = nullptr;
   int* mail = nullptr;           // pinned host mailbox the phase-ending kernels write into (frontend.h MAIL_*)
   int seq = 0;                   // last sequence number handed to a phase-ending kernel
   int times_pending = 0;         // 1: qtr_solve, 2: qtr_register_pair — stage times are read off the events lazily
@@ -104,6 +106,7 @@ void qtr_destroy(qtr_handle* h) {
     if (s.pinned_i32) (void)hipHostFree(s.pinned_i32);
     if (s.pinned_res) (void)hipHostFree(s.pinned_res);
     if (s.mail) (void)hipHostFree(s.mail);
+    if (s.seg_arena) (void)hipFree(s.seg_arena);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.stream2) (void)hipStreamDestroy(s.stream2);
   }
@@ -493,6 +496,116 @@ int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double ra
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   if (estimate) *estimate = out[0];
   if (n_card) *n_card = (int)out[1];
+  return QTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// range-image projection + sub-cluster rejection (segment.hip)
+int qtr_ip_default_params(const char* lidar, const char* nbr, qtr_ip_params* p) {
+  if (!lidar || !nbr || !p) return QTR_ERR_BAD_ARG;
+  struct Row {
+    const char* name;
+    int ns, hs;
+    float rx, ry, ab;
+  };
+  const Row rows[] = {  // reference include/imageProjection.hpp:85-131
+      {"Velodyne-64-HDE", 64, 1800, 360.0f / 1800.0f, 26.9f / 63.0f, 25.0f},
+      {"VLP-16", 16, 1800, 0.2f, 2.0f, (float)(15.0 + 0.1)},
+      {"HDL-32E", 32, 1800, 360.0f / 1800.0f, 41.33f / 31.0f, 30.67f},
+      {"Ouster-OS1-16", 16, 1024, 360.0f / 1024.0f, 33.2f / 15.0f, (float)(16.6 + 0.1)},
+      {"Ouster-OS1-64", 64, 1024, 360.0f / 1024.0f, 33.2f / 63.0f, (float)(16.6 + 0.1)},
+  };
+  const Row* r = nullptr;
+  for (const Row& q : rows)
+    if (strcmp(q.name, lidar) == 0) r = &q;
+  int mode = -1;
+  if (strcmp(nbr, "4Neighbor") == 0) mode = 0;
+  if (strcmp(nbr, "8Neighbor") == 0) mode = 1;
+  if (strcmp(nbr, "4CrossNeighbor") == 0) mode = 2;
+  if (!r || mode < 0) return QTR_ERR_BAD_ARG;
+  p->n_scan = r->ns;
+  p->horizon_scan = r->hs;
+  p->ang_res_x = r->rx;
+  p->ang_res_y = r->ry;
+  p->ang_bottom = r->ab;
+  p->neighbor_mode = mode;
+  p->num_min_pts = 30;
+  p->segment_theta = (float)(60.0 / 180.0 * M_PI);
+  p->valid_point_num = 5;
+  p->valid_line_num = 3;
+  return QTR_OK;
+}
+
+int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
+                      int cap_valid, int* n_valid, float* outl_xyzi, int cap_outl, int* n_outl, int* n_segments,
+                      int* labelmat, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !ip || !n_valid || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_valid = 0;
+  if (n_outl) *n_outl = 0;
+  if (n_segments) *n_segments = 0;
+  if (ip->n_scan < 1 || ip->n_scan > 64 || ip->horizon_scan < 4 || ip->horizon_scan > 8192 || !(ip->ang_res_x > 0) ||
+      !(ip->ang_res_y > 0) || ip->neighbor_mode < 0 || ip->neighbor_mode > 2) {
+    snprintf(h->err, sizeof(h->err), "[ImageProjection]:Check your paramter. (n_scan <= 64, horizon_scan <= 8192)");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (P > h->lim.max_points) {
+    snprintf(h->err, sizeof(h->err), "P=%d exceeds max_points=%d", P, h->lim.max_points);
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const int NP = ip->n_scan * ip->horizon_scan;
+  if (!s.seg_arena || s.seg.np_cap < NP) {
+    if (s.seg_arena) QTR_HIP_TRY(h, hipFree(s.seg_arena));
+    s.seg_arena = nullptr;
+    QTR_HIP_TRY(h, hipMalloc(&s.seg_arena, segment_scratch_bytes(NP)));
+    segment_carve(s.seg, s.seg_arena, NP);
+  }
+  const float4* d_in = (const float4*)xyz4;
+  if (mem == QTR_MEM_HOST && P > 0) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, xyz4, (size_t)P * 16, hipMemcpyHostToDevice, s.stream));
+    d_in = s.in_src;
+  }
+  IpDev d;
+  d.n_scan = ip->n_scan;
+  d.horizon_scan = ip->horizon_scan;
+  d.ang_res_x = ip->ang_res_x;
+  d.ang_res_y = ip->ang_res_y;
+  d.ang_bottom = ip->ang_bottom;
+  d.neighbor_mode = ip->neighbor_mode;
+  d.num_min_pts = ip->num_min_pts;
+  d.segment_theta = ip->segment_theta;
+  d.valid_point_num = ip->valid_point_num;
+  d.valid_line_num = ip->valid_line_num;
+  {  // segmentAlphaX / Y = ang_res / 180 * pi stored in float (:132-133); their sin / cos through qtr_math.h
+    const float ax = (float)((double)ip->ang_res_x / 180.0 * M_PI), ay = (float)((double)ip->ang_res_y / 180.0 * M_PI);
+    qm_sincosf(ax, &d.sx, &d.cx);
+    qm_sincosf(ay, &d.sy, &d.cy);
+  }
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  int* d_tot = s.seg.blk + 3 * ((NP + 1023) / 1024 + 1);
+  QTR_HIP_TRY(h, segment_enqueue(s.seg, d_in, P, d, d_tot, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, d_tot, 3 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  const int nv = s.pinned_i32[0], no = s.pinned_i32[1], nseg = s.pinned_i32[2];
+  *n_valid = nv;
+  if (n_outl) *n_outl = no;
+  if (n_segments) *n_segments = nseg;
+  if ((valid_xyzl && nv > cap_valid) || (outl_xyzi && no > cap_outl)) {
+    snprintf(h->err, sizeof(h->err), "output capacity too small (%d valid, %d outliers)", nv, no);
+    return QTR_ERR_CAPACITY;
+  }
+  const hipMemcpyKind kout = mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (valid_xyzl && nv > 0) QTR_HIP_TRY(h, hipMemcpyAsync(valid_xyzl, s.seg.out_valid, (size_t)nv * 16, kout, s.stream));
+  if (outl_xyzi && no > 0) QTR_HIP_TRY(h, hipMemcpyAsync(outl_xyzi, s.seg.out_outl, (size_t)no * 16, kout, s.stream));
+  if (labelmat) QTR_HIP_TRY(h, hipMemcpyAsync(labelmat, s.seg.labelmat, (size_t)NP * 4, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  float ms = 0;
+  s.times_pending = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.total = ms;
   return QTR_OK;
 }
 

@@ -3,4 +3,5 @@
 #include "stages.hip"
 #include "frontend.hip"
 #include "match.hip"
+#include "segment.hip"
 #include "capi.hip"

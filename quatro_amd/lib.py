@@ -57,14 +57,29 @@ class StageTimes(C.Structure):
                                           "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
 
 
+class IpParams(C.Structure):
+    _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("ang_res_x", C.c_float), ("ang_res_y", C.c_float),
+                ("ang_bottom", C.c_float), ("neighbor_mode", C.c_int), ("num_min_pts", C.c_int),
+                ("segment_theta", C.c_float), ("valid_point_num", C.c_int), ("valid_line_num", C.c_int)]
+
+
 EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
+
+
+def ip_params(lidar: str = "Velodyne-64-HDE", neighbor_mode: str = "4CrossNeighbor", num_min_pts: int = 30) -> IpParams:
+    p = IpParams()
+    rc = load().qtr_ip_default_params(lidar.encode(), neighbor_mode.encode(), C.byref(p))
+    if rc != QTR_OK:
+        raise ValueError("[ImageProjection]:Check your paramter. Lidar Type / neighbor selection mode is wrong!")
+    p.num_min_pts = num_min_pts
+    return p
 
 
 class QuatroHipError(RuntimeError):
@@ -116,6 +131,10 @@ def load():
                                        C.c_void_p]
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+    lib.qtr_ip_default_params.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IpParams)]
+    lib.qtr_segment_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(IpParams), C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.c_void_p, C.c_int]
     lib.qtr_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = lib
     return lib
@@ -261,6 +280,21 @@ class Handle:
         self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
                                              cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
         return cl[: n.value].copy(), mcore.value
+
+    # ---- range-image projection + sub-cluster rejection (ImageProjection::segmentCloud, "Patchwork" mode)
+    def segment_cloud(self, xyz4, ipp: "IpParams | None" = None, slot: int = 0, want_labels: bool = True):
+        xyz4 = _f4(xyz4)
+        ipp = ipp or ip_params()
+        NP = ipp.n_scan * ipp.horizon_scan
+        out = np.zeros((NP, 4), dtype=np.float32)
+        outl = np.zeros((NP, 4), dtype=np.float32)
+        lab = np.zeros(NP, dtype=np.int32) if want_labels else None
+        nv, no, nseg = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.qtr_segment_cloud(self._h, slot, xyz4.ctypes.data, xyz4.shape[0], C.byref(ipp),
+                                                out.ctypes.data, NP, C.byref(nv), outl.ctypes.data, NP, C.byref(no),
+                                                C.byref(nseg), lab.ctypes.data if want_labels else None, MEM_HOST))
+        return dict(valid=out[:nv.value].copy(), outliers=outl[:no.value].copy(), n_segments=nseg.value,
+                    labels=lab.reshape(ipp.n_scan, ipp.horizon_scan) if want_labels else None)
 
     # ---- the reference class's individually callable stages (row-major matrices) -------------------
     def compute_tims(self, v3n, slot: int = 0):

@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "fpfh_manager.hpp"
+#include "imageProjection.hpp"
 #include "quatro.hpp"
 
 static std::shared_ptr<pcl::PointCloud<PointType>> getCloud(const char* path) {  // reference :377-402
@@ -39,6 +40,24 @@ int main(int argc, char** argv) {
   params.inlier_selection_mode = QuatroT::INLIER_SELECTION_MODE::PMC_HEU;
   quatro.reset(params);
 
+  // optional 4th argument "segment": the demo's STEP 3 (reference :124-160) — range-image sub-cluster rejection
+  // before voxelisation (the inputs then play the role of the non-ground clouds)
+  if (argc > 4 && std::string(argv[4]) == "segment") {
+    ImageProjection IPSrc("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork"), IPTgt("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork");
+    IPSrc.segmentCloud(srcRaw);
+    IPTgt.segmentCloud(tgtRaw);
+    auto srcValid = std::make_shared<pcl::PointCloud<PointType>>();
+    auto tgtValid = std::make_shared<pcl::PointCloud<PointType>>();
+    IPSrc.getValidSegments(*srcValid);
+    IPTgt.getValidSegments(*tgtValid);
+    pcl::PointCloud<PointType> so, to;
+    IPSrc.getOutliers(so);
+    IPTgt.getOutliers(to);
+    std::printf("segments %d %d valid %zu %zu outliers %zu %zu\n", IPSrc.numSegments(), IPTgt.numSegments(), srcValid->size(),
+                tgtValid->size(), so.size(), to.size());
+    srcRaw = srcValid;
+    tgtRaw = tgtValid;
+  }
   auto srcFeat = std::make_shared<pcl::PointCloud<PointType>>();
   auto tgtFeat = std::make_shared<pcl::PointCloud<PointType>>();
   voxelize(srcRaw, srcFeat, 0.3);

@@ -647,3 +647,86 @@ def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):
     ra = np.stack([(R3[r, 0] * a64[:, 0] + R3[r, 1] * a64[:, 1]) + R3[r, 2] * a64[:, 2] for r in range(3)], axis=1)
     tt = [qo.cote_estimate(b[:, r].astype(np.float64) - ra[:, r], 0.3, True)[0] for r in range(3)]
     assert [float(x) for x in lines[4].split()[1:]] == tt
+
+
+# ------------------------------------------------------------- (f)1 range image + sub-cluster rejection
+@pytest.mark.parametrize("lidar,mode,minpts", [("Velodyne-64-HDE", "4CrossNeighbor", 30), ("Velodyne-64-HDE", "4Neighbor", 30),
+                                               ("Velodyne-64-HDE", "8Neighbor", 10), ("Ouster-OS1-64", "4CrossNeighbor", 30),
+                                               ("VLP-16", "4Neighbor", 30), ("HDL-32E", "8Neighbor", 30)])
+def test_segment_cloud_matches_oracle(hip, qo, lidar, mode, minpts):
+    """qtr_segment_cloud (ImageProjection::segmentCloud, "Patchwork" mode): label image, valid segments and
+    rejected sub-clusters bit-identical to the oracle's breadth-first restatement."""
+    for pid in (0, 3):
+        s, t, _ = synth.kitti64_pair(pid)
+        for cloud in (s, t):
+            o = qo.segment_cloud(cloud, qo.ip_params(lidar, mode, minpts))
+            g = hip.segment_cloud(cloud, ql.ip_params(lidar, mode, minpts))
+            assert np.array_equal(g["labels"], o["labels"])
+            assert np.array_equal(_b(g["valid"]), _b(o["valid"]))
+            assert np.array_equal(_b(g["outliers"]), _b(o["outliers"]))
+            assert g["n_segments"] == (o["labels"][(o["labels"] > 0) & (o["labels"] < 999999)].max(initial=0))
+
+
+def test_segment_cloud_edge_cases_and_pipeline(hip, qo):
+    ipp = ql.ip_params()
+    r = hip.segment_cloud(np.zeros((0, 4), dtype=np.float32), ipp)
+    assert r["valid"].shape[0] == 0 and r["outliers"].shape[0] == 0 and (r["labels"] == -1).all()
+    pts = np.array([[10, 0, 0, 0], [0.01, 0.01, 0, 0], [1, 0, 5, 0]], dtype=np.float32)
+    r = hip.segment_cloud(pts, ipp)
+    assert r["valid"].shape[0] == 0 and r["outliers"].shape[0] == 1 and (r["labels"] == 999999).sum() == 1
+    # many returns in one pixel: the last one in scan order owns it
+    dup = np.tile(np.array([[20, 1, 0.5, 0]], dtype=np.float32), (500, 1))
+    dup[:, 0] += np.linspace(0, 1e-3, 500, dtype=np.float32)
+    o = qo.segment_cloud(dup)
+    g = hip.segment_cloud(dup)
+    assert np.array_equal(g["labels"], o["labels"]) and np.array_equal(_b(g["outliers"]), _b(o["outliers"]))
+    with pytest.raises(ValueError):
+        ql.ip_params("no-such-lidar")
+    # the reference demo's order: segment -> voxelize -> ... -> transform, against the oracle doing the same
+    s, t, _ = synth.kitti64_pair(2)
+    vs, vt = hip.segment_cloud(s)["valid"], hip.segment_cloud(t)["valid"]
+    os_, ot = qo.segment_cloud(s)["valid"], qo.segment_cloud(t)["valid"]
+    _assert_same_solution(hip.register_pair(vs, vt, ql.default_frontend_params(seed=2)), qo.register_pair(os_, ot, seed=2))
+
+
+def test_cpp_dropin_demo_with_image_projection(hip, qo, tmp_path):
+    """The demo's STEP 3 + STEP 4 order (ImageProjection::segmentCloud -> voxelize -> FPFHManager -> Quatro) through
+    include/imageProjection.hpp, against the oracle running the same order."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    s, t, _ = synth.kitti64_pair(1)
+    synth.save_kitti_bin(str(tmp_path / "src.bin"), s)
+    synth.save_kitti_bin(str(tmp_path / "tgt.bin"), t)
+    exe = str(tmp_path / "dropin_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+        env = dict(os.environ)
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe, str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin"), "5", "segment"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            out = p.stdout
+            break
+    assert out is not None, p.stderr[-500:]
+    so, to = qo.segment_cloud(s), qo.segment_cloud(t)
+    lines = out.strip().splitlines()
+    w = lines[0].split()
+    nseg = lambda r: int(r["labels"][(r["labels"] > 0) & (r["labels"] < 999999)].max(initial=0))
+    assert [int(x) for x in (w[1], w[2], w[4], w[5], w[7], w[8])] == [nseg(so), nseg(to), so["valid"].shape[0],
+                                                                   to["valid"].shape[0], so["outliers"].shape[0],
+                                                                   to["outliers"].shape[0]]
+    vs, vt = so["valid"].copy(), to["valid"].copy()
+    vs[:, 3] = 0
+    vt[:, 3] = 0
+    o = qo.register_pair(vs, vt, seed=5)
+    head = dict(zip(lines[1].split()[0::2], lines[1].split()[1::2]))
+    assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (o["n_src"], o["n_tgt"], o["L"])
+    T = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[2:6]])
+    assert np.array_equal(T, o["T"])

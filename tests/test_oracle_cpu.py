@@ -342,3 +342,104 @@ def test_register_pair_end_to_end(qo, small_pair):
     yaw_gt = np.arctan2(Tgt[1, 0], Tgt[0, 0])
     assert abs(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt))) < 0.02
     assert np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) < 0.3
+
+
+# ------------------------------------------------------------------- (f)1 range image + sub-cluster rejection
+def test_segment_cloud_against_independent_numpy_restatement(qo):
+    """ImageProjection::segmentCloud restated twice: the oracle's breadth-first labelling vs projection + scipy
+    connected components + the validity rule in numpy (float64 trigonometry, so pixels / edges that sit within
+    1e-4 of a decision boundary are excluded from the comparison)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from quatro_amd import synth
+    s, _, _ = synth.kitti64_pair(1)
+    checked = 0
+    for lidar, mode in (("Velodyne-64-HDE", "4CrossNeighbor"), ("Velodyne-64-HDE", "4Neighbor"),
+                        ("Ouster-OS1-64", "8Neighbor")):
+        ipp = qo.ip_params(lidar, mode)
+        r = qo.segment_cloud(s, ipp)
+        NS, H = ipp.n_scan, ipp.horizon_scan
+        x, y, z = (s[:, k].astype(np.float64) for k in range(3))
+        va = np.degrees(np.arctan2(z, np.hypot(x, y)))
+        rowf = (va + ipp.ang_bottom) / ipp.ang_res_y
+        ha = np.degrees(np.arctan2(x, y))
+        colr = (ha - 90.0) / ipp.ang_res_x
+        col = (-np.round(colr) + H // 2).astype(np.int64)
+        col = np.where(col >= H, col - H, col)
+        rng_ = np.sqrt(x * x + y * y + z * z)
+        row = np.trunc(rowf).astype(np.int64)
+        ok = (rowf > -1) & (row < NS) & (col >= 0) & (col < H) & (rng_ >= 0.1)
+        sure = (np.abs(rowf - np.round(rowf)) > 1e-3) & (np.abs(colr - np.floor(colr) - 0.5) > 1e-3)
+        owner = np.full(NS * H, -1, dtype=np.int64)
+        for i in np.nonzero(ok)[0]:  # last writer wins
+            owner[row[i] * H + col[i]] = i
+        lab = r["labels"].reshape(-1)
+        if sure.all():
+            assert np.array_equal(owner >= 0, lab != -1)
+            assert np.allclose(r["ranges"].reshape(-1)[owner >= 0], rng_[owner[owner >= 0]], rtol=1e-6)
+        # edges
+        R = np.where(owner >= 0, rng_[np.maximum(owner, 0)], np.inf).reshape(NS, H)
+        ax, ay = np.radians(np.float32(ipp.ang_res_x)), np.radians(np.float32(ipp.ang_res_y))
+        offs = {0: [(0, 1), (1, 0)], 1: [(0, 1), (1, 0), (1, 1), (1, -1)], 2: [(1, 1), (1, -1)]}[ipp.neighbor_mode]
+        ii, jj, uu, vv = [], [], [], []
+        for dr, dc in offs:
+            A = R[:NS - dr] if dr else R
+            B = np.roll(R, -dc, axis=1)[dr:] if dr else np.roll(R, -dc, axis=1)
+            d1, d2 = np.maximum(A, B), np.minimum(A, B)
+            al = ax if dr == 0 else ay
+            with np.errstate(invalid="ignore"):
+                ang = np.arctan2(d2 * np.sin(al), d1 - d2 * np.cos(al))
+            valid = np.isfinite(A) & np.isfinite(B)
+            near = valid & (np.abs(ang - ipp.segment_theta) < 3e-6)  # float32 vs float64: undecided here
+            e = valid & (ang > ipp.segment_theta) & ~near
+            for mask, (li, lj) in ((e, (ii, jj)), (near, (uu, vv))):
+                rr, cc = np.nonzero(mask)
+                li.append(rr * H + cc)
+                lj.append((rr + dr) * H + (cc + dc) % H)
+        ii, jj, uu, vv = (np.concatenate(q) for q in (ii, jj, uu, vv))
+        assert sure.all()
+
+        def comps(a, b):
+            return connected_components(coo_matrix((np.ones(a.size), (a, b)), shape=(NS * H, NS * H)), directed=False)[1]
+        comp = comps(ii, jj)
+        comp_hi = comps(np.concatenate([ii, uu]), np.concatenate([jj, vv]))
+        occ = owner >= 0
+        # components untouched by an undecided edge are the ones both restatements must agree on exactly
+        touched = np.zeros(NS * H, dtype=bool)
+        touched[np.isin(comp_hi, comp_hi[np.concatenate([uu, vv])])] = True if uu.size else False
+        stable = occ & ~touched
+        assert stable.sum() > 0.5 * occ.sum(), (stable.sum(), occ.sum(), uu.size)
+        first = {}
+        for p in np.nonzero(stable)[0]:
+            first.setdefault(comp[p], p)
+        sizes = np.bincount(comp[occ], minlength=comp.max() + 1)
+        prev_label = 0
+        for cid, p0 in sorted(first.items(), key=lambda kv: kv[1]):
+            members = np.nonzero(occ & (comp == cid))[0]
+            assert len(set(lab[members].tolist())) == 1  # one oracle label per component
+            rows_pushed = {int(p) // H for p in members if p != p0}
+            good = sizes[cid] >= ipp.num_min_pts or (sizes[cid] >= 5 and len(rows_pushed) >= 3)
+            if good:
+                assert 0 < lab[p0] < 999999 and lab[p0] > prev_label  # numbered in row-major order of first pixels
+                assert (lab == lab[p0]).sum() == members.size       # ... and nobody else carries that label
+                prev_label = lab[p0]
+            else:
+                assert lab[p0] == 999999
+        valid_mask = occ & (lab != 999999)
+        assert r["valid"].shape[0] == int(valid_mask.sum()) and r["outliers"].shape[0] == int((lab == 999999).sum())
+        assert np.array_equal(r["valid"][:, 3].astype(np.int64), lab[valid_mask])
+        assert np.array_equal(r["valid"][:, :3], s[owner[valid_mask], :3])
+        checked += 1
+    assert checked == 3
+
+
+def test_segment_cloud_edge_cases(qo):
+    ipp = qo.ip_params()
+    r = qo.segment_cloud(np.zeros((0, 4), dtype=np.float32), ipp)
+    assert r["valid"].shape[0] == 0 and r["outliers"].shape[0] == 0 and (r["labels"] == -1).all()
+    # one isolated return -> a rejected sub-cluster; points closer than 0.1 m or outside the vertical FOV are dropped
+    pts = np.array([[10, 0, 0, 0], [0.01, 0.01, 0, 0], [1, 0, 5, 0]], dtype=np.float32)
+    r = qo.segment_cloud(pts, ipp)
+    assert r["valid"].shape[0] == 0 and r["outliers"].shape[0] == 1 and (r["labels"] == 999999).sum() == 1
+    with pytest.raises(KeyError):
+        qo.ip_params("no-such-lidar")
