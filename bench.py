@@ -151,6 +151,37 @@ def main() -> None:
                  "ms_per_step": 1e3 * tm / args.steps}
         hm.close()
 
+    # ---- next-row leg: range-image projection + sub-cluster rejection of the same scans
+    # (device-resident input, host copy of the two small outputs included); never part of `value`
+    seg = None
+    if world == 1 and args.workload == "kitti64_pair":
+        ipp = ql.ip_params()
+        NP = ipp.n_scan * ipp.horizon_scan
+        ov = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
+        oo = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
+        nv, no, nsg = C.c_int(), C.c_int(), C.c_int()
+
+        def seg_once(t):
+            rc = h._lib.qtr_segment_cloud(h._h, 0, t.data_ptr(), t.shape[0], C.byref(ipp), ov.data_ptr(), NP, C.byref(nv),
+                                          oo.data_ptr(), NP, C.byref(no), C.byref(nsg), None, ql.MEM_DEVICE)
+            if rc != ql.QTR_OK:
+                raise ql.QuatroHipError(rc, h.last_error())
+        for _ in range(3):
+            seg_once(pool[0]["src"])
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        nscan, gpu_ms = 0, 0.0
+        for k in range(max(args.steps, 10)):
+            p = pool[k % len(pool)]
+            for t in (p["src"], p["tgt"]):
+                seg_once(t)
+                gpu_ms += h.stage_times()["total"]
+                nscan += 1
+        torch.cuda.synchronize()
+        seg = {"what": "ImageProjection::segmentCloud (Velodyne-64-HDE, 4CrossNeighbor) on the bench scans",
+               "scans_per_s": nscan / (time.perf_counter() - ts0), "gpu_ms_per_scan": gpu_ms / nscan,
+               "points_in": int(pool[0]["src"].shape[0]), "valid_out": int(nv.value), "segments": int(nsg.value)}
+
     # ---- result records of the pool, gathered on rank 0 (the path's only collective)
     recs = []
     for p in pool:
@@ -188,6 +219,8 @@ def main() -> None:
     }
     if multi is not None:
         out["pairs_in_flight_leg"] = multi
+    if seg is not None:
+        out["segment_cloud_leg"] = seg
     if args.workload == "kitti64_pair":
         ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
         out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]
@@ -260,6 +293,13 @@ def main() -> None:
             "counts_equal": bool(args.workload != "kitti64_pair" or
                                  (r0["n_src"], r0["n_tgt"], r0["L"]) == (o["n_src"], o["n_tgt"], o["L"]))}
         out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
+        if seg is not None:  # the same scans through the oracle's breadth-first restatement, one thread (it is serial)
+            t1 = time.perf_counter()
+            so = qo.segment_cloud(p0["src_h"])
+            cpu_s = time.perf_counter() - t1
+            gs = h.segment_cloud(p0["src_h"])
+            out["segment_cloud_leg"]["cpu_port_scans_per_s"] = 1.0 / cpu_s
+            out["segment_cloud_leg"]["labels_bit_exact"] = bool(np.array_equal(gs["labels"], so["labels"]))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libquatro_hip.so")
-SOURCES = ["unity.hip", "solver.hip", "frontend.hip", "match.hip", "capi.hip", "common.h", "solver.h", "frontend.h",
-           os.path.join("..", "..", "include", "qtr_math.h"), os.path.join("..", "..", "include", "quatro_hip.h")]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [
+    os.path.join("..", "..", "include", "qtr_math.h"), os.path.join("..", "..", "include", "quatro_hip.h")]
 
 
 def is_stale() -> bool:

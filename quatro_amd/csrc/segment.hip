@@ -7,7 +7,7 @@
 //   K2 init         pixel range from its owner point; parent[p] = p
 //   K3 merge        union-find over the symmetric angle criterion (each undirected edge once, roots = smallest
 //                   pixel index = the BFS's seed: the first pixel of the component in row-major order)
-//   K4 flatten      root per pixel, component sizes, row masks of the non-seed pixels
+//   K4 flatten      root per pixel, component sizes, row masks of the non-seed pixels (atomics aggregated per wave)
 //   K5 classify     the BFS's validity rule -> valid / outlier / valid-root flags + per-block counts
 //   K6 blockscan    exclusive scan of the (<= 282) block counts
 //   K7 rootrank     label of every valid component = 1 + number of valid roots before it (row-major)
@@ -93,11 +93,23 @@ __device__ __forceinline__ int uf_find(const int* parent, int x) {
   }
   return x;
 }
+// find with path halving (used while the forest is still being built; the extra stores are benign races: every
+// value written is an ancestor of the node it is written to)
+__device__ __forceinline__ int uf_find_halve(int* parent, int x) {
+  int p = parent[x];
+  while (p != x) {
+    const int g = parent[p];
+    if (g != p) parent[x] = g;
+    x = p;
+    p = g;
+  }
+  return x;
+}
 // hook the larger root under the smaller one (roots end up being the smallest pixel index of their component)
 __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   while (true) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
+    a = uf_find_halve(parent, a);
+    b = uf_find_halve(parent, b);
     if (a == b) return;
     if (a > b) {
       const int t = a;
@@ -142,21 +154,45 @@ __global__ __launch_bounds__(256) void k_ip_merge(IpDev ip, const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void k_ip_flatten(int NP, int H, int* __restrict__ parent, int* __restrict__ cnt,
-                                                    u64* __restrict__ rowmask) {
+__global__ __launch_bounds__(256) void k_ip_flatten(int NP, int H, const int* __restrict__ parent, int* __restrict__ cnt,
+                                                    u64* __restrict__ rowmask, int* __restrict__ rootof) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= NP || parent[p] < 0) return;
+  if (p >= NP) return;
+  if (parent[p] < 0) {
+    rootof[p] = -1;
+    return;
+  }
   const int root = uf_find(parent, p);
+  rootof[p] = root;
   atomicAdd(&cnt[root], 1);
   if (p != root) atomicOr(&rowmask[root], 1ULL << (p / H));  // lineCountFlag is only set for PUSHED pixels (:533)
 }
-// second pass (parents are read-only now): every pixel points straight at its root
-__global__ __launch_bounds__(256) void k_ip_compress(int NP, int* __restrict__ parent, int* __restrict__ rootof) {
+// the same, with the atomics aggregated per wavefront: neighbouring pixels mostly share a root, and one global word
+// only takes ~90 updates per microsecond on this part
+__global__ __launch_bounds__(256) void k_ip_flatten_agg(int NP, int H, const int* __restrict__ parent, int* __restrict__ cnt,
+                                                        u64* __restrict__ rowmask, int* __restrict__ rootof) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= NP) return;
-  rootof[p] = parent[p] < 0 ? -1 : uf_find(parent, p);
+  const bool valid = p < NP && parent[p] >= 0;
+  const int root = valid ? uf_find(parent, p) : -1;
+  if (p < NP) rootof[p] = root;
+  const int lane = threadIdx.x & 63;
+  const int row = p / H;
+  const int row_a = __builtin_amdgcn_readfirstlane(row);  // 64 consecutive pixels span at most two rows (H >= 64)
+  u64 todo = __ballot(valid);
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    const int r0 = __builtin_amdgcn_readlane(root, l);
+    const u64 same = __ballot(valid && root == r0);
+    const u64 push_a = __ballot(valid && root == r0 && p != r0 && row == row_a);
+    const u64 push_b = __ballot(valid && root == r0 && p != r0 && row != row_a);
+    if (lane == l) {
+      atomicAdd(&cnt[r0], __popcll(same));
+      const u64 m = (push_a ? 1ULL << row_a : 0ULL) | (push_b ? 1ULL << (row_a + 1) : 0ULL);
+      if (m) atomicOr(&rowmask[r0], m);
+    }
+    todo &= ~same;
+  }
 }
-
 // 1024 pixels per workgroup; cls + the three per-block counts
 __global__ __launch_bounds__(1024) void k_ip_classify(IpDev ip, const int* __restrict__ rootof, const int* __restrict__ cnt,
                                                       const u64* __restrict__ rowmask, int* __restrict__ cls,
@@ -300,9 +336,11 @@ hipError_t segment_enqueue(const SegBufs& S, const float4* pts, int P, const IpD
   hipLaunchKernelGGL(k_ip_init, dim3((NP + 255) / 256), dim3(256), 0, st, pts, NP, S.owner, S.range, S.parent, S.cnt,
                      S.rowmask);
   hipLaunchKernelGGL(k_ip_merge, dim3((NP + 255) / 256), dim3(256), 0, st, ip, S.range, S.parent);
-  hipLaunchKernelGGL(k_ip_flatten, dim3((NP + 255) / 256), dim3(256), 0, st, NP, H, S.parent, S.cnt, S.rowmask);
   int* rootof = S.labelmat;
-  hipLaunchKernelGGL(k_ip_compress, dim3((NP + 255) / 256), dim3(256), 0, st, NP, S.parent, rootof);
+  if (H >= 64)
+    hipLaunchKernelGGL(k_ip_flatten_agg, dim3((NP + 255) / 256), dim3(256), 0, st, NP, H, S.parent, S.cnt, S.rowmask, rootof);
+  else
+    hipLaunchKernelGGL(k_ip_flatten, dim3((NP + 255) / 256), dim3(256), 0, st, NP, H, S.parent, S.cnt, S.rowmask, rootof);
   hipLaunchKernelGGL(k_ip_classify, dim3(nblk), dim3(1024), 0, st, ip, rootof, S.cnt, S.rowmask, S.cls, S.blk, nblk);
   hipLaunchKernelGGL(k_ip_blockscan, dim3(1), dim3(1024), 0, st, S.blk, nblk, totals);
   hipLaunchKernelGGL(k_ip_rootrank, dim3(nblk), dim3(1024), 0, st, NP, S.cls, S.blk, nblk, S.rootrank);
