@@ -77,6 +77,15 @@ QM_HD float qm_atan2f(float yf, float xf) {
   return (float)qm_copysign(a, y);
 }
 
+// atan2 in binary64 for finite, not-both-zero arguments (Patchwork's xy2theta); same core as qm_atan2f
+QM_HD double qm_atan2d(double y, double x) {
+  if (y == 0.0) return signbit(x) ? qm_copysign(QM_PI, y) : qm_copysign(0.0, y);
+  if (x == 0.0) return qm_copysign(QM_PI_2, y);
+  double a = qm_atan_pos(fabs(y) / fabs(x));
+  if (x < 0) a = QM_PI - a;
+  return qm_copysign(a, y);
+}
+
 // acosf on [-1,1]; NaN outside (as libm). acos(x) = 2*atan(sqrt((1-x)/(1+x))).
 QM_HD float qm_acosf(float xf) {
   const double x = (double)xf;
@@ -141,6 +150,12 @@ QM_HD uint32_t qm_rand_u32(uint64_t seed, uint64_t counter) {
 // qm_sum64_fold performs the fold on a 64-entry array (host oracle); the kernels do the same fold
 // with __shfl_down across one wavefront.
 QM_HD double qm_sum64_fold(double* p /*[64], clobbered*/) {
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int l = 0; l < off; ++l) p[l] = p[l] + p[l + off];
+  return p[0];
+}
+// the same fold for binary32 partials (Patchwork's per-patch moment sums)
+QM_HD float qm_sum64_fold_f(float* p /*[64], clobbered*/) {
   for (int off = 32; off >= 1; off >>= 1)
     for (int l = 0; l < off; ++l) p[l] = p[l] + p[l + off];
   return p[0];

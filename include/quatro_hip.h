@@ -20,6 +20,7 @@
  *   qtr_compute_tims / qtr_scale_mask / qtr_gnc_rotation2d / qtr_cote_estimate
  *                      <- the public stage methods computeTIMs :307-344, solveForScale :355-386,
  *                         solveForRotation2D :430-572, estimate :618-747 of include/quatro.hpp
+ *   qtr_patchwork      <- PatchWork::estimate_ground    include/patchwork.hpp:329-476
  *   qtr_segment_cloud  <- ImageProjection::segmentCloud ("Patchwork" mode) + getValidSegments / getOutliers
  *                                                          include/imageProjection.hpp:244-258,273-581
  *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
@@ -178,6 +179,26 @@ int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const doubl
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
+
+/* "Next" row (f)2: Patchwork ground segmentation, the first stage of the reference demo on raw scans
+ * (PatchWork::estimate_ground, include/patchwork.hpp:329-476; parameters config/patchwork_params.yaml).
+ * ground_xyzw / nonground_xyzw: the input records (16 bytes each, 4th float preserved) in the reference's output
+ * order (zone, ring, sector; ascending height inside a patch); capacities in points (P always suffices). */
+typedef struct qtr_pw_params {
+  double sensor_height;                     /* 1.723 */
+  int num_iter, num_lpr, num_min_pts;       /* 3, 20, 80 */
+  double th_seeds, th_dist, max_range, min_range, uprightness_thr, adaptive_seed_selection_margin;
+  int using_global_thr;
+  double global_elevation_thr;
+  int num_zones;                            /* <= 4 */
+  int num_sectors_each_zone[4], num_rings_each_zone[4];
+  double min_ranges[4];
+  int num_thr;                              /* size of the two threshold vectors (<= 8) */
+  double elevation_thr[8], flatness_thr[8];
+} qtr_pw_params;
+void qtr_pw_default_params(qtr_pw_params* p); /* config/patchwork_params.yaml */
+int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
+                  int cap_ground, int* n_ground, float* nonground_xyzw, int cap_nonground, int* n_nonground, int mem);
 
 /* "Next" row (f)1: range-image projection + sub-cluster rejection, the stage before voxelisation in the reference
  * demo (ImageProjection::segmentCloud in "Patchwork" mode + getValidSegments / getOutliers,

@@ -222,6 +222,48 @@ def cote_estimate(X, rng, median=True):
     return e, inl.astype(bool), nc.value
 
 
+class PwParams(C.Structure):
+    _fields_ = [("sensor_height", C.c_double), ("num_iter", C.c_int), ("num_lpr", C.c_int), ("num_min_pts", C.c_int),
+                ("th_seeds", C.c_double), ("th_dist", C.c_double), ("max_range", C.c_double), ("min_range", C.c_double),
+                ("uprightness_thr", C.c_double), ("adaptive_seed_selection_margin", C.c_double),
+                ("using_global_thr", C.c_int), ("global_elevation_thr", C.c_double), ("num_zones", C.c_int),
+                ("num_sectors_each_zone", C.c_int * 4), ("num_rings_each_zone", C.c_int * 4),
+                ("min_ranges", C.c_double * 4), ("num_thr", C.c_int), ("elevation_thr", C.c_double * 8),
+                ("flatness_thr", C.c_double * 8)]
+
+
+def pw_params():
+    """config/patchwork_params.yaml of the reference (the values its demo runs with)."""
+    p = PwParams()
+    p.sensor_height = 1.723
+    p.num_iter, p.num_lpr, p.num_min_pts = 3, 20, 80
+    p.th_seeds, p.th_dist, p.max_range, p.min_range = 0.25, 0.125, 80.0, 2.7
+    p.uprightness_thr, p.adaptive_seed_selection_margin = 0.707, -1.1
+    p.using_global_thr, p.global_elevation_thr = 0, -0.5
+    p.num_zones = 4
+    p.num_sectors_each_zone[:] = [16, 32, 54, 32]
+    p.num_rings_each_zone[:] = [2, 4, 4, 4]
+    p.min_ranges[:] = [2.7, 12.3625, 22.025, 41.35]
+    p.num_thr = 4
+    p.elevation_thr[:4] = [-1.2, -0.9984, -0.851, -0.605]
+    p.flatness_thr[:4] = [0.0001, 0.000125, 0.000185, 0.000185]
+    return p
+
+
+def patchwork(xyz4, pp: PwParams | None = None):
+    """PatchWork::estimate_ground -> ground, nonground (reference output order), patch id per input point."""
+    xyz4 = _f4(xyz4)
+    pp = pp or pw_params()
+    P = xyz4.shape[0]
+    g = np.zeros((max(P, 1), 4), dtype=np.float32)
+    n = np.zeros((max(P, 1), 4), dtype=np.float32)
+    pid = np.zeros(max(P, 1), dtype=np.int32)
+    ng, nn = C.c_int(), C.c_int()
+    lib().qo_patchwork(_p(xyz4, C.c_float), P, C.byref(pp), _p(g, C.c_float), C.byref(ng), _p(n, C.c_float),
+                       C.byref(nn), _p(pid, C.c_int))
+    return dict(ground=g[:ng.value].copy(), nonground=n[:nn.value].copy(), patch=pid[:P].copy())
+
+
 class IpParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("ang_res_x", C.c_float), ("ang_res_y", C.c_float),
                 ("ang_bottom", C.c_float), ("neighbor_mode", C.c_int), ("num_min_pts", C.c_int),

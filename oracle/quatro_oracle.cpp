@@ -926,6 +926,208 @@ double cote_estimate(const std::vector<double>& X, double range, bool median_sel
 // ================================================================================================
 // C API (ctypes-friendly)
 // =================================================================================================
+// "Next" row (f)2 of SURVEY.md section 8: Patchwork ground segmentation (reference include/patchwork.hpp:
+// estimate_ground :329-476, pc2czm :512-546, extract_initial_seeds_ :285-318, estimate_plane_ :271-283,
+// extract_piecewiseground :549-586; parameters config/patchwork_params.yaml).  Restated with these declared
+// choices where the reference leaves the result to its libraries:
+//   * the z sort is stable (std::sort in the reference: order of equal heights unspecified),
+//   * the per-patch moment sums (pcl::computeMeanAndCovarianceMatrix, float) are evaluated in the fixed sum64
+//     order of qtr_math.h instead of sequentially,
+//   * the plane normal is the smallest eigenvector from the closed-form pcl::eigen33 restatement used for the
+//     normals (instead of Eigen::JacobiSVD), oriented so that n_z >= 0 (the SVD's sign is an artefact; for
+//     ground-like patches it points up), and the singular values are the |eigenvalues| of the same solve,
+//   * atan2 / sqrt of the polar binning in binary64 through qm_atan2d.
+struct PwParams {
+  double sensor_height;
+  int num_iter, num_lpr, num_min_pts;
+  double th_seeds, th_dist, max_range, min_range, uprightness_thr, adaptive_seed_selection_margin;
+  int using_global_thr;
+  double global_elevation_thr;
+  int num_zones;
+  int num_sectors_each_zone[4], num_rings_each_zone[4];
+  double min_ranges[4];
+  int num_thr;  // num_rings_of_interest = size of the two threshold vectors
+  double elevation_thr[8], flatness_thr[8];
+};
+
+struct PwPlane {
+  float normal[3];
+  float mean[3];
+  float sv[3];      // descending |eigenvalues|
+  float th_dist_d;
+};
+
+
+static void pw_estimate_plane(const float* xyz4, const int* ids, int n, const std::vector<char>& in_ground,
+                              double th_dist, PwPlane& pl) {
+  // nine moment sums over the ground set, sum64 order: the point at patch position t goes to partial[t & 63]
+  float part[9][64];
+  for (int a = 0; a < 9; ++a)
+    for (int l = 0; l < 64; ++l) part[a][l] = 0.f;
+  int cnt = 0;
+  for (int t = 0; t < n; ++t) {
+    if (!in_ground[(size_t)t]) continue;
+    const float* q = xyz4 + 4 * (size_t)ids[t];
+    const int l = t & 63;
+    part[0][l] += q[0] * q[0];
+    part[1][l] += q[0] * q[1];
+    part[2][l] += q[0] * q[2];
+    part[3][l] += q[1] * q[1];
+    part[4][l] += q[1] * q[2];
+    part[5][l] += q[2] * q[2];
+    part[6][l] += q[0];
+    part[7][l] += q[1];
+    part[8][l] += q[2];
+    ++cnt;
+  }
+  float acc[9];
+  for (int a = 0; a < 9; ++a) acc[a] = qm_sum64_fold_f(part[a]);
+  const float kk = (float)cnt;
+  for (int a = 0; a < 9; ++a) acc[a] /= kk;
+  float cov[9];
+  cov[0] = acc[0] - acc[6] * acc[6];
+  cov[1] = acc[1] - acc[6] * acc[7];
+  cov[2] = acc[2] - acc[6] * acc[8];
+  cov[4] = acc[3] - acc[7] * acc[7];
+  cov[5] = acc[4] - acc[7] * acc[8];
+  cov[8] = acc[5] - acc[8] * acc[8];
+  cov[3] = cov[1];
+  cov[6] = cov[2];
+  cov[7] = cov[5];
+  float ev, vec[3];
+  eigen33_smallest(cov, &ev, vec);
+  // all three eigenvalues of the scaled matrix, as eigen33_smallest computes them
+  float scale = 0.f;
+  for (int i = 0; i < 9; ++i) scale = std::max(scale, fabsf(cov[i]));
+  if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+  float sm[9], roots[3];
+  for (int i = 0; i < 9; ++i) sm[i] = cov[i] / scale;
+  compute_roots(sm, roots);
+  float a0 = fabsf(roots[0] * scale), a1 = fabsf(roots[1] * scale), a2 = fabsf(roots[2] * scale);
+  if (a0 < a1) std::swap(a0, a1);
+  if (a1 < a2) std::swap(a1, a2);
+  if (a0 < a1) std::swap(a0, a1);
+  pl.sv[0] = a0;
+  pl.sv[1] = a1;
+  pl.sv[2] = a2;
+  const bool flip = vec[2] < 0.f || (vec[2] == 0.f && (vec[1] < 0.f || (vec[1] == 0.f && vec[0] < 0.f)));
+  for (int i = 0; i < 3; ++i) pl.normal[i] = flip ? -vec[i] : vec[i];
+  pl.mean[0] = acc[6];
+  pl.mean[1] = acc[7];
+  pl.mean[2] = acc[8];
+  const float d = -((pl.normal[0] * pl.mean[0] + pl.normal[1] * pl.mean[1]) + pl.normal[2] * pl.mean[2]);
+  pl.th_dist_d = (float)(th_dist - (double)d);
+}
+
+// ground4 / nonground4: x,y,z,w of the input points in the reference's output order; returns counts
+static void patchwork(const float* xyz4, int P, const PwParams& pw, float* ground4, int* n_ground, float* nonground4,
+                      int* n_nonground, int* patch_of /* optional [P]: patch id or -1 */) {
+  std::vector<int> order((size_t)P);
+  for (int i = 0; i < P; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return xyz4[4 * (size_t)a + 2] < xyz4[4 * (size_t)b + 2]; });
+  int base[5] = {0, 0, 0, 0, 0};
+  for (int k = 0; k < pw.num_zones; ++k) base[k + 1] = base[k] + pw.num_rings_each_zone[k] * pw.num_sectors_each_zone[k];
+  const int npatch = base[pw.num_zones];
+  double ring_size[4], sector_size[4];
+  for (int k = 0; k < pw.num_zones; ++k) {
+    const double hi = (k + 1 < pw.num_zones) ? pw.min_ranges[k + 1] : pw.max_range;
+    ring_size[k] = (hi - pw.min_ranges[k]) / pw.num_rings_each_zone[k];
+    sector_size[k] = 2 * M_PI / pw.num_sectors_each_zone[k];
+  }
+  std::vector<std::vector<int>> patch((size_t)npatch);
+  if (patch_of) std::fill(patch_of, patch_of + P, -1);
+  for (int t = 0; t < P; ++t) {
+    const int i = order[t];
+    const float* q = xyz4 + 4 * (size_t)i;
+    if ((double)q[2] < -1.8 * pw.sensor_height) continue;  // mirror reflections under the ground (:351-361)
+    const double x = q[0], y = q[1];
+    const double r = sqrt(x * x + y * y);
+    if (!((r <= pw.max_range) && (r > pw.min_range))) continue;
+    const double at = qm_atan2d(y, x);
+    const double theta = at > 0 ? at : at + 2 * M_PI;
+    int k = pw.num_zones - 1;
+    for (int z = 1; z < pw.num_zones; ++z)
+      if (r < pw.min_ranges[z]) {
+        k = z - 1;
+        break;
+      }
+    const int ring = std::min((int)((r - pw.min_ranges[k]) / ring_size[k]), pw.num_rings_each_zone[k] - 1);
+    const int sector = std::min((int)(theta / sector_size[k]), pw.num_sectors_each_zone[k] - 1);
+    const int pid = base[k] + ring * pw.num_sectors_each_zone[k] + sector;
+    patch[(size_t)pid].push_back(i);
+    if (patch_of) patch_of[i] = pid;
+  }
+  int ng = 0, nn = 0;
+  auto emit = [&](float* dst, int& cnt, int id) {
+    const float* q = xyz4 + 4 * (size_t)id;
+    dst[4 * (size_t)cnt] = q[0];
+    dst[4 * (size_t)cnt + 1] = q[1];
+    dst[4 * (size_t)cnt + 2] = q[2];
+    dst[4 * (size_t)cnt + 3] = q[3];
+    ++cnt;
+  };
+  const double margin = (pw.sensor_height == 0.0) ? -0.1 : pw.adaptive_seed_selection_margin * pw.sensor_height;
+  int concentric_idx = 0;
+  for (int k = 0; k < pw.num_zones; ++k)
+    for (int ring = 0; ring < pw.num_rings_each_zone[k]; ++ring) {
+      for (int sector = 0; sector < pw.num_sectors_each_zone[k]; ++sector) {
+        const std::vector<int>& ids = patch[(size_t)(base[k] + ring * pw.num_sectors_each_zone[k] + sector)];
+        const int n = (int)ids.size();
+        if (!(n > pw.num_min_pts)) continue;
+        // seeds (:285-318)
+        int init_idx = 0;
+        if (k == 0)
+          while (init_idx < n && (double)xyz4[4 * (size_t)ids[init_idx] + 2] < margin) ++init_idx;
+        double sum = 0;
+        int cnt = 0;
+        for (int t = init_idx; t < n && cnt < pw.num_lpr; ++t) {
+          sum += (double)xyz4[4 * (size_t)ids[t] + 2];
+          ++cnt;
+        }
+        const double lpr_height = cnt != 0 ? sum / cnt : 0;
+        std::vector<char> in_ground((size_t)n, 0), is_ground((size_t)n, 0);
+        for (int t = 0; t < n; ++t) in_ground[t] = ((double)xyz4[4 * (size_t)ids[t] + 2] < lpr_height + pw.th_seeds) ? 1 : 0;
+        PwPlane pl;
+        for (int it = 0; it < pw.num_iter; ++it) {
+          pw_estimate_plane(xyz4, ids.data(), n, in_ground, pw.th_dist, pl);
+          for (int t = 0; t < n; ++t) {
+            const float* q = xyz4 + 4 * (size_t)ids[t];
+            const float res = (q[0] * pl.normal[0] + q[1] * pl.normal[1]) + q[2] * pl.normal[2];
+            const char g = res < pl.th_dist_d ? 1 : 0;
+            if (it < pw.num_iter - 1)
+              in_ground[t] = g;
+            else
+              is_ground[t] = g;
+          }
+        }
+        const double ground_z_vec = fabs((double)pl.normal[2]);
+        const double ground_z_elevation = pl.mean[2];
+        const double surface_variable = (double)pl.sv[2] / (double)((pl.sv[0] + pl.sv[1]) + pl.sv[2]);
+        bool reject_all = false;
+        if (ground_z_vec < pw.uprightness_thr)
+          reject_all = true;
+        else if (concentric_idx < pw.num_thr) {
+          const int ti = ring + 2 * k;  // the reference's index (sic), :395
+          if (ground_z_elevation > pw.elevation_thr[ti] && !(pw.flatness_thr[ti] > surface_variable)) reject_all = true;
+        } else if (pw.using_global_thr && ground_z_elevation > pw.global_elevation_thr)
+          reject_all = true;
+        for (int t = 0; t < n; ++t)
+          if (is_ground[t]) {
+            if (reject_all)
+              emit(nonground4, nn, ids[t]);
+            else
+              emit(ground4, ng, ids[t]);
+          }
+        for (int t = 0; t < n; ++t)
+          if (!is_ground[t]) emit(nonground4, nn, ids[t]);
+      }
+      ++concentric_idx;
+    }
+  *n_ground = ng;
+  *n_nonground = nn;
+}
+
+// =================================================================================================
 // "Next" row (f)1 of SURVEY.md section 8: range-image projection + sub-cluster rejection
 // (reference include/imageProjection.hpp: projectPointCloud :308-352, maskGround :354-364 in "Patchwork" mode,
 // cloudSegmentation :424-483, labelComponents :485-581; LeGO-LOAM lineage).  Restated as: last-writer-wins
@@ -1156,6 +1358,28 @@ int qo_segment_cloud(const float* xyz4, int P, const qo_ip_params* ipp, float* o
   ip.valid_point_num = ipp->valid_point_num;
   ip.valid_line_num = ipp->valid_line_num;
   segment_cloud(xyz4, P, ip, out4, n_valid, outl4, n_outl, labelmat, rangemat);
+  return 0;
+}
+
+struct qo_pw_params {
+  double sensor_height;
+  int num_iter, num_lpr, num_min_pts;
+  double th_seeds, th_dist, max_range, min_range, uprightness_thr, adaptive_seed_selection_margin;
+  int using_global_thr;
+  double global_elevation_thr;
+  int num_zones;
+  int num_sectors_each_zone[4], num_rings_each_zone[4];
+  double min_ranges[4];
+  int num_thr;
+  double elevation_thr[8], flatness_thr[8];
+};
+// PatchWork::estimate_ground: ground4 / nonground4 have capacity P points each
+int qo_patchwork(const float* xyz4, int P, const qo_pw_params* pp, float* ground4, int* n_ground, float* nonground4,
+                 int* n_nonground, int* patch_of) {
+  static_assert(sizeof(qo_pw_params) == sizeof(PwParams), "same layout");
+  PwParams pw;
+  memcpy(&pw, pp, sizeof(pw));
+  patchwork(xyz4, P, pw, ground4, n_ground, nonground4, n_nonground, patch_of);
   return 0;
 }
 

@@ -23,6 +23,8 @@ struct Slot {
   qtr_result* pinned_res = nullptr;
   SegBufs seg;                   // range-image segmentation arena (allocated on first use)
   void* seg_arena = nullptr;
+  PwBufs pwb;                    // ground segmentation arena (allocated on first use)
+  void* pw_arena = nullptr;
   int* mail = nullptr;           // pinned host mailbox the phase-ending kernels write into (frontend.h MAIL_*)
   int seq = 0;                   // last sequence number handed to a phase-ending kernel
   int times_pending = 0;         // 1: qtr_solve, 2: qtr_register_pair — stage times are read off the events lazily
@@ -107,6 +109,7 @@ void qtr_destroy(qtr_handle* h) {
     if (s.pinned_res) (void)hipHostFree(s.pinned_res);
     if (s.mail) (void)hipHostFree(s.mail);
     if (s.seg_arena) (void)hipFree(s.seg_arena);
+    if (s.pw_arena) (void)hipFree(s.pw_arena);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.stream2) (void)hipStreamDestroy(s.stream2);
   }
@@ -496,6 +499,129 @@ int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double ra
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   if (estimate) *estimate = out[0];
   if (n_card) *n_card = (int)out[1];
+  return QTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patchwork ground segmentation (patchwork.hip)
+void qtr_pw_default_params(qtr_pw_params* p) {  // reference config/patchwork_params.yaml
+  memset(p, 0, sizeof(*p));
+  p->sensor_height = 1.723;
+  p->num_iter = 3;
+  p->num_lpr = 20;
+  p->num_min_pts = 80;
+  p->th_seeds = 0.25;
+  p->th_dist = 0.125;
+  p->max_range = 80.0;
+  p->min_range = 2.7;
+  p->uprightness_thr = 0.707;
+  p->adaptive_seed_selection_margin = -1.1;
+  p->using_global_thr = 0;
+  p->global_elevation_thr = -0.5;
+  p->num_zones = 4;
+  const int ns[4] = {16, 32, 54, 32}, nr[4] = {2, 4, 4, 4};
+  const double mr[4] = {2.7, 12.3625, 22.025, 41.35};
+  const double et[4] = {-1.2, -0.9984, -0.851, -0.605}, ft[4] = {0.0001, 0.000125, 0.000185, 0.000185};
+  for (int i = 0; i < 4; ++i) {
+    p->num_sectors_each_zone[i] = ns[i];
+    p->num_rings_each_zone[i] = nr[i];
+    p->min_ranges[i] = mr[i];
+    p->elevation_thr[i] = et[i];
+    p->flatness_thr[i] = ft[i];
+  }
+  p->num_thr = 4;
+}
+
+int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
+                  int cap_ground, int* n_ground, float* nonground_xyzw, int cap_nonground, int* n_nonground, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !pw || !n_ground || !n_nonground || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_ground = *n_nonground = 0;
+  // check_input_parameters_are_correct (:588-614) + what the kernels rely on
+  bool ok = pw->num_zones >= 1 && pw->num_zones <= 4 && pw->num_thr >= 0 && pw->num_thr <= 8 && pw->num_iter >= 1 &&
+            pw->num_lpr >= 1 && pw->min_range == pw->min_ranges[0] && pw->max_range > pw->min_range;
+  int npatch = 0, nrings = 0;
+  for (int k = 0; ok && k < pw->num_zones; ++k) {
+    ok = pw->num_sectors_each_zone[k] >= 1 && pw->num_rings_each_zone[k] >= 1 &&
+         (k == 0 || pw->min_ranges[k] > pw->min_ranges[k - 1]) && pw->min_ranges[k] < pw->max_range;
+    npatch += pw->num_sectors_each_zone[k] * pw->num_rings_each_zone[k];
+    nrings += pw->num_rings_each_zone[k];
+  }
+  if (ok) {  // the reference indexes the threshold vectors with ring + 2 * zone (:395)
+    for (int k = 0, ci = 0; k < pw->num_zones; ++k)
+      for (int r = 0; r < pw->num_rings_each_zone[k]; ++r, ++ci)
+        if (ci < pw->num_thr && r + 2 * k >= pw->num_thr) ok = false;
+  }
+  if (!ok || npatch > 1024) {
+    snprintf(h->err, sizeof(h->err), "Some parameters are wrong! the size of parameters should be same");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (P > h->lim.max_points) {
+    snprintf(h->err, sizeof(h->err), "P=%d exceeds max_points=%d", P, h->lim.max_points);
+    return QTR_ERR_CAPACITY;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  if (!s.pw_arena) {
+    QTR_HIP_TRY(h, hipMalloc(&s.pw_arena, patchwork_scratch_bytes(h->lim.max_points)));
+    patchwork_carve(s.pwb, s.pw_arena, h->lim.max_points);
+  }
+  const float4* d_in = (const float4*)xyz4;
+  if (mem == QTR_MEM_HOST && P > 0) {
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, xyz4, (size_t)P * 16, hipMemcpyHostToDevice, s.stream));
+    d_in = s.in_src;
+  }
+  PwDev d;
+  memset(&d, 0, sizeof(d));
+  d.sensor_height = pw->sensor_height;
+  d.num_iter = pw->num_iter;
+  d.num_lpr = pw->num_lpr;
+  d.num_min_pts = pw->num_min_pts;
+  d.th_seeds = pw->th_seeds;
+  d.th_dist = pw->th_dist;
+  d.max_range = pw->max_range;
+  d.min_range = pw->min_range;
+  d.uprightness_thr = pw->uprightness_thr;
+  d.margin = (pw->sensor_height == 0.0) ? -0.1 : pw->adaptive_seed_selection_margin * pw->sensor_height;  // :294
+  d.using_global_thr = pw->using_global_thr;
+  d.global_elevation_thr = pw->global_elevation_thr;
+  d.num_zones = pw->num_zones;
+  d.num_thr = pw->num_thr;
+  for (int k = 0, rb = 0; k < pw->num_zones; ++k) {
+    d.nsec[k] = pw->num_sectors_each_zone[k];
+    d.nring[k] = pw->num_rings_each_zone[k];
+    d.min_ranges[k] = pw->min_ranges[k];
+    const double hi = (k + 1 < pw->num_zones) ? pw->min_ranges[k + 1] : pw->max_range;
+    d.ring_size[k] = (hi - pw->min_ranges[k]) / pw->num_rings_each_zone[k];
+    d.sector_size[k] = 2 * M_PI / pw->num_sectors_each_zone[k];
+    d.base[k + 1] = d.base[k] + d.nring[k] * d.nsec[k];
+    d.ring_base[k] = rb;
+    rb += d.nring[k];
+  }
+  for (int i = 0; i < 8; ++i) {
+    d.elevation_thr[i] = pw->elevation_thr[i];
+    d.flatness_thr[i] = pw->flatness_thr[i];
+  }
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  QTR_HIP_TRY(h, patchwork_enqueue(s.fb, s.pwb, d_in, P, d, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, s.pwb.offs + 2 * 1024, 2 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  const int ng = s.pinned_i32[0], nn = s.pinned_i32[1];
+  *n_ground = ng;
+  *n_nonground = nn;
+  if ((ground_xyzw && ng > cap_ground) || (nonground_xyzw && nn > cap_nonground)) {
+    snprintf(h->err, sizeof(h->err), "output capacity too small (%d ground, %d non-ground)", ng, nn);
+    return QTR_ERR_CAPACITY;
+  }
+  const hipMemcpyKind kout = mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (ground_xyzw && ng > 0) QTR_HIP_TRY(h, hipMemcpyAsync(ground_xyzw, s.pwb.out_g, (size_t)ng * 16, kout, s.stream));
+  if (nonground_xyzw && nn > 0) QTR_HIP_TRY(h, hipMemcpyAsync(nonground_xyzw, s.pwb.out_n, (size_t)nn * 16, kout, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  float ms = 0;
+  s.times_pending = 0;
+  s.times = qtr_stage_times{};
+  if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.total = ms;
   return QTR_OK;
 }
 

@@ -46,6 +46,14 @@ __device__ __forceinline__ double wave_sum64_f64(double v) {
   }
   return __shfl(v, 0, 64);
 }
+__device__ __forceinline__ float wave_sum64_f32(float v) {  // qm_sum64_fold_f across one wavefront
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_down(v, off, 64);
+    v = v + o;
+  }
+  return __shfl(v, 0, 64);
+}
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << qk_lane()) - 1ULL; }
 
 // exclusive prefix sum of one int per lane across the wave

@@ -4,4 +4,5 @@
 #include "frontend.hip"
 #include "match.hip"
 #include "segment.hip"
+#include "patchwork.hip"
 #include "capi.hip"

@@ -57,6 +57,16 @@ class StageTimes(C.Structure):
                                           "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
 
 
+class PwParams(C.Structure):
+    _fields_ = [("sensor_height", C.c_double), ("num_iter", C.c_int), ("num_lpr", C.c_int), ("num_min_pts", C.c_int),
+                ("th_seeds", C.c_double), ("th_dist", C.c_double), ("max_range", C.c_double), ("min_range", C.c_double),
+                ("uprightness_thr", C.c_double), ("adaptive_seed_selection_margin", C.c_double),
+                ("using_global_thr", C.c_int), ("global_elevation_thr", C.c_double), ("num_zones", C.c_int),
+                ("num_sectors_each_zone", C.c_int * 4), ("num_rings_each_zone", C.c_int * 4),
+                ("min_ranges", C.c_double * 4), ("num_thr", C.c_int), ("elevation_thr", C.c_double * 8),
+                ("flatness_thr", C.c_double * 8)]
+
+
 class IpParams(C.Structure):
     _fields_ = [("n_scan", C.c_int), ("horizon_scan", C.c_int), ("ang_res_x", C.c_float), ("ang_res_y", C.c_float),
                 ("ang_bottom", C.c_float), ("neighbor_mode", C.c_int), ("num_min_pts", C.c_int),
@@ -67,10 +77,16 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
+
+
+def pw_params() -> PwParams:
+    p = PwParams()
+    load().qtr_pw_default_params(C.byref(p))
+    return p
 
 
 def ip_params(lidar: str = "Velodyne-64-HDE", neighbor_mode: str = "4CrossNeighbor", num_min_pts: int = 30) -> IpParams:
@@ -131,6 +147,10 @@ def load():
                                        C.c_void_p]
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+    lib.qtr_pw_default_params.argtypes = [C.POINTER(PwParams)]
+    lib.qtr_pw_default_params.restype = None
+    lib.qtr_patchwork.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PwParams), C.c_void_p, C.c_int,
+                                  C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.qtr_ip_default_params.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IpParams)]
     lib.qtr_segment_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(IpParams), C.c_void_p, C.c_int,
                                       C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -280,6 +300,18 @@ class Handle:
         self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
                                              cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
         return cl[: n.value].copy(), mcore.value
+
+    # ---- Patchwork ground segmentation (PatchWork::estimate_ground)
+    def patchwork(self, xyz4, pp: "PwParams | None" = None, slot: int = 0):
+        xyz4 = _f4(xyz4)
+        pp = pp or pw_params()
+        P = xyz4.shape[0]
+        g = np.zeros((max(P, 1), 4), dtype=np.float32)
+        n = np.zeros((max(P, 1), 4), dtype=np.float32)
+        ng, nn = C.c_int(), C.c_int()
+        self._check(self._lib.qtr_patchwork(self._h, slot, xyz4.ctypes.data, P, C.byref(pp), g.ctypes.data, max(P, 1),
+                                            C.byref(ng), n.ctypes.data, max(P, 1), C.byref(nn), MEM_HOST))
+        return dict(ground=g[:ng.value].copy(), nonground=n[:nn.value].copy())
 
     # ---- range-image projection + sub-cluster rejection (ImageProjection::segmentCloud, "Patchwork" mode)
     def segment_cloud(self, xyz4, ipp: "IpParams | None" = None, slot: int = 0, want_labels: bool = True):

@@ -86,7 +86,7 @@ def _ray_dirs() -> np.ndarray:
 
 
 def _scan(origin: np.ndarray, yaw: float, lo: np.ndarray, hi: np.ndarray, rng: np.random.Generator, sigma: float,
-          bump_k: np.ndarray, bump_ph: np.ndarray, bump_a: float) -> np.ndarray:
+          bump_k: np.ndarray, bump_ph: np.ndarray, bump_a: float, ground: bool = False):
     """Ray-cast one 64 x 1800 sweep.  Each box is only tested against the (beam, azimuth) window its
     corners subtend.  Surfaces get a smooth world-anchored range displacement (sum of sinusoids) so
     that local geometry is distinctive and repeatable between the two views."""
@@ -136,7 +136,23 @@ def _scan(origin: np.ndarray, yaw: float, lo: np.ndarray, hi: np.ndarray, rng: n
     out = np.zeros((pts_local.shape[0], 4), dtype=np.float32)
     out[:, :3] = pts_local.astype(np.float32)
     out[:, 3] = rng.random(pts_local.shape[0]).astype(np.float32)  # intensity (unused by the path)
-    return out
+    if not ground:
+        return out
+    # raw-scan mode (input of the ground-segmentation stage): the ground returns are kept, gently undulating,
+    # and the points come in sweep order (beam-major) with a flag telling which ones are ground
+    gk = np.isfinite(tg) & (tg <= MAX_RANGE) & ~(np.isfinite(t_hit) & (t_hit < tg))
+    pg = origin[None, :] + d[gk] * tg[gk][:, None]
+    und = 0.03 * np.sin(0.21 * pg[:, 0] + 0.4) * np.cos(0.17 * pg[:, 1] - 0.3)
+    tgm = tg[gk] + und / np.maximum(-dz[gk], 0.05) + rng.normal(0.0, sigma, size=int(gk.sum()))
+    gl = d_local[gk] * tgm[:, None]
+    full = np.zeros((N_BEAMS, N_AZ, 4), dtype=np.float32)
+    flag = np.zeros((N_BEAMS, N_AZ), dtype=np.int8)   # 0 none, 1 object, 2 ground
+    full[keep, :3] = pts_local.astype(np.float32)
+    flag[keep] = 1
+    full[gk, :3] = gl.astype(np.float32)
+    flag[gk] = 2
+    sel = flag.reshape(-1) > 0
+    return full.reshape(-1, 4)[sel], flag.reshape(-1)[sel] == 2
 
 
 def kitti64_pair(pair_id: int = 0, n_boxes: int = 100, n_poles: int = 60, n_clutter: int = 150, n_far: int = 300,
@@ -156,6 +172,15 @@ def kitti64_pair(pair_id: int = 0, n_boxes: int = 100, n_poles: int = 60, n_clut
     T[:3, :3] = R.T
     T[:3, 3] = -R.T @ t
     return src, tgt, T
+
+
+def kitti64_raw_scan(scan_id: int = 0, **kw):
+    """One raw KITTI-64-shaped sweep WITH its ground returns: (xyzi float32 in sweep order, is_ground bool)."""
+    rng = np.random.default_rng(SEED_BASE + 7919 * (scan_id + 1))
+    lo, hi = _scene(rng, kw.get("n_boxes", 100), kw.get("n_poles", 60), kw.get("n_clutter", 150), kw.get("n_far", 300))
+    bump_k = rng.normal(0.0, 2.0, size=(6, 3))
+    bump_ph = rng.uniform(0.0, 2 * np.pi, size=6)
+    return _scan(np.zeros(3), 0.0, lo, hi, rng, kw.get("sigma", 0.02), bump_k, bump_ph, kw.get("bump_a", 0.12), ground=True)
 
 
 def correspondences(L: int = 5000, inlier_frac: float = 0.05, seed: int = 0, noise: float = 0.1,

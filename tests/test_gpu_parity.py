@@ -730,3 +730,104 @@ def test_cpp_dropin_demo_with_image_projection(hip, qo, tmp_path):
     assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (o["n_src"], o["n_tgt"], o["L"])
     T = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[2:6]])
     assert np.array_equal(T, o["T"])
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row (f)2: Patchwork ground segmentation
+def _pw_equal(g, o):
+    assert g["ground"].shape == o["ground"].shape and g["nonground"].shape == o["nonground"].shape
+    assert np.array_equal(g["ground"].view(np.uint32), o["ground"].view(np.uint32))
+    assert np.array_equal(g["nonground"].view(np.uint32), o["nonground"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scan_id", [0, 1, 2])
+def test_patchwork_matches_oracle(hip, qo, scan_id):
+    """qtr_patchwork (PatchWork::estimate_ground, include/patchwork.hpp:329-476): ground and non-ground clouds in the
+    reference's output order, bit for bit against the CPU restatement, on raw 64-beam scans with ground."""
+    xyzi, is_ground = synth.kitti64_raw_scan(scan_id)
+    o = qo.patchwork(xyzi)
+    g = hip.patchwork(xyzi)
+    _pw_equal(g, o)
+    assert g["ground"].shape[0] > 0.5 * is_ground.sum()  # a sane split, not an empty one
+
+
+@pytest.mark.gpu
+def test_patchwork_parameter_variants(hip, qo):
+    xyzi, _ = synth.kitti64_raw_scan(3)
+    for mut in ("global_thr", "no_margin", "one_iter", "small_lpr", "thr8", "two_zones"):
+        po, pg = qo.pw_params(), ql.pw_params()
+        for p in (po, pg):
+            if mut == "global_thr":
+                p.using_global_thr, p.global_elevation_thr = 1, -1.4
+            elif mut == "no_margin":
+                p.sensor_height = 0.0
+            elif mut == "one_iter":
+                p.num_iter = 1
+            elif mut == "small_lpr":
+                p.num_lpr, p.num_min_pts = 5, 10
+            elif mut == "thr8":
+                p.num_thr = 8
+                p.elevation_thr[:] = [-1.2, -0.9984, -0.851, -0.605, -0.5, -0.4, -0.3, -0.2]
+                p.flatness_thr[:] = [1e-4, 1.25e-4, 1.85e-4, 1.85e-4, 2e-4, 2e-4, 3e-4, 3e-4]
+            elif mut == "two_zones":
+                p.num_zones = 2
+                p.num_sectors_each_zone[:] = [16, 32, 0, 0]
+                p.num_rings_each_zone[:] = [2, 4, 0, 0]
+                p.min_ranges[:] = [2.7, 12.3625, 0, 0]
+                p.max_range = 40.0
+        _pw_equal(hip.patchwork(xyzi, pg), qo.patchwork(xyzi, po))
+
+
+@pytest.mark.gpu
+def test_patchwork_edge_cases(hip, qo):
+    r = hip.patchwork(np.zeros((0, 4), dtype=np.float32))
+    assert r["ground"].shape[0] == 0 and r["nonground"].shape[0] == 0
+    rng = np.random.default_rng(5)
+    # everything inside min_range / beyond max_range: no patch receives a point, both outputs are empty (the
+    # reference drops such points, patchwork.hpp:541-560)
+    near = (rng.standard_normal((500, 4)) * 0.5).astype(np.float32)
+    far = near.copy()
+    far[:, 0] += 500.0
+    for pts in (near, far):
+        _pw_equal(hip.patchwork(pts), qo.patchwork(pts))
+    # a handful of points (every patch below num_min_pts), duplicates, and one dense flat patch
+    few = np.zeros((40, 4), dtype=np.float32)
+    few[:, 0] = np.linspace(5, 60, 40)
+    few[:, 2] = -1.7
+    _pw_equal(hip.patchwork(few), qo.patchwork(few))
+    dup = np.repeat(few[:4], 100, axis=0)
+    _pw_equal(hip.patchwork(dup), qo.patchwork(dup))
+    flat = np.zeros((5000, 4), dtype=np.float32)
+    flat[:, 0] = rng.uniform(5.0, 8.0, 5000)
+    flat[:, 1] = rng.uniform(-0.3, 0.3, 5000)
+    flat[:, 2] = -1.723 + rng.normal(0, 0.01, 5000)
+    flat[:, 3] = rng.uniform(0, 1, 5000)
+    _pw_equal(hip.patchwork(flat), qo.patchwork(flat))
+    # inconsistent parameters are refused like check_input_parameters_are_correct (:588-614)
+    bad = ql.pw_params()
+    bad.min_range = 3.0  # != min_ranges[0]
+    with pytest.raises(Exception):
+        hip.patchwork(few, bad)
+    bad = ql.pw_params()
+    bad.num_zones = 5
+    with pytest.raises(Exception):
+        hip.patchwork(few, bad)
+
+
+@pytest.mark.gpu
+def test_raw_scan_pipeline_matches_oracle(hip, qo):
+    """The reference demo's whole order on raw scans: Patchwork -> ImageProjection -> voxelize -> FPFH -> Quatro."""
+    a, _ = synth.kitti64_raw_scan(0)
+    b, _ = synth.kitti64_raw_scan(1)
+    outs = []
+    for be in (hip, qo):
+        clouds = []
+        for raw in (a, b):
+            ng = be.patchwork(raw)["nonground"]
+            clouds.append(be.segment_cloud(ng)["valid"])
+        outs.append(clouds)
+    for cg, co in zip(outs[0], outs[1]):
+        assert np.array_equal(cg.view(np.uint32), co.view(np.uint32))
+    _assert_same_solution(hip.register_pair(outs[0][0], outs[0][1], ql.default_frontend_params(seed=4)),
+                          qo.register_pair(outs[1][0], outs[1][1], seed=4))
