@@ -193,6 +193,39 @@ def main() -> None:
         recs.append(qdist.pack_record(p["id"], r))
     gathered = qdist.gather_records(np.stack(recs), dev)
 
+    # ---- next-row leg: Patchwork ground segmentation of raw 64-beam scans (with ground),
+    # device-resident input and outputs; never part of `value`
+    pwl = None
+    if world == 1 and args.workload == "kitti64_pair":
+        raws = [synth.kitti64_raw_scan(i)[0] for i in range(4)]
+        raw_d = [torch.from_numpy(r).to(dev) for r in raws]
+        capp = max(r.shape[0] for r in raws)
+        og = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
+        on = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
+        ngr, nng = C.c_int(), C.c_int()
+        pwp = ql.pw_params()
+
+        def pw_once(t):
+            rc = h._lib.qtr_patchwork(h._h, 0, t.data_ptr(), t.shape[0], C.byref(pwp), og.data_ptr(), capp, C.byref(ngr),
+                                      on.data_ptr(), capp, C.byref(nng), ql.MEM_DEVICE)
+            if rc != ql.QTR_OK:
+                raise ql.QuatroHipError(rc, h.last_error())
+        for _ in range(3):
+            pw_once(raw_d[0])
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        nscan, gpu_ms = 0, 0.0
+        for k in range(max(2 * args.steps, 20)):
+            pw_once(raw_d[k % len(raw_d)])
+            gpu_ms += h.stage_times()["total"]
+            nscan += 1
+        torch.cuda.synchronize()
+        pw_once(raw_d[0])
+        pwl = {"what": "PatchWork::estimate_ground (config/patchwork_params.yaml) on synthetic raw 64-beam scans",
+               "scans_per_s": nscan / (time.perf_counter() - tp0), "gpu_ms_per_scan": gpu_ms / nscan,
+               "points_in": int(raws[0].shape[0]), "ground_out": int(ngr.value), "nonground_out": int(nng.value)}
+        pwl["_raw0"] = raws[0]
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -221,6 +254,9 @@ def main() -> None:
         out["pairs_in_flight_leg"] = multi
     if seg is not None:
         out["segment_cloud_leg"] = seg
+    raw0 = pwl.pop("_raw0") if pwl is not None else None
+    if pwl is not None:
+        out["patchwork_leg"] = pwl
     if args.workload == "kitti64_pair":
         ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
         out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]
@@ -300,6 +336,14 @@ def main() -> None:
             gs = h.segment_cloud(p0["src_h"])
             out["segment_cloud_leg"]["cpu_port_scans_per_s"] = 1.0 / cpu_s
             out["segment_cloud_leg"]["labels_bit_exact"] = bool(np.array_equal(gs["labels"], so["labels"]))
+        if pwl is not None:  # the serial CPU restatement on one of the same scans
+            t1 = time.perf_counter()
+            po = qo.patchwork(raw0)
+            cpu_s = time.perf_counter() - t1
+            pg = h.patchwork(raw0)
+            out["patchwork_leg"]["cpu_port_scans_per_s"] = 1.0 / cpu_s
+            out["patchwork_leg"]["outputs_bit_exact"] = bool(np.array_equal(pg["ground"], po["ground"]) and
+                                                             np.array_equal(pg["nonground"], po["nonground"]))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -960,15 +960,16 @@ struct PwPlane {
 
 static void pw_estimate_plane(const float* xyz4, const int* ids, int n, const std::vector<char>& in_ground,
                               double th_dist, PwPlane& pl) {
-  // nine moment sums over the ground set, sum64 order: the point at patch position t goes to partial[t & 63]
-  float part[9][64];
+  // nine moment sums over the ground set, sum256 order: the point at patch position t goes to partial[t & 255];
+  // the 256 partials fold as four sum64 folds combined (s0 + s1) + (s2 + s3)
+  float part[9][256];
   for (int a = 0; a < 9; ++a)
-    for (int l = 0; l < 64; ++l) part[a][l] = 0.f;
+    for (int l = 0; l < 256; ++l) part[a][l] = 0.f;
   int cnt = 0;
   for (int t = 0; t < n; ++t) {
     if (!in_ground[(size_t)t]) continue;
     const float* q = xyz4 + 4 * (size_t)ids[t];
-    const int l = t & 63;
+    const int l = t & 255;
     part[0][l] += q[0] * q[0];
     part[1][l] += q[0] * q[1];
     part[2][l] += q[0] * q[2];
@@ -981,7 +982,11 @@ static void pw_estimate_plane(const float* xyz4, const int* ids, int n, const st
     ++cnt;
   }
   float acc[9];
-  for (int a = 0; a < 9; ++a) acc[a] = qm_sum64_fold_f(part[a]);
+  for (int a = 0; a < 9; ++a) {
+    const float s0 = qm_sum64_fold_f(part[a]), s1 = qm_sum64_fold_f(part[a] + 64);
+    const float s2 = qm_sum64_fold_f(part[a] + 128), s3 = qm_sum64_fold_f(part[a] + 192);
+    acc[a] = (s0 + s1) + (s2 + s3);
+  }
   const float kk = (float)cnt;
   for (int a = 0; a < 9; ++a) acc[a] /= kk;
   float cov[9];

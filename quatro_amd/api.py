@@ -92,6 +92,55 @@ def voxelize(src, voxelSize: float, handle=None) -> np.ndarray:
     return (handle or _handle()).voxelize(_as_cloud(src), float(voxelSize))
 
 
+class PatchWork:
+    """Reference include/patchwork.hpp:36-233 (ground segmentation on the concentric zone model).  The constructor
+    takes the "/patchwork/..." parameters as keyword arguments (names of config/patchwork_params.yaml, e.g.
+    sensor_height=1.723, czm={"num_zones": 4, ...}) instead of a ros::NodeHandle; unspecified ones keep the yaml values."""
+
+    _SCALARS = {"sensor_height": "sensor_height", "num_iter": "num_iter", "num_lpr": "num_lpr",
+                "num_min_pts": "num_min_pts", "th_seeds": "th_seeds", "th_dist": "th_dist", "max_r": "max_range",
+                "min_r": "min_range", "uprightness_thr": "uprightness_thr",
+                "adaptive_seed_selection_margin": "adaptive_seed_selection_margin",
+                "using_global_elevation": "using_global_thr", "global_elevation_threshold": "global_elevation_thr"}
+
+    def __init__(self, handle=None, czm: dict | None = None, **kw):
+        p = _ql.pw_params()
+        for k, v in kw.items():
+            if k not in self._SCALARS:
+                raise TypeError(f"unknown Patchwork parameter {k!r}")
+            setattr(p, self._SCALARS[k], type(getattr(p, self._SCALARS[k]))(v))
+        if czm:
+            nz = int(czm.get("num_zones", p.num_zones))
+            for key, field in (("num_sectors_each_zone", "num_sectors_each_zone"),
+                               ("num_rings_each_zone", "num_rings_each_zone"),
+                               ("min_ranges_each_zone", "min_ranges")):
+                if key in czm:
+                    if len(czm[key]) != nz:  # patchwork.hpp:598-604
+                        raise ValueError("Some parameters are wrong! the size of parameters should be same")
+                    arr = getattr(p, field)
+                    for i in range(4):
+                        arr[i] = czm[key][i] if i < nz else 0
+            p.num_zones = nz
+            if "elevation_thresholds" in czm or "flatness_thresholds" in czm:
+                e, f = czm.get("elevation_thresholds", []), czm.get("flatness_thresholds", [])
+                if len(e) != len(f) or len(e) > 8:  # :610
+                    raise ValueError("Some parameters are wrong! Check the elevation/flatness_thresholds")
+                p.num_thr = len(e)
+                for i in range(len(e)):
+                    p.elevation_thr[i], p.flatness_thr[i] = e[i], f[i]
+        if p.min_range != p.min_ranges[0]:  # :606
+            raise ValueError("Setting min. ranges are weired! The first term should be eqaul to min_range_")
+        self.params = p
+        self._h = handle
+
+    def estimate_ground(self, cloudIn):
+        """-> (cloudOut (ground), cloudNonground, time_taken [s]); (n, 4) float32 records in the reference's order."""
+        import time
+        t0 = time.perf_counter()
+        r = (self._h or _handle()).patchwork(_as_cloud(cloudIn), self.params)
+        return r["ground"], r["nonground"], time.perf_counter() - t0
+
+
 class ImageProjection:
     """Reference include/imageProjection.hpp:31-581 (range-image projection + sub-cluster rejection, "Patchwork"
     ground mode): segmentCloud then getValidSegments / getOutliers."""

@@ -9,6 +9,7 @@
 
 #include "fpfh_manager.hpp"
 #include "imageProjection.hpp"
+#include "patchwork.hpp"
 #include "quatro.hpp"
 
 static std::shared_ptr<pcl::PointCloud<PointType>> getCloud(const char* path) {  // reference :377-402
@@ -40,9 +41,25 @@ int main(int argc, char** argv) {
   params.inlier_selection_mode = QuatroT::INLIER_SELECTION_MODE::PMC_HEU;
   quatro.reset(params);
 
+  // optional 4th argument "raw": the demo's STEP 2 first (reference :136-146) — Patchwork ground removal on raw scans —
+  // then STEP 3 as under "segment"
+  const bool raw = argc > 4 && std::string(argv[4]) == "raw";
+  if (raw) {
+    PatchWork<PointType> patchwork;
+    pcl::PointCloud<PointType> srcGround, tgtGround;
+    auto srcNonground = std::make_shared<pcl::PointCloud<PointType>>();
+    auto tgtNonground = std::make_shared<pcl::PointCloud<PointType>>();
+    double tSrc = 0, tTgt = 0;
+    patchwork.estimate_ground(*srcRaw, srcGround, *srcNonground, tSrc);
+    patchwork.estimate_ground(*tgtRaw, tgtGround, *tgtNonground, tTgt);
+    std::printf("ground %zu %zu nonground %zu %zu\n", srcGround.size(), tgtGround.size(), srcNonground->size(),
+                tgtNonground->size());
+    srcRaw = srcNonground;
+    tgtRaw = tgtNonground;
+  }
   // optional 4th argument "segment": the demo's STEP 3 (reference :124-160) — range-image sub-cluster rejection
   // before voxelisation (the inputs then play the role of the non-ground clouds)
-  if (argc > 4 && std::string(argv[4]) == "segment") {
+  if (raw || (argc > 4 && std::string(argv[4]) == "segment")) {
     ImageProjection IPSrc("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork"), IPTgt("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork");
     IPSrc.segmentCloud(srcRaw);
     IPTgt.segmentCloud(tgtRaw);

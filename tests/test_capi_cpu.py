@@ -110,3 +110,30 @@ def test_cpp_dropin_header_compiles_against_c_abi(libpath, tmp_path):
                            "-L", os.path.dirname(libpath), "-lquatro_hip", "-Wl,-rpath," + os.path.dirname(libpath),
                            "-Wl,-rpath,/opt/rocm/lib"])
     assert exe.exists()
+
+
+def test_patchwork_parameter_mirror():
+    """api.PatchWork keeps the reference's parameter names and its consistency checks (patchwork.hpp:590-614); the
+    defaults of the C ABI equal config/patchwork_params.yaml as restated by the tests' oracle wrapper."""
+    from oracle import oracle as qo
+    from quatro_amd import api
+    from quatro_amd import lib as ql
+    a, b = ql.pw_params(), qo.pw_params()
+    for name, _ in ql.PwParams._fields_:
+        va, vb = getattr(a, name), getattr(b, name)
+        if hasattr(va, "__len__"):
+            assert list(va) == list(vb), name
+        else:
+            assert va == vb, name
+    pw = api.PatchWork(sensor_height=1.9, czm={"num_zones": 2, "num_sectors_each_zone": [8, 16],
+                                               "num_rings_each_zone": [2, 3], "min_ranges_each_zone": [2.7, 10.0],
+                                               "elevation_thresholds": [-1.0, -0.8], "flatness_thresholds": [1e-4, 2e-4]})
+    assert pw.params.num_zones == 2 and pw.params.num_thr == 2 and pw.params.sensor_height == 1.9
+    with pytest.raises(ValueError):
+        api.PatchWork(min_r=3.0)
+    with pytest.raises(ValueError):
+        api.PatchWork(czm={"num_zones": 3, "num_sectors_each_zone": [8, 16]})
+    with pytest.raises(ValueError):
+        api.PatchWork(czm={"elevation_thresholds": [-1.0], "flatness_thresholds": []})
+    with pytest.raises(TypeError):
+        api.PatchWork(bogus=1)

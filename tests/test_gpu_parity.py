@@ -831,3 +831,51 @@ def test_raw_scan_pipeline_matches_oracle(hip, qo):
         assert np.array_equal(cg.view(np.uint32), co.view(np.uint32))
     _assert_same_solution(hip.register_pair(outs[0][0], outs[0][1], ql.default_frontend_params(seed=4)),
                           qo.register_pair(outs[1][0], outs[1][1], seed=4))
+
+
+@pytest.mark.gpu
+def test_cpp_dropin_demo_raw_scans(hip, qo, tmp_path):
+    """The demo's STEP 2-4 on raw scans through include/patchwork.hpp + imageProjection.hpp + quatro.hpp
+    (PatchWork::estimate_ground -> ImageProjection::segmentCloud -> voxelize -> FPFHManager -> Quatro)."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    a, _ = synth.kitti64_raw_scan(0)
+    b, _ = synth.kitti64_raw_scan(1)
+    a[:, 3] = 0  # the demo's getCloud keeps x, y, z only
+    b[:, 3] = 0
+    synth.save_kitti_bin(str(tmp_path / "src.bin"), a)
+    synth.save_kitti_bin(str(tmp_path / "tgt.bin"), b)
+    exe = str(tmp_path / "dropin_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+        env = dict(os.environ)
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe, str(tmp_path / "src.bin"), str(tmp_path / "tgt.bin"), "4", "raw"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            out = p.stdout
+            break
+    assert out is not None, p.stderr[-500:]
+    pa, pb = qo.patchwork(a), qo.patchwork(b)
+    lines = out.strip().splitlines()
+    w = lines[0].split()
+    assert [int(w[1]), int(w[2]), int(w[4]), int(w[5])] == [pa["ground"].shape[0], pb["ground"].shape[0],
+                                                            pa["nonground"].shape[0], pb["nonground"].shape[0]]
+    so, to = qo.segment_cloud(pa["nonground"]), qo.segment_cloud(pb["nonground"])
+    w = lines[1].split()
+    assert [int(w[4]), int(w[5])] == [so["valid"].shape[0], to["valid"].shape[0]]
+    vs, vt = so["valid"].copy(), to["valid"].copy()
+    vs[:, 3] = 0
+    vt[:, 3] = 0
+    o = qo.register_pair(vs, vt, seed=4)
+    head = dict(zip(lines[2].split()[0::2], lines[2].split()[1::2]))
+    assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (o["n_src"], o["n_tgt"], o["L"])
+    T = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[3:7]])
+    assert np.array_equal(T, o["T"])

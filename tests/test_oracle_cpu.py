@@ -443,3 +443,73 @@ def test_segment_cloud_edge_cases(qo):
     assert r["valid"].shape[0] == 0 and r["outliers"].shape[0] == 1 and (r["labels"] == 999999).sum() == 1
     with pytest.raises(KeyError):
         qo.ip_params("no-such-lidar")
+
+
+def test_patchwork_against_independent_numpy_checks(qo):
+    """Patchwork restatement (reference include/patchwork.hpp:329-476): binning against a float64 numpy zone model,
+    partition/ordering properties of the two outputs, and ground quality on a synthetic scan with known ground."""
+    xyzi, is_ground = synth.kitti64_raw_scan(0)
+    pp = qo.pw_params()
+    r = qo.patchwork(xyzi, pp)
+    P = xyzi.shape[0]
+    x, y = xyzi[:, 0].astype(np.float64), xyzi[:, 1].astype(np.float64)
+    rad = np.sqrt(x * x + y * y)
+    theta = np.arctan2(y, x)
+    theta = np.where(theta < 0, theta + 2 * np.pi, theta)
+    mins = list(pp.min_ranges[:4]) + [pp.max_range]
+    nsec, nring = list(pp.num_sectors_each_zone[:4]), list(pp.num_rings_each_zone[:4])
+    want = np.full(P, -1)
+    base = 0
+    for k in range(4):
+        m = (rad >= mins[k]) & (rad < mins[k + 1]) if k else (rad > mins[0]) & (rad < mins[1])
+        ring = np.minimum(((rad - mins[k]) / ((mins[k + 1] - mins[k]) / nring[k])).astype(int), nring[k] - 1)
+        sec = np.minimum((theta / (2 * np.pi / nsec[k])).astype(int), nsec[k] - 1)
+        want[m] = (base + ring * nsec[k] + sec)[m]
+        base += nring[k] * nsec[k]
+    got = r["patch"]
+    # away from ring / sector / range boundaries the float64 model must agree exactly
+    ringf = np.concatenate([(rad - mins[k]) / ((mins[k + 1] - mins[k]) / nring[k]) for k in range(4)]).reshape(4, P)
+    secf = np.stack([theta / (2 * np.pi / nsec[k]) for k in range(4)])
+    safe = np.ones(P, bool)
+    for k in range(4):
+        safe &= np.abs(ringf[k] - np.round(ringf[k])) > 1e-4
+        safe &= np.abs(secf[k] - np.round(secf[k])) > 1e-4
+    for b in mins:
+        safe &= np.abs(rad - b) > 1e-4
+    assert safe.mean() > 0.95
+    assert np.array_equal(got[safe], want[safe])
+    # every binned point of a patch with more than num_min_pts members comes out exactly once
+    sizes = np.bincount(got[got >= 0], minlength=base)
+    kept = (got >= 0) & (sizes[np.maximum(got, 0)] > pp.num_min_pts)
+    out = np.concatenate([r["ground"], r["nonground"]])
+    assert out.shape[0] == kept.sum()
+    key = lambda a: np.sort(np.ascontiguousarray(a).view([("", np.uint32)] * 4).ravel())
+    assert np.array_equal(key(out), key(xyzi[kept]))
+    # quality against the generator's own ground truth
+    rec = lambda a: {bytes(v) for v in np.ascontiguousarray(a).view(np.uint8).reshape(-1, 16)}
+    gset = rec(r["ground"])
+    truth = rec(xyzi[is_ground & kept])
+    tp = len(gset & truth)
+    assert tp / max(len(gset), 1) > 0.93 and tp / max(len(truth), 1) > 0.90
+
+
+def test_patchwork_edge_cases_and_determinism(qo):
+    xyzi, _ = synth.kitti64_raw_scan(1)
+    a, b = qo.patchwork(xyzi), qo.patchwork(xyzi.copy())
+    assert np.array_equal(a["ground"], b["ground"]) and np.array_equal(a["nonground"], b["nonground"])
+    e = qo.patchwork(np.zeros((0, 4), dtype=np.float32))
+    assert e["ground"].shape[0] == 0 and e["nonground"].shape[0] == 0
+    # a tilted wall inside one patch is rejected by the uprightness rule: everything non-ground
+    rng = np.random.default_rng(2)
+    wall = np.zeros((3000, 4), dtype=np.float32)
+    wall[:, 0] = 6.0 + rng.normal(0, 0.005, 3000)
+    wall[:, 1] = rng.uniform(-0.3, 0.3, 3000)
+    wall[:, 2] = rng.uniform(-1.7, 0.5, 3000)
+    w = qo.patchwork(wall)
+    assert w["nonground"].shape[0] == 3000 and w["ground"].shape[0] == 0
+    # a flat floor at sensor height is all ground
+    floor = wall.copy()
+    floor[:, 0] = rng.uniform(5.0, 8.0, 3000)
+    floor[:, 2] = -1.723 + rng.normal(0, 0.01, 3000)
+    f = qo.patchwork(floor)
+    assert f["ground"].shape[0] == 3000
