@@ -1,11 +1,14 @@
 // fpfh_manager.hpp — drop-in for url-kaist/Quatro's include/fpfh_manager.hpp (class FPFHManager, :25-238):
 // normals + FPFH for both clouds, reciprocal matching, matched key-point clouds — all on the GPU through
-// the C ABI (qtr_fpfh, qtr_match).  The ROS / PCD-cache members of the reference class (saveFeaturePair,
-// loadFeaturePair) are I/O around the path and are not part of this back end.
+// the C ABI (qtr_fpfh, qtr_match).  The matched-pair PCD cache (setSaveDir / setLoadDir, saveFeaturePair,
+// loadFeaturePair, :91-96,179-232) goes through qtr_write_pcd_xyz / qtr_read_pcd_xyz: the same file name pattern
+// and the same layout (source key points, then target key points, in one ASCII PCD).
 #ifndef FPFH_MANAGER_H
 #define FPFH_MANAGER_H
 
+#include <cstdio>
 #include <stdexcept>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -88,6 +91,36 @@ class FPFHManager {
     }
   }
 
+  void setLoadDir(std::string loaddir) { loaddir_ = loaddir; }  // :91-93
+  void setSaveDir(std::string savedir) { savedir_ = savedir; }  // :94-96
+
+  // :179-200 — "Source is the first": one cloud, source half then target half
+  void saveFeaturePair(int src_idx, int tgt_idx, bool verbose = false) {
+    if (savedir_.empty()) throw std::invalid_argument("Save dir. is not set");
+    const std::string pcdname = pair_name(savedir_, src_idx, tgt_idx);
+    if (verbose) std::printf("[SAVER]: %s\n%zu + %zu\n", pcdname.c_str(), src_matched_pcl.size(), tgt_matched_pcl.size());
+    std::vector<PointType> merge(src_matched_pcl.points);
+    merge.insert(merge.end(), tgt_matched_pcl.points.begin(), tgt_matched_pcl.points.end());
+    if (qtr_write_pcd_xyz(pcdname.c_str(), reinterpret_cast<const float*>(merge.data()), static_cast<int>(merge.size()), 0) !=
+        QTR_OK)
+      throw std::runtime_error("[FPFHManager]: Save feature set failed.");
+  }
+  // :202-232
+  void loadFeaturePair(int src_idx, int tgt_idx, bool verbose = false) {
+    if (loaddir_.empty()) throw std::invalid_argument("Load dir. is not set");
+    const std::string pcdname = pair_name(loaddir_, src_idx, tgt_idx);
+    int n = 0;
+    int rc = qtr_read_pcd_xyz(pcdname.c_str(), nullptr, 0, &n);  // size query
+    std::vector<PointType> merge(static_cast<size_t>(n));
+    if (rc == QTR_ERR_CAPACITY) rc = qtr_read_pcd_xyz(pcdname.c_str(), reinterpret_cast<float*>(merge.data()), n, &n);
+    if (rc != QTR_OK) throw std::invalid_argument("[FPFHManager]: Load feature set failed.");
+    src_matched_pcl.clear();
+    tgt_matched_pcl.clear();
+    for (size_t i = 0; i < merge.size(); ++i) (i < merge.size() / 2 ? src_matched_pcl : tgt_matched_pcl).push_back(merge[i]);
+    if (verbose)
+      std::printf("[LOADER]: Loaded data from %s...\n=>%zu %zu\n", pcdname.c_str(), src_matched_pcl.size(), tgt_matched_pcl.size());
+  }
+
   pcl::PointCloud<PointType> getSrcKps() { return src_matched_pcl; }          // :172-174
   pcl::PointCloud<PointType> getTgtKps() { return tgt_matched_pcl; }          // :175-177
   std::vector<std::pair<int, int>> getCorrespondences() { return corr; }      // :234
@@ -95,6 +128,12 @@ class FPFHManager {
   const std::vector<float>& getSceneDescriptor() const { return scene_desc_; }
 
  private:
+  static std::string pair_name(const std::string& dir, int src_idx, int tgt_idx) {
+    char name[64];
+    std::snprintf(name, sizeof(name), "/%06d_to_%06d.pcd", src_idx, tgt_idx);
+    return dir + name;
+  }
+  std::string savedir_, loaddir_;
   void compute(qtr_handle* h, const std::vector<PointType>& cloud, std::vector<float>& desc) {
     desc.assign(33 * cloud.size(), 0.f);
     quatro_hip::check(h, qtr_fpfh(h, 0, quatro_hip::xyz4(cloud), static_cast<int>(cloud.size()),

@@ -55,6 +55,7 @@ extern "C" {
 #define QTR_ERR_CAPACITY 3         /* a qtr_limits bound or a caller buffer capacity was exceeded */
 #define QTR_ERR_HIP 4              /* HIP runtime error (message in qtr_last_error) */
 #define QTR_ERR_UNSUPPORTED 5      /* mode accepted by the reference's API but not built here */
+#define QTR_ERR_IO 6               /* file missing / unreadable / malformed (qtr_read_*, qtr_write_*) */
 
 #define QTR_MEM_HOST 0
 #define QTR_MEM_DEVICE 1
@@ -179,6 +180,19 @@ int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const doubl
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
+
+/* "Next" row (f)3: on-disk formats either side of the path (host code, no GPU work, no handle).
+ *   qtr_read_kitti_bin <- getCloud, examples/run_global_registration.cpp:377-402: float32 x,y,z,intensity records,
+ *                         at most max_points of them (the demo reads 1 000 000 floats = 250 000 points).
+ *   qtr_write_pcd_xyz / qtr_read_pcd_xyz <- the matched-pair cache of FPFHManager::saveFeaturePair / loadFeaturePair
+ *                         (include/fpfh_manager.hpp:179-232): PCD v0.7, fields x y z.  binary = 0 writes what
+ *                         pcl::io::savePCDFile writes by default (DATA ascii, 8 significant digits); the reader takes
+ *                         ascii, binary and binary_compressed files and picks x, y, z by field name.
+ * Points are 16-byte x,y,z,w records like everywhere else in this ABI (w: intensity for .bin, 0 for PCD).
+ * qtr_read_pcd_xyz always reports the file's point count; QTR_ERR_CAPACITY when cap is smaller. */
+int qtr_read_kitti_bin(const char* path, float* xyzi, int max_points, int* n_points);
+int qtr_write_pcd_xyz(const char* path, const float* xyz4, int n, int binary);
+int qtr_read_pcd_xyz(const char* path, float* xyz4, int cap, int* n_points);
 
 /* "Next" row (f)2: Patchwork ground segmentation, the first stage of the reference demo on raw scans
  * (PatchWork::estimate_ground, include/patchwork.hpp:329-476; parameters config/patchwork_params.yaml).

@@ -201,6 +201,38 @@ class FPFHManager:
     def flushAllFeatures(self):
         self.is_initial_ = True
 
+    # matched-pair PCD cache (reference :91-96, 179-232): "%06d_to_%06d.pcd", source half then target half
+    def setLoadDir(self, loaddir):
+        self.loaddir_ = str(loaddir)
+
+    def setSaveDir(self, savedir):
+        self.savedir_ = str(savedir)
+
+    def saveFeaturePair(self, src_idx: int, tgt_idx: int, verbose: bool = False):
+        if not getattr(self, "savedir_", ""):
+            raise ValueError("Save dir. is not set")
+        name = "%s/%06d_to_%06d.pcd" % (self.savedir_, src_idx, tgt_idx)
+        merge = np.concatenate([self.getSrcKps(), self.getTgtKps()])
+        if verbose:
+            print(f"[SAVER]: {name}")
+        _ql.write_pcd_xyz(name, merge)
+
+    def loadFeaturePair(self, src_idx: int, tgt_idx: int, verbose: bool = False):
+        if not getattr(self, "loaddir_", ""):
+            raise ValueError("Load dir. is not set")
+        name = "%s/%06d_to_%06d.pcd" % (self.loaddir_, src_idx, tgt_idx)
+        try:
+            merge = _ql.read_pcd_xyz(name)
+        except OSError:
+            raise ValueError("[FPFHManager]: Load feature set failed.") from None
+        half = merge.shape[0] // 2
+        self._src_kps, self._tgt_kps = merge[:half].copy(), merge[half:].copy()
+        self.src_matched = self._src_kps[:, :3].astype(np.float64).T.copy()
+        self.tgt_matched = self._tgt_kps[:, :3].astype(np.float64).T.copy()
+        if verbose:
+            print(f"[LOADER]: Loaded data from {name}...=>{half} {merge.shape[0] - half}")
+
+
     def setParams(self, normal_radius, fpfh_radius, interval):
         self.normal_radius_, self.fpfh_radius_, self.interval_ = float(normal_radius), float(fpfh_radius), interval
 
@@ -226,6 +258,7 @@ class FPFHManager:
         fp = _ql.default_frontend_params(normal_radius=self.normal_radius_, fpfh_radius=self.fpfh_radius_,
                                          tuple_scale=0.95, use_crosscheck=1, use_tuple_test=1, seed=self.seed)
         self.corr = h.match(self.src_cloud, self._obj, self.tgt_cloud, self._scene, fp)
+        self._src_kps = self._tgt_kps = None
         self.src_matched = self.src_cloud[self.corr[:, 0], :3].astype(np.float64).T.copy()  # 3 x L, as Eigen
         self.tgt_matched = self.tgt_cloud[self.corr[:, 1], :3].astype(np.float64).T.copy()
         self.tgt_normals = self._tgt_normals[self.corr[:, 1], :3].astype(np.float64).T.copy()
@@ -246,9 +279,13 @@ class FPFHManager:
         return self._scene
 
     def getSrcKps(self) -> np.ndarray:
+        if getattr(self, "_src_kps", None) is not None:  # loaded from the pair cache
+            return self._src_kps
         return _as_cloud(self.src_cloud[self.corr[:, 0], :3])
 
     def getTgtKps(self) -> np.ndarray:
+        if getattr(self, "_tgt_kps", None) is not None:
+            return self._tgt_kps
         return _as_cloud(self.tgt_cloud[self.corr[:, 1], :3])
 
     def getCorrespondences(self):

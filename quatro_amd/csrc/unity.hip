@@ -6,3 +6,4 @@
 #include "segment.hip"
 #include "patchwork.hip"
 #include "capi.hip"
+#include "formats.hip"

@@ -77,10 +77,46 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
+
+
+QTR_ERR_IO = 6
+
+
+def read_kitti_bin(path: str, max_points: int = 250000) -> np.ndarray:
+    """getCloud of the demo (examples/run_global_registration.cpp:377-402): (n, 4) float32 x, y, z, intensity."""
+    out = np.zeros((max(max_points, 1), 4), dtype=np.float32)
+    n = C.c_int()
+    rc = load().qtr_read_kitti_bin(os.fsencode(path), out.ctypes.data, max_points, C.byref(n))
+    if rc != QTR_OK:
+        raise OSError(f"error: failed to load {path}")
+    return out[:n.value].copy()
+
+
+def write_pcd_xyz(path: str, xyz, binary: bool = False) -> None:
+    a = np.asarray(xyz, dtype=np.float32).reshape(-1, np.asarray(xyz).shape[-1] if np.asarray(xyz).ndim == 2 else 3)
+    if a.shape[1] == 3:
+        a = np.concatenate([a, np.zeros((a.shape[0], 1), dtype=np.float32)], axis=1)
+    a = _f4(a[:, :4])
+    rc = load().qtr_write_pcd_xyz(os.fsencode(path), a.ctypes.data, a.shape[0], 1 if binary else 0)
+    if rc != QTR_OK:
+        raise OSError(f"failed to write {path}")
+
+
+def read_pcd_xyz(path: str) -> np.ndarray:
+    """(n, 4) float32 x, y, z, 0 from an ascii / binary / binary_compressed PCD holding fields x y z."""
+    n = C.c_int()
+    rc = load().qtr_read_pcd_xyz(os.fsencode(path), None, 0, C.byref(n))
+    if rc not in (QTR_OK, QTR_ERR_CAPACITY):
+        raise OSError(f"failed to read {path}")
+    out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+    rc = load().qtr_read_pcd_xyz(os.fsencode(path), out.ctypes.data, n.value, C.byref(n))
+    if rc != QTR_OK:
+        raise OSError(f"failed to read {path}")
+    return out[:n.value].copy()
 
 
 def pw_params() -> PwParams:
@@ -147,6 +183,9 @@ def load():
                                        C.c_void_p]
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+    lib.qtr_read_kitti_bin.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.qtr_write_pcd_xyz.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_read_pcd_xyz.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.qtr_pw_default_params.argtypes = [C.POINTER(PwParams)]
     lib.qtr_pw_default_params.restype = None
     lib.qtr_patchwork.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PwParams), C.c_void_p, C.c_int,

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <memory>
+#include <vector>
 
 #include "fpfh_manager.hpp"
 #include "imageProjection.hpp"
@@ -14,11 +15,10 @@
 
 static std::shared_ptr<pcl::PointCloud<PointType>> getCloud(const char* path) {  // reference :377-402
   auto cloud = std::make_shared<pcl::PointCloud<PointType>>();
-  std::ifstream f(path, std::ios::binary);
-  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
-  float rec[4];
-  while (f.read(reinterpret_cast<char*>(rec), sizeof(rec)) && cloud->size() < 250000)
-    cloud->push_back(PointType(rec[0], rec[1], rec[2]));
+  std::vector<float> buffer(1000000);  // the demo's cap: 250 000 points
+  int n = 0;
+  if (qtr_read_kitti_bin(path, buffer.data(), 250000, &n) != QTR_OK) throw std::runtime_error(std::string("error: failed to load ") + path);
+  for (int i = 0; i < n; ++i) cloud->push_back(PointType(buffer[4 * i], buffer[4 * i + 1], buffer[4 * i + 2]));
   return cloud;
 }
 
