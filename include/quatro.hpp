@@ -274,6 +274,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     const int L = static_cast<int>(input_->points.size());
     std::vector<int> clique(static_cast<size_t>(L > 0 ? L : 1)), rot(clique.size()), fin(clique.size());
     qtr_result res;
+    qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
     const int rc = qtr_solve(h, 0, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
                              clique.data(), rot.data(), fin.data(), static_cast<int>(clique.size()), QTR_MEM_HOST);
     quatro_hip::check(h, rc);

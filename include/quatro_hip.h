@@ -160,7 +160,9 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
 
 /* K10-K12 alone: the clique search on a caller-supplied graph.  adj = symmetric bit matrix, L rows of
  * ceil(L/64) uint64 words (bit j of row i set <=> edge i-j; the diagonal and bits >= L are ignored).
- * mode: QTR_INLIER_PMC_HEU or QTR_INLIER_KCORE_HEU (teaser CLIQUE_SOLVER_MODE 1 / 2).  clique receives
+ * mode: QTR_INLIER_PMC_EXACT, QTR_INLIER_PMC_HEU or QTR_INLIER_KCORE_HEU (teaser CLIQUE_SOLVER_MODE 0 / 1 / 2).
+ * PMC_EXACT ("next" row (f)4, src/graph.cc:106-127): the heuristic's clique when it is maximum, otherwise the first
+ * maximum clique in the canonical depth-first order; at most 32768 vertices.  clique receives
  * the member ids in ascending order (capacity cap); *n_out their count; *max_core_out (may be NULL) the
  * largest core number. */
 int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
@@ -180,6 +182,11 @@ int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const doubl
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
+
+/* PMC_EXACT only: Params::max_clique_time_limit (include/quatro.hpp:267, default 3600 s; <= 0 = none).  When the limit
+ * is hit the heuristic's clique is returned (the reference returns PMC's best so far) and qtr_exact_stats reports it. */
+void qtr_set_clique_time_limit(qtr_handle* h, double seconds);
+int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* aborted);
 
 /* "Next" row (f)3: on-disk formats either side of the path (host code, no GPU work, no handle).
  *   qtr_read_kitti_bin <- getCloud, examples/run_global_registration.cpp:377-402: float32 x,y,z,intensity records,

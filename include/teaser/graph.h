@@ -8,12 +8,13 @@
 // wants is assembled once inside findMaxClique.
 //
 // Differences a caller can observe:
-//   * PMC_EXACT is not implemented on the device ("next" row of SURVEY.md §8): findMaxClique throws
-//     std::invalid_argument for it.  PMC_HEU and KCORE_HEU follow the oracle's documented semantics
-//     (divergences D2/D3: sequential PMC heuristic, canonical (core, id) vertex order).
+//   * PMC_HEU and KCORE_HEU follow the documented deterministic semantics (divergences D2/D3:
+//     sequential PMC heuristic, canonical (core, id) vertex order).  PMC_EXACT returns the heuristic's clique when it
+//     is maximum, otherwise the first maximum clique of the canonical depth-first order (D10) — PMC's threads race
+//     for the incumbent, so the reference does not define which maximum clique comes back.
 //   * the returned ids are in ascending order (PMC returns them in search order; Quatro sorts them itself,
 //     include/quatro.hpp:805).
-//   * time_limit is accepted and ignored (the device search is bounded by construction).
+//   * time_limit bounds the exact search only; when it is hit the heuristic's clique is returned.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -125,6 +126,7 @@ class MaxCliqueSolver {
     if (params_.solver_mode == CLIQUE_SOLVER_MODE::PMC_HEU) mode = QTR_INLIER_PMC_HEU;
     if (params_.solver_mode == CLIQUE_SOLVER_MODE::KCORE_HEU) mode = QTR_INLIER_KCORE_HEU;
     qtr_handle* h = quatro_hip::default_handle();
+    qtr_set_clique_time_limit(h, params_.time_limit);
     const std::vector<unsigned long long> bm = graph.bitMatrix();
     int n = 0, max_core = 0;
     quatro_hip::check(h, qtr_max_clique(h, 0, bm.data(), N, mode, params_.kcore_heuristic_threshold, clique.data(),

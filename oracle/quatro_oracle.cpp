@@ -748,8 +748,132 @@ int heu_search(const Csr& g, const std::vector<int>& K, const std::vector<int>& 
   return (int)C_max.size();
 }
 
-// mode: 0 PMC_EXACT (unsupported here: falls back to heuristic result, flagged by caller), 1 PMC_HEU,
-// 2 KCORE_HEU.  Returns clique (unsorted, as PMC returns it).
+// Exact maximum clique ("next" row (f)4; reference src/graph.cc:106-127 hands the graph to PMC's branch-and-bound,
+// pmcx_maxclique::search / search_dense: k-core pruning, neighbourhood-core ordering, greedy-colouring bounds, on
+// OpenMP threads that race for the incumbent — which maximum clique comes back is not defined there).  Defined here
+// (D10) so that a parallel search can reproduce it:
+//   * H = the heuristic's clique (PMC_HEU semantics above), lb = |H|.  If lb = max_core + 1 the answer is H
+//     (src/graph.cc:100-102).
+//   * otherwise only vertices with core + 1 > lb can lie in a larger clique; they are searched in the canonical
+//     (core, id) order: roots ascending, candidates of a root = its later neighbours, children descending.  The
+//     incumbent changes only on a strictly larger clique, so the result is H when omega = lb, else the FIRST clique
+//     of size omega in that depth-first order — whatever bounds are used for pruning.
+// Bounds: |C| + |P| and a greedy sequential colouring of P (classes built from the highest-ranked vertex down).
+struct ExactSearch {
+  int n = 0, W = 0;
+  std::vector<uint64_t> adj;  // compact graph, rank order
+  int best = 0;
+  std::vector<int> C, bestC;
+  long long nodes = 0;
+  static int count(const uint64_t* p, int W) {
+    int c = 0;
+    for (int w = 0; w < W; ++w) c += __builtin_popcountll(p[w]);
+    return c;
+  }
+  static int highest(const uint64_t* p, int W) {
+    for (int w = W - 1; w >= 0; --w)
+      if (p[w]) return w * 64 + 63 - __builtin_clzll(p[w]);
+    return -1;
+  }
+  // number of colour classes of a greedy colouring, stopped at limit + 1
+  int colour_bound(const uint64_t* p, int limit) {
+    std::vector<uint64_t> u(p, p + W), q((size_t)W);
+    int colours = 0;
+    while (highest(u.data(), W) >= 0) {
+      if (++colours > limit) return limit + 1;
+      q = u;
+      int v;
+      while ((v = highest(q.data(), W)) >= 0) {
+        q[(size_t)(v >> 6)] &= ~(1ULL << (v & 63));
+        u[(size_t)(v >> 6)] &= ~(1ULL << (v & 63));
+        const uint64_t* row = &adj[(size_t)v * W];
+        for (int w = 0; w < W; ++w) q[(size_t)w] &= ~row[w];
+      }
+    }
+    return colours;
+  }
+  void expand(std::vector<uint64_t>& P) {
+    std::vector<uint64_t> R((size_t)W);
+    while (true) {
+      ++nodes;
+      const int cnt = count(P.data(), W), size = (int)C.size();
+      if (cnt == 0) {
+        return;
+      }
+      if (size + cnt <= best) return;
+      if (size + colour_bound(P.data(), best - size) <= best) return;
+      const int u = highest(P.data(), W);
+      P[(size_t)(u >> 6)] &= ~(1ULL << (u & 63));
+      const uint64_t* row = &adj[(size_t)u * W];
+      bool any = false;
+      for (int w = 0; w < W; ++w) {
+        R[(size_t)w] = P[(size_t)w] & row[w];
+        any |= R[(size_t)w] != 0;
+      }
+      C.push_back(u);
+      if (!any) {
+        if ((int)C.size() > best) {
+          best = (int)C.size();
+          bestC = C;
+        }
+      } else {
+        std::vector<uint64_t> child(R);
+        expand(child);
+      }
+      C.pop_back();
+    }
+  }
+};
+
+// returns true when a clique larger than |C_io| exists; C_io then holds it (original ids)
+bool exact_improve(const uint64_t* bm, int L, const std::vector<int>& K /* core + 1 */, std::vector<int>& C_io,
+                   long long* nodes_out) {
+  const int lb = (int)C_io.size(), W0 = graph_words(L);
+  std::vector<int> order((size_t)L);
+  for (int v = 0; v < L; ++v) order[(size_t)v] = v;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return K[(size_t)a] < K[(size_t)b]; });
+  std::vector<int> verts;  // candidates, canonical order
+  for (int i = 0; i < L; ++i)
+    if (K[(size_t)order[(size_t)i]] > lb) verts.push_back(order[(size_t)i]);
+  ExactSearch S;
+  S.n = (int)verts.size();
+  S.W = graph_words(S.n > 0 ? S.n : 1);
+  S.adj.assign((size_t)S.n * S.W, 0);
+  std::vector<int> pos((size_t)L, -1);
+  for (int i = 0; i < S.n; ++i) pos[(size_t)verts[(size_t)i]] = i;
+  for (int i = 0; i < S.n; ++i) {
+    const uint64_t* row = bm + (size_t)verts[(size_t)i] * W0;
+    for (int w = 0; w < W0; ++w) {
+      uint64_t x = row[w];
+      while (x) {
+        const int j = w * 64 + __builtin_ctzll(x);
+        x &= x - 1;
+        if (j < L && pos[(size_t)j] >= 0 && j != verts[(size_t)i])
+          S.adj[(size_t)i * S.W + (size_t)(pos[(size_t)j] >> 6)] |= 1ULL << (pos[(size_t)j] & 63);
+      }
+    }
+  }
+  S.best = lb;
+  for (int r = 0; r < S.n; ++r) {
+    if (K[(size_t)verts[(size_t)r]] <= S.best) continue;  // core + 1 bounds every clique through r
+    std::vector<uint64_t> P((size_t)S.W, 0);
+    for (int w = r >> 6; w < S.W; ++w) {
+      uint64_t x = S.adj[(size_t)r * S.W + (size_t)w];
+      if (w == (r >> 6)) x &= (r & 63) == 63 ? 0ULL : ~((2ULL << (r & 63)) - 1ULL);
+      P[(size_t)w] = x;
+    }
+    S.C.assign(1, r);
+    if (ExactSearch::count(P.data(), S.W) == 0) continue;  // a single vertex never beats lb >= 1 ... (lb >= 1 whenever L >= 1)
+    S.expand(P);
+  }
+  if (nodes_out) *nodes_out = S.nodes;
+  if (S.best <= lb) return false;
+  C_io.clear();
+  for (int c : S.bestC) C_io.push_back(verts[(size_t)c]);
+  return true;
+}
+
+// mode: 0 PMC_EXACT, 1 PMC_HEU, 2 KCORE_HEU.  Returns clique (unsorted, as PMC returns it).
 int find_max_clique(const uint64_t* bm, int L, int mode, double kcore_thr, int order_mode, std::vector<int>& C,
                     int* max_core_out, std::vector<int>* core_out) {
   Csr g;
@@ -774,6 +898,7 @@ int find_max_clique(const uint64_t* bm, int L, int mode, double kcore_thr, int o
   }
   const int ub = max_core + 1;
   heu_search(g, K, order, ub, order_mode, C);
+  if (mode == 0 && (int)C.size() < ub) exact_improve(bm, L, K, C, nullptr);
   return (int)C.size();
 }
 
@@ -1498,9 +1623,9 @@ int qo_solve(const float* src4, const float* tgt4, int L, const qo_params* prm, 
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 4; ++i) res->T[5 * i] = 1.0;
   res->cost = INFINITY;
-  if (prm->inlier_selection_mode == 3 || prm->inlier_selection_mode == 0) {
-    // NONE leaves max_clique_ empty in the reference (chain TIMs over an empty clique, then UB);
-    // PMC_EXACT needs PMC's exact branch-and-bound: both outside this restatement.
+  if (prm->inlier_selection_mode == 3) {
+    // NONE leaves max_clique_ empty in the reference (chain TIMs over an empty clique, then UB): outside this
+    // restatement.
     res->status = 2;
     return 2;
   }

@@ -23,10 +23,15 @@ struct Slot {
   qtr_result* pinned_res = nullptr;
   SegBufs seg;                   // range-image segmentation arena (allocated on first use)
   void* seg_arena = nullptr;
+  ExactBufs exb;                 // exact clique search arena (allocated / grown on demand)
+  void* ex_arena = nullptr;
+  size_t ex_bytes = 0;
   PwBufs pwb;                    // ground segmentation arena (allocated on first use)
   void* pw_arena = nullptr;
   int* mail = nullptr;           // pinned host mailbox the phase-ending kernels write into (frontend.h MAIL_*)
   int seq = 0;                   // last sequence number handed to a phase-ending kernel
+  unsigned long long exact_nodes = 0;  // search-tree nodes of the last PMC_EXACT run
+  int exact_aborted = 0;               // 1: its time limit was hit (heuristic clique returned)
   int times_pending = 0;         // 1: qtr_solve, 2: qtr_register_pair — stage times are read off the events lazily
   qtr_stage_times times = {};
   int last_L = 0;  // correspondences of the last solve
@@ -39,11 +44,23 @@ struct qtr_handle {
   qtr_limits lim;
   std::vector<Slot> slots;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
+  double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   char err[512];
 };
 
 extern "C" {
+
+void qtr_set_clique_time_limit(qtr_handle* h, double seconds) {
+  if (h) h->clique_time_limit = seconds;
+}
+
+int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* aborted) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size()) return QTR_ERR_BAD_ARG;
+  if (nodes) *nodes = h->slots[slot].exact_nodes;
+  if (aborted) *aborted = h->slots[slot].exact_aborted;
+  return QTR_OK;
+}
 
 void qtr_default_limits(qtr_limits* l) {
   l->max_points = 262144;
@@ -110,6 +127,7 @@ void qtr_destroy(qtr_handle* h) {
     if (s.mail) (void)hipHostFree(s.mail);
     if (s.seg_arena) (void)hipFree(s.seg_arena);
     if (s.pw_arena) (void)hipFree(s.pw_arena);
+    if (s.ex_arena) (void)hipFree(s.ex_arena);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.stream2) (void)hipStreamDestroy(s.stream2);
   }
@@ -260,11 +278,8 @@ static int check_params(qtr_handle* h, const qtr_params* prm) {
     snprintf(h->err, sizeof(h->err), "params is NULL");
     return QTR_ERR_BAD_ARG;
   }
-  if (prm->inlier_selection_mode == QTR_INLIER_NONE || prm->inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
-    snprintf(h->err, sizeof(h->err),
-             "inlier_selection_mode %d not supported (NONE is undefined behaviour in the reference, PMC_EXACT "
-             "is a 'next' row)",
-             prm->inlier_selection_mode);
+  if (prm->inlier_selection_mode == QTR_INLIER_NONE) {
+    snprintf(h->err, sizeof(h->err), "inlier_selection_mode NONE not supported (undefined behaviour in the reference)");
     return QTR_ERR_UNSUPPORTED;
   }
   if (prm->inlier_selection_mode < 0 || prm->inlier_selection_mode > 3 || !(prm->noise_bound > 0) ||
@@ -272,6 +287,59 @@ static int check_params(qtr_handle* h, const qtr_params* prm) {
     snprintf(h->err, sizeof(h->err), "invalid solver parameter");
     return QTR_ERR_BAD_ARG;
   }
+  return QTR_OK;
+}
+
+// PMC_EXACT after the heuristic has finished (state `hs` = the device SolverState as the host last saw it): proves the
+// heuristic clique maximum or replaces it (exact.hip).  *improved tells the caller that st->mc / best_r / picks changed.
+static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, bool* improved) {
+  *improved = false;
+  s.exact_nodes = 0;
+  s.exact_aborted = 0;
+  if (L <= 0 || hs.mc >= hs.ub || hs.mc < 1) return QTR_OK;  // lb == ub: reference src/graph.cc:100-102
+  const int W = (L + 63) / 64;
+  if (exact_nw(W) == 0) {
+    snprintf(h->err, sizeof(h->err), "PMC_EXACT supports at most 32768 vertices (L=%d)", L);
+    return QTR_ERR_CAPACITY;
+  }
+  const int depth_cap = hs.ub + 1;
+  int nwaves = 2048;
+  while (nwaves > 64 && exact_scratch_bytes(W, depth_cap, nwaves) > ((size_t)768 << 20)) nwaves >>= 1;
+  if (nwaves > L) nwaves = L < 1 ? 1 : L;
+  const size_t need = exact_scratch_bytes(W, depth_cap, nwaves);
+  if (need > s.ex_bytes) {
+    if (s.ex_arena) (void)hipFree(s.ex_arena);
+    s.ex_arena = nullptr;
+    s.ex_bytes = 0;
+    QTR_HIP_TRY(h, hipMalloc(&s.ex_arena, need));
+    s.ex_bytes = need;
+  }
+  exact_carve(s.exb, s.ex_arena, depth_cap, nwaves);
+  const long long ticks = h->clique_time_limit > 0 ? (long long)(h->clique_time_limit * 1e8) : 0;  // 100 MHz counter
+  hipLaunchKernelGGL(k_exact_init, dim3(1), dim3(1), 0, s.stream, s.sb.Kp, L, s.sb.st, s.exb.ctl);
+  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 0, ticks, s.stream);
+  ExactCtl* hc = (ExactCtl*)(s.pinned_i32 + 192);
+  QTR_HIP_TRY(h, hipMemcpyAsync(hc, s.exb.ctl, sizeof(ExactCtl), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  s.exact_nodes = hc->nodes;
+  if (hc->abort) {  // time limit: the heuristic clique stands (the reference returns PMC's best so far)
+    s.exact_aborted = 1;
+    return QTR_OK;
+  }
+  if (hc->gbest <= hs.mc) return QTR_OK;
+  QTR_HIP_TRY(h, hipMemsetAsync(s.exb.cliq, 0xff, (size_t)nwaves * (depth_cap + 2) * sizeof(int), s.stream));
+  hipLaunchKernelGGL(k_exact_phase_b, dim3(1), dim3(1), 0, s.stream, s.sb.Kp, L, s.exb.ctl);
+  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 1, ticks, s.stream);
+  hipLaunchKernelGGL(k_exact_commit, dim3(1), dim3(256), 0, s.stream, s.exb.ctl, s.exb.cliq, nwaves, depth_cap, s.sb.st,
+                     s.sb.picks);
+  QTR_HIP_TRY(h, hipMemcpyAsync(hc, s.exb.ctl, sizeof(ExactCtl), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  s.exact_nodes += hc->nodes;
+  if (hc->abort || hc->winner < 0) {
+    s.exact_aborted = 1;
+    return QTR_OK;
+  }
+  *improved = true;
   return QTR_OK;
 }
 
@@ -289,6 +357,18 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
     QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
     QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
+  }
+  if (L > 0 && prm->inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
+    SolverState hs;
+    memcpy(&hs, s.mail + MAIL_SOLVER + 64, sizeof(hs));
+    bool improved = false;
+    QTR_TRY(exact_phase(h, s, L, hs, &improved));
+    if (improved) {  // estimate again from the larger clique
+      s.sb.mail_seq = ++s.seq;
+      QTR_HIP_TRY(h, solver_refinalize(s.sb, d_src, d_tgt, L, *prm, s.stream));
+      QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+      QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
+    }
   }
   memcpy(s.pinned_res, s.mail + MAIL_SOLVER, sizeof(qtr_result));
   const int keep_ns = res->n_src, keep_nt = res->n_tgt, keep_nc = res->n_corr;
@@ -360,8 +440,8 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
   Slot& s = *sp;
   *n_out = 0;
   if (max_core_out) *max_core_out = 0;
-  if (mode != QTR_INLIER_PMC_HEU && mode != QTR_INLIER_KCORE_HEU) {
-    snprintf(h->err, sizeof(h->err), "clique solver mode %d not supported (PMC_EXACT is a 'next' row)", mode);
+  if (mode != QTR_INLIER_PMC_HEU && mode != QTR_INLIER_KCORE_HEU && mode != QTR_INLIER_PMC_EXACT) {
+    snprintf(h->err, sizeof(h->err), "clique solver mode %d not supported", mode);
     return QTR_ERR_UNSUPPORTED;
   }
   if (L > h->lim.max_corr) {
@@ -384,6 +464,12 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     qtr_params dummy;
     qtr_default_params(&dummy);
     QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128));
+  }
+  if (mode == QTR_INLIER_PMC_EXACT) {
+    SolverState hs;
+    memcpy(&hs, s.pinned_i32 + 128, sizeof(hs));
+    bool improved = false;
+    QTR_TRY(exact_phase(h, s, L, hs, &improved));
   }
   s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, clique_only_finish(s.sb, L, s.stream));

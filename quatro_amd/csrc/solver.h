@@ -43,6 +43,8 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
 hipError_t solver_init_attributes();
 hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                            hipStream_t stream, int* pinned_state);
+hipError_t solver_refinalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                             hipStream_t stream);
 // clique search alone (qtr_max_clique): enqueue, [solver_continue(src = nullptr) if !done], finish
 hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int mode, double kcore_thr,
                                hipStream_t stream);

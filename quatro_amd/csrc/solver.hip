@@ -1481,6 +1481,14 @@ hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4*
   return hipGetLastError();
 }
 
+// PMC_EXACT replaced the clique after the first finalisation: estimate again from the state as it is now.
+hipError_t solver_refinalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                             hipStream_t stream) {
+  (void)hipGetLastError();
+  launch_finalize(B, src, tgt, L, prm, stream);
+  return hipGetLastError();
+}
+
 // qtr_max_clique: bit matrix (device, L x ceil(L/64) words) -> degrees -> clique search.
 hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int mode, double kcore_thr,
                                hipStream_t stream) {

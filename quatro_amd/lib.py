@@ -77,7 +77,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
@@ -183,6 +183,9 @@ def load():
                                        C.c_void_p]
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+    lib.qtr_set_clique_time_limit.argtypes = [C.c_void_p, C.c_double]
+    lib.qtr_set_clique_time_limit.restype = None
+    lib.qtr_exact_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
     lib.qtr_read_kitti_bin.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.qtr_write_pcd_xyz.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
     lib.qtr_read_pcd_xyz.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -339,6 +342,14 @@ class Handle:
         self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
                                              cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
         return cl[: n.value].copy(), mcore.value
+
+    def set_clique_time_limit(self, seconds: float):
+        self._lib.qtr_set_clique_time_limit(self._h, float(seconds))
+
+    def exact_stats(self, slot: int = 0):
+        n, a = C.c_ulonglong(), C.c_int()
+        self._check(self._lib.qtr_exact_stats(self._h, slot, C.byref(n), C.byref(a)))
+        return dict(nodes=int(n.value), aborted=bool(a.value))
 
     # ---- Patchwork ground segmentation (PatchWork::estimate_ground)
     def patchwork(self, xyz4, pp: "PwParams | None" = None, slot: int = 0):

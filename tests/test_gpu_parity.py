@@ -447,7 +447,7 @@ def test_max_clique_entry_hygiene_and_errors(hip, qo):
     got, _ = hip.max_clique(dirty, 1)
     assert np.array_equal(got, ref)
     with pytest.raises(ql.QuatroHipError) as e:
-        hip.max_clique(bm, 0)  # PMC_EXACT
+        hip.max_clique(bm, 3)  # NONE is not a clique solver mode
     assert e.value.code == ql.QTR_ERR_UNSUPPORTED
     empty, mcore = hip.max_clique(np.zeros((0, 0), dtype=np.uint64), 1)
     assert empty.size == 0 and mcore == 0
@@ -495,7 +495,8 @@ def test_cpp_teaser_graph_dropin(hip, qo, tmp_path):
     assert int(out[5]) == qo.kcore(bm)[2]
     out = run(2, 0.0).split()
     assert [int(x) for x in out[7:]] == qo.max_clique(bm, 2, 0.0).tolist()
-    assert run(0, 0.5).startswith("invalid_argument")
+    out = run(0, 0.5).split()  # PMC_EXACT, the class's default mode
+    assert [int(x) for x in out[7:]] == np.sort(qo.max_clique(bm, 0)).tolist()
 
 
 def test_dense_mode_front_end_at_50k_points(qo):
@@ -879,3 +880,75 @@ def test_cpp_dropin_demo_raw_scans(hip, qo, tmp_path):
     assert (int(head["n_src"]), int(head["n_tgt"]), int(head["L"])) == (o["n_src"], o["n_tgt"], o["L"])
     T = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[3:7]])
     assert np.array_equal(T, o["T"])
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row (f)4: PMC_EXACT
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,p,planted,seed", [(1, 0.0, 0, 0), (2, 1.0, 0, 0), (60, 0.3, 0, 1), (120, 0.2, 10, 2),
+                                              (200, 0.1, 12, 3), (150, 0.5, 0, 4), (300, 0.3, 25, 5), (400, 0.05, 0, 6),
+                                              (90, 0.7, 0, 7), (1000, 0.1, 30, 8), (5000, 0.02, 40, 9)])
+def test_exact_max_clique_matches_oracle(hip, qo, L, p, planted, seed):
+    """qtr_max_clique in PMC_EXACT mode (reference src/graph.cc:106-127): the same clique as the CPU restatement's
+    sequential branch and bound (the heuristic's when it is maximum, else the first maximum clique in the canonical
+    depth-first order), and a clique of the input graph."""
+    bm, A = _random_graph_bitmap(L, p, seed, planted)
+    ref = np.sort(qo.max_clique(bm, 0))
+    got, _ = hip.max_clique(bm, 0)
+    assert np.array_equal(got, ref)
+    heu, _ = hip.max_clique(bm, 1)
+    assert got.size >= heu.size and got.size >= planted
+    if got.size == heu.size:
+        assert np.array_equal(got, heu)
+    if got.size > 1:
+        sub = A[np.ix_(got, got)]
+        assert sub.sum() == got.size * (got.size - 1)
+    st = hip.exact_stats()
+    assert not st["aborted"]
+
+
+@pytest.mark.gpu
+def test_exact_max_clique_is_maximum_vs_networkx(hip):
+    nx = pytest.importorskip("networkx")
+    for seed, (L, p) in enumerate([(80, 0.4), (150, 0.3), (250, 0.15), (64, 0.8)]):
+        bm, A = _random_graph_bitmap(L, p, 100 + seed)
+        got, _ = hip.max_clique(bm, 0)
+        omega = max(len(c) for c in nx.find_cliques(nx.from_numpy_array(A.astype(int))))
+        assert got.size == omega
+
+
+@pytest.mark.gpu
+def test_exact_mode_through_the_solver(hip, qo):
+    """Quatro with INLIER_SELECTION_MODE::PMC_EXACT: whole back end against the oracle, on an easy case (heuristic
+    already maximum) and on one where the exact search replaces the clique before the estimation."""
+    for L, frac, seed in ((300, 0.3, 1), (800, 0.1, 2), (2000, 0.05, 3)):
+        src, tgt, _, _ = synth.correspondences(L, frac, seed=seed, noise=0.05)
+        _assert_same_solution(hip.solve(src, tgt, ql.demo_params(inlier_selection_mode=ql.INLIER_PMC_EXACT)),
+                              qo.solve(src, tgt, qo.default_params(inlier_selection_mode=0)))
+    # points scattered inside a box the size of a few noise bounds: a dense, random-looking consistency graph on which
+    # the heuristic is beaten, so the estimation runs a second time from the exact clique
+    for L, size, seed in ((120, 1.5, 1), (200, 2.0, 3), (250, 2.5, 5), (180, 1.8, 6)):
+        rng = np.random.default_rng(seed)
+        src = np.zeros((L, 4), dtype=np.float32)
+        tgt = np.zeros((L, 4), dtype=np.float32)
+        src[:, :3] = rng.uniform(0, size, (L, 3))
+        tgt[:, :3] = rng.uniform(0, size, (L, 3))
+        g = hip.solve(src, tgt, ql.demo_params(inlier_selection_mode=ql.INLIER_PMC_EXACT))
+        o = qo.solve(src, tgt, qo.default_params(inlier_selection_mode=0))
+        _assert_same_solution(g, o)
+        assert g["clique"].size > hip.solve(src, tgt)["clique"].size
+
+
+@pytest.mark.gpu
+def test_exact_time_limit_returns_heuristic(hip, qo):
+    """Params::max_clique_time_limit: a dense random graph with an absurdly small limit comes back with the heuristic
+    clique and the abort flag, quickly."""
+    bm, _ = _random_graph_bitmap(600, 0.6, 11)
+    hip.set_clique_time_limit(1e-4)
+    try:
+        got, _ = hip.max_clique(bm, 0)
+        st = hip.exact_stats()
+    finally:
+        hip.set_clique_time_limit(3600.0)
+    heu, _ = hip.max_clique(bm, 1)
+    assert st["aborted"] and np.array_equal(got, heu)

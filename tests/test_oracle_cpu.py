@@ -513,3 +513,35 @@ def test_patchwork_edge_cases_and_determinism(qo):
     floor[:, 2] = -1.723 + rng.normal(0, 0.01, 3000)
     f = qo.patchwork(floor)
     assert f["ground"].shape[0] == 3000
+
+
+def test_exact_clique_is_maximum_and_defined(qo):
+    """PMC_EXACT restatement (reference src/graph.cc:106-127): the size equals networkx's exact clique number, the
+    result is a clique, and it is the heuristic's own clique whenever that is already maximum (D10)."""
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(0)
+    beaten = 0
+    for L, p, plant in [(60, 0.3, 0), (120, 0.2, 10), (200, 0.1, 12), (150, 0.5, 0), (300, 0.3, 25), (400, 0.05, 0),
+                        (90, 0.7, 0), (1, 0.0, 0), (2, 1.0, 0), (5, 0.0, 0)]:
+        A = np.triu(rng.random((L, L)) < p, 1)
+        A = A | A.T
+        if plant:
+            idx = rng.choice(L, plant, replace=False)
+            A[np.ix_(idx, idx)] = True
+            A[idx, idx] = False
+        W = (L + 63) // 64
+        bits = np.zeros((L, W * 64), dtype=np.uint8)
+        bits[:, :L] = A
+        bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W)
+        ce, ch = qo.max_clique(bm, 0), qo.max_clique(bm, 1)
+        omega = max(len(c) for c in nx.find_cliques(nx.from_numpy_array(A.astype(int))))
+        if A.sum() == 0:
+            omega = ch.size  # PMC reports no clique on an edgeless graph; exact mode keeps that
+        assert ce.size == omega >= ch.size
+        assert all(A[a, b] for a in ce for b in ce if a != b)
+        if ce.size == ch.size:
+            assert np.array_equal(np.sort(ce), np.sort(ch))
+        else:
+            beaten += 1
+        assert np.array_equal(qo.max_clique(bm, 0), ce)  # deterministic
+    assert beaten >= 2
