@@ -133,6 +133,87 @@ QM_HD void qm_sincosf(float thetaf, float* s_out, float* c_out) {
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG (SplitMix64 finaliser over seed + counter).  Replaces srand(time(NULL))/rand()
 // in the tuple test: trial t draws r_k = qm_rand_u32(seed, 3*t + k) % ncorr, k = 0,1,2.
+// Rotation R (row-major 3x3) maximising trace(R * H) for H = sum_j w_j x_j y_j^T (row-major: H[3a+b] = sum w x_a y_b)
+// — the rotation teaser::utils::svdRot returns (reference include/teaser/utils.h:123-149: V diag(1,1,det) U^T of
+// H = U S V^T).  Horn's unit-quaternion form instead of Eigen::JacobiSVD: the dominant eigenvector of the symmetric
+// 4x4 N(H), by cyclic Jacobi rotations with a fixed sweep count (binary64 + - * / sqrt only, so host and device agree
+// bit for bit).  Always a proper rotation; H = 0 gives the identity.
+QM_HD void qm_rot3_from_h(const double* H, double* R) {
+  const double Sxx = H[0], Sxy = H[1], Sxz = H[2], Syx = H[3], Syy = H[4], Syz = H[5], Szx = H[6], Szy = H[7], Szz = H[8];
+  double A[4][4] = {{(Sxx + Syy) + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                    {Syz - Szy, (Sxx - Syy) - Szz, Sxy + Syx, Szx + Sxz},
+                    {Szx - Sxz, Sxy + Syx, (Syy - Sxx) - Szz, Syz + Szy},
+                    {Sxy - Syx, Szx + Sxz, Syz + Szy, (Szz - Sxx) - Syy}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int sweep = 0; sweep < 10; ++sweep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int p = 0; p < 3; ++p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int q = p + 1; q < 4; ++q) {
+        const double apq = A[p][q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double at = theta < 0 ? -theta : theta;
+        double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+        if (theta < 0) t = -t;
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; ++k) {  // columns p, q of A and V
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; ++k) {  // rows p, q of A
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+      }
+    }
+  }
+  double q0 = V[0][0], q1 = V[1][0], q2 = V[2][0], q3 = V[3][0], best = A[0][0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > best) {
+      best = A[k][k];
+      q0 = V[0][k];
+      q1 = V[1][k];
+      q2 = V[2][k];
+      q3 = V[3][k];
+    }
+  const double nq = sqrt((q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3));
+  q0 = q0 / nq;
+  q1 = q1 / nq;
+  q2 = q2 / nq;
+  q3 = q3 / nq;
+  R[0] = ((q0 * q0 + q1 * q1) - q2 * q2) - q3 * q3;
+  R[1] = 2.0 * (q1 * q2 - q0 * q3);
+  R[2] = 2.0 * (q1 * q3 + q0 * q2);
+  R[3] = 2.0 * (q1 * q2 + q0 * q3);
+  R[4] = ((q0 * q0 - q1 * q1) + q2 * q2) - q3 * q3;
+  R[5] = 2.0 * (q2 * q3 - q0 * q1);
+  R[6] = 2.0 * (q1 * q3 - q0 * q2);
+  R[7] = 2.0 * (q2 * q3 + q0 * q1);
+  R[8] = ((q0 * q0 - q1 * q1) - q2 * q2) + q3 * q3;
+}
+
 QM_HD uint64_t qm_mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

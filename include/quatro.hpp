@@ -251,8 +251,9 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     if (!input_ || !target_) throw std::invalid_argument("[Quatro] input clouds are not set");
     if (input_->points.size() != target_->points.size())
       throw std::invalid_argument("[Quatro] source and target keypoint clouds must have equal length");
-    if (reg_name_ != "Quatro")
+    if (reg_name_ != "Quatro" && reg_name_ != "TEASER")
       throw std::invalid_argument("[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'");  // :410
+    if (reg_name_ == "TEASER" && using_pre_estimated_RyRx_) throw std::invalid_argument("Wrong reg type name is coming!");  // :424-426
     if (params_.cote_mode != "median" && params_.cote_mode != "weighted_mean")
       throw std::invalid_argument("[COTE]: Wrong parameter comes!");  // :911
     qtr_handle* h = quatro_hip::default_handle();
@@ -273,6 +274,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     p.using_pre_estimated_ryrx = using_pre_estimated_RyRx_ ? 1 : 0;
     const int L = static_cast<int>(input_->points.size());
     std::vector<int> clique(static_cast<size_t>(L > 0 ? L : 1)), rot(clique.size()), fin(clique.size());
+    p.reg_mode = reg_name_ == "TEASER" ? QTR_REG_TEASER : QTR_REG_QUATRO;
     qtr_result res;
     qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
     const int rc = qtr_solve(h, 0, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
@@ -358,6 +360,31 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
   Eigen::Matrix3d solveForRotation(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v1,
                                    const Eigen::Matrix<double, 3, Eigen::Dynamic>& v2) {
     rotation_inliers_mask_.resize(1, static_cast<int>(v1.cols()));
+    if (reg_name_ == "TEASER") {  // the branch the reference names in its message but never implements (:409-411)
+      if (using_pre_estimated_RyRx_) throw std::invalid_argument("Wrong reg type name is coming!");  // :424-426
+      if (v1.cols() != v2.cols() || !(params_.rotation_gnc_factor > 1))
+        throw std::invalid_argument("[solveForRotation] bad arguments");
+      const int M = static_cast<int>(v1.cols());
+      if (M == 0) return solution_.rotation;
+      std::vector<double> a(static_cast<size_t>(3) * M), b(a.size());
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < M; ++c) {
+          a[static_cast<size_t>(r) * M + c] = v1(r, c);
+          b[static_cast<size_t>(r) * M + c] = v2(r, c);
+        }
+      double R9[9], cost = 0;
+      int iters = 0;
+      std::vector<unsigned char> inl(static_cast<size_t>(M));
+      qtr_handle* h = quatro_hip::default_handle();
+      quatro_hip::check(h, qtr_gnc_rotation3d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
+                                              static_cast<int>(params_.rotation_max_iterations),
+                                              params_.rotation_cost_threshold, R9, &cost, &iters, inl.data()));
+      cost_ = cost;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) solution_.rotation(r, c) = R9[3 * r + c];
+      for (int c = 0; c < M; ++c) rotation_inliers_mask_(0, c) = inl[static_cast<size_t>(c)] != 0;
+      return solution_.rotation;
+    }
     if (reg_name_ != "Quatro")
       throw std::invalid_argument("[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'");
     Eigen::Matrix<double, 2, Eigen::Dynamic> src_2d(2, static_cast<int>(v1.cols())), dst_2d(2, static_cast<int>(v2.cols()));

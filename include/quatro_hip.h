@@ -77,6 +77,8 @@ typedef struct qtr_limits {
 
 /* The fields of Quatro::Params that the path consumes (reference include/quatro.hpp:202-268), plus the
  * public member noise_bound_ (:269, used by COTE :600-601) and estimated_RyRx_ (:159). */
+#define QTR_REG_QUATRO 0
+#define QTR_REG_TEASER 1
 typedef struct qtr_params {
   double noise_bound;               /* 0.3 */
   double cbar2;                     /* 1.0 */
@@ -90,7 +92,7 @@ typedef struct qtr_params {
   int cote_median;                  /* 1 = cote_mode "median", 0 = "weighted_mean" */
   int using_rot_inliers_when_estimating_cote; /* 0 */
   int using_pre_estimated_ryrx;     /* 0 */
-  int reserved;
+  int reg_mode;                     /* QTR_REG_QUATRO (Params::reg_name "Quatro", yaw) or QTR_REG_TEASER (3-DoF, row (f)4) */
 } qtr_params;
 
 /* Front-end knobs of the demo (reference examples/run_global_registration.cpp:37-55, config/params.yaml:22-25)
@@ -179,6 +181,12 @@ int qtr_scale_mask(qtr_handle* h, int slot, const double* tims_src3k, const doub
                    double noise_bound, double cbar2, unsigned char* mask /* K */);
 int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const double* dst2m, int M, double noise_bound,
                        double gnc_factor, int max_iterations, double cost_threshold, double* R4 /* row-major 2x2 */,
+                       double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
+/* "Next" row (f)4, second half: the 3-DoF rotation of reg_name "TEASER" (solveForRotation throws for it in the
+ * reference, include/quatro.hpp:409-411; teaser::utils::svdRot, include/teaser/utils.h:123-149, is what it would
+ * call): TEASER++'s GNC-TLS loop over 3-D TIMs.  Also reachable through qtr_solve with reg_mode = QTR_REG_TEASER. */
+int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const double* dst3m, int M, double noise_bound,
+                       double gnc_factor, int max_iterations, double cost_threshold, double* R9 /* row-major 3x3 */,
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);

@@ -33,7 +33,7 @@ class Params(C.Structure):
         ("cote_noise_bound", C.c_double), ("ryrx", C.c_double * 9),
         ("rotation_max_iterations", C.c_int), ("inlier_selection_mode", C.c_int), ("cote_median", C.c_int),
         ("using_rot_inliers_when_estimating_cote", C.c_int), ("using_pre_estimated_ryrx", C.c_int),
-        ("clique_order", C.c_int),
+        ("clique_order", C.c_int), ("reg_mode", C.c_int),
     ]
 
 
@@ -197,6 +197,28 @@ def max_clique(bitmap, mode=1, kcore_thr=0.5, order_mode=0):
     cl = np.zeros(max(L, 1), dtype=np.int32)
     m = lib().qo_max_clique(_p(bitmap, C.c_ulonglong), L, mode, C.c_double(kcore_thr), order_mode, _p(cl, C.c_int))
     return cl[:m].copy()
+
+
+def rot3_from_h(H):
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+    R = np.zeros(9)
+    lib().qo_rot3_from_h(_p(H, C.c_double), _p(R, C.c_double))
+    return R.reshape(3, 3)
+
+
+def gnc_rotation3d(src3, dst3, noise_bound, gnc_factor=1.4, max_iter=50, cost_thr=1.1e-4):
+    """M x 3 row-major TIMs -> (R 3x3, cost, iters, inlier mask)."""
+    src3 = np.ascontiguousarray(src3, dtype=np.float64)
+    dst3 = np.ascontiguousarray(dst3, dtype=np.float64)
+    M = src3.shape[0]
+    R = np.zeros(9)
+    cost = C.c_double()
+    iters = C.c_int()
+    inl = np.zeros(max(M, 1), dtype=np.uint8)
+    lib().qo_gnc_rotation3d(_p(src3, C.c_double), _p(dst3, C.c_double), M, C.c_double(noise_bound), C.c_double(gnc_factor),
+                            max_iter, C.c_double(cost_thr), _p(R, C.c_double), C.byref(cost), C.byref(iters),
+                            _p(inl, C.c_ubyte))
+    return R.reshape(3, 3), cost.value, iters.value, inl[:M].astype(bool)
 
 
 def gnc_rotation2d(src2, dst2, noise_bound, gnc_factor=1.4, max_iter=50, cost_thr=1.1e-4):

@@ -984,6 +984,68 @@ void gnc_rotation2d(const double* src2, const double* dst2, int M, double noise_
   for (int j = 0; j < M; ++j) inliers[j] = w[j] >= 0.4;
 }
 
+// "Next" row (f)4, second half: the 3-DoF rotation the reference's API names but never reaches ("TEASER" reg_name:
+// solveForRotation throws, include/quatro.hpp:409-411; teaser::utils::svdRot, include/teaser/utils.h:123-149, is the
+// only piece present).  Restated as TEASER++'s GNC-TLS rotation solver — the loop solveForRotation2D (:430-572) was
+// derived from — with 3-D residuals and the 3x3 weighted rotation of qtr_math.h (Horn quaternion form instead of
+// JacobiSVD, fixed summation order: same kind of divergence as D6).  src3 / dst3: M x 3 row-major.
+struct Gnc3Out {
+  double R[9];
+  double cost;
+  int iters;
+};
+void gnc_rotation3d(const double* src3, const double* dst3, int M, double noise_bound, double gnc_factor, int max_iter,
+                    double cost_thr, Gnc3Out& out, std::vector<char>& inliers) {
+  double mu = 1, prev_cost = INFINITY;
+  out.cost = INFINITY;
+  out.iters = 0;
+  double nb_sq = noise_bound * noise_bound;
+  if (nb_sq < 1e-16) nb_sq = 1e-2;
+  std::vector<double> w((size_t)M, 1.0), r2((size_t)M), t((size_t)M);
+  for (int i = 0; i < 9; ++i) out.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int it = 0; it < max_iter; ++it) {
+    out.iters = it + 1;
+    double H[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        for (int j = 0; j < M; ++j) t[(size_t)j] = (w[(size_t)j] * src3[3 * j + a]) * dst3[3 * j + b];
+        H[3 * a + b] = sum64_strided(t);
+      }
+    qm_rot3_from_h(H, out.R);
+    const double* R = out.R;
+    double max_r = -INFINITY;
+    for (int j = 0; j < M; ++j) {
+      const double x0 = src3[3 * j], x1 = src3[3 * j + 1], x2 = src3[3 * j + 2];
+      const double e0 = dst3[3 * j] - ((R[0] * x0 + R[1] * x1) + R[2] * x2);
+      const double e1 = dst3[3 * j + 1] - ((R[3] * x0 + R[4] * x1) + R[5] * x2);
+      const double e2 = dst3[3 * j + 2] - ((R[6] * x0 + R[7] * x1) + R[8] * x2);
+      r2[(size_t)j] = (e0 * e0 + e1 * e1) + e2 * e2;
+      if (r2[(size_t)j] > max_r) max_r = r2[(size_t)j];
+    }
+    if (it == 0) {
+      mu = 1 / (2 * max_r / nb_sq - 1);
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
+    for (int j = 0; j < M; ++j) t[(size_t)j] = w[(size_t)j] * r2[(size_t)j];
+    out.cost = sum64_strided(t);
+    for (int j = 0; j < M; ++j) {
+      if (r2[(size_t)j] >= th1)
+        w[(size_t)j] = 0;
+      else if (r2[(size_t)j] <= th2)
+        w[(size_t)j] = 1;
+      else
+        w[(size_t)j] = sqrt(nb_sq * mu * (mu + 1) / r2[(size_t)j]) - mu;
+    }
+    const double cost_diff = fabs(out.cost - prev_cost);
+    mu = mu * gnc_factor;
+    prev_cost = out.cost;
+    if (cost_diff < cost_thr) break;
+  }
+  inliers.resize((size_t)M);
+  for (int j = 0; j < M; ++j) inliers[(size_t)j] = w[(size_t)j] >= 0.4;
+}
+
 // ================================================================================================
 // K15  COTE (component-wise translation estimate).  Follows Quatro::estimate (reference
 // include/quatro.hpp:618-747): adaptive-voting sweep over 2N interval endpoints.  Sort is stable by
@@ -1425,6 +1487,7 @@ struct qo_params {
   int using_rot_inliers_when_estimating_cote;
   int using_pre_estimated_ryrx;
   int clique_order;           // 0 canonical, 1 bz  (oracle-only knob, D2)
+  int reg_mode;               // 0 = reg_name "Quatro" (yaw), 1 = "TEASER" (3-DoF rotation, row (f)4)
 };
 
 struct qo_result {
@@ -1596,6 +1659,23 @@ int qo_max_clique(const unsigned long long* bitmap, int L, int mode, double kcor
   return (int)C.size();
 }
 
+int qo_rot3_from_h(const double* H9, double* R9) {
+  qm_rot3_from_h(H9, R9);
+  return 0;
+}
+
+int qo_gnc_rotation3d(const double* src3, const double* dst3, int M, double noise_bound, double gnc_factor, int max_iter,
+                      double cost_thr, double* R9, double* cost, int* iters, unsigned char* inliers) {
+  Gnc3Out o;
+  std::vector<char> inl;
+  gnc_rotation3d(src3, dst3, M, noise_bound, gnc_factor, max_iter, cost_thr, o, inl);
+  for (int i = 0; i < 9; ++i) R9[i] = o.R[i];
+  *cost = o.cost;
+  *iters = o.iters;
+  for (int j = 0; j < M; ++j) inliers[j] = (unsigned char)inl[j];
+  return 0;
+}
+
 int qo_gnc_rotation2d(const double* src2, const double* dst2, int M, double noise_bound, double gnc_factor, int max_iter,
                       double cost_thr, double* R4, double* cost, int* iters, unsigned char* inliers) {
   GncOut o;
@@ -1654,22 +1734,45 @@ int qo_solve(const float* src4, const float* tgt4, int L, const qo_params* prm, 
     return 1;
   }
   // chain TIMs (quatro.hpp:817-844), XY rows only for the 2-D solver (:396-402)
-  std::vector<double> ps(2 * (size_t)M), pd(2 * (size_t)M);
-  for (int i = 0; i < M; ++i) {
-    const int root = C[i], leaf = (i != M - 1) ? C[i + 1] : C[0];
-    for (int a = 0; a < 2; ++a) {
-      ps[2 * i + a] = s[3 * leaf + a] - s[3 * root + a];
-      pd[2 * i + a] = (t[3 * leaf + a] - t[3 * root + a]) * (1 / 1.0);  // pruned_dst_tims_ *= 1/scale, scale = 1
-    }
-  }
   const double rot_nb = prm->noise_bound * (2 / 1.0);  // params.noise_bound *= 2/scale (:850-852)
-  GncOut g;
   std::vector<char> rmask;
-  gnc_rotation2d(ps.data(), pd.data(), M, rot_nb, prm->rotation_gnc_factor, prm->rotation_max_iterations,
-                 prm->rotation_cost_threshold, g, rmask);
-  res->cost = g.cost;
-  res->gnc_iters = g.iters;
-  double R[9] = {g.R[0], g.R[1], 0, g.R[2], g.R[3], 0, 0, 0, 1};
+  double R[9];
+  if (prm->reg_mode == 1) {
+    if (prm->using_pre_estimated_ryrx) {  // "Wrong reg type name is coming!" (:424-426)
+      res->status = 2;
+      return 2;
+    }
+    std::vector<double> ps(3 * (size_t)M), pd(3 * (size_t)M);
+    for (int i = 0; i < M; ++i) {
+      const int root = C[i], leaf = (i != M - 1) ? C[i + 1] : C[0];
+      for (int a = 0; a < 3; ++a) {
+        ps[3 * i + a] = s[3 * leaf + a] - s[3 * root + a];
+        pd[3 * i + a] = (t[3 * leaf + a] - t[3 * root + a]) * (1 / 1.0);
+      }
+    }
+    Gnc3Out g3;
+    gnc_rotation3d(ps.data(), pd.data(), M, rot_nb, prm->rotation_gnc_factor, prm->rotation_max_iterations,
+                   prm->rotation_cost_threshold, g3, rmask);
+    res->cost = g3.cost;
+    res->gnc_iters = g3.iters;
+    memcpy(R, g3.R, sizeof(R));
+  } else {
+    std::vector<double> ps(2 * (size_t)M), pd(2 * (size_t)M);
+    for (int i = 0; i < M; ++i) {
+      const int root = C[i], leaf = (i != M - 1) ? C[i + 1] : C[0];
+      for (int a = 0; a < 2; ++a) {
+        ps[2 * i + a] = s[3 * leaf + a] - s[3 * root + a];
+        pd[2 * i + a] = (t[3 * leaf + a] - t[3 * root + a]) * (1 / 1.0);  // pruned_dst_tims_ *= 1/scale, scale = 1
+      }
+    }
+    GncOut g;
+    gnc_rotation2d(ps.data(), pd.data(), M, rot_nb, prm->rotation_gnc_factor, prm->rotation_max_iterations,
+                   prm->rotation_cost_threshold, g, rmask);
+    res->cost = g.cost;
+    res->gnc_iters = g.iters;
+    const double Ry[9] = {g.R[0], g.R[1], 0, g.R[2], g.R[3], 0, 0, 0, 1};
+    memcpy(R, Ry, sizeof(R));
+  }
   if (prm->using_pre_estimated_ryrx) {  // solution_.rotation * estimated_RyRx_ (:419-423)
     double Rn[9];
     for (int r = 0; r < 3; ++r)

@@ -348,9 +348,12 @@ class Quatro:
         p = self.params_
         if p.cote_mode not in ("median", "weighted_mean"):
             raise ValueError("[COTE]: Wrong parameter comes!")  # reference :911
-        if self.reg_name_ != "Quatro":
+        if self.reg_name_ not in ("Quatro", "TEASER"):
             raise ValueError("[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'")  # :410
+        if self.reg_name_ == "TEASER" and self.using_pre_estimated_RyRx_:
+            raise ValueError("Wrong reg type name is coming!")  # :424-426
         cp = _ql.default_params()
+        cp.reg_mode = _ql.REG_TEASER if self.reg_name_ == "TEASER" else _ql.REG_QUATRO
         cp.noise_bound = p.noise_bound
         cp.cbar2 = p.cbar2
         cp.rotation_gnc_factor = p.rotation_gnc_factor

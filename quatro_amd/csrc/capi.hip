@@ -282,6 +282,14 @@ static int check_params(qtr_handle* h, const qtr_params* prm) {
     snprintf(h->err, sizeof(h->err), "inlier_selection_mode NONE not supported (undefined behaviour in the reference)");
     return QTR_ERR_UNSUPPORTED;
   }
+  if (prm->reg_mode != QTR_REG_QUATRO && prm->reg_mode != QTR_REG_TEASER) {
+    snprintf(h->err, sizeof(h->err), "[solveForRotation] The param is wrong! It should be 'TEASER' or 'Quatro'");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (prm->reg_mode == QTR_REG_TEASER && prm->using_pre_estimated_ryrx) {  // reference include/quatro.hpp:424-426
+    snprintf(h->err, sizeof(h->err), "Wrong reg type name is coming!");
+    return QTR_ERR_BAD_ARG;
+  }
   if (prm->inlier_selection_mode < 0 || prm->inlier_selection_mode > 3 || !(prm->noise_bound > 0) ||
       !(prm->rotation_gnc_factor > 1) || prm->rotation_max_iterations < 1) {
     snprintf(h->err, sizeof(h->err), "invalid solver parameter");
@@ -561,6 +569,34 @@ int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const doubl
   for (int i = 0; i < 4; ++i) R4[i] = out[i];
   if (cost) *cost = out[4];
   if (iterations) *iterations = (int)out[5];
+  return QTR_OK;
+}
+
+int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const double* dst3m, int M, double noise_bound,
+                       double gnc_factor, int max_iterations, double cost_threshold, double* R9, double* cost,
+                       int* iterations, unsigned char* inliers) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || M < 1 || !src3m || !dst3m || !R9 || !(gnc_factor > 1) || max_iterations < 1) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  if (!stage_fits(h, s, (size_t)7 * M + 16, (size_t)(M + 3) / 4)) return QTR_ERR_CAPACITY;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  double* d_s = s.sb.f64;
+  double* d_d = d_s + (size_t)3 * M;
+  double* d_w = d_d + (size_t)3 * M;
+  double* d_o = d_w + (size_t)M;
+  unsigned char* d_i = (unsigned char*)s.sb.i32;
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_s, src3m, sizeof(double) * 3 * (size_t)M, hipMemcpyHostToDevice, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_d, dst3m, sizeof(double) * 3 * (size_t)M, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_gnc3d_only, dim3(1), dim3(64), 0, s.stream, d_s, d_d, M, noise_bound, gnc_factor, max_iterations,
+                     cost_threshold, d_w, d_o, d_i);
+  QTR_HIP_TRY(h, hipGetLastError());
+  double out[11];
+  QTR_HIP_TRY(h, hipMemcpyAsync(out, d_o, sizeof(out), hipMemcpyDeviceToHost, s.stream));
+  if (inliers) QTR_HIP_TRY(h, hipMemcpyAsync(inliers, d_i, (size_t)M, hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  for (int i = 0; i < 9; ++i) R9[i] = out[i];
+  if (cost) *cost = out[9];
+  if (iterations) *iterations = (int)out[10];
   return QTR_OK;
 }
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
       const int d = deg[v];
       if (d > KC_REMOVED / 2) {
         if (d <= k) {
-          deg[v] = 2 * KC_REMOVED + 1024;  // stays far below KC_REMOVED/2 under any number of decrements
+          deg[v] = KC_REMOVED;  // -2^30: at most L <= 2^15 further decrements keep it below KC_REMOVED/2, no wrap-around
           core_out[v] = k;
           queue[atomicAdd(&s_qn[p], 1)] = v;
         } else {
@@ -793,6 +793,81 @@ __device__ __forceinline__ void gnc_wave(int lane, const double* X0, const doubl
   *iters_out = iters;
 }
 
+// The 3-DoF counterpart ("next" row (f)4, reg_name "TEASER"): the same GNC-TLS loop over 3-D TIMs with the weighted
+// 3x3 rotation of qtr_math.h (teaser::utils::svdRot restated in Horn's quaternion form, reference
+// include/teaser/utils.h:123-149).  X = source, Y = destination rows; Wt = weights (in: 1).
+__device__ __forceinline__ void gnc3_wave(int lane, const double* X0, const double* X1, const double* X2, const double* Y0,
+                                          const double* Y1, const double* Y2, double* Wt, int M, double rot_nb,
+                                          double gnc_factor, int max_it, double cost_thr, double (&Rout)[9],
+                                          double* cost_out, int* iters_out) {
+  double nb_sq = rot_nb * rot_nb;
+  if (nb_sq < 1e-16) nb_sq = 1e-2;
+  double mu = 1.0, prev_cost = INFINITY, cost = INFINITY;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  int iters = 0;
+  for (int it = 0; it < max_it; ++it) {
+    iters = it + 1;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = lane; j < M; j += 64) {
+      const double w = Wt[j];
+      const double wx0 = w * X0[j], wx1 = w * X1[j], wx2 = w * X2[j];
+      const double y0 = Y0[j], y1 = Y1[j], y2 = Y2[j];
+      H[0] = H[0] + wx0 * y0;
+      H[1] = H[1] + wx0 * y1;
+      H[2] = H[2] + wx0 * y2;
+      H[3] = H[3] + wx1 * y0;
+      H[4] = H[4] + wx1 * y1;
+      H[5] = H[5] + wx1 * y2;
+      H[6] = H[6] + wx2 * y0;
+      H[7] = H[7] + wx2 * y1;
+      H[8] = H[8] + wx2 * y2;
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) H[a] = wave_sum64_f64(H[a]);
+    qm_rot3_from_h(H, R);
+    if (it == 0) {
+      double max_r = -INFINITY;
+      for (int j = lane; j < M; j += 64) {
+        const double x0 = X0[j], x1 = X1[j], x2 = X2[j];
+        const double e0 = Y0[j] - ((R[0] * x0 + R[1] * x1) + R[2] * x2);
+        const double e1 = Y1[j] - ((R[3] * x0 + R[4] * x1) + R[5] * x2);
+        const double e2 = Y2[j] - ((R[6] * x0 + R[7] * x1) + R[8] * x2);
+        max_r = fmax(max_r, (e0 * e0 + e1 * e1) + e2 * e2);
+      }
+      max_r = wave_max_f64(max_r);
+      mu = 1 / (2 * max_r / nb_sq - 1);
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * nb_sq, th2 = mu / (mu + 1) * nb_sq;
+    double cpart = 0;
+    for (int j = lane; j < M; j += 64) {
+      const double x0 = X0[j], x1 = X1[j], x2 = X2[j];
+      const double e0 = Y0[j] - ((R[0] * x0 + R[1] * x1) + R[2] * x2);
+      const double e1 = Y1[j] - ((R[3] * x0 + R[4] * x1) + R[5] * x2);
+      const double e2 = Y2[j] - ((R[6] * x0 + R[7] * x1) + R[8] * x2);
+      const double r2 = (e0 * e0 + e1 * e1) + e2 * e2;
+      cpart = cpart + Wt[j] * r2;
+      double w;
+      if (r2 >= th1)
+        w = 0;
+      else if (r2 <= th2)
+        w = 1;
+      else
+        w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
+      Wt[j] = w;
+    }
+    cost = wave_sum64_f64(cpart);
+    const double cost_diff = fabs(cost - prev_cost);
+    mu = mu * gnc_factor;
+    prev_cost = cost;
+    if (cost_diff < cost_thr) break;
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) Rout[a] = R[a];
+  *cost_out = cost;
+  *iters_out = iters;
+}
+
 // One COTE axis on one GROUP of four wavefronts (256 threads; reference estimate(), include/quatro.hpp:618-747).
 // Every thread of the workgroup calls it with identical N so that the barriers match; `act` is false for
 // threads that only keep the barriers company.  Steps:
@@ -1103,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_row_degrees(u64* __restrict__ bm, int L
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   extern __shared__ __attribute__((aligned(16))) double fin_lds[];
   __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
-  __shared__ double s_R[4], s_cost, s_est, s_bestcost;
+  __shared__ double s_R[9], s_cost, s_est, s_bestcost;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int L = A.L, W = A.W;
   SolverState* st = A.st;
@@ -1134,25 +1209,36 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
     return;
   }
 
-  // ---- scratch layout: LDS when it fits (5 arrays of M doubles), else global
+  // ---- scratch layout: LDS when it fits (5 arrays of M doubles; 7 in the 3-DoF mode), else global
   double* X0;
   double* X1;
   double* Y0;
   double* Y1;
   double* Wt;
-  const bool use_lds = ((size_t)M * 5 * sizeof(double) <= (size_t)FIN_LDS_BYTES);
+  double* X2 = nullptr;
+  double* Y2 = nullptr;
+  const bool teaser = A.prm.reg_mode == QTR_REG_TEASER;
+  const bool use_lds = ((size_t)M * (teaser ? 7 : 5) * sizeof(double) <= (size_t)FIN_LDS_BYTES);
   if (use_lds) {
     X0 = fin_lds;
     X1 = X0 + M;
     Y0 = X1 + M;
     Y1 = Y0 + M;
     Wt = Y1 + M;
+    if (teaser) {
+      X2 = Wt + M;
+      Y2 = X2 + M;
+    }
   } else {
     X0 = A.f64;
     X1 = X0 + L;
     Y0 = X1 + L;
     Y1 = Y0 + L;
     Wt = Y1 + L;
+    if (teaser) {  // the RAW area (3 L doubles) is free until the rotation is known
+      X2 = A.f64 + 5 * (size_t)L;
+      Y2 = X2 + L;
+    }
   }
   // chain TIMs over the sorted clique, XY rows (:817-844, :396-402); scale == 1
   for (int i = tid; i < M; i += nthr) {
@@ -1163,12 +1249,26 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
     Y0[i] = ((double)tl.x - (double)tr.x) * (1 / 1.0);
     Y1[i] = ((double)tl.y - (double)tr.y) * (1 / 1.0);
     Wt[i] = 1.0;
+    if (teaser) {
+      X2[i] = (double)sl.z - (double)sr.z;
+      Y2[i] = ((double)tl.z - (double)tr.z) * (1 / 1.0);
+    }
   }
   __syncthreads();
 
   const long long t_fin1 = clock64();
   // ---- GNC-TLS (wavefront 0), reference :430-572
-  if (wave == 0) {
+  if (wave == 0 && teaser) {
+    double Rg[9], costg;
+    int itersg;
+    gnc3_wave(lane, X0, X1, X2, Y0, Y1, Y2, Wt, M, A.prm.noise_bound * (2 / 1.0), A.prm.rotation_gnc_factor,
+              A.prm.rotation_max_iterations, A.prm.rotation_cost_threshold, Rg, &costg, &itersg);
+    if (lane == 0) {
+      for (int a = 0; a < 9; ++a) s_R[a] = Rg[a];
+      s_cost = costg;
+      s_iters = itersg;
+    }
+  } else if (wave == 0) {
     double Rg[4], costg;
     int itersg;
     gnc_wave(lane, X0, X1, Y0, Y1, Wt, M, A.prm.noise_bound * (2 / 1.0), A.prm.rotation_gnc_factor,
@@ -1187,6 +1287,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   const long long t_fin2 = clock64();
   // ---- rotation (yaw block, optional R * RyRx :419-423), rotation inliers (:857-874)
   double R[9] = {s_R[0], s_R[1], 0, s_R[2], s_R[3], 0, 0, 0, 1};
+  if (teaser)
+    for (int a = 0; a < 9; ++a) R[a] = s_R[a];
   if (A.prm.using_pre_estimated_ryrx) {
     double Rn[9];
     for (int r = 0; r < 3; ++r)
@@ -1397,6 +1499,14 @@ static void launch_finalize(const SolverBufs& B, const float4* src, const float4
 // B.bm and the degrees in B.deg; everything stays on `stream`.
 static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kcore_thr, hipStream_t stream) {
   const int W = (L + 63) / 64;
+  static const bool dbg_sync = getenv("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
+#define CS_DBG(name)                                                                                   \
+  do {                                                                                                 \
+    if (dbg_sync) {                                                                                    \
+      const hipError_t de = hipStreamSynchronize(stream);                                              \
+      fprintf(stderr, "[clique stage] %s done (%s)\n", name, hipGetErrorString(de));                   \
+    }                                                                                                  \
+  } while (0)
   {
     const bool q_in_lds = (size_t)2 * L * sizeof(int) <= (size_t)128 * 1024;
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
@@ -1419,14 +1529,17 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
       const int kc_threads = 1024;
       hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
                          B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
+      CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
       (void)hipMemsetAsync(B.rankof, 0, sizeof(int) * (size_t)L, stream);
       hipLaunchKernelGGL(k_rank_partial, dim3((L + 255) / 256, slices), dim3(256), 0, stream, B.core, L, B.rankof);
       hipLaunchKernelGGL(k_rank_finish, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.rankof, B.perm, B.Kp);
       hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
+      CS_DBG("rank");
     }
     hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
+    CS_DBG("k_permute");
     bool heuristic = true;
     if (mode == QTR_INLIER_KCORE_HEU) {
       hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, kcore_thr, B.st,
@@ -1442,8 +1555,10 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
                            B.gsz, B.picks_buf);
       else
         hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
+      CS_DBG("clique batch 0");
       hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
+      CS_DBG("clique scan 0");
       // Rounds 0 and 1 are enqueued unconditionally: the heuristic nearly always terminates within them (the
       // first start finds the large clique, the second batch only confirms that no start can beat it).  The
       // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
@@ -1453,10 +1568,13 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
       else
         hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
                            B.picks_buf);
+      CS_DBG("clique batch 1");
       hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
                          B.picks);
+      CS_DBG("clique scan 1");
     }
   }
+#undef CS_DBG
 }
 
 // Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host

@@ -59,6 +59,27 @@ __global__ __launch_bounds__(64) void k_gnc_only(const double* __restrict__ src,
   }
 }
 
+// GNC-TLS 3-DoF rotation on one wavefront.  src/dst: row-major 3 x M.  out: R[9], cost, then (as double) iters.
+__global__ __launch_bounds__(64) void k_gnc3d_only(const double* __restrict__ src, const double* __restrict__ dst, int M,
+                                                   double rot_nb, double gnc_factor, int max_it, double cost_thr,
+                                                   double* __restrict__ wt, double* __restrict__ out,
+                                                   unsigned char* __restrict__ inl) {
+  const int lane = threadIdx.x;
+  for (int j = lane; j < M; j += 64) wt[j] = 1.0;
+  __syncthreads();
+  double R[9], cost;
+  int iters;
+  gnc3_wave(lane, src, src + M, src + 2 * (size_t)M, dst, dst + M, dst + 2 * (size_t)M, wt, M, rot_nb, gnc_factor, max_it,
+            cost_thr, R, &cost, &iters);
+  __syncthreads();
+  for (int j = lane; j < M; j += 64) inl[j] = (wt[j] >= 0.4) ? 1 : 0;
+  if (lane == 0) {
+    for (int a = 0; a < 9; ++a) out[a] = R[a];
+    out[9] = cost;
+    out[10] = (double)iters;
+  }
+}
+
 // COTE on one group of four wavefronts (uniform range).  scratch: 14*N doubles + 2*N ints of global memory.
 __global__ __launch_bounds__(256) void k_cote_only(const double* __restrict__ X, int N, double range, int median_sel,
                                                    double* __restrict__ scratch_f, int* __restrict__ scratch_i,

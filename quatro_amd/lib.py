@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libquatro_hip.so")
 QTR_OK, QTR_ERR_BAD_ARG, QTR_ERR_CLIQUE_TOO_SMALL, QTR_ERR_CAPACITY, QTR_ERR_HIP, QTR_ERR_UNSUPPORTED = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
 INLIER_PMC_EXACT, INLIER_PMC_HEU, INLIER_KCORE_HEU, INLIER_NONE = range(4)
+REG_QUATRO, REG_TEASER = 0, 1
 
 DBG_GRAPH_BITMAP, DBG_CORE, DBG_PERM, DBG_NBR_OFFSETS, DBG_NBR_INDEX, DBG_NBR_DIST2, DBG_SPFH = 1, 2, 3, 4, 5, 6, 7
 DBG_NN_LARGE_OF_SMALL, DBG_NN_SMALL_OF_LARGE, DBG_VOX_SRC, DBG_VOX_TGT, DBG_CORR, DBG_MATCH_STATS = 8, 9, 10, 11, 12, 13
@@ -33,7 +34,7 @@ class Params(C.Structure):
         ("cote_noise_bound", C.c_double), ("ryrx", C.c_double * 9),
         ("rotation_max_iterations", C.c_int), ("inlier_selection_mode", C.c_int), ("cote_median", C.c_int),
         ("using_rot_inliers_when_estimating_cote", C.c_int), ("using_pre_estimated_ryrx", C.c_int),
-        ("reserved", C.c_int),
+        ("reg_mode", C.c_int),
     ]
 
 
@@ -77,7 +78,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
 ]
 
 _lib = None
@@ -181,6 +182,7 @@ def load():
     lib.qtr_gnc_rotation2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                        C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                        C.c_void_p]
+    lib.qtr_gnc_rotation3d.argtypes = lib.qtr_gnc_rotation2d.argtypes
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
     lib.qtr_set_clique_time_limit.argtypes = [C.c_void_p, C.c_double]
@@ -410,6 +412,20 @@ class Handle:
                                                  gnc_factor, max_iter, cost_thr, R.ctypes.data, C.byref(cost),
                                                  C.byref(iters), inl.ctypes.data))
         return R.reshape(2, 2), cost.value, iters.value, inl.astype(bool)
+
+    def gnc_rotation3d(self, src3, dst3, noise_bound: float, gnc_factor: float = 1.4, max_iter: int = 50,
+                       cost_thr: float = 1.1e-4, slot: int = 0):
+        """src3/dst3: (M, 3) TIMs -> (R 3x3, cost, iterations, inlier mask); reg_name "TEASER"."""
+        s3 = np.ascontiguousarray(np.asarray(src3, dtype=np.float64).T)
+        d3 = np.ascontiguousarray(np.asarray(dst3, dtype=np.float64).T)
+        M = s3.shape[1]
+        R = np.zeros(9)
+        cost, iters = C.c_double(), C.c_int()
+        inl = np.zeros(M, dtype=np.uint8)
+        self._check(self._lib.qtr_gnc_rotation3d(self._h, slot, s3.ctypes.data, d3.ctypes.data, M, noise_bound,
+                                                 gnc_factor, max_iter, cost_thr, R.ctypes.data, C.byref(cost),
+                                                 C.byref(iters), inl.ctypes.data))
+        return R.reshape(3, 3), cost.value, iters.value, inl.astype(bool)
 
     def cote_estimate(self, X, rng: float, median: bool = True, slot: int = 0):
         X = np.ascontiguousarray(X, dtype=np.float64)

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.abspath(ROOT))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a device kernel that never returns must fail ONE test, not hang the whole run (pytest-timeout, when installed)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 300
 
 
 @pytest.fixture(scope="session")

@@ -421,7 +421,8 @@ def _random_graph_bitmap(L, p, seed, planted=0):
 
 
 @pytest.mark.parametrize("L,p,planted,seed", [(1, 0.0, 0, 0), (2, 1.0, 0, 0), (65, 0.3, 0, 1), (200, 0.05, 12, 2),
-                                              (777, 0.02, 25, 3), (1500, 0.3, 40, 4), (3000, 0.01, 30, 5)])
+                                              (777, 0.02, 25, 3), (1500, 0.3, 40, 4), (3000, 0.01, 30, 5),
+                                              (2600, 0.01, 1300, 6), (6000, 0.005, 2500, 7)])
 def test_max_clique_entry_matches_oracle(hip, qo, L, p, planted, seed):
     """qtr_max_clique (the teaser::MaxCliqueSolver boundary) on arbitrary graphs, both heuristic modes."""
     bm, A = _random_graph_bitmap(L, p, seed, planted)
@@ -952,3 +953,61 @@ def test_exact_time_limit_returns_heuristic(hip, qo):
         hip.set_clique_time_limit(3600.0)
     heu, _ = hip.max_clique(bm, 1)
     assert st["aborted"] and np.array_equal(got, heu)
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row (f)4, second half: 3-DoF rotation (reg_name "TEASER")
+def _planted_3dof(L, frac, seed, noise=0.02):
+    from scipy.spatial.transform import Rotation as Rt
+    rng = np.random.default_rng(seed)
+    src = np.zeros((L, 4), dtype=np.float32)
+    src[:, :3] = rng.uniform(-20, 20, (L, 3))
+    Rm = Rt.from_euler("zyx", rng.uniform(-60, 60, 3), degrees=True).as_matrix()
+    tv = rng.uniform(-3, 3, 3)
+    tgt = np.zeros((L, 4), dtype=np.float32)
+    tgt[:, :3] = src[:, :3] @ Rm.T + tv + rng.normal(0, noise, (L, 3))
+    out = rng.random(L) >= frac
+    tgt[out, :3] = rng.uniform(-20, 20, (int(out.sum()), 3))
+    return src, tgt, Rm, tv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,seed", [(1, 0), (2, 1), (63, 2), (64, 3), (200, 4), (1000, 5), (5000, 6)])
+def test_gnc_rotation3d_matches_oracle(hip, qo, M, seed):
+    """qtr_gnc_rotation3d (teaser::utils::svdRot inside TEASER++'s GNC-TLS loop): R, cost, iteration count and inlier
+    mask bit for bit against the CPU restatement; R within 1e-4 rad of the planted rotation when there is one."""
+    from scipy.spatial.transform import Rotation as Rt
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-10, 10, (M, 3))
+    Rm = Rt.from_euler("zyx", rng.uniform(-90, 90, 3), degrees=True).as_matrix()
+    Y = X @ Rm.T + rng.normal(0, 0.02, (M, 3))
+    bad = rng.random(M) < 0.3
+    Y[bad] = rng.uniform(-10, 10, (int(bad.sum()), 3))
+    for nb, it in ((0.6, 50), (0.1, 100), (0.6, 1)):
+        Ro, co, io, mo = qo.gnc_rotation3d(X, Y, nb, 1.4, it, 1.1e-4)
+        Rg, cg, ig, mg = hip.gnc_rotation3d(X, Y, nb, 1.4, it, 1.1e-4)
+        assert np.array_equal(Rg, Ro) and ig == io and np.array_equal(mg, mo)
+        assert cg == co or (np.isinf(cg) and np.isinf(co))
+    if M >= 200:
+        ang = np.arccos(np.clip((np.trace(Rg.T @ Rm) - 1) / 2, -1, 1))
+        Rg, *_ = hip.gnc_rotation3d(X, Y, 0.6, 1.4, 50, 1.1e-4)
+        assert np.arccos(np.clip((np.trace(Rg.T @ Rm) - 1) / 2, -1, 1)) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,frac,seed", [(300, 0.4, 1), (1000, 0.2, 2), (3000, 0.1, 3), (12000, 0.3, 4)])
+def test_teaser_mode_through_the_solver(hip, qo, L, frac, seed):
+    """qtr_solve with reg_mode = QTR_REG_TEASER: clique, rotation inliers, 3-DoF rotation, COTE translation against the
+    oracle, and the planted 6-DoF transform recovered (which the yaw-only mode cannot do)."""
+    src, tgt, Rm, tv = _planted_3dof(L, frac, seed)
+    g = hip.solve(src, tgt, ql.demo_params(reg_mode=ql.REG_TEASER))
+    o = qo.solve(src, tgt, qo.default_params(reg_mode=1))
+    _assert_same_solution(g, o)
+    assert g["valid"]
+    ang = np.arccos(np.clip((np.trace(g["T"][:3, :3].T @ Rm) - 1) / 2, -1, 1))
+    assert ang < 5e-3 and np.abs(g["T"][:3, 3] - tv).max() < 0.05
+    with pytest.raises(ql.QuatroHipError) as e:
+        hip.solve(src, tgt, ql.demo_params(reg_mode=ql.REG_TEASER, using_pre_estimated_ryrx=1))
+    assert e.value.code == ql.QTR_ERR_BAD_ARG
+    with pytest.raises(ql.QuatroHipError):
+        hip.solve(src, tgt, ql.demo_params(reg_mode=7))
