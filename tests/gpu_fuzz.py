@@ -1,0 +1,170 @@
+"""Randomised GPU-vs-oracle sweep (run on the GPU box: python tests/gpu_fuzz.py [seed] [budget_s]).  Prints one line per
+mismatch and a summary; exits 1 on any mismatch.  Not collected by pytest (no test_ prefix)."""
+import faulthandler
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
+faulthandler.dump_traceback_later(int(sys.argv[3]) if len(sys.argv) > 3 else 240, exit=True)
+import torch  # noqa: F401,E402
+from oracle import oracle as qo  # noqa: E402
+from quatro_amd import lib as ql  # noqa: E402
+from quatro_amd import synth  # noqa: E402
+from test_gpu_parity import _random_graph_bitmap  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+rng = np.random.default_rng(seed)
+h = ql.Handle(0)
+qo.build()
+qo.set_threads(qo.max_threads())
+bad, n_cases, t_end = 0, 0, time.time() + budget
+
+
+def report(kind, desc, what):
+    global bad
+    bad += 1
+    print(f"MISMATCH {kind} {desc}: {what}", flush=True)
+
+
+def same_solution(g, o):
+    if g["status"] != o["status"] and not (g["status"] == ql.QTR_ERR_CLIQUE_TOO_SMALL and o["status"] == 1):
+        return f"status {g['status']} vs {o['status']}"
+    if g["valid"] != o["valid"]:
+        return "valid"
+    if not np.array_equal(g["clique"], np.sort(o["clique"])):
+        return f"clique {g['clique'].size} vs {o['clique'].size}"
+    if not g["valid"]:
+        return None
+    if not np.array_equal(g["rot_inliers"], o["rot_inliers"]):
+        return "rot_inliers"
+    if not np.array_equal(g["final_inliers"], o["final_inliers"]):
+        return "final_inliers"
+    if g["gnc_iters"] != o["gnc_iters"]:
+        return "gnc_iters"
+    if not np.array_equal(g["T"], o["T"]):
+        return f"T max diff {np.abs(g['T'] - o['T']).max()}"
+    return None
+
+
+while time.time() < t_end:
+    kind = rng.choice(["solve", "solve", "clique", "pair", "patchwork", "segment", "gnc3", "cote"])
+    n_cases += 1
+    try:
+        if kind == "solve":
+            L = int(rng.choice([2, 3, 5, 17, 64, 65, 300, 1281, 2000, 4097, 7000]))
+            frac = float(rng.choice([0.0, 0.02, 0.1, 0.5, 0.9, 1.0]))
+            noise = float(rng.choice([0.0, 0.02, 0.1]))
+            kw = {}
+            if rng.random() < 0.4:
+                kw["inlier_selection_mode"] = int(rng.choice([0, 1, 2]))
+            if rng.random() < 0.3:
+                kw["reg_mode"] = 1
+            if rng.random() < 0.3:
+                kw["cote_median"] = 0
+            if rng.random() < 0.3:
+                kw["using_rot_inliers_when_estimating_cote"] = 1
+            if rng.random() < 0.3:
+                kw["noise_bound"] = float(rng.choice([0.05, 0.6]))
+            if kw.get("inlier_selection_mode") == 0 and L > 2000 and frac < 0.05:
+                kw["inlier_selection_mode"] = 1  # keep the exact search short
+            src, tgt, _, _ = synth.correspondences(L, frac, seed=int(rng.integers(1 << 30)), noise=noise)
+            desc = f"L={L} frac={frac} noise={noise} {kw}"
+            g = h.solve(src, tgt, ql.demo_params(**kw))
+            o = qo.solve(src, tgt, qo.default_params(**kw))
+            w = same_solution(g, o)
+            if w:
+                report(kind, desc, w)
+        elif kind == "clique":
+            L = int(rng.choice([1, 2, 63, 64, 65, 129, 500, 1280, 1281, 2500, 5000]))
+            p = float(rng.choice([0.0, 0.01, 0.05, 0.3, 0.9, 1.0]))
+            if L > 600 and p > 0.3:
+                p = 0.05
+            planted = int(rng.choice([0, 0, 5, L // 10, L // 2])) if L > 10 else 0
+            bm, A = _random_graph_bitmap(L, p, int(rng.integers(1 << 30)), planted)
+            modes = [(1, 0.5), (2, 0.5), (2, 0.1)]
+            if L <= 600 or p <= 0.05:
+                modes.append((0, 0.5))
+            for mode, thr in modes:
+                if mode == 0 and L > 300 and p >= 0.3:
+                    continue
+                ref = np.sort(qo.max_clique(bm, mode, thr))
+                got, _ = h.max_clique(bm, mode, thr)
+                if not np.array_equal(got, ref if mode != 2 else qo.max_clique(bm, mode, thr)):
+                    report(kind, f"L={L} p={p} planted={planted} mode={mode} thr={thr}", f"{got.size} vs {ref.size}")
+        elif kind == "pair":
+            pid = int(rng.integers(0, 50))
+            s, t, _ = synth.kitti64_pair(pid)
+            keep = float(rng.choice([0.05, 0.3, 1.0]))
+            s = s[rng.random(s.shape[0]) < keep]
+            t = t[rng.random(t.shape[0]) < keep]
+            leaf = float(rng.choice([0.3, 0.5, 1.0]))
+            fp = ql.default_frontend_params(seed=pid, voxel_size=leaf, normal_radius=leaf * 5 / 3, fpfh_radius=leaf * 2.5)
+            desc = f"pair={pid} keep={keep} leaf={leaf} n=({s.shape[0]},{t.shape[0]})"
+            g = h.register_pair(s, t, fp)
+            o = qo.register_pair(s, t, leaf=leaf, r_normal=leaf * 5 / 3, r_fpfh=leaf * 2.5, seed=pid)
+            if (g["n_src"], g["n_tgt"], g["L"]) != (o["n_src"], o["n_tgt"], o["L"]):
+                report(kind, desc, f"counts {(g['n_src'], g['n_tgt'], g['L'])} vs {(o['n_src'], o['n_tgt'], o['L'])}")
+            else:
+                w = same_solution(g, o)
+                if w:
+                    report(kind, desc, w)
+        elif kind == "patchwork":
+            sid = int(rng.integers(0, 50))
+            xyzi, _ = synth.kitti64_raw_scan(sid)
+            keep = float(rng.choice([0.02, 0.3, 1.0]))
+            xyzi = xyzi[rng.random(xyzi.shape[0]) < keep]
+            po, pg = qo.pw_params(), ql.pw_params()
+            if rng.random() < 0.5:
+                for p in (po, pg):
+                    p.num_iter = int(rng.integers(1, 5))
+                    p.num_lpr = int(rng.choice([1, 20, 300]))
+                    p.num_min_pts = int(rng.choice([0, 10, 80]))
+                    p.th_dist = float(rng.choice([0.05, 0.125, 0.3]))
+                rng_state = None
+            a, b = h.patchwork(xyzi, pg), qo.patchwork(xyzi, po)
+            if not (np.array_equal(a["ground"].view(np.uint32), b["ground"].view(np.uint32)) and
+                    np.array_equal(a["nonground"].view(np.uint32), b["nonground"].view(np.uint32))):
+                report(kind, f"scan={sid} keep={keep} it={pg.num_iter} lpr={pg.num_lpr} min={pg.num_min_pts}",
+                       f"{a['ground'].shape[0]}/{a['nonground'].shape[0]} vs {b['ground'].shape[0]}/{b['nonground'].shape[0]}")
+        elif kind == "segment":
+            pid = int(rng.integers(0, 50))
+            s, _, _ = synth.kitti64_pair(pid)
+            keep = float(rng.choice([0.05, 0.5, 1.0]))
+            s = s[rng.random(s.shape[0]) < keep]
+            lidar = str(rng.choice(["Velodyne-64-HDE", "VLP-16", "HDL-32E", "Ouster-OS1-64"]))
+            mode = str(rng.choice(["4Neighbor", "4CrossNeighbor", "8Neighbor"]))
+            mp = int(rng.choice([5, 30, 100]))
+            try:
+                ip_o, ip_g = qo.ip_params(lidar, mode, mp), ql.ip_params(lidar, mode, mp)
+            except Exception:
+                continue
+            a, b = h.segment_cloud(s, ip_g), qo.segment_cloud(s, ip_o)
+            if not (np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["valid"], b["valid"]) and
+                    np.array_equal(a["outliers"], b["outliers"])):
+                report(kind, f"pair={pid} keep={keep} {lidar} {mode} {mp}", "labels/valid/outliers")
+        elif kind == "gnc3":
+            M = int(rng.choice([1, 2, 3, 64, 65, 500, 4000]))
+            X = rng.uniform(-10, 10, (M, 3))
+            Y = X + rng.normal(0, float(rng.choice([0.0, 0.05, 3.0])), (M, 3))
+            nb = float(rng.choice([1e-9, 0.1, 0.6]))
+            a, b = h.gnc_rotation3d(X, Y, nb, 1.4, 50, 1.1e-4), qo.gnc_rotation3d(X, Y, nb, 1.4, 50, 1.1e-4)
+            if not (np.array_equal(a[0], b[0]) and a[2] == b[2] and np.array_equal(a[3], b[3])):
+                report(kind, f"M={M} nb={nb}", f"iters {a[2]} vs {b[2]}")
+        elif kind == "cote":
+            N = int(rng.choice([1, 2, 3, 64, 255, 256, 257, 1000, 5000]))
+            X = rng.normal(0, float(rng.choice([0.0, 0.1, 5.0])), N)
+            if rng.random() < 0.3:
+                X = np.round(X, 1)  # ties
+            r = float(rng.choice([0.05, 0.3]))
+            med = bool(rng.integers(0, 2))
+            a, b = h.cote_estimate(X, r, med), qo.cote_estimate(X, r, med)
+            if not (a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]):
+                report(kind, f"N={N} r={r} med={med}", f"{a[0]} vs {b[0]} ncard {a[2]} vs {b[2]}")
+    except ql.QuatroHipError as e:
+        report(kind, "exception", f"{e}")
+print(f"fuzz seed={seed}: {n_cases} cases, {bad} mismatches", flush=True)
+sys.exit(1 if bad else 0)

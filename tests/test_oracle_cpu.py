@@ -545,3 +545,49 @@ def test_exact_clique_is_maximum_and_defined(qo):
             beaten += 1
         assert np.array_equal(qo.max_clique(bm, 0), ce)  # deterministic
     assert beaten >= 2
+
+
+def test_rot3_matches_svd_construction(qo):
+    """qm_rot3_from_h (Horn quaternion form) against teaser::utils::svdRot's construction with numpy's SVD
+    (reference include/teaser/utils.h:123-149: V diag(1, 1, det) U^T): same matrix when H is well conditioned, same
+    objective and a proper rotation always."""
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for trial in range(500):
+        n = int(rng.integers(1, 30))
+        X, Y = rng.standard_normal((3, n)), rng.standard_normal((3, n))
+        if trial % 7 == 0:
+            X[2] = 0
+            Y[2] = 0
+        w = rng.random(n)
+        H = (X * w) @ Y.T
+        U, S, Vt = np.linalg.svd(H)
+        V = Vt.T
+        if np.linalg.det(U) * np.linalg.det(V) < 0:
+            V[:, 2] *= -1
+        Rref = V @ U.T
+        R = qo.rot3_from_h(H)
+        assert abs(np.linalg.det(R) - 1) < 1e-12 and np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+        assert np.trace(R @ H) >= np.trace(Rref @ H) - 1e-9 * max(1.0, abs(np.trace(Rref @ H)))
+        if n >= 3 and trial % 7 and S[1] > 1e-6 * S[0]:
+            worst = max(worst, np.abs(R - Rref).max())
+    assert worst < 1e-10
+    assert np.array_equal(qo.rot3_from_h(np.zeros((3, 3))), np.eye(3))
+
+
+def test_gnc_rotation3d_recovers_rotation_and_flags_outliers(qo):
+    from scipy.spatial.transform import Rotation as Rt
+    rng = np.random.default_rng(1)
+    M = 400
+    X = rng.uniform(-10, 10, (M, 3))
+    Rm = Rt.from_euler("zyx", [50, -20, 10], degrees=True).as_matrix()
+    Y = X @ Rm.T + rng.normal(0, 0.02, (M, 3))
+    bad = rng.random(M) < 0.4
+    Y[bad] = rng.uniform(-10, 10, (int(bad.sum()), 3))
+    R, cost, iters, mask = qo.gnc_rotation3d(X, Y, 0.2, 1.4, 100, 1e-6)
+    ang = np.arccos(np.clip((np.trace(R.T @ Rm) - 1) / 2, -1, 1))
+    assert ang < 2e-3 and 1 < iters < 100
+    assert mask[~bad].mean() > 0.98 and mask[bad].mean() < 0.05
+    # no outliers and a generous bound: the degenerate-mu exit after one iteration, all inliers
+    R1, _, it1, m1 = qo.gnc_rotation3d(X, X @ Rm.T, 5.0, 1.4, 100, 1e-6)
+    assert it1 == 1 and m1.all() and np.abs(R1 - Rm).max() < 1e-9
