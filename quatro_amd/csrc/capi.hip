@@ -311,9 +311,10 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
     return QTR_ERR_CAPACITY;
   }
   const int depth_cap = hs.ub + 1;
-  int nwaves = 2048;
+  const size_t small_lds = exact_small_lds(L, W, hs.t0, depth_cap);
+  int nwaves = small_lds ? 1024 : 2048;
   while (nwaves > 64 && exact_scratch_bytes(W, depth_cap, nwaves) > ((size_t)768 << 20)) nwaves >>= 1;
-  if (nwaves > L) nwaves = L < 1 ? 1 : L;
+  if (!small_lds && nwaves > L) nwaves = L < 1 ? 1 : L;
   const size_t need = exact_scratch_bytes(W, depth_cap, nwaves);
   if (need > s.ex_bytes) {
     if (s.ex_arena) (void)hipFree(s.ex_arena);
@@ -325,7 +326,7 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
   exact_carve(s.exb, s.ex_arena, depth_cap, nwaves);
   const long long ticks = h->clique_time_limit > 0 ? (long long)(h->clique_time_limit * 1e8) : 0;  // 100 MHz counter
   hipLaunchKernelGGL(k_exact_init, dim3(1), dim3(1), 0, s.stream, s.sb.Kp, L, s.sb.st, s.exb.ctl);
-  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 0, ticks, s.stream);
+  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 0, ticks, s.stream, hs.t0, small_lds);
   ExactCtl* hc = (ExactCtl*)(s.pinned_i32 + 192);
   QTR_HIP_TRY(h, hipMemcpyAsync(hc, s.exb.ctl, sizeof(ExactCtl), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -337,7 +338,7 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
   if (hc->gbest <= hs.mc) return QTR_OK;
   QTR_HIP_TRY(h, hipMemsetAsync(s.exb.cliq, 0xff, (size_t)nwaves * (depth_cap + 2) * sizeof(int), s.stream));
   hipLaunchKernelGGL(k_exact_phase_b, dim3(1), dim3(1), 0, s.stream, s.sb.Kp, L, s.exb.ctl);
-  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 1, ticks, s.stream);
+  exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 1, ticks, s.stream, hs.t0, small_lds);
   hipLaunchKernelGGL(k_exact_commit, dim3(1), dim3(256), 0, s.stream, s.exb.ctl, s.exb.cliq, nwaves, depth_cap, s.sb.st,
                      s.sb.picks);
   QTR_HIP_TRY(h, hipMemcpyAsync(hc, s.exb.ctl, sizeof(ExactCtl), hipMemcpyDeviceToHost, s.stream));

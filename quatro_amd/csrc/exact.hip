@@ -18,10 +18,11 @@
 struct ExactCtl {
   int gbest;       // phase A incumbent size; omega afterwards
   int next_root;   // next root rank to hand out
-  int first_root;  // phase B: lowest root whose subtree holds a clique of size omega (INT_MAX none)
+  int first_root;  // phase B: lowest (root << 16 | top-level child index) whose subtree holds a clique of size omega
   int t0;          // first rank with Kp > lb
   int abort;       // time limit hit
   int lb, ub, winner;
+  int task;        // small-graph kernel: next (root, slice) task of the current launch
   unsigned long long nodes;
   long long t_start;
 };
@@ -42,6 +43,7 @@ __global__ void k_exact_init(const int* __restrict__ Kp, int L, const SolverStat
   ctl->first_root = INT_MAX;
   ctl->abort = 0;
   ctl->winner = -1;
+  ctl->task = 0;
   ctl->nodes = 0;
   ctl->t_start = (long long)wall_clock64();
 }
@@ -56,6 +58,7 @@ __global__ void k_exact_phase_b(const int* __restrict__ Kp, int L, ExactCtl* ctl
   }
   ctl->next_root = lo;
   ctl->first_root = INT_MAX;
+  ctl->task = 0;
 }
 
 template <int NW>
@@ -214,6 +217,157 @@ __global__ __launch_bounds__(64) void k_exact_search(const u64* __restrict__ adj
   if (lane == 0 && nodes) atomicAdd(&ctl->nodes, nodes);
 }
 
+// Small candidate sets (the ranks >= t0 fit 64 words and, with the per-level stack, 60 KB of LDS): adjacency rows and the
+// stack live in LDS, and the top-level branches of a root are dealt round-robin to SLICES tasks — a root of a small
+// dense graph is a whole search on its own, so roots alone leave the chip idle.  Task (root r, slice s) walks r's
+// children in descending rank, expands those whose index i has i mod SLICES = s (the earlier children are removed from
+// the candidate set exactly as the sequential search would have done), and in phase B reports the key (r << 16 | i):
+// the lowest key is the first maximum clique of the depth-first order.
+#define EX_SLICES 32
+__global__ __launch_bounds__(64) void k_exact_search_small(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L, int W,
+                                                           ExactCtl* ctl, int depth_cap, int* __restrict__ cliq, int phase_b,
+                                                           long long tick_limit, int t0_host) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ex_lds[];
+  const int lane = threadIdx.x, wave = blockIdx.x;
+  const int t0 = t0_host, w0 = t0 >> 6, Wq = W - w0, n = L - (w0 << 6);  // rows / bits are relative to rank w0 * 64
+  if (ctl->t0 != t0_host) {  // the host sized the LDS from its copy of the search state: they must agree
+    if (lane == 0) ctl->abort = 1;
+    return;
+  }
+  u64* rows = (u64*)ex_lds;                         // [n][Wq]
+  u64* stk = rows + (size_t)n * Wq;                 // [depth_cap][Wq]
+  int* Cl = (int*)(stk + (size_t)depth_cap * Wq);   // [depth_cap + 2]
+  for (int e = lane; e < n * Wq; e += 64) {
+    const int v = e / Wq, j = e - v * Wq;
+    rows[e] = adjP[(size_t)(v + (w0 << 6)) * W + w0 + j];
+  }
+  __syncthreads();
+  int* mine = cliq + (size_t)wave * (depth_cap + 2);
+  volatile int* v_gbest = &ctl->gbest;
+  volatile int* v_first = &ctl->first_root;
+  volatile int* v_abort = &ctl->abort;
+  const int omega = ctl->gbest;
+  const long long t_start = ctl->t_start;
+  const int r_begin = phase_b ? ctl->next_root : t0;  // (next_root holds phase B's first root; tasks count from it)
+  unsigned long long nodes = 0;
+  bool finished = false;
+  const int wl = lane < Wq ? lane : 0;
+  const bool act = lane < Wq;
+  auto count = [&](u64 x) { return wave_sum_i32(act ? __popcll(x) : 0); };
+  auto highest = [&](u64 x) { return wave_max_i32((act && x) ? lane * 64 + 63 - __clzll((long long)x) : -1); };
+  auto colour_bound = [&](u64 pp, int limit) {
+    u64 u = pp;
+    int colours = 0;
+    while (__any(act && u != 0)) {
+      if (++colours > limit) return limit + 1;
+      u64 q = u;
+      while (true) {
+        const int v = highest(q);
+        if (v < 0) break;
+        if (lane == (v >> 6)) {
+          q &= ~(1ULL << (v & 63));
+          u &= ~(1ULL << (v & 63));
+        }
+        q &= ~rows[(size_t)v * Wq + wl];
+      }
+    }
+    return colours;
+  };
+  while (!finished) {
+    int task = 0;
+    if (lane == 0) task = atomicAdd(&ctl->task, 1);
+    task = __shfl(task, 0, 64);
+    const int r = r_begin + task / EX_SLICES, slice = task % EX_SLICES;
+    if (r >= L || *v_abort) break;
+    if (phase_b && r > (*v_first >> 16)) break;
+    int thr = phase_b ? omega - 1 : *v_gbest;
+    if (Kp[r] <= thr) continue;
+    const int rr = r - (w0 << 6);
+    u64 p = act ? rows[(size_t)rr * Wq + lane] : 0ULL;
+    if (lane < (rr >> 6)) p = 0;
+    else if (lane == (rr >> 6)) p &= ~((2ULL << (rr & 63)) - 1ULL);
+    if (lane == 0) Cl[0] = r;
+    int d = 0, size = 1, top_i = 0, cur_i = 0;
+    bool root_done = false;
+    while (!root_done) {
+      ++nodes;
+      if ((nodes & 63) == 0) {
+        if (tick_limit > 0 && (long long)wall_clock64() - t_start > tick_limit && lane == 0) ctl->abort = 1;
+        if (*v_abort) {
+          finished = true;
+          break;
+        }
+      }
+      if (!phase_b) thr = *v_gbest;
+      else if (((r << 16) | cur_i) > *v_first) break;
+      bool prune = false;
+      int u = -1;
+      if (d == 0) {
+        // next child of the root that belongs to this slice
+        while (true) {
+          const int cnt = count(p);
+          if (cnt == 0 || 1 + cnt <= thr) {
+            root_done = true;
+            break;
+          }
+          u = highest(p);
+          const int i = top_i++;
+          if (i % EX_SLICES == slice) {
+            cur_i = i;
+            break;
+          }
+          if (lane == (u >> 6)) p &= ~(1ULL << (u & 63));
+        }
+        if (root_done) break;
+        if (phase_b && ((r << 16) | cur_i) > *v_first) break;
+        if (1 + colour_bound(p, thr - 1) <= thr) break;  // prunes this child and every later one
+      } else {
+        const int cnt = count(p);
+        if (cnt == 0) {
+          prune = true;
+          if (size > thr) {
+            if (!phase_b) {
+              if (lane == 0) atomicMax(&ctl->gbest, size);
+            } else {
+              __syncthreads();
+              for (int i = lane; i < size; i += 64) mine[2 + i] = Cl[i];
+              if (lane == 0) {
+                mine[1] = size;
+                mine[0] = (r << 16) | cur_i;
+                __threadfence();
+                atomicMin(&ctl->first_root, (r << 16) | cur_i);
+              }
+              finished = true;
+              break;
+            }
+          }
+        } else if (size + cnt <= thr) {
+          prune = true;
+        } else {
+          prune = size + colour_bound(p, thr - size) <= thr;
+        }
+        if (!prune) u = highest(p);
+      }
+      if (!prune) {
+        const int uu = u;  // relative to rank w0 * 64, like every bit index here
+        if (lane == (uu >> 6)) p &= ~(1ULL << (uu & 63));
+        if (act) stk[(size_t)d * Wq + lane] = p;
+        p &= rows[(size_t)uu * Wq + wl];
+        if (!act) p = 0;
+        if (lane == 0) Cl[size] = uu + (w0 << 6);
+        ++size;
+        ++d;
+        continue;
+      }
+      if (d == 0) break;
+      --d;
+      --size;
+      p = act ? stk[(size_t)d * Wq + lane] : 0ULL;
+    }
+  }
+  if (lane == 0 && nodes) atomicAdd(&ctl->nodes, nodes);
+}
+
 // the clique of the lowest successful root becomes the search result of solver.hip's state (best_r + picks)
 __global__ __launch_bounds__(256) void k_exact_commit(ExactCtl* ctl, const int* __restrict__ cliq, int nwaves, int depth_cap,
                                                       SolverState* st, int* __restrict__ picks) {
@@ -235,6 +389,14 @@ __global__ __launch_bounds__(256) void k_exact_commit(ExactCtl* ctl, const int* 
     st->best_r = mine[2];
     ctl->winner = w;
   }
+}
+
+// LDS bytes of the small-graph kernel (0: does not apply)
+static size_t exact_small_lds(int L, int W, int t0, int depth_cap) {
+  const int w0 = t0 >> 6, Wq = W - w0, n = L - (w0 << 6);
+  if (Wq < 1 || Wq > 64) return 0;
+  const size_t bytes = ((size_t)n * Wq + (size_t)depth_cap * Wq) * 8 + (size_t)(depth_cap + 2) * 4;
+  return bytes <= (size_t)60 * 1024 ? bytes : 0;
 }
 
 static int exact_nw(int W) { return W <= 64 ? 1 : W <= 128 ? 2 : W <= 256 ? 4 : W <= 512 ? 8 : 0; }
@@ -260,8 +422,13 @@ static void exact_carve(ExactBufs& E, void* base, int depth_cap, int nwaves) {
 }
 
 static void exact_launch_search(const SolverBufs& B, const ExactBufs& E, int L, int depth_cap, int nwaves, int phase_b,
-                                long long tick_limit, hipStream_t st) {
+                                long long tick_limit, hipStream_t st, int t0_host, size_t small_lds) {
   const int W = (L + 63) / 64;
+  if (small_lds) {
+    hipLaunchKernelGGL(k_exact_search_small, dim3(nwaves), dim3(64), small_lds, st, B.adjP, B.Kp, L, W, E.ctl, depth_cap,
+                       E.cliq, phase_b, tick_limit, t0_host);
+    return;
+  }
   const size_t lds = (size_t)(depth_cap + 2) * sizeof(int);
 #define EX_LAUNCH(NWV)                                                                                              \
   hipLaunchKernelGGL(k_exact_search<NWV>, dim3(nwaves), dim3(64), lds, st, B.adjP, B.Kp, L, W, E.ctl, E.stack, depth_cap, \
