@@ -221,7 +221,7 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
     QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   } else {
     for (unsigned long spins = 1;; ++spins) {
-      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return QTR_OK;
+      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) break;  // now make sure the payload it announces is complete
       if ((spins & 0xffff) == 0) {
         const hipError_t q = hipStreamQuery(s.stream);
         if (q == hipSuccess) break;  // stream drained: the word must be there now (checked below)
@@ -235,7 +235,44 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
     snprintf(h->err, sizeof(h->err), "mailbox word %d holds %d, expected %d (phase kernel did not run)", idx, (int)*p, seq);
     return QTR_ERR_HIP;
   }
-  return QTR_OK;
+  // the payload is consumed only once its tag matches (common.h, mail_store_line): the sequence word can reach host
+  // memory before the counters it announces
+  auto line_ok = [&](int base) {
+    const volatile int* l = s.mail + base;
+    int x = 0;
+    for (int i = 0; i < 15; ++i) x ^= l[i];
+    return l[15] == (seq ^ x ^ MAIL_TAG_SALT);
+  };
+  auto solver_ok = [&]() {
+    const volatile int* m = s.mail + MAIL_SOLVER;
+    int x = 0;
+    for (int i = 0; i < (int)(sizeof(qtr_result) / 4); ++i) x ^= m[i];
+    for (int i = 0; i < (int)(sizeof(SolverState) / 4); ++i) x ^= m[64 + i];
+    return m[63] == (seq ^ x ^ MAIL_TAG_SALT);
+  };
+  auto payload_ok = [&]() {
+    switch (idx) {
+      case MAIL_SEQ_VOX0: return line_ok(MAIL_VOX0);
+      case MAIL_SEQ_VOX1: return line_ok(MAIL_VOX1);
+      case MAIL_SEQ_MATCH: return line_ok(MAIL_MATCH) && line_ok(MAIL_CNT0) && line_ok(MAIL_CNT1);
+      case MAIL_SEQ_SOLVE: return solver_ok();
+      default: return true;
+    }
+  };
+  bool drained = false;
+  for (unsigned long spins = 1;; ++spins) {
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (payload_ok()) return QTR_OK;
+    if ((spins & 0x3fff) == 0) {
+      if (drained) break;  // the stream was idle one round ago and the payload still does not add up
+      const hipError_t q = hipStreamSynchronize(s.stream);
+      if (q != hipSuccess) QTR_HIP_TRY(h, q);
+      drained = true;
+    }
+    __builtin_ia32_pause();
+  }
+  snprintf(h->err, sizeof(h->err), "mailbox payload of word %d does not match its tag (sequence %d)", idx, seq);
+  return QTR_ERR_HIP;
 }
 #define QTR_TRY(expr)                  \
   do {                                 \

@@ -68,6 +68,22 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int* total) {
   return x - v;
 }
 
+// ---- host mailbox lines --------------------------------------------------------------------------
+// A mailbox payload line is 16 ints in pinned host memory: words 0..14 carry data, word 15 a tag = seq ^ xor(data) ^
+// MAIL_TAG_SALT.  The host accepts a line only when the tag matches what it recomputes, so it never consumes a line
+// whose words have not all arrived — whatever order the stores reach host memory in (seen on MI355X: roughly one
+// phase in 10^4 delivered the sequence word before the counters although a system-scope fence separates them).
+#define MAIL_TAG_SALT 0x5bd1e995
+// called by the 16 lanes of an ALIGNED 16-lane group (t = 0..15); lane 15's `value` is ignored
+__device__ __forceinline__ void mail_store_line(int* __restrict__ line, int t, int value, int seq) {
+  int x = (t < 15) ? value : 0;
+  x ^= __shfl_xor(x, 1, 16);
+  x ^= __shfl_xor(x, 2, 16);
+  x ^= __shfl_xor(x, 4, 16);
+  x ^= __shfl_xor(x, 8, 16);
+  line[t] = (t == 15) ? (seq ^ x ^ MAIL_TAG_SALT) : value;
+}
+
 // ---- host-side plumbing ------------------------------------------------------------------------
 struct QtrDeviceBuf {
   void* p = nullptr;

@@ -355,7 +355,7 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   int running = blkoff[blockIdx.x];
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
   if (mail && blockIdx.x == 0 && threadIdx.x < 16) {  // this is the last voxelise kernel: hand the counters to the host
-    mail[threadIdx.x] = (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x];
+    mail_store_line(mail, threadIdx.x, (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x], seq);
     __threadfence_system();
     if (threadIdx.x == 0) *mail_seq_slot = seq;
   }

@@ -414,11 +414,11 @@ __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restr
   if (mail && blockIdx.x == 0 && threadIdx.x < 48) {  // last matcher kernel: counters for the host, no copy launches
     const int t = threadIdx.x;
     if (t < 16)
-      mail[MAIL_MATCH + t] = (t == MC_NCORR) ? scan[ns] : mcounts[t];
+      mail_store_line(mail + MAIL_MATCH, t, (t == MC_NCORR) ? scan[ns] : mcounts[t], seq);
     else if (t < 32)
-      mail[MAIL_CNT0 + (t - 16)] = counts0[t - 16];
+      mail_store_line(mail + MAIL_CNT0, t - 16, counts0[t - 16], seq);
     else
-      mail[MAIL_CNT1 + (t - 32)] = counts1[t - 32];
+      mail_store_line(mail + MAIL_CNT1, t - 32, counts1[t - 32], seq);
     __threadfence_system();  // threads 0..47 are one wavefront: the stores above are acknowledged before ...
     if (t == 0) mail[MAIL_SEQ_MATCH] = seq;  // ... the word the host is watching changes
   }
@@ -644,11 +644,11 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(const int* __restrict__ cr
   if (mail && tid < 48) {  // last matcher kernel: counters for the host, no copy launches
     const int t = tid;
     if (t < 16)
-      mail[MAIL_MATCH + t] = (t == MC_NCORR) ? total : (t == MC_NTUPLE) ? s_ntuple : mcounts[t];
+      mail_store_line(mail + MAIL_MATCH, t, (t == MC_NCORR) ? total : (t == MC_NTUPLE) ? s_ntuple : mcounts[t], seq);
     else if (t < 32)
-      mail[MAIL_CNT0 + (t - 16)] = counts0[t - 16];
+      mail_store_line(mail + MAIL_CNT0, t - 16, counts0[t - 16], seq);
     else
-      mail[MAIL_CNT1 + (t - 32)] = counts1[t - 32];
+      mail_store_line(mail + MAIL_CNT1, t - 32, counts1[t - 32], seq);
     __threadfence_system();  // threads 0..47 are one wavefront: the stores above are acknowledged before ...
     if (t == 0) mail[MAIL_SEQ_MATCH] = seq;  // ... the word the host is watching changes
   }

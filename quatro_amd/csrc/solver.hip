@@ -1133,6 +1133,13 @@ __device__ __forceinline__ void export_result(int* __restrict__ mail, const qtr_
   const int t = threadIdx.x;
   if (t < NR) mail[MAIL_SOLVER + t] = ((const int*)res)[t];
   if (t >= 64 && t < 64 + NS) mail[MAIL_SOLVER + 64 + (t - 64)] = ((const int*)st)[t - 64];
+  if (t == 0) {  // tag over the record and the state (common.h: the host recomputes it before trusting the payload)
+    static_assert(NR <= 63, "word 63 of the solver area holds the tag");
+    int x = 0;
+    for (int i = 0; i < NR; ++i) x ^= ((const int*)res)[i];
+    for (int i = 0; i < NS; ++i) x ^= ((const int*)st)[i];
+    mail[MAIL_SOLVER + 63] = seq ^ x ^ MAIL_TAG_SALT;
+  }
   __threadfence_system();
   __syncthreads();
   if (t == 0) {

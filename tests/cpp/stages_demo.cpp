@@ -75,5 +75,31 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 3; ++r) ra(r, c) = (R(r, 0) * a(0, c) + R(r, 1) * a(1, c)) + R(r, 2) * a(2, c);
   const Eigen::Vector3d t = quatro.solveForTranslation(ra, b, true);
   std::printf("t %.17g %.17g %.17g\n", t(0, 0), t(1, 0), t(2, 0));
+  // reg_name "TEASER": the 3-DoF branch the reference names but throws for (include/quatro.hpp:409-411)
+  Q teaser;
+  p.reg_name = "TEASER";
+  teaser.reset(p);
+  const Eigen::Matrix3d R3 = teaser.solveForRotation(a, b);
+  std::printf("R3");
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) std::printf(" %.17g", R3(r, c));
+  std::printf("\n");
+  Eigen::Matrix4d T3 = Eigen::Matrix4d::Identity();
+  auto srcM = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+  auto tgtM = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+  for (int c = 0; c < L; ++c) {
+    srcM->push_back(pcl::PointXYZ(src[static_cast<size_t>(corr[c].first)].x, src[static_cast<size_t>(corr[c].first)].y,
+                                  src[static_cast<size_t>(corr[c].first)].z));
+    tgtM->push_back(pcl::PointXYZ(tgt[static_cast<size_t>(corr[c].second)].x, tgt[static_cast<size_t>(corr[c].second)].y,
+                                  tgt[static_cast<size_t>(corr[c].second)].z));
+  }
+  teaser.reset(p);
+  teaser.setInputSource(srcM);
+  teaser.setInputTarget(tgtM);
+  teaser.computeTransformation(T3);
+  std::printf("T3");
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf(" %.17g", T3(r, c));
+  std::printf("\n");
   return 0;
 }

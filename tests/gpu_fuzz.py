@@ -125,6 +125,27 @@ while time.time() < t_end:
             o = qo.register_pair(s, t, leaf=leaf, r_normal=leaf * 5 / 3, r_fpfh=leaf * 2.5, seed=pid)
             if (g["n_src"], g["n_tgt"], g["L"]) != (o["n_src"], o["n_tgt"], o["L"]):
                 report(kind, desc, f"counts {(g['n_src'], g['n_tgt'], g['L'])} vs {(o['n_src'], o['n_tgt'], o['L'])}")
+                # stage-level diagnosis on the same handle, in the state the failure happened in
+                g2 = h.register_pair(s, t, fp)
+                print("  again:", (g2["n_src"], g2["n_tgt"], g2["L"]), "stats", h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[:16], flush=True)
+                vs, vt = qo.voxelize(s, leaf), qo.voxelize(t, leaf)
+                print("  vox equal", np.array_equal(h.voxelize(s, leaf), vs), np.array_equal(h.voxelize(t, leaf), vt), flush=True)
+                _, _, do = qo.fpfh(vs, leaf * 5 / 3, leaf * 2.5)
+                _, _, dto = qo.fpfh(vt, leaf * 5 / 3, leaf * 2.5)
+                _, dg = h.fpfh(vs, leaf * 5 / 3, leaf * 2.5)
+                _, dgt = h.fpfh(vt, leaf * 5 / 3, leaf * 2.5)
+                print("  desc equal", np.array_equal(dg, do), np.array_equal(dgt, dto), flush=True)
+                cg = h.match(vs, do, vt, dto, fp)
+                co, nn_ij, nn_ji = qo.match(vs, do, vt, dto, seed=pid, debug=True)
+                g_ij = h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32)[:nn_ij.size]
+                print("  match L", cg.shape[0], co.shape[0], "nn ij diff", int((g_ij != nn_ij).sum()), "of", nn_ij.size,
+                      "stats", h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[:16], flush=True)
+                g3 = h.register_pair(s, t, fp)
+                print("  third:", (g3["n_src"], g3["n_tgt"], g3["L"]), flush=True)
+                h2 = ql.Handle(0)
+                g4 = h2.register_pair(s, t, fp)
+                print("  fresh handle:", (g4["n_src"], g4["n_tgt"], g4["L"]), flush=True)
+                h2.close()
             else:
                 w = same_solution(g, o)
                 if w:

@@ -4,6 +4,7 @@ properties.  Bar: bit-exact for integer/index outputs (inlier sets, cliques, cor
 lists) and, since both sides evaluate identical IEEE operation sequences, bit-exact floats as well; the
 stated tolerance of the north star (1e-4 rad / 1e-3 m) is asserted explicitly on the transforms."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -649,6 +650,12 @@ def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):
     ra = np.stack([(R3[r, 0] * a64[:, 0] + R3[r, 1] * a64[:, 1]) + R3[r, 2] * a64[:, 2] for r in range(3)], axis=1)
     tt = [qo.cote_estimate(b[:, r].astype(np.float64) - ra[:, r], 0.3, True)[0] for r in range(3)]
     assert [float(x) for x in lines[4].split()[1:]] == tt
+    # reg_name "TEASER": stage method, then the whole back end
+    b64 = b[:, :3].astype(np.float64)
+    R3o, _, _, _ = qo.gnc_rotation3d(a64, b64, 0.3)
+    assert [float(x) for x in lines[5].split()[1:]] == R3o.ravel().tolist()
+    o3 = qo.solve(vs[corr[:, 0]], vt[corr[:, 1]], qo.default_params(reg_mode=1))
+    assert [float(x) for x in lines[6].split()[1:]] == o3["T"].ravel().tolist()
 
 
 # ------------------------------------------------------------- (f)1 range image + sub-cluster rejection
@@ -1011,3 +1018,30 @@ def test_teaser_mode_through_the_solver(hip, qo, L, frac, seed):
     assert e.value.code == ql.QTR_ERR_BAD_ARG
     with pytest.raises(ql.QuatroHipError):
         hip.solve(src, tgt, ql.demo_params(reg_mode=7))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_phase_counters_are_never_stale_across_calls(hip, qo):
+    """Alternating registrations of very different sizes on one handle: every call must report ITS OWN voxel counts and
+    correspondence count.  The phase-ending kernels hand these counters to the host through a pinned mailbox; before the
+    payload was tagged, about one phase in 10^4 let the host run ahead with the previous call's numbers (found by
+    tests/gpu_fuzz.py; tests/golden/sparse_pair_case.npz is the input it tripped on)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sparse_pair_case.npz"))
+    s, t = z["s"], z["t"]
+    fp = ql.default_frontend_params(seed=1)
+    o = qo.register_pair(s, t, seed=1)
+    want = (o["n_src"], o["n_tgt"], o["L"])
+    S, T, _ = synth.kitti64_pair(0)
+    big = hip.register_pair(S, T, ql.default_frontend_params(seed=3))
+    want_big = (big["n_src"], big["n_tgt"], big["L"])
+    t_end = time.time() + 6.0
+    n = 0
+    while time.time() < t_end:
+        r = hip.register_pair(s, t, fp)
+        assert (r["n_src"], r["n_tgt"], r["L"]) == want, n
+        b = hip.register_pair(S, T, ql.default_frontend_params(seed=3))
+        assert (b["n_src"], b["n_tgt"], b["L"]) == want_big, n
+        n += 1
+    assert n > 500
+    _assert_same_solution(hip.register_pair(s, t, fp), o)
