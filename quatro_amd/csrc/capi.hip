@@ -245,10 +245,10 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
   };
   auto solver_ok = [&]() {
     const volatile int* m = s.mail + MAIL_SOLVER;
-    int x = 0;
+    int x = 0, y = 0;
     for (int i = 0; i < (int)(sizeof(qtr_result) / 4); ++i) x ^= m[i];
-    for (int i = 0; i < (int)(sizeof(SolverState) / 4); ++i) x ^= m[64 + i];
-    return m[63] == (seq ^ x ^ MAIL_TAG_SALT);
+    for (int i = 0; i < (int)(sizeof(SolverState) / 4); ++i) y ^= m[64 + i];
+    return m[63] == (seq ^ x ^ MAIL_TAG_SALT) && m[96] == (seq ^ y ^ MAIL_TAG_SALT);
   };
   auto payload_ok = [&]() {
     switch (idx) {

@@ -1131,14 +1131,24 @@ __device__ __forceinline__ void export_result(int* __restrict__ mail, const qtr_
   __syncthreads();
   constexpr int NR = (int)(sizeof(qtr_result) / 4), NS = (int)(sizeof(SolverState) / 4);
   const int t = threadIdx.x;
-  if (t < NR) mail[MAIL_SOLVER + t] = ((const int*)res)[t];
-  if (t >= 64 && t < 64 + NS) mail[MAIL_SOLVER + 64 + (t - 64)] = ((const int*)st)[t - 64];
-  if (t == 0) {  // tag over the record and the state (common.h: the host recomputes it before trusting the payload)
-    static_assert(NR <= 63, "word 63 of the solver area holds the tag");
-    int x = 0;
-    for (int i = 0; i < NR; ++i) x ^= ((const int*)res)[i];
-    for (int i = 0; i < NS; ++i) x ^= ((const int*)st)[i];
-    mail[MAIL_SOLVER + 63] = seq ^ x ^ MAIL_TAG_SALT;
+  // wavefront 0 carries the record, wavefront 1 the state; each folds its own tag (common.h: the host recomputes both
+  // before trusting the payload) — word 63 for the record, word 96 for the state
+  static_assert(NR <= 63 && NS <= 32, "tag words 63 and 96 of the solver area");
+  if (t < 64) {
+    const int v = (t < NR) ? ((const int*)res)[t] : 0;
+    int x = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (t < NR) mail[MAIL_SOLVER + t] = v;
+    if (t == 63) mail[MAIL_SOLVER + 63] = seq ^ x ^ MAIL_TAG_SALT;
+  } else if (t < 128) {
+    const int i = t - 64;
+    const int v = (i < NS) ? ((const int*)st)[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (i < NS) mail[MAIL_SOLVER + 64 + i] = v;
+    if (i == 32) mail[MAIL_SOLVER + 96] = seq ^ x ^ MAIL_TAG_SALT;
   }
   __threadfence_system();
   __syncthreads();
