@@ -23,12 +23,6 @@ __device__ __forceinline__ float dec_f32(u32 e) {
   return __uint_as_float(b);
 }
 
-__global__ void k_cloud_init(int* counts, u32* mm) {
-  const int t = threadIdx.x;
-  if (t < 16) counts[t] = 0;
-  if (t < 3) mm[t] = 0xffffffffu;       // running minima
-  if (t >= 3 && t < 6) mm[t] = 0u;      // running maxima
-}
 
 __global__ void k_set_count(int* counts, int which, int value) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counts[which] = value;
@@ -111,41 +105,6 @@ __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, 
   ((uint4*)(hist + (size_t)blk * NB))[lane] = mine;  // hist[blk][digit]: one coalesced 1 KB row per tile
 }
 
-// exclusive scan of m 32-bit counters by one workgroup (m up to a few hundred thousand)
-__device__ __forceinline__ void d_scan_u32(u32* __restrict__ data, int m, u32* __restrict__ total_out) {
-  __shared__ u32 wsum[16];
-  __shared__ u32 carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < m; base += 1024 * 4) {
-    // each thread owns 4 consecutive entries
-    const int i0 = base + tid * 4;
-    u32 v[4];
-    u32 s = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = (i0 + q < m) ? data[i0 + q] : 0u;
-      s += v[q];
-    }
-    int tot;
-    const int ex = wave_excl_scan_i32((int)s, &tot);
-    if (lane == 63) wsum[wave] = (u32)tot;
-    __syncthreads();
-    u32 woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    u32 run = carry_s + woff + (u32)ex;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (i0 + q < m) data[i0 + q] = run;
-      run += v[q];
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = run;
-    __syncthreads();
-  }
-  if (tid == 0 && total_out) *total_out = carry_s;
-}
 
 template <int BITS, int TILE>
 __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
@@ -1024,10 +983,6 @@ __global__ __launch_bounds__(256) void k2_cell_keys(Clouds2 a, float cell) {
 __global__ __launch_bounds__(64) void k2_radix_hist(Clouds2 a, int use_vox, int shift) {
   const CloudView& C = a.c[blockIdx.y];
   d_radix_hist<8, RADIX_TILE>(C.keys_in, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
-}
-__global__ __launch_bounds__(1024) void k2_radix_scan(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_scan_u32(C.hist, 256 * C.nblk, (u32*)nullptr);
 }
 __global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift) {
   const CloudView& C = a.c[blockIdx.y];

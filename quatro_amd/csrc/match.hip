@@ -42,12 +42,6 @@ __device__ __forceinline__ float l2_flann33_g(const float* a, const float* __res
   return result;
 }
 
-__global__ void k_fill_u64(u64* p, int n, u64 v) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
-}
-__global__ void k_fill_i32(int* p, int n, int v) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
-}
 
 // grid (ceil(nA/256), nsplit): thread = one query of A, blockIdx.y = slice of B
 __global__ __launch_bounds__(256) void k_nn_exact(const float* __restrict__ A, int nA, const float* __restrict__ B,
@@ -86,12 +80,6 @@ __global__ __launch_bounds__(256) void k_nn_exact(const float* __restrict__ A, i
   if (a_idx >= 0 && bi >= 0) atomicMin(&best[a_idx], ((u64)__float_as_uint(bd) << 32) | (u32)bi);
 }
 
-__global__ void k_nn_unpack(const u64* __restrict__ best, int n, int* __restrict__ nn) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const u64 b = best[i];
-    nn[i] = (b == ~0ULL) ? 0 : (int)(u32)b;
-  }
-}
 
 // =================================================================================================
 // MFMA engine.  d~(a,b) = |a|^2 + (|b|^2 - 2 a.b): the bracket is ONE f32 MFMA chain over K = 34
@@ -424,14 +412,6 @@ __global__ void k_corr_compact2(const int* __restrict__ scan, const int* __restr
   }
 }
 
-// cross-check flags over the larger cloud (index i): keep iff NN_small(i) = j and NN_large(j) = i
-__global__ void k_cross_flags(const int* __restrict__ nn_of_large, const int* __restrict__ nn_of_small, int n_large,
-                              int* __restrict__ flags) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_large; i += gridDim.x * blockDim.x) {
-    const int j = nn_of_large[i];
-    flags[i] = (nn_of_small[j] == i) ? 1 : 0;
-  }
-}
 
 __global__ void k_cross_compact(const int* __restrict__ flags, const int* __restrict__ scan,
                                 const int* __restrict__ nn_of_large, int n_large, int* __restrict__ cross_i,
