@@ -965,29 +965,19 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     double* t = T + (size_t)lane * nc;
     double acc = (lane == 2) ? s_bcast[2] : 0.0;
     int i = 0;
-    if (nc >= 8) {
-      double v[8], nx[8];
+    // sixteen terms per round: the loads go out back to back, the additions stay a dependent chain in the reference's
+    // order, the stores follow (one wavefront issues an instruction every ~5 clocks, so instructions per event matter)
+    for (; i + 16 <= nc; i += 16) {
+      double v[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = t[q];
-      for (; i + 16 <= nc; i += 8) {
+      for (int q = 0; q < 16; ++q) v[q] = t[i + q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) nx[q] = t[i + 8 + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          acc += v[q];
-          v[q] = acc;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t[i + q] = v[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = nx[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 16; ++q) {
         acc += v[q];
-        t[i + q] = acc;
+        v[q] = acc;
       }
-      i += 8;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[i + q] = v[q];
     }
     for (; i < nc; ++i) {
       acc += t[i];
@@ -1055,8 +1045,8 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
   // ---- 6. the two middle order statistics of {X of events mi, mi-1, ..., mi-ncard+1}
   if (act && median_sel && ncard >= 2) {
     const int ra = ncard / 2 - 1, rb = ncard / 2;
-    for (int j = tl; j < ncard; j += 256) {
-      const double vj = sxv[mi - j];
+    for (int j = tl; j < ncard; j += 256) {  // (spreading one value's comparisons over a wavefront was measured 4x
+      const double vj = sxv[mi - j];          //  slower: the cross-lane reduction costs more than the serial walk)
       int rk = 0;
       for (int q = 0; q < ncard; ++q) {
         const double vq = sxv[mi - q];
