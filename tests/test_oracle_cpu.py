@@ -104,6 +104,102 @@ def test_normals_close_to_eigh_and_oriented(qo):
     assert np.all((nrm[ok, 3] >= 0) & (nrm[ok, 3] <= 1.0 / 3 + 1e-3))
 
 
+def _ref_fpfh_float64(xyz, rn, rf):
+    """pcl::NormalEstimation + FPFHEstimation restated from SURVEY.md Appendix A.2 in plain float64 numpy (O(n^2))."""
+    P = xyz.astype(np.float64)
+    n = P.shape[0]
+    D2 = ((P[:, None, :] - P[None, :, :]) ** 2).sum(-1)
+    normals = np.full((n, 3), np.nan)
+    for i in range(n):
+        nb = np.nonzero(D2[i] <= rn * rn)[0]
+        if nb.size < 3:
+            continue
+        Q = P[nb]
+        m = Q.mean(0)
+        C = (Q[:, :, None] * Q[:, None, :]).mean(0) - np.outer(m, m)
+        w, V = np.linalg.eigh(C)
+        v = V[:, 0]
+        if np.dot(v, -P[i]) < 0:
+            v = -v
+        normals[i] = v
+    spfh = np.zeros((n, 33))
+    nbrs = []
+    for i in range(n):
+        nb = np.nonzero(D2[i] <= rf * rf)[0]
+        nbrs.append(nb)
+        k = nb.size
+        if k < 2:
+            continue
+        incr = 100.0 / (k - 1)
+        for q in nb:
+            if q == i:
+                continue
+            d = P[q] - P[i]
+            f4 = np.linalg.norm(d)
+            if f4 == 0:
+                continue
+            n_p, n_q = normals[i], normals[q]
+            a1 = np.dot(n_p, d) / f4
+            a2 = np.dot(n_q, d) / f4
+            if np.arccos(abs(a1)) > np.arccos(abs(a2)):
+                n1, n2, dd, f3 = n_q, n_p, -d, -a2
+            else:
+                n1, n2, dd, f3 = n_p, n_q, d, a1
+            v = np.cross(dd, n1)
+            nv = np.linalg.norm(v)
+            if nv == 0:
+                continue
+            v = v / nv
+            w = np.cross(n1, v)
+            f2 = np.dot(v, n2)
+            f1 = np.arctan2(np.dot(w, n2), np.dot(n1, n2))
+            feats = [(f1 + np.pi) / (2 * np.pi), (f2 + 1) / 2, (f3 + 1) / 2]
+            if any(np.isnan(feats)):
+                bins = [0, 0, 0]
+            else:
+                bins = [min(10, max(0, int(np.floor(11 * f)))) for f in feats]
+            for b, bb in enumerate(bins):
+                spfh[i, 11 * b + bb] += incr
+    fpfh = np.zeros((n, 33))
+    for i in range(n):
+        for q in nbrs[i]:
+            if D2[i, q] == 0:
+                continue
+            fpfh[i] += spfh[q] / D2[i, q]
+        for b in range(3):
+            s = fpfh[i, 11 * b:11 * b + 11].sum()
+            if s != 0:
+                fpfh[i, 11 * b:11 * b + 11] *= 100.0 / s
+    return normals, spfh, fpfh
+
+
+def test_normals_spfh_fpfh_against_independent_float64_restatement(qo):
+    """The oracle's K2-K4 (float32, PCL's operation order) against an independent float64 numpy restatement of the same
+    published algorithm: identical NaN pattern, normals within 1e-3 rad, SPFH rows identical except where a pair feature
+    sits within float32 reach of a bin edge or of the p/q role swap (then one or two neighbours' mass moves between
+    bins), FPFH within the mass that propagates from those rows."""
+    rng = np.random.default_rng(0)
+    n = 350
+    c = np.zeros((n, 4), dtype=np.float32)
+    c[:, 0] = rng.uniform(6, 10, n)
+    c[:, 1] = rng.uniform(-2, 2, n)
+    c[:, 2] = 0.3 * np.sin(c[:, 0]) + 0.2 * np.cos(1.5 * c[:, 1]) + 0.01 * rng.normal(size=n)
+    no, so, fo = qo.fpfh(c, 0.5, 0.75)
+    nr, sr, fr = _ref_fpfh_float64(c[:, :3], 0.5, 0.75)
+    ok = ~np.isnan(nr[:, 0])
+    assert np.array_equal(np.isnan(no[:, 0]), ~ok) and ok.sum() > 0.9 * n
+    dots = np.einsum("ij,ij->i", no[ok, :3].astype(np.float64), nr[ok])
+    assert np.all(dots > 1 - 1e-6)  # same orientation, < 1.5e-3 rad apart (single-pass float32 covariance)
+    D2 = ((c[:, None, :3].astype(np.float64) - c[None, :, :3].astype(np.float64)) ** 2).sum(-1)
+    k = (D2 <= 0.75 ** 2).sum(1)
+    ds = np.abs(so.astype(np.float64) - sr).sum(1)
+    assert (ds < 1e-3).mean() > 0.9
+    assert np.all(ds <= 4 * 100.0 / np.maximum(k - 1, 1) + 1e-3)  # at most two neighbours change bins in a row
+    assert np.allclose(sr.reshape(n, 3, 11).sum(2)[k > 1], 100.0) and np.allclose(so.reshape(n, 3, 11).sum(2)[k > 1], 100.0, atol=1e-2)
+    df = np.abs(fo.astype(np.float64) - fr).sum(1)
+    assert np.median(df) < 0.5 and df.max() < 15.0  # out of 300 per row
+
+
 def test_fpfh_blocks_sum_to_100(qo):
     s, t, _ = synth.kitti64_pair(5)
     v = qo.voxelize(s, 0.3)[:2500]
@@ -591,3 +687,178 @@ def test_gnc_rotation3d_recovers_rotation_and_flags_outliers(qo):
     # no outliers and a generous bound: the degenerate-mu exit after one iteration, all inliers
     R1, _, it1, m1 = qo.gnc_rotation3d(X, X @ Rm.T, 5.0, 1.4, 100, 1e-6)
     assert it1 == 1 and m1.all() and np.abs(R1 - Rm).max() < 1e-9
+
+
+def _ref_cote_python(X, r, median):
+    """Quatro::estimate (reference include/quatro.hpp:618-747) written again, directly from the reference text, as plain
+    Python floats (IEEE binary64, the same operation order); uniform ranges; std::sort's unspecified order among equal
+    keys taken as insertion order (the oracle's definition)."""
+    N = len(X)
+    h = []
+    for i in range(N):
+        h.append((X[i] - r, i + 1))
+        h.append((X[i] + r, -i - 1))
+    h.sort(key=lambda e: e[0])  # stable
+    w = 1.0 / (r * r)
+    ranges_inverse_sum = 0.0
+    for _ in range(N):
+        ranges_inverse_sum += r
+    dot_X_weights = dot_weights_consensus = sum_xi = sum_xi_square = 0.0
+    card = 0
+    x_hat, x_cost, set_card = [], [], []
+    for key, tag in h:
+        idx = abs(tag) - 1
+        eps = 1 if tag > 0 else -1
+        card += eps
+        dot_weights_consensus += eps * w
+        dot_X_weights += eps * w * X[idx]
+        ranges_inverse_sum -= eps * r
+        sum_xi += eps * X[idx]
+        sum_xi_square += eps * X[idx] * X[idx]
+        set_card.append(card)
+        xh = dot_X_weights / dot_weights_consensus if dot_weights_consensus != 0 else float("nan")
+        x_hat.append(xh)
+        x_cost.append(card * xh * xh + sum_xi_square - 2 * sum_xi * xh + ranges_inverse_sum)
+    mi = min(range(2 * N), key=lambda i: (x_cost[i], i))  # Eigen minCoeff: first minimum
+    n_card = set_card[mi]
+    if median:
+        cand = sorted(X[abs(h[mi - j][1]) - 1] for j in range(n_card))
+        est = (cand[len(cand) // 2 - 1] + cand[len(cand) // 2]) / 2.0 if n_card >= 2 else (cand[0] if n_card == 1 else x_hat[mi])
+    else:
+        est = x_hat[mi]
+    return est, n_card, [abs(x - est) <= r for x in X]
+
+
+def test_cote_against_a_second_restatement_of_the_reference(qo):
+    rng = np.random.default_rng(7)
+    checked = 0
+    for N, spread, r in [(2, 0.1, 0.3), (5, 0.5, 0.3), (64, 0.2, 0.3), (300, 1.0, 0.3), (301, 0.05, 0.15), (1000, 3.0, 0.6)]:
+        for trial in range(4):
+            X = rng.normal(0.3, spread, N)
+            if trial == 1:
+                X = np.round(X, 1)  # exact ties among the interval endpoints
+            if trial == 2:
+                X[: N // 3] += 5.0  # a far cluster of outliers
+            for median in (True, False):
+                e_ref, card_ref, inl_ref = _ref_cote_python([float(v) for v in X], r, median)
+                if any(np.isnan(v) for v in [e_ref]):
+                    continue
+                e, inl, card = qo.cote_estimate(X, r, median)
+                assert card == card_ref
+                assert e == e_ref, (N, trial, median, e, e_ref)
+                assert inl.tolist() == inl_ref
+                checked += 1
+    assert checked >= 40
+
+
+def _ref_gnc_rotation2d_numpy(src, dst, noise_bound, gnc_factor, max_iter, cost_thr):
+    """solveForRotation2D (reference include/quatro.hpp:430-572) with teaser::utils::svdRot2d (include/teaser/utils.h:
+    151-166) written again from the reference text: numpy SVD, sequential cost sum."""
+    X, Y = np.asarray(src, dtype=np.float64).T, np.asarray(dst, dtype=np.float64).T  # 2 x M
+    M = X.shape[1]
+    w = np.ones(M)
+    mu, prev_cost, cost = 1.0, np.inf, np.inf
+    nb_sq = noise_bound ** 2
+    if nb_sq < 1e-16:
+        nb_sq = 1e-2
+    R = np.eye(2)
+    iters = 0
+    for i in range(max_iter):
+        iters = i + 1
+        H = (X * w) @ Y.T
+        U, _, Vt = np.linalg.svd(H)
+        V = Vt.T
+        if np.linalg.det(U) * np.linalg.det(V) < 0:
+            V[:, 1] *= -1
+        R = V @ U.T
+        res = ((Y - R @ X) ** 2).sum(0)
+        if i == 0:
+            mu = 1 / (2 * res.max() / nb_sq - 1)
+            if mu <= 0:
+                break
+        th1, th2 = (mu + 1) / mu * nb_sq, mu / (mu + 1) * nb_sq
+        cost = 0.0
+        for j in range(M):
+            cost += w[j] * res[j]
+            if res[j] >= th1:
+                w[j] = 0
+            elif res[j] <= th2:
+                w[j] = 1
+            else:
+                w[j] = np.sqrt(nb_sq * mu * (mu + 1) / res[j]) - mu
+        cost_diff = abs(cost - prev_cost)
+        mu *= gnc_factor
+        prev_cost = cost
+        if cost_diff < cost_thr:
+            break
+    return R, cost, iters, w >= 0.4
+
+
+def test_gnc_rotation2d_against_a_second_restatement_of_the_reference(qo):
+    """Same loop, SVD instead of the closed form and a different summation order: the iteration count and the inlier
+    mask agree exactly, the rotation to 1e-9 and the cost to 1e-9 relative, on clean, noisy and outlier-heavy inputs."""
+    rng = np.random.default_rng(11)
+    for M, noise, frac_out, nb in [(2, 0.0, 0.0, 0.6), (50, 0.02, 0.2, 0.6), (300, 0.05, 0.5, 0.6), (1000, 0.05, 0.7, 0.2),
+                                   (200, 0.0, 0.0, 0.6), (400, 0.3, 0.3, 0.1)]:
+        X = rng.uniform(-10, 10, (M, 2))
+        a = rng.uniform(-np.pi, np.pi)
+        Rm = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        Y = X @ Rm.T + rng.normal(0, noise, (M, 2))
+        out = rng.random(M) < frac_out
+        Y[out] = rng.uniform(-10, 10, (int(out.sum()), 2))
+        R, cost, iters, mask = qo.gnc_rotation2d(X, Y, nb, 1.4, 50, 1.1e-4)
+        Rr, costr, itr, maskr = _ref_gnc_rotation2d_numpy(X, Y, nb, 1.4, 50, 1.1e-4)
+        assert iters == itr and np.array_equal(mask, maskr)
+        assert np.abs(R - Rr).max() < 1e-9
+        assert (np.isinf(cost) and np.isinf(costr)) or abs(cost - costr) <= 1e-9 * max(1.0, abs(costr))
+
+
+def _ref_pmc_heu_python(A):
+    """pmc_heu::search_bounds with the "kcore" strategy, single thread, restated once more from SURVEY.md Appendix A.4
+    with Python sets and networkx core numbers (canonical (core, id) orders, as the oracle defines them)."""
+    import networkx as nx
+    V = A.shape[0]
+    core = nx.core_number(nx.from_numpy_array(A.astype(int)))
+    K = [core[v] + 1 for v in range(V)]
+    nbrs = [set(np.nonzero(A[v])[0].tolist()) for v in range(V)]
+    order = sorted(range(V), key=lambda v: (K[v], v))
+    ub = max(K) if V else 0
+    mc, C_max = 0, []
+    for v in reversed(order):
+        if not K[v] > mc:
+            continue
+        P = sorted((u for u in nbrs[v] if K[u] > mc), key=lambda u: (K[u], u))
+        if len(P) <= mc:
+            continue
+        mc_cur, depth, chosen = mc, 1, []
+        while P:
+            u = P.pop()
+            chosen.append(u)
+            P = [w for w in P if w in nbrs[u] and K[w] > mc_cur]
+            depth += 1
+        if depth > mc_cur:
+            mc_cur = depth
+        if mc_cur > mc:
+            mc = mc_cur
+            C_max = chosen + [v]
+            if mc >= ub:
+                break
+    return sorted(C_max)
+
+
+def test_clique_heuristic_against_a_second_restatement(qo):
+    rng = np.random.default_rng(13)
+    for L, p, planted in [(30, 0.3, 0), (80, 0.2, 8), (200, 0.05, 12), (150, 0.5, 0), (400, 0.02, 15), (300, 0.3, 25),
+                          (64, 0.9, 0), (500, 0.01, 0)]:
+        A = np.triu(rng.random((L, L)) < p, 1)
+        A = A | A.T
+        if planted:
+            idx = rng.choice(L, planted, replace=False)
+            A[np.ix_(idx, idx)] = True
+            A[idx, idx] = False
+        W = (L + 63) // 64
+        bits = np.zeros((L, W * 64), dtype=np.uint8)
+        bits[:, :L] = A
+        bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W)
+        got = sorted(qo.max_clique(bm, 1).tolist())
+        assert got == _ref_pmc_heu_python(A), (L, p, planted)
