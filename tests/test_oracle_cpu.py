@@ -862,3 +862,97 @@ def test_clique_heuristic_against_a_second_restatement(qo):
         bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W)
         got = sorted(qo.max_clique(bm, 1).tolist())
         assert got == _ref_pmc_heu_python(A), (L, p, planted)
+
+
+def _ref_patchwork_float64(xyz, pp):
+    """PatchWork::estimate_ground (reference include/patchwork.hpp:264-318, 329-476, 492-586) written again from the
+    reference text in float64 numpy with numpy's SVD of the patch covariance.  Returns a label per input point:
+    1 ground, 0 non-ground, -1 not emitted."""
+    P = np.asarray(xyz, dtype=np.float64)
+    n = P.shape[0]
+    label = np.full(n, -1)
+    order = np.argsort(P[:, 2], kind="stable")
+    order = order[P[order, 2] >= -1.8 * pp.sensor_height]
+    r = np.sqrt(P[:, 0] ** 2 + P[:, 1] ** 2)
+    th = np.arctan2(P[:, 1], P[:, 0])
+    th = np.where(th > 0, th, th + 2 * np.pi)
+    mins = [pp.min_ranges[i] for i in range(pp.num_zones)] + [pp.max_range]
+    patches = {}
+    for i in order:
+        if not (r[i] <= pp.max_range and r[i] > pp.min_range):
+            continue
+        k = pp.num_zones - 1
+        for z in range(1, pp.num_zones):
+            if r[i] < mins[z]:
+                k = z - 1
+                break
+        nr, ns = pp.num_rings_each_zone[k], pp.num_sectors_each_zone[k]
+        ring = min(int((r[i] - mins[k]) / ((mins[k + 1] - mins[k]) / nr)), nr - 1)
+        sec = min(int(th[i] / (2 * np.pi / ns)), ns - 1)
+        patches.setdefault((k, ring, sec), []).append(i)
+    margin = -0.1 if pp.sensor_height == 0.0 else pp.adaptive_seed_selection_margin * pp.sensor_height
+    cidx = 0
+    for k in range(pp.num_zones):
+        for ring in range(pp.num_rings_each_zone[k]):
+            for sec in range(pp.num_sectors_each_zone[k]):
+                ids = np.array(patches.get((k, ring, sec), []), dtype=int)
+                if not ids.size > pp.num_min_pts:
+                    continue
+                Q = P[ids]
+                init = 0
+                if k == 0:
+                    while init < ids.size and Q[init, 2] < margin:
+                        init += 1
+                lpr = Q[init:init + pp.num_lpr, 2]
+                lpr_h = lpr.mean() if lpr.size else 0.0
+                g = Q[:, 2] < lpr_h + pp.th_seeds
+                for it in range(pp.num_iter):
+                    G = Q[g]
+                    mean = G.mean(0)
+                    cov = (G - mean).T @ (G - mean) / G.shape[0]
+                    U, S, _ = np.linalg.svd(cov)
+                    normal = U[:, 2]
+                    d = -normal @ mean
+                    g = Q @ normal < pp.th_dist - d
+                zvec, elev = abs(normal[2]), mean[2]
+                surf = S.min() / S.sum()
+                reject = False
+                if zvec < pp.uprightness_thr:
+                    reject = True
+                elif cidx < pp.num_thr:
+                    ti = ring + 2 * k
+                    if elev > pp.elevation_thr[ti] and not (pp.flatness_thr[ti] > surf):
+                        reject = True
+                elif pp.using_global_thr and elev > pp.global_elevation_thr:
+                    reject = True
+                label[ids] = 0
+                if not reject:
+                    label[ids[g]] = 1
+            cidx += 1
+    return label
+
+
+def test_patchwork_against_a_second_restatement_of_the_reference(qo):
+    """The oracle's float32, fixed-order plane fits against a float64 SVD restatement of the same text: the same points are
+    emitted, and all but a sliver of them (points within rounding of th_dist, patches within rounding of a threshold)
+    get the same ground / non-ground label."""
+    for scan_id, mutate in [(0, None), (2, None), (1, "iter1"), (3, "global")]:
+        xyzi, _ = synth.kitti64_raw_scan(scan_id)
+        pp = qo.pw_params()
+        if mutate == "iter1":
+            pp.num_iter, pp.num_lpr = 1, 5
+        if mutate == "global":
+            pp.using_global_thr, pp.global_elevation_thr = 1, -1.5
+        r = qo.patchwork(xyzi, pp)
+        key = lambda a: [bytes(v) for v in np.ascontiguousarray(a).view(np.uint8).reshape(-1, 16)]
+        lab_o = {}
+        for k_ in key(r["ground"]):
+            lab_o[k_] = 1
+        for k_ in key(r["nonground"]):
+            lab_o[k_] = 0
+        lab_r = _ref_patchwork_float64(xyzi[:, :3], pp)
+        recs = key(xyzi)
+        got = np.array([lab_o.get(k_, -1) for k_ in recs])
+        assert np.array_equal(got == -1, lab_r == -1)  # the same points are emitted
+        emitted = lab_r >= 0
+        assert (got[emitted] == lab_r[emitted]).mean() > 0.995, (scan_id, mutate)
