@@ -956,3 +956,111 @@ def test_patchwork_against_a_second_restatement_of_the_reference(qo):
         assert np.array_equal(got == -1, lab_r == -1)  # the same points are emitted
         emitted = lab_r >= 0
         assert (got[emitted] == lab_r[emitted]).mean() > 0.995, (scan_id, mutate)
+
+
+def _ref_advanced_matching_python(feat_src, feat_tgt):
+    """Matcher::advancedMatching with use_crosscheck = true and the tuple test off (reference
+    src/teaser_utils/feature_matcher.cc:77-170, 252-265) written again from the reference text: brute-force exact nearest
+    neighbours in float64 (FLANN's single kd-tree with eps = 0 is exact), lazy i_to_j, Mi / Mj cross check, un-swap, sort,
+    unique."""
+    feats = [np.asarray(feat_src, dtype=np.float64), np.asarray(feat_tgt, dtype=np.float64)]
+    fi, fj, swapped = 0, 1, False
+    if feats[fj].shape[0] > feats[fi].shape[0]:
+        fi, fj, swapped = 1, 0, True
+
+    def nn(tree, q):
+        return int(np.argmin(((tree - q) ** 2).sum(1)))
+    nPti, nPtj = feats[fi].shape[0], feats[fj].shape[0]
+    i_to_j = [-1] * nPti
+    corres_ji = []
+    for j in range(nPtj):
+        i = nn(feats[fi], feats[fj][j])
+        if i_to_j[i] == -1:
+            i_to_j[i] = nn(feats[fj], feats[fi][i])
+        corres_ji.append((i, j))
+    corres_ij = [(i, i_to_j[i]) for i in range(nPti) if i_to_j[i] != -1]
+    Mi = [[] for _ in range(nPti)]
+    Mj = [[] for _ in range(nPtj)]
+    for ci, cj in corres_ij:
+        Mi[ci].append(cj)
+    for ci, cj in corres_ji:
+        Mj[cj].append(ci)
+    corres = []
+    for i in range(nPti):
+        for j in Mi[i]:
+            for ii in Mj[j]:
+                if ii == i:
+                    corres.append((i, j))
+    if swapped:
+        corres = [(b, a) for a, b in corres]
+    return sorted(set(corres))
+
+
+def test_matcher_cross_check_against_a_second_restatement(qo):
+    rng = np.random.default_rng(17)
+    for ns, nt in [(40, 55), (300, 180), (257, 257), (1, 7), (500, 640)]:
+        # clustered descriptors so that mutual nearest neighbours are neither rare nor universal
+        centres = rng.uniform(0, 100, (max(ns, nt) // 3 + 1, 33))
+        fs = (centres[rng.integers(0, centres.shape[0], ns)] + rng.normal(0, 3.0, (ns, 33))).astype(np.float32)
+        ft = (centres[rng.integers(0, centres.shape[0], nt)] + rng.normal(0, 3.0, (nt, 33))).astype(np.float32)
+        xs = rng.uniform(-10, 10, (ns, 4)).astype(np.float32)
+        xt = rng.uniform(-10, 10, (nt, 4)).astype(np.float32)
+        got = qo.match(xs, fs, xt, ft, crosscheck=True, tuple_test=False)
+        want = _ref_advanced_matching_python(fs, ft)
+        assert [tuple(r) for r in got.tolist()] == want, (ns, nt)
+        assert len(want) > 0
+
+
+def _ref_compute_transformation_python(src4, tgt4, noise_bound=0.3, cbar2=1.0):
+    """Quatro::computeTransformation (reference include/quatro.hpp:769-936) composed once more from the second
+    restatements above: scale-consistency graph (:355-386), PMC heuristic, chain TIMs (:817-844), GNC-TLS yaw with the
+    doubled noise bound (:850-852), the rotation-inlier chain rule (:857-874), COTE per axis on dst - R src (:585-615)."""
+    s = np.asarray(src4, dtype=np.float32)[:, :3].astype(np.float64)
+    t = np.asarray(tgt4, dtype=np.float32)[:, :3].astype(np.float64)
+    L = s.shape[0]
+    beta = 2 * noise_bound * np.sqrt(cbar2)
+    A = np.zeros((L, L), dtype=bool)
+    for i in range(L):
+        v1 = np.sqrt(((s[i + 1:] - s[i]) ** 2).sum(1))
+        v2 = np.sqrt(((t[i + 1:] - t[i]) ** 2).sum(1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ok = (np.abs(v2 / v1 - 1) <= beta / v1) & (np.abs(v1 / v2 - 1) <= beta / v2)
+        A[i, i + 1:] = ok
+    A = A | A.T
+    clique = _ref_pmc_heu_python(A)
+    if len(clique) <= 1:
+        return dict(valid=False, clique=clique)
+    M = len(clique)
+    leaf = clique[1:] + clique[:1]
+    ps, pd = s[leaf] - s[clique], t[leaf] - t[clique]
+    R2, cost, iters, mask = _ref_gnc_rotation2d_numpy(ps[:, :2], pd[:, :2], 2 * noise_bound, 1.4, 50, 1.1e-4)
+    R = np.eye(3)
+    R[:2, :2] = R2
+    rot = [i for i in range(M) if mask[i - 1 if i else M - 1] and mask[i]]
+    raw = t[clique] - s[clique] @ R.T
+    r = 0.3 * np.sqrt(cbar2)
+    tr, inl = [], np.ones(M, dtype=bool)
+    for a in range(3):
+        e, _, ia = _ref_cote_python([float(v) for v in raw[:, a]], r, True)
+        tr.append(e)
+        inl &= np.array(ia)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = tr
+    return dict(valid=True, clique=clique, rot_inliers=rot, final_inliers=[clique[i] for i in np.nonzero(inl)[0]], T=T,
+                gnc_iters=iters)
+
+
+@pytest.mark.parametrize("L,frac,noise,seed", [(60, 0.5, 0.02, 1), (200, 0.3, 0.05, 2), (400, 0.1, 0.05, 3), (150, 0.0, 0.0, 4),
+                                               (300, 0.9, 0.1, 5)])
+def test_back_end_against_the_composed_second_restatement(qo, L, frac, noise, seed):
+    src, tgt, _, _ = synth.correspondences(L, frac, seed=seed, noise=noise)
+    o = qo.solve(src, tgt)
+    r = _ref_compute_transformation_python(src, tgt)
+    assert o["valid"] == r["valid"]
+    assert sorted(o["clique"].tolist()) == r["clique"]
+    if not r["valid"]:
+        return
+    assert o["rot_inliers"].tolist() == r["rot_inliers"] and o["gnc_iters"] == r["gnc_iters"]
+    assert o["final_inliers"].tolist() == r["final_inliers"]
+    assert np.abs(o["T"] - r["T"]).max() < 1e-9
