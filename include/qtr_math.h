@@ -130,9 +130,6 @@ QM_HD void qm_sincosf(float thetaf, float* s_out, float* c_out) {
   *c_out = (float)c;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Counter-based RNG (SplitMix64 finaliser over seed + counter).  Replaces srand(time(NULL))/rand()
-// in the tuple test: trial t draws r_k = qm_rand_u32(seed, 3*t + k) % ncorr, k = 0,1,2.
 // Rotation R (row-major 3x3) maximising trace(R * H) for H = sum_j w_j x_j y_j^T (row-major: H[3a+b] = sum w x_a y_b)
 // — the rotation teaser::utils::svdRot returns (reference include/teaser/utils.h:123-149: V diag(1,1,det) U^T of
 // H = U S V^T).  Horn's unit-quaternion form instead of Eigen::JacobiSVD: the dominant eigenvector of the symmetric
@@ -214,6 +211,9 @@ QM_HD void qm_rot3_from_h(const double* H, double* R) {
   R[8] = ((q0 * q0 - q1 * q1) - q2 * q2) + q3 * q3;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG (SplitMix64 finaliser over seed + counter).  Replaces srand(time(NULL))/rand()
+// in the tuple test: trial t draws r_k = qm_rand_u32(seed, 3*t + k) % ncorr, k = 0,1,2.
 QM_HD uint64_t qm_mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
