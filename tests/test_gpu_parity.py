@@ -4,6 +4,7 @@ properties.  Bar: bit-exact for integer/index outputs (inlier sets, cliques, cor
 lists) and, since both sides evaluate identical IEEE operation sequences, bit-exact floats as well; the
 stated tolerance of the north star (1e-4 rad / 1e-3 m) is asserted explicitly on the transforms."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -1046,3 +1047,15 @@ def test_phase_counters_are_never_stale_across_calls(hip, qo):
         n += 1
     assert n > 500
     _assert_same_solution(hip.register_pair(s, t, fp), o)
+
+
+@pytest.mark.gpu
+def test_randomised_sweep_against_oracle():
+    """Ten seconds of tests/gpu_fuzz.py (random solver / clique / pair / raw-scan stage / stand-alone stage cases against
+    the oracle) in its own process; any mismatch fails."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz.py"), "5", "10"], cwd=root, capture_output=True,
+                       text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-500:])
+    assert "0 mismatches" in p.stdout
