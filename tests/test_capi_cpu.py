@@ -199,3 +199,41 @@ def test_teaser_utils_header_against_numpy_svd(tmp_path):
     keep = np.nonzero(w >= 0.5)[0]
     assert [int(v) for v in out[3].split()[1:]] == keep.tolist()
     assert [int(v) for v in out[4].split()[1:]] == (100 + keep).tolist()
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every struct of include/quatro_hip.h has the same size and the same field offsets in quatro_amd/lib.py's ctypes
+    mirror (a C program compiled against the header prints sizeof / offsetof; field names must match too)."""
+    from quatro_amd import lib as ql
+    pairs = {"qtr_limits": ql.Limits, "qtr_params": ql.Params, "qtr_frontend_params": ql.FrontendParams,
+             "qtr_result": ql.Result, "qtr_stage_times": ql.StageTimes, "qtr_pw_params": ql.PwParams,
+             "qtr_ip_params": ql.IpParams}
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    hdr = open(os.path.join(root, "include", "quatro_hip.h")).read()
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "quatro_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(",") if "[" not in decl or decl.count(",") else [decl]:
+                names.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1]).lstrip("*"))
+        assert names == [n for n, _ in cls._fields_], (cname, names)
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for n in names:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {n}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line in out:
+        w = line.split()
+        cls = pairs[w[0]]
+        assert int(w[1]) == ctypes.sizeof(cls), w[0]
+        assert [int(v) for v in w[2:]] == [getattr(cls, n).offset for n, _ in cls._fields_], w[0]
