@@ -84,14 +84,15 @@ bool read_pcd_header(FILE* f, PcdHeader& h) {
     } else if (key == "DATA" && w.size() > 1) {
       h.data = w[1];
       if (h.points < 0) h.points = h.width * h.height;
-      int off = 0;
+      long long off = 0;  // sizes come from the file: bound them before any arithmetic or allocation depends on them
       for (PcdField& fl : h.fields) {
-        if (fl.size <= 0 || fl.count <= 0) return false;
-        fl.offset = off;
-        off += fl.size * fl.count;
+        if ((fl.size != 1 && fl.size != 2 && fl.size != 4 && fl.size != 8) || fl.count < 1 || fl.count > 65536) return false;
+        fl.offset = (int)off;
+        off += (long long)fl.size * fl.count;
+        if (off > (1 << 20)) return false;
       }
-      h.record_bytes = off;
-      return !h.fields.empty() && h.points >= 0;
+      h.record_bytes = (int)off;
+      return !h.fields.empty() && h.points >= 0 && h.width >= 0 && h.height >= 0;
     }
   }
   return false;
@@ -243,11 +244,22 @@ int qtr_read_pcd_xyz(const char* path, float* xyz4, int cap, int* n_points) {
     }
   } else if (h.data == "binary" || h.data == "binary_compressed") {
     const size_t total = (size_t)n * (size_t)h.record_bytes;
-    std::vector<unsigned char> buf(total ? total : 1);
     const bool soa = h.data == "binary_compressed";
+    // what is left of the file bounds what a truthful header can announce (no allocation on a header's word alone)
+    const long here = ftell(f);
+    long left = 0;
+    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+      left = ftell(f) - here;
+      (void)fseek(f, here, SEEK_SET);
+    }
+    if (left < 0 || (!soa && (size_t)left < total) || (soa && (left < 8 || total > ((size_t)1 << 31)))) {
+      fclose(f);
+      return QTR_ERR_IO;
+    }
+    std::vector<unsigned char> buf(total ? total : 1);
     if (soa) {
       uint32_t sizes[2] = {0, 0};
-      if (fread(sizes, 4, 2, f) != 2 || sizes[1] != total) {
+      if (fread(sizes, 4, 2, f) != 2 || sizes[1] != total || (size_t)sizes[0] > (size_t)left - 8) {
         rc = QTR_ERR_IO;
       } else {
         std::vector<unsigned char> comp(sizes[0] ? sizes[0] : 1);

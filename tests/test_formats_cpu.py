@@ -198,3 +198,24 @@ def test_feature_pair_cache_python_and_cpp_agree(tmp_path):
 
 def fm2_merge(fm):
     return np.concatenate([fm.getSrcKps()[:, :3], fm.getTgtKps()[:, :3]])
+
+
+def test_pcd_reader_survives_hostile_headers(tmp_path):
+    """Sizes come from the file: absurd SIZE / COUNT / POINTS / compressed-size words must end in an I/O error, not in
+    arithmetic overflow or a giant allocation (found by fuzzing the reader under ASan/UBSan)."""
+    body = "1 2 3\n"
+    for bad in ("SIZE 4 4 2147483647", "COUNT 1 1 2147483647", "SIZE 4 4 0", "COUNT 1 1 -3"):
+        head = "VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n"
+        key = bad.split()[0]
+        head = "\n".join(bad if ln.startswith(key) else ln for ln in head.split("\n"))
+        (tmp_path / "h.pcd").write_text(head + body)
+        with pytest.raises(OSError):
+            ql.read_pcd_xyz(str(tmp_path / "h.pcd"))
+    head = "VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2000000000\nHEIGHT 1\nPOINTS 2000000000\n"
+    (tmp_path / "big.pcd").write_bytes((head + "DATA binary\n").encode() + b"\x00" * 24)
+    with pytest.raises(OSError):
+        ql.read_pcd_xyz(str(tmp_path / "big.pcd"))
+    (tmp_path / "lzf.pcd").write_bytes((head.replace("2000000000", "10") + "DATA binary_compressed\n").encode() +
+                                       struct.pack("<II", 0xFFFFFFFF, 120) + b"\x00" * 16)
+    with pytest.raises(OSError):
+        ql.read_pcd_xyz(str(tmp_path / "lzf.pcd"))
