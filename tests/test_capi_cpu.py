@@ -237,3 +237,58 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         cls = pairs[w[0]]
         assert int(w[1]) == ctypes.sizeof(cls), w[0]
         assert [int(v) for v in w[2:]] == [getattr(cls, n).offset for n, _ in cls._fields_], w[0]
+
+
+def test_teaser_graph_host_class_under_sanitizers(tmp_path):
+    """teaser::Graph of include/teaser/graph.h (addEdge refuses duplicates / unknown vertices, removeEdge, adjacency
+    lists, the bit matrix handed to qtr_max_clique) against a Python model, compiled with ASan + UBSan; no GPU."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "graph_host_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "graph_host_demo.cpp"),
+                           "-o", exe, "-L", libdir, "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(5)
+    n = 150
+    ops, adj, nedges = [], [[] for _ in range(n)], 0
+    for _ in range(3000):
+        a, b = int(rng.integers(-2, n + 2)), int(rng.integers(-2, n + 2))
+        if rng.random() < 0.8:
+            ops.append(f"+ {a} {b}")
+            if 0 <= a < n and 0 <= b < n and b not in adj[a]:
+                adj[a].append(b)
+                if a != b:
+                    adj[b].append(a)
+                else:
+                    adj[a].append(a)
+                nedges += 1
+        else:
+            ops.append(f"- {a} {b}")
+            if 0 <= a < n and 0 <= b < n and b in adj[a]:
+                adj[a] = [x for x in adj[a] if x != b]
+                adj[b] = [x for x in adj[b] if x != a]
+                nedges -= 1
+    import torch
+    out = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe], input=f"{n}\n" + "\n".join(ops) + "\n", capture_output=True, text=True, env=env, timeout=120)
+        if p.returncode == 0:
+            out = p.stdout.strip().splitlines()
+            break
+    assert out is not None, p.stderr[-800:]
+    assert out[0].split() == [str(n), str(nedges)]
+    for v in range(n):
+        assert out[1 + v] == f"{v}:" + "".join(f" {u}" for u in adj[v]), v
+    W = (n + 63) // 64
+    words = [int(x, 16) for x in out[1 + n:1 + n + n * W]]
+    for v in range(n):
+        bits = 0
+        for u in adj[v]:
+            if u != v:
+                bits |= 1 << u
+        got = sum(words[v * W + w] << (64 * w) for w in range(W))
+        assert got == bits, v
+    assert out[-1].split() == ["has", "1" if 1 in adj[0] else "0", "0", "0"]
