@@ -1064,3 +1064,51 @@ def test_back_end_against_the_composed_second_restatement(qo, L, frac, noise, se
     assert o["rot_inliers"].tolist() == r["rot_inliers"] and o["gnc_iters"] == r["gnc_iters"]
     assert o["final_inliers"].tolist() == r["final_inliers"]
     assert np.abs(o["T"] - r["T"]).max() < 1e-9
+
+
+def test_gnc_rotation3d_against_an_svd_restatement(qo):
+    """The 3-DoF loop with numpy's SVD-based svdRot (reference include/teaser/utils.h:123-149) and a sequential cost sum:
+    same iteration count and inlier mask, rotation to 1e-9."""
+    from scipy.spatial.transform import Rotation as Rt
+
+    def ref(X, Y, nb, factor, max_iter, thr):
+        X, Y = X.T, Y.T
+        M = X.shape[1]
+        w = np.ones(M)
+        mu, prev, cost, iters = 1.0, np.inf, np.inf, 0
+        nb_sq = nb * nb if nb * nb >= 1e-16 else 1e-2
+        R = np.eye(3)
+        for i in range(max_iter):
+            iters = i + 1
+            U, _, Vt = np.linalg.svd((X * w) @ Y.T)
+            V = Vt.T
+            if np.linalg.det(U) * np.linalg.det(V) < 0:
+                V[:, 2] *= -1
+            R = V @ U.T
+            res = ((Y - R @ X) ** 2).sum(0)
+            if i == 0:
+                mu = 1 / (2 * res.max() / nb_sq - 1)
+                if mu <= 0:
+                    break
+            th1, th2 = (mu + 1) / mu * nb_sq, mu / (mu + 1) * nb_sq
+            cost = 0.0
+            for j in range(M):
+                cost += w[j] * res[j]
+                w[j] = 0 if res[j] >= th1 else 1 if res[j] <= th2 else np.sqrt(nb_sq * mu * (mu + 1) / res[j]) - mu
+            d = abs(cost - prev)
+            mu *= factor
+            prev = cost
+            if d < thr:
+                break
+        return R, cost, iters, w >= 0.4
+    rng = np.random.default_rng(19)
+    for M, noise, frac_out, nb in [(3, 0.0, 0.0, 0.6), (80, 0.02, 0.25, 0.6), (400, 0.05, 0.5, 0.3), (900, 0.05, 0.7, 0.2)]:
+        X = rng.uniform(-10, 10, (M, 3))
+        Rm = Rt.from_euler("zyx", rng.uniform(-80, 80, 3), degrees=True).as_matrix()
+        Y = X @ Rm.T + rng.normal(0, noise, (M, 3))
+        out = rng.random(M) < frac_out
+        Y[out] = rng.uniform(-10, 10, (int(out.sum()), 3))
+        R, cost, iters, mask = qo.gnc_rotation3d(X, Y, nb, 1.4, 60, 1.1e-4)
+        Rr, costr, itr, maskr = ref(X, Y, nb, 1.4, 60, 1.1e-4)
+        assert iters == itr and np.array_equal(mask, maskr)
+        assert np.abs(R - Rr).max() < 1e-9
