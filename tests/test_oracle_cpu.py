@@ -1112,3 +1112,65 @@ def test_gnc_rotation3d_against_an_svd_restatement(qo):
         Rr, costr, itr, maskr = ref(X, Y, nb, 1.4, 60, 1.1e-4)
         assert iters == itr and np.array_equal(mask, maskr)
         assert np.abs(R - Rr).max() < 1e-9
+
+
+def _splitmix_u32(seed, counter):
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    return mix(mix(seed) ^ ((counter * 0xD1342543DE82EF95) & M)) >> 32
+
+
+def test_tuple_test_against_a_second_restatement(qo):
+    """The tuple constraint (reference src/teaser_utils/feature_matcher.cc:172-247) with the oracle's declared RNG (D1:
+    trial t draws qm_rand_u32(seed, 3t + k) mod ncorr) written again in Python with float32 arithmetic: normalizePoints'
+    sequential float means, ncorr * 100 trials, the six scale tests, un-swap, sort, unique."""
+    f32 = np.float32
+    rng = np.random.default_rng(23)
+    for ns, nt, seed in [(60, 80, 0), (200, 150, 5), (120, 120, 123456789)]:
+        centres = rng.uniform(0, 100, (max(ns, nt) // 2, 33))
+        pick_s, pick_t = rng.integers(0, centres.shape[0], ns), rng.integers(0, centres.shape[0], nt)
+        fs = (centres[pick_s] + rng.normal(0, 2.0, (ns, 33))).astype(f32)
+        ft = (centres[pick_t] + rng.normal(0, 2.0, (nt, 33))).astype(f32)
+        # geometry consistent with the descriptor clusters, so that a good share of the triples passes
+        anchor = rng.uniform(-20, 20, (centres.shape[0], 3))
+        xs = np.zeros((ns, 4), dtype=f32)
+        xt = np.zeros((nt, 4), dtype=f32)
+        xs[:, :3] = anchor[pick_s] + rng.normal(0, 0.05, (ns, 3))
+        xt[:, :3] = anchor[pick_t] + rng.normal(0, 0.05, (nt, 3)) + np.array([3.0, -1.0, 0.5])
+        cross = qo.match(xs, fs, xt, ft, crosscheck=True, tuple_test=False)
+        got = qo.match(xs, fs, xt, ft, crosscheck=True, tuple_test=True, tuple_scale=0.95, seed=seed)
+
+        def centred(x):  # Matcher::normalizePoints with use_absolute_scale: sequential float mean, subtracted
+            m = np.zeros(3, dtype=f32)
+            for p in x[:, :3]:
+                m = (m + p).astype(f32)
+            m = (m / f32(x.shape[0])).astype(f32)
+            return (x[:, :3] - m).astype(f32)
+        pc = [centred(xs), centred(xt)]
+        swapped = nt > ns
+        fi, fj = (1, 0) if swapped else (0, 1)
+        corres = [(int(b), int(a)) if swapped else (int(a), int(b)) for a, b in cross]  # (i in fi, j in fj), ascending i
+        corres.sort()
+        ncorr = len(corres)
+        assert ncorr > 3
+
+        def norm3(a, b):
+            d = (a - b).astype(f32)
+            return np.sqrt(f32(d[0] * d[0]) + (f32(d[1] * d[1]) + f32(d[2] * d[2])), dtype=f32)
+        scale = f32(0.95)
+        kept = set()
+        for t in range(ncorr * 100):
+            r = [_splitmix_u32(seed, 3 * t + k) % ncorr for k in range(3)]
+            (i0, j0), (i1, j1), (i2, j2) = corres[r[0]], corres[r[1]], corres[r[2]]
+            li = [norm3(pc[fi][i0], pc[fi][i1]), norm3(pc[fi][i1], pc[fi][i2]), norm3(pc[fi][i2], pc[fi][i0])]
+            lj = [norm3(pc[fj][j0], pc[fj][j1]), norm3(pc[fj][j1], pc[fj][j2]), norm3(pc[fj][j2], pc[fj][j0])]
+            if all((f32(a * scale) < b) and (b < f32(a / scale)) for a, b in zip(li, lj)):
+                kept.update([(i0, j0), (i1, j1), (i2, j2)])
+        want = sorted((j, i) if swapped else (i, j) for i, j in kept)
+        assert [tuple(v) for v in got.tolist()] == want, (ns, nt, seed)
+        assert 0 < len(want) <= ncorr
