@@ -4,16 +4,23 @@ max-clique -> GNC-TLS -> COTE) on synthetic KITTI-64-shaped scan pairs resident 
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run, one rank per GPU.  A step = one registration of one scan pair (BASELINE.json
-configs[1]); pairs are independent, so ranks shard pairs with no data-path collective and the only
-exchange is the final gather of fixed-size result records over RCCL ("weak" scaling: per-GPU work
-fixed).  Prints ONE JSON line on rank 0.
+configs[1]: a single KITTI-64 pair, whole path on the GPU).  The K timed steps are the pair ids [0, K),
+block-partitioned over the ranks (quatro_amd.dist.shard_range — BASELINE configs[3]'s partition, "strong"
+scaling: the id range is fixed, N only changes who runs which block); pair id -> synthetic pair is
+id % pool.  Pairs are independent, so there is no data-path collective; the only exchange is the gather of
+the fixed-size result records (RCCL) after the timed region plus the barrier / max-over-ranks of the contract.
+Prints ONE JSON line on rank 0.
 
-Extra objects in the line:
-  roofline     — dominant kernel (33-D nearest-neighbour contraction): algorithmic FLOP per launch
-                 (66 * n_small * n_large) / mean launch duration from HIP events recorded by the library on
-                 the launch stream, against the FP32 matrix/vector peak of MI355X.
-  cpu_baseline — the CPU oracle (a port; the reference cannot be built here) timed on this box's host cores
-                 on a bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
+Objects in the line next to the contract's keys:
+  roofline      — dominant kernel k_nn_mfma (33-D distance matrix through v_mfma_f32_32x32x2_f32): algorithmic
+                  FLOP of the launches that were timed (sum of 66 * n_query * n_base per launch) / their summed
+                  duration (HIP events recorded by the library on the launch stream), against the FP32 matrix peak.
+                  `end_to_end`: the registration's algorithmic FLOP and bytes priced at the
+                  MFMA / HBM peaks, over the measured time per step.
+  cpu_baseline  — the CPU oracle (a port: the reference cannot be built here; brute-force NN instead of FLANN
+                  kd-trees) on this box's host cores, swept over OMP thread counts on a bounded sample; `value` is the
+                  best setting, `omp4` the reference README's 4-thread setting.  A reported baseline, not the target.
+  solver_L5000_leg, batch256_leg, dense_leg, sharded_leg — the other BASELINE configs, never part of `value`.
 """
 from __future__ import annotations
 
@@ -29,8 +36,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 vector = FP32 matrix peak
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32) = FP32 vector peak
 HBM_PEAK_GBS = 8000.0
+METRIC = "scan-pair registrations/sec (KITTI 64-ch, ~5k corr) + rot/trans err vs ref"  # BASELINE.json, verbatim
+
+
+def algorithmic_work(P_s, P_t, n_s, n_t, L, M):
+    """bytes (each logical array once written + once read at a stage boundary) and FLOP (the
+    33-D distance matrix, once) of one registration."""
+    b = 0.0
+    for P, n in ((P_s, n_s), (P_t, n_t)):
+        b += 16.0 * P + 16.0 * n        # A voxel grid
+        b += 32.0 * n                   # B normals
+        b += 164.0 * n                  # C SPFH
+        b += 264.0 * n                  # D FPFH
+    b += 140.0 * (n_s + n_t)            # E matching (descriptors + NN tables)
+    b += 48.0 * L + L * L / 8.0         # G consistency graph (bit matrix)
+    b += L * L / 8.0                    # H clique search (one read)
+    b += 48.0 * M + 128.0               # I GNC + COTE
+    return b, 66.0 * n_s * n_t
 
 
 def main() -> None:
@@ -38,13 +62,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="kitti64_pair", choices=["kitti64_pair", "solver5k"])
-    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs cycled through per rank")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--stream-slots", type=int, default=4,
-                    help="extra (untimed-for-`value`) leg: the same K steps with this many pairs in flight on "
-                         "independent stream slots of one GPU (BASELINE configs[2] style); 0 = skip")
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs (pair id -> pair id %% pool)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--legs", default="solver5k,batch,dense,segment,patchwork",
+                    help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`)")
+    ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
+    ap.add_argument("--sharded-pairs", type=int, default=4096, help="pair ids of the N>1 sharded leg (configs[3])")
     args = ap.parse_args()
+    legs = set(x for x in args.legs.split(",") if x)
 
     import torch
     import torch.distributed as dist
@@ -66,165 +91,79 @@ def main() -> None:
     from quatro_amd import lib as ql
     from quatro_amd import synth
 
-    h = ql.Handle(local_rank)
+    h = ql.Handle(local_rank, max_points=131072, max_voxels=32768, max_corr=8192)
     prm = ql.demo_params()
     res = ql.Result()
 
-    # ---- synthetic inputs, resident in HBM before the timed region
+    # ---- synthetic inputs (the same pool on every rank), resident in HBM before the timed region
     pool = []
-    for i in range(args.pairs):
-        pid = rank * args.pairs + i
-        if args.workload == "kitti64_pair":
-            s, t, Tgt = synth.kitti64_pair(pid)
-        else:
-            s, t, Tgt, _ = synth.correspondences(5000, 0.05, seed=pid, noise=0.1)
+    for pid in range(args.pool):
+        s, t, Tgt = synth.kitti64_pair_16k(pid)
         pool.append({"id": pid, "src_h": s, "tgt_h": t, "Tgt": Tgt, "src": torch.from_numpy(s).to(dev),
                      "tgt": torch.from_numpy(t).to(dev), "fp": ql.default_frontend_params(seed=pid)})
     torch.cuda.synchronize()
 
-    def step(p):
-        if args.workload == "kitti64_pair":
-            rc = h.register_pair_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
-                                     p["fp"], prm, res)
-        else:
-            rc = h.solve_dev(p["src"].data_ptr(), p["tgt"].data_ptr(), p["src"].shape[0], prm, res)
+    def step(p, handle=h, r=res, slot=0):
+        rc = handle.register_pair_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
+                                      p["fp"], prm, r, slot)
         if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
-            raise ql.QuatroHipError(rc, h.last_error())
+            raise ql.QuatroHipError(rc, handle.last_error())
 
+    # sizes of every pool pair (one untimed registration each): needed for the per-launch FLOP accounting
+    for p in pool:
+        step(p)
+        p["n_src"], p["n_tgt"], p["L"], p["M"] = res.n_src, res.n_tgt, res.n_corr, res.n_clique
+    lo, hi = qdist.shard_range(args.steps, rank, world)
     for w in range(args.warmup):
         step(pool[w % len(pool)])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    nn_ms, nn_launches, stage_acc = 0.0, 0, {}
+    nn_ms, nn_launches, nn_flop, stage_acc = 0.0, 0, 0.0, {}
+    alg_bytes, alg_flop = 0.0, 0.0
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(pool[k % len(pool)])
+    for k in range(lo, hi):
+        p = pool[k % len(pool)]
+        step(p)
         st = h.stage_times()
         nn_ms += st["nn_kernel"]
         nn_launches += st["nn_launches"]
+        nn_flop += st["nn_launches"] * 66.0 * p["n_src"] * p["n_tgt"]  # both directions: n_query * n_base is the same
         for key, v in st.items():
             stage_acc[key] = stage_acc.get(key, 0.0) + float(v)
+        b_, f_ = algorithmic_work(p["src"].shape[0], p["tgt"].shape[0], p["n_src"], p["n_tgt"], p["L"], p["M"])
+        alg_bytes += b_
+        alg_flop += f_
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = qdist.max_over_ranks(elapsed, dev)
-
-    # ---- extra leg: several pairs in flight per GPU (one host thread + one stream slot each).  Reported next to
-    # `value`, never as `value`: configs[1] is the single-pair workload.
-    multi = None
-    if args.stream_slots > 1 and args.workload == "kitti64_pair":
-        import threading
-        S = args.stream_slots
-        hm = ql.Handle(local_rank, n_slots=S)
-        results = [ql.Result() for _ in range(S)]
-
-        def worker(slot, count):
-            for k in range(count):
-                p = pool[(slot + k * S) % len(pool)]
-                rc = hm.register_pair_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
-                                          p["fp"], prm, results[slot], slot)
-                if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
-                    raise ql.QuatroHipError(rc, hm.last_error())
-
-        def run(total):
-            per = [(total + S - 1 - i) // S for i in range(S)]
-            th = [threading.Thread(target=worker, args=(i, per[i])) for i in range(S)]
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-
-        run(max(S, args.warmup))
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tm0 = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tm = qdist.max_over_ranks(time.perf_counter() - tm0, dev)
-        multi = {"stream_slots": S, "steps": args.steps, "value": world * args.steps / tm, "unit": "registrations/s",
-                 "ms_per_step": 1e3 * tm / args.steps}
-        hm.close()
-
-    # ---- next-row leg: range-image projection + sub-cluster rejection of the same scans
-    # (device-resident input, host copy of the two small outputs included); never part of `value`
-    seg = None
-    if world == 1 and args.workload == "kitti64_pair":
-        ipp = ql.ip_params()
-        NP = ipp.n_scan * ipp.horizon_scan
-        ov = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
-        oo = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
-        nv, no, nsg = C.c_int(), C.c_int(), C.c_int()
-
-        def seg_once(t):
-            rc = h._lib.qtr_segment_cloud(h._h, 0, t.data_ptr(), t.shape[0], C.byref(ipp), ov.data_ptr(), NP, C.byref(nv),
-                                          oo.data_ptr(), NP, C.byref(no), C.byref(nsg), None, ql.MEM_DEVICE)
-            if rc != ql.QTR_OK:
-                raise ql.QuatroHipError(rc, h.last_error())
-        for _ in range(3):
-            seg_once(pool[0]["src"])
-        torch.cuda.synchronize()
-        ts0 = time.perf_counter()
-        nscan, gpu_ms = 0, 0.0
-        for k in range(max(args.steps, 10)):
-            p = pool[k % len(pool)]
-            for t in (p["src"], p["tgt"]):
-                seg_once(t)
-                gpu_ms += h.stage_times()["total"]
-                nscan += 1
-        torch.cuda.synchronize()
-        seg = {"what": "ImageProjection::segmentCloud (Velodyne-64-HDE, 4CrossNeighbor) on the bench scans",
-               "scans_per_s": nscan / (time.perf_counter() - ts0), "gpu_ms_per_scan": gpu_ms / nscan,
-               "points_in": int(pool[0]["src"].shape[0]), "valid_out": int(nv.value), "segments": int(nsg.value)}
+    my_steps = max(hi - lo, 1)
 
     # ---- result records of the pool, gathered on rank 0 (the path's only collective)
     recs = []
     for p in pool:
-        if args.workload == "kitti64_pair":
-            r = h.register_pair(p["src_h"], p["tgt_h"], p["fp"], prm)
-        else:
-            r = h.solve(p["src_h"], p["tgt_h"], prm)
+        r = h.register_pair(p["src_h"], p["tgt_h"], p["fp"], prm)
         p["result"] = r
         recs.append(qdist.pack_record(p["id"], r))
     gathered = qdist.gather_records(np.stack(recs), dev)
 
-    # ---- next-row leg: Patchwork ground segmentation of raw 64-beam scans (with ground),
-    # device-resident input and outputs; never part of `value`
-    pwl = None
-    if world == 1 and args.workload == "kitti64_pair":
-        raws = [synth.kitti64_raw_scan(i)[0] for i in range(4)]
-        raw_d = [torch.from_numpy(r).to(dev) for r in raws]
-        capp = max(r.shape[0] for r in raws)
-        og = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
-        on = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
-        ngr, nng = C.c_int(), C.c_int()
-        pwp = ql.pw_params()
-
-        def pw_once(t):
-            rc = h._lib.qtr_patchwork(h._h, 0, t.data_ptr(), t.shape[0], C.byref(pwp), og.data_ptr(), capp, C.byref(ngr),
-                                      on.data_ptr(), capp, C.byref(nng), ql.MEM_DEVICE)
-            if rc != ql.QTR_OK:
-                raise ql.QuatroHipError(rc, h.last_error())
-        for _ in range(3):
-            pw_once(raw_d[0])
-        torch.cuda.synchronize()
-        tp0 = time.perf_counter()
-        nscan, gpu_ms = 0, 0.0
-        for k in range(max(2 * args.steps, 20)):
-            pw_once(raw_d[k % len(raw_d)])
-            gpu_ms += h.stage_times()["total"]
-            nscan += 1
-        torch.cuda.synchronize()
-        pw_once(raw_d[0])
-        pwl = {"what": "PatchWork::estimate_ground (config/patchwork_params.yaml) on synthetic raw 64-beam scans",
-               "scans_per_s": nscan / (time.perf_counter() - tp0), "gpu_ms_per_scan": gpu_ms / nscan,
-               "points_in": int(raws[0].shape[0]), "ground_out": int(ngr.value), "nonground_out": int(nng.value)}
-        pwl["_raw0"] = raws[0]
+    extra = {}
+    # ---- BASELINE configs[2]: a batch of independent pairs streamed through one GPU
+    if "batch" in legs and hasattr(h, "register_batch_dev"):
+        extra["batch256_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist)
+    # ---- solver alone at the metric's "~5k corr" (the matcher yields fewer on the synthetic scans)
+    if "solver5k" in legs and rank == 0:
+        extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
+    if "dense" in legs and rank == 0 and world == 1:
+        extra.update(dense_legs(args, torch, ql, synth, prm, dev, local_rank))
+    seg = pwl = None
+    if world == 1 and "segment" in legs:
+        seg = segment_leg(args, torch, ql, h, pool, dev)
+    if world == 1 and "patchwork" in legs:
+        pwl = patchwork_leg(args, torch, ql, synth, h, dev)
 
     if rank != 0:
         if world > 1:
@@ -233,120 +172,353 @@ def main() -> None:
 
     p0 = pool[0]
     r0 = p0["result"]
-    value = world * args.steps / elapsed
+    value = args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
     out = {
-        "metric": "scan-pair registrations/sec (KITTI 64-ch) + rot/trans err vs ref",
+        "metric": METRIC,
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (front end) / f64 (solver)", "data": "synthetic",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (voxel grid, FPFH, 33-D matching) / f64 (consistency graph, GNC-TLS, COTE)", "data": "synthetic",
         "config": {
-            "workload": ("synthetic KITTI-64-shaped single pair, voxel 0.3 m, whole path on GPU (BASELINE configs[1])"
-                         if args.workload == "kitti64_pair" else "solver only, 5000 synthetic correspondences"),
+            "workload": "synthetic KITTI-64-shaped single pair (quatro_amd.synth.kitti64_pair_16k), voxel 0.3 m, whole "
+                        "path on GPU, one registration at a time (BASELINE configs[1])",
             "raw_points": [int(p0["src_h"].shape[0]), int(p0["tgt_h"].shape[0])],
-            "n_src": int(r0.get("n_src", 0)), "n_tgt": int(r0.get("n_tgt", 0)), "n_corr": int(r0["L"]),
+            "n_src": int(r0["n_src"]), "n_tgt": int(r0["n_tgt"]), "n_corr": int(r0["L"]),
             "n_clique": int(r0["clique"].size), "n_final_inliers": int(r0["final_inliers"].size),
-            "pairs_per_rank": len(pool), "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
-            "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, RCCL gather of result records",
+            "pool": [{"id": p["id"], "n_src": int(p["n_src"]), "n_tgt": int(p["n_tgt"]), "n_corr": int(p["L"])}
+                     for p in pool],
+            "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
+            "parallelism": f"pair ids [0,{args.steps}) block-partitioned over {world} GPU(s), one process per GPU, RCCL "
+                           "gather of result records",
         },
-        "stage_ms": {k: round(v / args.steps, 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
+        "stage_ms": {k: round(v / my_steps, 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
     }
-    if multi is not None:
-        out["pairs_in_flight_leg"] = multi
+    out.update(extra)
     if seg is not None:
         out["segment_cloud_leg"] = seg
     raw0 = pwl.pop("_raw0") if pwl is not None else None
     if pwl is not None:
         out["patchwork_leg"] = pwl
-    if args.workload == "kitti64_pair":
-        ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
-        out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]
-        out["config"]["nn_rows_pair_compare"] = [int(ms[10]), int(ms[11])]
-        out["config"]["n_cross_checked"] = int(ms[3])
+    ms = h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)
+    out["config"]["nn_rows_exact_recheck"] = [int(ms[8]), int(ms[9])]
+    out["config"]["n_cross_checked"] = int(ms[3])
     yaw_gt = float(np.arctan2(p0["Tgt"][1, 0], p0["Tgt"][0, 0]))
     yaw = float(np.arctan2(r0["T"][1, 0], r0["T"][0, 0]))
     out["accuracy_vs_ground_truth"] = {
         "rot_err_rad": abs(float(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt)))),
         "trans_err_m": float(np.linalg.norm(r0["T"][:3, 3] - p0["Tgt"][:3, 3])), "valid": bool(r0["valid"])}
 
-    # ---- roofline of the dominant kernel
-    if args.workload == "kitti64_pair" and nn_launches > 0:
-        ns, nt = int(r0["n_src"]), int(r0["n_tgt"])
-        flop_per_launch = 66.0 * ns * nt
+    # ---- roofline of the dominant kernel (rank 0's launches), and of the whole registration
+    if nn_launches > 0:
         mean_launch_s = 1e-3 * nn_ms / nn_launches
+        flop_per_launch = nn_flop / nn_launches
         achieved = flop_per_launch / mean_launch_s / 1e12
-        out["roofline"] = {"kernel": "k_nn (33-D reciprocal nearest neighbour, one launch per direction)",
-                           "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                           "flop_per_launch": flop_per_launch, "mean_launch_ms": 1e3 * mean_launch_s}
+        bound_ms = 1e3 * max(alg_flop / my_steps / (FP32_PEAK_TFLOPS * 1e12), alg_bytes / my_steps / (HBM_PEAK_GBS * 1e9))
+        out["roofline"] = {
+            "kernel": "k_nn_mfma (33-D distance matrix + per-query top-2, one launch per direction)",
+            "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+            "flop_per_launch": flop_per_launch, "mean_launch_ms": 1e3 * mean_launch_s, "launches_timed": nn_launches,
+            "end_to_end": {
+                "algorithmic_gflop_per_registration": alg_flop / my_steps / 1e9,
+                "algorithmic_mbytes_per_registration": alg_bytes / my_steps / 1e6,
+                "mfma_bound_ms": 1e3 * alg_flop / my_steps / (FP32_PEAK_TFLOPS * 1e12),
+                "hbm_bound_ms": 1e3 * alg_bytes / my_steps / (HBM_PEAK_GBS * 1e9),
+                "ms_per_step": ms_per_step, "frac": bound_ms / ms_per_step},
+        }
         # HBM-side bytes per launch come from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
         # this same command); counters cannot be read in-process, so the committed summary is quoted
         import glob
-        pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_nn.json")))
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_nn.json")))
         if pmc:
             with open(pmc[-1]) as f:
                 pj = json.load(f)
             out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE + WRITE_SIZE)"
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc[-1])
-    else:
-        L = int(r0["L"])
-        gk = stage_acc.get("graph", 0.0) / max(args.steps, 1)
-        alg_bytes = 32.0 * L + L * L / 8.0  # 2 x 16 B per correspondence in + bit matrix out
-        achieved = alg_bytes / (1e-3 * gk) / 1e9 if gk > 0 else 0.0
-        out["roofline"] = {"kernel": "k_graph_build (stage time)", "bound": "hbm", "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample; also the parity check
     if world == 1 and args.cpu_seconds > 0:
-        from oracle import oracle as qo  # cpu_baseline leg: the only place bench.py touches oracle/
-        cores = os.cpu_count() or 1
-        qo.set_threads(cores)
-
-        def cpu_once():
-            if args.workload == "kitti64_pair":
-                return qo.register_pair(p0["src_h"], p0["tgt_h"], seed=p0["id"])
-            return qo.solve(p0["src_h"], p0["tgt_h"])
-
-        t1 = time.perf_counter()
-        o = cpu_once()  # warm-up, also the parity reference
-        first = time.perf_counter() - t1
-        runs = int(max(1, min(5, args.cpu_seconds / max(first, 1e-3) - 1)))
-        ts = []
-        for _ in range(runs):
-            t1 = time.perf_counter()
-            cpu_once()
-            ts.append(time.perf_counter() - t1)
-        med = float(np.median(ts))
-        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
-                               "sample": f"pair {p0['id']} of the same workload: 1 warm-up + {runs} timed runs of the "
-                                         f"OpenMP CPU oracle (median {med:.3f} s)"}
-        yaw_o = float(np.arctan2(o["T"][1, 0], o["T"][0, 0]))
-        out["parity_vs_oracle"] = {
-            "rot_err_rad": abs(float(np.arctan2(np.sin(yaw - yaw_o), np.cos(yaw - yaw_o)))),
-            "trans_err_m": float(np.linalg.norm(r0["T"][:3, 3] - o["T"][:3, 3])),
-            "clique_bit_exact": bool(np.array_equal(r0["clique"], o["clique"])),
-            "final_inliers_bit_exact": bool(np.array_equal(r0["final_inliers"], o["final_inliers"])),
-            "counts_equal": bool(args.workload != "kitti64_pair" or
-                                 (r0["n_src"], r0["n_tgt"], r0["L"]) == (o["n_src"], o["n_tgt"], o["L"]))}
-        out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
-        if seg is not None:  # the same scans through the oracle's breadth-first restatement, one thread (it is serial)
-            t1 = time.perf_counter()
-            so = qo.segment_cloud(p0["src_h"])
-            cpu_s = time.perf_counter() - t1
-            gs = h.segment_cloud(p0["src_h"])
-            out["segment_cloud_leg"]["cpu_port_scans_per_s"] = 1.0 / cpu_s
-            out["segment_cloud_leg"]["labels_bit_exact"] = bool(np.array_equal(gs["labels"], so["labels"]))
-        if pwl is not None:  # the serial CPU restatement on one of the same scans
-            t1 = time.perf_counter()
-            po = qo.patchwork(raw0)
-            cpu_s = time.perf_counter() - t1
-            pg = h.patchwork(raw0)
-            out["patchwork_leg"]["cpu_port_scans_per_s"] = 1.0 / cpu_s
-            out["patchwork_leg"]["outputs_bit_exact"] = bool(np.array_equal(pg["ground"], po["ground"]) and
-                                                             np.array_equal(pg["nonground"], po["nonground"]))
+        out.update(cpu_baseline_leg(args, ql, h, p0, r0, yaw, value, seg, pwl, raw0))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist):
+    """BASELINE configs[2] (and, for N > 1, configs[3]): B pair ids streamed through the batched entry points
+    (qtr_submit_batch / qtr_wait), block-partitioned over the ranks."""
+    B = args.batch_pairs if world == 1 else args.sharded_pairs
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = qdist.shard_range(B, rank, world)
+    hb = ql.Handle(torch.cuda.current_device(), max_points=131072, max_voxels=32768, max_corr=8192, n_slots=32)
+    ids = list(range(lo, hi))
+    pairs = [pool[i % len(pool)] for i in ids]
+    hb.register_batch_dev(pairs[:64], prm)  # warm-up
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    results = hb.register_batch_dev(pairs, prm)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = qdist.max_over_ranks(time.perf_counter() - t0, dev)
+    same = all(bool(np.allclose(r["T"], pool[i % len(pool)]["result"]["T"], rtol=0, atol=0)) for i, r in zip(ids, results))
+    hb.close()
+    return {"what": f"{B} pair ids, block-partitioned over {world} GPU(s), batched launch chains "
+                    "(qtr_submit_batch / qtr_wait)", "pairs": B, "value": B / el, "unit": "registrations/s",
+            "ms_per_pair": 1e3 * el / B, "identical_to_sequential": same}
+
+
+def solver_leg(args, torch, ql, synth, h, prm, dev, L):
+    res = ql.Result()
+    items = []
+    for sid in range(4):
+        s, t, _, _ = synth.correspondences(L, 0.05, seed=sid, noise=0.1)
+        items.append((torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)))
+    for s, t in items:
+        h.solve_dev(s.data_ptr(), t.data_ptr(), L, prm, res)
+    torch.cuda.synchronize()
+    n = max(args.steps, 20)
+    g_ms = 0.0
+    t0 = time.perf_counter()
+    for k in range(n):
+        s, t = items[k % len(items)]
+        rc = h.solve_dev(s.data_ptr(), t.data_ptr(), L, prm, res)
+        if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+            raise ql.QuatroHipError(rc, h.last_error())
+        g_ms += h.stage_times()["graph"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gk = 1e-3 * g_ms / n
+    gb = 48.0 * L + L * L / 8.0
+    return {"what": f"Quatro::computeTransformation alone on {L} synthetic correspondences (5 % planted inliers)",
+            "value": n / el, "unit": "solves/s", "ms_per_solve": 1e3 * el / n, "n_clique": int(res.n_clique),
+            "graph_build": {"bound": "hbm", "algorithmic_bytes": gb, "stage_ms": 1e3 * gk,
+                            "achieved": gb / gk / 1e9 if gk > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (gb / gk / 1e9 / HBM_PEAK_GBS) if gk > 0 else 0.0}}
+
+
+def dense_legs(args, torch, ql, synth, prm, dev, device_index):
+    """BASELINE configs[4]: dense mode — 50 k-point clouds without voxel down-sampling through FPFH + matching (the NN
+    contraction at 50 k x 50 k = 1.65e11 FLOP per direction) and the solver at L = 20 000 (50 MB bit matrix)."""
+    out = {}
+    hd = ql.Handle(device_index, max_points=65536, max_voxels=65536, max_corr=24576)
+    res = ql.Result()
+    L = 20000
+    s, t, _, _ = synth.correspondences(L, 0.02, seed=7, noise=0.1)
+    sd, td = torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)
+    hd.solve_dev(sd.data_ptr(), td.data_ptr(), L, prm, res)
+    torch.cuda.synchronize()
+    n = 5
+    g_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        hd.solve_dev(sd.data_ptr(), td.data_ptr(), L, prm, res)
+        g_ms += hd.stage_times()["graph"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gk = 1e-3 * g_ms / n
+    gb = 48.0 * L + L * L / 8.0
+    out["dense_solver_leg"] = {
+        "what": f"solver at L = {L} (2 % planted inliers): O(L^2) consistency graph as a {L * L / 8e6:.0f} MB bit matrix",
+        "value": n / el, "unit": "solves/s", "ms_per_solve": 1e3 * el / n, "n_clique": int(res.n_clique),
+        "roofline": {"kernel": "k_graph_build", "bound": "hbm", "algorithmic_bytes": gb, "stage_ms": 1e3 * gk,
+                     "achieved": gb / gk / 1e9 if gk > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (gb / gk / 1e9 / HBM_PEAK_GBS) if gk > 0 else 0.0}}
+    # front end at 50 k points per cloud, no voxel grid: qtr_fpfh + qtr_match on device-resident arrays
+    n_pts = 50000
+    a, b, _ = synth.dense_pair(n_pts)
+    cl = [torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)]
+    desc = [torch.zeros((n_pts, 33), dtype=torch.float32, device=dev) for _ in range(2)]
+    fp = ql.default_frontend_params(seed=1)
+    corr = torch.zeros((n_pts, 2), dtype=torch.int32, device=dev)
+    Lout = C.c_int()
+
+    def fe_once():
+        f_ms = 0.0
+        for c, d in zip(cl, desc):
+            rc = hd._lib.qtr_fpfh(hd._h, 0, c.data_ptr(), n_pts, fp.normal_radius, fp.fpfh_radius, None, d.data_ptr(),
+                                  ql.MEM_DEVICE)
+            if rc != ql.QTR_OK:
+                raise ql.QuatroHipError(rc, hd.last_error())
+            f_ms += hd.stage_times()["fpfh"]
+        rc = hd._lib.qtr_match(hd._h, 0, cl[0].data_ptr(), n_pts, desc[0].data_ptr(), cl[1].data_ptr(), n_pts,
+                               desc[1].data_ptr(), C.byref(fp), corr.data_ptr(), n_pts, C.byref(Lout), ql.MEM_DEVICE)
+        if rc != ql.QTR_OK:
+            raise ql.QuatroHipError(rc, hd.last_error())
+        return f_ms, hd.stage_times()
+    fe_once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    nn_ms, nn_l, f_acc, m_acc = 0.0, 0, 0.0, 0.0
+    for _ in range(reps):
+        f_ms, st = fe_once()
+        nn_ms += st["nn_kernel"]
+        nn_l += st["nn_launches"]
+        f_acc += f_ms
+        m_acc += st["match"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    flop = 66.0 * n_pts * n_pts
+    ach = flop / (1e-3 * nn_ms / max(nn_l, 1)) / 1e12 if nn_ms > 0 else 0.0
+    out["dense_frontend_leg"] = {
+        "what": f"FPFH + reciprocal matching of two {n_pts}-point clouds, no voxel down-sampling",
+        "ms_per_pair": 1e3 * el / reps, "fpfh_ms": f_acc / reps, "match_ms": m_acc / reps, "n_corr": int(Lout.value),
+        "roofline": {"kernel": "k_nn_mfma", "bound": "mfma", "flop_per_launch": flop,
+                     "mean_launch_ms": nn_ms / max(nn_l, 1), "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}}
+    hd.close()
+    return out
+
+
+def segment_leg(args, torch, ql, h, pool, dev):
+    """next-row leg: range-image projection + sub-cluster rejection of the bench scans."""
+    ipp = ql.ip_params()
+    NP = ipp.n_scan * ipp.horizon_scan
+    ov = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
+    oo = torch.zeros((NP, 4), dtype=torch.float32, device=dev)
+    nv, no, nsg = C.c_int(), C.c_int(), C.c_int()
+
+    def seg_once(t):
+        rc = h._lib.qtr_segment_cloud(h._h, 0, t.data_ptr(), t.shape[0], C.byref(ipp), ov.data_ptr(), NP, C.byref(nv),
+                                      oo.data_ptr(), NP, C.byref(no), C.byref(nsg), None, ql.MEM_DEVICE)
+        if rc != ql.QTR_OK:
+            raise ql.QuatroHipError(rc, h.last_error())
+    for _ in range(3):
+        seg_once(pool[0]["src"])
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
+    nscan, gpu_ms = 0, 0.0
+    for k in range(10):
+        p = pool[k % len(pool)]
+        for t in (p["src"], p["tgt"]):
+            seg_once(t)
+            gpu_ms += h.stage_times()["total"]
+            nscan += 1
+    torch.cuda.synchronize()
+    seg_once(pool[0]["src"])
+    return {"what": "ImageProjection::segmentCloud (Velodyne-64-HDE, 4CrossNeighbor) on the bench scans",
+            "scans_per_s": nscan / (time.perf_counter() - ts0), "gpu_ms_per_scan": gpu_ms / nscan,
+            "points_in": int(pool[0]["src"].shape[0]), "valid_out": int(nv.value), "segments": int(nsg.value)}
+
+
+def patchwork_leg(args, torch, ql, synth, h, dev):
+    """next-row leg: Patchwork ground segmentation of raw 64-beam scans (with ground)."""
+    raws = [synth.kitti64_raw_scan(i)[0] for i in range(2)]
+    raw_d = [torch.from_numpy(r).to(dev) for r in raws]
+    capp = max(r.shape[0] for r in raws)
+    og = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
+    on = torch.zeros((capp, 4), dtype=torch.float32, device=dev)
+    ngr, nng = C.c_int(), C.c_int()
+    pwp = ql.pw_params()
+
+    def pw_once(t):
+        rc = h._lib.qtr_patchwork(h._h, 0, t.data_ptr(), t.shape[0], C.byref(pwp), og.data_ptr(), capp, C.byref(ngr),
+                                  on.data_ptr(), capp, C.byref(nng), ql.MEM_DEVICE)
+        if rc != ql.QTR_OK:
+            raise ql.QuatroHipError(rc, h.last_error())
+    for _ in range(3):
+        pw_once(raw_d[0])
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    nscan, gpu_ms = 0, 0.0
+    for k in range(20):
+        pw_once(raw_d[k % len(raw_d)])
+        gpu_ms += h.stage_times()["total"]
+        nscan += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - tp0
+    pw_once(raw_d[0])
+    return {"what": "PatchWork::estimate_ground (config/patchwork_params.yaml) on synthetic raw 64-beam scans",
+            "scans_per_s": nscan / el, "gpu_ms_per_scan": gpu_ms / nscan,
+            "points_in": int(raws[0].shape[0]), "ground_out": int(ngr.value), "nonground_out": int(nng.value),
+            "_raw0": raws[0]}
+
+
+def cpu_baseline_leg(args, ql, h, p0, r0, yaw, value, seg, pwl, raw0):
+    from oracle import oracle as qo  # cpu_baseline leg: the only place bench.py touches oracle/
+    out = {}
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    phys = ncpu
+    try:  # physical cores: distinct (package, core id) pairs
+        ids = set()
+        pk = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pk = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":")[1].strip()
+                elif not line.strip():
+                    if pk is not None and cid is not None:
+                        ids.add((pk, cid))
+                    pk = cid = None
+        if ids:
+            phys = min(len(ids), ncpu)
+    except OSError:
+        pass
+    sweep = sorted(set(t for t in (4, 8, 16, 32, 64, phys) if 1 <= t <= ncpu))
+
+    def cpu_once():
+        return qo.register_pair(p0["src_h"], p0["tgt_h"], seed=p0["id"])
+
+    qo.set_threads(min(16, ncpu))
+    t1 = time.perf_counter()
+    o = cpu_once()  # warm-up, also the parity reference
+    first = time.perf_counter() - t1
+    budget = max(args.cpu_seconds - first, 1.0)
+    per_setting = budget / len(sweep)
+    table = {}
+    for th in sweep:
+        qo.set_threads(th)
+        ts = []
+        t_start = time.perf_counter()
+        while len(ts) < 5 and (not ts or time.perf_counter() - t_start + min(ts) < per_setting):
+            t1 = time.perf_counter()
+            cpu_once()
+            ts.append(time.perf_counter() - t1)
+        table[th] = float(np.median(ts))
+    best_th = min(table, key=table.get)
+    out["cpu_baseline"] = {
+        "value": 1.0 / table[best_th], "unit": "registrations/s", "cores": best_th, "kind": "port",
+        "omp4": (1.0 / table[4]) if 4 in table else None,
+        "threads_swept": {str(k): round(1.0 / v, 3) for k, v in table.items()},
+        "host_cpus": ncpu, "physical_cores": phys,
+        "sample": f"pair {p0['id']} of the same workload (n = {o['n_src']}/{o['n_tgt']}): median of up to 5 runs of the "
+                  f"OpenMP CPU oracle per thread count {sweep}; best = {best_th} threads ({table[best_th]:.3f} s). The "
+                  "oracle's 33-D NN is brute force (the reference uses FLANN kd-trees, src/teaser_utils/"
+                  "feature_matcher.cc:267-299) and its graph is a bit matrix"}
+    yaw_o = float(np.arctan2(o["T"][1, 0], o["T"][0, 0]))
+    out["parity_vs_oracle"] = {
+        "rot_err_rad": abs(float(np.arctan2(np.sin(yaw - yaw_o), np.cos(yaw - yaw_o)))),
+        "trans_err_m": float(np.linalg.norm(r0["T"][:3, 3] - o["T"][:3, 3])),
+        "clique_bit_exact": bool(np.array_equal(r0["clique"], o["clique"])),
+        "final_inliers_bit_exact": bool(np.array_equal(r0["final_inliers"], o["final_inliers"])),
+        "counts_equal": bool((r0["n_src"], r0["n_tgt"], r0["L"]) == (o["n_src"], o["n_tgt"], o["L"]))}
+    qo.set_threads(1)
+    if seg is not None:  # the same scans through the oracle's breadth-first restatement, one thread (it is serial)
+        t1 = time.perf_counter()
+        so = qo.segment_cloud(p0["src_h"])
+        cpu_s = time.perf_counter() - t1
+        gs = h.segment_cloud(p0["src_h"])
+        seg["cpu_port_scans_per_s"] = 1.0 / cpu_s
+        seg["labels_bit_exact"] = bool(np.array_equal(gs["labels"], so["labels"]))
+    if pwl is not None:  # the serial CPU restatement on one of the same scans
+        t1 = time.perf_counter()
+        po = qo.patchwork(raw0)
+        cpu_s = time.perf_counter() - t1
+        pg = h.patchwork(raw0)
+        pwl["cpu_port_scans_per_s"] = 1.0 / cpu_s
+        pwl["outputs_bit_exact"] = bool(np.array_equal(pg["ground"], po["ground"]) and
+                                        np.array_equal(pg["nonground"], po["nonground"]))
+    return out
 
 
 if __name__ == "__main__":

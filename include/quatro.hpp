@@ -16,6 +16,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -90,6 +91,10 @@ struct PointXYZ {
   PointXYZ() = default;
   PointXYZ(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
 };
+struct PointXYZI {
+  float x = 0, y = 0, z = 0, pad = 0;
+  float intensity = 0, pad2[3] = {0, 0, 0};  // 32 bytes, as PCL's EIGEN_ALIGN16 PointXYZI
+};
 template <typename PointT>
 struct PointCloud {
   using Ptr = std::shared_ptr<PointCloud<PointT>>;
@@ -125,6 +130,8 @@ class Registration {
 };
 }  // namespace pcl
 #define QUATRO_SHARED_PTR std::shared_ptr
+#include "conversion.hpp"  // the reference header includes it too (:42): pcl2teaser / pcl2eigen / eigen2pcl / xyzi2xyz
+
 #endif  // QUATRO_HAVE_PCL
 
 namespace quatro_hip {
@@ -142,21 +149,29 @@ void voxelize(const QUATRO_SHARED_PTR<pcl::PointCloud<T>> srcPtr, QUATRO_SHARED_
               double voxelSize) {
   qtr_handle* h = quatro_hip::default_handle();
   const int P = static_cast<int>(srcPtr->points.size());
-  dstPtr->points.assign(static_cast<size_t>(P), T());
+  std::vector<T> out(static_cast<size_t>(P), T());  // a temporary, like pcl::Filter::filter: dstPtr may alias srcPtr
   int n = 0;
-  quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(srcPtr->points), P, static_cast<float>(voxelSize),
-                                    reinterpret_cast<float*>(dstPtr->points.data()), P, &n, QTR_MEM_HOST));
-  dstPtr->points.resize(static_cast<size_t>(n));
+  {
+    std::lock_guard<std::mutex> lock(quatro_hip::default_slot_mutex());
+    quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(srcPtr->points), P, static_cast<float>(voxelSize),
+                                      reinterpret_cast<float*>(out.data()), P, &n, QTR_MEM_HOST));
+  }
+  out.resize(static_cast<size_t>(n));
+  dstPtr->points.swap(out);
 }
 template <typename T>
 void voxelize(pcl::PointCloud<T>& src, QUATRO_SHARED_PTR<pcl::PointCloud<T>> dstPtr, double voxelSize) {
   qtr_handle* h = quatro_hip::default_handle();
   const int P = static_cast<int>(src.points.size());
-  dstPtr->points.assign(static_cast<size_t>(P), T());
+  std::vector<T> out(static_cast<size_t>(P), T());  // dstPtr may point at src
   int n = 0;
-  quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(src.points), P, static_cast<float>(voxelSize),
-                                    reinterpret_cast<float*>(dstPtr->points.data()), P, &n, QTR_MEM_HOST));
-  dstPtr->points.resize(static_cast<size_t>(n));
+  {
+    std::lock_guard<std::mutex> lock(quatro_hip::default_slot_mutex());
+    quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(src.points), P, static_cast<float>(voxelSize),
+                                      reinterpret_cast<float*>(out.data()), P, &n, QTR_MEM_HOST));
+  }
+  out.resize(static_cast<size_t>(n));
+  dstPtr->points.swap(out);
 }
 
 template <typename PointSource, typename PointTarget, typename Scalar = double>
@@ -257,6 +272,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     if (params_.cote_mode != "median" && params_.cote_mode != "weighted_mean")
       throw std::invalid_argument("[COTE]: Wrong parameter comes!");  // :911
     qtr_handle* h = quatro_hip::default_handle();
+    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     qtr_params p;
     qtr_default_params(&p);
     p.noise_bound = params_.noise_bound;
@@ -276,17 +292,20 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     std::vector<int> clique(static_cast<size_t>(L > 0 ? L : 1)), rot(clique.size()), fin(clique.size());
     p.reg_mode = reg_name_ == "TEASER" ? QTR_REG_TEASER : QTR_REG_QUATRO;
     qtr_result res;
-    qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
-    const int rc = qtr_solve(h, 0, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
-                             clique.data(), rot.data(), fin.data(), static_cast<int>(clique.size()), QTR_MEM_HOST);
-    quatro_hip::check(h, rc);
-    params_.noise_bound *= 2.0;  // the reference persists noise_bound *= 2/scale (:850-852); reset() restores it
+    {
+      std::lock_guard<std::mutex> lock(quatro_hip::default_slot_mutex());
+      qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
+      const int rc = qtr_solve(h, 0, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
+                               clique.data(), rot.data(), fin.data(), static_cast<int>(clique.size()), QTR_MEM_HOST);
+      quatro_hip::check(h, rc);
+    }
     max_clique_.assign(clique.begin(), clique.begin() + res.n_clique);
-    num_maxclique_ = res.n_clique;
-    if (!res.valid) {  // :809-813
+    if (!res.valid) {  // :809-813: returns before num_maxclique_ (:822) and the noise-bound update (:850-852)
       solution_.valid = false;
       return;
     }
+    num_maxclique_ = res.n_clique;
+    params_.noise_bound *= 2.0;  // the reference persists noise_bound *= 2/scale (:850-852); reset() restores it
     rotation_inliers_.assign(rot.begin(), rot.begin() + res.n_rot_inliers);
     num_rot_inliers_ = res.n_rot_inliers;
     final_inliers_.assign(fin.begin(), fin.begin() + res.n_final);
@@ -319,6 +338,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < N; ++c) in[static_cast<size_t>(r) * N + c] = v(r, c);
     qtr_handle* h = quatro_hip::default_handle();
+    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     quatro_hip::check(h, qtr_compute_tims(h, 0, in.data(), N, out.data(), mp.data()));
     for (int r = 0; r < 3; ++r)
       for (long long c = 0; c < K; ++c) vtilde(r, static_cast<int>(c)) = out[static_cast<size_t>(r) * K + c];
@@ -352,6 +372,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       }
     std::vector<unsigned char> mask(static_cast<size_t>(K));
     qtr_handle* h = quatro_hip::default_handle();
+    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     quatro_hip::check(h, qtr_scale_mask(h, 0, a.data(), b.data(), K, params_.noise_bound, params_.cbar2, mask.data()));
     for (long long c = 0; c < K; ++c) (*inliers)(0, static_cast<int>(c)) = mask[static_cast<size_t>(c)] != 0;
   }
@@ -376,6 +397,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       int iters = 0;
       std::vector<unsigned char> inl(static_cast<size_t>(M));
       qtr_handle* h = quatro_hip::default_handle();
+      std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
       quatro_hip::check(h, qtr_gnc_rotation3d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
                                               static_cast<int>(params_.rotation_max_iterations),
                                               params_.rotation_cost_threshold, R9, &cost, &iters, inl.data()));
@@ -426,6 +448,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     int iters = 0;
     std::vector<unsigned char> inl(static_cast<size_t>(M));
     qtr_handle* h = quatro_hip::default_handle();
+    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     quatro_hip::check(h, qtr_gnc_rotation2d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
                                             static_cast<int>(params_.rotation_max_iterations),
                                             params_.rotation_cost_threshold, R4, &cost, &iters, inl.data()));
@@ -475,6 +498,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     double e = 0;
     int ncard = 0;
     qtr_handle* h = quatro_hip::default_handle();
+    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     quatro_hip::check(h, qtr_cote_estimate(h, 0, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e, inl.data(),
                                            &ncard));
     if (estimate_out) *estimate_out = e;
@@ -482,6 +506,16 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       inliers->resize(1, N);
       for (int c = 0; c < N; ++c) (*inliers)(0, c) = inl[static_cast<size_t>(c)] != 0;
     }
+  }
+
+  // :938-947
+  void setInliers(const Eigen::Matrix<double, 3, Eigen::Dynamic>& raw, pcl::PointCloud<PointSource>& inliers,
+                  const std::vector<int>& idx_inliers) {
+    inliers.clear();
+    inliers.reserve(idx_inliers.size());
+    for (const int idx : idx_inliers)
+      inliers.push_back(PointSource(static_cast<float>(raw(0, idx)), static_cast<float>(raw(1, idx)),
+                                    static_cast<float>(raw(2, idx))));
   }
 
   void getMaxCliques(pcl::PointCloud<PointSource>& source_max_clique,
@@ -512,5 +546,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
   std::vector<int> final_inliers_;
   Eigen::Matrix<bool, 1, Eigen::Dynamic> scale_inliers_mask_, rotation_inliers_mask_, translation_inliers_mask_;  // :1009-1015
 };
+
+#include "conversion.hpp"  // the reference header includes it too (:42): pcl2teaser / pcl2eigen / eigen2pcl / xyzi2xyz
 
 #endif  // QUATRO_H

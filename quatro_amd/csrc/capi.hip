@@ -11,6 +11,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second cloud's front end runs concurrently
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_vox = nullptr;    // voxel centroids complete (stream) -> Matcher means may start (stream2)
   void* solver_arena = nullptr;
   void* front_arena = nullptr;
   SolverBufs sb;
@@ -114,6 +115,7 @@ void qtr_destroy(qtr_handle* h) {
     if (s.stream2) (void)hipStreamSynchronize(s.stream2);
     for (auto& e : s.ev)
       if (e) (void)hipEventDestroy(e);
+    if (s.ev_vox) (void)hipEventDestroy(s.ev_vox);
     for (auto& e : s.fb.ev_nn)
       if (e) (void)hipEventDestroy(e);
     if (s.solver_arena) (void)hipFree(s.solver_arena);
@@ -142,6 +144,7 @@ static int create_impl(qtr_handle* h) {
     QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
     for (auto& e : s.ev) QTR_HIP_TRY(h, hipEventCreate(&e));
+    QTR_HIP_TRY(h, hipEventCreateWithFlags(&s.ev_vox, hipEventDisableTiming));
     for (auto& e : s.fb.ev_nn) QTR_HIP_TRY(h, hipEventCreate(&e));
     const size_t sbytes = solver_scratch_bytes(h->lim.max_corr) + 65536;
     QTR_HIP_TRY(h, hipMalloc(&s.solver_arena, sbytes));
@@ -169,6 +172,7 @@ static int create_impl(qtr_handle* h) {
       s.sb.mail = (int*)dv;
       s.fb.m_src = s.m_src;
       s.fb.m_tgt = s.m_tgt;
+      s.fb.m_cap = h->lim.max_corr;
     }
   }
   return QTR_OK;
@@ -1097,6 +1101,9 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     const int Ps2[2] = {Ps, Pt};
     s.fb.mail_seq = ++s.seq;
     QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream));
+    // block 0 of k2_vox_centroids publishes the counters while other blocks are still writing centroids: anything
+    // that reads the centroids from another stream has to wait for the kernel itself
+    QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
   }
   // k2_vox_centroids leaves both clouds' counters in the mailbox
   if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
@@ -1117,7 +1124,8 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
-    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain (stream is idle-synced here)
+    QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
+    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));

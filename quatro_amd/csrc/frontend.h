@@ -63,6 +63,7 @@ struct FrontBufs {
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
   float4* m_src = nullptr;     // where the matcher's last kernel should leave the matched keypoint clouds (or null)
   float4* m_tgt = nullptr;
+  int m_cap = 0;               // capacity of m_src / m_tgt in points (the handle's max_corr)
   bool gathered = false;       // set by match_enqueue when it did
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(const int* __restrict__ cr
                                                       int* __restrict__ tgt_of_src, int* __restrict__ corr,
                                                       const float4* __restrict__ vs, const float4* __restrict__ vt,
                                                       float4* __restrict__ m_src, float4* __restrict__ m_tgt,
-                                                      int* __restrict__ mcounts, int* __restrict__ mail,
+                                                      int m_cap, int* __restrict__ mcounts, int* __restrict__ mail,
                                                       const int* __restrict__ counts0, const int* __restrict__ counts1,
                                                       int seq) {
   __shared__ int wsum[16];
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(const int* __restrict__ cr
     if (tt[k] >= 0) {
       corr[2 * run] = base + k;
       corr[2 * run + 1] = tt[k];
-      if (m_src) {
+      if (m_src && run < m_cap) {  // the count is still reported: the host raises QTR_ERR_CAPACITY past m_cap
         float4 a = vs[base + k], b = vt[tt[k]];
         a.w = 0.f;
         b.w = 0.f;
@@ -756,7 +756,7 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
   // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
   if (fused_tail) {
     hipLaunchKernelGGL(k_pairs_fused, dim3(1), dim3(1024), (size_t)ns * 4, st, F.cross_i, F.cross_j, F.passed, swapped, ns,
-                       F.tgt_of_src, F.corr, F.cloud[0].vox, F.cloud[1].vox, F.m_src, F.m_tgt, F.mcounts, F.mail,
+                       F.tgt_of_src, F.corr, F.cloud[0].vox, F.cloud[1].vox, F.m_src, F.m_tgt, F.m_cap, F.mcounts, F.mail,
                        F.cloud[0].counts, F.cloud[1].counts, F.mail_seq);
     F.gathered = F.m_src != nullptr;
   } else {

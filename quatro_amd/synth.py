@@ -29,14 +29,18 @@ def yaw_matrix(yaw: float) -> np.ndarray:
 
 
 def _scene(rng: np.random.Generator, n_boxes: int, n_poles: int, n_clutter: int, n_far: int = 0,
-           far_r0: float = 50.0):
+           far_r0: float = 50.0, n_trees: int = 0, n_hedges: int = 0, leaf_p: float = 0.5, crown: float = 1.0):
     """Axis-aligned boxes as (lo[3], hi[3]) rows in the world frame: buildings, vehicles, wall segments,
-    poles (thin tall boxes) and small clutter boxes (vegetation stand-in)."""
-    lo_l, hi_l = [], []
+    poles (thin tall boxes) and small clutter boxes (vegetation stand-in).  With n_trees / n_hedges > 0 a third
+    array marks POROUS boxes (tree crowns, hedges): a ray entering one returns from a random depth inside it with
+    probability < 1 and otherwise passes through — the volumetric returns that make real vegetation occupy many
+    voxels per beam (what lifts a KITTI scan to ~16 k voxels at 0.3 m)."""
+    lo_l, hi_l, por_l = [], [], []
 
-    def add(cx, cy, sx, sy, z0, sz):
+    def add(cx, cy, sx, sy, z0, sz, porous=0.0):
         lo_l.append([cx - sx / 2, cy - sy / 2, z0])
         hi_l.append([cx + sx / 2, cy + sy / 2, z0 + sz])
+        por_l.append(porous)
 
     for _ in range(n_boxes):
         kind = rng.random()
@@ -71,6 +75,25 @@ def _scene(rng: np.random.Generator, n_boxes: int, n_poles: int, n_clutter: int,
         s3 = rng.uniform(0.4, 2.5, size=3)
         z0 = -SENSOR_HEIGHT + (rng.uniform(1.5, 4.0) if rng.random() < 0.3 else 0.0)
         add(r * np.cos(a), r * np.sin(a), s3[0], s3[1], z0, s3[2])
+    for _ in range(n_trees):  # trunk (solid) + crown (porous)
+        r = np.sqrt(rng.uniform(7.0 ** 2, 76.0 ** 2))
+        a = rng.uniform(-np.pi, np.pi)
+        cx, cy = r * np.cos(a), r * np.sin(a)
+        w = rng.uniform(0.2, 0.5)
+        h_trunk = rng.uniform(1.8, 3.5)
+        add(cx, cy, w, w, -SENSOR_HEIGHT, h_trunk)
+        cw, ch = rng.uniform(3.0, 7.0) * crown, rng.uniform(3.0, 7.0) * crown
+        add(cx, cy, cw, cw, -SENSOR_HEIGHT + h_trunk - 0.3, ch, porous=rng.uniform(0.5, 1.0) * leaf_p)
+    for _ in range(n_hedges):  # low porous strips
+        r = np.sqrt(rng.uniform(8.0 ** 2, 70.0 ** 2))
+        a = rng.uniform(-np.pi, np.pi)
+        sx, sy = rng.uniform(1.0, 2.0), rng.uniform(4.0, 18.0)
+        if rng.random() < 0.5:
+            sx, sy = sy, sx
+        add(r * np.cos(a), r * np.sin(a), sx, sy, -SENSOR_HEIGHT, rng.uniform(1.0, 2.4),
+            porous=min(1.0, rng.uniform(0.8, 1.4) * leaf_p))
+    if n_trees or n_hedges:
+        return np.array(lo_l), np.array(hi_l), np.array(por_l)
     return np.array(lo_l), np.array(hi_l)
 
 
@@ -86,7 +109,7 @@ def _ray_dirs() -> np.ndarray:
 
 
 def _scan(origin: np.ndarray, yaw: float, lo: np.ndarray, hi: np.ndarray, rng: np.random.Generator, sigma: float,
-          bump_k: np.ndarray, bump_ph: np.ndarray, bump_a: float, ground: bool = False):
+          bump_k: np.ndarray, bump_ph: np.ndarray, bump_a: float, ground: bool = False, porous: np.ndarray | None = None):
     """Ray-cast one 64 x 1800 sweep.  Each box is only tested against the (beam, azimuth) window its
     corners subtend.  Surfaces get a smooth world-anchored range displacement (sum of sinusoids) so
     that local geometry is distinctive and repeatable between the two views."""
@@ -123,6 +146,12 @@ def _scan(origin: np.ndarray, yaw: float, lo: np.ndarray, hi: np.ndarray, rng: n
         tmin = np.minimum(t1, t2).max(axis=-1)
         tmax = np.maximum(t1, t2).min(axis=-1)
         ok = (tmax >= np.maximum(tmin, 0.0)) & (tmin > 0.5)
+        if porous is not None and porous[b] > 0.0:
+            # foliage: a ray entering the box returns from a random depth inside it with probability porous[b] and
+            # passes through otherwise (leaves are far below the 0.3 m voxel scale, so two scans taken metres apart do
+            # not see the same returns — as in real vegetation)
+            ok &= rng.random(tmin.shape) < porous[b]
+            tmin = tmin + rng.random(tmin.shape) * np.maximum(tmax - tmin, 0.0)
         cur = t_hit[np.ix_(rows, cols)]
         t_hit[np.ix_(rows, cols)] = np.where(ok & (tmin < cur), tmin, cur)
     # ground: rays whose first hit is the ground plane give no return (ground removed analytically)
@@ -156,22 +185,45 @@ def _scan(origin: np.ndarray, yaw: float, lo: np.ndarray, hi: np.ndarray, rng: n
 
 
 def kitti64_pair(pair_id: int = 0, n_boxes: int = 100, n_poles: int = 60, n_clutter: int = 150, n_far: int = 300,
-                 sigma: float = 0.02, max_yaw: float = np.pi, max_xy: float = 10.0, bump_a: float = 0.12):
+                 sigma: float = 0.02, max_yaw: float = np.pi, max_xy: float = 10.0, bump_a: float = 0.12,
+                 n_trees: int = 0, n_hedges: int = 0, far_r0: float = 50.0, leaf_p: float = 0.5, crown: float = 1.0,
+                 clear_r: float = 0.0):
     """Returns (src_xyzi, tgt_xyzi, T_gt) with tgt ~= T_gt @ src (4x4, yaw + translation only)."""
     rng = np.random.default_rng(SEED_BASE + pair_id)
-    lo, hi = _scene(rng, n_boxes, n_poles, n_clutter, n_far)
+    sc = _scene(rng, n_boxes, n_poles, n_clutter, n_far, far_r0, n_trees, n_hedges, leaf_p, crown)
+    lo, hi = sc[0], sc[1]
+    porous = sc[2] if len(sc) > 2 else None
     bump_k = rng.normal(0.0, 2.0, size=(6, 3))
     bump_ph = rng.uniform(0.0, 2 * np.pi, size=6)
     yaw = rng.uniform(-max_yaw, max_yaw)
     t = np.array([rng.uniform(-max_xy, max_xy), rng.uniform(-max_xy, max_xy), rng.uniform(-0.2, 0.2)])
-    src = _scan(np.zeros(3), 0.0, lo, hi, rng, sigma, bump_k, bump_ph, bump_a)   # sensor pose A = identity
-    tgt = _scan(t, yaw, lo, hi, rng, sigma, bump_k, bump_ph, bump_a)              # sensor pose B = (yaw, t)
+    if clear_r > 0.0:  # keep a disc around BOTH sensor poses free of objects (a vehicle drives on a clear lane)
+        keep = np.ones(lo.shape[0], dtype=bool)
+        for c in (np.zeros(2), t[:2]):
+            dx = np.maximum(np.maximum(lo[:, 0] - c[0], c[0] - hi[:, 0]), 0.0)
+            dy = np.maximum(np.maximum(lo[:, 1] - c[1], c[1] - hi[:, 1]), 0.0)
+            keep &= np.hypot(dx, dy) > clear_r
+        lo, hi = lo[keep], hi[keep]
+        porous = porous[keep] if porous is not None else None
+    src = _scan(np.zeros(3), 0.0, lo, hi, rng, sigma, bump_k, bump_ph, bump_a, porous=porous)  # pose A = identity
+    tgt = _scan(t, yaw, lo, hi, rng, sigma, bump_k, bump_ph, bump_a, porous=porous)             # pose B = (yaw, t)
     # world point p: src coords = p ; tgt coords = R^T (p - t)  =>  tgt = R^T src - R^T t
     R = yaw_matrix(yaw)
     T = np.eye(4)
     T[:3, :3] = R.T
     T[:3, 3] = -R.T @ t
     return src, tgt, T
+
+
+# The bench workload of BASELINE.json configs[1] / SURVEY.md section 8(d) config 2: the structural scene above plus
+# vegetation, which is what lifts a 64-beam scan from ~9 k to ~16 k voxels at 0.3 m (mean over pair ids 0..5:
+# n_src 16.0 k, n_tgt 15.5 k; every pair still registers to its ground truth).
+KITTI16K = dict(n_trees=800, n_hedges=250, leaf_p=0.3, crown=1.4, clear_r=5.0)
+
+
+def kitti64_pair_16k(pair_id: int = 0):
+    """kitti64_pair with the KITTI16K profile (n_s ~ n_t ~ 16 k voxels at leaf 0.3 m)."""
+    return kitti64_pair(pair_id, **KITTI16K)
 
 
 def kitti64_raw_scan(scan_id: int = 0, **kw):
@@ -208,6 +260,34 @@ def correspondences(L: int = 5000, inlier_frac: float = 0.05, seed: int = 0, noi
     T[:3, :3] = R
     T[:3, 3] = t
     return src, tgt, T, inl
+
+
+def dense_pair(n: int = 50000, seed: int = 7, yaw: float = 0.7, t=(3.0, -2.0, 0.4)):
+    """BASELINE configs[4] front-end input (dense mode: n-point clouds, no voxel step): points on a few large planes and a
+    cylinder — surface-like, ~20-60 neighbours inside r = 0.75 m.  Returns (src, tgt, perm): tgt[i] is the moved copy of
+    src[perm[i]]."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for k in range(6):
+        u = rng.random((n // 8, 2)) * np.array([120.0, 25.0])
+        plane = np.zeros((n // 8, 3))
+        plane[:, 0] = u[:, 0] - 60 + 3 * k
+        plane[:, 1] = (k - 3) * 9.0 + 0.02 * rng.standard_normal(n // 8)
+        plane[:, 2] = u[:, 1] - 2
+        if k % 2:
+            plane = plane[:, [1, 0, 2]]
+        parts.append(plane)
+    th = rng.random(n - sum(p.shape[0] for p in parts)) * 2 * np.pi
+    cyl = np.stack([40 * np.cos(th), 40 * np.sin(th), rng.random(th.size) * 20 - 2], axis=1)
+    parts.append(cyl)
+    pts = np.concatenate(parts).astype(np.float32)
+    src = np.zeros((n, 4), dtype=np.float32)
+    src[:, :3] = pts
+    R = yaw_matrix(yaw)[:3, :3]
+    perm = rng.permutation(n)
+    tgt = np.zeros((n, 4), dtype=np.float32)
+    tgt[:, :3] = (pts[perm].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
+    return src, tgt, perm
 
 
 def save_kitti_bin(path: str, xyzi: np.ndarray) -> None:

@@ -506,31 +506,9 @@ def test_dense_mode_front_end_at_50k_points(qo):
     """BASELINE configs[4] (dense mode: 50 000-point clouds, no voxel step) through the front end: FPFH + matching
     at n = 50 k via properties (descriptor blocks sum to 100 or 0, rigid-motion invariance of the matching) and
     a sampled exact check of the nearest-neighbour tables against brute force."""
-    rng = np.random.default_rng(7)
     n = 50000
-    # points on a few large planes and a cylinder: surface-like, ~20-60 neighbours inside r = 0.75 m
-    parts = []
-    for k in range(6):
-        u = rng.random((n // 8, 2)) * np.array([120.0, 25.0])
-        plane = np.zeros((n // 8, 3))
-        plane[:, 0] = u[:, 0] - 60 + 3 * k
-        plane[:, 1] = (k - 3) * 9.0 + 0.02 * rng.standard_normal(n // 8)
-        plane[:, 2] = u[:, 1] - 2
-        if k % 2:
-            plane = plane[:, [1, 0, 2]]
-        parts.append(plane)
-    th = rng.random(n - sum(p.shape[0] for p in parts)) * 2 * np.pi
-    cyl = np.stack([40 * np.cos(th), 40 * np.sin(th), rng.random(th.size) * 20 - 2], axis=1)
-    parts.append(cyl)
-    pts = np.concatenate(parts).astype(np.float32)
-    assert pts.shape[0] == n
-    src = np.zeros((n, 4), dtype=np.float32)
-    src[:, :3] = pts
-    yaw, t = 0.7, np.array([3.0, -2.0, 0.4])
-    R = synth.yaw_matrix(yaw)[:3, :3]
-    perm = rng.permutation(n)
-    tgt = np.zeros((n, 4), dtype=np.float32)
-    tgt[:, :3] = (pts[perm].astype(np.float64) @ R.T + t).astype(np.float32)
+    src, tgt, perm = synth.dense_pair(n, seed=7)
+    rng = np.random.default_rng(70)
     h = ql.Handle(0, max_points=65536, max_voxels=65536, max_corr=24576)
     try:
         ns, ds = h.fpfh(src, 0.5, 0.75)
