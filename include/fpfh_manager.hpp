@@ -58,7 +58,7 @@ class FPFHManager {
     if (normal_radius_ > fpfh_radius_)
       throw std::invalid_argument("[FPFHManager]: Normal should be lower than fpfh_radius!!!!");  // :99-102
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     if (is_initial_ && !is_odometry_test_) {
       src_cloud_ = src->points;
       compute(h, src_cloud_, obj_desc_);

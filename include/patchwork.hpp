@@ -84,7 +84,7 @@ class PatchWork {
     n_.resize(4 * cap);
     int ng = 0, nn = 0;
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     const float* in = pack(cloudIn);
     quatro_hip::check(h, qtr_patchwork(h, 0, in, P, &pw_, g_.data(), static_cast<int>(cap), &ng, n_.data(),
                                        static_cast<int>(cap), &nn, QTR_MEM_HOST));

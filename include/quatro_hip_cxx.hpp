@@ -27,8 +27,8 @@ inline qtr_handle* default_handle() {
 // Every drop-in object forwards to slot 0 of that handle, and the C ABI wants same-slot calls serialised: reference
 // objects are independent of each other, so two of them may legally be driven from two threads — the wrappers take
 // this mutex around every slot-0 call (and around reading the error text that belongs to it).
-inline std::mutex& default_slot_mutex() {
-  static std::mutex m;
+inline std::recursive_mutex& default_slot_mutex() {
+  static std::recursive_mutex m;
   return m;
 }
 inline void check(qtr_handle* h, int rc) {

@@ -126,7 +126,7 @@ class MaxCliqueSolver {
     if (params_.solver_mode == CLIQUE_SOLVER_MODE::PMC_HEU) mode = QTR_INLIER_PMC_HEU;
     if (params_.solver_mode == CLIQUE_SOLVER_MODE::KCORE_HEU) mode = QTR_INLIER_KCORE_HEU;
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     qtr_set_clique_time_limit(h, params_.time_limit);
     const std::vector<unsigned long long> bm = graph.bitMatrix();
     int n = 0, max_core = 0;

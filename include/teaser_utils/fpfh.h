@@ -53,7 +53,7 @@ class FPFHEstimation {
       xyz4[4 * static_cast<size_t>(i) + 2] = input_cloud[static_cast<size_t>(i)].z;
     }
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     quatro_hip::check(h, qtr_fpfh(h, 0, xyz4.data(), n, static_cast<float>(normal_search_radius),
                                   static_cast<float>(fpfh_search_radius), nrm.data(), desc.data(), QTR_MEM_HOST));
     for (int i = 0; i < n; ++i) {

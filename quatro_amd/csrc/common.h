@@ -101,3 +101,23 @@ struct QtrDeviceBuf {
   } while (0)
 
 static inline int qtr_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- per-item views of a batched launch -----------------------------------------------------------
+// Every kernel of the registration path takes the views (pointers + sizes) of the items it works on — clouds,
+// pairs — and picks its own with a block index.  One or two items travel inside the kernel arguments; a larger batch
+// (qtr_submit_batch) puts the array in device memory: the host fills a pinned staging area and one async copy on the
+// launch stream carries it over.  A stage is rewound when the chunk that used it has completed.
+struct ViewStage {
+  char* h = nullptr;  // pinned host
+  char* d = nullptr;  // device
+  size_t cap = 0, off = 0;
+};
+static inline const void* stage_push(ViewStage* s, const void* src, size_t bytes, hipStream_t st) {
+  const size_t padded = (bytes + 255) & ~(size_t)255;
+  if (!s || !s->h || s->off + padded > s->cap) return nullptr;
+  memcpy(s->h + s->off, src, bytes);
+  if (hipMemcpyAsync(s->d + s->off, s->h + s->off, padded, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+  const void* r = s->d + s->off;
+  s->off += padded;
+  return r;
+}

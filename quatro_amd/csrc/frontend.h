@@ -9,7 +9,11 @@
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
 // matcher device counters (FrontBufs::mcounts, 16 ints)
 // MC_RECHECKx: rows sent to the exact re-check; MC_RECHECKx + 2: rows settled by the two-candidate exact compare
-enum { MC_NCORR = 0, MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5 };
+// MC_NQ0 / MC_NHIT: query counts of the two nearest-neighbour directions (device-side: the second direction only asks
+// for the rows of the larger cloud that some row of the smaller cloud points at); MC_HIDDEN_I / _J: descriptor rows
+// hidden from the base tables because a lower row holds the bit-identical descriptor
+enum { MC_NCORR = 0, MC_HIDDEN_I = 1, MC_HIDDEN_J = 2, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5, MC_NQ0 = 6, MC_NHIT = 7,
+       MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11 };
 
 // Host mailbox (ints): the kernel that finishes a phase stores the few counters the host needs straight into
 // pinned host memory, so a phase boundary costs one stream synchronisation and no copy launches.
@@ -40,6 +44,93 @@ struct CloudBufs {
   float* queryT = nullptr;     // [34][n_pad] -2*descriptor + ones row            (MFMA stationary operand)
   float* norms = nullptr;      // [max_voxels] |desc|^2
   u32* max_norm = nullptr;     // 1: bits of the largest |desc|^2
+  u64* dd_hash = nullptr;      // [max_voxels] 64-bit hash of the descriptor bits
+  u64* dd_table = nullptr;     // [dd_slots] open-addressing table: (hash tag << 32) | lowest row holding that hash
+};
+
+// What a front-end kernel needs to know about one cloud; kernels pick theirs with blockIdx.y (see Clouds2).
+struct CloudView {
+  const float4* raw;   // raw scan (voxelise)
+  int P;               // raw points
+  int n;               // voxel count (known on the host after the voxelise read-back)
+  int* counts;
+  u32* mm;
+  float4* vox;
+  float4* normals;
+  float* spfh;
+  float* fpfh;
+  u64* keys_a;         // sort ping / pong; a kernel argument says which one holds the input of the pass
+  u64* keys_b;
+  u32* hist;
+  int* mail;           // host mailbox slot of this cloud's voxelise counters (or null)
+  int* mail_seq_slot;  // ... and the word that receives the sequence number after them
+  int seq;             // ... and that number
+  int* blkcnt;
+  int* blkoff;
+  int* nbr_cnt;
+  int* nbr_off;
+  int* nbr_idx;
+  float* nbr_d2;
+  float4* spts;
+  int* ranges;
+  float* mean;
+};
+struct Clouds2 {
+  CloudView c[2];        // up to two clouds travel in the kernel arguments ...
+  const CloudView* ext;  // ... a batch of pairs puts the array in device memory (null otherwise)
+};
+
+// One direction of the 33-D nearest-neighbour search of one pair.
+struct NnDir {
+  const float* baseT;   // [34][nb_pad] k-major base table (row 33: scaled |b|^2; hidden / pad rows 1e30)
+  const float* bnorm;   // [nb] |b|^2 as rounded once from binary64
+  int nb, nb_pad;
+  const float* queryT;  // [34][nq_pad] the table k_nn_mfma reads (direction 1: the compacted hit rows)
+  const float* qnorm;   // [.] |a|^2 per column of that table
+  const int* qmap;      // column -> row of the query cloud (null: identity)
+  int nq_pad;
+  const float* A;       // [n][33] descriptors of the query cloud (exact re-check)
+  const float* QT;      // its full k-major table (-2a rows), stride qt_pad
+  int qt_pad;
+  u64* best;            // per row of the query cloud: packed (distance bits << 32 | index), or the bare index
+  int nq_slot, rc_slot; // mcounts indices: number of queries, re-check counter
+};
+struct NnPartial {
+  float b1, b2;
+  int i1;
+  int pad;
+};
+// Everything the matcher kernels need for one pair; picked with blockIdx.z (see MatchArgs).
+struct MatchView {
+  NnDir d[2];                  // 0: rows of the smaller cloud ask the larger one; 1: hit rows of the larger ask the smaller
+  const float4 *vox_i, *vox_j; // i = larger cloud (fi), j = smaller (fj), reference feature_matcher.cc:84-92
+  const float *mean_i, *mean_j;
+  const float *fpfh_i, *fpfh_j;
+  float *baseT_i, *queryT_i, *norms_i, *baseT_j, *queryT_j, *norms_j;
+  u64 *hash_i, *hash_j, *table_i, *table_j;
+  int dd_mask;                 // table slots - 1
+  int n_large, n_small, pad_large, pad_small, swapped, ns, nt;
+  u64 *best_small, *best_large;
+  int *nn_of_small, *nn_of_large, *cross_i, *cross_j, *flags, *scan, *passed, *tgt_of_src, *corr, *mcounts;
+  NnPartial* partial;
+  int* recheck_rows;
+  float* recheck_thr;
+  int* hit_rows;               // ascending rows of the larger cloud that direction 0 points at
+  float* queryT_c;             // [34][pad_large] their columns of queryT_i
+  float* norms_c;
+  const float4 *vox_s, *vox_t; // source / target voxel clouds (un-swapped)
+  float4 *m_src, *m_tgt;       // matched keypoint clouds (or null)
+  int m_cap;
+  int* mail;                   // host mailbox of the pair's slot (or null)
+  const int *counts0, *counts1;
+  int seq;
+  int tuple;                   // 1: run the tuple test
+  float tuple_scale;
+  u64 seed;
+};
+struct MatchArgs {
+  MatchView one;
+  const MatchView* ext;
 };
 
 struct FrontBufs {
@@ -60,6 +151,10 @@ struct FrontBufs {
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
   float* recheck_thr = nullptr; // [max_voxels] per listed row: approximate best + 2 eps (candidates above it cannot win)
+  int* hit_rows = nullptr;     // [max_voxels]
+  float* queryT_c = nullptr;   // [34][max_voxels_pad]
+  float* norms_c = nullptr;    // [max_voxels_pad]
+  int dd_slots = 0;            // slots of each cloud's dedup table (power of two >= 2 * max_voxels)
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
   float4* m_src = nullptr;     // where the matcher's last kernel should leave the matched keypoint clouds (or null)
   float4* m_tgt = nullptr;
@@ -85,6 +180,16 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
+
+// The same stages for G pairs at once (qtr_submit_batch): one launch chain, the views of all pairs in device memory
+// (pushed through `stage`).  F[g] is pair g's arena; raw / P / n hold two entries per pair (source, target).
+hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* const* raw, const int* P, float leaf,
+                                  ViewStage* stage, hipStream_t st);
+hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st);
+hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
+                              hipStream_t st);
+hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
+                               const unsigned long long* seeds, ViewStage* stage, hipStream_t st);
 
 // shared small kernels (defined in frontend.hip)
 hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st);  // out has n+1 entries

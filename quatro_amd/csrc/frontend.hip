@@ -10,6 +10,8 @@
 // sorted by packed cell key and a query scans 9 contiguous key ranges.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 #include "frontend.h"
 
@@ -930,115 +932,89 @@ __device__ __forceinline__ void d_seq_mean(const float4* __restrict__ pts, int n
 // chain of ~35 small dependent kernels each; one launch serves both (blockIdx.y = cloud), which halves the
 // dispatch count on the critical path and doubles the work per dispatch.  A CloudView carries one cloud's
 // pointers and sizes; kernels pick theirs with blockIdx.y.
-struct CloudView {
-  const float4* raw;   // raw scan (voxelise)
-  int P;               // raw points
-  int n;               // voxel count (known on the host after the voxelise read-back)
-  int nblk;            // radix tiles of the array being sorted
-  int nblk_vox;        // 1024-element tiles of the sorted raw scan
-  int* counts;
-  u32* mm;
-  float4* vox;
-  float4* normals;
-  float* spfh;
-  float* fpfh;
-  const u64* keys_in;  // ping-pong roles of the current radix pass
-  u64* keys_out;
-  u32* hist;
-  int* mail;           // host mailbox slot of this cloud's voxelise counters (or null)
-  int* mail_seq_slot;  // ... and the word that receives the sequence number after them
-  int* blkcnt;
-  int* blkoff;
-  int* nbr_cnt;
-  int* nbr_off;
-  int* nbr_idx;
-  float* nbr_d2;
-  float4* spts;
-  int* ranges;
-  float* mean;
-};
-struct Clouds2 {
-  CloudView c[2];
-};
+__device__ __forceinline__ const CloudView& cv(const Clouds2& a) { return a.ext ? a.ext[blockIdx.y] : a.c[blockIdx.y]; }
+__device__ __forceinline__ const u64* keys_src(const CloudView& C, int src) { return src == 0 ? C.keys_a : C.keys_b; }
+__device__ __forceinline__ u64* keys_dst(const CloudView& C, int src) { return src == 0 ? C.keys_b : C.keys_a; }
 
 __global__ void k2_cloud_init(Clouds2 a, int keep_counts) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   const int t = threadIdx.x;
   if (!keep_counts && t < 16) C.counts[t] = 0;
   if (t < 3) C.mm[t] = 0xffffffffu;
   if (t >= 3 && t < 6) C.mm[t] = 0u;
 }
 __global__ __launch_bounds__(256) void k2_minmax(Clouds2 a, int use_vox) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm);
 }
 __global__ __launch_bounds__(256) void k2_vox_keys(Clouds2 a, float leaf) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_vox_keys(C.raw, C.P, leaf, C.mm, C.keys_out, C.counts);
+  const CloudView& C = cv(a);
+  d_vox_keys(C.raw, C.P, leaf, C.mm, C.keys_a, C.counts);
 }
 __global__ __launch_bounds__(256) void k2_cell_keys(Clouds2 a, float cell) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_cell_keys(C.vox, C.n, C.mm, cell, C.keys_out);
+  const CloudView& C = cv(a);
+  d_cell_keys(C.vox, C.n, C.mm, cell, C.keys_a);
 }
-__global__ __launch_bounds__(64) void k2_radix_hist(Clouds2 a, int use_vox, int shift) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_radix_hist<8, RADIX_TILE>(C.keys_in, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
+// src: which of keys_a (0) / keys_b (1) holds the input of this pass
+__global__ __launch_bounds__(64) void k2_radix_hist(Clouds2 a, int use_vox, int shift, int src) {
+  const CloudView& C = cv(a);
+  const int n = use_vox ? C.n : C.P;
+  d_radix_hist<8, RADIX_TILE>(keys_src(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
 }
-__global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_radix_scatter<8, RADIX_TILE>(C.keys_in, C.keys_out, use_vox ? C.n : C.P, shift, C.hist, C.nblk);
+__global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift, int src) {
+  const CloudView& C = cv(a);
+  const int n = use_vox ? C.n : C.P;
+  d_radix_scatter<8, RADIX_TILE>(keys_src(C, src), keys_dst(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
 }
-__global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_vox_headcount(C.keys_in, C.P, C.blkcnt);
+__global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a, int src) {
+  const CloudView& C = cv(a);
+  d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
 }
 __global__ __launch_bounds__(1024) void k2_vox_blockscan(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_scan_i32_copy(C.blkcnt, C.blkoff, C.nblk_vox);
+  const CloudView& C = cv(a);
+  d_scan_i32_copy(C.blkcnt, C.blkoff, (C.P + 1023) / 1024);
 }
-__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap, int seq) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_vox_centroids(C.keys_in, C.raw, C.P, C.blkoff, C.vox, cap, C.nblk_vox, C.counts, C.mail, C.mail_seq_slot, seq);
+__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap, int src) {
+  const CloudView& C = cv(a);
+  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkoff, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
+                  C.mail_seq_slot, C.seq);
 }
-__global__ __launch_bounds__(256) void k2_sorted_points(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
-  d_sorted_points(C.vox, C.keys_in, C.n, C.spts);
-}
-__global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell) {
-  const CloudView& C = a.c[blockIdx.y];
+__global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell, int src) {
+  const CloudView& C = cv(a);
+  const u64* sorted = keys_src(C, src);
   {  // the first n threads of the launch also gather the points into cell-sorted order (was k2_sorted_points)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < C.n) {
-      const u32 j = (u32)C.keys_in[t];
+      const u32 j = (u32)sorted[t];
       float4 p = C.vox[j];
       p.w = __uint_as_float(j);
       C.spts[t] = p;
     }
   }
-  d_ranges(C.vox, C.n, C.keys_in, C.mm, cell, C.ranges);
+  d_ranges(C.vox, C.n, sorted, C.mm, cell, C.ranges);
 }
 __global__ __launch_bounds__(64) void k2_neighbors(Clouds2 a, float r2) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_neighbors(C.vox, C.n, C.spts, C.ranges, r2, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.counts);
 }
 __global__ __launch_bounds__(1024) void k2_nbr_scan(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_scan_i32_copy(C.nbr_cnt, C.nbr_off, C.n);
 }
 __global__ __launch_bounds__(256) void k2_normals(Clouds2 a, float rn2) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_normals(C.vox, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2, C.normals);
 }
 __global__ __launch_bounds__(64) void k2_spfh(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, C.nbr_idx, C.spfh);
 }
 __global__ __launch_bounds__(64) void k2_fpfh(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_fpfh(C.spfh, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
 }
 __global__ __launch_bounds__(256) void k2_seq_mean(Clouds2 a) {
-  const CloudView& C = a.c[blockIdx.y];
+  const CloudView& C = cv(a);
   d_seq_mean(C.vox, C.n, C.mean);
 }
 __global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
@@ -1050,7 +1026,7 @@ hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st) {
   return hipGetLastError();
 }
 
-static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
+static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n, int* mail, int* mail_seq_slot, int seq) {
   CloudView v;
   memset(&v, 0, sizeof(v));
   v.raw = raw;
@@ -1062,7 +1038,14 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
   v.normals = C.normals;
   v.spfh = C.spfh;
   v.fpfh = C.fpfh;
+  v.keys_a = C.keys_a;
+  v.keys_b = C.keys_b;
   v.hist = C.hist;
+  v.mail = mail;
+  v.mail_seq_slot = mail_seq_slot;
+  v.seq = seq;
+  v.blkcnt = (int*)C.hist;
+  v.blkoff = v.blkcnt + (P + 1023) / 1024 + 8;
   v.nbr_cnt = C.nbr_cnt;
   v.nbr_off = C.nbr_off;
   v.nbr_idx = C.nbr_idx;
@@ -1073,57 +1056,87 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n) {
   return v;
 }
 
-// stable LSD radix sort of keys_a (both clouds) by bits [32, 32+key_bits); returns which buffer holds the result
-static int radix_sort2(Clouds2& a, CloudBufs* const* C, int nc, int use_vox, int key_bits, hipStream_t st) {
-  int maxblk = 1;
+// The clouds one launch chain works on: up to two ride in the kernel arguments, more go through the stage.
+struct CloudSet {
+  Clouds2 a;
+  int nc = 0;
+  int maxP = 1, maxn = 1;
+};
+static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, ViewStage* stage, hipStream_t st) {
+  S.nc = nc;
+  S.a.ext = nullptr;
+  S.maxP = S.maxn = 1;
   for (int c = 0; c < nc; ++c) {
-    const int n = use_vox ? a.c[c].n : a.c[c].P;
-    a.c[c].nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
-    if (a.c[c].nblk > maxblk) maxblk = a.c[c].nblk;
+    if (views[c].P > S.maxP) S.maxP = views[c].P;
+    if (views[c].n > S.maxn) S.maxn = views[c].n;
   }
+  if (nc <= 2) {
+    S.a.c[0] = views[0];
+    S.a.c[1] = views[nc > 1 ? 1 : 0];
+    return hipSuccess;
+  }
+  S.a.c[0] = S.a.c[1] = views[0];
+  S.a.ext = (const CloudView*)stage_push(stage, views, sizeof(CloudView) * (size_t)nc, st);
+  return S.a.ext ? hipSuccess : hipErrorOutOfMemory;
+}
+
+// stable LSD radix sort of keys_a by bits [32, 32+key_bits); returns which buffer holds the result (0: keys_a)
+static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st) {
+  const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
   int src = 0;  // 0: keys_a holds the input
   for (int shift = 32; shift < 32 + key_bits; shift += 8) {
-    for (int c = 0; c < nc; ++c) {
-      a.c[c].keys_in = src == 0 ? C[c]->keys_a : C[c]->keys_b;
-      a.c[c].keys_out = src == 0 ? C[c]->keys_b : C[c]->keys_a;
-    }
     // two launches per pass: a single-launch pass (tiles exchanging histograms through flags) needs
     // device-scope fences, which on this multi-XCD part cost more than the launch boundary
-    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
-    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, nc), dim3(64), 0, st, a, use_vox, shift);
+    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, S.nc), dim3(64), 0, st, S.a, use_vox, shift, src);
+    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, S.nc), dim3(64), 0, st, S.a, use_vox, shift, src);
     src ^= 1;
   }
   return src;
 }
 
+static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st) {
+  const int nc = S.nc;
+  const int g = min(1024, (S.maxP + 255) / 256);
+  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, S.a, 0);
+  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, S.a, 0);
+  hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, S.a, leaf);
+  const int where = radix_sort2(S, 0, 32, st);
+  const int nblk = (S.maxP + 1023) / 1024;
+  hipLaunchKernelGGL(k2_vox_headcount, dim3(nblk, nc), dim3(256), 0, st, S.a, where);
+  hipLaunchKernelGGL(k2_vox_blockscan, dim3(1, nc), dim3(1024), 0, st, S.a);
+  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, S.a, max_voxels, where);
+}
+
 // voxel-grid down-sampling of nc (1 or 2) raw clouds
 hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st) {
   (void)hipGetLastError();
-  Clouds2 a;
-  CloudBufs* C[2] = {&F.cloud[0], &F.cloud[nc > 1 ? 1 : 0]};
-  int maxP = 1;
+  CloudView v[2];
   for (int c = 0; c < nc; ++c) {
-    a.c[c] = make_view(*C[c], raw[c], P[c], 0);
-    a.c[c].keys_out = C[c]->keys_a;
-    a.c[c].mail = F.mail ? F.mail + (C[c] == &F.cloud[1] ? MAIL_VOX1 : MAIL_VOX0) : nullptr;
-    a.c[c].mail_seq_slot = F.mail ? F.mail + (C[c] == &F.cloud[1] ? MAIL_SEQ_VOX1 : MAIL_SEQ_VOX0) : nullptr;
-    a.c[c].nblk_vox = (P[c] + 1023) / 1024;
-    a.c[c].blkcnt = (int*)C[c]->hist;
-    a.c[c].blkoff = a.c[c].blkcnt + a.c[c].nblk_vox + 8;
-    if (P[c] > maxP) maxP = P[c];
+    const int ci = (nc > 1 && c == 1) ? 1 : 0;
+    v[c] = make_view(F.cloud[ci], raw[c], P[c], 0, F.mail ? F.mail + (ci ? MAIL_VOX1 : MAIL_VOX0) : nullptr,
+                     F.mail ? F.mail + (ci ? MAIL_SEQ_VOX1 : MAIL_SEQ_VOX0) : nullptr, F.mail_seq);
   }
-  if (nc == 1) a.c[1] = a.c[0];
-  const int g = min(1024, (maxP + 255) / 256);
-  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 0);
-  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 0);
-  hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, a, leaf);
-  const int where = radix_sort2(a, C, nc, 0, 32, st);
-  for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
-  if (nc == 1) a.c[1] = a.c[0];
-  const int nblk = (maxP + 1023) / 1024;
-  hipLaunchKernelGGL(k2_vox_headcount, dim3(nblk, nc), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k2_vox_blockscan, dim3(1, nc), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, a, F.max_voxels, F.mail_seq);
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
+  if (e != hipSuccess) return e;
+  voxelize_launch(S, leaf, F.max_voxels, st);
+  return hipGetLastError();
+}
+
+hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* const* raw, const int* P, float leaf,
+                                  ViewStage* stage, hipStream_t st) {
+  (void)hipGetLastError();
+  std::vector<CloudView> v((size_t)2 * G);
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < 2; ++c) {
+      FrontBufs& Fg = *F[g];
+      v[2 * g + c] = make_view(Fg.cloud[c], raw[2 * g + c], P[2 * g + c], 0, Fg.mail ? Fg.mail + (c ? MAIL_VOX1 : MAIL_VOX0) : nullptr,
+                               Fg.mail ? Fg.mail + (c ? MAIL_SEQ_VOX1 : MAIL_SEQ_VOX0) : nullptr, Fg.mail_seq);
+    }
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
+  if (e != hipSuccess) return e;
+  voxelize_launch(S, leaf, F[0]->max_voxels, st);
   return hipGetLastError();
 }
 
@@ -1132,52 +1145,80 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
   return hipGetLastError();
 }
 
-// normals + SPFH + FPFH (+ the matcher's sequential mean) of nc (1 or 2) clouds held in F.cloud[first + c]
 // Matcher::normalizePoints means of nc clouds; independent of the FPFH chain, so the whole-path driver runs it
 // on the slot's second stream
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st) {
-  Clouds2 a;
-  for (int c = 0; c < nc; ++c) a.c[c] = make_view(F.cloud[first + c], nullptr, 0, n[c]);
-  if (nc == 1) a.c[1] = a.c[0];
-  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
+  CloudView v[2];
+  for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, S.a);
   return hipGetLastError();
+}
+hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st) {
+  std::vector<CloudView> v((size_t)2 * G);
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < 2; ++c) v[2 * g + c] = make_view(F[g]->cloud[c], nullptr, 0, n[2 * g + c], nullptr, nullptr, 0);
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k2_seq_mean, dim3(1, 2 * G), dim3(256), 0, st, S.a);
+  return hipGetLastError();
+}
+
+// normals + SPFH + FPFH (+ the matcher's sequential mean) of the clouds of S
+static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean) {
+  const int nc = S.nc, maxn = S.maxn;
+  const int g = min(1024, (maxn + 255) / 256);
+  const float cell = r_fpfh * 1.001f;
+  const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
+  const float rn2 = (float)((double)r_normal * (double)r_normal);
+  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, S.a, 1);  // keeps the counters of the voxel stage
+  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, S.a, 1);
+  hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, S.a, cell);
+  const int where = radix_sort2(S, 1, 24, st);
+  // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
+  hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, S.a, cell, where);
+  // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
+  // thread and the launch went from 21 + 14 us to 51 us)
+  hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, S.a, r2);
+  hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, S.a, rn2);
+  hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, S.a);
+  hipLaunchKernelGGL(k2_fpfh, dim3(maxn, nc), dim3(64), 0, st, S.a);
+  if (with_mean) hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, S.a);
 }
 
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
                         bool with_mean) {
   (void)hipGetLastError();
-  Clouds2 a;
-  CloudBufs* C[2] = {&F.cloud[first], &F.cloud[nc > 1 ? first + 1 : first]};
-  int maxn = 1;
-  for (int c = 0; c < nc; ++c) {
-    a.c[c] = make_view(*C[c], nullptr, 0, n[c]);
-    a.c[c].keys_out = C[c]->keys_a;
-    if (n[c] > maxn) maxn = n[c];
-  }
-  if (nc == 1) a.c[1] = a.c[0];
-  const int g = min(1024, (maxn + 255) / 256);
-  const float cell = r_fpfh * 1.001f;
-  const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
-  const float rn2 = (float)((double)r_normal * (double)r_normal);
-  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, a, 1);  // keeps the counters of the voxel stage
-  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, a, 1);
-  hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, a, cell);
-  const int where = radix_sort2(a, C, nc, 1, 24, st);
-  for (int c = 0; c < nc; ++c) a.c[c].keys_in = where == 0 ? C[c]->keys_a : C[c]->keys_b;
-  if (nc == 1) a.c[1] = a.c[0];
-  // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
-  hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, a, cell);
-  // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
-  // thread and the launch went from 21 + 14 us to 51 us)
-  hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, a, r2);
-  hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, a, rn2);
-  hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(k2_fpfh, dim3(maxn, nc), dim3(64), 0, st, a);
-  if (with_mean) hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, a);
+  CloudView v[2];
+  for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
+  if (e != hipSuccess) return e;
+  fpfh_launch(S, r_normal, r_fpfh, st, with_mean);
+  return hipGetLastError();
+}
+hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
+                              hipStream_t st) {
+  (void)hipGetLastError();
+  std::vector<CloudView> v((size_t)2 * G);
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < 2; ++c) v[2 * g + c] = make_view(F[g]->cloud[c], nullptr, 0, n[2 * g + c], nullptr, nullptr, 0);
+  CloudSet S;
+  hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
+  if (e != hipSuccess) return e;
+  fpfh_launch(S, r_normal, r_fpfh, st, false);
   return hipGetLastError();
 }
 
 // =================================================================================================
+static int dedup_slots(int max_voxels) {
+  int m = 1024;
+  while (m < 2 * max_voxels) m <<= 1;
+  return m;
+}
 size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   size_t per_cloud = 0;
   per_cloud += 4096;                                         // counts, mm, mean
@@ -1191,7 +1232,9 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   size_t shared = (size_t)max_voxels * 64 + 16384;
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
+  per_cloud += (size_t)max_voxels * 8 + (size_t)dedup_slots(max_voxels) * 8 + 512;  // dd_hash, dd_table
   shared += vpad * 32 * 16 + 2 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr
+  shared += (size_t)max_voxels * 4 + 34 * vpad * 4 + vpad * 4 + 1024;  // hit_rows, queryT_c, norms_c
   return 2 * per_cloud + shared + 64 * 256;
 }
 
@@ -1228,7 +1271,10 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.queryT = (float*)take(34 * vpad * 4);
     C.norms = (float*)take((size_t)max_voxels * 4);
     C.max_norm = (u32*)take(64);
+    C.dd_hash = (u64*)take((size_t)max_voxels * 8);
+    C.dd_table = (u64*)take((size_t)dedup_slots(max_voxels) * 8);
   }
+  F.dd_slots = dedup_slots(max_voxels);
   F.best_small = (u64*)take((size_t)max_voxels * 8);
   F.best_large = (u64*)take((size_t)max_voxels * 8);
   F.nn_of_small = (int*)take((size_t)max_voxels * 4);
@@ -1244,6 +1290,9 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.nn_partial = take((((size_t)max_voxels + 511) / 512 * 512) * 32 * 16);
   F.recheck_rows = (int*)take((size_t)max_voxels * 4);
   F.recheck_thr = (float*)take((size_t)max_voxels * 4);
+  F.hit_rows = (int*)take((size_t)max_voxels * 4);
+  F.queryT_c = (float*)take(34 * (((size_t)max_voxels + 511) / 512 * 512) * 4);
+  F.norms_c = (float*)take((((size_t)max_voxels + 511) / 512 * 512) * 4);
   {
     const char* e = getenv("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : 1;

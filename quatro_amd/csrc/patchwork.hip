@@ -392,15 +392,17 @@ hipError_t patchwork_enqueue(FrontBufs& F, const PwBufs& B, const float4* pts, i
   const int npatch = pw.base[pw.num_zones];
   if ((e = hipMemsetAsync(B.first, 0, 2 * 1024 * 4, st)) != hipSuccess) return e;
   CloudBufs* C[2] = {&F.cloud[0], &F.cloud[0]};
-  Clouds2 a;
-  a.c[0] = make_view(*C[0], pts, P, 0);
-  a.c[1] = a.c[0];
+  CloudSet S;
+  {
+    const CloudView v = make_view(*C[0], pts, P, 0, nullptr, nullptr, 0);
+    if ((e = cloudset_finish(S, &v, 1, nullptr, st)) != hipSuccess) return e;
+  }
   if (P > 0) {
     hipLaunchKernelGGL(k_pw_keys, dim3((P + 255) / 256), dim3(256), 0, st, pts, P, C[0]->keys_a);
-    const int w1 = radix_sort2(a, C, 1, 0, 32, st);
+    const int w1 = radix_sort2(S, 0, 32, st);
     u64* zs = w1 == 0 ? C[0]->keys_a : C[0]->keys_b;
     hipLaunchKernelGGL(k_pw_bin, dim3((P + 255) / 256), dim3(256), 0, st, pts, P, pw, zs, C[0]->keys_a);
-    const int w2 = radix_sort2(a, C, 1, 0, 16, st);
+    const int w2 = radix_sort2(S, 0, 16, st);
     const u64* sorted = w2 == 0 ? C[0]->keys_a : C[0]->keys_b;
     hipLaunchKernelGGL(k_pw_bounds, dim3((P + 255) / 256), dim3(256), 0, st, pts, P, sorted, B.first, B.last, B.spts);
     hipLaunchKernelGGL(k_pw_patch, dim3(npatch), dim3(256), 0, st, B.spts, pw, B.first, B.last, B.flag, B.info);

@@ -218,7 +218,7 @@ def kitti64_pair(pair_id: int = 0, n_boxes: int = 100, n_poles: int = 60, n_clut
 # The bench workload of BASELINE.json configs[1] / SURVEY.md section 8(d) config 2: the structural scene above plus
 # vegetation, which is what lifts a 64-beam scan from ~9 k to ~16 k voxels at 0.3 m (mean over pair ids 0..5:
 # n_src 16.0 k, n_tgt 15.5 k; every pair still registers to its ground truth).
-KITTI16K = dict(n_trees=800, n_hedges=250, leaf_p=0.3, crown=1.4, clear_r=5.0)
+KITTI16K = dict(n_trees=1000, n_hedges=300, leaf_p=0.35, crown=1.4, clear_r=5.0)
 
 
 def kitti64_pair_16k(pair_id: int = 0):
