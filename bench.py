@@ -113,6 +113,7 @@ def main() -> None:
     for p in pool:
         step(p)
         p["n_src"], p["n_tgt"], p["L"], p["M"] = res.n_src, res.n_tgt, res.n_corr, res.n_clique
+        p["n_hit"] = int(h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[7])  # rows the second NN direction is asked for
     lo, hi = qdist.shard_range(args.steps, rank, world)
     for w in range(args.warmup):
         step(pool[w % len(pool)])
@@ -129,7 +130,9 @@ def main() -> None:
         st = h.stage_times()
         nn_ms += st["nn_kernel"]
         nn_launches += st["nn_launches"]
-        nn_flop += st["nn_launches"] * 66.0 * p["n_src"] * p["n_tgt"]  # both directions: n_query * n_base is the same
+        # launch 1: every row of the smaller cloud against the larger one; launch 2: the hit rows of the larger cloud
+        # against the smaller one
+        nn_flop += 66.0 * p["n_src"] * p["n_tgt"] + 66.0 * p["n_hit"] * min(p["n_src"], p["n_tgt"])
         for key, v in st.items():
             stage_acc[key] = stage_acc.get(key, 0.0) + float(v)
         b_, f_ = algorithmic_work(p["src"].shape[0], p["tgt"].shape[0], p["n_src"], p["n_tgt"], p["L"], p["M"])
@@ -185,7 +188,8 @@ def main() -> None:
             "raw_points": [int(p0["src_h"].shape[0]), int(p0["tgt_h"].shape[0])],
             "n_src": int(r0["n_src"]), "n_tgt": int(r0["n_tgt"]), "n_corr": int(r0["L"]),
             "n_clique": int(r0["clique"].size), "n_final_inliers": int(r0["final_inliers"].size),
-            "pool": [{"id": p["id"], "n_src": int(p["n_src"]), "n_tgt": int(p["n_tgt"]), "n_corr": int(p["L"])}
+            "pool": [{"id": p["id"], "n_src": int(p["n_src"]), "n_tgt": int(p["n_tgt"]), "n_corr": int(p["L"]),
+                      "n_hit": int(p["n_hit"])}
                      for p in pool],
             "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
             "parallelism": f"pair ids [0,{args.steps}) block-partitioned over {world} GPU(s), one process per GPU, RCCL "

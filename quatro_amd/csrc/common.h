@@ -68,6 +68,16 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int* total) {
   return x - v;
 }
 
+// Views of a batched launch that live in device memory reach the kernels through this small by-value struct (NOT a
+// bare pointer parameter and NOT a member of a large argument struct): with this shape the compiler's kernel-argument
+// promotion also marks the pointers LOADED from the view as global-memory pointers; in the other two shapes every
+// access behind the view degrades to flat_load / flat_store (checked in the ISA, hipcc 7.2).
+template <typename V>
+struct ViewExt {
+  const V* ext;
+  int pad[3];
+};
+
 // ---- host mailbox lines --------------------------------------------------------------------------
 // A mailbox payload line is 16 ints in pinned host memory: words 0..14 carry data, word 15 a tag = seq ^ xor(data) ^
 // MAIL_TAG_SALT.  The host accepts a line only when the tag matches what it recomputes, so it never consumes a line

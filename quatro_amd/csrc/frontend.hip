@@ -932,55 +932,72 @@ __device__ __forceinline__ void d_seq_mean(const float4* __restrict__ pts, int n
 // chain of ~35 small dependent kernels each; one launch serves both (blockIdx.y = cloud), which halves the
 // dispatch count on the critical path and doubles the work per dispatch.  A CloudView carries one cloud's
 // pointers and sizes; kernels pick theirs with blockIdx.y.
-__device__ __forceinline__ const CloudView& cv(const Clouds2& a) { return a.ext ? a.ext[blockIdx.y] : a.c[blockIdx.y]; }
+// EXT: view in the kernel arguments (false) or in device memory (true) — a template parameter, see match.hip
+#define LAUNCH_CV(kern, a, grid, block, lds, st, ...)                                       \
+  do {                                                                                      \
+    if ((a).ext)                                                                            \
+      hipLaunchKernelGGL((kern<true>), grid, block, lds, st, (ViewExt<CloudView>{(a).ext, {0, 0, 0}}), a, ##__VA_ARGS__);             \
+    else                                                                                    \
+      hipLaunchKernelGGL((kern<false>), grid, block, lds, st, (ViewExt<CloudView>{nullptr, {0, 0, 0}}), a, ##__VA_ARGS__);            \
+  } while (0)
 __device__ __forceinline__ const u64* keys_src(const CloudView& C, int src) { return src == 0 ? C.keys_a : C.keys_b; }
 __device__ __forceinline__ u64* keys_dst(const CloudView& C, int src) { return src == 0 ? C.keys_b : C.keys_a; }
 
-__global__ void k2_cloud_init(Clouds2 a, int keep_counts) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ void k2_cloud_init(ViewExt<CloudView> x, Clouds2 a, int keep_counts) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int t = threadIdx.x;
   if (!keep_counts && t < 16) C.counts[t] = 0;
   if (t < 3) C.mm[t] = 0xffffffffu;
   if (t >= 3 && t < 6) C.mm[t] = 0u;
 }
-__global__ __launch_bounds__(256) void k2_minmax(Clouds2 a, int use_vox) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_minmax(ViewExt<CloudView> x, Clouds2 a, int use_vox) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm);
 }
-__global__ __launch_bounds__(256) void k2_vox_keys(Clouds2 a, float leaf) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_vox_keys(ViewExt<CloudView> x, Clouds2 a, float leaf) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_vox_keys(C.raw, C.P, leaf, C.mm, C.keys_a, C.counts);
 }
-__global__ __launch_bounds__(256) void k2_cell_keys(Clouds2 a, float cell) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_cell_keys(ViewExt<CloudView> x, Clouds2 a, float cell) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_cell_keys(C.vox, C.n, C.mm, cell, C.keys_a);
 }
 // src: which of keys_a (0) / keys_b (1) holds the input of this pass
-__global__ __launch_bounds__(64) void k2_radix_hist(Clouds2 a, int use_vox, int shift, int src) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(64) void k2_radix_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
   d_radix_hist<8, RADIX_TILE>(keys_src(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
 }
-__global__ __launch_bounds__(64) void k2_radix_scatter(Clouds2 a, int use_vox, int shift, int src) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(64) void k2_radix_scatter(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
   d_radix_scatter<8, RADIX_TILE>(keys_src(C, src), keys_dst(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
 }
-__global__ __launch_bounds__(256) void k2_vox_headcount(Clouds2 a, int src) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_vox_headcount(ViewExt<CloudView> x, Clouds2 a, int src) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
 }
-__global__ __launch_bounds__(1024) void k2_vox_blockscan(Clouds2 a) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k2_vox_blockscan(ViewExt<CloudView> x, Clouds2 a) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_scan_i32_copy(C.blkcnt, C.blkoff, (C.P + 1023) / 1024);
 }
-__global__ __launch_bounds__(256) void k2_vox_centroids(Clouds2 a, int cap, int src) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkoff, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
                   C.mail_seq_slot, C.seq);
 }
-__global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell, int src) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_ranges(ViewExt<CloudView> x, Clouds2 a, float cell, int src) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const u64* sorted = keys_src(C, src);
   {  // the first n threads of the launch also gather the points into cell-sorted order (was k2_sorted_points)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -993,28 +1010,34 @@ __global__ __launch_bounds__(256) void k2_ranges(Clouds2 a, float cell, int src)
   }
   d_ranges(C.vox, C.n, sorted, C.mm, cell, C.ranges);
 }
-__global__ __launch_bounds__(64) void k2_neighbors(Clouds2 a, float r2) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(64) void k2_neighbors(ViewExt<CloudView> x, Clouds2 a, float r2) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_neighbors(C.vox, C.n, C.spts, C.ranges, r2, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.counts);
 }
-__global__ __launch_bounds__(1024) void k2_nbr_scan(Clouds2 a) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k2_nbr_scan(ViewExt<CloudView> x, Clouds2 a) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_scan_i32_copy(C.nbr_cnt, C.nbr_off, C.n);
 }
-__global__ __launch_bounds__(256) void k2_normals(Clouds2 a, float rn2) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_normals(ViewExt<CloudView> x, Clouds2 a, float rn2) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_normals(C.vox, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2, C.normals);
 }
-__global__ __launch_bounds__(64) void k2_spfh(Clouds2 a) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(64) void k2_spfh(ViewExt<CloudView> x, Clouds2 a) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, C.nbr_idx, C.spfh);
 }
-__global__ __launch_bounds__(64) void k2_fpfh(Clouds2 a) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(64) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_fpfh(C.spfh, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
 }
-__global__ __launch_bounds__(256) void k2_seq_mean(Clouds2 a) {
-  const CloudView& C = cv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_seq_mean(ViewExt<CloudView> x, Clouds2 a) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_seq_mean(C.vox, C.n, C.mean);
 }
 __global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
@@ -1087,8 +1110,8 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
   for (int shift = 32; shift < 32 + key_bits; shift += 8) {
     // two launches per pass: a single-launch pass (tiles exchanging histograms through flags) needs
     // device-scope fences, which on this multi-XCD part cost more than the launch boundary
-    hipLaunchKernelGGL(k2_radix_hist, dim3(maxblk, S.nc), dim3(64), 0, st, S.a, use_vox, shift, src);
-    hipLaunchKernelGGL(k2_radix_scatter, dim3(maxblk, S.nc), dim3(64), 0, st, S.a, use_vox, shift, src);
+    LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, shift, src);
+    LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, shift, src);
     src ^= 1;
   }
   return src;
@@ -1097,14 +1120,14 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
 static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st) {
   const int nc = S.nc;
   const int g = min(1024, (S.maxP + 255) / 256);
-  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, S.a, 0);
-  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, S.a, 0);
-  hipLaunchKernelGGL(k2_vox_keys, dim3(g, nc), dim3(256), 0, st, S.a, leaf);
+  LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 0);
+  LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 0);
+  LAUNCH_CV(k2_vox_keys, S.a, dim3(g, nc), dim3(256), 0, st, leaf);
   const int where = radix_sort2(S, 0, 32, st);
   const int nblk = (S.maxP + 1023) / 1024;
-  hipLaunchKernelGGL(k2_vox_headcount, dim3(nblk, nc), dim3(256), 0, st, S.a, where);
-  hipLaunchKernelGGL(k2_vox_blockscan, dim3(1, nc), dim3(1024), 0, st, S.a);
-  hipLaunchKernelGGL(k2_vox_centroids, dim3(nblk, nc), dim3(256), 0, st, S.a, max_voxels, where);
+  LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
+  LAUNCH_CV(k2_vox_blockscan, S.a, dim3(1, nc), dim3(1024), 0, st);
+  LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
 // voxel-grid down-sampling of nc (1 or 2) raw clouds
@@ -1153,7 +1176,7 @@ hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, S.a);
+  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
   return hipGetLastError();
 }
 hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st) {
@@ -1163,7 +1186,7 @@ hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStag
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k2_seq_mean, dim3(1, 2 * G), dim3(256), 0, st, S.a);
+  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, 2 * G), dim3(256), 0, st);
   return hipGetLastError();
 }
 
@@ -1174,19 +1197,19 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   const float cell = r_fpfh * 1.001f;
   const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
   const float rn2 = (float)((double)r_normal * (double)r_normal);
-  hipLaunchKernelGGL(k2_cloud_init, dim3(1, nc), dim3(64), 0, st, S.a, 1);  // keeps the counters of the voxel stage
-  hipLaunchKernelGGL(k2_minmax, dim3(min(g, 128), nc), dim3(256), 0, st, S.a, 1);
-  hipLaunchKernelGGL(k2_cell_keys, dim3(g, nc), dim3(256), 0, st, S.a, cell);
+  LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 1);  // keeps the counters of the voxel stage
+  LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 1);
+  LAUNCH_CV(k2_cell_keys, S.a, dim3(g, nc), dim3(256), 0, st, cell);
   const int where = radix_sort2(S, 1, 24, st);
   // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
-  hipLaunchKernelGGL(k2_ranges, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, S.a, cell, where);
+  LAUNCH_CV(k2_ranges, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell, where);
   // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
   // thread and the launch went from 21 + 14 us to 51 us)
-  hipLaunchKernelGGL(k2_neighbors, dim3(maxn, nc), dim3(64), 0, st, S.a, r2);
-  hipLaunchKernelGGL(k2_normals, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, S.a, rn2);
-  hipLaunchKernelGGL(k2_spfh, dim3(maxn, nc), dim3(64), 0, st, S.a);
-  hipLaunchKernelGGL(k2_fpfh, dim3(maxn, nc), dim3(64), 0, st, S.a);
-  if (with_mean) hipLaunchKernelGGL(k2_seq_mean, dim3(1, nc), dim3(256), 0, st, S.a);
+  LAUNCH_CV(k2_neighbors, S.a, dim3(maxn, nc), dim3(64), 0, st, r2);
+  LAUNCH_CV(k2_normals, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, rn2);
+  LAUNCH_CV(k2_spfh, S.a, dim3(maxn, nc), dim3(64), 0, st);
+  LAUNCH_CV(k2_fpfh, S.a, dim3(maxn, nc), dim3(64), 0, st);
+  if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
 }
 
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,

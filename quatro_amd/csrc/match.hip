@@ -26,7 +26,17 @@
 #define NN_TILE 64
 #define NN_STRIDE 36  // floats per staged descriptor row (33 + 3 zero pad; 16-byte aligned rows)
 
-__device__ __forceinline__ const MatchView& mv(const MatchArgs& a) { return a.ext ? a.ext[blockIdx.z] : a.one; }
+// EXT (view in the kernel arguments / in device memory) is a template parameter, not a run-time select: a reference that
+// may point into either is a generic pointer, and every load behind it degrades to flat_load.  The pick itself is
+// written inline in every kernel — routed through a helper that takes the argument structs by reference, the compiler
+// loses the kernel-argument provenance again (see ViewExt in common.h).
+#define LAUNCH_MV(kern, a, grid, block, lds, st, ...)                                       \
+  do {                                                                                      \
+    if ((a).ext)                                                                            \
+      hipLaunchKernelGGL((kern<true>), grid, block, lds, st, (ViewExt<MatchView>{(a).ext, {0, 0, 0}}), (a).one, ##__VA_ARGS__);             \
+    else                                                                                    \
+      hipLaunchKernelGGL((kern<false>), grid, block, lds, st, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one, ##__VA_ARGS__);            \
+  } while (0)
 
 __device__ __forceinline__ float l2_flann33(const float* a, const float* b /* LDS row, stride-36 */) {
   float result = 0.f;
@@ -43,8 +53,9 @@ __device__ __forceinline__ float l2_flann33(const float* a, const float* b /* LD
 
 // All-exact engine (QTR_NN_ENGINE=exact).  grid (ceil(nq_max/256), slices, pairs): thread = one query, blockIdx.y =
 // slice of the base cloud.  Direction 1 evaluates the hit rows only (rows = hit list, count on the device).
-__global__ __launch_bounds__(256) void k_nn_exact(MatchArgs a, int dir) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nn_exact(ViewExt<MatchView> x, MatchView one, int dir) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   __shared__ __attribute__((aligned(16))) float tile[NN_TILE * NN_STRIDE];
   const int q = blockIdx.x * 256 + threadIdx.x;
@@ -173,8 +184,9 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
   }
 }
 // grid (pad_large_max / 256, 2, pairs): blockIdx.y = cloud (0: larger, 1: smaller)
-__global__ __launch_bounds__(256) void k_desc_prep(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   if (blockIdx.y == 0)
     d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, V.queryT_i, V.norms_i, V.hash_i, V.table_i, V.dd_mask);
   else
@@ -213,8 +225,9 @@ __device__ __forceinline__ void d_desc_dedup(const float* __restrict__ desc, int
   const u64 bal = __ballot(hide);
   if (qk_lane() == 0 && bal) atomicAdd(hidden_count, __popcll(bal));
 }
-__global__ __launch_bounds__(256) void k_desc_dedup(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_desc_dedup(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   if (blockIdx.y == 0)
     d_desc_dedup(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, V.hash_i, V.table_i, V.dd_mask, V.mcounts + MC_HIDDEN_I);
   else
@@ -238,8 +251,9 @@ __device__ __forceinline__ void nn_slicing(int nq, int ntiles, int X, int& qbloc
 // blockIdx.x + X, ...  Each wave keeps 4 x 32 query columns stationary (68 VGPRs), streams 32-row base tiles (17
 // coalesced dword loads per lane, software prefetched one tile ahead in a second register set) and issues 68 MFMAs per
 // tile.
-__global__ __launch_bounds__(256, 2) void k_nn_mfma(MatchArgs a, int dir) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256, 1) void k_nn_mfma(ViewExt<MatchView> x, MatchView one, int dir) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -333,8 +347,9 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(MatchArgs a, int dir) {
 
 // Merge the per-slice partials and decide each query: certified (see the header comment) or listed for the exact
 // re-check.  X = gridDim.x of the k_nn_mfma launch it follows.  grid (ceil(nq_max/256), 1, pairs).
-__global__ __launch_bounds__(256) void k_nn_finish(MatchArgs a, int dir, int X) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nq = V.mcounts[D.nq_slot];
   const int q = blockIdx.x * 256 + threadIdx.x;
@@ -371,74 +386,112 @@ __global__ __launch_bounds__(256) void k_nn_finish(MatchArgs a, int dir, int X) 
   }
 }
 
-// exact re-decision of the listed rows (list length read on the device).  One WAVEFRONT per (listed row, base
-// slice): the query row is wave-uniform, so its 33 values and their -2x counterparts (from the k-major query
-// table) live in SGPRs and every lane scans base descriptors (34 coalesced loads each from the k-major base
-// table) with ~60 VGPRs — many resident waves hide the load latency, there is no LDS staging and no barrier.
+// exact re-decision of the listed rows (list length read on the device).  A workgroup takes EIGHT listed rows at a
+// time: their 33 values (and the -2x copies the approximate chain needs) sit in LDS, where every lane reads them with
+// broadcast 16-byte loads, and each of the four waves streams a quarter of the base slice — 34 coalesced loads per
+// base row serve all eight queries, so the re-check moves an eighth of the L2 traffic of a row-at-a-time scan (it was
+// L2-bound: one pass over the k-major base table per listed row).
 // The test is two-staged: a 33-term fma chain gives the approximate (lower-bound, like the MFMA result) value, and
 // only base rows under the row's threshold can be the exact arg-min — those few are evaluated with the exact
 // flann::L2 arithmetic.  The exact winner always passes the filter, so the tables are unchanged.  Hidden duplicate
 // rows carry 1e30 and are skipped: their lower-indexed twin has the same exact distance and wins the tie.
-// A wave arg-min feeds one packed 64-bit atomicMin per (row, slice).  grid (64, slices, pairs).
-__global__ __launch_bounds__(256) void k_nn_exact_rows(MatchArgs a, int dir) {
-  const MatchView& V = mv(a);
+// Candidates fold into an LDS minimum per row; one packed 64-bit atomicMin per (row, slice) publishes it.
+// grid (groups, slices, pairs).
+#define XR 8
+template <bool EXT>
+__global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, MatchView one, int dir) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
+  __shared__ __attribute__((aligned(16))) float s_m2a[33][XR];  // [k][row]: -2 * a
+  __shared__ __attribute__((aligned(16))) float s_a[XR][36];    // [row][k]
+  __shared__ float s_thr[XR];
+  __shared__ int s_row[XR];
+  __shared__ u64 s_best[XR];  // packed (exact distance bits << 32 | base row) minima of the group's rows
   const float* __restrict__ A = D.A;
-  const float* __restrict__ QT = D.QT;
   const float* __restrict__ BT = D.baseT;
-  const int nq_pad = D.qt_pad, nB = D.nb, nb_pad = D.nb_pad;
+  const int nB = D.nb, nb_pad = D.nb_pad;
   const int* __restrict__ rows = V.recheck_rows;
   const float* __restrict__ thr = V.recheck_thr;
   u64* __restrict__ best = D.best;
   const int per = (nB + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nB, b0 + per);
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
-  for (int ri = blockIdx.x * 4 + wave; ri < nrows; ri += gridDim.x * 4) {
-    const int a_idx = __builtin_amdgcn_readfirstlane(rows[ri]);
-    const float tr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(thr[ri])));
-    float av[33], m2a[33];
-#pragma unroll
-    for (int k = 0; k < 33; ++k) {
-      av[k] = A[(size_t)a_idx * 33 + k];               // uniform address -> scalar loads
-      m2a[k] = QT[(size_t)k * nq_pad + a_idx];         // -2 * a[k]
+  const int ngroups = (nrows + XR - 1) / XR;
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < XR * 33; e += 256) {
+      const int r = e / 33, k = e - r * 33;
+      const int ri = g * XR + r;
+      const float val = (ri < nrows) ? A[(size_t)rows[ri] * 33 + k] : 0.f;
+      s_a[r][k] = val;
+      s_m2a[k][r] = -2.0f * val;
     }
-    u64 mine = ~0ULL;
-    for (int b = b0 + lane; b < b1; b += 64) {
+    if (threadIdx.x < XR) {
+      const int ri = g * XR + threadIdx.x;
+      s_row[threadIdx.x] = (ri < nrows) ? rows[ri] : -1;
+      s_thr[threadIdx.x] = (ri < nrows) ? thr[ri] : -INFINITY;
+      s_best[threadIdx.x] = ~0ULL;
+    }
+    __syncthreads();
+    for (int b = b0 + wave * 64 + lane; b < b1; b += 256) {
+      // (compiler barrier: without it the 66 loop-invariant 16-byte LDS reads below are hoisted out of the loop and
+      // held in 264 registers — spills; they are meant to be re-read, broadcast, every iteration)
+      asm volatile("" ::: "memory");
       float v[34];
+      const u32 bu = (u32)b;  // uniform row pointer + 32-bit lane offset: scalar-base loads, one offset register
 #pragma unroll
-      for (int k = 0; k < 34; ++k) v[k] = BT[(size_t)k * nb_pad + b];
-      float approx = v[33];  // scaled |b|^2
+      for (int k = 0; k < 34; ++k) v[k] = (BT + (size_t)k * nb_pad)[bu];
+      float ap[XR];
 #pragma unroll
-      for (int k = 0; k < 33; ++k) approx = fmaf(m2a[k], v[k], approx);
-      if (approx <= tr) {  // rare: exact flann::L2 order
+      for (int r = 0; r < XR; ++r) ap[r] = v[33];  // scaled |b|^2
+#pragma unroll
+      for (int k = 0; k < 33; ++k) {
+        if (k % 4 == 0) asm volatile("" ::: "memory");  // bounds how many LDS reads are in flight (registers)
+        const float4 ma = *(const float4*)&s_m2a[k][0], mb = *(const float4*)&s_m2a[k][4];
+        ap[0] = fmaf(ma.x, v[k], ap[0]);
+        ap[1] = fmaf(ma.y, v[k], ap[1]);
+        ap[2] = fmaf(ma.z, v[k], ap[2]);
+        ap[3] = fmaf(ma.w, v[k], ap[3]);
+        ap[4] = fmaf(mb.x, v[k], ap[4]);
+        ap[5] = fmaf(mb.y, v[k], ap[5]);
+        ap[6] = fmaf(mb.z, v[k], ap[6]);
+        ap[7] = fmaf(mb.w, v[k], ap[7]);
+      }
+      u32 pass = 0;
+#pragma unroll
+      for (int r = 0; r < XR; ++r) pass |= (ap[r] <= s_thr[r]) ? (1u << r) : 0u;
+      // rare (except among degenerate near-identical descriptors): exact flann::L2 order, one row at a time (a loop, not
+      // eight predicated copies: those would keep eight LDS rows in registers)
+      while (pass) {
+        const int r = __ffs((int)pass) - 1;
+        pass &= pass - 1;
+        const float* av = s_a[r];
         float result = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-          const float d0 = av[4 * g] - v[4 * g], d1 = av[4 * g + 1] - v[4 * g + 1], d2 = av[4 * g + 2] - v[4 * g + 2],
-                      d3 = av[4 * g + 3] - v[4 * g + 3];
+        for (int q4 = 0; q4 < 8; ++q4) {
+          const float4 a4 = *(const float4*)(av + 4 * q4);
+          const float d0 = a4.x - v[4 * q4], d1 = a4.y - v[4 * q4 + 1], d2 = a4.z - v[4 * q4 + 2],
+                      d3 = a4.w - v[4 * q4 + 3];
           result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
         const float dt = av[32] - v[32];
         result += dt * dt;
-        const u64 key = ((u64)__float_as_uint(result) << 32) | (u32)b;
-        mine = key < mine ? key : mine;
+        atomicMin(&s_best[r], ((u64)__float_as_uint(result) << 32) | (u32)b);
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const u64 o = __shfl_xor(mine, off, 64);
-      mine = o < mine ? o : mine;
-    }
-    if (lane == 0 && mine != ~0ULL) atomicMin(&best[a_idx], mine);
+    __syncthreads();
+    if (threadIdx.x < XR && s_row[threadIdx.x] >= 0 && s_best[threadIdx.x] != ~0ULL)
+      atomicMin(&best[s_row[threadIdx.x]], s_best[threadIdx.x]);
   }
 }
 
 // one launch instead of a handful of memsets/fills: counters, tuple-test flags, source->target table, NN tables,
 // dedup tables.  grid (g, 1, pairs)
-__global__ __launch_bounds__(256) void k_match_init(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
   const int pv = V.tuple ? 0 : 1;
@@ -454,8 +507,9 @@ __global__ __launch_bounds__(256) void k_match_init(MatchArgs a) {
 
 // Rows of the larger cloud that the (final) first direction points at, ascending: a bit set in LDS (one workgroup per
 // pair), then a scan over its words.  grid (1, 1, pairs), 1024 threads.
-__global__ __launch_bounds__(1024) void k_hit_compact(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ u32 hit_bits[];  // ceil(n_large / 32) words
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -496,8 +550,9 @@ __global__ __launch_bounds__(1024) void k_hit_compact(MatchArgs a) {
 
 // query columns of the hit rows, gathered into a compact k-major table (pad columns: zeros with the constant-1 row,
 // never read back).  grid (pad_large_max / 256, 1, pairs)
-__global__ __launch_bounds__(256) void k_hit_gather(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_hit_gather(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int nhit = V.mcounts[MC_NHIT];
   const int padded = (nhit + NN_QPB - 1) / NN_QPB * NN_QPB;
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -518,8 +573,9 @@ __global__ __launch_bounds__(256) void k_hit_gather(MatchArgs a) {
 
 // unpack both NN tables and evaluate the mutual-NN test in one pass (rows of the larger cloud that were not asked
 // hold ~0 and decode to -1: nobody points at them)
-__global__ __launch_bounds__(256) void k_cross_flags2(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_cross_flags2(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   for (int j = gid; j < V.n_small; j += gsz) {
     const u64 b = V.best_small[j];
@@ -536,12 +592,14 @@ __global__ __launch_bounds__(256) void k_cross_flags2(MatchArgs a) {
 }
 
 // exclusive scans (one workgroup per pair); out has n+1 entries
-__global__ __launch_bounds__(1024) void k_scan_flags(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_scan_flags(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   d_block_scan(V.flags, V.scan, V.n_large, [](int x) { return x; });
 }
-__global__ __launch_bounds__(1024) void k_scan_nonneg(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_scan_nonneg(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   d_block_scan(V.tgt_of_src, V.scan, V.ns, [](int x) { return x >= 0 ? 1 : 0; });
 }
 
@@ -558,8 +616,9 @@ __device__ __forceinline__ void match_mail(const MatchView& V, int t, int total,
   if (t == 0) mail[MAIL_SEQ_MATCH] = V.seq;  // ... the word the host is watching changes
 }
 
-__global__ void k_corr_compact2(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ void k_corr_compact2(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int ns = V.ns;
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
     const int t = V.tgt_of_src[s];
@@ -572,8 +631,9 @@ __global__ void k_corr_compact2(MatchArgs a) {
   if (V.mail && blockIdx.x == 0 && threadIdx.x < 48) match_mail(V, threadIdx.x, V.scan[ns], V.mcounts[MC_NTUPLE]);
 }
 
-__global__ void k_cross_compact(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ void k_cross_compact(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n_large; i += gridDim.x * blockDim.x) {
     if (V.flags[i]) {
       V.cross_i[V.scan[i]] = i;
@@ -584,8 +644,9 @@ __global__ void k_cross_compact(MatchArgs a) {
 }
 
 // tuple test (reference feature_matcher.cc:187-247); trial t draws qm_rand_u32(seed, 3t+k) % ncorr
-__global__ __launch_bounds__(256) void k_tuple(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_tuple(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   if (!V.tuple) return;
   const int ncorr = V.mcounts[MC_NCROSS];
   if (ncorr <= 0) return;
@@ -637,8 +698,9 @@ __global__ __launch_bounds__(256) void k_tuple(MatchArgs a) {
 }
 
 // passed cross pairs -> tgt_of_src (each source index occurs at most once after the cross-check)
-__global__ void k_scatter_pairs(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ void k_scatter_pairs(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int nc = V.mcounts[MC_NCROSS];
   const int swapped = V.swapped;
   int local = 0;
@@ -658,8 +720,9 @@ __global__ void k_scatter_pairs(MatchArgs a) {
 // contiguous run of at most 16 indices, so flag -> exclusive scan -> compaction happens in registers and LDS
 // without the three-launch (flags, scan, compact) round trips.
 // K6: unpack both NN tables, mutual-NN test, cross pairs in ascending i.
-__global__ __launch_bounds__(1024) void k_cross_fused(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ int fl_s[];  // [n_large] nn index | keep flag << 31, staged with coalesced (striped) accesses
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -716,8 +779,9 @@ __global__ __launch_bounds__(1024) void k_cross_fused(MatchArgs a) {
 
 // K8 + gather: passed cross pairs -> tgt_of_src, compaction in source order, the matched keypoint clouds
 // (when asked for) and the counters for the host.
-__global__ __launch_bounds__(1024) void k_pairs_fused(MatchArgs a) {
-  const MatchView& V = mv(a);
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   __shared__ int wsum[16];
   __shared__ int s_ntuple;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -910,7 +974,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     any_tuple = any_tuple || views[g].tuple;
   }
   const dim3 B256(256);
-  hipLaunchKernelGGL(k_match_init, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st, a);
+  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st);
   // K5: NN of every small-cloud descriptor in the large cloud, then of the HIT rows of the large cloud in the small
   // one (the reference asks the latter lazily, feature_matcher.cc:113-122; the mutual test only reads hit rows)
   if (nn_engine == 0) {
@@ -924,57 +988,55 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       return s;
     };
     if (ev && ev[0]) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(k_nn_exact, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, a, 0);
+    LAUNCH_MV(k_nn_exact, a, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, 0);
     if (ev && ev[1]) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_hit_compact, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, a);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
     if (ev && ev[2]) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_nn_exact, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, a, 1);
+    LAUNCH_MV(k_nn_exact, a, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, 1);
     if (ev && ev[3]) (void)hipEventRecord(ev[3], st);
   } else {
-    hipLaunchKernelGGL(k_desc_prep, dim3(max_pad / 256, 2, G), B256, 0, st, a);
-    hipLaunchKernelGGL(k_desc_dedup, dim3((max_large + 255) / 256, 2, G), B256, 0, st, a);
+    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+    LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     // workgroups per pair: the whole device for one pair, an equal share for a group (a workgroup loops over its
     // items, so any X is correct; this one keeps one workgroup per compute unit in flight)
     int X = (n_cu + G - 1) / G;
     if (X < 1) X = 1;
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0) (void)hipEventRecord(e0, st);
-      hipLaunchKernelGGL(k_nn_mfma, dim3(X, 1, G), B256, 0, st, a, dir);
+      LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, G), B256, 0, st, dir);
       if (e1) (void)hipEventRecord(e1, st);
-      hipLaunchKernelGGL(k_nn_finish, dim3((nq_max + 255) / 256, 1, G), B256, 0, st, a, dir, X);
-      int ey = (nb_max + 255) / 256;  // ~4 base descriptors per lane and slice
-      if (ey > 64) ey = 64;
+      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + 255) / 256, 1, G), B256, 0, st, dir, X);
+      // (row group, base slice) workgroups: a slice gives each of the four waves >= ~8 chunks of 64 base rows
+      int ey = (nb_max + 2047) / 2048;
+      if (ey > 16) ey = 16;
       if (ey < 1) ey = 1;
-      int ex = 64;
-      if (G > 1) {  // a group shares the device: fewer (row, slice) waves per pair
-        ey = max(1, ey / 4);
-        ex = 16;
-      }
-      hipLaunchKernelGGL(k_nn_exact_rows, dim3(ex, ey, G), B256, 0, st, a, dir);
+      int ex = 128;
+      if (G > 1) ex = max(8, 256 / G);  // a group shares the device
+      LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-    hipLaunchKernelGGL(k_hit_compact, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, a);
-    hipLaunchKernelGGL(k_hit_gather, dim3(max_pad / 256, 1, G), B256, 0, st, a);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
+    LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st);
     run_dir(1, max_large, max_small, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
   const bool fused_tail = max_large <= 16384 && max_ns <= 16384;
   if (fused_tail) {
-    hipLaunchKernelGGL(k_cross_fused, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st, a);
+    LAUNCH_MV(k_cross_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
   } else {
-    hipLaunchKernelGGL(k_cross_flags2, dim3(grid_for(max_large), 1, G), B256, 0, st, a);
-    hipLaunchKernelGGL(k_scan_flags, dim3(1, 1, G), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(k_cross_compact, dim3(grid_for(max_large), 1, G), B256, 0, st, a);
+    LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
+    LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
+    LAUNCH_MV(k_cross_compact, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
   }
   // K7 tuple test
-  if (any_tuple) hipLaunchKernelGGL(k_tuple, dim3(G > 1 ? 256 : 2048, 1, G), B256, 0, st, a);
+  if (any_tuple) LAUNCH_MV(k_tuple, a, dim3(G > 1 ? 256 : 2048, 1, G), B256, 0, st);
   // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
   if (fused_tail) {
-    hipLaunchKernelGGL(k_pairs_fused, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st, a);
+    LAUNCH_MV(k_pairs_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
   } else {
-    hipLaunchKernelGGL(k_scatter_pairs, dim3(grid_for(max_small), 1, G), B256, 0, st, a);
-    hipLaunchKernelGGL(k_scan_nonneg, dim3(1, 1, G), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(k_corr_compact2, dim3(grid_for(max_ns), 1, G), B256, 0, st, a);
+    LAUNCH_MV(k_scatter_pairs, a, dim3(grid_for(max_small), 1, G), B256, 0, st);
+    LAUNCH_MV(k_scan_nonneg, a, dim3(1, 1, G), dim3(1024), 0, st);
+    LAUNCH_MV(k_corr_compact2, a, dim3(grid_for(max_ns), 1, G), B256, 0, st);
   }
   return hipGetLastError();
 }
