@@ -36,11 +36,37 @@ struct SolverBufs {
   int mail_seq = 0;     // sequence number the next k_finalize / k_clique_only publishes
 };
 
+// What the back-end kernels need to know about one pair; picked with blockIdx.z (one pair travels in the kernel
+// arguments, a group of pairs sits in device memory — see ViewExt in common.h).
+struct SolverView {
+  const float4* src;  // matched keypoint clouds (L each)
+  const float4* tgt;
+  int L, W;           // correspondences, words per bit-matrix row
+  u64* bm;
+  u64* adjP;
+  int *deg, *core, *perm, *rankof, *Kp, *picks, *gsz, *clique, *rot_inl, *final_inl;
+  double* f64;
+  int* i32;
+  u64* member_bits;
+  int* picks_buf;
+  SolverState* st;
+  qtr_result* res;
+  int* mail;
+  int seq;
+};
+struct SolverArgs {
+  SolverView one;
+  const SolverView* ext;
+};
+
 size_t solver_scratch_bytes(int Lcap);
 void solver_carve(SolverBufs& B, void* base, int Lcap);
 hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                           hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique);
 hipError_t solver_init_attributes();
+// the same for G pairs at once (qtr_submit_batch): B[g] is pair g's arena, views go through `stage`
+hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,
+                                const int* L, const qtr_params& prm, ViewStage* stage, hipStream_t stream);
 hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                            hipStream_t stream, int* pinned_state);
 hipError_t solver_refinalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,

@@ -7,6 +7,8 @@
 // solveForRotation2D (:430-572) + svdRot2d (include/teaser/utils.h:151-166), solveForTranslation /
 // estimate (:585-747).  No TIM is ever materialised: the L x L predicate is evaluated tile-wise and
 // ballot-packed into a bit matrix (L^2/8 bytes instead of the reference's ~32.5 L^2 bytes).
+#include <vector>
+
 #include "common.h"
 #include "solver.h"
 
@@ -35,9 +37,14 @@ __device__ __forceinline__ bool pair_consistent(double s, double t, double beta,
   return fwd && rev;
 }
 
-__global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ src, const float4* __restrict__ tgt,
-                                                     int L, int W, double beta, u64* __restrict__ bm,
-                                                     int* __restrict__ deg, int* __restrict__ n_edges2) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const float4* __restrict__ src = V.src;
+  const float4* __restrict__ tgt = V.tgt;
+  const int L = V.L, W = V.W;
+  u64* __restrict__ bm = V.bm;
+  int* __restrict__ deg = V.deg;
   const int lane = qk_lane();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= L) return;
@@ -80,10 +87,19 @@ __global__ __launch_bounds__(256) void k_graph_build(const float4* __restrict__ 
 // workgroup barrier that orders LDS traffic only: the core_out stores issued inside the peeling loop are
 // never read by this kernel, and waiting for their HBM acknowledgement would cost ~1.5 us per round
 #define KC_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
-__global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int L, int W, const int* __restrict__ deg_in,
-                                                int* __restrict__ core_out, SolverState* __restrict__ st,
-                                                int* __restrict__ gqueue /* used when the queue does not fit LDS */,
-                                                int lds_bitmap) {
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverView one,
+                                                int use_gqueue /* the queue does not fit LDS */, int lds_bitmap_max) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ bm = V.bm;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const int* __restrict__ deg_in = V.deg;
+  int* __restrict__ core_out = V.core;
+  SolverState* __restrict__ st = V.st;
+  int* __restrict__ gqueue = use_gqueue ? V.picks : nullptr;
+  // the launch sized its LDS for the largest pair of the group: a smaller matrix fits a fortiori
+  const int lds_bitmap = lds_bitmap_max;
   extern __shared__ __attribute__((aligned(16))) int kc_lds[];
   int* deg = kc_lds;
   int* queue = gqueue ? gqueue : kc_lds + L;
@@ -171,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
     st->ub = maxcore + 1;
     st->pad[0] = kc_rounds;  // statistics
   }
+  for (int v = tid; v < L; v += nthr) V.rankof[v] = 0;  // k_rank_partial accumulates into it
 }
 
 // Level-parallel variant for L <= 1280: peeling is a chain of hundreds of dependent rounds (one per occupied
@@ -184,9 +201,14 @@ __global__ __launch_bounds__(1024) void k_kcore(const u64* __restrict__ bm, int 
 // next kernel reads every vertex's core number off its column.  Core numbers are unique, so this equals
 // compute_cores' (Batagelj-Zaversnik) result.
 #define KCL_VPT 5  // most vertices per thread: 256 * 5 = 1280
-template <int VT>
-__global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm, int L, int W,
-                                                     const int* __restrict__ deg_in, u64* __restrict__ M) {
+template <bool EXT, int VT>
+__global__ __launch_bounds__(256) void k_kcore_levels(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ bm = V.bm;
+  const int L = V.L, W = V.W;
+  if ((int)blockIdx.x + 1 >= L) return;  // levels 1 .. L-1 of THIS pair (the grid is sized for the largest)
+  const int* __restrict__ deg_in = V.deg;
+  u64* __restrict__ M = V.adjP;
   constexpr int WT = 4 * VT;
   __shared__ u64 s_alive[2][4 * KCL_VPT];
   __shared__ int s_cnt;
@@ -258,10 +280,18 @@ __global__ __launch_bounds__(256) void k_kcore_levels(const u64* __restrict__ bm
 // (L <= 1280 <= 2 vertices per thread); the ranks come from one stable counting-sort pass keyed by the core
 // number, and thread 0 initialises the clique search — one launch instead of five (collect, memset, rank
 // partial, rank finish, clique init).
-__global__ __launch_bounds__(1024) void k_kcore_collect_rank(const u64* __restrict__ M, int L, int W, int K,
-                                                            const int* __restrict__ deg_in, int* __restrict__ core_out,
-                                                            int* __restrict__ perm, int* __restrict__ Kp,
-                                                            SolverState* __restrict__ st) {
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_kcore_collect_rank(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ M = V.adjP;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const int K = L > 1 ? L - 1 : 1;  // levels k_kcore_levels wrote for this pair
+  const int* __restrict__ deg_in = V.deg;
+  int* __restrict__ core_out = V.core;
+  int* __restrict__ perm = V.perm;
+  int* __restrict__ Kp = V.Kp;
+  SolverState* __restrict__ st = V.st;
   __shared__ __attribute__((aligned(16))) int s_core[2048 + 4];
   __shared__ int s_bin[2048];
   __shared__ int s_red[32], s_tot[2];
@@ -391,7 +421,13 @@ __global__ __launch_bounds__(1024) void k_kcore_collect_rank(const u64* __restri
 // K12b: rank of every vertex in the (core, id) ascending order; perm[rank] = vertex; Kp[rank] = core+1
 // (PMC's "kcore" value).  This single order serves both as the outer start order of the heuristic
 // (traversed from the back) and as the greedy pick order (highest rank = max (K, id)).
-__global__ __launch_bounds__(256) void k_rank_partial(const int* __restrict__ core, int L, int* __restrict__ rankof) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_rank_partial(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int* __restrict__ core = V.core;
+  const int L = V.L;
+  if ((int)blockIdx.x * 256 >= L) return;
+  int* __restrict__ rankof = V.rankof;
   // grid (ceil(L/256), slices): thread = vertex v, blockIdx.y = slice of the comparison range
   __shared__ int tile[1024];
   const int v = blockIdx.x * 256 + threadIdx.x;
@@ -411,8 +447,14 @@ __global__ __launch_bounds__(256) void k_rank_partial(const int* __restrict__ co
   }
   if (v < L && r) atomicAdd(&rankof[v], r);
 }
-__global__ __launch_bounds__(256) void k_rank_finish(const int* __restrict__ core, int L, const int* __restrict__ rankof,
-                                                      int* __restrict__ perm, int* __restrict__ Kp) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_rank_finish(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int* __restrict__ core = V.core;
+  const int L = V.L;
+  const int* __restrict__ rankof = V.rankof;
+  int* __restrict__ perm = V.perm;
+  int* __restrict__ Kp = V.Kp;
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v < L) {
     const int r = rankof[v];
@@ -424,10 +466,16 @@ __global__ __launch_bounds__(256) void k_rank_finish(const int* __restrict__ cor
 // K12c: adjacency in rank labels: adjP[r][s] = adj[perm[r]][perm[s]].  One workgroup per output row:
 // the source row is staged in LDS, each wave builds output words with one LDS bit probe per lane and
 // a ballot.
-__global__ __launch_bounds__(256) void k_permute(const u64* __restrict__ bm, const int* __restrict__ perm, int L, int W,
-                                                  u64* __restrict__ adjP) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_permute(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ bm = V.bm;
+  const int* __restrict__ perm = V.perm;
+  const int L = V.L, W = V.W;
+  u64* __restrict__ adjP = V.adjP;
   extern __shared__ u64 prow[];
   const int r = blockIdx.x;
+  if (r >= L) return;
   const int v = perm[r];
   for (int w = threadIdx.x; w < W; w += 256) prow[w] = bm[(size_t)v * W + w];
   __syncthreads();
@@ -534,7 +582,11 @@ __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, in
   return greedy_descent<8>(adjP, W, r, t0, lane, picks);  // W <= 512  (L <= 32768)
 }
 
-__global__ __launch_bounds__(256) void k_clique_init(const int* __restrict__ Kp, int L, SolverState* st) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_clique_init(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L;
+  SolverState* st = V.st;
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st->mc = 0;
     st->best_r = -1;
@@ -547,9 +599,16 @@ __global__ __launch_bounds__(256) void k_clique_init(const int* __restrict__ Kp,
   }
 }
 
-__global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
-                                                      int W, const SolverState* __restrict__ st,
-                                                      int* __restrict__ gsz, int* __restrict__ picks_buf) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_clique_batch(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int* __restrict__ Kp = V.Kp;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const SolverState* __restrict__ st = V.st;
+  int* __restrict__ gsz = V.gsz;
+  int* __restrict__ picks_buf = V.picks_buf;
   const int lane = qk_lane();
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (st->done || wid >= st->batch) return;
@@ -562,9 +621,16 @@ __global__ __launch_bounds__(256) void k_clique_batch(const u64* __restrict__ ad
 // Round 0 of the heuristic is a single start (the top-ranked vertex) whose greedy descent is one long
 // dependent chain (one row AND per clique member).  When the rank-labelled bit matrix fits in LDS the
 // chain runs out of LDS (~100 cycles per step instead of an L2 round trip).
-__global__ __launch_bounds__(256) void k_clique_batch_lds(const u64* __restrict__ adjP, const int* __restrict__ Kp,
-                                                          int L, int W, const SolverState* __restrict__ st,
-                                                          int* __restrict__ gsz, int* __restrict__ picks_buf) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_clique_batch_lds(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int* __restrict__ Kp = V.Kp;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const SolverState* __restrict__ st = V.st;
+  int* __restrict__ gsz = V.gsz;
+  int* __restrict__ picks_buf = V.picks_buf;
   extern __shared__ __attribute__((aligned(16))) u64 cl_rows[];
   if (st->done) return;
   const int lane = qk_lane();
@@ -594,10 +660,17 @@ __global__ __launch_bounds__(256) void k_clique_batch_lds(const u64* __restrict_
 }
 
 // Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
-__global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP, const int* __restrict__ Kp, int L,
-                                                    int W, SolverState* __restrict__ st, const int* __restrict__ gsz,
-                                                    int next_batch, const int* __restrict__ picks_buf,
-                                                    int* __restrict__ best_picks) {
+template <bool EXT>
+__global__ __launch_bounds__(64) void k_clique_scan(ViewExt<SolverView> x, SolverView one, int next_batch) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int* __restrict__ Kp = V.Kp;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  SolverState* __restrict__ st = V.st;
+  const int* __restrict__ gsz = V.gsz;
+  const int* __restrict__ picks_buf = V.picks_buf;
+  int* __restrict__ best_picks = V.picks;
   if (st->done) return;
   const int lane = qk_lane();
   const int B = st->batch, pos = st->pos, ub = st->ub;
@@ -663,8 +736,14 @@ __global__ __launch_bounds__(64) void k_clique_scan(const u64* __restrict__ adjP
 
 // KCORE_HEU shortcut (reference src/graph.cc:67-82, including its shifted indexing): decided on device.
 // Writes the member bitset directly; st->mc = clique size, st->best_r = -2 marks "bitset already built".
-__global__ __launch_bounds__(256) void k_kcore_heu(const int* __restrict__ core, int L, double thr, SolverState* st,
-                                                   u64* __restrict__ member_bits, int W) {
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_kcore_heu(ViewExt<SolverView> x, SolverView one, double thr) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int* __restrict__ core = V.core;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  SolverState* st = V.st;
+  u64* __restrict__ member_bits = V.member_bits;
   __shared__ int s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -693,26 +772,6 @@ __global__ __launch_bounds__(256) void k_kcore_heu(const int* __restrict__ core,
 // of 256 threads; wavefront 0 runs the GNC loop with the fixed-shape sum64 reductions.
 #define FIN_LDS_BYTES (152 * 1024)
 #define FIN_THREADS 768  // three groups of four wavefronts: one COTE axis each
-struct FinalizeArgs {
-  const float4* src;
-  const float4* tgt;
-  const u64* adjP;
-  const int* perm;
-  int L, W;
-  qtr_params prm;
-  SolverState* st;
-  // global scratch (capacity >= L each unless noted)
-  u64* member_bits;  // W words
-  int* picks;        // L
-  int* clique;       // L  (sorted vertex ids)  -- also an output
-  int* rot_inl;      // L  output
-  int* final_inl;    // L  output
-  double* f64;       // 12 * L doubles
-  int* i32;          // 8 * L ints
-  qtr_result* res;   // device copy of the result record
-  int* mail;         // host mailbox (pinned, device visible) for the result record + solver state, or null
-  int seq;           // sequence number published after them
-};
 
 // GNC-TLS yaw estimation on ONE wavefront (reference solveForRotation2D, include/quatro.hpp:430-572; closed-form
 // 2x2 rotation instead of JacobiSVD, fixed 64-lane summation order — oracle divergence D6).  X = source, Y =
@@ -1182,7 +1241,9 @@ __global__ __launch_bounds__(256) void k_row_degrees(u64* __restrict__ bm, int L
   if (lane == 0) deg[row] = c;
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
+template <bool EXT>
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x, SolverView one, qtr_params prm) {
+  const SolverView& A = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ __attribute__((aligned(16))) double fin_lds[];
   __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
   __shared__ double s_R[9], s_cost, s_est, s_bestcost;
@@ -1224,7 +1285,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   double* Wt;
   double* X2 = nullptr;
   double* Y2 = nullptr;
-  const bool teaser = A.prm.reg_mode == QTR_REG_TEASER;
+  const bool teaser = prm.reg_mode == QTR_REG_TEASER;
   const bool use_lds = ((size_t)M * (teaser ? 7 : 5) * sizeof(double) <= (size_t)FIN_LDS_BYTES);
   if (use_lds) {
     X0 = fin_lds;
@@ -1268,8 +1329,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   if (wave == 0 && teaser) {
     double Rg[9], costg;
     int itersg;
-    gnc3_wave(lane, X0, X1, X2, Y0, Y1, Y2, Wt, M, A.prm.noise_bound * (2 / 1.0), A.prm.rotation_gnc_factor,
-              A.prm.rotation_max_iterations, A.prm.rotation_cost_threshold, Rg, &costg, &itersg);
+    gnc3_wave(lane, X0, X1, X2, Y0, Y1, Y2, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
+              prm.rotation_max_iterations, prm.rotation_cost_threshold, Rg, &costg, &itersg);
     if (lane == 0) {
       for (int a = 0; a < 9; ++a) s_R[a] = Rg[a];
       s_cost = costg;
@@ -1278,8 +1339,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   } else if (wave == 0) {
     double Rg[4], costg;
     int itersg;
-    gnc_wave(lane, X0, X1, Y0, Y1, Wt, M, A.prm.noise_bound * (2 / 1.0), A.prm.rotation_gnc_factor,
-             A.prm.rotation_max_iterations, A.prm.rotation_cost_threshold, Rg, &costg, &itersg);
+    gnc_wave(lane, X0, X1, Y0, Y1, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
+             prm.rotation_max_iterations, prm.rotation_cost_threshold, Rg, &costg, &itersg);
     if (lane == 0) {
       s_R[0] = Rg[0];
       s_R[1] = Rg[1];
@@ -1296,12 +1357,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   double R[9] = {s_R[0], s_R[1], 0, s_R[2], s_R[3], 0, 0, 0, 1};
   if (teaser)
     for (int a = 0; a < 9; ++a) R[a] = s_R[a];
-  if (A.prm.using_pre_estimated_ryrx) {
+  if (prm.using_pre_estimated_ryrx) {
     double Rn[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c)
         Rn[3 * r + c] =
-            (R[3 * r] * A.prm.ryrx[c] + R[3 * r + 1] * A.prm.ryrx[3 + c]) + R[3 * r + 2] * A.prm.ryrx[6 + c];
+            (R[3 * r] * prm.ryrx[c] + R[3 * r + 1] * prm.ryrx[3 + c]) + R[3 * r + 2] * prm.ryrx[6 + c];
     for (int i = 0; i < 9; ++i) R[i] = Rn[i];
   }
   if (tid == 0) s_nrot = 0;
@@ -1323,7 +1384,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   }
   __syncthreads();
   const int NR = s_nrot;
-  const bool use_rot = A.prm.using_rot_inliers_when_estimating_cote && NR > 0;
+  const bool use_rot = prm.using_rot_inliers_when_estimating_cote && NR > 0;
   const int N = use_rot ? NR : M;
   int* sel = A.i32;  // N selected vertex ids
   for (int i = tid; i < N; i += nthr) sel[i] = use_rot ? A.clique[A.rot_inl[i]] : A.clique[i];
@@ -1334,8 +1395,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   for (int i = tid; i < N; i += nthr) {
     const float4 s4 = A.src[sel[i]], t4 = A.tgt[sel[i]];
     double x = s4.x, y = s4.y, z = s4.z;
-    if (!use_rot && A.prm.using_pre_estimated_ryrx) {
-      const double* Y = A.prm.ryrx;
+    if (!use_rot && prm.using_pre_estimated_ryrx) {
+      const double* Y = prm.ryrx;
       const double nx = (Y[0] * x + Y[1] * y) + Y[2] * z, ny = (Y[3] * x + Y[4] * y) + Y[5] * z,
                    nz = (Y[6] * x + Y[7] * y) + Y[8] * z;
       x = nx;
@@ -1351,7 +1412,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   const long long t_fin3 = clock64();
   // ---- COTE (reference estimate(), :618-747).  The three axes are independent: threads 256a..256a+255
   // handle axis a (see cote_axis4).
-  const double range = A.prm.cote_noise_bound * sqrt(A.prm.cbar2);
+  const double range = prm.cote_noise_bound * sqrt(prm.cbar2);
   const int nc = 2 * N;
   const int ax = tid >> 8, tl = tid & 255;
   const bool act = ax < 3;
@@ -1366,12 +1427,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
   CoteOut co;
   if (3 * a_total <= (size_t)FIN_LDS_BYTES) {
     char* base = (char*)fin_lds + (size_t)axc * a_total;  // LDS: pointers derive from the shared array
-    co = cote_axis4(act, tl, X, N, nc, range, A.prm.cote_median, (double*)base, (int*)(base + a_spos),
+    co = cote_axis4(act, tl, X, N, nc, range, prm.cote_median, (double*)base, (int*)(base + a_spos),
                     (double*)(base + a_T), s_bc[axc], s_redc[axc], s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   } else {
     double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
     int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
-    co = cote_axis4(act, tl, X, N, nc, range, A.prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
+    co = cote_axis4(act, tl, X, N, nc, range, prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
                     s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   }
   if (act && tl == 0) {
@@ -1425,15 +1486,37 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(FinalizeArgs A) {
 }
 
 // =================================================================================================
-// host-side launcher (called from capi.hip)
+// host-side launchers (called from capi.hip)
+#define LAUNCH_SV(kern, a, grid, block, lds, st, ...)                                                     \
+  do {                                                                                                    \
+    if ((a).ext)                                                                                          \
+      hipLaunchKernelGGL((kern<true>), grid, block, lds, st, (ViewExt<SolverView>{(a).ext, {0, 0, 0}}), (a).one, \
+                         ##__VA_ARGS__);                                                                  \
+    else                                                                                                  \
+      hipLaunchKernelGGL((kern<false>), grid, block, lds, st, (ViewExt<SolverView>{nullptr, {0, 0, 0}}), (a).one, \
+                         ##__VA_ARGS__);                                                                  \
+  } while (0)
+#define LAUNCH_SV_T(kern, T, a, grid, block, lds, st)                                                     \
+  do {                                                                                                    \
+    if ((a).ext)                                                                                          \
+      hipLaunchKernelGGL((kern<true, T>), grid, block, lds, st, (ViewExt<SolverView>{(a).ext, {0, 0, 0}}), (a).one); \
+    else                                                                                                  \
+      hipLaunchKernelGGL((kern<false, T>), grid, block, lds, st, (ViewExt<SolverView>{nullptr, {0, 0, 0}}), (a).one); \
+  } while (0)
+
 hipError_t solver_init_attributes() {
-  hipError_t e = hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_kcore, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_clique_batch_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)k_permute, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipError_t e;
+#define SET_LDS(kern, bytes)                                                                                         \
+  if ((e = hipFuncSetAttribute((const void*)kern<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) \
+    return e;                                                                                                        \
+  if ((e = hipFuncSetAttribute((const void*)kern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess)  \
+    return e;
+  SET_LDS(k_finalize, FIN_LDS_BYTES)
+  SET_LDS(k_kcore, 156 * 1024)
+  SET_LDS(k_clique_batch_lds, 156 * 1024)
+  SET_LDS(k_permute, 64 * 1024)
+#undef SET_LDS
+  return hipSuccess;
 }
 size_t solver_scratch_bytes(int Lcap) {
   const size_t W = (size_t)(Lcap + 63) / 64;
@@ -1477,34 +1560,62 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
   B.res = (qtr_result*)take(sizeof(qtr_result));
 }
 
-static void launch_finalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                            hipStream_t stream) {
-  const int W = (L + 63) / 64;
-  FinalizeArgs A;
-  A.src = src;
-  A.tgt = tgt;
-  A.adjP = B.adjP;
-  A.perm = B.perm;
-  A.L = L;
-  A.W = W;
-  A.prm = prm;
-  A.st = B.st;
-  A.member_bits = B.member_bits;
-  A.picks = B.picks;
-  A.clique = B.clique;
-  A.rot_inl = B.rot_inl;
-  A.final_inl = B.final_inl;
-  A.f64 = B.f64;
-  A.i32 = B.i32;
-  A.res = B.res;
-  A.mail = B.mail;
-  A.seq = B.mail_seq;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, A);
+static SolverView make_solver_view(const SolverBufs& B, const float4* src, const float4* tgt, int L) {
+  SolverView V;
+  memset(&V, 0, sizeof(V));
+  V.src = src;
+  V.tgt = tgt;
+  V.L = L;
+  V.W = (L + 63) / 64;
+  V.bm = B.bm;
+  V.adjP = B.adjP;
+  V.deg = B.deg;
+  V.core = B.core;
+  V.perm = B.perm;
+  V.rankof = B.rankof;
+  V.Kp = B.Kp;
+  V.picks = B.picks;
+  V.gsz = B.gsz;
+  V.clique = B.clique;
+  V.rot_inl = B.rot_inl;
+  V.final_inl = B.final_inl;
+  V.f64 = B.f64;
+  V.i32 = B.i32;
+  V.member_bits = B.member_bits;
+  V.picks_buf = B.picks_buf;
+  V.st = B.st;
+  V.res = B.res;
+  V.mail = B.mail;
+  V.seq = B.mail_seq;
+  return V;
+}
+// one pair in the kernel arguments, or a group through the stage
+static hipError_t solver_args(SolverArgs& a, const SolverView* views, int G, ViewStage* stage, hipStream_t st) {
+  a.one = views[0];
+  a.ext = nullptr;
+  if (G > 1) {
+    a.ext = (const SolverView*)stage_push(stage, views, sizeof(SolverView) * (size_t)G, st);
+    if (!a.ext) return hipErrorOutOfMemory;
+  }
+  return hipSuccess;
 }
 
-// K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds.  Expects the bit matrix in
-// B.bm and the degrees in B.deg; everything stays on `stream`.
-static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kcore_thr, hipStream_t stream) {
+// the solver state of every pair starts from zero (was a hipMemsetAsync per pair)
+template <bool EXT>
+__global__ void k_solver_reset(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;
+  int* p = (int*)V.st;
+  if (threadIdx.x < (int)(sizeof(SolverState) / 4)) p[threadIdx.x] = 0;
+}
+
+static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, hipStream_t stream) {
+  LAUNCH_SV(k_finalize, a, dim3(1, 1, G), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, prm);
+}
+
+// K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds, for the G pairs of `a` (Lmax = the
+// largest L among them: grids, LDS sizes and kernel variants are chosen for it; every kernel reads its own pair's L).
+// Expects the bit matrices in bm and the degrees in deg; everything stays on `stream`.
+static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream) {
   const int W = (L + 63) / 64;
   static const bool dbg_sync = getenv("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
 #define CS_DBG(name)                                                                                   \
@@ -1520,64 +1631,49 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
     const size_t bm_bytes = (size_t)L * W * 8;
     const bool kc_single_wave = (L <= 256 * KCL_VPT);
     if (kc_single_wave) {
-      const dim3 kgrid(L > 1 ? L - 1 : 1);
-#define KCL_LAUNCH(VT) \
-  hipLaunchKernelGGL(k_kcore_levels<VT>, kgrid, dim3(256), 0, stream, B.bm, L, W, B.deg, B.adjP)
-      if (W <= 4) KCL_LAUNCH(1);
-      else if (W <= 8) KCL_LAUNCH(2);
-      else if (W <= 12) KCL_LAUNCH(3);
-      else if (W <= 16) KCL_LAUNCH(4);
-      else KCL_LAUNCH(5);
-#undef KCL_LAUNCH
-      hipLaunchKernelGGL(k_kcore_collect_rank, dim3(1), dim3(1024), 0, stream, B.adjP, L, W, (int)kgrid.x, B.deg, B.core,
-                         B.perm, B.Kp, B.st);
+      const dim3 kgrid(L > 1 ? L - 1 : 1, 1, G);
+      if (W <= 4) LAUNCH_SV_T(k_kcore_levels, 1, a, kgrid, dim3(256), 0, stream);
+      else if (W <= 8) LAUNCH_SV_T(k_kcore_levels, 2, a, kgrid, dim3(256), 0, stream);
+      else if (W <= 12) LAUNCH_SV_T(k_kcore_levels, 3, a, kgrid, dim3(256), 0, stream);
+      else if (W <= 16) LAUNCH_SV_T(k_kcore_levels, 4, a, kgrid, dim3(256), 0, stream);
+      else LAUNCH_SV_T(k_kcore_levels, 5, a, kgrid, dim3(256), 0, stream);
+      LAUNCH_SV(k_kcore_collect_rank, a, dim3(1, 1, G), dim3(1024), 0, stream);
     } else {
       const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
-      const int kc_threads = 1024;
-      hipLaunchKernelGGL(k_kcore, dim3(1), dim3(kc_threads), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, B.bm, L, W,
-                         B.deg, B.core, B.st, q_in_lds ? (int*)nullptr : B.picks, lds_bitmap);
+      LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, q_in_lds ? 0 : 1,
+                lds_bitmap);
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
-      (void)hipMemsetAsync(B.rankof, 0, sizeof(int) * (size_t)L, stream);
-      hipLaunchKernelGGL(k_rank_partial, dim3((L + 255) / 256, slices), dim3(256), 0, stream, B.core, L, B.rankof);
-      hipLaunchKernelGGL(k_rank_finish, dim3((L + 255) / 256), dim3(256), 0, stream, B.core, L, B.rankof, B.perm, B.Kp);
-      hipLaunchKernelGGL(k_clique_init, dim3(1), dim3(64), 0, stream, B.Kp, L, B.st);
+      LAUNCH_SV(k_rank_partial, a, dim3((L + 255) / 256, slices, G), dim3(256), 0, stream);
+      LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
+      LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
       CS_DBG("rank");
     }
-    hipLaunchKernelGGL(k_permute, dim3(L), dim3(256), (size_t)W * 8, stream, B.bm, B.perm, L, W, B.adjP);
+    LAUNCH_SV(k_permute, a, dim3(L, 1, G), dim3(256), (size_t)W * 8, stream);
     CS_DBG("k_permute");
-    bool heuristic = true;
-    if (mode == QTR_INLIER_KCORE_HEU) {
-      hipLaunchKernelGGL(k_kcore_heu, dim3(1), dim3(256), 0, stream, B.core, L, kcore_thr, B.st,
-                         B.member_bits, W);
-    }
-    if (heuristic) {
+    if (mode == QTR_INLIER_KCORE_HEU) LAUNCH_SV(k_kcore_heu, a, dim3(1, 1, G), dim3(256), 0, stream, kcore_thr);
+    {
       const int BATCH = CLIQUE_BATCH;
       // round 0: the single top-ranked start; round 1..: BATCH starts each
       const size_t cl_lds = (size_t)L * W * 8 + (size_t)4 * L * sizeof(int);  // matrix + four per-wave pick lists
       const bool lds_rows = cl_lds <= (size_t)150 * 1024;
       if (lds_rows)
-        hipLaunchKernelGGL(k_clique_batch_lds, dim3(1), dim3(256), cl_lds, stream, B.adjP, B.Kp, L, W, B.st,
-                           B.gsz, B.picks_buf);
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(1, 1, G), dim3(256), cl_lds, stream);
       else
-        hipLaunchKernelGGL(k_clique_batch, dim3(1), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, B.picks_buf);
+        LAUNCH_SV(k_clique_batch, a, dim3(1, 1, G), dim3(256), 0, stream);
       CS_DBG("clique batch 0");
-      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
-                         B.picks);
+      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
       CS_DBG("clique scan 0");
       // Rounds 0 and 1 are enqueued unconditionally: the heuristic nearly always terminates within them (the
       // first start finds the large clique, the second batch only confirms that no start can beat it).  The
       // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
       if (lds_rows)
-        hipLaunchKernelGGL(k_clique_batch_lds, dim3(BATCH / 4), dim3(256), cl_lds, stream, B.adjP, B.Kp, L, W,
-                           B.st, B.gsz, B.picks_buf);
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
       else
-        hipLaunchKernelGGL(k_clique_batch, dim3(BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
-                           B.picks_buf);
+        LAUNCH_SV(k_clique_batch, a, dim3(BATCH / 4, 1, G), dim3(256), 0, stream);
       CS_DBG("clique batch 1");
-      hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, BATCH, B.picks_buf,
-                         B.picks);
+      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
       CS_DBG("clique scan 1");
     }
   }
@@ -1588,21 +1684,21 @@ static void clique_stage_enqueue(const SolverBufs& B, int L, int mode, double kc
 // check per round) and the finalisation again.
 hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                            hipStream_t stream, int* pinned_state) {
-  const int W = (L + 63) / 64;
   hipError_t e;
   int guard = 0;
+  const SolverView V = make_solver_view(B, src, tgt, L);
+  SolverArgs a;
+  if ((e = solver_args(a, &V, 1, nullptr, stream)) != hipSuccess) return e;
   while (true) {
-    hipLaunchKernelGGL(k_clique_batch, dim3(CLIQUE_BATCH / 4), dim3(256), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz,
-                       B.picks_buf);
-    hipLaunchKernelGGL(k_clique_scan, dim3(1), dim3(64), 0, stream, B.adjP, B.Kp, L, W, B.st, B.gsz, CLIQUE_BATCH,
-                       B.picks_buf, B.picks);
+    LAUNCH_SV(k_clique_batch, a, dim3(CLIQUE_BATCH / 4, 1, 1), dim3(256), 0, stream);
+    LAUNCH_SV(k_clique_scan, a, dim3(1, 1, 1), dim3(64), 0, stream, CLIQUE_BATCH);
     if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
       return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     if (((const SolverState*)pinned_state)->done) break;
     if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
   }
-  if (src) launch_finalize(B, src, tgt, L, prm, stream);
+  if (src) launch_finalize(a, 1, prm, stream);
   return hipGetLastError();
 }
 
@@ -1610,7 +1706,11 @@ hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4*
 hipError_t solver_refinalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                              hipStream_t stream) {
   (void)hipGetLastError();
-  launch_finalize(B, src, tgt, L, prm, stream);
+  const SolverView V = make_solver_view(B, src, tgt, L);
+  SolverArgs a;
+  hipError_t e = solver_args(a, &V, 1, nullptr, stream);
+  if (e != hipSuccess) return e;
+  launch_finalize(a, 1, prm, stream);
   return hipGetLastError();
 }
 
@@ -1627,7 +1727,10 @@ hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int
         (e = hipMemcpyAsync(B.bm, d_adj, (size_t)L * W * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
       return e;
     hipLaunchKernelGGL(k_row_degrees, dim3((L + 3) / 4), dim3(256), 0, stream, B.bm, L, W, B.deg);
-    clique_stage_enqueue(B, L, mode, kcore_thr, stream);
+    const SolverView V = make_solver_view(B, nullptr, nullptr, L);
+    SolverArgs a;
+    if ((e = solver_args(a, &V, 1, nullptr, stream)) != hipSuccess) return e;
+    clique_stage_launch(a, 1, L, mode, kcore_thr, stream);
   }
   return hipGetLastError();
 }
@@ -1639,25 +1742,39 @@ hipError_t clique_only_finish(const SolverBufs& B, int L, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Enqueues the whole back end on `stream`.  L is known on the host.  Returns a HIP error code.
-// The clique heuristic normally terminates after the first two batches (see header comment of
-// k_clique_batch); `*host_done` (pinned) is polled between further rounds.
-hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                          hipStream_t stream, int* pinned_state /* >= 16 ints, host pinned */,
-                          hipEvent_t ev_graph, hipEvent_t ev_clique) {
-  const int W = (L + 63) / 64;
+// The whole back end of the G pairs of `views` on `stream` (L known on the host).  The clique heuristic normally
+// terminates after the first two batches (see k_clique_batch); the host checks `done` with the result record.
+static hipError_t solver_launch(const SolverView* views, int G, const qtr_params& prm, ViewStage* stage,
+                                hipStream_t stream, hipEvent_t ev_graph, hipEvent_t ev_clique) {
   hipError_t e;
   (void)hipGetLastError();  // a stale sticky error (e.g. timing query on an unrecorded event) is not ours
-  if ((e = hipMemsetAsync(B.st, 0, sizeof(SolverState), stream)) != hipSuccess) return e;
+  SolverArgs a;
+  if ((e = solver_args(a, views, G, stage, stream)) != hipSuccess) return e;
+  int L = 0;
+  for (int g = 0; g < G; ++g) L = max(L, views[g].L);
+  LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
-    hipLaunchKernelGGL(k_graph_build, dim3((L + 3) / 4), dim3(256), 0, stream, src, tgt, L, W, beta, B.bm, B.deg,
-                       &B.st->n_edges2);
+    LAUNCH_SV(k_graph_build, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, beta);
     if (ev_graph) hipEventRecord(ev_graph, stream);
-    clique_stage_enqueue(B, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream);
+    clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream);
   }
   if (ev_clique) hipEventRecord(ev_clique, stream);
-  launch_finalize(B, src, tgt, L, prm, stream);
+  launch_finalize(a, G, prm, stream);
   return hipGetLastError();
+}
+
+hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
+                          hipStream_t stream, int* pinned_state /* unused */, hipEvent_t ev_graph, hipEvent_t ev_clique) {
+  (void)pinned_state;
+  const SolverView V = make_solver_view(B, src, tgt, L);
+  return solver_launch(&V, 1, prm, nullptr, stream, ev_graph, ev_clique);
+}
+
+hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,
+                                const int* L, const qtr_params& prm, ViewStage* stage, hipStream_t stream) {
+  std::vector<SolverView> v((size_t)G);
+  for (int g = 0; g < G; ++g) v[g] = make_solver_view(*B[g], src[g], tgt[g], L[g]);
+  return solver_launch(v.data(), G, prm, stage, stream, nullptr, nullptr);
 }
