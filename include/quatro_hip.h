@@ -23,6 +23,8 @@
  *   qtr_patchwork      <- PatchWork::estimate_ground    include/patchwork.hpp:329-476
  *   qtr_segment_cloud  <- ImageProjection::segmentCloud ("Patchwork" mode) + getValidSegments / getOutliers
  *                                                          include/imageProjection.hpp:244-258,273-581
+ *   qtr_submit_batch / qtr_wait <- the demo's loop over scan pairs (one Quatro object, reset() between
+ *                         registrations)                   examples/run_global_registration.cpp:97-108
  *   qtr_register_pair  <- the demo's whole path        examples/run_global_registration.cpp:206-246
  *                         (voxelize x2, FPFHManager::setFeaturePair include/fpfh_manager.hpp:98-153,
  *                          setInputSource/setInputTarget/computeTransformation)
@@ -255,6 +257,32 @@ int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const q
 int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
                       const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
                       int* final_inliers, int cap, int mem);
+
+/* Batched registration (BASELINE configs[2] / [3]; the reference's usage is one Quatro object reused over many pairs,
+ * examples/run_global_registration.cpp:97-108).  B independent pairs go through the SAME kernels as qtr_register_pair,
+ * a group of pairs per launch (blockIdx.z = pair): the handle's stream slots are split into two lanes of
+ * n_slots / 2 pairs each, a lane runs voxelise -> FPFH + matching -> solver as three launch chains with ONE host
+ * read-back of the device-side sizes per chain and group (not per pair), and the two lanes alternate so that one's
+ * kernels cover the other's read-back.  Results are bit-identical to B sequential qtr_register_pair calls.
+ *   qtr_submit_batch  validates, records the job and enqueues the first chains; returns without waiting.
+ *   qtr_wait          drives the job to completion (call it from the same thread).  results[i] receives pair i's
+ *                     record (its own status: QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL, QTR_ERR_CAPACITY ...); the return
+ *                     value is QTR_OK unless the job itself failed (HIP error, bad argument).
+ * pairs / results must stay valid until qtr_wait returns; one job at a time per handle; every slot of the handle is
+ * used (do not run slot calls concurrently).  mem as elsewhere (raw scans and the optional index lists). */
+typedef struct qtr_pair_desc {
+  const float* src_raw4; /* raw source scan, 16-byte x,y,z,* records */
+  int n_src;
+  const float* tgt_raw4;
+  int n_tgt;
+  unsigned long long seed; /* tuple-test RNG seed of this pair (qtr_frontend_params.seed is ignored) */
+  int* clique;             /* optional: getMaxCliques indices, capacity `cap` ints (NULL: not wanted) */
+  int* final_inliers;      /* optional: getFinalInliersIndices */
+  int cap;
+} qtr_pair_desc;
+int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,
+                     const qtr_params* prm, qtr_result* results, int mem);
+int qtr_wait(qtr_handle* h);
 
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 

@@ -40,10 +40,32 @@ struct Slot {
   int last_ns = 0, last_nt = 0;
 };
 
+// One lane of the batch driver (qtr_submit_batch): a contiguous group of slots stepped through the three launch
+// chains in lockstep on the first slot's streams.
+struct Lane {
+  int first_slot = 0, cap = 0;  // slots [first_slot, first_slot + cap)
+  ViewStage stage;              // views of the group (pinned host + device)
+  int phase = 0;                // 0 idle, 1 voxelise pending, 2 matching pending, 3 solver pending
+  int first_pair = 0, count = 0;  // pairs [first_pair, first_pair + count) of the job are on this lane
+  std::vector<int> active;      // indices g (0..count) of the pairs still alive after each chain's checks
+  std::vector<int> ns, nt, L;   // per g
+};
+struct BatchJob {
+  const qtr_pair_desc* pairs = nullptr;
+  int B = 0, next = 0, done = 0;
+  qtr_frontend_params fp;
+  qtr_params prm;
+  qtr_result* results = nullptr;
+  int mem = QTR_MEM_HOST;
+  bool active = false;
+};
+
 struct qtr_handle {
   int device = 0;
   qtr_limits lim;
   std::vector<Slot> slots;
+  std::vector<Lane> lanes;
+  BatchJob job;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
   double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
@@ -110,6 +132,10 @@ void* qtr_slot_stream(qtr_handle* h, int slot) {
 void qtr_destroy(qtr_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  for (auto& l : h->lanes) {
+    if (l.stage.h) (void)hipHostFree(l.stage.h);
+    if (l.stage.d) (void)hipFree(l.stage.d);
+  }
   for (auto& s : h->slots) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     if (s.stream2) (void)hipStreamSynchronize(s.stream2);
@@ -175,6 +201,18 @@ static int create_impl(qtr_handle* h) {
       s.fb.m_cap = h->lim.max_corr;
     }
   }
+  // batch lanes: two groups of slots that alternate (one's kernels cover the other's host read-back)
+  const int S = (int)h->slots.size();
+  const int NL = S >= 2 ? 2 : 1;
+  h->lanes.resize((size_t)NL);
+  for (int l = 0; l < NL; ++l) {
+    Lane& ln = h->lanes[l];
+    ln.cap = S / NL;
+    ln.first_slot = l * ln.cap;
+    ln.stage.cap = (size_t)64 * 1024 + (size_t)ln.cap * 8192;
+    QTR_HIP_TRY(h, hipHostMalloc((void**)&ln.stage.h, ln.stage.cap));
+    QTR_HIP_TRY(h, hipMalloc((void**)&ln.stage.d, ln.stage.cap));
+  }
   return QTR_OK;
 }
 
@@ -219,6 +257,37 @@ static void fill_nn_times(Slot& s) {
 // default is to WATCH the pinned word — the store crosses PCIe in ~1-2 us, the runtime's stream wait costs
 // 20-30 us per phase boundary (three per registration) — and to fall back to the runtime every 64k polls so
 // that a failed launch or a lost device ends the wait.  QTR_HOST_WAIT=block uses hipStreamSynchronize only.
+// the payload a sequence word announces is consumed only once its tag matches (common.h, mail_store_line): the
+// sequence word can reach host memory before the counters
+static bool mail_payload_ok(const Slot& s, int idx, int seq) {
+  auto line_ok = [&](int base) {
+    const volatile int* l = s.mail + base;
+    int x = 0;
+    for (int i = 0; i < 15; ++i) x ^= l[i];
+    return l[15] == (seq ^ x ^ MAIL_TAG_SALT);
+  };
+  auto solver_ok = [&]() {
+    const volatile int* m = s.mail + MAIL_SOLVER;
+    int x = 0, y = 0;
+    for (int i = 0; i < (int)(sizeof(qtr_result) / 4); ++i) x ^= m[i];
+    for (int i = 0; i < (int)(sizeof(SolverState) / 4); ++i) y ^= m[64 + i];
+    return m[63] == (seq ^ x ^ MAIL_TAG_SALT) && m[96] == (seq ^ y ^ MAIL_TAG_SALT);
+  };
+  switch (idx) {
+    case MAIL_SEQ_VOX0: return line_ok(MAIL_VOX0);
+    case MAIL_SEQ_VOX1: return line_ok(MAIL_VOX1);
+    case MAIL_SEQ_MATCH: return line_ok(MAIL_MATCH) && line_ok(MAIL_CNT0) && line_ok(MAIL_CNT1);
+    case MAIL_SEQ_SOLVE: return solver_ok();
+    default: return true;
+  }
+}
+// non-blocking: has the phase-ending kernel published `seq` in word `idx`, payload complete?
+static bool mail_ready(const Slot& s, int idx, int seq) {
+  if (__atomic_load_n((volatile int*)(s.mail + idx), __ATOMIC_ACQUIRE) != seq) return false;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return mail_payload_ok(s, idx, seq);
+}
+
 static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
   volatile int* p = s.mail + idx;
   if (!h->spin_wait) {
@@ -239,30 +308,7 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
     snprintf(h->err, sizeof(h->err), "mailbox word %d holds %d, expected %d (phase kernel did not run)", idx, (int)*p, seq);
     return QTR_ERR_HIP;
   }
-  // the payload is consumed only once its tag matches (common.h, mail_store_line): the sequence word can reach host
-  // memory before the counters it announces
-  auto line_ok = [&](int base) {
-    const volatile int* l = s.mail + base;
-    int x = 0;
-    for (int i = 0; i < 15; ++i) x ^= l[i];
-    return l[15] == (seq ^ x ^ MAIL_TAG_SALT);
-  };
-  auto solver_ok = [&]() {
-    const volatile int* m = s.mail + MAIL_SOLVER;
-    int x = 0, y = 0;
-    for (int i = 0; i < (int)(sizeof(qtr_result) / 4); ++i) x ^= m[i];
-    for (int i = 0; i < (int)(sizeof(SolverState) / 4); ++i) y ^= m[64 + i];
-    return m[63] == (seq ^ x ^ MAIL_TAG_SALT) && m[96] == (seq ^ y ^ MAIL_TAG_SALT);
-  };
-  auto payload_ok = [&]() {
-    switch (idx) {
-      case MAIL_SEQ_VOX0: return line_ok(MAIL_VOX0);
-      case MAIL_SEQ_VOX1: return line_ok(MAIL_VOX1);
-      case MAIL_SEQ_MATCH: return line_ok(MAIL_MATCH) && line_ok(MAIL_CNT0) && line_ok(MAIL_CNT1);
-      case MAIL_SEQ_SOLVE: return solver_ok();
-      default: return true;
-    }
-  };
+  auto payload_ok = [&]() { return mail_payload_ok(s, idx, seq); };
   bool drained = false;
   for (unsigned long spins = 1;; ++spins) {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1151,6 +1197,320 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   s.times_pending = 2;
   const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched registration: lanes of slots stepped through the three launch chains in lockstep
+static void batch_fail_pair(qtr_handle* h, int pair, int status) {
+  qtr_result& r = h->job.results[pair];
+  r.status = status;
+  r.valid = 0;
+  ++h->job.done;
+}
+
+static int lane_start_chunk(qtr_handle* h, Lane& ln) {
+  BatchJob& J = h->job;
+  if (J.next >= J.B) {
+    ln.phase = 0;
+    ln.count = 0;
+    return QTR_OK;
+  }
+  ln.first_pair = J.next;
+  ln.count = min(ln.cap, J.B - J.next);
+  J.next += ln.count;
+  ln.stage.off = 0;
+  ln.active.clear();
+  ln.ns.assign((size_t)ln.count, 0);
+  ln.nt.assign((size_t)ln.count, 0);
+  ln.L.assign((size_t)ln.count, 0);
+  Slot& lead = h->slots[ln.first_slot];
+  std::vector<FrontBufs*> F;
+  std::vector<const float4*> raws;
+  std::vector<int> Ps;
+  for (int g = 0; g < ln.count; ++g) {
+    const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+    Slot& s = h->slots[ln.first_slot + g];
+    qtr_result& r = J.results[ln.first_pair + g];
+    memset(&r, 0, sizeof(r));
+    if (pd.n_src <= 0 || pd.n_tgt <= 0 || !pd.src_raw4 || !pd.tgt_raw4) {
+      batch_fail_pair(h, ln.first_pair + g, QTR_ERR_BAD_ARG);
+      continue;
+    }
+    if (pd.n_src > h->lim.max_points || pd.n_tgt > h->lim.max_points) {
+      batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
+      continue;
+    }
+    const float4 *d_s = (const float4*)pd.src_raw4, *d_t = (const float4*)pd.tgt_raw4;
+    if (J.mem == QTR_MEM_HOST) {
+      QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, pd.src_raw4, (size_t)pd.n_src * 16, hipMemcpyHostToDevice, lead.stream));
+      QTR_HIP_TRY(h, hipMemcpyAsync(s.in_tgt, pd.tgt_raw4, (size_t)pd.n_tgt * 16, hipMemcpyHostToDevice, lead.stream));
+      d_s = s.in_src;
+      d_t = s.in_tgt;
+    }
+    s.fb.mail_seq = ++s.seq;
+    s.times_pending = 0;
+    ln.active.push_back(g);
+    F.push_back(&s.fb);
+    raws.push_back(d_s);
+    raws.push_back(d_t);
+    Ps.push_back(pd.n_src);
+    Ps.push_back(pd.n_tgt);
+  }
+  if (ln.active.empty()) return lane_start_chunk(h, ln);  // nothing valid in this chunk: take the next one
+  QTR_HIP_TRY(h, voxelize_enqueue_group(F.data(), (int)F.size(), raws.data(), Ps.data(), J.fp.voxel_size, &ln.stage,
+                                        lead.stream));
+  QTR_HIP_TRY(h, hipEventRecord(lead.ev_vox, lead.stream));
+  ln.phase = 1;
+  return QTR_OK;
+}
+
+// advances the lane by at most one chain; *progress is set when it did
+static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
+  BatchJob& J = h->job;
+  if (ln.phase == 0) return QTR_OK;
+  Slot& lead = h->slots[ln.first_slot];
+  if (ln.phase == 1) {
+    for (int g : ln.active) {
+      Slot& s = h->slots[ln.first_slot + g];
+      if (!mail_ready(s, MAIL_SEQ_VOX0, s.seq) || !mail_ready(s, MAIL_SEQ_VOX1, s.seq)) return QTR_OK;
+    }
+    *progress = true;
+    std::vector<int> keep;
+    std::vector<FrontBufs*> F;
+    std::vector<int> n2;
+    std::vector<unsigned long long> seeds;
+    for (int g : ln.active) {
+      Slot& s = h->slots[ln.first_slot + g];
+      qtr_result& r = J.results[ln.first_pair + g];
+      const int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+      r.n_src = ns;
+      r.n_tgt = nt;
+      if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] || ns > h->lim.max_voxels ||
+          nt > h->lim.max_voxels || ns <= 0 || nt <= 0) {
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
+        continue;
+      }
+      ln.ns[g] = ns;
+      ln.nt[g] = nt;
+      s.last_ns = ns;
+      s.last_nt = nt;
+      keep.push_back(g);
+      F.push_back(&s.fb);
+      n2.push_back(ns);
+      n2.push_back(nt);
+      seeds.push_back(J.pairs[ln.first_pair + g].seed);
+    }
+    ln.active.swap(keep);
+    if (ln.active.empty()) return lane_start_chunk(h, ln);
+    const int G = (int)F.size();
+    QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream2, lead.ev_vox, 0));
+    QTR_HIP_TRY(h, mean_enqueue_group(F.data(), G, n2.data(), &ln.stage, lead.stream2));  // beside the FPFH chain
+    QTR_HIP_TRY(h, hipEventRecord(lead.ev[5], lead.stream2));
+    QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream));
+    QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, lead.ev[5], 0));
+    for (int g : ln.active) {
+      Slot& s = h->slots[ln.first_slot + g];
+      s.fb.mail_seq = ++s.seq;
+    }
+    QTR_HIP_TRY(h, match_enqueue_group(F.data(), G, n2.data(), &J.fp, seeds.data(), &ln.stage, lead.stream));
+    ln.phase = 2;
+    return QTR_OK;
+  }
+  if (ln.phase == 2) {
+    for (int g : ln.active) {
+      Slot& s = h->slots[ln.first_slot + g];
+      if (!mail_ready(s, MAIL_SEQ_MATCH, s.seq)) return QTR_OK;
+    }
+    *progress = true;
+    std::vector<int> keep, Ls;
+    std::vector<SolverBufs*> SB;
+    std::vector<const float4*> srcs, tgts;
+    for (int g : ln.active) {
+      Slot& s = h->slots[ln.first_slot + g];
+      qtr_result& r = J.results[ln.first_pair + g];
+      const int L = s.mail[MAIL_MATCH + MC_NCORR];
+      r.n_corr = L;
+      if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW] || L > h->lim.max_corr) {
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
+        continue;
+      }
+      QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail
+      ln.L[g] = L;
+      s.last_L = L;
+      s.sb.mail_seq = ++s.seq;
+      keep.push_back(g);
+      SB.push_back(&s.sb);
+      srcs.push_back(s.m_src);
+      tgts.push_back(s.m_tgt);
+      Ls.push_back(L);
+    }
+    ln.active.swap(keep);
+    if (ln.active.empty()) return lane_start_chunk(h, ln);
+    QTR_HIP_TRY(h, solver_enqueue_group(SB.data(), (int)SB.size(), srcs.data(), tgts.data(), Ls.data(), J.prm, &ln.stage,
+                                        lead.stream));
+    ln.phase = 3;
+    return QTR_OK;
+  }
+  // phase 3
+  for (int g : ln.active) {
+    Slot& s = h->slots[ln.first_slot + g];
+    if (!mail_ready(s, MAIL_SEQ_SOLVE, s.seq)) return QTR_OK;
+  }
+  *progress = true;
+  bool copies = false;
+  for (int g : ln.active) {
+    Slot& s = h->slots[ln.first_slot + g];
+    const int pair = ln.first_pair + g;
+    qtr_result& r = J.results[pair];
+    const qtr_pair_desc& pd = J.pairs[pair];
+    const int L = ln.L[g];
+    int rc = QTR_OK;
+    if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
+      s.sb.mail_seq = ++s.seq;
+      QTR_HIP_TRY(h, solver_continue(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128));
+      QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
+    }
+    if (L > 0 && J.prm.inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
+      SolverState hs;
+      memcpy(&hs, s.mail + MAIL_SOLVER + 64, sizeof(hs));
+      bool improved = false;
+      hipStream_t keep_stream = s.stream;
+      s.stream = lead.stream;  // exact_phase enqueues on s.stream: the lane's chain owns this slot's arenas
+      rc = exact_phase(h, s, L, hs, &improved);
+      if (rc == QTR_OK && improved) {
+        s.sb.mail_seq = ++s.seq;
+        const hipError_t e = solver_refinalize(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream);
+        s.stream = keep_stream;
+        QTR_HIP_TRY(h, e);
+        QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
+      }
+      s.stream = keep_stream;
+      if (rc != QTR_OK) return rc;
+    }
+    const int keep_ns = r.n_src, keep_nt = r.n_tgt, keep_nc = r.n_corr;
+    memcpy(&r, s.mail + MAIL_SOLVER, sizeof(qtr_result));
+    r.n_src = keep_ns;
+    r.n_tgt = keep_nt;
+    r.n_corr = keep_nc;
+    const hipMemcpyKind kind = (J.mem == QTR_MEM_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (pd.clique && r.n_clique > 0) {
+      if (r.n_clique > pd.cap) r.status = QTR_ERR_CAPACITY;
+      else {
+        QTR_HIP_TRY(h, hipMemcpyAsync(pd.clique, s.sb.clique, sizeof(int) * (size_t)r.n_clique, kind, lead.stream));
+        copies = true;
+      }
+    }
+    if (pd.final_inliers && r.n_final > 0) {
+      if (r.n_final > pd.cap) r.status = QTR_ERR_CAPACITY;
+      else {
+        QTR_HIP_TRY(h, hipMemcpyAsync(pd.final_inliers, s.sb.final_inl, sizeof(int) * (size_t)r.n_final, kind, lead.stream));
+        copies = true;
+      }
+    }
+    ++J.done;
+  }
+  if (copies) QTR_HIP_TRY(h, hipStreamSynchronize(lead.stream));
+  return lane_start_chunk(h, ln);
+}
+
+int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,
+                     const qtr_params* prm, qtr_result* results, int mem) {
+  if (!h) return QTR_ERR_BAD_ARG;
+  if (h->job.active) {
+    snprintf(h->err, sizeof(h->err), "a batch is already in flight on this handle (call qtr_wait first)");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (B < 0 || (B > 0 && (!pairs || !results)) || !fp) {
+    snprintf(h->err, sizeof(h->err), "bad batch arguments");
+    return QTR_ERR_BAD_ARG;
+  }
+  const int rc = check_params(h, prm);
+  if (rc != QTR_OK) return rc;
+  if (fp->normal_radius > fp->fpfh_radius) {
+    snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (!fp->use_crosscheck) {
+    snprintf(h->err, sizeof(h->err), "use_crosscheck = 0 is not supported by the batched path");
+    return QTR_ERR_UNSUPPORTED;
+  }
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  BatchJob& J = h->job;
+  J.pairs = pairs;
+  J.B = B;
+  J.next = 0;
+  J.done = 0;
+  J.fp = *fp;
+  J.prm = *prm;
+  J.results = results;
+  J.mem = mem;
+  J.active = true;
+  for (auto& ln : h->lanes) {
+    const int r = lane_start_chunk(h, ln);
+    if (r != QTR_OK) {
+      J.active = false;
+      return r;
+    }
+  }
+  return QTR_OK;
+}
+
+int qtr_wait(qtr_handle* h) {
+  if (!h) return QTR_ERR_BAD_ARG;
+  BatchJob& J = h->job;
+  if (!J.active) return QTR_OK;
+  (void)hipSetDevice(h->device);
+  int rc = QTR_OK;
+  unsigned long idle = 0;
+  while (true) {
+    bool any_active = false, progress = false;
+    for (auto& ln : h->lanes) {
+      if (ln.phase == 0) continue;
+      any_active = true;
+      rc = lane_poll(h, ln, &progress);
+      if (rc != QTR_OK) break;
+    }
+    if (rc != QTR_OK || !any_active) break;
+    if (progress) {
+      idle = 0;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++idle & 0xfffff) == 0) {  // nothing moved for a long while: has a launch failed, is the device gone?
+      for (auto& ln : h->lanes) {
+        if (ln.phase == 0) continue;
+        Slot& lead = h->slots[ln.first_slot];
+        const hipError_t q = hipStreamQuery(lead.stream);
+        if (q == hipSuccess) {  // stream drained, yet a mailbox never arrived
+          bool all = true;
+          for (int g : ln.active) {
+            Slot& s = h->slots[ln.first_slot + g];
+            const int idx = ln.phase == 1 ? MAIL_SEQ_VOX1 : ln.phase == 2 ? MAIL_SEQ_MATCH : MAIL_SEQ_SOLVE;
+            all = all && mail_ready(s, idx, s.seq);
+          }
+          if (!all) {
+            snprintf(h->err, sizeof(h->err), "batch lane drained its stream without publishing phase %d", ln.phase);
+            rc = QTR_ERR_HIP;
+          }
+        } else if (q != hipErrorNotReady) {
+          snprintf(h->err, sizeof(h->err), "batch lane: %s", hipGetErrorString(q));
+          rc = QTR_ERR_HIP;
+        }
+        (void)hipGetLastError();
+      }
+      if (rc != QTR_OK) break;
+    }
+  }
+  if (rc != QTR_OK) {  // leave the handle usable: drain what is in flight
+    for (auto& ln : h->lanes) {
+      Slot& lead = h->slots[ln.first_slot];
+      (void)hipStreamSynchronize(lead.stream);
+      (void)hipStreamSynchronize(lead.stream2);
+      ln.phase = 0;
+    }
+  }
+  J.active = false;
   return rc;
 }
 

@@ -53,6 +53,11 @@ class Result(C.Structure):
     ]
 
 
+class PairDesc(C.Structure):
+    _fields_ = [("src_raw4", C.c_void_p), ("n_src", C.c_int), ("tgt_raw4", C.c_void_p), ("n_tgt", C.c_int),
+                ("seed", C.c_ulonglong), ("clique", C.c_void_p), ("final_inliers", C.c_void_p), ("cap", C.c_int)]
+
+
 class StageTimes(C.Structure):
     _fields_ = ([(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total",
                                           "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
@@ -78,7 +83,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math",
+    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait",
 ]
 
 _lib = None
@@ -200,6 +205,9 @@ def load():
                                       C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.c_void_p, C.c_int]
     lib.qtr_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.qtr_submit_batch.argtypes = [C.c_void_p, C.POINTER(PairDesc), C.c_int, C.POINTER(FrontendParams),
+                                     C.POINTER(Params), C.POINTER(Result), C.c_int]
+    lib.qtr_wait.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -459,6 +467,54 @@ class Handle:
     def solve_dev(self, src_ptr: int, tgt_ptr: int, L: int, prm: Params, res: Result, slot: int = 0) -> int:
         return self._lib.qtr_solve(self._h, slot, src_ptr, tgt_ptr, L, C.byref(prm), C.byref(res), None, None, None,
                                    0, MEM_DEVICE)
+
+    # ---- batched registration (qtr_submit_batch / qtr_wait): every slot of the handle is used
+    def register_batch(self, pairs, fp: FrontendParams | None = None, params: Params | None = None, want_lists=True):
+        """pairs: sequence of (src [n,4] float32, tgt [m,4] float32, seed).  Returns one result dict per pair, in
+        order — the same dicts register_pair returns."""
+        fp = fp or default_frontend_params()
+        prm = params or demo_params()
+        B = len(pairs)
+        descs = (PairDesc * max(B, 1))()
+        results = (Result * max(B, 1))()
+        keep = []
+        cap = int(self.limits.max_corr)
+        for i, (s_, t_, seed) in enumerate(pairs):
+            s_, t_ = _f4(s_), _f4(t_)
+            cl = np.zeros(cap if want_lists else 1, dtype=np.int32)
+            fin = np.zeros(cap if want_lists else 1, dtype=np.int32)
+            keep.append((s_, t_, cl, fin))
+            descs[i] = PairDesc(s_.ctypes.data, s_.shape[0], t_.ctypes.data, t_.shape[0], int(seed),
+                                cl.ctypes.data if want_lists else None, fin.ctypes.data if want_lists else None, cap)
+        self._check(self._lib.qtr_submit_batch(self._h, descs, B, C.byref(fp), C.byref(prm), results, MEM_HOST))
+        self._check(self._lib.qtr_wait(self._h))
+        out = []
+        for i in range(B):
+            _, _, cl, fin = keep[i]
+            r = results[i]
+            if want_lists and r.status in (QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL):
+                out.append(_result_dict(r, cl, None, fin))
+            else:
+                out.append({"status": r.status, "valid": bool(r.valid), "T": np.array(r.T[:]).reshape(4, 4),
+                            "cost": r.cost, "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr,
+                            "n_clique": r.n_clique, "n_final": r.n_final, "n_rot_inliers": r.n_rot_inliers})
+        return out
+
+    def register_batch_dev(self, items, prm: Params, fp: FrontendParams | None = None):
+        """items: dicts with device tensors "src" / "tgt" and a FrontendParams "fp" (its seed is the pair's seed).
+        Inputs stay in HBM; only the result records come back.  Returns a list of dicts (status, valid, T, sizes)."""
+        fp = fp or default_frontend_params()
+        B = len(items)
+        descs = (PairDesc * max(B, 1))()
+        results = (Result * max(B, 1))()
+        for i, it in enumerate(items):
+            descs[i] = PairDesc(it["src"].data_ptr(), it["src"].shape[0], it["tgt"].data_ptr(), it["tgt"].shape[0],
+                                int(it["fp"].seed), None, None, 0)
+        self._check(self._lib.qtr_submit_batch(self._h, descs, B, C.byref(fp), C.byref(prm), results, MEM_DEVICE))
+        self._check(self._lib.qtr_wait(self._h))
+        return [{"status": r.status, "valid": bool(r.valid), "T": np.array(r.T[:]).reshape(4, 4), "cost": r.cost,
+                 "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr, "n_clique": r.n_clique, "n_final": r.n_final}
+                for r in results[:B]]
 
     def stage_times(self, slot: int = 0) -> dict:
         t = StageTimes()

@@ -1038,3 +1038,83 @@ def test_randomised_sweep_against_oracle():
                        text=True, timeout=280)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-500:])
     assert "0 mismatches" in p.stdout
+
+
+# ---------------------------------------------------------------------------------------------- batched path
+def _seq_results(h, pairs):
+    return [h.register_pair(s, t, ql.default_frontend_params(seed=seed), slot=0) for (s, t, seed) in pairs]
+
+
+def _assert_same_record(a, b):
+    assert a["status"] == b["status"] and a["valid"] == b["valid"]
+    assert (a["n_src"], a["n_tgt"], a["L"]) == (b["n_src"], b["n_tgt"], b["L"])
+    assert np.array_equal(a["clique"], b["clique"]) and np.array_equal(a["final_inliers"], b["final_inliers"])
+    assert np.array_equal(a["T"], b["T"]) and (a["cost"] == b["cost"] or (np.isinf(a["cost"]) and np.isinf(b["cost"])))
+
+
+def test_batch_is_bit_identical_to_sequential_runs():
+    """qtr_submit_batch / qtr_wait (groups of pairs per launch chain, two lanes) against one qtr_register_pair per pair:
+    every record, clique and inlier list identical.  11 pairs on 8 slots: full chunks, a ragged last chunk, both lanes."""
+    pairs = []
+    for i in range(11):
+        s, t, _ = synth.kitti64_pair(i % 4) if i % 3 else synth.kitti64_pair(4 + i % 2, n_boxes=60)
+        if i == 5:
+            s = s[: s.shape[0] // 3]       # a much smaller pair inside a group
+        pairs.append((s, t, 100 + i))
+    h1 = ql.Handle(0)
+    seq = _seq_results(h1, pairs)
+    h1.close()
+    hb = ql.Handle(0, n_slots=8, max_points=131072, max_voxels=32768, max_corr=8192)
+    try:
+        got = hb.register_batch(pairs)
+        assert len(got) == len(seq)
+        for a, b in zip(got, seq):
+            _assert_same_record(a, b)
+        again = hb.register_batch(pairs[:3])   # the handle is reusable, a batch smaller than one lane
+        for a, b in zip(again, seq[:3]):
+            _assert_same_record(a, b)
+        one = hb.register_pair(*pairs[2][:2], ql.default_frontend_params(seed=pairs[2][2]), slot=3)  # slots still work
+        _assert_same_record(one, seq[2])
+    finally:
+        hb.close()
+
+
+def test_batch_256_pair_ids_agree_with_sequential_runs():
+    """BASELINE configs[2]: 256 pair ids streamed through one GPU (pool of 8 distinct synthetic pairs, distinct tuple-test
+    seeds per id): the batched records equal the sequential ones for every id."""
+    pool = [synth.kitti64_pair(i) for i in range(8)]
+    ids = list(range(256))
+    h1 = ql.Handle(0, max_points=131072, max_voxels=32768, max_corr=8192)
+    # sequential reference: one run per distinct (pool pair, seed) — seeds cycle with period 16
+    ref = {}
+    for i in ids:
+        key = (i % 8, i % 16)
+        if key not in ref:
+            s, t, _ = pool[key[0]]
+            ref[key] = h1.register_pair(s, t, ql.default_frontend_params(seed=key[1]))
+    h1.close()
+    hb = ql.Handle(0, n_slots=32, max_points=131072, max_voxels=32768, max_corr=8192)
+    try:
+        got = hb.register_batch([(pool[i % 8][0], pool[i % 8][1], i % 16) for i in ids])
+        for i, g in zip(ids, got):
+            _assert_same_record(g, ref[(i % 8, i % 16)])
+    finally:
+        hb.close()
+
+
+def test_batch_reports_per_pair_failures_and_keeps_going():
+    """A pair that exceeds a limit gets its own QTR_ERR_CAPACITY; the rest of the batch is unaffected."""
+    good = synth.kitti64_pair(1)
+    big = np.zeros((70000, 4), dtype=np.float32)
+    big[:, :3] = np.random.default_rng(1).uniform(-40, 40, size=(70000, 3))
+    hb = ql.Handle(0, n_slots=4, max_points=65536, max_voxels=32768, max_corr=8192)
+    h1 = ql.Handle(0)
+    try:
+        ref = h1.register_pair(good[0], good[1], ql.default_frontend_params(seed=9))
+        got = hb.register_batch([(good[0], good[1], 9), (big, good[1], 1), (good[0], good[1], 9)])
+        assert got[1]["status"] == ql.QTR_ERR_CAPACITY
+        _assert_same_record(got[0], ref)
+        _assert_same_record(got[2], ref)
+    finally:
+        hb.close()
+        h1.close()
