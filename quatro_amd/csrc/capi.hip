@@ -207,8 +207,8 @@ static int create_impl(qtr_handle* h) {
   h->lanes.resize((size_t)NL);
   for (int l = 0; l < NL; ++l) {
     Lane& ln = h->lanes[l];
-    ln.cap = S / NL;
-    ln.first_slot = l * ln.cap;
+    ln.cap = min(S / NL, 64);  // a launch chain serves at most 64 pairs (match.hip NN_MAXG)
+    ln.first_slot = l * (S / NL);
     ln.stage.cap = (size_t)64 * 1024 + (size_t)ln.cap * 8192;
     QTR_HIP_TRY(h, hipHostMalloc((void**)&ln.stage.h, ln.stage.cap));
     QTR_HIP_TRY(h, hipMalloc((void**)&ln.stage.d, ln.stage.cap));

@@ -234,38 +234,78 @@ __global__ __launch_bounds__(256) void k_desc_dedup(ViewExt<MatchView> x, MatchV
     d_desc_dedup(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, V.hash_j, V.table_j, V.dd_mask, V.mcounts + MC_HIDDEN_J);
 }
 
-// How the (query block, base slice) work items of one pair and direction are cut: as many slices as give every one of
-// the X workgroups of the launch one item (never more items than workgroups when the query blocks allow it — two
-// workgroups on one compute unit share the matrix pipe and lose ~40 % to each other's loads).
-__device__ __forceinline__ void nn_slicing(int nq, int ntiles, int X, int& qblocks, int& nsplit, int& tps) {
-  qblocks = (nq + NN_QPB - 1) / NN_QPB;
-  int s = qblocks > 0 ? X / qblocks : 1;
-  if (s > NN_MAXSPLIT) s = NN_MAXSPLIT;
-  if (s > ntiles) s = ntiles;
-  if (s < 1) s = 1;
-  tps = (ntiles + s - 1) / s;
-  nsplit = (ntiles + tps - 1) / tps;
-}
+// How the work of one k_nn_mfma launch is cut into items = (pair, block of 512 queries, slice of the base cloud), and in
+// which order the X workgroups of the launch take them.
+//   * few query blocks (one pair): as many slices as give every workgroup one item and no more — a second round with a
+//     handful of items costs as much as a full one;
+//   * many (a group of pairs): items of ~1/8 of a workgroup's share, handed out through an atomic counter, so that
+//     pairs of different size and the ragged last round cost a few per cent instead of a third of the launch.
+// Evaluated by wave 0 of every workgroup (of this kernel and of k_nn_finish, which has to find the same slicing) from
+// the device-side query counts of all pairs; results in LDS.  Written as a macro on purpose: the kernel-argument
+// structs must not travel by reference (see ViewExt).
+#define NN_MAXG 64
+#define NN_PLAN(G_, dir_, X_)                                                                                   \
+  __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG];                                             \
+  if (threadIdx.x < 64) {                                                                                       \
+    const int g_ = threadIdx.x;                                                                                 \
+    int qb_ = 0, nt_ = 1;                                                                                       \
+    if (g_ < (G_)) {                                                                                            \
+      const MatchView& P_ = EXT ? x.ext[g_] : one;                                                              \
+      qb_ = (P_.mcounts[P_.d[dir_].nq_slot] + NN_QPB - 1) / NN_QPB;                                             \
+      nt_ = P_.d[dir_].nb_pad / 32;                                                                             \
+    }                                                                                                           \
+    const int S_ = wave_sum_i32(qb_), W_ = wave_sum_i32(qb_ * nt_);                                             \
+    int sp_;                                                                                                    \
+    if (S_ <= (X_)) {                                                                                           \
+      sp_ = (X_) / max(S_, 1);                                                                                  \
+    } else {                                                                                                    \
+      const int T_ = max(64, (W_ + (X_) * 8 - 1) / ((X_) * 8));                                                 \
+      sp_ = (nt_ + T_ - 1) / T_;                                                                                \
+    }                                                                                                           \
+    sp_ = max(1, min(min(sp_, NN_MAXSPLIT), nt_));                                                              \
+    const int tps_ = (nt_ + sp_ - 1) / sp_;                                                                     \
+    sp_ = (nt_ + tps_ - 1) / tps_;                                                                              \
+    int tot_;                                                                                                   \
+    const int ex_ = wave_excl_scan_i32(qb_ * sp_, &tot_);                                                       \
+    if (g_ < (G_)) {                                                                                            \
+      s_off[g_] = ex_;                                                                                          \
+      s_ns[g_] = sp_;                                                                                           \
+      s_tps[g_] = tps_;                                                                                         \
+    }                                                                                                           \
+    if (g_ == 0) s_off[(G_)] = tot_;                                                                            \
+  }                                                                                                             \
+  __syncthreads();
 
-// grid (X, 1, pairs).  A work item = 512 queries x one slice of the base cloud; a workgroup takes items blockIdx.x,
-// blockIdx.x + X, ...  Each wave keeps 4 x 32 query columns stationary (68 VGPRs), streams 32-row base tiles (17
-// coalesced dword loads per lane, software prefetched one tile ahead in a second register set) and issues 68 MFMAs per
-// tile.
+// grid (X): persistent workgroups that take items until the launch's counter runs out.  Each wave keeps 4 x 32 query
+// columns stationary (68 VGPRs), streams 32-row base tiles (17 coalesced dword loads per lane, software prefetched one
+// tile ahead in a second register set) and issues 68 MFMAs per tile.
 template <bool EXT>
-__global__ __launch_bounds__(256, 1) void k_nn_mfma(ViewExt<MatchView> x, MatchView one, int dir) {
-  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  const NnDir& D = V.d[dir];
+__global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchView one, int dir, int G) {
+  NN_PLAN(G, dir, (int)gridDim.x)
+  __shared__ int s_item;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int nb_pad = D.nb_pad, nq_pad = D.nq_pad;
-  const int ntiles = nb_pad / 32;
-  int qblocks, nsplit, tps;
-  nn_slicing(V.mcounts[D.nq_slot], ntiles, (int)gridDim.x, qblocks, nsplit, tps);
-  const float* __restrict__ baseT = D.baseT;
-  const float* __restrict__ queryT = D.queryT;
-  NnPartial* __restrict__ partial = V.partial;
-  for (int item = blockIdx.x; item < qblocks * nsplit; item += gridDim.x) {
-    const int qb = item / nsplit, slice = item - qb * nsplit;
+  int* counter = (EXT ? x.ext[0].mcounts : one.mcounts) + 14 + dir;  // zeroed by k_match_init
+  const int total = s_off[G];
+#pragma unroll 1
+  while (true) {
+    if (threadIdx.x == 0) s_item = atomicAdd(counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();
+    if (item >= total) break;
+    int g = 0;
+    while (g + 1 < G && item >= s_off[g + 1]) ++g;
+    const MatchView& V = EXT ? x.ext[g] : one;  // (inline on purpose: see ViewExt)
+    const NnDir& D = V.d[dir];
+    const int nb_pad = D.nb_pad, nq_pad = D.nq_pad;
+    const int ntiles = nb_pad / 32;
+    const int nsplit = s_ns[g], tps = s_tps[g];
+    const float* __restrict__ baseT = D.baseT;
+    const float* __restrict__ queryT = D.queryT;
+    NnPartial* __restrict__ partial = V.partial;
+    const int local = item - s_off[g];
+    const int qb = local / nsplit, slice = local - qb * nsplit;
     const int qbase = (qb * 4 + wave) * NN_QPW + col;
     float q[4][NN_K2];
 #pragma unroll
@@ -284,12 +324,15 @@ __global__ __launch_bounds__(256, 1) void k_nn_mfma(ViewExt<MatchView> x, MatchV
       it1[c] = -1;
     }
     const int t_begin = slice * tps, t_end = min(ntiles, t_begin + tps);
-    const float* bp = baseT + (size_t)half * nb_pad + col;
+    // uniform row pointers (scalar registers) + ONE 32-bit lane offset: the 17 loads of a tile use the scalar-base
+    // addressing form instead of 17 64-bit address pairs in vector registers (the kernel has to fit 256 registers: with
+    // more the accumulators move to AGPRs and every value of the epilogue costs an extra v_accvgpr_read)
+    const u32 lane_off = (u32)half * (u32)nb_pad + (u32)col;
     float m0[NN_K2], m1[NN_K2];
     auto load_tile = [&](float* m, int t) {
-      const float* p = bp + (size_t)t * 32;
+      const u32 off = lane_off + (u32)t * 32u;
 #pragma unroll
-      for (int kk = 0; kk < NN_K2; ++kk) m[kk] = p[(size_t)(2 * kk) * nb_pad];
+      for (int kk = 0; kk < NN_K2; ++kk) m[kk] = (baseT + (size_t)(2 * kk) * nb_pad)[off];
     };
     auto compute_tile = [&](const float* m, int t) {
       f32x16 acc[4];
@@ -348,14 +391,14 @@ __global__ __launch_bounds__(256, 1) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 // Merge the per-slice partials and decide each query: certified (see the header comment) or listed for the exact
 // re-check.  X = gridDim.x of the k_nn_mfma launch it follows.  grid (ceil(nq_max/256), 1, pairs).
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X) {
+__global__ __launch_bounds__(256) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G) {
+  NN_PLAN(G, dir, X)
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nq = V.mcounts[D.nq_slot];
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  int qblocks, nsplit, tps;
-  nn_slicing(nq, D.nb_pad / 32, X, qblocks, nsplit, tps);
+  const int nsplit = s_ns[blockIdx.z];
   float b1 = INFINITY, b2 = INFINITY;
   int i1 = -1;
   const NnPartial* __restrict__ partial = V.partial;
@@ -997,15 +1040,12 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   } else {
     LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);
     LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
-    // workgroups per pair: the whole device for one pair, an equal share for a group (a workgroup loops over its
-    // items, so any X is correct; this one keeps one workgroup per compute unit in flight)
-    int X = (n_cu + G - 1) / G;
-    if (X < 1) X = 1;
+    const int X = n_cu;  // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second)
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0) (void)hipEventRecord(e0, st);
-      LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, G), B256, 0, st, dir);
+      LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
       if (e1) (void)hipEventRecord(e1, st);
-      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + 255) / 256, 1, G), B256, 0, st, dir, X);
+      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + 255) / 256, 1, G), B256, 0, st, dir, X, G);
       // (row group, base slice) workgroups: a slice gives each of the four waves >= ~8 chunks of 64 base rows
       int ey = (nb_max + 2047) / 2048;
       if (ey > 16) ey = 16;

@@ -109,6 +109,68 @@ void run2(const char* name) {
   hipFree(clk);
 }
 
+
+// The c-outer design in isolation: a dependent chain of 17 MFMAs into one accumulator while the 16 values of the OTHER
+// accumulator (finished one chain ago) are folded into a running top-2, one value per MFMA slot.
+// SGB 1: order pinned with sched_group_barrier; PACK 1: index packed into the mantissa (3 VALU / value), 0: 2 VALU
+template <int SGB, int PACK, int SKIP0>
+__global__ __launch_bounds__(256) void k_probe3(float* out, long long* clk, int iters) {
+  f32x16 acc0 = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+  const f32x16 zero16 = acc0;
+  float x = threadIdx.x * 0.001f, y = 1.0f + threadIdx.x * 0.002f;
+  float b1 = 1e30f, b2 = 1e30f;
+  float ninf = -INFINITY;
+  asm volatile("" : "+v"(ninf));  // opaque: keeps med3(b1, v, -inf) a v_med3 (a literal folds to canonicalise + v_min)
+  const long long c0 = clock64();
+#define P3_FOLD(PACC, R)                                                                              \
+  {                                                                                                   \
+    const float v_ = PACK ? __uint_as_float((__float_as_uint(PACC[R]) & 0xfffffff0u) | (unsigned)(R)) : PACC[R]; \
+    b2 = __builtin_amdgcn_fmed3f(b1, b2, v_);                                                         \
+    b1 = __builtin_amdgcn_fmed3f(b1, v_, ninf);                                                       \
+  }
+#define P3_CHAIN(ACC, PACC)                                                                           \
+  {                                                                                                   \
+    ACC = zero16;                                                                                     \
+    asm volatile("" : "+v"(x), "+v"(y));  /* opaque operands: the four chains are not common subexpressions */ \
+    _Pragma("unroll") for (int kk = 0; kk < 17; ++kk) {                                               \
+      ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, ACC, 0, 0, 0);                                 \
+      if (SKIP0 ? (kk >= 1) : (kk < 16)) P3_FOLD(PACC, (SKIP0 ? kk - 1 : kk))                         \
+      if (SGB) {                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x002, PACK ? 3 : 2, 0);                                 \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+  for (int it = 0; it < iters; ++it) {
+    P3_CHAIN(acc0, acc1)
+    P3_CHAIN(acc1, acc0)
+    P3_CHAIN(acc0, acc1)
+    P3_CHAIN(acc1, acc0)
+  }
+  const long long c1 = clock64();
+  float s = b1 + b2;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = c1 - c0;
+}
+template <int SGB, int PACK, int SKIP0>
+void run3(const char* name) {
+  float* out;
+  long long* clk;
+  hipMalloc(&out, (size_t)256 * 256 * 4);
+  hipMalloc(&clk, 16);
+  const int iters = 100;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipLaunchKernelGGL((k_probe3<SGB, PACK, SKIP0>), dim3(256), dim3(256), 0, 0, out, clk, iters);
+    hipDeviceSynchronize();
+  }
+  long long h[2];
+  hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  printf("%-50s clk per 68-MFMA tile %.0f (68 x 64 = 4352)\n", name, (double)h[0] / iters);
+  hipFree(out);
+  hipFree(clk);
+}
+
 template <int NACC, int VPM>
 void run(const char* name, int blocks, int threads) {
   float* out;
@@ -179,6 +241,12 @@ void occ(int blocks) {
 }
 
 int main() {
+  run3<0, 1, 0>("chain + fold, source order, pack");
+  run3<1, 1, 0>("chain + fold, sgb, pack");
+  run3<1, 0, 0>("chain + fold, sgb, nopack");
+  run3<0, 0, 0>("chain + fold, source order, nopack");
+  run3<1, 1, 1>("chain + fold, sgb, pack, skip slot 0");
+  run3<1, 0, 1>("chain + fold, sgb, nopack, skip slot 0");
   run2<0>("epilogue reads the other accumulator set");
   run2<1>("epilogue on plain registers");
   occ<100>(512);
