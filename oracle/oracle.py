@@ -1,8 +1,11 @@
 """ctypes binding of oracle/libquatro_oracle.so — TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED (see quatro_oracle.cpp header): the reference has no golden vectors and cannot be built
-here, so this oracle defines the deterministic semantics the HIP path is compared against.
+Pinning status (see quatro_oracle.cpp header and DESIGN.md section 4): the reference ships no golden vectors and most of
+it cannot be built here (PCL / FLANN / Eigen / PMC absent).  ONE stage can: teaser::Matcher — its own
+feature_matcher.cc is compiled in place into oracle/_ref/libref_matcher.so (oracle/Makefile, target `ref`) and the
+oracle's match() is checked against it (ref_match below, tests/test_ref_cpu.py, tests/golden/matcher_ref.npz).  For the
+other stages the oracle defines the deterministic semantics the HIP path is compared against: parity unpinned there.
 """
 from __future__ import annotations
 
@@ -24,6 +27,52 @@ def build(force: bool = False) -> str:
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
     return _LIB_PATH
+
+
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_matcher.so")
+REFERENCE_ROOT = os.environ.get("QUATRO_REFERENCE", "/root/reference")
+_ref = None
+
+
+def ref_buildable() -> bool:
+    return os.path.exists(os.path.join(REFERENCE_ROOT, "src", "teaser_utils", "feature_matcher.cc"))
+
+
+def build_ref(force: bool = False):
+    """Compiles the reference's teaser::Matcher where it lies (never copied).  Returns the .so path, or None when
+    /root/reference is absent (GPU box: the prebuilt file travels with the snapshot)."""
+    if ref_buildable():
+        subprocess.check_call(["make", "-C", _HERE, "ref", "REF=" + REFERENCE_ROOT] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+    return _REF_PATH if os.path.exists(_REF_PATH) else None
+
+
+def ref_available() -> bool:
+    return os.path.exists(_REF_PATH)
+
+
+def ref_match(xyz_s, desc_s, xyz_t, desc_t, crosscheck=True, tuple_test=True, tuple_scale=0.95, seed=0):
+    """teaser::Matcher::calculateCorrespondences of the REFERENCE (compiled from /root/reference), with
+    use_absolute_scale = true as FPFHManager calls it (include/fpfh_manager.hpp:126-127).  The only substitutions are the
+    absent libraries (exact brute-force scan behind FLANN's interface) and the tuple test's random draws (counter RNG
+    instead of srand(time) / rand()).  Prints the reference's own progress lines on stdout."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REF_PATH)
+        _ref.ref_calculate_correspondences.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                       C.c_int, C.c_int, C.c_int, C.c_float, C.c_ulonglong, C.c_void_p,
+                                                       C.c_int]
+    xs = np.ascontiguousarray(np.asarray(xyz_s)[:, :3], dtype=np.float32)
+    xt = np.ascontiguousarray(np.asarray(xyz_t)[:, :3], dtype=np.float32)
+    ds = np.ascontiguousarray(desc_s, dtype=np.float32)
+    dt = np.ascontiguousarray(desc_t, dtype=np.float32)
+    cap = 3 * 100 * (len(xs) + len(xt)) + 16
+    corr = np.zeros((cap, 2), dtype=np.int32)
+    n = _ref.ref_calculate_correspondences(xs.ctypes.data, len(xs), ds.ctypes.data, xt.ctypes.data, len(xt),
+                                           dt.ctypes.data, 1, int(crosscheck), int(tuple_test), tuple_scale, int(seed),
+                                           corr.ctypes.data, cap)
+    assert n <= cap
+    return corr[:n].copy()
 
 
 class Params(C.Structure):
@@ -142,6 +191,16 @@ def fpfh(xyz4, r_normal: float, r_fpfh: float):
     lib().qo_fpfh(_p(xyz4, C.c_float), n, C.c_double(r_normal), C.c_double(r_fpfh), _p(nrm, C.c_float),
                   _p(sp, C.c_float), _p(de, C.c_float))
     return nrm, sp, de
+
+
+def eigen33(cov):
+    """pcl::eigen33 restatement on n symmetric 3x3 float matrices -> (smallest eigenvalues [n], eigenvectors [n,3])."""
+    cov = np.ascontiguousarray(cov, dtype=np.float32).reshape(-1, 9)
+    n = cov.shape[0]
+    ev = np.zeros(n, dtype=np.float32)
+    vec = np.zeros((n, 3), dtype=np.float32)
+    lib().qo_eigen33(_p(cov, C.c_float), n, _p(ev, C.c_float), _p(vec, C.c_float))
+    return ev, vec
 
 
 def nn33(query, data):

@@ -1609,6 +1609,12 @@ int qo_fpfh(const float* xyz4, int n, double r_normal, double r_fpfh, float* nor
   return 0;
 }
 
+// pcl::eigen33 smallest eigenpair of n symmetric 3x3 matrices (row-major 9 floats each) — exported so that the
+// restatement can be checked against an independent eigen-solver on many random covariances
+void qo_eigen33(const float* cov9, int n, float* evals, float* evecs3) {
+  for (int i = 0; i < n; ++i) eigen33_smallest(cov9 + 9 * (size_t)i, evals + i, evecs3 + 3 * (size_t)i);
+}
+
 int qo_nn33(const float* query, int nq, const float* data, int n, int* out) {
 #pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
   for (int q = 0; q < nq; ++q) out[q] = nn33(query + 33 * (size_t)q, data, n);

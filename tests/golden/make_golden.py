@@ -1,5 +1,6 @@
-"""Generates the committed fixtures under tests/golden/ from the CPU oracle (the reference itself has no
-golden vectors and cannot run here — see oracle/quatro_oracle.cpp header).  They pin the oracle against
+"""Generates the committed fixtures under tests/golden/: matcher_ref.npz from the REFERENCE's own teaser::Matcher
+(compiled from /root/reference by oracle/Makefile, target `ref`), the others from the CPU oracle (the reference has no
+golden vectors and its other stages cannot run here — see oracle/quatro_oracle.cpp header).  They pin the oracle against
 accidental drift and give the GPU tests inputs/outputs that do not depend on the oracle being rebuilt.
 
     python tests/golden/make_golden.py
@@ -44,6 +45,21 @@ def main():
     corr, nn_ij, nn_ji = qo.match(a, da, b, db, seed=5, debug=True)
     np.savez_compressed(os.path.join(HERE, "matcher_small.npz"), xyz_s=a, desc_s=da, xyz_t=b, desc_t=db, corr=corr,
                         nn_large_of_small=nn_ij, nn_small_of_large=nn_ji, seed=5)
+    # --- the REFERENCE's own matcher (oracle/_ref, compiled from /root/reference): outputs the repository's code did not
+    # produce.  Cases: source larger / smaller (the swap), cross-check off, tuple test off.
+    if qo.build_ref():
+        v3 = qo.voxelize(synth.kitti64_pair(3)[0], 0.4)
+        v4 = qo.voxelize(synth.kitti64_pair(3)[1], 0.4)
+        a2, b2 = v3[:1400].copy(), v4[:1100].copy()
+        _, _, da2 = qo.fpfh(a2, 0.6, 0.9)
+        _, _, db2 = qo.fpfh(b2, 0.6, 0.9)
+        out = {"xyz_a": a2, "desc_a": da2, "xyz_b": b2, "desc_b": db2}
+        for name, (x1, d1, x2, d2, cross, tup, seed) in {
+                "ab": (a2, da2, b2, db2, True, True, 11), "ba": (b2, db2, a2, da2, True, True, 12),
+                "ab_nocross": (a2, da2, b2, db2, False, True, 13), "ba_nocross_notuple": (b2, db2, a2, da2, False, False, 14),
+                "ab_notuple": (a2, da2, b2, db2, True, False, 15)}.items():
+            out["corr_" + name] = qo.ref_match(x1, d1, x2, d2, crosscheck=cross, tuple_test=tup, seed=seed)
+        np.savez_compressed(os.path.join(HERE, "matcher_ref.npz"), **out)
     print("golden fixtures written to", HERE)
 
 

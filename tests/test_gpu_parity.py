@@ -200,6 +200,17 @@ def test_match_matches_oracle(hip, qo, small_pair):
         assert np.array_equal(nt, qo.match(a, da, b, db, tuple_test=False))
 
 
+@pytest.mark.parametrize("name,order,tup,seed", [("ab", "ab", 1, 11), ("ba", "ba", 1, 12), ("ab_notuple", "ab", 0, 15)])
+def test_match_equals_reference_generated_golden(hip, name, order, tup, seed):
+    """tests/golden/matcher_ref.npz: what the REFERENCE's own teaser::Matcher (compiled from /root/reference, oracle/
+    Makefile target `ref`) returned for these inputs — the HIP matcher has to return the same lists."""
+    g = np.load(os.path.join(G, "matcher_ref.npz"))
+    s_, t_ = order[0], order[1]
+    corr = hip.match(g["xyz_" + s_], g["desc_" + s_], g["xyz_" + t_], g["desc_" + t_],
+                     ql.default_frontend_params(seed=seed, use_tuple_test=tup))
+    assert np.array_equal(corr, g["corr_" + name])
+
+
 def test_match_fixture(hip):
     g = np.load(os.path.join(G, "matcher_small.npz"))
     corr = hip.match(g["xyz_s"], g["desc_s"], g["xyz_t"], g["desc_t"], ql.default_frontend_params(seed=int(g["seed"])))
