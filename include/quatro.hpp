@@ -459,7 +459,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       for (int c = 0; c < M; ++c) (*inliers)(0, c) = inl[static_cast<size_t>(c)] != 0;
   }
 
-  // solveForTranslation :574-615, estimate :618-747 (uniform ranges, as every call site of the class passes)
+  // solveForTranslation :574-615, estimate :618-747
   Eigen::Vector3d solveForTranslation(const Eigen::Matrix<double, 3, Eigen::Dynamic>& v1,
                                       const Eigen::Matrix<double, 3, Eigen::Dynamic>& v2,
                                       bool using_median_selection = false) {
@@ -489,18 +489,24 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
                 Eigen::Matrix<bool, 1, Eigen::Dynamic>* inliers, bool using_median_selection = false) {
     const int N = static_cast<int>(X.cols());
     if (ranges.cols() != N || N < 2) throw std::invalid_argument("[estimate] dimension mismatch or a single element");
-    for (int c = 1; c < N; ++c)
-      if (ranges(0, c) != ranges(0, 0))
-        throw std::invalid_argument("[estimate] non-uniform ranges are not supported by the device path");
-    std::vector<double> x(static_cast<size_t>(N));
-    for (int c = 0; c < N; ++c) x[static_cast<size_t>(c)] = X(0, c);
+    bool uniform = true;
+    for (int c = 1; c < N; ++c) uniform = uniform && (ranges(0, c) == ranges(0, 0));
+    std::vector<double> x(static_cast<size_t>(N)), r(static_cast<size_t>(N));
+    for (int c = 0; c < N; ++c) {
+      x[static_cast<size_t>(c)] = X(0, c);
+      r[static_cast<size_t>(c)] = ranges(0, c);
+    }
     std::vector<unsigned char> inl(static_cast<size_t>(N));
     double e = 0;
     int ncard = 0;
     qtr_handle* h = quatro_hip::default_handle();
     std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_cote_estimate(h, 0, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e, inl.data(),
-                                           &ncard));
+    if (uniform)
+      quatro_hip::check(h, qtr_cote_estimate(h, 0, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e,
+                                             inl.data(), &ncard));
+    else
+      quatro_hip::check(h, qtr_cote_estimate_ranges(h, 0, x.data(), r.data(), N, using_median_selection ? 1 : 0, &e,
+                                                    inl.data(), &ncard));
     if (estimate_out) *estimate_out = e;
     if (inliers) {
       inliers->resize(1, N);

@@ -192,6 +192,9 @@ int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const doubl
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
+/* the same with one range per element (estimate() takes a RowVectorXd of ranges, include/quatro.hpp:618-630) */
+int qtr_cote_estimate_ranges(qtr_handle* h, int slot, const double* X, const double* ranges, int N, int median_selection,
+                             double* estimate, unsigned char* inliers /* N */, int* n_card);
 
 /* PMC_EXACT only: Params::max_clique_time_limit (include/quatro.hpp:267, default 3600 s; <= 0 = none).  When the limit
  * is hit the heuristic's clique is returned (the reference returns PMC's best so far) and qtr_exact_stats reports it. */

@@ -303,6 +303,17 @@ def cote_estimate(X, rng, median=True):
     return e, inl.astype(bool), nc.value
 
 
+def cote_estimate_ranges(X, ranges, median=True):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    R = np.ascontiguousarray(ranges, dtype=np.float64)
+    inl = np.zeros(X.shape[0], dtype=np.uint8)
+    nc = C.c_int()
+    lib().qo_cote_estimate_ranges.restype = C.c_double
+    e = lib().qo_cote_estimate_ranges(_p(X, C.c_double), _p(R, C.c_double), X.shape[0], int(median), _p(inl, C.c_ubyte),
+                                      C.byref(nc))
+    return e, inl.astype(bool), nc.value
+
+
 class PwParams(C.Structure):
     _fields_ = [("sensor_height", C.c_double), ("num_iter", C.c_int), ("num_lpr", C.c_int), ("num_min_pts", C.c_int),
                 ("th_seeds", C.c_double), ("th_dist", C.c_double), ("max_range", C.c_double), ("min_range", C.c_double),

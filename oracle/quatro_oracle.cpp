@@ -1051,8 +1051,9 @@ void gnc_rotation3d(const double* src3, const double* dst3, int M, double noise_
 // include/quatro.hpp:618-747): adaptive-voting sweep over 2N interval endpoints.  Sort is stable by
 // (value, insertion position) (D3); median of the last n_card sweep members (quirk kept), n_card<=1
 // defined (D4).
-double cote_estimate(const std::vector<double>& X, double range, bool median_sel, std::vector<char>& inl,
-                     int* n_card_out) {
+// R: one range per element (estimate() takes a vector of ranges; the class itself only ever passes equal ones)
+double cote_estimate_ranges(const std::vector<double>& X, const std::vector<double>& R, bool median_sel,
+                            std::vector<char>& inl, int* n_card_out) {
   const int N = (int)X.size();
   struct Ev {
     double v;
@@ -1061,21 +1062,22 @@ double cote_estimate(const std::vector<double>& X, double range, bool median_sel
   };
   std::vector<Ev> h((size_t)(2 * N));
   for (int i = 0; i < N; ++i) {
-    h[2 * i] = Ev{X[i] - range, i + 1, 2 * i};
-    h[2 * i + 1] = Ev{X[i] + range, -i - 1, 2 * i + 1};
+    h[2 * i] = Ev{X[i] - R[i], i + 1, 2 * i};
+    h[2 * i + 1] = Ev{X[i] + R[i], -i - 1, 2 * i + 1};
   }
   std::sort(h.begin(), h.end(), [](const Ev& a, const Ev& b) { return a.v < b.v || (a.v == b.v && a.pos < b.pos); });
-  const double weight = 1.0 / (range * range);  // weights = ranges.square().inverse()
   const int nc = 2 * N;
   std::vector<double> x_hat((size_t)nc), x_cost((size_t)nc);
   std::vector<int> card((size_t)nc);
-  double ranges_inverse_sum = 0;  // ranges.sum(): sequential add of N equal values
-  for (int i = 0; i < N; ++i) ranges_inverse_sum += range;
+  double ranges_inverse_sum = 0;  // ranges.sum(): sequential add (Eigen's packet order for unequal ranges is not restated)
+  for (int i = 0; i < N; ++i) ranges_inverse_sum += R[i];
   double dot_X_weights = 0, dot_weights_consensus = 0, sum_xi = 0, sum_xi_square = 0;
   int consensus = 0;
   for (int i = 0; i < nc; ++i) {
     const int idx = std::abs(h[i].id) - 1;
     const int eps = h[i].id > 0 ? 1 : -1;
+    const double range = R[idx];
+    const double weight = 1.0 / (range * range);  // weights = ranges.square().inverse()
     consensus += eps;
     dot_weights_consensus += eps * weight;
     dot_X_weights += eps * weight * X[idx];
@@ -1104,8 +1106,12 @@ double cote_estimate(const std::vector<double>& X, double range, bool median_sel
     }
   }
   inl.resize((size_t)N);
-  for (int i = 0; i < N; ++i) inl[i] = fabs(X[i] - est) <= range;
+  for (int i = 0; i < N; ++i) inl[i] = fabs(X[i] - est) <= R[i];
   return est;
+}
+double cote_estimate(const std::vector<double>& X, double range, bool median_sel, std::vector<char>& inl,
+                     int* n_card_out) {
+  return cote_estimate_ranges(X, std::vector<double>(X.size(), range), median_sel, inl, n_card_out);
 }
 
 }  // namespace
@@ -1698,6 +1704,15 @@ double qo_cote_estimate(const double* X, int N, double range, int median_sel, un
   std::vector<double> x(X, X + N);
   std::vector<char> inl;
   const double e = cote_estimate(x, range, median_sel != 0, inl, n_card);
+  for (int i = 0; i < N; ++i) inliers[i] = (unsigned char)inl[i];
+  return e;
+}
+
+double qo_cote_estimate_ranges(const double* X, const double* R, int N, int median_sel, unsigned char* inliers,
+                               int* n_card) {
+  std::vector<double> x(X, X + N), r(R, R + N);
+  std::vector<char> inl;
+  const double e = cote_estimate_ranges(x, r, median_sel != 0, inl, n_card);
   for (int i = 0; i < N; ++i) inliers[i] = (unsigned char)inl[i];
   return e;
 }

@@ -688,20 +688,23 @@ int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const doubl
   return QTR_OK;
 }
 
-int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range, int median_selection,
-                      double* estimate, unsigned char* inliers, int* n_card) {
+static int cote_impl(qtr_handle* h, int slot, const double* X, const double* ranges, int N, double range,
+                     int median_selection, double* estimate, unsigned char* inliers, int* n_card) {
   Slot* sp = get_slot(h, slot);
-  if (!sp || N < 1 || !X || !(range > 0)) return QTR_ERR_BAD_ARG;
+  if (!sp || N < 1 || !X) return QTR_ERR_BAD_ARG;
   Slot& s = *sp;
-  if (!stage_fits(h, s, (size_t)15 * N + 8, (size_t)2 * N + (size_t)(N + 3) / 4)) return QTR_ERR_CAPACITY;
+  if (!stage_fits(h, s, (size_t)16 * N + 8, (size_t)2 * N + (size_t)(N + 3) / 4)) return QTR_ERR_CAPACITY;
   QTR_HIP_TRY(h, hipSetDevice(h->device));
   double* d_x = s.sb.f64;
-  double* d_f = d_x + (size_t)N;
+  double* d_r = d_x + (size_t)N;
+  double* d_f = d_r + (size_t)N;
   double* d_o = d_f + (size_t)14 * N;
   int* d_si = s.sb.i32;
   unsigned char* d_i = (unsigned char*)(d_si + (size_t)2 * N);
   QTR_HIP_TRY(h, hipMemcpyAsync(d_x, X, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, s.stream));
-  hipLaunchKernelGGL(k_cote_only, dim3(1), dim3(256), 0, s.stream, d_x, N, range, median_selection ? 1 : 0, d_f, d_si, d_o, d_i);
+  if (ranges) QTR_HIP_TRY(h, hipMemcpyAsync(d_r, ranges, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, s.stream));
+  hipLaunchKernelGGL(k_cote_only, dim3(1), dim3(256), 0, s.stream, d_x, N, range, ranges ? d_r : (const double*)nullptr,
+                     median_selection ? 1 : 0, d_f, d_si, d_o, d_i);
   QTR_HIP_TRY(h, hipGetLastError());
   double out[2];
   QTR_HIP_TRY(h, hipMemcpyAsync(out, d_o, sizeof(out), hipMemcpyDeviceToHost, s.stream));
@@ -710,6 +713,20 @@ int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double ra
   if (estimate) *estimate = out[0];
   if (n_card) *n_card = (int)out[1];
   return QTR_OK;
+}
+
+int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range, int median_selection,
+                      double* estimate, unsigned char* inliers, int* n_card) {
+  if (!(range > 0)) return QTR_ERR_BAD_ARG;
+  return cote_impl(h, slot, X, nullptr, N, range, median_selection, estimate, inliers, n_card);
+}
+
+int qtr_cote_estimate_ranges(qtr_handle* h, int slot, const double* X, const double* ranges, int N, int median_selection,
+                             double* estimate, unsigned char* inliers, int* n_card) {
+  if (!ranges || N < 1) return QTR_ERR_BAD_ARG;
+  for (int i = 0; i < N; ++i)
+    if (!(ranges[i] > 0)) return QTR_ERR_BAD_ARG;
+  return cote_impl(h, slot, X, ranges, N, ranges[0], median_selection, estimate, inliers, n_card);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1072,10 +1089,6 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   s.last_nt = n_t;
   if (n_s == 0 || n_t == 0) return QTR_OK;
   if (!xyz4_s || !xyz4_t || !desc33_s || !desc33_t || !corr2) return QTR_ERR_BAD_ARG;
-  if (!fp->use_crosscheck) {  // the reference's only call site passes true (include/fpfh_manager.hpp:126-127)
-    snprintf(h->err, sizeof(h->err), "use_crosscheck = 0 is not supported (the one-directional pair list is a 'next' row)");
-    return QTR_ERR_UNSUPPORTED;
-  }
   if (n_s > h->lim.max_voxels || n_t > h->lim.max_voxels) {
     snprintf(h->err, sizeof(h->err), "cloud size exceeds max_voxels=%d", h->lim.max_voxels);
     return QTR_ERR_CAPACITY;

@@ -124,6 +124,8 @@ struct MatchView {
   int* mail;                   // host mailbox of the pair's slot (or null)
   const int *counts0, *counts1;
   int seq;
+  int *nc_cnt, *nc_fill, *nc_off, *nc_list;  // use_crosscheck = 0: per-source counts, fill cursors, offsets, targets
+  int crosscheck;              // 0: corres_ij + corres_ji go to the tuple test unfiltered (feature_matcher.cc:146-181)
   int tuple;                   // 1: run the tuple test
   float tuple_scale;
   u64 seed;
@@ -155,6 +157,7 @@ struct FrontBufs {
   float* queryT_c = nullptr;   // [34][max_voxels_pad]
   float* norms_c = nullptr;    // [max_voxels_pad]
   int dd_slots = 0;            // slots of each cloud's dedup table (power of two >= 2 * max_voxels)
+  int *nc_cnt = nullptr, *nc_fill = nullptr, *nc_off = nullptr, *nc_list = nullptr;  // cross-check off: per-source target lists
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
   float4* m_src = nullptr;     // where the matcher's last kernel should leave the matched keypoint clouds (or null)
   float4* m_tgt = nullptr;

@@ -1253,6 +1253,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
   per_cloud += (size_t)max_points * 16 + 256;                // raw_sorted
   size_t shared = (size_t)max_voxels * 64 + 16384;
+  shared += (size_t)max_voxels * (4 + 4 + 4 + 8) + (size_t)max_voxels * 4 * 6 + 4096;  // doubled pair lists + nc_* (cross-check off)
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
   per_cloud += (size_t)max_voxels * 8 + (size_t)dedup_slots(max_voxels) * 8 + 512;  // dd_hash, dd_table
@@ -1302,13 +1303,17 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.best_large = (u64*)take((size_t)max_voxels * 8);
   F.nn_of_small = (int*)take((size_t)max_voxels * 4);
   F.nn_of_large = (int*)take((size_t)max_voxels * 4);
-  F.cross_i = (int*)take((size_t)max_voxels * 4);
-  F.cross_j = (int*)take((size_t)max_voxels * 4);
+  F.cross_i = (int*)take((size_t)max_voxels * 8);  // 2 x max_voxels: without the cross-check the list is corres_ij + corres_ji
+  F.cross_j = (int*)take((size_t)max_voxels * 8);
   F.flags = (int*)take((size_t)max_voxels * 4);
   F.scan = (int*)take((size_t)(max_voxels + 1) * 4);
-  F.passed = (int*)take((size_t)max_voxels * 4);
+  F.passed = (int*)take((size_t)max_voxels * 8);
   F.tgt_of_src = (int*)take((size_t)max_voxels * 4);
-  F.corr = (int*)take((size_t)max_voxels * 8);
+  F.corr = (int*)take((size_t)max_voxels * 16);
+  F.nc_cnt = (int*)take((size_t)max_voxels * 4);
+  F.nc_fill = (int*)take((size_t)max_voxels * 4);
+  F.nc_off = (int*)take((size_t)(max_voxels + 1) * 4);
+  F.nc_list = (int*)take((size_t)max_voxels * 8);
   F.mcounts = (int*)take(16 * 4);
   F.nn_partial = take((((size_t)max_voxels + 511) / 512 * 512) * 32 * 16);
   F.recheck_rows = (int*)take((size_t)max_voxels * 4);

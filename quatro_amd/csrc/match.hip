@@ -538,7 +538,10 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
   const int pv = V.tuple ? 0 : 1;
-  for (int i = gid; i < V.n_small; i += gsz) V.passed[i] = pv;
+  const int np = V.crosscheck ? V.n_small : V.n_small + V.n_large;
+  for (int i = gid; i < np; i += gsz) V.passed[i] = pv;
+  if (!V.crosscheck)
+    for (int i = gid; i < V.ns; i += gsz) V.nc_cnt[i] = V.nc_fill[i] = 0;
   for (int i = gid; i < V.ns; i += gsz) V.tgt_of_src[i] = -1;
   for (int i = gid; i < V.n_small; i += gsz) V.best_small[i] = ~0ULL;
   for (int i = gid; i < V.n_large; i += gsz) V.best_large[i] = ~0ULL;
@@ -759,6 +762,93 @@ __global__ void k_scatter_pairs(ViewExt<MatchView> x, MatchView one) {
   if (qk_lane() == 0 && local) atomicAdd(&V.mcounts[MC_NTUPLE], local);
 }
 
+// ---- use_crosscheck = 0 (reference feature_matcher.cc:124-181: "Skipping Cross Check"): the list handed to the tuple
+// test is corres_ij (every hit row i of the larger cloud with ITS nearest neighbour, ascending i) followed by corres_ji
+// (every row j of the smaller cloud with its nearest neighbour, ascending j); the survivors are un-swapped, sorted and
+// made unique.  A source index can now carry several targets, so the tail builds per-source target lists instead of
+// the one-target-per-source table of the cross-checked path.  Single pair only (the batched path keeps the cross-check).
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nc_list(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int nhit = V.mcounts[MC_NHIT], n = nhit + V.n_small;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    if (e < nhit) {
+      const int i = V.hit_rows[e];
+      V.cross_i[e] = i;
+      V.cross_j[e] = V.nn_of_large[i];
+    } else {
+      const int j = e - nhit;
+      V.cross_i[e] = V.nn_of_small[j];
+      V.cross_j[e] = j;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) V.mcounts[MC_NCROSS] = n;
+}
+// pass 0: count the survivors of every source index; pass 1: drop their targets into the source's slice
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nc_scatter(ViewExt<MatchView> x, MatchView one, int pass) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int nc = V.mcounts[MC_NCROSS], swapped = V.swapped;
+  int local = 0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    if (!V.passed[c]) continue;
+    const int i = V.cross_i[c], j = V.cross_j[c];
+    const int s = swapped ? j : i, t = swapped ? i : j;
+    if (pass == 0) {
+      atomicAdd(&V.nc_cnt[s], 1);
+      ++local;
+    } else {
+      V.nc_list[V.nc_off[s] + atomicAdd(&V.nc_fill[s], 1)] = t;
+    }
+  }
+  if (pass == 0) {
+    local = wave_sum_i32(local);
+    if (qk_lane() == 0 && local) atomicAdd(&V.mcounts[MC_NTUPLE], local);
+  }
+}
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_nc_scan(ViewExt<MatchView> x, MatchView one, int which) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  d_block_scan(which == 0 ? V.nc_cnt : V.nc_fill, which == 0 ? V.nc_off : V.scan, V.ns, [](int v) { return v; });
+}
+// every source sorts its (short) target list, drops repeats and leaves the distinct count in nc_fill
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nc_unique(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < V.ns; s += gridDim.x * blockDim.x) {
+    int* l = V.nc_list + V.nc_off[s];
+    const int k = V.nc_cnt[s];
+    for (int a = 1; a < k; ++a) {  // insertion sort: lists are a handful of entries
+      const int v = l[a];
+      int b = a - 1;
+      while (b >= 0 && l[b] > v) {
+        l[b + 1] = l[b];
+        --b;
+      }
+      l[b + 1] = v;
+    }
+    int u = 0;
+    for (int a = 0; a < k; ++a)
+      if (a == 0 || l[a] != l[a - 1]) l[u++] = l[a];
+    V.nc_fill[s] = u;
+  }
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_nc_emit(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int ns = V.ns;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    const int u = V.nc_fill[s], o = V.scan[s];
+    const int* l = V.nc_list + V.nc_off[s];
+    for (int a = 0; a < u; ++a) {
+      V.corr[2 * (o + a)] = s;
+      V.corr[2 * (o + a) + 1] = l[a];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) V.mcounts[MC_NCORR] = V.scan[ns];
+  if (V.mail && blockIdx.x == 0 && threadIdx.x < 48) match_mail(V, threadIdx.x, V.scan[ns], V.mcounts[MC_NTUPLE]);
+}
+
 // ---- fused tails for clouds of up to 16384 points: one workgroup of 1024 threads per pair, every thread owning one
 // contiguous run of at most 16 indices, so flag -> exclusive scan -> compaction happens in registers and LDS
 // without the three-launch (flags, scan, compact) round trips.
@@ -960,6 +1050,11 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.counts0 = F.cloud[0].counts;
   V.counts1 = F.cloud[1].counts;
   V.seq = F.mail_seq;
+  V.nc_cnt = F.nc_cnt;
+  V.nc_fill = F.nc_fill;
+  V.nc_off = F.nc_off;
+  V.nc_list = F.nc_list;
+  V.crosscheck = fp.use_crosscheck ? 1 : 0;
   V.tuple = (fp.use_tuple_test && fp.tuple_scale != 0) ? 1 : 0;
   V.tuple_scale = fp.tuple_scale;
   V.seed = seed;
@@ -1060,8 +1155,12 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     run_dir(1, max_large, max_small, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
-  const bool fused_tail = max_large <= 16384 && max_ns <= 16384;
-  if (fused_tail) {
+  const bool crosscheck = views[0].crosscheck != 0;
+  const bool fused_tail = crosscheck && max_large <= 16384 && max_ns <= 16384;
+  if (!crosscheck) {  // single pair (qtr_submit_batch refuses it): the unfiltered list, see k_nc_list
+    LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
+    LAUNCH_MV(k_nc_list, a, dim3(grid_for(max_large + max_small), 1, G), B256, 0, st);
+  } else if (fused_tail) {
     LAUNCH_MV(k_cross_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
   } else {
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
@@ -1071,7 +1170,15 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   // K7 tuple test
   if (any_tuple) LAUNCH_MV(k_tuple, a, dim3(G > 1 ? 256 : 2048, 1, G), B256, 0, st);
   // K8 un-swap, sort by (src, tgt), unique  ==  compaction in source-index order
-  if (fused_tail) {
+  if (!crosscheck) {
+    const int gl = grid_for(max_large + max_small), gs = grid_for(max_ns);
+    LAUNCH_MV(k_nc_scatter, a, dim3(gl, 1, G), B256, 0, st, 0);
+    LAUNCH_MV(k_nc_scan, a, dim3(1, 1, G), dim3(1024), 0, st, 0);
+    LAUNCH_MV(k_nc_scatter, a, dim3(gl, 1, G), B256, 0, st, 1);
+    LAUNCH_MV(k_nc_unique, a, dim3(gs, 1, G), B256, 0, st);
+    LAUNCH_MV(k_nc_scan, a, dim3(1, 1, G), dim3(1024), 0, st, 1);
+    LAUNCH_MV(k_nc_emit, a, dim3(gs, 1, G), B256, 0, st);
+  } else if (fused_tail) {
     LAUNCH_MV(k_pairs_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
   } else {
     LAUNCH_MV(k_scatter_pairs, a, dim3(grid_for(max_small), 1, G), B256, 0, st);
@@ -1084,7 +1191,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
   (void)hipGetLastError();
   const MatchView V = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
-  const bool fused_tail = V.n_large <= 16384 && ns <= 16384;
+  const bool fused_tail = V.crosscheck && V.n_large <= 16384 && ns <= 16384;
   F.gathered = fused_tail && F.m_src != nullptr;
   const bool evs = F.nn_events != 0;
   return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr);

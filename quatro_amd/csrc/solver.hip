@@ -947,7 +947,8 @@ struct CoteOut {
   int ncard;
 };
 __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __restrict__ X, int N, int nc,
-                                              double range, int median_sel, double* sxv, int* spos,
+                                              double range, const double* __restrict__ R /* per-element ranges, or null */,
+                                              int median_sel, double* sxv, int* spos,
                                               double* T /* 6 arrays of nc; first holds the sort keys/positions */,
                                               double* s_bcast /* [4] per axis */, double* s_redc /* [4] */,
                                               int* s_redi /* [4] */, int* dbg) {
@@ -966,7 +967,8 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
   int* epos = (int*)(T + n2);
   if (act)
     for (int i = tl; i < n2; i += 256) {
-      ekey[i] = (i < nc) ? ((i & 1) ? X[i >> 1] + range : X[i >> 1] - range) : INFINITY;
+      const double ri = (R && i < nc) ? R[i >> 1] : range;
+      ekey[i] = (i < nc) ? ((i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri) : INFINITY;
       epos[i] = i;
     }
   for (int k = 2; k <= n2; k <<= 1) {
@@ -999,19 +1001,21 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
   COTE_TICK(0)
   if (act && tl == 64) {  // sum of N ranges in the reference's order (:660), off the serial wave
     double r = 0;
-    for (int i = 0; i < N; ++i) r += range;
+    for (int i = 0; i < N; ++i) r += R ? R[i] : range;
     s_bcast[2] = r;
   }
   __syncthreads();
   // ---- 3. per-event terms (sort keys are dead: T takes their place)
   if (act) {
-    const double weight = 1.0 / (range * range);
+    const double weight_u = 1.0 / (range * range);
     for (int i = tl; i < nc; i += 256) {
       const int eps = (spos[i] & 1) ? -1 : 1;
       const double xv = sxv[i];
+      const double rv = R ? R[spos[i] >> 1] : range;
+      const double weight = R ? 1.0 / (rv * rv) : weight_u;  // weights = ranges.square().inverse()
       T[i] = eps * weight;
       T[(size_t)nc + i] = eps * weight * xv;
-      T[2 * (size_t)nc + i] = -(eps * range);
+      T[2 * (size_t)nc + i] = -(eps * rv);
       T[3 * (size_t)nc + i] = eps * xv;
       T[4 * (size_t)nc + i] = eps * xv * xv;
       T[5 * (size_t)nc + i] = (double)eps;
@@ -1427,12 +1431,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   CoteOut co;
   if (3 * a_total <= (size_t)FIN_LDS_BYTES) {
     char* base = (char*)fin_lds + (size_t)axc * a_total;  // LDS: pointers derive from the shared array
-    co = cote_axis4(act, tl, X, N, nc, range, prm.cote_median, (double*)base, (int*)(base + a_spos),
+    co = cote_axis4(act, tl, X, N, nc, range, nullptr, prm.cote_median, (double*)base, (int*)(base + a_spos),
                     (double*)(base + a_T), s_bc[axc], s_redc[axc], s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   } else {
     double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
     int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
-    co = cote_axis4(act, tl, X, N, nc, range, prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
+    co = cote_axis4(act, tl, X, N, nc, range, nullptr, prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
                     s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
   }
   if (act && tl == 0) {

@@ -80,17 +80,20 @@ __global__ __launch_bounds__(64) void k_gnc3d_only(const double* __restrict__ sr
   }
 }
 
-// COTE on one group of four wavefronts (uniform range).  scratch: 14*N doubles + 2*N ints of global memory.
-__global__ __launch_bounds__(256) void k_cote_only(const double* __restrict__ X, int N, double range, int median_sel,
+// COTE on one group of four wavefronts.  R: per-element ranges (Quatro::estimate accepts any, reference
+// include/quatro.hpp:618-747) or null for the uniform `range` the class itself passes.  scratch: 14*N doubles + 2*N ints
+// of global memory.
+__global__ __launch_bounds__(256) void k_cote_only(const double* __restrict__ X, int N, double range,
+                                                   const double* __restrict__ R, int median_sel,
                                                    double* __restrict__ scratch_f, int* __restrict__ scratch_i,
                                                    double* __restrict__ out, unsigned char* __restrict__ inl) {
   __shared__ double s_bc[4], s_redc[4];
   __shared__ int s_redi[4];
   const int nc = 2 * N;
-  const CoteOut co = cote_axis4(true, (int)threadIdx.x, X, N, nc, range, median_sel, scratch_f, scratch_i,
+  const CoteOut co = cote_axis4(true, (int)threadIdx.x, X, N, nc, range, R, median_sel, scratch_f, scratch_i,
                                 scratch_f + 2 * (size_t)N, s_bc, s_redc, s_redi, nullptr);
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += 256) inl[i] = (fabs(X[i] - co.est) <= range) ? 1 : 0;  // reference :741-744
+  for (int i = threadIdx.x; i < N; i += 256) inl[i] = (fabs(X[i] - co.est) <= (R ? R[i] : range)) ? 1 : 0;  // :741-744
   if (threadIdx.x == 0) {
     out[0] = co.est;
     out[1] = (double)co.ncard;

@@ -83,7 +83,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait",
 ]
 
 _lib = None
@@ -190,6 +190,8 @@ def load():
     lib.qtr_gnc_rotation3d.argtypes = lib.qtr_gnc_rotation2d.argtypes
     lib.qtr_cote_estimate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+    lib.qtr_cote_estimate_ranges.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
     lib.qtr_set_clique_time_limit.argtypes = [C.c_void_p, C.c_double]
     lib.qtr_set_clique_time_limit.restype = None
     lib.qtr_exact_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -319,7 +321,8 @@ class Handle:
         desc_s = np.ascontiguousarray(desc_s, dtype=np.float32)
         desc_t = np.ascontiguousarray(desc_t, dtype=np.float32)
         fp = fp or default_frontend_params()
-        cap = max(min(xyz_s.shape[0], xyz_t.shape[0]), 1)
+        # cross-checked lists hold at most min(n_s, n_t) pairs; without the cross-check up to n_s + n_t
+        cap = max(min(xyz_s.shape[0], xyz_t.shape[0]) if fp.use_crosscheck else xyz_s.shape[0] + xyz_t.shape[0], 1)
         corr = np.zeros((cap, 2), dtype=np.int32)
         L = C.c_int()
         self._check(self._lib.qtr_match(self._h, slot, xyz_s.ctypes.data, xyz_s.shape[0], desc_s.ctypes.data,
@@ -441,6 +444,15 @@ class Handle:
         est, nc = C.c_double(), C.c_int()
         self._check(self._lib.qtr_cote_estimate(self._h, slot, X.ctypes.data, X.shape[0], rng, 1 if median else 0,
                                                 C.byref(est), inl.ctypes.data, C.byref(nc)))
+        return est.value, inl.astype(bool), nc.value
+
+    def cote_estimate_ranges(self, X, ranges, median: bool = True, slot: int = 0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        R = np.ascontiguousarray(ranges, dtype=np.float64)
+        inl = np.zeros(X.shape[0], dtype=np.uint8)
+        est, nc = C.c_double(), C.c_int()
+        self._check(self._lib.qtr_cote_estimate_ranges(self._h, slot, X.ctypes.data, R.ctypes.data, X.shape[0],
+                                                       1 if median else 0, C.byref(est), inl.ctypes.data, C.byref(nc)))
         return est.value, inl.astype(bool), nc.value
 
     def register_pair(self, src_raw4, tgt_raw4, fp: FrontendParams | None = None, params: Params | None = None,

@@ -198,16 +198,22 @@ def test_match_matches_oracle(hip, qo, small_pair):
         assert np.array_equal(corr_g, corr_o)
         nt = hip.match(a, da, b, db, ql.default_frontend_params(seed=seed, use_tuple_test=0))
         assert np.array_equal(nt, qo.match(a, da, b, db, tuple_test=False))
+        # use_crosscheck = false (reference feature_matcher.cc:146-181): corres_ij + corres_ji, with and without tuple test
+        for tup in (1, 0):
+            nc = hip.match(a, da, b, db, ql.default_frontend_params(seed=seed, use_crosscheck=0, use_tuple_test=tup))
+            assert np.array_equal(nc, qo.match(a, da, b, db, crosscheck=False, tuple_test=bool(tup), seed=seed))
 
 
-@pytest.mark.parametrize("name,order,tup,seed", [("ab", "ab", 1, 11), ("ba", "ba", 1, 12), ("ab_notuple", "ab", 0, 15)])
-def test_match_equals_reference_generated_golden(hip, name, order, tup, seed):
+@pytest.mark.parametrize("name,order,cross,tup,seed", [("ab", "ab", 1, 1, 11), ("ba", "ba", 1, 1, 12),
+                                                       ("ab_notuple", "ab", 1, 0, 15), ("ab_nocross", "ab", 0, 1, 13),
+                                                       ("ba_nocross_notuple", "ba", 0, 0, 14)])
+def test_match_equals_reference_generated_golden(hip, name, order, cross, tup, seed):
     """tests/golden/matcher_ref.npz: what the REFERENCE's own teaser::Matcher (compiled from /root/reference, oracle/
     Makefile target `ref`) returned for these inputs — the HIP matcher has to return the same lists."""
     g = np.load(os.path.join(G, "matcher_ref.npz"))
     s_, t_ = order[0], order[1]
     corr = hip.match(g["xyz_" + s_], g["desc_" + s_], g["xyz_" + t_], g["desc_" + t_],
-                     ql.default_frontend_params(seed=seed, use_tuple_test=tup))
+                     ql.default_frontend_params(seed=seed, use_tuple_test=tup, use_crosscheck=cross))
     assert np.array_equal(corr, g["corr_" + name])
 
 
@@ -589,6 +595,10 @@ def test_stage_entry_points_match_oracle_and_numpy(hip, qo):
             eo, mo, no = qo.cote_estimate(X, 0.3, median)
             eg, mg, ng = hip.cote_estimate(X, 0.3, median)
             assert eg == eo and ng == no and np.array_equal(mg, mo), (Nn, median)
+            R = g.uniform(0.05, 0.6, Nn)  # one range per element (include/quatro.hpp:618-630 takes a vector)
+            eo, mo, no = qo.cote_estimate_ranges(X, R, median)
+            eg, mg, ng = hip.cote_estimate_ranges(X, R, median)
+            assert eg == eo and ng == no and np.array_equal(mg, mo), (Nn, median, "ranges")
 
 
 def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):

@@ -691,28 +691,29 @@ def test_gnc_rotation3d_recovers_rotation_and_flags_outliers(qo):
 
 def _ref_cote_python(X, r, median):
     """Quatro::estimate (reference include/quatro.hpp:618-747) written again, directly from the reference text, as plain
-    Python floats (IEEE binary64, the same operation order); uniform ranges; std::sort's unspecified order among equal
-    keys taken as insertion order (the oracle's definition)."""
+    Python floats (IEEE binary64, the same operation order); r: one range or one per element; std::sort's unspecified
+    order among equal keys taken as insertion order (the oracle's definition); ranges.sum() taken sequentially."""
     N = len(X)
+    R = [float(r)] * N if np.isscalar(r) else [float(v) for v in r]
     h = []
     for i in range(N):
-        h.append((X[i] - r, i + 1))
-        h.append((X[i] + r, -i - 1))
+        h.append((X[i] - R[i], i + 1))
+        h.append((X[i] + R[i], -i - 1))
     h.sort(key=lambda e: e[0])  # stable
-    w = 1.0 / (r * r)
     ranges_inverse_sum = 0.0
-    for _ in range(N):
-        ranges_inverse_sum += r
+    for i in range(N):
+        ranges_inverse_sum += R[i]
     dot_X_weights = dot_weights_consensus = sum_xi = sum_xi_square = 0.0
     card = 0
     x_hat, x_cost, set_card = [], [], []
     for key, tag in h:
         idx = abs(tag) - 1
         eps = 1 if tag > 0 else -1
+        w = 1.0 / (R[idx] * R[idx])
         card += eps
         dot_weights_consensus += eps * w
         dot_X_weights += eps * w * X[idx]
-        ranges_inverse_sum -= eps * r
+        ranges_inverse_sum -= eps * R[idx]
         sum_xi += eps * X[idx]
         sum_xi_square += eps * X[idx] * X[idx]
         set_card.append(card)
@@ -726,7 +727,7 @@ def _ref_cote_python(X, r, median):
         est = (cand[len(cand) // 2 - 1] + cand[len(cand) // 2]) / 2.0 if n_card >= 2 else (cand[0] if n_card == 1 else x_hat[mi])
     else:
         est = x_hat[mi]
-    return est, n_card, [abs(x - est) <= r for x in X]
+    return est, n_card, [abs(x - est) <= ri for x, ri in zip(X, R)]
 
 
 def test_cote_against_a_second_restatement_of_the_reference(qo):
@@ -749,6 +750,14 @@ def test_cote_against_a_second_restatement_of_the_reference(qo):
                 assert inl.tolist() == inl_ref
                 checked += 1
     assert checked >= 40
+    # one range per element (estimate() takes a vector of ranges; the class only ever passes equal ones)
+    for N in (2, 7, 120, 500):
+        X = rng.normal(0.3, 0.5, N)
+        R = rng.uniform(0.05, 0.6, N)
+        for median in (True, False):
+            e_ref, card_ref, inl_ref = _ref_cote_python([float(v) for v in X], R, median)
+            e, inl, card = qo.cote_estimate_ranges(X, R, median)
+            assert card == card_ref and e == e_ref and inl.tolist() == inl_ref
 
 
 def _ref_gnc_rotation2d_numpy(src, dst, noise_bound, gnc_factor, max_iter, cost_thr):
