@@ -287,6 +287,22 @@ int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr
                      const qtr_params* prm, qtr_result* results, int mem);
 int qtr_wait(qtr_handle* h);
 
+/* Multi-GPU (BASELINE configs[3]): pairs are independent, so every process / device registers its own block of pair
+ * ids and the ONLY exchange is the final gather of the fixed-size result records — RCCL over xGMI (one ncclAllGather of
+ * n_local * sizeof(qtr_result) bytes per rank; latency-bound, far from link bandwidth).  One handle = one rank.
+ *   qtr_comm_unique_id   rank 0 creates the 128-byte rendezvous id; the host application hands it to the other ranks
+ *                        (MPI, a file, torch.distributed.broadcast ...)
+ *   qtr_comm_init        joins the communicator on the handle's device (collective: every rank calls it)
+ *   qtr_gather_results   all-gather: `all` receives world * n_local records in rank order on EVERY rank; n_local must
+ *                        be the same on all ranks (pad the last block)
+ * librccl is opened at run time (dlopen), so single-GPU users do not need it.  QTR_ERR_HIP with the RCCL message in
+ * qtr_last_error on failure. */
+#define QTR_COMM_ID_BYTES 128
+int qtr_comm_unique_id(char id[QTR_COMM_ID_BYTES]);
+int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int world);
+int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all);
+void qtr_comm_destroy(qtr_handle* h);
+
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to

@@ -1,11 +1,17 @@
 // capi.hip — implementation of the C ABI declared in include/quatro_hip.h.
 // Host-side orchestration only: arenas, stream slots, staging copies, kernel sequencing.
+#include <dlfcn.h>
+
 #include <new>
 #include <vector>
 
 #include "common.h"
 #include "frontend.h"
 #include "solver.h"
+
+struct RcclIdByValue {  // ncclUniqueId: passed by value to ncclCommInitRank
+  char internal[QTR_COMM_ID_BYTES];
+};
 
 struct Slot {
   hipStream_t stream = nullptr;
@@ -66,13 +72,120 @@ struct qtr_handle {
   std::vector<Slot> slots;
   std::vector<Lane> lanes;
   BatchJob job;
+  void* comm = nullptr;        // ncclComm_t of this rank (qtr_comm_init)
+  int comm_rank = 0, comm_world = 1;
+  void* comm_buf = nullptr;    // device staging of the gather
+  size_t comm_bytes = 0;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
   double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   char err[512];
 };
 
+// ---- RCCL, opened at run time (the soname torch ships resolves to the copy that is already loaded)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclIdByValue, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi* rccl_api(char* err, size_t errn) {
+  static RcclApi api;
+  static int state = 0;  // 0 untried, 1 ok, -1 failed
+  if (state == 0) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.lib) {
+      api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void**, int, RcclIdByValue, int))dlsym(api.lib, "ncclCommInitRank");
+      api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+      api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+      api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+    }
+    state = (api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy) ? 1 : -1;
+  }
+  if (state != 1) {
+    if (err) snprintf(err, errn, "librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+    return nullptr;
+  }
+  return &api;
+}
+
 extern "C" {
+
+int qtr_comm_unique_id(char id[QTR_COMM_ID_BYTES]) {
+  RcclApi* a = rccl_api(nullptr, 0);
+  if (!a || !id) return QTR_ERR_HIP;
+  return a->GetUniqueId(id) == 0 ? QTR_OK : QTR_ERR_HIP;
+}
+
+int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int world) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return QTR_ERR_BAD_ARG;
+  RcclApi* a = rccl_api(h->err, sizeof(h->err));
+  if (!a) return QTR_ERR_HIP;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  qtr_comm_destroy(h);
+  RcclIdByValue v;
+  memcpy(v.internal, id, QTR_COMM_ID_BYTES);
+  const int rc = a->CommInitRank(&h->comm, world, v, rank);
+  if (rc != 0) {
+    snprintf(h->err, sizeof(h->err), "ncclCommInitRank: %s", a->GetErrorString ? a->GetErrorString(rc) : "error");
+    h->comm = nullptr;
+    return QTR_ERR_HIP;
+  }
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return QTR_OK;
+}
+
+int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all) {
+  if (!h || n_local < 0 || (n_local > 0 && (!local || !all))) return QTR_ERR_BAD_ARG;
+  if (!h->comm) {
+    snprintf(h->err, sizeof(h->err), "qtr_gather_results: call qtr_comm_init first");
+    return QTR_ERR_BAD_ARG;
+  }
+  if (n_local == 0) return QTR_OK;
+  RcclApi* a = rccl_api(h->err, sizeof(h->err));
+  if (!a) return QTR_ERR_HIP;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const size_t mine = (size_t)n_local * sizeof(qtr_result), total = mine * (size_t)h->comm_world;
+  if (h->comm_bytes < mine + total) {
+    if (h->comm_buf) (void)hipFree(h->comm_buf);
+    h->comm_buf = nullptr;
+    h->comm_bytes = 0;
+    QTR_HIP_TRY(h, hipMalloc(&h->comm_buf, mine + total));
+    h->comm_bytes = mine + total;
+  }
+  hipStream_t st = h->slots[0].stream;
+  char* d_send = (char*)h->comm_buf;
+  char* d_recv = d_send + mine;
+  QTR_HIP_TRY(h, hipMemcpyAsync(d_send, local, mine, hipMemcpyHostToDevice, st));
+  const int rc = a->AllGather(d_send, d_recv, mine, /* ncclChar */ 0, h->comm, st);
+  if (rc != 0) {
+    snprintf(h->err, sizeof(h->err), "ncclAllGather: %s", a->GetErrorString ? a->GetErrorString(rc) : "error");
+    return QTR_ERR_HIP;
+  }
+  QTR_HIP_TRY(h, hipMemcpyAsync(all, d_recv, total, hipMemcpyDeviceToHost, st));
+  QTR_HIP_TRY(h, hipStreamSynchronize(st));
+  return QTR_OK;
+}
+
+void qtr_comm_destroy(qtr_handle* h) {
+  if (!h) return;
+  if (h->comm) {
+    RcclApi* a = rccl_api(nullptr, 0);
+    if (a) (void)a->CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  if (h->comm_buf) {
+    (void)hipFree(h->comm_buf);
+    h->comm_buf = nullptr;
+    h->comm_bytes = 0;
+  }
+}
 
 void qtr_set_clique_time_limit(qtr_handle* h, double seconds) {
   if (h) h->clique_time_limit = seconds;
@@ -132,6 +245,7 @@ void* qtr_slot_stream(qtr_handle* h, int slot) {
 void qtr_destroy(qtr_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  qtr_comm_destroy(h);
   for (auto& l : h->lanes) {
     if (l.stage.h) (void)hipHostFree(l.stage.h);
     if (l.stage.d) (void)hipFree(l.stage.d);

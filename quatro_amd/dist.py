@@ -32,26 +32,30 @@ def pack_record(pair_id: int, res: dict) -> np.ndarray:
 
 
 def gather_records(local: "np.ndarray", device=None):
-    """Gathers [n_local, RECORD_DOUBLES] records from every rank onto rank 0 (all ranks must hold the same
-    n_local).  Returns the [world * n_local, RECORD_DOUBLES] array on rank 0, None elsewhere."""
+    """Gathers [n_local, RECORD_DOUBLES] records from every rank onto rank 0, in rank order (block partitions of
+    shard_range differ by at most one record: blocks are padded to the longest and trimmed after the gather).
+    Returns the concatenated array on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
 
-    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
-    if device is not None:
-        t = t.to(device)
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, RECORD_DOUBLES)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return t.cpu().numpy()
+        return local.copy()
     world, rank = dist.get_world_size(), dist.get_rank()
-    if dist.get_backend() == "gloo":
-        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-        dist.gather(t, out, dst=0)
-    else:  # RCCL: all_gather is the portable fixed-size collective
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
+    dev = device if device is not None else "cpu"
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    nmax = max(max(counts), 1)
+    pad = np.zeros((nmax, RECORD_DOUBLES), dtype=np.float64)
+    pad[: local.shape[0]] = local
+    t = torch.from_numpy(pad).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)  # fixed-size collective on both back ends (RCCL has no gather-to-root primitive)
     if rank != 0:
         return None
-    return torch.cat([o.cpu() for o in out], dim=0).numpy()
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

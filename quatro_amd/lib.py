@@ -83,7 +83,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -210,8 +210,21 @@ def load():
     lib.qtr_submit_batch.argtypes = [C.c_void_p, C.POINTER(PairDesc), C.c_int, C.POINTER(FrontendParams),
                                      C.POINTER(Params), C.POINTER(Result), C.c_int]
     lib.qtr_wait.argtypes = [C.c_void_p]
+    lib.qtr_comm_unique_id.argtypes = [C.c_char_p]
+    lib.qtr_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.qtr_gather_results.argtypes = [C.c_void_p, C.POINTER(Result), C.c_int, C.POINTER(Result)]
+    lib.qtr_comm_destroy.argtypes = [C.c_void_p]
+    lib.qtr_comm_destroy.restype = None
     _lib = lib
     return lib
+
+
+def comm_unique_id() -> bytes:
+    """The rendezvous id rank 0 creates for qtr_comm_init (128 bytes)."""
+    buf = C.create_string_buffer(128)
+    if load().qtr_comm_unique_id(buf) != QTR_OK:
+        raise RuntimeError("qtr_comm_unique_id failed (librccl not available?)")
+    return buf.raw
 
 
 def default_params() -> Params:
@@ -527,6 +540,17 @@ class Handle:
         return [{"status": r.status, "valid": bool(r.valid), "T": np.array(r.T[:]).reshape(4, 4), "cost": r.cost,
                  "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr, "n_clique": r.n_clique, "n_final": r.n_final}
                 for r in results[:B]]
+
+    # ---- multi-GPU: RCCL all-gather of the result records through the C ABI (one handle = one rank)
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        self._check(self._lib.qtr_comm_init(self._h, unique_id, rank, world))
+
+    def gather_results(self, results, world: int):
+        """results: ctypes array (Result * n_local).  Returns a (Result * (world * n_local)) array, rank order."""
+        n = len(results)
+        out = (Result * max(world * n, 1))()
+        self._check(self._lib.qtr_gather_results(self._h, results, n, out))
+        return out
 
     def stage_times(self, slot: int = 0) -> dict:
         t = StageTimes()

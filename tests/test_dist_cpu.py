@@ -60,3 +60,51 @@ def test_gather_and_max_over_ranks_gloo_world2():
     assert g[:, 3].tolist() == [0, 1, 2, 3, 4, 5]           # T[0,3]
     assert g[:, 18].tolist() == [2, 3, 4, 5, 6, 7]          # clique sizes
     assert tmax == 2.0
+
+
+def _worker_real(rank, world, port, q):
+    """Every rank registers ITS block of pair ids (the CPU oracle stands in for the GPU worker: same records) and the
+    records meet on rank 0 — the N > 1 path of bench.py / BASELINE configs[3] with real registrations."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as qo
+    from quatro_amd import dist as qd
+    from quatro_amd import synth
+    qo.set_threads(1)
+    lo, hi = qd.shard_range(7, rank, world)  # 7 ids over 2 ranks: blocks of 4 and 3
+    recs = []
+    for pid in range(lo, hi):
+        src, tgt, _, _ = synth.correspondences(200 + 10 * pid, 0.3, seed=pid, noise=0.2)
+        r = qo.solve(src, tgt)
+        r["L"] = src.shape[0]
+        recs.append(qd.pack_record(pid, r))
+    g = qd.gather_records(np.stack(recs))
+    if rank == 0:
+        q.put(g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_registrations_gather_on_rank0_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    from oracle import oracle as qo
+    from quatro_amd import synth
+    qo.set_threads(1)
+    assert g.shape == (7, 24) and g[:, 22].tolist() == list(range(7))
+    for pid in range(7):  # the gathered records equal a serial run of the same ids
+        src, tgt, Tgt, _ = synth.correspondences(200 + 10 * pid, 0.3, seed=pid, noise=0.2)
+        r = qo.solve(src, tgt)
+        assert np.array_equal(g[pid, :16].reshape(4, 4), r["T"]) and g[pid, 18] == len(r["clique"])
+        assert g[pid, 17] == 1.0 and np.abs(r["T"][:3, 3] - Tgt[:3, 3]).max() < 0.2

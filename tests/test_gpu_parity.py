@@ -1139,3 +1139,26 @@ def test_batch_reports_per_pair_failures_and_keeps_going():
     finally:
         hb.close()
         h1.close()
+
+
+def test_rccl_gather_of_result_records_through_the_c_abi():
+    """qtr_comm_unique_id / qtr_comm_init / qtr_gather_results on a communicator of one rank (the box has one GPU): the
+    RCCL plumbing — run-time loading, communicator, device staging, ncclAllGather — returns the records unchanged."""
+    import ctypes as C
+    h = ql.Handle(0)
+    try:
+        h.comm_init(ql.comm_unique_id(), 0, 1)
+        res = (ql.Result * 3)()
+        for i in range(3):
+            res[i].status = i
+            res[i].valid = 1
+            res[i].cost = 0.25 * i
+            res[i].n_clique = 10 + i
+            for k in range(16):
+                res[i].T[k] = i + 0.5 * k
+        out = h.gather_results(res, 1)
+        assert bytes(C.string_at(C.addressof(out), C.sizeof(res))) == bytes(C.string_at(C.addressof(res), C.sizeof(res)))
+        src, tgt, _, _ = synth.correspondences(300, 0.2, seed=1, noise=0.2)   # the handle still registers afterwards
+        assert h.solve(src, tgt)["valid"]
+    finally:
+        h.close()
