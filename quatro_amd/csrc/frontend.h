@@ -4,6 +4,7 @@
 
 #define QTR_KMAX 256        // capacity of one point's radius-neighbour list (entries)
 #define RADIX_TILE 1024     // elements per radix-sort workgroup (one wavefront)
+#define NORM_BINS 192       // bins of width 1 over sqrt(|descriptor|^2) (<= sqrt(3 * 100^2) = 173.3)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
@@ -44,6 +45,9 @@ struct CloudBufs {
   float* queryT = nullptr;     // [34][n_pad] -2*descriptor + ones row            (MFMA stationary operand)
   float* norms = nullptr;      // [max_voxels] |desc|^2
   u32* max_norm = nullptr;     // 1: bits of the largest |desc|^2
+  float* baseTb = nullptr;     // [34][n_pad] baseT with its columns in norm-bin order (exact re-check)
+  int* nb_row = nullptr;       // [max_voxels] row of every column of baseTb (rows sorted by bin of sqrt|desc|^2)
+  int* nb_start = nullptr;     // [NORM_BINS + 1] first column of every bin
   u64* dd_hash = nullptr;      // [max_voxels] 64-bit hash of the descriptor bits
   u64* dd_table = nullptr;     // [dd_slots] open-addressing table: (hash tag << 32) | lowest row holding that hash
 };
@@ -92,6 +96,10 @@ struct NnDir {
   const float* A;       // [n][33] descriptors of the query cloud (exact re-check)
   const float* QT;      // its full k-major table (-2a rows), stride qt_pad
   int qt_pad;
+  const float* baseTb;  // baseT with its columns in norm-bin order; brow: row of each column; bstart: first column per bin
+  const int* brow;
+  const int* bstart;
+  const int* qorder;    // queries visited in this order by k_nn_finish (norm-bin order of the query cloud), or null
   u64* best;            // per row of the query cloud: packed (distance bits << 32 | index), or the bare index
   int nq_slot, rc_slot; // mcounts indices: number of queries, re-check counter
 };
@@ -107,6 +115,8 @@ struct MatchView {
   const float *mean_i, *mean_j;
   const float *fpfh_i, *fpfh_j;
   float *baseT_i, *queryT_i, *norms_i, *baseT_j, *queryT_j, *norms_j;
+  float *baseTb_i, *baseTb_j;
+  int *nb_row_i, *nb_row_j, *nb_start_i, *nb_start_j;
   u64 *hash_i, *hash_j, *table_i, *table_j;
   int dd_mask;                 // table slots - 1
   int n_large, n_small, pad_large, pad_small, swapped, ns, nt;
@@ -115,6 +125,7 @@ struct MatchView {
   NnPartial* partial;
   int* recheck_rows;
   float* recheck_thr;
+  int2* recheck_span;          // per listed row: [first, last) column of the base cloud's norm-bin order that can hold its arg-min
   int* hit_rows;               // ascending rows of the larger cloud that direction 0 points at
   float* queryT_c;             // [34][pad_large] their columns of queryT_i
   float* norms_c;
@@ -153,6 +164,7 @@ struct FrontBufs {
   void* nn_partial = nullptr;  // [max_voxels_pad][32] NnPartial (16 B)
   int* recheck_rows = nullptr; // [max_voxels]
   float* recheck_thr = nullptr; // [max_voxels] per listed row: approximate best + 2 eps (candidates above it cannot win)
+  int2* recheck_span = nullptr; // [max_voxels]
   int* hit_rows = nullptr;     // [max_voxels]
   float* queryT_c = nullptr;   // [34][max_voxels_pad]
   float* norms_c = nullptr;    // [max_voxels_pad]

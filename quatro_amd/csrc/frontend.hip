@@ -1255,9 +1255,9 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   size_t shared = (size_t)max_voxels * 64 + 16384;
   shared += (size_t)max_voxels * (4 + 4 + 4 + 8) + (size_t)max_voxels * 4 * 6 + 4096;  // doubled pair lists + nc_* (cross-check off)
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
-  per_cloud += 2 * 34 * vpad * 4 + (size_t)max_voxels * 4 + 1024;  // baseT, queryT, norms, max_norm
+  per_cloud += 3 * 34 * vpad * 4 + (size_t)max_voxels * 8 + 4096;  // baseT, queryT, baseTb, norms, nb_row, nb_start, max_norm
   per_cloud += (size_t)max_voxels * 8 + (size_t)dedup_slots(max_voxels) * 8 + 512;  // dd_hash, dd_table
-  shared += vpad * 32 * 16 + 2 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr
+  shared += vpad * 32 * 16 + 4 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr, recheck_span
   shared += (size_t)max_voxels * 4 + 34 * vpad * 4 + vpad * 4 + 1024;  // hit_rows, queryT_c, norms_c
   return 2 * per_cloud + shared + 64 * 256;
 }
@@ -1293,6 +1293,9 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
     C.baseT = (float*)take(34 * vpad * 4);
     C.queryT = (float*)take(34 * vpad * 4);
+    C.baseTb = (float*)take(34 * vpad * 4);
+    C.nb_row = (int*)take((size_t)max_voxels * 4);
+    C.nb_start = (int*)take((NORM_BINS + 2) * 4);
     C.norms = (float*)take((size_t)max_voxels * 4);
     C.max_norm = (u32*)take(64);
     C.dd_hash = (u64*)take((size_t)max_voxels * 8);
@@ -1318,6 +1321,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.nn_partial = take((((size_t)max_voxels + 511) / 512 * 512) * 32 * 16);
   F.recheck_rows = (int*)take((size_t)max_voxels * 4);
   F.recheck_thr = (float*)take((size_t)max_voxels * 4);
+  F.recheck_span = (int2*)take((size_t)max_voxels * 8);
   F.hit_rows = (int*)take((size_t)max_voxels * 4);
   F.queryT_c = (float*)take(34 * (((size_t)max_voxels + 511) / 512 * 512) * 4);
   F.norms_c = (float*)take((((size_t)max_voxels + 511) / 512 * 512) * 4);
@@ -1335,4 +1339,5 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   }
 }
 
-hipError_t frontend_init_attributes() { return hipSuccess; }
+hipError_t match_init_attributes();
+hipError_t frontend_init_attributes() { return match_init_attributes(); }

@@ -30,6 +30,13 @@
 // may point into either is a generic pointer, and every load behind it degrades to flat_load.  The pick itself is
 // written inline in every kernel — routed through a helper that takes the argument structs by reference, the compiler
 // loses the kernel-argument provenance again (see ViewExt in common.h).
+#define LAUNCH_MV_K(kern, K, a, grid, block, lds, st)                                                            \
+  do {                                                                                                          \
+    if ((a).ext)                                                                                                \
+      hipLaunchKernelGGL((kern<true, K>), grid, block, lds, st, (ViewExt<MatchView>{(a).ext, {0, 0, 0}}), (a).one); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((kern<false, K>), grid, block, lds, st, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one); \
+  } while (0)
 #define LAUNCH_MV(kern, a, grid, block, lds, st, ...)                                       \
   do {                                                                                      \
     if ((a).ext)                                                                            \
@@ -234,6 +241,58 @@ __global__ __launch_bounds__(256) void k_desc_dedup(ViewExt<MatchView> x, MatchV
     d_desc_dedup(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, V.hash_j, V.table_j, V.dd_mask, V.mcounts + MC_HIDDEN_J);
 }
 
+// Norm-bin order of a cloud's descriptors for the exact re-check.  d(a,b) >= (|a| - |b|)^2, so a base row can only be
+// the arg-min of a listed query if sqrt|b|^2 lies within sqrt(d_best + slack) of sqrt|a|^2: with the base table's columns
+// sorted by bin of sqrt|b|^2 a listed row scans one contiguous span instead of the whole cloud (~6 % of it on lidar
+// scans: most listed rows are near-degenerate descriptors that only compete with each other).
+// k_norm_bins: one workgroup per cloud — histogram, scan, scatter (order inside a bin is arbitrary; the arg-min key carries
+// the row).  k_norm_gather: the permuted copy of the base table (after k_desc_dedup: hidden rows keep their 1e30).
+__device__ __forceinline__ int norm_bin(float nrm) { return min(NORM_BINS - 1, max(0, (int)floorf(sqrtf(fmaxf(nrm, 0.f))))); }
+__device__ __forceinline__ void d_norm_bins(const float* __restrict__ norms, int n, int* __restrict__ row_of,
+                                            int* __restrict__ start) {
+  __shared__ int s_cnt[NORM_BINS], s_cur[NORM_BINS];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < NORM_BINS; b += 1024) s_cnt[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&s_cnt[norm_bin(norms[i])], 1);
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of 192 counters by one wave (three per lane)
+    const int c0 = s_cnt[3 * tid], c1 = s_cnt[3 * tid + 1], c2 = s_cnt[3 * tid + 2];
+    int tot;
+    const int ex = wave_excl_scan_i32(c0 + c1 + c2, &tot);
+    s_cur[3 * tid] = ex;
+    s_cur[3 * tid + 1] = ex + c0;
+    s_cur[3 * tid + 2] = ex + c0 + c1;
+    start[3 * tid] = ex;
+    start[3 * tid + 1] = ex + c0;
+    start[3 * tid + 2] = ex + c0 + c1;
+    if (tid == 0) start[NORM_BINS] = tot;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) row_of[atomicAdd(&s_cur[norm_bin(norms[i])], 1)] = i;
+}
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_norm_bins(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  static_assert(NORM_BINS == 192, "three counters per lane of one wave");
+  if (blockIdx.y == 0)
+    d_norm_bins(V.norms_i, V.n_large, V.nb_row_i, V.nb_start_i);
+  else
+    d_norm_bins(V.norms_j, V.n_small, V.nb_row_j, V.nb_start_j);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y == 0 ? V.n_large : V.n_small, pad = blockIdx.y == 0 ? V.pad_large : V.pad_small;
+  if (c >= n) return;
+  const float* __restrict__ src = blockIdx.y == 0 ? V.baseT_i : V.baseT_j;
+  float* __restrict__ dst = blockIdx.y == 0 ? V.baseTb_i : V.baseTb_j;
+  const int r = (blockIdx.y == 0 ? V.nb_row_i : V.nb_row_j)[c];
+#pragma unroll
+  for (int k = 0; k < 34; ++k) dst[(size_t)k * pad + c] = src[(size_t)k * pad + r];
+}
+
 // How the work of one k_nn_mfma launch is cut into items = (pair, block of 512 queries, slice of the base cloud), and in
 // which order the X workgroups of the launch take them.
 //   * few query blocks (one pair): as many slices as give every workgroup one item and no more — a second round with a
@@ -390,42 +449,75 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 
 // Merge the per-slice partials and decide each query: certified (see the header comment) or listed for the exact
 // re-check.  X = gridDim.x of the k_nn_mfma launch it follows.  grid (ceil(nq_max/256), 1, pairs).
+#define NN_FIN_THREADS 512
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G) {
+__global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G) {
   NN_PLAN(G, dir, X)
+  __shared__ int s_w[16], s_base;
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nq = V.mcounts[D.nq_slot];
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
+  if ((int)blockIdx.x * NN_FIN_THREADS >= nq) return;
+  const int t = blockIdx.x * NN_FIN_THREADS + threadIdx.x;
+  const bool valid = t < nq;
+  // the queries are visited in norm-bin order (direction 0: qorder; direction 1: the hit list is built in that order)
+  // and the re-check list is appended in visiting order, one block of 512 queries at a time: the eight rows a re-check
+  // workgroup shares then have overlapping spans of the base cloud
+  const int q = valid ? (D.qorder ? D.qorder[t] : t) : 0;
   const int nsplit = s_ns[blockIdx.z];
   float b1 = INFINITY, b2 = INFINITY;
   int i1 = -1;
   const NnPartial* __restrict__ partial = V.partial;
-  for (int sidx = 0; sidx < nsplit; ++sidx) {
-    const NnPartial p = partial[(size_t)q * nsplit + sidx];
-    const bool take = (p.b1 < b1) || (p.b1 == b1 && p.i1 >= 0 && (i1 < 0 || p.i1 < i1));
-    const float nb2 = fminf(fminf(b2, p.b2), take ? b1 : p.b1);
-    b1 = take ? p.b1 : b1;
-    i1 = take ? p.i1 : i1;
-    b2 = nb2;
-  }
-  const int row = D.qmap ? D.qmap[q] : q;
-  const float na = D.qnorm[q];
+  if (valid)
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+      const NnPartial p = partial[(size_t)q * nsplit + sidx];
+      const bool take = (p.b1 < b1) || (p.b1 == b1 && p.i1 >= 0 && (i1 < 0 || p.i1 < i1));
+      const float nb2 = fminf(fminf(b2, p.b2), take ? b1 : p.b1);
+      b1 = take ? p.b1 : b1;
+      i1 = take ? p.i1 : i1;
+      b2 = nb2;
+    }
+  const int row = valid ? (D.qmap ? D.qmap[q] : q) : 0;
+  const float na = valid ? D.qnorm[q] : 0.f;
   const float nb1 = (i1 >= 0) ? D.bnorm[i1] : 0.f;
   const float u = 5.9604645e-08f;
   const float d1 = fmaxf(na + b1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
   const float d2 = (b2 < INFINITY) ? fmaxf(na + b2, 0.f) + 1.0f : d1;
   const float gap = u * (144.0f * na + 280.0f * nb1 + 40.0f * (d1 + d2)) * 1.01f;
-  if (i1 >= 0 && (b2 == INFINITY || b2 - b1 > gap)) {
-    D.best[row] = (u64)(u32)i1;
-  } else {
-    D.best[row] = ~0ULL;
-    const int slot = atomicAdd(V.mcounts + D.rc_slot, 1);
+  const bool certified = i1 >= 0 && (b2 == INFINITY || b2 - b1 > gap);
+  const bool listed = valid && !certified;
+  if (valid) D.best[row] = certified ? (u64)(u32)i1 : ~0ULL;
+  // ordered append: ranks inside the workgroup from ballots, one atomic per workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u64 bal = __ballot(listed);
+  if (lane == 0) s_w[wave] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < NN_FIN_THREADS / 64; ++w) {
+      const int c = s_w[w];
+      s_w[w] = tot;
+      tot += c;
+    }
+    s_base = tot ? atomicAdd(V.mcounts + D.rc_slot, tot) : 0;
+  }
+  __syncthreads();
+  if (listed) {
+    const int slot = s_base + s_w[wave] + __popcll(bal & lanemask_lt());
     V.recheck_rows[slot] = row;
     // a base row whose approximate (lower-bound) value exceeds this cannot be the exact arg-min; +inf when the slice
     // merge found nothing
-    V.recheck_thr[slot] = (i1 >= 0) ? b1 + u * (144.0f * na + 280.0f * nb1 + 80.0f * d1) * 1.02f + 1e-30f : INFINITY;
+    const float thr = (i1 >= 0) ? b1 + u * (144.0f * na + 280.0f * nb1 + 80.0f * d1) * 1.02f + 1e-30f : INFINITY;
+    V.recheck_thr[slot] = thr;
+    // columns of the norm-bin order that can hold the arg-min: |sqrt|b|^2 - sqrt|a|^2| <= sqrt(d) and d <= |a|^2~ + thr
+    // (+ the rounding slack of the bound above, norms rounded to float: 0.02 and 0.1 % cover both generously)
+    int lo = 0, hi = NORM_BINS - 1;
+    if (i1 >= 0) {
+      const float sa = sqrtf(fmaxf(na, 0.f)), R = sqrtf(fmaxf(na + thr, 0.f) + 1.0f) * 1.001f + 0.02f;
+      lo = max(0, (int)floorf(sa - R));
+      hi = min(NORM_BINS - 1, (int)floorf(sa + R));
+    }
+    V.recheck_span[slot] = make_int2(D.bstart[lo], D.bstart[hi + 1]);
   }
 }
 
@@ -452,14 +544,15 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
   __shared__ float s_thr[XR];
   __shared__ int s_row[XR];
   __shared__ u64 s_best[XR];  // packed (exact distance bits << 32 | base row) minima of the group's rows
+  __shared__ int s_span[2];
   const float* __restrict__ A = D.A;
-  const float* __restrict__ BT = D.baseT;
-  const int nB = D.nb, nb_pad = D.nb_pad;
+  const float* __restrict__ BT = D.baseTb;   // columns in norm-bin order (k_norm_bins): a listed row scans one span
+  const int* __restrict__ brow = D.brow;
+  const int nb_pad = D.nb_pad;
   const int* __restrict__ rows = V.recheck_rows;
   const float* __restrict__ thr = V.recheck_thr;
+  const int2* __restrict__ span = V.recheck_span;
   u64* __restrict__ best = D.best;
-  const int per = (nB + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nB, b0 + per);
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   const int ngroups = (nrows + XR - 1) / XR;
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -477,7 +570,22 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
       s_thr[threadIdx.x] = (ri < nrows) ? thr[ri] : -INFINITY;
       s_best[threadIdx.x] = ~0ULL;
     }
+    if (threadIdx.x == 64) {  // union of the group's spans (the list is nearly sorted by norm: they overlap)
+      int lo = 0x7fffffff, hi = 0;
+      for (int r = 0; r < XR; ++r) {
+        const int ri = g * XR + r;
+        if (ri < nrows) {
+          const int2 sp = span[ri];
+          lo = min(lo, sp.x);
+          hi = max(hi, sp.y);
+        }
+      }
+      s_span[0] = lo;
+      s_span[1] = hi;
+    }
     __syncthreads();
+    const int per = (max(s_span[1] - s_span[0], 0) + gridDim.y - 1) / gridDim.y;
+    const int b0 = s_span[0] + blockIdx.y * per, b1 = min(s_span[1], b0 + per);
     for (int b = b0 + wave * 64 + lane; b < b1; b += 256) {
       // (compiler barrier: without it the 66 loop-invariant 16-byte LDS reads below are hoisted out of the loop and
       // held in 264 registers — spills; they are meant to be re-read, broadcast, every iteration)
@@ -521,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
         }
         const float dt = av[32] - v[32];
         result += dt * dt;
-        atomicMin(&s_best[r], ((u64)__float_as_uint(result) << 32) | (u32)b);
+        atomicMin(&s_best[r], ((u64)__float_as_uint(result) << 32) | (u32)brow[b]);
       }
     }
     __syncthreads();
@@ -551,15 +659,17 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
   }
 }
 
-// Rows of the larger cloud that the (final) first direction points at, ascending: a bit set in LDS (one workgroup per
-// pair), then a scan over its words.  grid (1, 1, pairs), 1024 threads.
+// Rows of the larger cloud that the (final) first direction points at, in the cloud's NORM-BIN order (k_norm_bins): a
+// bit set in LDS (one workgroup per pair), then a scan over the bin-ordered rows.  (The order only matters to the
+// re-check of direction 1, whose listed rows then share spans; the cross-check reads the NN tables by row.)
+// grid (1, 1, pairs), 1024 threads.
 template <bool EXT>
 __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ u32 hit_bits[];  // ceil(n_large / 32) words
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nw = (V.n_large + 31) / 32;
+  const int n = V.n_large, nw = (n + 31) / 32;
   for (int w = tid; w < nw; w += 1024) hit_bits[w] = 0u;
   __syncthreads();
   for (int j = tid; j < V.n_small; j += 1024) {
@@ -568,11 +678,14 @@ __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, Matc
     atomicOr(&hit_bits[i >> 5], 1u << (i & 31));
   }
   __syncthreads();
-  // words are dealt in contiguous runs so that the output stays ascending
-  const int per = (nw + 1023) / 1024;
-  const int w0 = min(nw, tid * per), w1 = min(nw, w0 + per);
+  // positions of the bin order are dealt in contiguous runs so that the output keeps that order
+  const int per = (n + 1023) / 1024;
+  const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
   int cnt = 0;
-  for (int w = w0; w < w1; ++w) cnt += __popc(hit_bits[w]);
+  for (int p = p0; p < p1; ++p) {
+    const int r = V.nb_row_i[p];
+    cnt += (hit_bits[r >> 5] >> (r & 31)) & 1u;
+  }
   int tot;
   const int ex = wave_excl_scan_i32(cnt, &tot);
   if (lane == 63) wsum[wave] = tot;
@@ -583,13 +696,9 @@ __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, Matc
     run += (w < wave) ? wsum[w] : 0;
     total += wsum[w];
   }
-  for (int w = w0; w < w1; ++w) {
-    u32 x = hit_bits[w];
-    while (x) {
-      const int b = __ffs((int)x) - 1;
-      x &= x - 1;
-      V.hit_rows[run++] = w * 32 + b;
-    }
+  for (int p = p0; p < p1; ++p) {
+    const int r = V.nb_row_i[p];
+    if ((hit_bits[r >> 5] >> (r & 31)) & 1u) V.hit_rows[run++] = r;
   }
   if (tid == 0) V.mcounts[MC_NHIT] = total;
 }
@@ -633,7 +742,7 @@ __global__ __launch_bounds__(256) void k_cross_flags2(ViewExt<MatchView> x, Matc
     V.nn_of_large[i] = (b == ~0ULL) ? -1 : j;
     const u64 bs = V.best_small[j];
     const int back = (bs == ~0ULL) ? 0 : (int)(u32)bs;
-    V.flags[i] = (b != ~0ULL && back == i) ? 1 : 0;
+    V.flags[i] = V.crosscheck ? ((b != ~0ULL && back == i) ? 1 : 0) : ((b != ~0ULL) ? 1 : 0);  // mutual pair / asked row
   }
 }
 
@@ -770,16 +879,18 @@ __global__ void k_scatter_pairs(ViewExt<MatchView> x, MatchView one) {
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_nc_list(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  const int nhit = V.mcounts[MC_NHIT], n = nhit + V.n_small;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    if (e < nhit) {
-      const int i = V.hit_rows[e];
-      V.cross_i[e] = i;
-      V.cross_j[e] = V.nn_of_large[i];
+  // corres_ij in ascending i: flags (row asked in direction 1 = hit) and their scan come from k_cross_flags2 / k_scan_flags
+  const int nhit = V.scan[V.n_large], n = nhit + V.n_small;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < V.n_large + V.n_small; e += gridDim.x * blockDim.x) {
+    if (e < V.n_large) {
+      if (V.flags[e]) {
+        V.cross_i[V.scan[e]] = e;
+        V.cross_j[V.scan[e]] = V.nn_of_large[e];
+      }
     } else {
-      const int j = e - nhit;
-      V.cross_i[e] = V.nn_of_small[j];
-      V.cross_j[e] = j;
+      const int j = e - V.n_large;
+      V.cross_i[nhit + j] = V.nn_of_small[j];
+      V.cross_j[nhit + j] = j;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) V.mcounts[MC_NCROSS] = n;
@@ -849,11 +960,11 @@ __global__ __launch_bounds__(256) void k_nc_emit(ViewExt<MatchView> x, MatchView
   if (V.mail && blockIdx.x == 0 && threadIdx.x < 48) match_mail(V, threadIdx.x, V.scan[ns], V.mcounts[MC_NTUPLE]);
 }
 
-// ---- fused tails for clouds of up to 16384 points: one workgroup of 1024 threads per pair, every thread owning one
-// contiguous run of at most 16 indices, so flag -> exclusive scan -> compaction happens in registers and LDS
+// ---- fused tails for clouds of up to 32768 points: one workgroup of 1024 threads per pair, every thread owning one
+// contiguous run of at most KMAX (16 or 32) indices, so flag -> exclusive scan -> compaction happens in registers and LDS
 // without the three-launch (flags, scan, compact) round trips.
 // K6: unpack both NN tables, mutual-NN test, cross pairs in ascending i.
-template <bool EXT>
+template <bool EXT, int KMAX>
 __global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ int fl_s[];  // [n_large] nn index | keep flag << 31, staged with coalesced (striped) accesses
@@ -874,11 +985,11 @@ __global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, Matc
   }
   __syncthreads();
   const int K = (n_large + 1023) >> 10, base = tid * K;
-  int jj[16];
+  int jj[KMAX];
   u32 keep = 0;
   int cnt = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < KMAX; ++k) {
     const int i = base + k;
     jj[k] = 0;
     if (k < K && i < n_large) {
@@ -901,7 +1012,7 @@ __global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, Matc
     total += wsum[w];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
+  for (int k = 0; k < KMAX; ++k)
     if ((keep >> k) & 1u) {
       V.cross_i[run] = base + k;
       V.cross_j[run] = jj[k];
@@ -912,7 +1023,7 @@ __global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, Matc
 
 // K8 + gather: passed cross pairs -> tgt_of_src, compaction in source order, the matched keypoint clouds
 // (when asked for) and the counters for the host.
-template <bool EXT>
+template <bool EXT, int KMAX>
 __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   __shared__ int wsum[16];
@@ -937,10 +1048,10 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
   for (int i = tid; i < ns; i += 1024) tg_s[i] = V.tgt_of_src[i];
   __syncthreads();
   const int K = (ns + 1023) >> 10, base = tid * K;
-  int tt[16];
+  int tt[KMAX];
   int cnt = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < KMAX; ++k) {
     const int sidx = base + k;
     tt[k] = (k < K && sidx < ns) ? tg_s[sidx] : -1;
     cnt += tt[k] >= 0 ? 1 : 0;
@@ -956,7 +1067,7 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
     total += wsum[w];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
+  for (int k = 0; k < KMAX; ++k)
     if (tt[k] >= 0) {
       V.corr[2 * run] = base + k;
       V.corr[2 * run + 1] = tt[k];
@@ -1018,6 +1129,12 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.baseT_j = Cj.baseT;
   V.queryT_j = Cj.queryT;
   V.norms_j = Cj.norms;
+  V.baseTb_i = Ci.baseTb;
+  V.baseTb_j = Cj.baseTb;
+  V.nb_row_i = Ci.nb_row;
+  V.nb_row_j = Cj.nb_row;
+  V.nb_start_i = Ci.nb_start;
+  V.nb_start_j = Cj.nb_start;
   V.hash_i = Ci.dd_hash;
   V.hash_j = Cj.dd_hash;
   V.table_i = Ci.dd_table;
@@ -1038,6 +1155,7 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.partial = (NnPartial*)F.nn_partial;
   V.recheck_rows = F.recheck_rows;
   V.recheck_thr = F.recheck_thr;
+  V.recheck_span = F.recheck_span;
   V.hit_rows = F.hit_rows;
   V.queryT_c = F.queryT_c;
   V.norms_c = F.norms_c;
@@ -1070,6 +1188,10 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   d0.A = Cj.fpfh;
   d0.QT = Cj.queryT;
   d0.qt_pad = V.pad_small;
+  d0.baseTb = Ci.baseTb;
+  d0.brow = Ci.nb_row;
+  d0.bstart = Ci.nb_start;
+  d0.qorder = Cj.nb_row;
   d0.best = F.best_small;
   d0.nq_slot = MC_NQ0;
   d0.rc_slot = MC_RECHECK0;
@@ -1085,6 +1207,10 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   d1.A = Ci.fpfh;
   d1.QT = Ci.queryT;
   d1.qt_pad = V.pad_large;
+  d1.baseTb = Cj.baseTb;
+  d1.brow = Cj.nb_row;
+  d1.bstart = Cj.nb_start;
+  d1.qorder = nullptr;
   d1.best = F.best_large;
   d1.nq_slot = MC_NHIT;
   d1.rc_slot = MC_RECHECK1;
@@ -1125,6 +1251,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       if (s > 256) s = 256;
       return s;
     };
+    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);  // norms for the bin order k_hit_compact follows
+    LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
     if (ev && ev[0]) (void)hipEventRecord(ev[0], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, 0);
     if (ev && ev[1]) (void)hipEventRecord(ev[1], st);
@@ -1135,18 +1263,22 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   } else {
     LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);
     LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
+    LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
+    LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     const int X = n_cu;  // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second)
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0) (void)hipEventRecord(e0, st);
       LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
       if (e1) (void)hipEventRecord(e1, st);
-      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + 255) / 256, 1, G), B256, 0, st, dir, X, G);
-      // (row group, base slice) workgroups: a slice gives each of the four waves >= ~8 chunks of 64 base rows
-      int ey = (nb_max + 2047) / 2048;
-      if (ey > 16) ey = 16;
-      if (ey < 1) ey = 1;
+      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
+                G);
+      // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
+      (void)nb_max;
+      // (most spans are a fraction of a per cent of the cloud, a few cover half of it: enough slices that the widest
+      // span is shared by many workgroups)
+      const int ey = G > 1 ? 4 : 16;
       int ex = 128;
-      if (G > 1) ex = max(8, 256 / G);  // a group shares the device
+      if (G > 1) ex = max(8, 384 / G);  // a group of pairs shares the device
       LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
@@ -1156,12 +1288,15 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   }
   // K6 cross-check -> pairs in ascending i
   const bool crosscheck = views[0].crosscheck != 0;
-  const bool fused_tail = crosscheck && max_large <= 16384 && max_ns <= 16384;
+  const bool fused_tail = crosscheck && max_large <= 32768 && max_ns <= 32768;
+  const bool fused16 = max_large <= 16384 && max_ns <= 16384;
   if (!crosscheck) {  // single pair (qtr_submit_batch refuses it): the unfiltered list, see k_nc_list
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
+    LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
     LAUNCH_MV(k_nc_list, a, dim3(grid_for(max_large + max_small), 1, G), B256, 0, st);
   } else if (fused_tail) {
-    LAUNCH_MV(k_cross_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
+    if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
+    else LAUNCH_MV_K(k_cross_fused, 32, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
   } else {
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -1179,7 +1314,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_nc_scan, a, dim3(1, 1, G), dim3(1024), 0, st, 1);
     LAUNCH_MV(k_nc_emit, a, dim3(gs, 1, G), B256, 0, st);
   } else if (fused_tail) {
-    LAUNCH_MV(k_pairs_fused, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
+    if (fused16) LAUNCH_MV_K(k_pairs_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
+    else LAUNCH_MV_K(k_pairs_fused, 32, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
   } else {
     LAUNCH_MV(k_scatter_pairs, a, dim3(grid_for(max_small), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_nonneg, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -1191,7 +1327,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
   (void)hipGetLastError();
   const MatchView V = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
-  const bool fused_tail = V.crosscheck && V.n_large <= 16384 && ns <= 16384;
+  const bool fused_tail = V.crosscheck && V.n_large <= 32768 && ns <= 32768;
   F.gathered = fused_tail && F.m_src != nullptr;
   const bool evs = F.nn_events != 0;
   return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr);
@@ -1207,7 +1343,7 @@ hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const q
     max_large = max(max_large, v[g].n_large);
     max_ns = max(max_ns, v[g].ns);
   }
-  const bool fused_tail = max_large <= 16384 && max_ns <= 16384;
+  const bool fused_tail = max_large <= 32768 && max_ns <= 32768;
   for (int g = 0; g < G; ++g) F[g]->gathered = fused_tail && F[g]->m_src != nullptr;
   return match_launch(v.data(), G, F[0]->nn_engine, F[0]->n_cu, stage, st, nullptr);
 }
@@ -1217,4 +1353,18 @@ hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_
   hipLaunchKernelGGL(k_gather_matched, dim3(grid_for(L)), dim3(256), 0, st, F.cloud[0].vox, F.cloud[1].vox, F.corr, L,
                      m_src, m_tgt);
   return hipGetLastError();
+}
+
+// the 32-per-thread fused tails stage up to 32768 ints (128 KB) in dynamic LDS
+hipError_t match_init_attributes() {
+  hipError_t e;
+#define SET_LDS2(kern)                                                                                                   \
+  if ((e = hipFuncSetAttribute((const void*)kern<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess) \
+    return e;                                                                                                            \
+  if ((e = hipFuncSetAttribute((const void*)kern<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess)  \
+    return e;
+  SET_LDS2(k_cross_fused)
+  SET_LDS2(k_pairs_fused)
+#undef SET_LDS2
+  return hipSuccess;
 }
