@@ -20,5 +20,5 @@ f, w = mean(fetch_db, "FETCH_SIZE", pat), mean(write_db, "WRITE_SIZE", pat)
 out = dict(kernel=pat, fetch=f, write=w, traffic_bytes_per_launch=(f["mean_kib"] + w["mean_kib"]) * 1024.0,
            correction="none applied (dword loads; FETCH_SIZE x2 rule is calibrated for 16 B/lane reads only)",
            command="rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 8 --warmup 2 "
-                   "--cpu-seconds 0 --stream-slots 0 (two separate passes)")
+                   "--legs '' --cpu-seconds 0 (two separate passes; profiles/collect_r2.sh)")
 print(json.dumps(out, indent=1))
