@@ -60,13 +60,13 @@ class FPFHManager {
     qtr_handle* h = quatro_hip::default_handle();
     std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
     if (is_initial_ && !is_odometry_test_) {
-      src_cloud_ = src->points;
+      src_cloud_.assign(src->points.begin(), src->points.end());  // PCL's storage has its own allocator type
       compute(h, src_cloud_, obj_desc_);
       is_initial_ = false;
     } else {
       swapTgt2Src();
     }
-    tgt_cloud_ = target->points;
+    tgt_cloud_.assign(target->points.begin(), target->points.end());
     compute(h, tgt_cloud_, scene_desc_);
     qtr_frontend_params fp;
     qtr_default_frontend_params(&fp);
@@ -100,7 +100,7 @@ class FPFHManager {
     if (savedir_.empty()) throw std::invalid_argument("Save dir. is not set");
     const std::string pcdname = pair_name(savedir_, src_idx, tgt_idx);
     if (verbose) std::printf("[SAVER]: %s\n%zu + %zu\n", pcdname.c_str(), src_matched_pcl.size(), tgt_matched_pcl.size());
-    std::vector<PointType> merge(src_matched_pcl.points);
+    std::vector<PointType> merge(src_matched_pcl.points.begin(), src_matched_pcl.points.end());
     merge.insert(merge.end(), tgt_matched_pcl.points.begin(), tgt_matched_pcl.points.end());
     if (qtr_write_pcd_xyz(pcdname.c_str(), reinterpret_cast<const float*>(merge.data()), static_cast<int>(merge.size()), 0) !=
         QTR_OK)

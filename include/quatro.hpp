@@ -136,8 +136,8 @@ class Registration {
 
 namespace quatro_hip {
 // pcl::PointXYZ and friends are 16-byte records starting with float x,y,z: passed through as xyz4.
-template <typename PointT>
-inline const float* xyz4(const std::vector<PointT>& pts) {
+template <typename PointT, typename Alloc>
+inline const float* xyz4(const std::vector<PointT, Alloc>& pts) {  // any allocator: PCL's storage uses Eigen::aligned_allocator
   static_assert(sizeof(PointT) == 16, "point type must be a 16-byte x,y,z,pad record (pcl::PointXYZ)");
   return reinterpret_cast<const float*>(pts.data());
 }
@@ -149,7 +149,7 @@ void voxelize(const QUATRO_SHARED_PTR<pcl::PointCloud<T>> srcPtr, QUATRO_SHARED_
               double voxelSize) {
   qtr_handle* h = quatro_hip::default_handle();
   const int P = static_cast<int>(srcPtr->points.size());
-  std::vector<T> out(static_cast<size_t>(P), T());  // a temporary, like pcl::Filter::filter: dstPtr may alias srcPtr
+  decltype(dstPtr->points) out(static_cast<size_t>(P), T());  // a temporary, like pcl::Filter::filter: dstPtr may alias srcPtr
   int n = 0;
   {
     std::lock_guard<std::recursive_mutex> lock(quatro_hip::default_slot_mutex());
@@ -163,7 +163,7 @@ template <typename T>
 void voxelize(pcl::PointCloud<T>& src, QUATRO_SHARED_PTR<pcl::PointCloud<T>> dstPtr, double voxelSize) {
   qtr_handle* h = quatro_hip::default_handle();
   const int P = static_cast<int>(src.points.size());
-  std::vector<T> out(static_cast<size_t>(P), T());  // dstPtr may point at src
+  decltype(dstPtr->points) out(static_cast<size_t>(P), T());  // dstPtr may point at src
   int n = 0;
   {
     std::lock_guard<std::recursive_mutex> lock(quatro_hip::default_slot_mutex());

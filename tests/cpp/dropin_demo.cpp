@@ -13,8 +13,8 @@
 #include "patchwork.hpp"
 #include "quatro.hpp"
 
-static std::shared_ptr<pcl::PointCloud<PointType>> getCloud(const char* path) {  // reference :377-402
-  auto cloud = std::make_shared<pcl::PointCloud<PointType>>();
+static pcl::PointCloud<PointType>::Ptr getCloud(const char* path) {  // reference :377-402
+  pcl::PointCloud<PointType>::Ptr cloud(new pcl::PointCloud<PointType>());
   std::vector<float> buffer(1000000);  // the demo's cap: 250 000 points
   int n = 0;
   if (qtr_read_kitti_bin(path, buffer.data(), 250000, &n) != QTR_OK) throw std::runtime_error(std::string("error: failed to load ") + path);
@@ -47,8 +47,8 @@ int main(int argc, char** argv) {
   if (raw) {
     PatchWork<PointType> patchwork;
     pcl::PointCloud<PointType> srcGround, tgtGround;
-    auto srcNonground = std::make_shared<pcl::PointCloud<PointType>>();
-    auto tgtNonground = std::make_shared<pcl::PointCloud<PointType>>();
+    pcl::PointCloud<PointType>::Ptr srcNonground(new pcl::PointCloud<PointType>());
+    pcl::PointCloud<PointType>::Ptr tgtNonground(new pcl::PointCloud<PointType>());
     double tSrc = 0, tTgt = 0;
     patchwork.estimate_ground(*srcRaw, srcGround, *srcNonground, tSrc);
     patchwork.estimate_ground(*tgtRaw, tgtGround, *tgtNonground, tTgt);
@@ -63,8 +63,8 @@ int main(int argc, char** argv) {
     ImageProjection IPSrc("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork"), IPTgt("Velodyne-64-HDE", "4CrossNeighbor", "Patchwork");
     IPSrc.segmentCloud(srcRaw);
     IPTgt.segmentCloud(tgtRaw);
-    auto srcValid = std::make_shared<pcl::PointCloud<PointType>>();
-    auto tgtValid = std::make_shared<pcl::PointCloud<PointType>>();
+    pcl::PointCloud<PointType>::Ptr srcValid(new pcl::PointCloud<PointType>());
+    pcl::PointCloud<PointType>::Ptr tgtValid(new pcl::PointCloud<PointType>());
     IPSrc.getValidSegments(*srcValid);
     IPTgt.getValidSegments(*tgtValid);
     pcl::PointCloud<PointType> so, to;
@@ -75,16 +75,16 @@ int main(int argc, char** argv) {
     srcRaw = srcValid;
     tgtRaw = tgtValid;
   }
-  auto srcFeat = std::make_shared<pcl::PointCloud<PointType>>();
-  auto tgtFeat = std::make_shared<pcl::PointCloud<PointType>>();
+  pcl::PointCloud<PointType>::Ptr srcFeat(new pcl::PointCloud<PointType>());
+  pcl::PointCloud<PointType>::Ptr tgtFeat(new pcl::PointCloud<PointType>());
   voxelize(srcRaw, srcFeat, 0.3);
   voxelize(tgtRaw, tgtFeat, 0.3);
   FPFHManager fpfhmanager(0.5, 0.75);
   fpfhmanager.seed_ = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 0;
   fpfhmanager.flushAllFeatures();
   fpfhmanager.setFeaturePair(srcFeat, tgtFeat);
-  auto srcMatched = std::make_shared<pcl::PointCloud<PointType>>(fpfhmanager.getSrcKps());
-  auto tgtMatched = std::make_shared<pcl::PointCloud<PointType>>(fpfhmanager.getTgtKps());
+  pcl::PointCloud<PointType>::Ptr srcMatched(new pcl::PointCloud<PointType>(fpfhmanager.getSrcKps()));
+  pcl::PointCloud<PointType>::Ptr tgtMatched(new pcl::PointCloud<PointType>(fpfhmanager.getTgtKps()));
 
   quatro.setInputSource(srcMatched);
   quatro.setInputTarget(tgtMatched);

@@ -85,8 +85,8 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 3; ++c) std::printf(" %.17g", R3(r, c));
   std::printf("\n");
   Eigen::Matrix4d T3 = Eigen::Matrix4d::Identity();
-  auto srcM = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
-  auto tgtM = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+  pcl::PointCloud<pcl::PointXYZ>::Ptr srcM(new pcl::PointCloud<pcl::PointXYZ>());
+  pcl::PointCloud<pcl::PointXYZ>::Ptr tgtM(new pcl::PointCloud<pcl::PointXYZ>());
   for (int c = 0; c < L; ++c) {
     srcM->push_back(pcl::PointXYZ(src[static_cast<size_t>(corr[c].first)].x, src[static_cast<size_t>(corr[c].first)].y,
                                   src[static_cast<size_t>(corr[c].first)].z));

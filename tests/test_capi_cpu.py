@@ -139,6 +139,24 @@ def test_patchwork_parameter_mirror():
         api.PatchWork(bogus=1)
 
 
+def test_drop_in_headers_type_check_against_pcl_shaped_headers():
+    """The QUATRO_HAVE_PCL branch of the drop-in headers (real pcl:: / Eigen:: / boost:: types instead of the built-in
+    stand-ins) is compiled against tests/cpp/pcl_stub: declaration-level headers shaped like PCL 1.10 / Eigen 3.3
+    (boost::shared_ptr cloud pointers, aligned-allocator point storage, column-major six-parameter Eigen::Matrix,
+    pcl::Registration<Source, Target, Scalar> with its pure virtual computeTransformation).  Every demo must build in
+    that configuration too, warning-free."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cpp = os.path.join(root, "tests", "cpp")
+    stub = os.path.join(cpp, "pcl_stub")
+    macros = subprocess.run(["g++", "-std=c++17", "-dM", "-E", "-I", stub, "-I", os.path.join(root, "include"),
+                             os.path.join(cpp, "dropin_demo.cpp")], capture_output=True, text=True, check=True).stdout
+    assert "#define QUATRO_HAVE_PCL 1" in macros  # the branch under test is really the one selected
+    for name in sorted(os.listdir(cpp)):
+        if name.endswith(".cpp"):
+            subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", stub,
+                                   "-I", os.path.join(root, "include"), os.path.join(cpp, name)])
+
+
 def test_cpp_drop_in_headers_compile_and_read_ros_style_parameters(tmp_path):
     """Every C++ demo compiles against the drop-in headers (syntax check, no GPU needed), and PatchWork's NodeHandle-style
     constructor reads "/patchwork/..." parameters from any object with ros::NodeHandle's param()/getParam()."""

@@ -257,9 +257,12 @@ def test_host_mirror_reads_like_the_reference_demo(hip, qo, small_pair):
     assert len(fm.getCorrespondences()) == o["L"]
 
 
-def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path):
+@pytest.mark.parametrize("pcl_shaped", [False, True])
+def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path, pcl_shaped):
     """The reference demo's call sequence compiled against include/quatro.hpp + include/fpfh_manager.hpp
-    (tests/cpp/dropin_demo.cpp) gives the oracle's answer, digit for digit."""
+    (tests/cpp/dropin_demo.cpp) gives the oracle's answer, digit for digit — with the headers' built-in pcl:: / Eigen::
+    stand-ins and with the QUATRO_HAVE_PCL branch over tests/cpp/pcl_stub (boost::shared_ptr, aligned-allocator storage,
+    column-major Eigen)."""
     import subprocess
 
     import torch
@@ -269,7 +272,8 @@ def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path):
     synth.save_kitti_bin(str(tmp_path / "tgt.bin"), t)
     exe = str(tmp_path / "dropin_demo")
     libdir = os.path.join(root, "quatro_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+    stub = ["-I", os.path.join(root, "tests", "cpp", "pcl_stub")] if pcl_shaped else []
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + stub + ["-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir,
                            "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = None
@@ -601,9 +605,11 @@ def test_stage_entry_points_match_oracle_and_numpy(hip, qo):
             assert eg == eo and ng == no and np.array_equal(mg, mo), (Nn, median, "ranges")
 
 
-def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):
+@pytest.mark.parametrize("pcl_shaped", [False, True])
+def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path, pcl_shaped):
     """tests/cpp/stages_demo.cpp: teaser::FPFHEstimation / teaser::Matcher and the public stage methods of class
-    Quatro from this repository's headers give the oracle's numbers, digit for digit."""
+    Quatro from this repository's headers give the oracle's numbers, digit for digit (also over tests/cpp/pcl_stub,
+    i.e. the QUATRO_HAVE_PCL branch with column-major Eigen matrices)."""
     import subprocess
 
     import torch
@@ -614,7 +620,8 @@ def test_cpp_stage_methods_and_front_end_classes(hip, qo, small_pair, tmp_path):
     synth.save_kitti_bin(str(tmp_path / "tgt.bin"), vt)
     exe = str(tmp_path / "stages_demo")
     libdir = os.path.join(root, "quatro_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+    stub = ["-I", os.path.join(root, "tests", "cpp", "pcl_stub")] if pcl_shaped else []
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + stub + ["-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "stages_demo.cpp"), "-o", exe, "-L", libdir,
                            "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = None
