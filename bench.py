@@ -12,11 +12,16 @@ the fixed-size result records (RCCL) after the timed region plus the barrier / m
 Prints ONE JSON line on rank 0.
 
 Objects in the line next to the contract's keys:
-  roofline      — dominant kernel k_nn_mfma (33-D distance matrix through v_mfma_f32_32x32x2_f32): algorithmic
-                  FLOP of the launches that were timed (sum of 66 * n_query * n_base per launch) / their summed
-                  duration (HIP events recorded by the library on the launch stream), against the FP32 matrix peak.
+  roofline      — dominant kernel k_nn_f16: the 33-D distance matrix nb' - 2 a.b evaluated on the f16 matrix pipe with
+                  every f32 operand split in two halves (3 x 33 products + 3 norm slots = 102 per matrix entry, see
+                  match.hip).  `achieved` = 2 * 102 * n_query * n_base FLOP per launch (K padding to 112 not counted)
+                  / mean launch duration (HIP events recorded by the library on the launch stream), `peak` = the dense
+                  f16/bf16 MFMA peak.  `f32_equivalent` restates the same launches in SURVEY.md section 8(d)'s unit
+                  (66 * n_query * n_base FLOP of an f32 evaluation) against the FP32 matrix peak — the figure earlier
+                  rounds reported for the f32 kernel k_nn_mfma (QTR_NN_ENGINE=mfma32 still runs it, and is then the
+                  kernel this object describes).
                   `end_to_end`: the registration's algorithmic FLOP and bytes priced at the
-                  MFMA / HBM peaks, over the measured time per step.
+                  FP32-matrix / HBM peaks, over the measured time per step.
   cpu_baseline  — the CPU oracle (a port: the reference cannot be built here; brute-force NN instead of FLANN
                   kd-trees) on this box's host cores, swept over OMP thread counts on a bounded sample; `value` is the
                   best setting, `omp4` the reference README's 4-thread setting.  A reported baseline, not the target.
@@ -37,6 +42,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32) = FP32 vector peak
+F16_PEAK_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA, dense (v_mfma_f32_32x32x16_f16: 32 cycles per SIMD)
+NN_ENGINE = os.environ.get("QTR_NN_ENGINE", "f16")  # f16 (default): k_nn_f16; mfma32: k_nn_mfma; exact: no MFMA kernel
+F16_FLOP_PER_ENTRY, F32_FLOP_PER_ENTRY = 204.0, 66.0
+
+
+def nn_roofline(entries_per_launch, mean_launch_s):
+    """roofline fields of the nearest-neighbour kernel for one launch of `entries_per_launch` distance-matrix entries"""
+    f32_rate = F32_FLOP_PER_ENTRY * entries_per_launch / mean_launch_s / 1e12
+    f32eq = {"flop_per_launch": F32_FLOP_PER_ENTRY * entries_per_launch, "achieved": f32_rate, "peak": FP32_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "ratio": f32_rate / FP32_PEAK_TFLOPS,
+             "note": "SURVEY 8(d) row E unit: 33 multiply-adds per matrix entry as an f32 evaluation would need"}
+    if NN_ENGINE == "mfma32":
+        return {"kernel": "k_nn_mfma (33-D distance matrix on v_mfma_f32_32x32x2_f32 + per-query top-2, one launch per direction)",
+                "bound": "mfma", "dtype": "f32", "achieved": f32_rate, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": f32_rate / FP32_PEAK_TFLOPS, "flop_per_launch": F32_FLOP_PER_ENTRY * entries_per_launch,
+                "mean_launch_ms": 1e3 * mean_launch_s}
+    rate = F16_FLOP_PER_ENTRY * entries_per_launch / mean_launch_s / 1e12
+    return {"kernel": "k_nn_f16 (33-D distance matrix on v_mfma_f32_32x32x16_f16, f32 operands split in two f16 halves, "
+                      "+ per-query top-2; one launch per direction)",
+            "bound": "mfma", "dtype": "f16 (2-way split of f32 operands, f32 accumulate)", "achieved": rate,
+            "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rate / F16_PEAK_TFLOPS,
+            "flop_per_launch": F16_FLOP_PER_ENTRY * entries_per_launch, "mean_launch_ms": 1e3 * mean_launch_s,
+            "f32_equivalent": f32eq}
 HBM_PEAK_GBS = 8000.0
 METRIC = "scan-pair registrations/sec (KITTI 64-ch, ~5k corr) + rot/trans err vs ref"  # BASELINE.json, verbatim
 
@@ -181,7 +209,7 @@ def main() -> None:
         "metric": METRIC,
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 (voxel grid, FPFH, 33-D matching) / f64 (consistency graph, GNC-TLS, COTE)", "data": "synthetic",
+        "dtype": "f32 (voxel grid, FPFH, 33-D matching: f16-split MFMA filter, exact f32 decision) / f64 (consistency graph, GNC-TLS, COTE)", "data": "synthetic",
         "config": {
             "workload": "synthetic KITTI-64-shaped single pair (quatro_amd.synth.kitti64_pair_16k), voxel 0.3 m, whole "
                         "path on GPU, one registration at a time (BASELINE configs[1])",
@@ -215,25 +243,25 @@ def main() -> None:
     # ---- roofline of the dominant kernel (rank 0's launches), and of the whole registration
     if nn_launches > 0:
         mean_launch_s = 1e-3 * nn_ms / nn_launches
-        flop_per_launch = nn_flop / nn_launches
-        achieved = flop_per_launch / mean_launch_s / 1e12
         bound_ms = 1e3 * max(alg_flop / my_steps / (FP32_PEAK_TFLOPS * 1e12), alg_bytes / my_steps / (HBM_PEAK_GBS * 1e9))
-        out["roofline"] = {
-            "kernel": "k_nn_mfma (33-D distance matrix + per-query top-2, one launch per direction)",
-            "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-            "flop_per_launch": flop_per_launch, "mean_launch_ms": 1e3 * mean_launch_s, "launches_timed": nn_launches,
+        out["roofline"] = nn_roofline(nn_flop / F32_FLOP_PER_ENTRY / nn_launches, mean_launch_s)
+        out["roofline"].update({
+            "traffic": None, "launches_timed": nn_launches,
             "end_to_end": {
                 "algorithmic_gflop_per_registration": alg_flop / my_steps / 1e9,
                 "algorithmic_mbytes_per_registration": alg_bytes / my_steps / 1e6,
                 "mfma_bound_ms": 1e3 * alg_flop / my_steps / (FP32_PEAK_TFLOPS * 1e12),
                 "hbm_bound_ms": 1e3 * alg_bytes / my_steps / (HBM_PEAK_GBS * 1e9),
                 "ms_per_step": ms_per_step, "frac": bound_ms / ms_per_step},
-        }
+        })
         # HBM-side bytes per launch come from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
         # this same command); counters cannot be read in-process, so the committed summary is quoted
         import glob
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2*_pmc_nn.json")))
+        if pmc and NN_ENGINE != "mfma32":
+            with open(pmc[-1]) as f:
+                if "k_nn_f16" not in json.load(f).get("kernel", ""):
+                    pmc = []  # the committed counters are of the other kernel
         if pmc:
             with open(pmc[-1]) as f:
                 pj = json.load(f)
@@ -366,14 +394,10 @@ def dense_legs(args, torch, ql, synth, prm, dev, device_index):
         m_acc += st["match"]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    flop = 66.0 * n_pts * n_pts
-    ach = flop / (1e-3 * nn_ms / max(nn_l, 1)) / 1e12 if nn_ms > 0 else 0.0
     out["dense_frontend_leg"] = {
         "what": f"FPFH + reciprocal matching of two {n_pts}-point clouds, no voxel down-sampling",
         "ms_per_pair": 1e3 * el / reps, "fpfh_ms": f_acc / reps, "match_ms": m_acc / reps, "n_corr": int(Lout.value),
-        "roofline": {"kernel": "k_nn_mfma", "bound": "mfma", "flop_per_launch": flop,
-                     "mean_launch_ms": nn_ms / max(nn_l, 1), "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}}
+        "roofline": nn_roofline(float(n_pts) * n_pts, 1e-3 * nn_ms / max(nn_l, 1)) if nn_ms > 0 else None}
     hd.close()
     return out
 

@@ -3,7 +3,7 @@
 #   gpurun_out/TAG_bench.json            the bench line (all legs)
 #   gpurun_out/TAG_kernel_stats.txt      rocprofv3 --kernel-trace of the headline loop (sequential single pairs)
 #   gpurun_out/TAG_batch_kernel_stats.txt  ... of the batched leg (256 pairs, groups of 16 per launch chain)
-#   gpurun_out/TAG_pmc_nn.json           FETCH_SIZE / WRITE_SIZE of k_nn_mfma, two separate --pmc passes
+#   gpurun_out/TAG_pmc_nn.json           FETCH_SIZE / WRITE_SIZE of k_nn_f16 (NN_KERNEL overrides the name), two separate --pmc passes
 # Copy what is to be judged into profiles/.
 TAG=${1:-r2}
 export TMPDIR=/tmp
@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_write -o 
 cd $R
 python profiles/summarize_rocpd.py $(ls gpurun_out/prof_${TAG}_seq/*.db | head -1) 53 > gpurun_out/${TAG}_kernel_stats.txt
 python profiles/summarize_rocpd.py $(ls gpurun_out/prof_${TAG}_batch/*.db | head -1) > gpurun_out/${TAG}_batch_kernel_stats.txt
-python profiles/summarize_pmc.py $(ls gpurun_out/prof_${TAG}_fetch/*.db | head -1) $(ls gpurun_out/prof_${TAG}_write/*.db | head -1) 'void k_nn_mfma' > gpurun_out/${TAG}_pmc_nn.json
+python profiles/summarize_pmc.py $(ls gpurun_out/prof_${TAG}_fetch/*.db | head -1) $(ls gpurun_out/prof_${TAG}_write/*.db | head -1) "${NN_KERNEL:-void k_nn_f16}" > gpurun_out/${TAG}_pmc_nn.json
 rm -rf gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write

@@ -1,8 +1,9 @@
 """Per-launch HBM-side traffic of one kernel from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
-rocpd sqlite output).  usage: python profiles/summarize_pmc.py fetch.db write.db 'k_nn_mfma(' > profiles/<tag>_pmc_nn.json
-FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is calibrated (x2) only
-for 16-byte-per-lane streaming reads; this kernel issues 4-byte-per-lane loads of 128-byte segments, so the raw
-counter is reported uncorrected and flagged as such."""
+rocpd sqlite output).  usage: python profiles/summarize_pmc.py fetch.db write.db 'void k_nn_f16' > profiles/<tag>_pmc_nn.json
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes
+of wide coalesced streaming reads (16 bytes per lane) and is to be doubled for them; other widths are uncalibrated.
+k_nn_f16 reads its operand tables with global_load_dwordx4 (16 B per lane, 512 contiguous bytes per half-wave): doubled.
+k_nn_mfma (the f32 engine) issues 4-byte-per-lane loads: reported raw and flagged as such."""
 import json
 import sqlite3
 import sys
@@ -17,8 +18,11 @@ def mean(db, counter, pat):
 
 fetch_db, write_db, pat = sys.argv[1], sys.argv[2], sys.argv[3]
 f, w = mean(fetch_db, "FETCH_SIZE", pat), mean(write_db, "WRITE_SIZE", pat)
-out = dict(kernel=pat, fetch=f, write=w, traffic_bytes_per_launch=(f["mean_kib"] + w["mean_kib"]) * 1024.0,
-           correction="none applied (dword loads; FETCH_SIZE x2 rule is calibrated for 16 B/lane reads only)",
+wide = "k_nn_f16" in pat
+out = dict(kernel=pat, fetch=f, write=w,
+           traffic_bytes_per_launch=((2.0 if wide else 1.0) * f["mean_kib"] + w["mean_kib"]) * 1024.0,
+           correction=("FETCH_SIZE x 2 (16 B/lane streaming reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE raw" if wide else
+                       "none applied (dword loads; FETCH_SIZE x2 rule is calibrated for 16 B/lane reads only)"),
            command="rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 8 --warmup 2 "
                    "--legs '' --cpu-seconds 0 (two separate passes; profiles/collect_r2.sh)")
 print(json.dumps(out, indent=1))

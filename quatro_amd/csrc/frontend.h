@@ -14,7 +14,7 @@ enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW =
 // for the rows of the larger cloud that some row of the smaller cloud points at); MC_HIDDEN_I / _J: descriptor rows
 // hidden from the base tables because a lower row holds the bit-identical descriptor
 enum { MC_NCORR = 0, MC_HIDDEN_I = 1, MC_HIDDEN_J = 2, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5, MC_NQ0 = 6, MC_NHIT = 7,
-       MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11 };
+       MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_PAIRCMP0 = 10, MC_PAIRCMP1 = 11, MC_UNSAFE = 12 };
 
 // Host mailbox (ints): the kernel that finishes a phase stores the few counters the host needs straight into
 // pinned host memory, so a phase boundary costs one stream synchronisation and no copy launches.
@@ -48,6 +48,8 @@ struct CloudBufs {
   float* baseTb = nullptr;     // [34][n_pad] baseT with its columns in norm-bin order (exact re-check)
   int* nb_row = nullptr;       // [max_voxels] row of every column of baseTb (rows sorted by bin of sqrt|desc|^2)
   int* nb_start = nullptr;     // [NORM_BINS + 1] first column of every bin
+  uint4* baseH = nullptr;      // [n_pad/32][14][32] x 16 B: the f16-split base operand of k_nn_f16 (see match.hip)
+  uint4* queryH = nullptr;     // same layout: the f16-split query operand (all rows of the cloud)
   u64* dd_hash = nullptr;      // [max_voxels] 64-bit hash of the descriptor bits
   u64* dd_table = nullptr;     // [dd_slots] open-addressing table: (hash tag << 32) | lowest row holding that hash
 };
@@ -90,6 +92,8 @@ struct NnDir {
   const float* bnorm;   // [nb] |b|^2 as rounded once from binary64
   int nb, nb_pad;
   const float* queryT;  // [34][nq_pad] the table k_nn_mfma reads (direction 1: the compacted hit rows)
+  const uint4* baseH;   // f16-split operands of k_nn_f16: [rows/32][14][32] x 16 B (direction 1's queryH: compacted hit rows)
+  const uint4* queryH;
   const float* qnorm;   // [.] |a|^2 per column of that table
   const int* qmap;      // column -> row of the query cloud (null: identity)
   int nq_pad;
@@ -116,6 +120,7 @@ struct MatchView {
   const float *fpfh_i, *fpfh_j;
   float *baseT_i, *queryT_i, *norms_i, *baseT_j, *queryT_j, *norms_j;
   float *baseTb_i, *baseTb_j;
+  uint4 *baseH_i, *baseH_j, *queryH_i, *queryH_j, *queryH_c;
   int *nb_row_i, *nb_row_j, *nb_start_i, *nb_start_j;
   u64 *hash_i, *hash_j, *table_i, *table_j;
   int dd_mask;                 // table slots - 1
@@ -168,6 +173,7 @@ struct FrontBufs {
   int* hit_rows = nullptr;     // [max_voxels]
   float* queryT_c = nullptr;   // [34][max_voxels_pad]
   float* norms_c = nullptr;    // [max_voxels_pad]
+  uint4* queryH_c = nullptr;   // [max_voxels_pad/32][14][32] x 16 B: f16-split query operand of the hit rows
   int dd_slots = 0;            // slots of each cloud's dedup table (power of two >= 2 * max_voxels)
   int *nc_cnt = nullptr, *nc_fill = nullptr, *nc_off = nullptr, *nc_list = nullptr;  // cross-check off: per-source target lists
   int* mail = nullptr;         // device view of the slot's pinned host mailbox (see MAIL_* above); may be null
@@ -176,7 +182,8 @@ struct FrontBufs {
   int m_cap = 0;               // capacity of m_src / m_tgt in points (the handle's max_corr)
   bool gathered = false;       // set by match_enqueue when it did
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
-  int nn_engine = 1;           // 1 = MFMA + exact re-check, 0 = exact VALU only (QTR_NN_ENGINE=exact)
+  int nn_engine = 2;           // 2 = f16-split MFMA filter + exact re-check (default), 1 = f32 MFMA + exact re-check
+                               // (QTR_NN_ENGINE=mfma32), 0 = exact VALU only (QTR_NN_ENGINE=exact)
   int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit
   int n_cu = 256;              // compute units of the device
   int nn_trace = 0;            // QTR_NN_TRACE=1: k_nn_mfma (first direction) leaves clocks per tile / workgroup lives in mcounts[12..15]

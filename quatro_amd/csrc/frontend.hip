@@ -1256,9 +1256,11 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   shared += (size_t)max_voxels * (4 + 4 + 4 + 8) + (size_t)max_voxels * 4 * 6 + 4096;  // doubled pair lists + nc_* (cross-check off)
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 3 * 34 * vpad * 4 + (size_t)max_voxels * 8 + 4096;  // baseT, queryT, baseTb, norms, nb_row, nb_start, max_norm
+  per_cloud += 2 * (vpad * 224 + 2 * 7168) + 512;                   // baseH, queryH (+ two tiles the prefetch may touch)
   per_cloud += (size_t)max_voxels * 8 + (size_t)dedup_slots(max_voxels) * 8 + 512;  // dd_hash, dd_table
   shared += vpad * 32 * 16 + 4 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr, recheck_span
   shared += (size_t)max_voxels * 4 + 34 * vpad * 4 + vpad * 4 + 1024;  // hit_rows, queryT_c, norms_c
+  shared += vpad * 224 + 2 * 7168 + 256;                               // queryH_c
   return 2 * per_cloud + shared + 64 * 256;
 }
 
@@ -1294,6 +1296,8 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.baseT = (float*)take(34 * vpad * 4);
     C.queryT = (float*)take(34 * vpad * 4);
     C.baseTb = (float*)take(34 * vpad * 4);
+    C.baseH = (uint4*)take(vpad * 224 + 2 * 7168);  // two tiles of slack: the core prefetches past its slice
+    C.queryH = (uint4*)take(vpad * 224 + 2 * 7168);
     C.nb_row = (int*)take((size_t)max_voxels * 4);
     C.nb_start = (int*)take((NORM_BINS + 2) * 4);
     C.norms = (float*)take((size_t)max_voxels * 4);
@@ -1325,9 +1329,10 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.hit_rows = (int*)take((size_t)max_voxels * 4);
   F.queryT_c = (float*)take(34 * (((size_t)max_voxels + 511) / 512 * 512) * 4);
   F.norms_c = (float*)take((((size_t)max_voxels + 511) / 512 * 512) * 4);
+  F.queryH_c = (uint4*)take((((size_t)max_voxels + 511) / 512 * 512) * 224 + 2 * 7168);
   {
     const char* e = getenv("QTR_NN_ENGINE");
-    F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : 1;
+    F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "mfma32") == 0) ? 1 : 2;
     const char* w = getenv("QTR_NN_WAVES");
     F.nn_target_waves = (w && atoi(w) > 0) ? atoi(w) : 0;
     const char* tr = getenv("QTR_NN_TRACE");

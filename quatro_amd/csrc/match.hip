@@ -377,6 +377,8 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
     // by noticing that best changed.  The <16 ulp perturbation is part of the rounding bound of the finish.
     float b1[4], b2[4];
     int it1[4];  // tile of the best
+    float ninf = -INFINITY;
+    asm volatile("" : "+v"(ninf));  // opaque: med3(best, v, -inf) stays ONE v_med3 (a literal folds to canonicalise + min)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       b1[c] = b2[c] = INFINITY;
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
         for (int r = 0; r < 16; ++r) {
           const float v = __uint_as_float((__float_as_uint(acc[c][r]) & 0xfffffff0u) | (u32)r);
           b2[c] = __builtin_amdgcn_fmed3f(b1[c], b2[c], v);
-          b1[c] = __builtin_amdgcn_fmed3f(b1[c], v, -INFINITY);
+          b1[c] = __builtin_amdgcn_fmed3f(b1[c], v, ninf);
         }
         it1[c] = (b1[c] != before) ? t : it1[c];
       }
@@ -447,11 +449,182 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
   }
 }
 
+// =================================================================================================
+// f16-split engine (the default).  On gfx950 v_mfma_f32_32x32x2_f32 and the VALU exclude each other — a wave's (and a
+// SIMD's) FP32 matrix instructions and vector instructions add up, they do not overlap (tests/probe/gen_probe3.py:
+// 4352 clocks of MFMA + 880 of fold = 5230 per tile however the two are interleaved, one or two waves per SIMD) — while
+// v_mfma_f32_32x32x16_f16 runs on the matrix cores proper: 32 clocks each, and VALU work interleaved with it is hidden.
+// The filter therefore evaluates v = nb' - 2 a.b on the f16 pipe with every f32 operand split in two halves:
+//     x^ = S x,  x1 = RN16(x^),  x2 = RN16(x^ - x1),   x^ = x1 + x2 + dx,  |dx| <= max(2^-22 |x^|, 2^-14)
+// (the second alternative covers a subnormal x2, whether or not the hardware flushes it), S = 128 for base rows, -2S for
+// queries, and a.b ~ sum (b1 q1 + b2 q1 + b1 q2): 3 x 33 products, plus three slots that carry nb' = c1 + c2 + c3 (f16
+// pieces) against the constant S^2 = 16384: K = 102, padded to 112 = 7 MFMAs per accumulator instead of 17 at half the
+// issue time — 896 clocks of matrix work per tile instead of 4352, with the 3-VALU-per-value fold riding under it.
+// Every product of two f16 numbers is exact in f32; the accumulation inside and across the 7 MFMAs was measured at
+// <= 5.5 u sum|terms| on adversarial exponents (3.0 u on histogram-like data; same probe) and is budgeted at 16 u.
+//
+// Rounding bound, unscaled (u = 2^-24):  |V / S^2 - (nb' - 2 a.b)| <=
+//     12.1u (|a|^2 + |b|^2)   dropped products b2 q2, db q, b dq (3 x 2^-22 |b^ q^| each, Cauchy-Schwarz)
+//   + 16.1u (|a|^2 + 2|b|^2)  accumulation, sum|terms| / S^2 <= nb' + 2|a||b| (1 + 2^-10)
+//   + 32u   (|a|^2 + 2|b|^2)  the accumulator-register index in the four low mantissa bits
+//   + 8u (33 + |a|^2) + 4u (33 + |b|^2)   subnormal second halves: 2^-14 (sum|q^| + sum|b^|) / S^2, |x| <= (1 + x^2)/2
+//   <= 69u |a|^2 + 114u |b|^2 + 396u
+// against 66u |a|^2 + 132u |b|^2 of the f32 chain: the same certification inequality holds with + 800u on the right-hand
+// side (k_nn_finish).  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
+// -256 x) and every |b|^2 < 65000 (f16 range of the norm pieces); a pair that violates them (not an FPFH descriptor:
+// those are bounded by 100) sets MC_UNSAFE and k_nn_finish sends all of its rows to the exact re-check.
+// Hidden / pad rows carry 3 x 65504 in the norm slots (196512 > any real nb').
+//
+// Operand layout (both operands): 32 rows form a tile; a row's 112 halves are cut into 14 chunks of 8 (chunk 2m+g is
+// what lane group g = lane/32 feeds to MFMA m); a tile stores chunk-major, [tile][14][32 rows] x 16 bytes, so that a
+// fragment load is one coalesced 16-byte load per lane.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define NNH_CHUNKS 14
+#define NNH_S 128.0f
+#define NNH_UNSCALE 6.103515625e-05f  // 1 / S^2 = 2^-14
+
+struct HalfRow {
+  _Float16 h1[33], h2[33];
+};
+__device__ __forceinline__ void half_split(const float* v, float scale, HalfRow& o) {
+#pragma unroll
+  for (int k = 0; k < 33; ++k) {
+    const float xs = v[k] * scale;  // exact: power of two
+    const _Float16 a = (_Float16)xs;
+    o.h1[k] = a;
+    o.h2[k] = (_Float16)(xs - (float)a);
+  }
+}
+// slot s of the base role / the query role (compile-time s after unrolling)
+__device__ __forceinline__ _Float16 base_slot(const HalfRow& b, const _Float16* c, int s) {
+  return s < 33 ? b.h1[s] : s < 66 ? b.h2[s - 33] : s < 99 ? b.h1[s - 66] : s < 102 ? c[s - 99] : (_Float16)0.f;
+}
+__device__ __forceinline__ _Float16 query_slot(const HalfRow& q, int s) {
+  return s < 33 ? q.h1[s] : s < 66 ? q.h1[s - 33] : s < 99 ? q.h2[s - 66] : s < 102 ? (_Float16)16384.f : (_Float16)0.f;
+}
+__device__ __forceinline__ void d_half_tables(const float* __restrict__ baseT, const float* __restrict__ norms, int n,
+                                              int n_pad, uint4* __restrict__ baseH, uint4* __restrict__ queryH,
+                                              int* __restrict__ unsafe) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pad) return;
+  float v[33];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 33; ++k) {
+    v[k] = baseT[(size_t)k * n_pad + i];
+    bad = bad || !(fabsf(v[k]) <= 255.0f);
+  }
+  const float nbp = baseT[(size_t)33 * n_pad + i];  // scaled-down |b|^2; 1e30: hidden duplicate or pad row
+  if (i < n) bad = bad || !(norms[i] < 65000.0f);
+  if (bad) *unsafe = 1;
+  _Float16 c[3];
+  if (!(nbp < 65000.0f)) {
+    c[0] = c[1] = c[2] = (_Float16)65504.f;
+  } else {
+    c[0] = (_Float16)nbp;
+    const float r1 = nbp - (float)c[0];
+    c[1] = (_Float16)r1;
+    c[2] = (_Float16)(r1 - (float)c[1]);
+  }
+  HalfRow hb, hq;
+  half_split(v, NNH_S, hb);
+  half_split(v, -2.0f * NNH_S, hq);
+  const size_t t0 = ((size_t)(i >> 5) * NNH_CHUNKS) * 32 + (i & 31);
+#pragma unroll
+  for (int ch = 0; ch < NNH_CHUNKS; ++ch) {
+    h8 b8, q8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      b8[e] = base_slot(hb, c, 8 * ch + e);
+      q8[e] = query_slot(hq, 8 * ch + e);
+    }
+    ((h8*)baseH)[t0 + (size_t)ch * 32] = b8;
+    ((h8*)queryH)[t0 + (size_t)ch * 32] = q8;
+  }
+}
+// after k_desc_dedup (hidden rows already carry 1e30 in the norm row).  grid (pad_large_max / 256, 2, pairs)
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  if (blockIdx.y == 0)
+    d_half_tables(V.baseT_i, V.norms_i, V.n_large, V.pad_large, V.baseH_i, V.queryH_i, V.mcounts + MC_UNSAFE);
+  else
+    d_half_tables(V.baseT_j, V.norms_j, V.n_small, V.pad_small, V.baseH_j, V.queryH_j, V.mcounts + MC_UNSAFE);
+}
+
+// Same items, queue and partial records as k_nn_mfma.  Per wave: 4 x 32 stationary query columns (4 x 7 fragments of
+// 16 bytes, in AGPRs), TWO accumulator sets — the 28 MFMAs of a tile go to one set while the 64 values the previous
+// tile left in the other set are folded into the running top-2 in the shadow of the matrix instructions.  The inner
+// loop is the hand-scheduled block of nn_f16_core.inc (generated by gen_nn_f16_core.py: register map, schedule and the
+// wait states it has to respect are documented there).  ~250 VGPRs + 112 AGPRs: one workgroup per compute unit.
+#include "nn_f16_core.inc"
+template <bool EXT>
+__global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G) {
+  NN_PLAN(G, dir, (int)gridDim.x)
+  __shared__ int s_item;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  int* counter = (EXT ? x.ext[0].mcounts : one.mcounts) + 14 + dir;  // zeroed by k_match_init
+  const int total = s_off[G];
+#pragma unroll 1
+  while (true) {
+    if (threadIdx.x == 0) s_item = atomicAdd(counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();
+    if (item >= total) break;
+    int g = 0;
+    while (g + 1 < G && item >= s_off[g + 1]) ++g;
+    const MatchView& V = EXT ? x.ext[g] : one;  // (inline on purpose: see ViewExt)
+    const NnDir& D = V.d[dir];
+    const int ntiles = D.nb_pad / 32;
+    const int nsplit = s_ns[g], tps = s_tps[g];
+    NnPartial* __restrict__ partial = V.partial;
+    const int local = item - s_off[g];
+    const int qb = local / nsplit, slice = local - qb * nsplit;
+    const int qbase = (qb * 4 + wave) * NN_QPW + col;
+    const int t_begin = slice * tps, t_end = min(ntiles, t_begin + tps);
+    float b1[4], b2[4];
+    int it1[4];  // tile of the best
+    if (t_begin < t_end) {
+      nn_f16_core(D.queryH + (size_t)((qb * 4 + wave) * 4) * (NNH_CHUNKS * 32), D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32),
+                  t_end - t_begin, t_begin, ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        b1[c] = b2[c] = INFINITY;
+        it1[c] = -1;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // decode the best's row, then merge the two lanes (half 0 / half 1) that own the same query column
+      const int r = (int)(__float_as_uint(b1[c]) & 15u);
+      int row = (it1[c] < 0) ? -1 : (it1[c] * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
+      const float ob1 = __shfl_xor(b1[c], 32, 64), ob2 = __shfl_xor(b2[c], 32, 64);
+      const int orow = __shfl_xor(row, 32, 64);
+      const bool take = (ob1 < b1[c]) || (ob1 == b1[c] && orow >= 0 && (row < 0 || orow < row));
+      const float nb2 = fminf(fminf(b2[c], ob2), take ? b1[c] : ob1);
+      const float nb1 = take ? ob1 : b1[c];
+      row = take ? orow : row;
+      if (half == 0) {
+        NnPartial p;
+        p.b1 = nb1 * NNH_UNSCALE;  // exact (power of two): the finish works in unscaled units
+        p.b2 = nb2 * NNH_UNSCALE;
+        p.i1 = row;
+        p.pad = 0;
+        partial[(size_t)(qbase + 32 * c) * nsplit + slice] = p;
+      }
+    }
+  }
+}
+
 // Merge the per-slice partials and decide each query: certified (see the header comment) or listed for the exact
 // re-check.  X = gridDim.x of the k_nn_mfma launch it follows.  grid (ceil(nq_max/256), 1, pairs).
 #define NN_FIN_THREADS 512
 template <bool EXT>
-__global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G) {
+__global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G,
+                                                              float cadd) {
   NN_PLAN(G, dir, X)
   __shared__ int s_w[16], s_base;
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -483,7 +656,10 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
   const float u = 5.9604645e-08f;
   const float d1 = fmaxf(na + b1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
   const float d2 = (b2 < INFINITY) ? fmaxf(na + b2, 0.f) + 1.0f : d1;
-  const float gap = u * (144.0f * na + 280.0f * nb1 + 40.0f * (d1 + d2)) * 1.01f;
+  // cadd: the engine's constant term (f16-split engine: 800; see its header comment)
+  const float gap = u * (144.0f * na + 280.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;
+  const bool unsafe = V.mcounts[MC_UNSAFE] != 0;  // descriptor values outside the f16 engine's range: everything is re-checked
+  if (unsafe) i1 = -1;
   const bool certified = i1 >= 0 && (b2 == INFINITY || b2 - b1 > gap);
   const bool listed = valid && !certified;
   if (valid) D.best[row] = certified ? (u64)(u32)i1 : ~0ULL;
@@ -507,7 +683,7 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
     V.recheck_rows[slot] = row;
     // a base row whose approximate (lower-bound) value exceeds this cannot be the exact arg-min; +inf when the slice
     // merge found nothing
-    const float thr = (i1 >= 0) ? b1 + u * (144.0f * na + 280.0f * nb1 + 80.0f * d1) * 1.02f + 1e-30f : INFINITY;
+    const float thr = (i1 >= 0) ? b1 + u * (144.0f * na + 280.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
     V.recheck_thr[slot] = thr;
     // columns of the norm-bin order that can hold the arg-min: |sqrt|b|^2 - sqrt|a|^2| <= sqrt(d) and d <= |a|^2~ + thr
     // (+ the rounding slack of the bound above, norms rounded to float: 0.02 and 0.1 % cover both generously)
@@ -718,7 +894,12 @@ __global__ __launch_bounds__(256) void k_hit_gather(ViewExt<MatchView> x, MatchV
 #pragma unroll
     for (int k = 0; k < 34; ++k) V.queryT_c[(size_t)k * pad + c] = V.queryT_i[(size_t)k * pad + r];
     V.norms_c[c] = V.norms_i[r];
+#pragma unroll
+    for (int ch = 0; ch < NNH_CHUNKS; ++ch)
+      V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = V.queryH_i[((size_t)(r >> 5) * NNH_CHUNKS + ch) * 32 + (r & 31)];
   } else {
+#pragma unroll
+    for (int ch = 0; ch < NNH_CHUNKS; ++ch) V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 33; ++k) V.queryT_c[(size_t)k * pad + c] = 0.f;
     V.queryT_c[(size_t)33 * pad + c] = 1.0f;
@@ -1131,6 +1312,11 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.norms_j = Cj.norms;
   V.baseTb_i = Ci.baseTb;
   V.baseTb_j = Cj.baseTb;
+  V.baseH_i = Ci.baseH;
+  V.baseH_j = Cj.baseH;
+  V.queryH_i = Ci.queryH;
+  V.queryH_j = Cj.queryH;
+  V.queryH_c = F.queryH_c;
   V.nb_row_i = Ci.nb_row;
   V.nb_row_j = Cj.nb_row;
   V.nb_start_i = Ci.nb_start;
@@ -1182,6 +1368,8 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   d0.nb = V.n_large;
   d0.nb_pad = V.pad_large;
   d0.queryT = Cj.queryT;
+  d0.baseH = Ci.baseH;
+  d0.queryH = Cj.queryH;
   d0.qnorm = Cj.norms;
   d0.qmap = nullptr;
   d0.nq_pad = V.pad_small;
@@ -1201,6 +1389,8 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   d1.nb = V.n_small;
   d1.nb_pad = V.pad_small;
   d1.queryT = F.queryT_c;
+  d1.baseH = Cj.baseH;
+  d1.queryH = F.queryH_c;
   d1.qnorm = F.norms_c;
   d1.qmap = F.hit_rows;
   d1.nq_pad = V.pad_large;
@@ -1265,13 +1455,22 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
     LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
-    const int X = n_cu;  // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second)
+    const bool f16 = nn_engine == 2;
+    if (f16) LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+    // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second).
+    // QTR_NN_WGS_PER_CU = 2 (experiment knob) launches both from this chain.
+    static const int wgs_per_cu = [] {
+      const char* e = getenv("QTR_NN_WGS_PER_CU");
+      return (e && atoi(e) == 2) ? 2 : 1;
+    }();
+    const int X = n_cu * wgs_per_cu;
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0) (void)hipEventRecord(e0, st);
-      LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+      if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+      else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
       if (e1) (void)hipEventRecord(e1, st);
       LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
-                G);
+                G, f16 ? 800.0f : 0.0f);
       // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
       (void)nb_max;
       // (most spans are a fraction of a per cent of the cloud, a few cover half of it: enough slices that the widest

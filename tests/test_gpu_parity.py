@@ -298,29 +298,70 @@ def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path, pcl_
     assert final == o["final_inliers"].tolist()
 
 
+def _nn_tables(engine, vs, ds, vt, dt, seed=4):
+    if engine:
+        os.environ["QTR_NN_ENGINE"] = engine
+    try:
+        h = ql.Handle(0)
+    finally:
+        os.environ.pop("QTR_NN_ENGINE", None)
+    corr = h.match(vs, ds, vt, dt, ql.default_frontend_params(seed=seed))
+    out = (corr, h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32), h.debug_fetch(ql.DBG_NN_SMALL_OF_LARGE, np.int32),
+           h.debug_fetch(ql.DBG_MATCH_STATS, np.int32))
+    h.close()
+    return out
+
+
 def test_nn_engines_produce_identical_tables(qo, small_pair):
-    """MFMA engine (+ exact re-check of uncertified rows) vs the all-exact VALU engine: same tables, and the
-    re-check fraction stays small."""
+    """The three nearest-neighbour engines — f16-split MFMA filter (default), f32 MFMA filter, all-exact VALU — give the
+    same tables (the filters certify most rows and hand the rest to the exact re-check), and the re-check fraction stays
+    small."""
     s, t, _ = small_pair
     vs, vt = qo.voxelize(s, 0.3), qo.voxelize(t, 0.3)
     _, _, ds = qo.fpfh(vs, 0.5, 0.75)
     _, _, dt = qo.fpfh(vt, 0.5, 0.75)
-    tables = {}
-    for engine in ("exact", "mfma"):
-        os.environ["QTR_NN_ENGINE"] = engine
-        try:
-            h = ql.Handle(0)
-        finally:
-            os.environ.pop("QTR_NN_ENGINE", None)
-        corr = h.match(vs, ds, vt, dt, ql.default_frontend_params(seed=4))
-        tables[engine] = (corr, h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32),
-                          h.debug_fetch(ql.DBG_NN_SMALL_OF_LARGE, np.int32),
-                          h.debug_fetch(ql.DBG_MATCH_STATS, np.int32))
-        h.close()
-    for a, b in zip(tables["exact"][:3], tables["mfma"][:3]):
+    tables = {e: _nn_tables(e, vs, ds, vt, dt) for e in ("exact", "mfma32", "")}
+    for e in ("mfma32", ""):
+        for a, b in zip(tables["exact"][:3], tables[e][:3]):
+            assert np.array_equal(a, b), e
+        stats = tables[e][3]
+        assert stats[12] == 0  # descriptor values inside the f16 engine's range
+        assert stats[8] + stats[9] < 0.2 * (vs.shape[0] + vt.shape[0]), e  # rows that needed the exact re-check
+
+
+@pytest.mark.parametrize("case", ["big_values", "big_norm", "tiny_values", "wide_range", "near_ties"])
+def test_f16_filter_holds_on_adversarial_descriptors(qo, case):
+    """The f16-split filter's rounding bound and range guard on descriptors that are nothing like FPFH histograms: values
+    outside the f16 range (every row must go to the exact re-check), norms outside it, values far below the f16 normal
+    range, twelve orders of magnitude inside one cloud, and clusters of near-identical rows.  Tables equal the all-exact
+    engine's."""
+    g = np.random.default_rng({"big_values": 1, "big_norm": 2, "tiny_values": 3, "wide_range": 4, "near_ties": 5}[case])
+    ns, nt = 1500, 1700
+    vs = np.zeros((ns, 4), np.float32)
+    vt = np.zeros((nt, 4), np.float32)
+    vs[:, :3] = g.uniform(-20, 20, (ns, 3))
+    vt[:, :3] = g.uniform(-20, 20, (nt, 3))
+    if case == "big_values":
+        ds = g.uniform(0, 900, (ns, 33)).astype(np.float32)
+        dt = g.uniform(0, 900, (nt, 33)).astype(np.float32)
+    elif case == "big_norm":
+        ds = g.uniform(0, 250, (ns, 33)).astype(np.float32)  # values in range, |b|^2 ~ 7e5 is not
+        dt = g.uniform(0, 250, (nt, 33)).astype(np.float32)
+    elif case == "tiny_values":
+        ds = (g.uniform(0, 1, (ns, 33)) * 1e-6).astype(np.float32)
+        dt = (g.uniform(0, 1, (nt, 33)) * 1e-6).astype(np.float32)
+    elif case == "wide_range":
+        ds = (10.0 ** g.uniform(-10, 2, (ns, 33))).astype(np.float32)
+        dt = (10.0 ** g.uniform(-10, 2, (nt, 33))).astype(np.float32)
+    else:
+        centres = g.uniform(0, 40, (40, 33))
+        ds = (centres[g.integers(0, 40, ns)] * (1 + 1e-7 * g.integers(-3, 4, (ns, 33)))).astype(np.float32)
+        dt = (centres[g.integers(0, 40, nt)] * (1 + 1e-7 * g.integers(-3, 4, (nt, 33)))).astype(np.float32)
+    ref = _nn_tables("exact", vs, ds, vt, dt)
+    got = _nn_tables("", vs, ds, vt, dt)
+    for a, b in zip(ref[:3], got[:3]):
         assert np.array_equal(a, b)
-    stats = tables["mfma"][3]
-    assert stats[8] + stats[9] < 0.2 * (vs.shape[0] + vt.shape[0])  # rows that needed the exact re-check
+    assert (got[3][12] != 0) == (case in ("big_values", "big_norm"))
 
 
 def test_stream_slots_run_concurrently_and_agree(qo):
