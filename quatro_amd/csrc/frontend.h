@@ -7,7 +7,8 @@
 #define NORM_BINS 192       // bins of width 1 over sqrt(|descriptor|^2) (<= sqrt(3 * 100^2) = 173.3)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
-enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5 };
+enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5,
+       CNT_SORT_BITS = 6 /* significant bits of the voxel sort's keys */ };
 // matcher device counters (FrontBufs::mcounts, 16 ints)
 // MC_RECHECKx: rows sent to the exact re-check; MC_RECHECKx + 2: rows settled by the two-candidate exact compare
 // MC_NQ0 / MC_NHIT: query counts of the two nearest-neighbour directions (device-side: the second direction only asks

@@ -76,6 +76,10 @@ __device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, 
 // ballot match masks and in-order LDS updates (no barriers).  Used with key = (cell index << 32) |
 // point index on inputs that are already in ascending point-index order, so equal cells keep ascending
 // point order — the accumulation order the oracle defines for pcl::VoxelGrid centroids.
+// The three histogram buffers of a sort rotate: pass p reads H[p % 3] (tile-major rows of 256 counters), adds the NEXT
+// pass's histogram into H[(p + 1) % 3] while it scatters (each key's destination tile and next digit are known at that
+// point: one fire-and-forget global atomic per key instead of a histogram launch per pass) and clears its tile's row of
+// H[(p + 2) % 3].  Only the first pass has a histogram kernel of its own.
 template <int BITS, int TILE>
 __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
                                                    int nblk) {
@@ -83,6 +87,8 @@ __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, 
   __shared__ u32 cnt[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
   if (blk >= nblk) return;
+  ((uint4*)(hist + ((size_t)nblk + blk) * NB))[lane] = make_uint4(0, 0, 0, 0);      // H[1], H[2]: rows of this tile
+  ((uint4*)(hist + ((size_t)2 * nblk + blk) * NB))[lane] = make_uint4(0, 0, 0, 0);
   for (int d = lane; d < NB; d += 64) cnt[d] = 0;
   __syncthreads();
   const int base = blk * TILE;
@@ -110,11 +116,14 @@ __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, 
 
 template <int BITS, int TILE>
 __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
-                                                      int shift, const u32* __restrict__ hist, int nblk) {
+                                                      int shift, const u32* __restrict__ hist, int nblk,
+                                                      u32* __restrict__ hist_next /* or null: last pass */,
+                                                      u32* __restrict__ hist_clear /* or null */) {
   constexpr int NB = 1 << BITS;
   __shared__ u32 base[NB];
   const int lane = threadIdx.x, blk = blockIdx.x;
   if (blk >= nblk) return;
+  if (hist_clear) ((uint4*)(hist_clear + (size_t)blk * NB))[lane] = make_uint4(0, 0, 0, 0);
   // offsets from the RAW per-tile histograms (no separate scan launch): digit d of this tile starts at
   //   sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d]        (rows are tile-major: one 16-byte load per tile)
   {
@@ -172,6 +181,7 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
     if (valid) {
       const u32 pos = base[d] + (u32)__popcll(m & lanemask_lt());
       out[pos] = key;
+      if (hist_next) atomicAdd(&hist_next[(size_t)(pos / TILE) * NB + ((u32)(key >> (shift + BITS)) & (u32)(NB - 1))], 1u);
     }
     __syncthreads();  // single-wave workgroup: orders the LDS reads above before the updates below
     if (valid && (m & lanemask_lt()) == 0) base[d] += (u32)__popcll(m);
@@ -266,7 +276,11 @@ __device__ __forceinline__ void d_vox_keys(const float4* __restrict__ pts, int P
                                                   const u32* __restrict__ mm, u64* __restrict__ keys,
                                                   int* __restrict__ counts) {
   const VoxGrid g = vox_grid(mm, leaf);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && g.overflow) counts[CNT_VOX_OVERFLOW] = 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (g.overflow) counts[CNT_VOX_OVERFLOW] = 1;
+    const long long cells = (long long)g.divb[0] * g.divb[1] * g.divb[2];  // every key is below this
+    counts[CNT_SORT_BITS] = (g.overflow || cells <= 1) ? (g.overflow ? 32 : 1) : 64 - __clzll(cells - 1);
+  }
   const int mul1 = g.divb[0], mul2 = g.divb[0] * g.divb[1];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
     const float4 p = pts[i];
@@ -790,88 +804,168 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   return true;
 }
 
+// SPFH of a block of SPFH_PB consecutive points per workgroup.  The work is one Darboux-frame evaluation per (point,
+// neighbour) pair — two arc cosines and an arc tangent in binary64-based software — and a point has ~18 neighbours: one
+// wavefront per point leaves 70 % of the lanes idle.  The block's pairs are therefore dealt to the 256 threads as one
+// flat list (prefix of the neighbour counts in LDS); hits are integer counts per (point, bin) in LDS, so the order in
+// which pairs are evaluated cannot matter, and the histogram is rebuilt as `count` additions of hist_incr like the
+// reference's accumulation.
+#define SPFH_PB 32
 __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const float4* __restrict__ normals, int n,
                                              const int* __restrict__ nbr_cnt, const int* __restrict__ nbr_idx,
                                              float* __restrict__ spfh) {
-  __shared__ int cnt[33];
-  const int lane = threadIdx.x, i = blockIdx.x;
-  if (i >= n) return;
-  if (lane < 33) cnt[lane] = 0;
-  __syncthreads();
-  const int k = nbr_cnt[i];
-  const float hist_incr = 100.0f / (float)(k - 1);
-  const float d_pi = 1.0f / (2.0f * (float)M_PI);
-  const float4 p = pts[i], np = normals[i];
-  for (int t = lane; t < k; t += 64) {
-    const int j = nbr_idx[(size_t)i * QTR_KMAX + t];
-    if (j == i) continue;
-    float f[3];
-    if (!dev_pair_features(p, np, pts[j], normals[j], f)) continue;
-    atomicAdd(&cnt[bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))], 1);
-    atomicAdd(&cnt[11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))], 1);
-    atomicAdd(&cnt[22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))], 1);
+  __shared__ int cnt[SPFH_PB][33];
+  __shared__ int s_off[SPFH_PB + 1], s_k[SPFH_PB];
+  __shared__ float4 s_p[SPFH_PB], s_n[SPFH_PB];
+  const int tid = threadIdx.x, i0 = blockIdx.x * SPFH_PB;
+  if (i0 >= n) return;
+  const int np = min(SPFH_PB, n - i0);
+  for (int e = tid; e < SPFH_PB * 33; e += 256) (&cnt[0][0])[e] = 0;
+  if (tid < 64) {
+    const int k = (tid < np) ? nbr_cnt[i0 + tid] : 0;
+    int tot;
+    const int ex = wave_excl_scan_i32(k, &tot);
+    if (tid < SPFH_PB) {
+      s_off[tid] = ex;
+      s_k[tid] = k;
+      if (tid < np) {
+        s_p[tid] = pts[i0 + tid];
+        s_n[tid] = normals[i0 + tid];
+      }
+    }
+    if (tid == 0) s_off[SPFH_PB] = tot;
   }
   __syncthreads();
-  if (lane < 33) {
+  const int total = s_off[SPFH_PB];
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
+  for (int t = tid; t < total; t += 256) {
+    int pi = 0;  // the point this pair belongs to: largest pi with s_off[pi] <= t (5 halvings of 32)
+#pragma unroll
+    for (int step = SPFH_PB / 2; step > 0; step >>= 1) pi += (s_off[pi + step] <= t) ? step : 0;
+    const int i = i0 + pi;
+    const int j = nbr_idx[(size_t)i * QTR_KMAX + (t - s_off[pi])];
+    if (j == i) continue;
+    float f[3];
+    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f)) continue;
+    atomicAdd(&cnt[pi][bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))], 1);
+    atomicAdd(&cnt[pi][11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))], 1);
+    atomicAdd(&cnt[pi][22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))], 1);
+  }
+  __syncthreads();
+  for (int e = tid; e < np * 33; e += 256) {
+    const int pi = e / 33, b = e - pi * 33;
+    const float hist_incr = 100.0f / (float)(s_k[pi] - 1);
     float h = 0.f;
-    const int c = cnt[lane];
+    const int c = cnt[pi][b];
     for (int q = 0; q < c; ++q) h += hist_incr;
-    spfh[(size_t)i * 33 + lane] = h;
+    spfh[(size_t)(i0 + pi) * 33 + b] = h;
   }
 }
 
-// K4  FPFH weighting (weightPointSPFHSignature).  Lanes 0..32 own one histogram bin each and add the
-// neighbours' contributions in list order; lanes 33..35 own the three binary64 normalisation sums,
-// each adding its 11 per-neighbour terms in the reference's nested (neighbour, bin) order.
-#define FPFH_CHUNK 16
+// K4  FPFH weighting (weightPointSPFHSignature).  A workgroup serves FPFH_PB = 7 points: thread (point, bin) adds the
+// neighbours' weighted SPFH values in list order (binary32, the reference's accumulation order); the neighbour indices
+// and weights of a chunk are staged in LDS by one thread each.
+// The three binary64 normalisation sums are, in the reference, one nested (neighbour, bin) loop each — a chain of
+// 11 * k dependent additions.  Every term is a non-negative binary32 value; when the largest and the smallest non-zero
+// term of a block are at most 17 binary exponents apart, every partial sum of up to 2816 of them is exactly
+// representable in binary64 (2816 < 2^12, 24 + 12 + 17 = 53), so ANY summation order gives the reference's bits: the
+// threads then keep private binary64 sums and add them up at the end.  Otherwise (not seen on lidar data; covered by a
+// test) one thread per block redoes the sum in the reference's order.
+#define FPFH_PB 7
+#define FPFH_CHUNK 32
 __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
                                              const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
                                              float* __restrict__ fpfh) {
-  __shared__ float rows[FPFH_CHUNK][33];
-  __shared__ float wts[FPFH_CHUNK];
-  __shared__ double sums[3];
-  const int lane = threadIdx.x, i = blockIdx.x;
-  if (i >= n) return;
-  const int k = nbr_cnt[i];
-  float h = 0.f;
-  double sum = 0.0;
-  for (int t0 = 0; t0 < k; t0 += FPFH_CHUNK) {
-    const int m = min(FPFH_CHUNK, k - t0);
+  __shared__ int s_idx[FPFH_PB][FPFH_CHUNK];
+  __shared__ float s_w[FPFH_PB][FPFH_CHUNK];  // 1 / d^2, or 0 for an entry the reference skips (d^2 == 0)
+  __shared__ int s_k[FPFH_PB];
+  __shared__ double s_part[FPFH_PB][33];
+  __shared__ float s_vmin[FPFH_PB][33], s_vmax[FPFH_PB][33];
+  const int tid = threadIdx.x, i0 = blockIdx.x * FPFH_PB;
+  if (i0 >= n) return;
+  const int np = min(FPFH_PB, n - i0);
+  const int pi = tid / 33, b = tid - pi * 33;      // this thread's (point, bin); tid >= 231: staging only
+  const bool owner = pi < np;
+  const int lp = tid >> 5, lq = tid & 31;          // staging role: (point, entry of the chunk); 7 x 32 = 224 threads
+  if (tid < FPFH_PB) s_k[tid] = (tid < np) ? nbr_cnt[i0 + tid] : 0;
+  __syncthreads();
+  int kmax = 0;
+#pragma unroll
+  for (int q = 0; q < FPFH_PB; ++q) kmax = max(kmax, s_k[q]);
+  const int k = owner ? s_k[pi] : 0;
+  float h = 0.f, vmin = INFINITY, vmax = 0.f;
+  double part = 0.0;
+  for (int t0 = 0; t0 < kmax; t0 += FPFH_CHUNK) {
     __syncthreads();
-    for (int e = lane; e < m * 33; e += 64) {
-      const int q = e / 33, b = e - q * 33;
-      rows[q][b] = spfh[(size_t)nbr_idx[(size_t)i * QTR_KMAX + t0 + q] * 33 + b];
-    }
-    if (lane < m) {
-      const float d2 = nbr_d2[(size_t)i * QTR_KMAX + t0 + lane];
-      wts[lane] = (d2 == 0) ? 0.f : 1.0f / d2;
-      if (d2 == 0) wts[lane] = -1.f;  // marker: skip (weights are otherwise positive)
-    }
-    __syncthreads();
-    if (lane < 33) {
-      for (int q = 0; q < m; ++q) {
-        const float w = wts[q];
-        if (w < 0.f) continue;
-        h += rows[q][lane] * w;
+    if (lp < FPFH_PB) {
+      int j = 0;
+      float w = 0.f;
+      if (lp < np && t0 + lq < s_k[lp]) {
+        j = nbr_idx[(size_t)(i0 + lp) * QTR_KMAX + t0 + lq];
+        const float d2 = nbr_d2[(size_t)(i0 + lp) * QTR_KMAX + t0 + lq];
+        w = (d2 == 0) ? 0.f : 1.0f / d2;
       }
-    } else if (lane < 36) {
-      const int blk = lane - 33;
-      for (int q = 0; q < m; ++q) {
-        const float w = wts[q];
-        if (w < 0.f) continue;
-        for (int c = 0; c < 11; ++c) {
-          const float val = rows[q][11 * blk + c] * w;
-          sum += val;
+      s_idx[lp][lq] = j;
+      s_w[lp][lq] = w;
+    }
+    __syncthreads();
+    if (owner) {
+      const int m = min(FPFH_CHUNK, k - t0);
+      for (int q0 = 0; q0 < m; q0 += 4) {
+        float x[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four independent gathers in flight (entries past m are staged as row 0, weight 0)
+          w[u] = s_w[pi][q0 + u];
+          x[u] = spfh[(size_t)s_idx[pi][q0 + u] * 33 + b];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (q0 + u < m && w[u] != 0.f) {
+            const float val = x[u] * w[u];
+            h += val;
+            part += (double)val;
+            vmax = fmaxf(vmax, val);
+            vmin = (val > 0.f) ? fminf(vmin, val) : vmin;
+          }
         }
       }
     }
   }
-  if (lane >= 33 && lane < 36) {
-    if (sum != 0) sum = 100.0 / sum;
-    sums[lane - 33] = sum;
+  if (owner) {
+    s_part[pi][b] = part;
+    s_vmin[pi][b] = vmin;
+    s_vmax[pi][b] = vmax;
   }
   __syncthreads();
-  if (lane < 33) fpfh[(size_t)i * 33 + lane] = h * (float)sums[lane / 11];
+  if (!owner) return;
+  const int blk = b / 11;
+  double sum = 0.0;
+  float lo = INFINITY, hi = 0.f;
+#pragma unroll
+  for (int c = 0; c < 11; ++c) {
+    sum += s_part[pi][11 * blk + c];
+    lo = fminf(lo, s_vmin[pi][11 * blk + c]);
+    hi = fmaxf(hi, s_vmax[pi][11 * blk + c]);
+  }
+  // exponent fields (denormals count as exponent 1: their unit in the last place is that of the smallest normal)
+  const int e_hi = (int)((__float_as_uint(hi) >> 23) & 255u), e_lo = max(1, (int)((__float_as_uint(lo) >> 23) & 255u));
+  const bool exact = !(hi > 0.f) || (hi < INFINITY && e_hi - e_lo <= 17);
+  if (!exact) {  // the reference's nested order, straight from memory
+    sum = 0.0;
+    const int i = i0 + pi;
+    for (int q = 0; q < k; ++q) {
+      const float d2 = nbr_d2[(size_t)i * QTR_KMAX + q];
+      if (d2 == 0) continue;
+      const float w = 1.0f / d2;
+      const float* row = spfh + (size_t)nbr_idx[(size_t)i * QTR_KMAX + q] * 33 + 11 * blk;
+      for (int c = 0; c < 11; ++c) {
+        const float val = row[c] * w;
+        sum += val;
+      }
+    }
+  }
+  if (sum != 0) sum = 100.0 / sum;
+  fpfh[(size_t)(i0 + pi) * 33 + b] = h * (float)sum;
 }
 
 // Matcher::normalizePoints mean (reference src/teaser_utils/feature_matcher.cc:27-36): a plain
@@ -973,15 +1067,34 @@ __global__ __launch_bounds__(64) void k2_radix_hist(ViewExt<CloudView> x, Clouds
   const int n = use_vox ? C.n : C.P;
   d_radix_hist<8, RADIX_TILE>(keys_src(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
 }
+// pass: 0-based; last: no pass follows; adaptive: the keys carry C.counts[CNT_SORT_BITS] significant bits (known on the
+// device only) and a pass whose digit lies wholly above them is skipped — the consumers pick the buffer with
+// sorted_src() below
 template <bool EXT>
-__global__ __launch_bounds__(64) void k2_radix_scatter(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
+__global__ __launch_bounds__(64) void k2_radix_scatter(ViewExt<CloudView> x, Clouds2 a, int use_vox, int pass, int last,
+                                                      int adaptive) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
-  d_radix_scatter<8, RADIX_TILE>(keys_src(C, src), keys_dst(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
+  const int nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
+  if (adaptive && 8 * pass >= C.counts[CNT_SORT_BITS] && pass > 0) return;
+  const bool final_pass = last || (adaptive && 8 * (pass + 1) >= C.counts[CNT_SORT_BITS]);
+  const int src = pass & 1;
+  u32* H = C.hist;
+  const size_t hs = (size_t)nblk * 256;
+  d_radix_scatter<8, RADIX_TILE>(keys_src(C, src), keys_dst(C, src), n, 32 + 8 * pass, H + (size_t)(pass % 3) * hs, nblk,
+                                 final_pass ? nullptr : H + (size_t)((pass + 1) % 3) * hs,
+                                 final_pass ? nullptr : H + (size_t)((pass + 2) % 3) * hs);
+}
+// which of keys_a (0) / keys_b (1) holds the sorted keys after `passes` passes of which the adaptive ones may have been
+// skipped
+__device__ __forceinline__ int sorted_src(const CloudView& C, int passes, int adaptive) {
+  const int done = adaptive ? max(1, min(passes, (C.counts[CNT_SORT_BITS] + 7) >> 3)) : passes;
+  return done & 1;
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_headcount(ViewExt<CloudView> x, Clouds2 a, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  if (src < 0) src = sorted_src(C, 4, 1);
   d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
 }
 template <bool EXT>
@@ -992,6 +1105,7 @@ __global__ __launch_bounds__(1024) void k2_vox_blockscan(ViewExt<CloudView> x, C
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  if (src < 0) src = sorted_src(C, 4, 1);
   d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkoff, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
                   C.mail_seq_slot, C.seq);
 }
@@ -1026,12 +1140,12 @@ __global__ __launch_bounds__(256) void k2_normals(ViewExt<CloudView> x, Clouds2 
   d_normals(C.vox, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2, C.normals);
 }
 template <bool EXT>
-__global__ __launch_bounds__(64) void k2_spfh(ViewExt<CloudView> x, Clouds2 a) {
+__global__ __launch_bounds__(256) void k2_spfh(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, C.nbr_idx, C.spfh);
 }
 template <bool EXT>
-__global__ __launch_bounds__(64) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) {
+__global__ __launch_bounds__(256) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_fpfh(C.spfh, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
 }
@@ -1104,17 +1218,18 @@ static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, V
 }
 
 // stable LSD radix sort of keys_a by bits [32, 32+key_bits); returns which buffer holds the result (0: keys_a)
-static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st) {
+// adaptive: the keys' significant bits are in counts[CNT_SORT_BITS]; passes above them return at once and the result's
+// buffer is only known on the device (the return value is then -1: consumers call sorted_src())
+static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false) {
   const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
-  int src = 0;  // 0: keys_a holds the input
-  for (int shift = 32; shift < 32 + key_bits; shift += 8) {
-    // two launches per pass: a single-launch pass (tiles exchanging histograms through flags) needs
-    // device-scope fences, which on this multi-XCD part cost more than the launch boundary
-    LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, shift, src);
-    LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, shift, src);
-    src ^= 1;
-  }
-  return src;
+  const int passes = key_bits / 8;
+  // one histogram launch for the first pass; every scatter accumulates the next pass's histogram (see d_radix_hist).
+  // A single-launch pass (tiles exchanging offsets through flags) needs device-scope fences, which on this multi-XCD
+  // part cost more than the launch boundary.
+  LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, 32, 0);
+  for (int p = 0; p < passes; ++p)
+    LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
+  return adaptive ? -1 : (passes & 1);
 }
 
 static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st) {
@@ -1123,7 +1238,7 @@ static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipSt
   LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 0);
   LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 0);
   LAUNCH_CV(k2_vox_keys, S.a, dim3(g, nc), dim3(256), 0, st, leaf);
-  const int where = radix_sort2(S, 0, 32, st);
+  const int where = radix_sort2(S, 0, 32, st, true);  // the fourth pass only runs for grids of more than 2^24 voxels
   const int nblk = (S.maxP + 1023) / 1024;
   LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
   LAUNCH_CV(k2_vox_blockscan, S.a, dim3(1, nc), dim3(1024), 0, st);
@@ -1207,8 +1322,8 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   // thread and the launch went from 21 + 14 us to 51 us)
   LAUNCH_CV(k2_neighbors, S.a, dim3(maxn, nc), dim3(64), 0, st, r2);
   LAUNCH_CV(k2_normals, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, rn2);
-  LAUNCH_CV(k2_spfh, S.a, dim3(maxn, nc), dim3(64), 0, st);
-  LAUNCH_CV(k2_fpfh, S.a, dim3(maxn, nc), dim3(64), 0, st);
+  LAUNCH_CV(k2_spfh, S.a, dim3((maxn + SPFH_PB - 1) / SPFH_PB, nc), dim3(256), 0, st);
+  LAUNCH_CV(k2_fpfh, S.a, dim3((maxn + FPFH_PB - 1) / FPFH_PB, nc), dim3(256), 0, st);
   if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
 }
 

@@ -172,6 +172,31 @@ def test_fpfh_matches_oracle(hip, qo, small_pair):
     assert np.array_equal(_b(de_g), _b(de_o))
 
 
+def test_fpfh_normalisation_sums_on_clustered_points(hip, qo):
+    """FPFH on a cloud of tight clusters (neighbour distances from 1e-4 m to 0.7 m: weights 1/d^2 spread over 2^25).  The
+    kernel's private binary64 sums are only used when every term of a block lies within 17 binary exponents — here they
+    do not, and the reference-order fallback has to give the oracle's bits; long lists (> one staged chunk) too."""
+    g = np.random.default_rng(11)
+    centres = g.uniform(-6, 6, (220, 3))
+    pts = []
+    for c in centres:
+        m = int(g.integers(2, 9))
+        scale = 10.0 ** g.uniform(-4, -0.5)
+        pts.append(c + g.normal(0, scale, (m, 3)))
+    pts.append(g.uniform(-1, 1, (400, 3)) * [1.0, 1.0, 0.05])  # a dense slab: neighbour lists of 60-250 entries
+    v = np.zeros((sum(len(x) for x in pts), 4), np.float32)
+    v[:, :3] = np.concatenate(pts)
+    nrm_o, sp_o, de_o = qo.fpfh(v, 0.5, 0.75)
+    nrm_g, de_g = hip.fpfh(v, 0.5, 0.75)
+    sp_g = hip.debug_fetch(ql.DBG_SPFH, np.float32).reshape(v.shape[0], 33)
+    assert np.all((_b(nrm_g) == _b(nrm_o)) | (np.isnan(nrm_g) & np.isnan(nrm_o)))
+    assert np.array_equal(_b(sp_g), _b(sp_o))
+    assert np.array_equal(_b(de_g), _b(de_o))
+    off_o, idx_o, d2_o = qo.radius_neighbors(v, 0.75)
+    w = 1.0 / d2_o[d2_o > 0]
+    assert w.max() / w.min() > 2.0 ** 20 and np.diff(off_o).max() > 64
+
+
 def test_fpfh_fixture_and_argument_check(hip):
     g = np.load(os.path.join(G, "frontend_patch.npz"))
     nrm, de = hip.fpfh(g["cloud"], 0.5, 0.75)
