@@ -84,58 +84,58 @@ template <int BITS, int TILE>
 __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
                                                    int nblk) {
   constexpr int NB = 1 << BITS;
+  static_assert(NB == 256 && TILE == 1024, "256 threads: one digit and four keys each");
   __shared__ u32 cnt[NB];
-  const int lane = threadIdx.x, blk = blockIdx.x;
+  const int tid = threadIdx.x, blk = blockIdx.x;
   if (blk >= nblk) return;
-  ((uint4*)(hist + ((size_t)nblk + blk) * NB))[lane] = make_uint4(0, 0, 0, 0);      // H[1], H[2]: rows of this tile
-  ((uint4*)(hist + ((size_t)2 * nblk + blk) * NB))[lane] = make_uint4(0, 0, 0, 0);
-  for (int d = lane; d < NB; d += 64) cnt[d] = 0;
+  hist[((size_t)nblk + blk) * NB + tid] = 0;      // H[1], H[2]: rows of this tile
+  hist[((size_t)2 * nblk + blk) * NB + tid] = 0;
+  cnt[tid] = 0;
   __syncthreads();
   const int base = blk * TILE;
-  u64 keys[TILE / 64];
 #pragma unroll
-  for (int s = 0; s < TILE / 64; ++s) {
-    const int i = base + s * 64 + lane;
-    keys[s] = (i < n) ? in[i] : 0ULL;
-  }
-#pragma unroll
-  for (int s = 0; s < TILE / 64; ++s) {
-    const int i = base + s * 64 + lane;
-    if (i < n) atomicAdd(&cnt[(u32)(keys[s] >> shift) & (u32)(NB - 1)], 1u);
+  for (int s = 0; s < TILE / 256; ++s) {
+    const int i = base + s * 256 + tid;
+    if (i < n) atomicAdd(&cnt[(u32)(in[i] >> shift) & (u32)(NB - 1)], 1u);
   }
   __syncthreads();
-  static_assert(NB == 256, "tile-major rows of 256 counters, four per lane");
-  uint4 mine;
-  mine.x = cnt[lane * 4 + 0];
-  mine.y = cnt[lane * 4 + 1];
-  mine.z = cnt[lane * 4 + 2];
-  mine.w = cnt[lane * 4 + 3];
-  ((uint4*)(hist + (size_t)blk * NB))[lane] = mine;  // hist[blk][digit]: one coalesced 1 KB row per tile
+  hist[(size_t)blk * NB + tid] = cnt[tid];  // hist[blk][digit]: one coalesced 1 KB row per tile
 }
 
-
+// One workgroup of four wavefronts per 1024-key tile.  Stability needs ranks in element order: wave w owns the w-th
+// quarter of the tile, so after a counting phase (per-wave digit counts in LDS) every wave knows where its keys of each
+// digit start, and ranks its own 256 keys in order with ballot match masks (four steps of 64 instead of the sixteen a
+// single wave needed: the pass is latency-bound, the chip has 45 tiles to chew on).
 template <int BITS, int TILE>
 __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64* __restrict__ out, int n,
                                                       int shift, const u32* __restrict__ hist, int nblk,
                                                       u32* __restrict__ hist_next /* or null: last pass */,
                                                       u32* __restrict__ hist_clear /* or null */) {
   constexpr int NB = 1 << BITS;
-  __shared__ u32 base[NB];
-  const int lane = threadIdx.x, blk = blockIdx.x;
+  static_assert(NB == 256 && TILE == 1024, "256 threads: one digit and four keys each");
+  __shared__ u32 s_tot[4][NB], s_bef[4][NB];  // partial column sums of the tile histograms, one slice per wave
+  __shared__ u32 cntw[4][NB];                 // digit counts of each wave's quarter, then its running bases
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   if (blk >= nblk) return;
-  if (hist_clear) ((uint4*)(hist_clear + (size_t)blk * NB))[lane] = make_uint4(0, 0, 0, 0);
+  if (hist_clear) hist_clear[(size_t)blk * NB + tid] = 0;
+  const int tbase = blk * TILE + wave * 256;
+  u64 keys[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int i = tbase + s * 64 + lane;
+    keys[s] = (i < n) ? in[i] : 0ULL;
+  }
   // offsets from the RAW per-tile histograms (no separate scan launch): digit d of this tile starts at
-  //   sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d]        (rows are tile-major: one 16-byte load per tile)
+  //   sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d];   wave w adds up the rows b = w, w+4, ... (4 digits per lane)
   {
-    static_assert(NB == 256, "offset computation below assumes 4 digits per lane");
     u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
-    for (int b0 = 0; b0 < nblk; b0 += 16) {  // 16 rows in flight per round trip
-      uint4 h[16];
+    for (int b0 = wave; b0 < nblk; b0 += 32) {  // eight rows in flight per round trip
+      uint4 h[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) h[q] = ((const uint4*)(hist + (size_t)min(b0 + q, nblk - 1) * NB))[lane];
+      for (int q = 0; q < 8; ++q) h[q] = ((const uint4*)(hist + (size_t)min(b0 + 4 * q, nblk - 1) * NB))[lane];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int b = b0 + q;
+      for (int q = 0; q < 8; ++q) {
+        const int b = b0 + 4 * q;
         const u32 live = (b < nblk) ? 0xffffffffu : 0u, m = (b < blk) ? 0xffffffffu : 0u;
         tot[0] += h[q].x & live;
         tot[1] += h[q].y & live;
@@ -147,26 +147,38 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
         before[3] += h[q].w & m;
       }
     }
-    int wtot;
-    const int ex = wave_excl_scan_i32((int)(tot[0] + tot[1] + tot[2] + tot[3]), &wtot);
-    u32 run = (u32)ex;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      base[lane * 4 + q] = run + before[q];
-      run += tot[q];
+      s_tot[wave][lane * 4 + q] = tot[q];
+      s_bef[wave][lane * 4 + q] = before[q];
+      cntw[wave][lane * 4 + q] = 0;
     }
   }
   __syncthreads();
-  const int tbase = blk * TILE;
-  constexpr int ITER = TILE / 64;
-  u64 keys[ITER];  // the whole tile in registers: the barriers below would otherwise serialise 16 global loads
 #pragma unroll
-  for (int s = 0; s < ITER; ++s) {
-    const int i = tbase + s * 64 + lane;
-    keys[s] = (i < n) ? in[i] : 0ULL;
+  for (int s = 0; s < 4; ++s)
+    if (tbase + s * 64 + lane < n) atomicAdd(&cntw[wave][(u32)(keys[s] >> shift) & (u32)(NB - 1)], 1u);
+  // thread = digit: global start of the digit, then the four waves' starts inside it
+  const u32 mytot = s_tot[0][tid] + s_tot[1][tid] + s_tot[2][tid] + s_tot[3][tid];
+  const u32 mybef = s_bef[0][tid] + s_bef[1][tid] + s_bef[2][tid] + s_bef[3][tid];
+  __shared__ u32 s_wsum[4];
+  int wtot;
+  const int ex = wave_excl_scan_i32((int)mytot, &wtot);
+  if (lane == 63) s_wsum[wave] = (u32)wtot;
+  __syncthreads();
+  {
+    u32 run = (u32)ex + mybef;
+    for (int w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const u32 c = cntw[w][tid];
+      cntw[w][tid] = run;
+      run += c;
+    }
   }
+  __syncthreads();
 #pragma unroll
-  for (int s = 0; s < ITER; ++s) {
+  for (int s = 0; s < 4; ++s) {
     const int i = tbase + s * 64 + lane;
     const bool valid = i < n;
     const u64 key = keys[s];
@@ -179,12 +191,12 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
       m &= one ? b : ~b;
     }
     if (valid) {
-      const u32 pos = base[d] + (u32)__popcll(m & lanemask_lt());
+      const u32 pos = cntw[wave][d] + (u32)__popcll(m & lanemask_lt());
       out[pos] = key;
       if (hist_next) atomicAdd(&hist_next[(size_t)(pos / TILE) * NB + ((u32)(key >> (shift + BITS)) & (u32)(NB - 1))], 1u);
     }
-    __syncthreads();  // single-wave workgroup: orders the LDS reads above before the updates below
-    if (valid && (m & lanemask_lt()) == 0) base[d] += (u32)__popcll(m);
+    __syncthreads();  // orders the LDS reads above before the updates below (each wave only touches its own row)
+    if (valid && (m & lanemask_lt()) == 0) cntw[wave][d] += (u32)__popcll(m);
     __syncthreads();
   }
 }
@@ -1062,7 +1074,7 @@ __global__ __launch_bounds__(256) void k2_cell_keys(ViewExt<CloudView> x, Clouds
 }
 // src: which of keys_a (0) / keys_b (1) holds the input of this pass
 template <bool EXT>
-__global__ __launch_bounds__(64) void k2_radix_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
+__global__ __launch_bounds__(256) void k2_radix_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
   d_radix_hist<8, RADIX_TILE>(keys_src(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
@@ -1071,7 +1083,7 @@ __global__ __launch_bounds__(64) void k2_radix_hist(ViewExt<CloudView> x, Clouds
 // device only) and a pass whose digit lies wholly above them is skipped — the consumers pick the buffer with
 // sorted_src() below
 template <bool EXT>
-__global__ __launch_bounds__(64) void k2_radix_scatter(ViewExt<CloudView> x, Clouds2 a, int use_vox, int pass, int last,
+__global__ __launch_bounds__(256) void k2_radix_scatter(ViewExt<CloudView> x, Clouds2 a, int use_vox, int pass, int last,
                                                       int adaptive) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
@@ -1226,9 +1238,9 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
   // one histogram launch for the first pass; every scatter accumulates the next pass's histogram (see d_radix_hist).
   // A single-launch pass (tiles exchanging offsets through flags) needs device-scope fences, which on this multi-XCD
   // part cost more than the launch boundary.
-  LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, 32, 0);
+  LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, 32, 0);
   for (int p = 0; p < passes; ++p)
-    LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(64), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
+    LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
   return adaptive ? -1 : (passes & 1);
 }
 

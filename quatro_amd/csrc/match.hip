@@ -146,8 +146,9 @@ __device__ __forceinline__ u64 desc_hash(const float* d) {
 // queryT[34][n_pad] (-2 * desc, row 33 = 1); the norms (binary64 sum rounded once); and the row's entry in the
 // dedup table: slot sequence from the low hash bits, tag = high 32 bits, value = lowest row with that tag.
 __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int n, int n_pad, float* __restrict__ baseT,
-                                            float* __restrict__ queryT, float* __restrict__ norms,
-                                            u64* __restrict__ hashes, u64* __restrict__ table, int mask) {
+                                            float* __restrict__ queryT /* null: the f16 engine does not read it */,
+                                            float* __restrict__ norms, u64* __restrict__ hashes, u64* __restrict__ table,
+                                            int mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_pad) return;
   if (i < n) {
@@ -157,10 +158,10 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
       v[k] = desc[(size_t)i * 33 + k];
       acc += (double)v[k] * (double)v[k];
       baseT[(size_t)k * n_pad + i] = v[k];
-      queryT[(size_t)k * n_pad + i] = -2.0f * v[k];
+      if (queryT) queryT[(size_t)k * n_pad + i] = -2.0f * v[k];
     }
     baseT[(size_t)33 * n_pad + i] = __double2float_rd(acc * NN_NORM_SCALE);
-    queryT[(size_t)33 * n_pad + i] = 1.0f;
+    if (queryT) queryT[(size_t)33 * n_pad + i] = 1.0f;
     norms[i] = (float)acc;
     const u64 h = desc_hash(v);
     hashes[i] = h;
@@ -184,20 +185,22 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
   } else {
     for (int k = 0; k < 33; ++k) {
       baseT[(size_t)k * n_pad + i] = 0.f;
-      queryT[(size_t)k * n_pad + i] = 0.f;
+      if (queryT) queryT[(size_t)k * n_pad + i] = 0.f;
     }
     baseT[(size_t)33 * n_pad + i] = 1e30f;
-    queryT[(size_t)33 * n_pad + i] = 1.0f;
+    if (queryT) queryT[(size_t)33 * n_pad + i] = 1.0f;
   }
 }
 // grid (pad_large_max / 256, 2, pairs): blockIdx.y = cloud (0: larger, 1: smaller)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one) {
+__global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one, int f32_tables) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   if (blockIdx.y == 0)
-    d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, V.queryT_i, V.norms_i, V.hash_i, V.table_i, V.dd_mask);
+    d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, f32_tables ? V.queryT_i : nullptr, V.norms_i, V.hash_i, V.table_i,
+                V.dd_mask);
   else
-    d_desc_prep(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, V.queryT_j, V.norms_j, V.hash_j, V.table_j, V.dd_mask);
+    d_desc_prep(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, f32_tables ? V.queryT_j : nullptr, V.norms_j, V.hash_j, V.table_j,
+                V.dd_mask);
 }
 
 // Hides base rows that duplicate a lower row bit for bit (see the header comment).  The table gives the lowest row
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, Matc
 // query columns of the hit rows, gathered into a compact k-major table (pad columns: zeros with the constant-1 row,
 // never read back).  grid (pad_large_max / 256, 1, pairs)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_hit_gather(ViewExt<MatchView> x, MatchView one) {
+__global__ __launch_bounds__(256) void k_hit_gather(ViewExt<MatchView> x, MatchView one, int f32_tables) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int nhit = V.mcounts[MC_NHIT];
   const int padded = (nhit + NN_QPB - 1) / NN_QPB * NN_QPB;
@@ -891,19 +894,25 @@ __global__ __launch_bounds__(256) void k_hit_gather(ViewExt<MatchView> x, MatchV
   const int pad = V.pad_large;
   if (c < nhit) {
     const int r = V.hit_rows[c];
-#pragma unroll
-    for (int k = 0; k < 34; ++k) V.queryT_c[(size_t)k * pad + c] = V.queryT_i[(size_t)k * pad + r];
     V.norms_c[c] = V.norms_i[r];
+    if (f32_tables) {
 #pragma unroll
-    for (int ch = 0; ch < NNH_CHUNKS; ++ch)
-      V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = V.queryH_i[((size_t)(r >> 5) * NNH_CHUNKS + ch) * 32 + (r & 31)];
+      for (int k = 0; k < 34; ++k) V.queryT_c[(size_t)k * pad + c] = V.queryT_i[(size_t)k * pad + r];
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < NNH_CHUNKS; ++ch)
+        V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = V.queryH_i[((size_t)(r >> 5) * NNH_CHUNKS + ch) * 32 + (r & 31)];
+    }
   } else {
-#pragma unroll
-    for (int ch = 0; ch < NNH_CHUNKS; ++ch) V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 33; ++k) V.queryT_c[(size_t)k * pad + c] = 0.f;
-    V.queryT_c[(size_t)33 * pad + c] = 1.0f;
     V.norms_c[c] = 0.f;
+    if (f32_tables) {
+#pragma unroll
+      for (int k = 0; k < 33; ++k) V.queryT_c[(size_t)k * pad + c] = 0.f;
+      V.queryT_c[(size_t)33 * pad + c] = 1.0f;
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < NNH_CHUNKS; ++ch) V.queryH_c[((size_t)(c >> 5) * NNH_CHUNKS + ch) * 32 + (c & 31)] = make_uint4(0, 0, 0, 0);
+    }
   }
 }
 
@@ -1441,7 +1450,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       if (s > 256) s = 256;
       return s;
     };
-    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);  // norms for the bin order k_hit_compact follows
+    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, 1);  // norms for the bin order k_hit_compact follows
     LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
     if (ev && ev[0]) (void)hipEventRecord(ev[0], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, 0);
@@ -1451,7 +1460,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_nn_exact, a, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, 1);
     if (ev && ev[3]) (void)hipEventRecord(ev[3], st);
   } else {
-    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, nn_engine == 2 ? 0 : 1);
     LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
     LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
@@ -1482,7 +1491,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
-    LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st);
+    LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st, f16 ? 0 : 1);
     run_dir(1, max_large, max_small, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
