@@ -89,11 +89,13 @@ __global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, Solv
 #define KC_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
 template <bool EXT>
 __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverView one,
-                                                int use_gqueue /* the queue does not fit LDS */, int lds_bitmap_max) {
+                                                int use_gqueue /* the queue does not fit LDS */, int lds_bitmap_max,
+                                                int after_hcore /* 1: only needed if the h-index iteration gave up */) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const u64* __restrict__ bm = V.bm;
   const int L = V.L, W = V.W;
   if (L <= 0) return;
+  if (after_hcore && V.st->pad[5] == 0) return;
   const int* __restrict__ deg_in = V.deg;
   int* __restrict__ core_out = V.core;
   SolverState* __restrict__ st = V.st;
@@ -188,6 +190,159 @@ __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverVie
     st->pad[0] = kc_rounds;  // statistics
   }
   for (int v = tid; v < L; v += nthr) V.rankof[v] = 0;  // k_rank_partial accumulates into it
+}
+
+// =================================================================================================
+// K12c: core numbers of larger graphs (L > 1280) by h-index iteration.  Peeling is a chain of dependent rounds — one per
+// occupied degree level and sub-round, thousands at L = 20000, ~5 us each in one workgroup.  The coreness is also the
+// fixed point of  c(v) <- H({c(u) : u ~ v})  started from the degrees (Lu, Zhou, Zhang, Stanley 2016; asynchronous
+// updates converge to the same point: Montresor, De Pellegrini, Miorandi 2013), H = the h-index of a multiset, and the
+// iteration is a handful of fully parallel sweeps over the bit matrix: one wavefront per row gathers its neighbours'
+// current values, counts them into an LDS histogram capped at its own value (values only ever decrease) and reads the
+// new value off the suffix counts.  Updates are in place; a stale read is an upper bound, which is all the iteration
+// needs.  Core numbers are unique, so the result equals the peeling's (and pmc_graph::compute_cores').
+// HC_MAXIT sweeps are enqueued; a sweep returns at once when the one before it changed nothing (14 - 35 do something on
+// the synthetic correspondence sets of 2000 - 20000 pairs; the rest cost ~1 us each).  If the last one still changed
+// something (long chains could do it) k_kcore runs after all.  Measured against the peeling kernel, whole solve:
+// L = 5000 0.80 -> 0.62 ms, 8192 1.63 -> 1.09 ms, 20000 6.95 -> 3.1 ms; no gain at 2000, so it is used above 3000.
+#define HC_MAXIT 64
+#define HC_BINS 2048
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_hcore_init(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < V.L) {
+    V.core[v] = V.deg[v];
+    V.Kp[v] = 0;  // the sweep from which on the vertex has to be looked at again (Kp is not in use yet)
+  }
+  if (v < HC_MAXIT + 1) V.perm[v] = 0;  // per-sweep "something changed" flags (perm is not in use yet)
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, SolverView one, int it) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  int* __restrict__ flags = V.perm;
+  if (it > 0 && flags[it - 1] == 0) return;
+  __shared__ int hist[4][HC_BINS];
+  const int L = V.L, W = V.W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= L) return;
+  int* __restrict__ core = V.core;
+  int* __restrict__ due = V.Kp;
+  // a value can only drop after a neighbour's did: whoever lowers its value stamps its neighbours "due next sweep", and
+  // a vertex nobody stamped since its last visit is skipped (the late sweeps touch a few hundred rows, not all L)
+  if (due[row] < it) return;
+  const u64* __restrict__ rowp = V.bm + (size_t)row * W;
+  const int cv = core[row];
+  if (cv <= 0) return;
+  int h;
+  if (cv < HC_BINS) {
+    int* hw = hist[wave];
+    for (int t = lane; t <= cv; t += 64) hw[t] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int w = lane; w < W; w += 64) {
+      u64 bits = rowp[w];
+      while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        atomicAdd(&hw[min(core[w * 64 + b], cv)], 1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // largest t <= cv with #(values >= t) >= t.  Lane l owns bins [l K, (l + 1) K); suffix counts across lanes by a scan.
+    const int K = (cv + 64) / 64;
+    const int lo = lane * K, hi = min(cv + 1, lo + K);
+    int mine = 0;
+    for (int t = lo; t < hi; ++t) mine += hw[t];
+    int tot;
+    const int ex = wave_excl_scan_i32(mine, &tot);
+    int run = tot - ex - mine;  // values in the bins of higher lanes
+    int best = -1;
+    for (int t = hi - 1; t >= lo; --t) {
+      run += hw[t];
+      if (run >= t) {
+        best = t;
+        break;
+      }
+    }
+    h = wave_max_i32(best);
+  } else {
+    // a vertex of very high degree: count by threshold, bisect (the predicate #(values >= t) >= t is monotone in t)
+    auto count_ge = [&](int th) {
+      int c = 0;
+      for (int w = lane; w < W; w += 64) {
+        u64 bits = rowp[w];
+        while (bits) {
+          const int b = __ffsll((long long)bits) - 1;
+          bits &= bits - 1;
+          c += core[w * 64 + b] >= th;
+        }
+      }
+      return wave_sum_i32(c);
+    };
+    if (count_ge(cv) >= cv) {
+      h = cv;
+    } else {
+      int a = 0, z = cv - 1;
+      while (a < z) {
+        const int mid = (a + z + 1) >> 1;
+        if (count_ge(mid) >= mid) a = mid;
+        else z = mid - 1;
+      }
+      h = a;
+    }
+  }
+  if (h < cv) {
+    if (lane == 0) {
+      core[row] = h;
+      flags[it] = 1;
+    }
+    for (int w = lane; w < W; w += 64) {
+      u64 bits = rowp[w];
+      while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        due[w * 64 + b] = it + 1;
+      }
+    }
+  }
+}
+// what k_kcore leaves behind besides the core numbers: edge total, largest core, the zeroed rank accumulator
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_hcore_finish(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L;
+  if (L <= 0) return;
+  SolverState* __restrict__ st = V.st;
+  const int* __restrict__ flags = V.perm;
+  if (flags[HC_MAXIT - 1] != 0) {  // not converged: the peeling kernel takes over
+    if (threadIdx.x == 0) st->pad[5] = 1;
+    return;
+  }
+  __shared__ int s_max, s_edges, s_iters;
+  if (threadIdx.x == 0) s_max = s_edges = s_iters = 0;
+  __syncthreads();
+  int mx = 0, es = 0;
+  for (int v = threadIdx.x; v < L; v += 1024) {
+    mx = max(mx, V.core[v]);
+    es += V.deg[v];
+    V.rankof[v] = 0;  // k_rank_partial accumulates into it
+  }
+  mx = wave_max_i32(mx);
+  es = wave_sum_i32(es);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&s_max, mx);
+    atomicAdd(&s_edges, es);
+  }
+  if (threadIdx.x < HC_MAXIT && flags[threadIdx.x]) atomicAdd(&s_iters, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->n_edges2 = s_edges;
+    st->max_core = s_max;
+    st->ub = s_max + 1;
+    st->pad[0] = s_iters + 1;  // statistics: sweeps that ran
+    st->pad[5] = 0;
+  }
 }
 
 // Level-parallel variant for L <= 1280: peeling is a chain of hundreds of dependent rounds (one per occupied
@@ -1644,8 +1799,18 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       LAUNCH_SV(k_kcore_collect_rank, a, dim3(1, 1, G), dim3(1024), 0, stream);
     } else {
       const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
+      static const bool peel_only = [] {
+        const char* e = getenv("QTR_KCORE");
+        return e && strcmp(e, "peel") == 0;
+      }();
+      const bool hcore = !peel_only && L > 3000;
+      if (hcore) {
+        LAUNCH_SV(k_hcore_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
+        for (int it = 0; it < HC_MAXIT; ++it) LAUNCH_SV(k_hcore_sweep, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, it);
+        LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream);
+      }
       LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, q_in_lds ? 0 : 1,
-                lds_bitmap);
+                lds_bitmap, hcore ? 1 : 0);
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
