@@ -583,7 +583,7 @@ __device__ __forceinline__ void d_neighbors(const float4* __restrict__ pts, int 
     }
     k = QTR_KMAX;
   }
-  int n2 = 64;
+  int n2 = 8;  // (most lists are shorter than 32: 10 - 15 compare stages instead of the 21 a 64-key network needs)
   while (n2 < k) n2 <<= 1;
   for (int t = k + lane; t < n2; t += 64) buf[t] = ~0ULL;
   // bitonic sort of n2 (<= 256) packed keys in LDS: ascending (d2, index)
