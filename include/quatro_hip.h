@@ -304,6 +304,13 @@ int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_
 void qtr_comm_destroy(qtr_handle* h);
 
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
+/* Instrumentation (no reference counterpart; the demo times its stages with std::chrono around the calls,
+ * examples/run_global_registration.cpp:206-246).  qtr_set_stage_events(0) stops recording the per-stage events (the
+ * stage fields of qtr_stage_times then read 0); the two nearest-neighbour launches keep their event pairs, whose
+ * elapsed times accumulate per slot: qtr_get_nn_totals returns (and optionally resets) the sum and the launch count
+ * without a per-call query. */
+int qtr_set_stage_events(qtr_handle* h, int on);
+int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset);
 
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to
  * `bytes` bytes to host memory `dst`; returns the number of bytes the item holds, or <0 on error. */

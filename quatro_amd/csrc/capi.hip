@@ -40,6 +40,9 @@ struct Slot {
   unsigned long long exact_nodes = 0;  // search-tree nodes of the last PMC_EXACT run
   int exact_aborted = 0;               // 1: its time limit was hit (heuristic clique returned)
   int times_pending = 0;         // 1: qtr_solve, 2: qtr_register_pair — stage times are read off the events lazily
+  int nn_pending = 0;            // the nearest-neighbour events of the last match have not been added to the totals yet
+  double nn_total_ms = 0;        // qtr_get_nn_totals
+  long long nn_total_launches = 0;
   qtr_stage_times times = {};
   int last_L = 0;  // correspondences of the last solve
   int last_n = 0;  // points of the last qtr_fpfh
@@ -356,6 +359,20 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   const int rc = create_impl(h);
   *out = h;  // returned even on failure so that qtr_last_error can be read; caller destroys it
   return rc;
+}
+
+// adds the nearest-neighbour kernel times of the last match (events on its launch stream) to the slot's totals; called
+// before the events are recorded again and by qtr_get_nn_totals
+static void flush_nn_totals(Slot& s) {
+  if (!s.nn_pending) return;
+  s.nn_pending = 0;
+  float a = 0, b = 0;
+  if (hipEventElapsedTime(&a, s.fb.ev_nn[0], s.fb.ev_nn[1]) == hipSuccess &&
+      hipEventElapsedTime(&b, s.fb.ev_nn[2], s.fb.ev_nn[3]) == hipSuccess) {
+    s.nn_total_ms += (double)a + (double)b;
+    s.nn_total_launches += 2;
+  }
+  (void)hipGetLastError();
 }
 
 static void fill_nn_times(Slot& s) {
@@ -1076,6 +1093,26 @@ int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const q
   return QTR_OK;
 }
 
+int qtr_set_stage_events(qtr_handle* h, int on) {
+  if (!h) return QTR_ERR_BAD_ARG;
+  h->stage_events = on ? 1 : 0;
+  return QTR_OK;
+}
+
+int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp) return QTR_ERR_BAD_ARG;
+  (void)hipStreamSynchronize(sp->stream);
+  flush_nn_totals(*sp);
+  if (total_ms) *total_ms = sp->nn_total_ms;
+  if (launches) *launches = sp->nn_total_launches;
+  if (reset) {
+    sp->nn_total_ms = 0;
+    sp->nn_total_launches = 0;
+  }
+  return QTR_OK;
+}
+
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !out) return QTR_ERR_BAD_ARG;
@@ -1186,6 +1223,8 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
 static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out) {
+  flush_nn_totals(s);
+  s.nn_pending = (s.fb.nn_events && s.fb.nn_engine != 0) ? 1 : 0;
   s.fb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
