@@ -65,11 +65,39 @@ def same_solution(g, o):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["solve", "solve", "clique", "pair", "patchwork", "segment", "gnc3", "cote"])
+    kind = rng.choice(["solve", "solve", "clique", "pair", "match", "match", "patchwork", "segment", "gnc3", "cote"])
     n_cases += 1
     print(f"case {n_cases} {kind}", file=sys.stderr, flush=True)
     try:
-        if kind == "solve":
+        if kind == "match":
+            # descriptors that are NOT FPFH output: the f16-split filter's bound and range guard against the oracle's
+            # exact matcher — clusters of near-identical rows, exact duplicates, sparse rows, values near and beyond the
+            # f16 range, tiny values
+            ns, nt = int(rng.integers(40, 2500)), int(rng.integers(40, 2500))
+            ncl = int(rng.choice([3, 20, 200]))
+            centres = rng.uniform(0, 1, (ncl, 33)) * (rng.random((ncl, 33)) < rng.choice([0.3, 1.0]))
+            rel = float(rng.choice([0.0, 1e-7, 1e-5, 1e-2, 0.5]))
+            scale = float(rng.choice([1e-4, 1.0, 100.0, 250.0, 600.0]))
+
+            def draw(n):
+                d = centres[rng.integers(0, ncl, n)] * (1.0 + rel * rng.standard_normal((n, 33)))
+                return np.abs(d * scale).astype(np.float32)
+            ds, dt = draw(ns), draw(nt)
+            vs = np.zeros((ns, 4), np.float32)
+            vt = np.zeros((nt, 4), np.float32)
+            vs[:, :3] = rng.uniform(-30, 30, (ns, 3))
+            vt[:, :3] = rng.uniform(-30, 30, (nt, 3))
+            sd = int(rng.integers(0, 1000))
+            desc = f"ns={ns} nt={nt} clusters={ncl} rel={rel} scale={scale} seed={sd}"
+            co, nn_ij, nn_ji = qo.match(vs, ds, vt, dt, seed=sd, debug=True)
+            cg = h.match(vs, ds, vt, dt, ql.default_frontend_params(seed=sd))
+            if not DRY:
+                g_ij = h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32)[:nn_ij.size]
+                if not np.array_equal(g_ij, nn_ij):
+                    report(kind, desc, f"NN table differs in {int((g_ij != nn_ij).sum())} of {nn_ij.size} rows")
+                elif not np.array_equal(cg, co):
+                    report(kind, desc, f"correspondences {cg.shape[0]} vs {co.shape[0]}")
+        elif kind == "solve":
             L = int(rng.choice([2, 3, 5, 17, 64, 65, 300, 1281, 2000, 4097, 7000]))
             frac = float(rng.choice([0.0, 0.02, 0.1, 0.5, 0.9, 1.0]))
             noise = float(rng.choice([0.0, 0.02, 0.1]))

@@ -354,6 +354,21 @@ def test_nn_engines_produce_identical_tables(qo, small_pair):
         assert stats[8] + stats[9] < 0.2 * (vs.shape[0] + vt.shape[0]), e  # rows that needed the exact re-check
 
 
+def test_mfma_f16_accumulation_stays_inside_the_budget(tmp_path):
+    """The one hardware assumption of the f16-split filter's rounding bound — how far the f32 accumulation of
+    v_mfma_f32_32x32x16_f16 (one instruction, and a chain of seven) can be from the exact sum of its exact products — is
+    measured on this device (tests/gpu_checks/mfma_f16_accumulation.hip: the kernel's operand shapes and adversarial
+    exponent spreads, 2 million sums): it has to stay below half of the 16 u the bound budgets."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "mfma_f16_accumulation")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-value",
+                           os.path.join(root, "tests", "gpu_checks", "mfma_f16_accumulation.hip"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-800:] + p.stderr[-400:]
+    assert "worst" in p.stdout
+
+
 @pytest.mark.parametrize("case", ["big_values", "big_norm", "tiny_values", "wide_range", "near_ties"])
 def test_f16_filter_holds_on_adversarial_descriptors(qo, case):
     """The f16-split filter's rounding bound and range guard on descriptors that are nothing like FPFH histograms: values
