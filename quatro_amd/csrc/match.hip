@@ -148,14 +148,23 @@ __device__ __forceinline__ u64 desc_hash(const float* d) {
 __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int n, int n_pad, float* __restrict__ baseT,
                                             float* __restrict__ queryT /* null: the f16 engine does not read it */,
                                             float* __restrict__ norms, u64* __restrict__ hashes, u64* __restrict__ table,
-                                            int mask) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+                                            int mask, float* s_rows /* LDS, 256 x 33 */) {
+  // the rows of this workgroup, staged through LDS: coalesced loads of the row-major table (a thread reading its own
+  // 132-byte row costs one cache-line access per lane and instruction), then conflict-free row reads (stride 33)
+  const int row0 = blockIdx.x * 256;
+  if (row0 >= n_pad) return;
+  {
+    const size_t base = (size_t)row0 * 33, lim = (size_t)n * 33;
+    for (int e = threadIdx.x; e < 256 * 33; e += 256) s_rows[e] = (base + e < lim) ? desc[base + e] : 0.f;
+  }
+  __syncthreads();
+  const int i = row0 + threadIdx.x;
   if (i >= n_pad) return;
   if (i < n) {
     double acc = 0.0;
     float v[33];
     for (int k = 0; k < 33; ++k) {
-      v[k] = desc[(size_t)i * 33 + k];
+      v[k] = s_rows[threadIdx.x * 33 + k];
       acc += (double)v[k] * (double)v[k];
       baseT[(size_t)k * n_pad + i] = v[k];
       if (queryT) queryT[(size_t)k * n_pad + i] = -2.0f * v[k];
@@ -195,12 +204,13 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one, int f32_tables) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  __shared__ float s_rows[256 * 33];
   if (blockIdx.y == 0)
     d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, f32_tables ? V.queryT_i : nullptr, V.norms_i, V.hash_i, V.table_i,
-                V.dd_mask);
+                V.dd_mask, s_rows);
   else
     d_desc_prep(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, f32_tables ? V.queryT_j : nullptr, V.norms_j, V.hash_j, V.table_j,
-                V.dd_mask);
+                V.dd_mask, s_rows);
 }
 
 // Hides base rows that duplicate a lower row bit for bit (see the header comment).  The table gives the lowest row
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
 #define NN_FIN_THREADS 512
 template <bool EXT>
 __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G,
-                                                              float cadd) {
+                                                              float cadd, int f16) {
   NN_PLAN(G, dir, X)
   __shared__ int s_w[16], s_base;
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -697,6 +707,109 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
       hi = min(NORM_BINS - 1, (int)floorf(sa + R));
     }
     V.recheck_span[slot] = make_int2(D.bstart[lo], D.bstart[hi + 1]);
+    if (f16) V.recheck_q[slot] = q;  // where k_recheck_filter finds the row's f16 query fragments (column of D.queryH)
+  }
+}
+
+// Re-check of the listed rows (f16 engine): the matrix pipe again.  A listed row's exact arg-min is among the base rows
+// whose filter value is at most the row's threshold (k_nn_finish: the leader's value plus twice the rounding bound) —
+// two or three near-ties, typically — so the listed rows go through the same 7-MFMA chain once more, this time
+// comparing every entry with the row's threshold; the (row, base row) pairs that pass are buffered in LDS and get the
+// exact flann::L2 evaluation by the same workgroup.  A workgroup takes 128 listed rows (32 per wave) and a slice of the
+// base tiles (fragments of the next tile prefetched).  If the buffer overflows, or a row has no finite threshold, or the
+// descriptors are outside the filter's range (MC_UNSAFE: the chain may produce NaN), the direction's flag makes
+// k_nn_exact_rows — the span scan, which needs no list — redo it.  grid (query groups, slices, pairs).
+#define RC_CAP 2048
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const NnDir& D = V.d[dir];
+  const int nrows = V.mcounts[D.rc_slot];
+  if (nrows <= 0) return;
+  int* __restrict__ fallback = V.rc_counts + 4 * dir + 1;
+  if (V.mcounts[MC_UNSAFE]) {
+    if (threadIdx.x == 0) *fallback = 1;
+    return;
+  }
+  __shared__ int s_n;
+  __shared__ int2 s_cand[RC_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  const u32 frag = (u32)half * 32u + (u32)col;
+  const int ntiles = D.nb_pad / 32;
+  const int per = (ntiles + gridDim.y - 1) / gridDim.y;
+  const int t0 = blockIdx.y * per, t1 = min(ntiles, t0 + per);
+  const h8* __restrict__ baseH = (const h8*)D.baseH;
+  const h8* __restrict__ queryH = (const h8*)D.queryH;
+  const int* __restrict__ qcol = V.recheck_q;  // listed row -> its column of the query table (k_nn_finish)
+  const float* __restrict__ A = D.A;
+  const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
+  const int qgroups = (nrows + 127) / 128;
+  for (int qg = blockIdx.x; qg < qgroups; qg += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int qtile = qg * 4 + wave;
+    const int slot = qtile * 32 + col;
+    h8 q[7], m0[7], m1[7];
+    {
+      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; their threshold rejects everything)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) q[m] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + half) * 32 + (qc & 31)];
+    }
+    float thr = -INFINITY;
+    if (slot < nrows) {
+      thr = V.recheck_thr[slot] * (NNH_S * NNH_S);
+      if (!(thr < INFINITY)) *fallback = 1;
+    }
+    auto load = [&](h8* m, int t) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];  // (padded: t1 may be read)
+    };
+    auto tile = [&](const h8* m, int t) {
+      f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (acc[r] <= thr) {
+          const int pos = atomicAdd(&s_n, 1);
+          if (pos < RC_CAP) s_cand[pos] = make_int2(slot, t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
+        }
+      }
+    };
+    if (t0 < t1) load(m0, t0);
+    for (int t = t0; t < t1; t += 2) {
+      load(m1, t + 1);
+      tile(m0, t);
+      if (t + 1 < t1) {
+        load(m0, t + 2);
+        tile(m1, t + 1);
+      }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n > RC_CAP) {
+      if (threadIdx.x == 0) *fallback = 1;
+      continue;
+    }
+    // exact distance of every collected pair, folded into the row's packed (distance, base row) minimum
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int2 c = s_cand[e];
+      if (c.y >= D.nb) continue;  // a pad row of the last tile (cannot pass a finite threshold; belt and braces)
+      const int row = V.recheck_rows[c.x];
+      const float* a = A + (size_t)row * 33;
+      const float* b = B + (size_t)c.y * 33;
+      float result = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
+                    d3 = a[4 * g + 3] - b[4 * g + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+      const float dt = a[32] - b[32];
+      result += dt * dt;
+      atomicMin(&D.best[row], ((u64)__float_as_uint(result) << 32) | (u32)c.y);
+    }
   }
 }
 
@@ -713,11 +826,13 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
 // grid (groups, slices, pairs).
 #define XR 8
 template <bool EXT>
-__global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, MatchView one, int dir) {
+__global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, MatchView one, int dir,
+                                                         int after_filter /* 1: only if k_recheck_filter overflowed */) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
+  if (after_filter && V.rc_counts[4 * dir + 1] == 0) return;
   __shared__ __attribute__((aligned(16))) float s_m2a[33][XR];  // [k][row]: -2 * a
   __shared__ __attribute__((aligned(16))) float s_a[XR][36];    // [row][k]
   __shared__ float s_thr[XR];
@@ -824,6 +939,7 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
+  if (gid < 8) V.rc_counts[gid] = 0;
   const int pv = V.tuple ? 0 : 1;
   const int np = V.crosscheck ? V.n_small : V.n_small + V.n_large;
   for (int i = gid; i < np; i += gsz) V.passed[i] = pv;
@@ -1351,6 +1467,8 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.recheck_rows = F.recheck_rows;
   V.recheck_thr = F.recheck_thr;
   V.recheck_span = F.recheck_span;
+  V.recheck_q = F.recheck_q;
+  V.rc_counts = F.rc_counts;
   V.hit_rows = F.hit_rows;
   V.queryT_c = F.queryT_c;
   V.norms_c = F.norms_c;
@@ -1479,7 +1597,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
       if (e1) (void)hipEventRecord(e1, st);
       LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
-                G, f16 ? 800.0f : 0.0f);
+                G, f16 ? 800.0f : 0.0f, f16 ? 1 : 0);
+      if (f16) LAUNCH_MV(k_recheck_filter, a, dim3(8, G > 1 ? 16 : 96, G), B256, 0, st, dir);
       // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
       (void)nb_max;
       // (most spans are a fraction of a per cent of the cloud, a few cover half of it: enough slices that the widest
@@ -1487,7 +1606,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       const int ey = G > 1 ? 4 : 16;
       int ex = 128;
       if (G > 1) ex = max(8, 384 / G);  // a group of pairs shares the device
-      LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);
+      if (f16) LAUNCH_MV(k_nn_exact_rows, a, dim3(32, 8, G), B256, 0, st, dir, 1);  // (returns at once unless the filter gave up)
+      else LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir, 0);
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
