@@ -2,10 +2,15 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 Pinning status (see quatro_oracle.cpp header and DESIGN.md section 4): the reference ships no golden vectors and most of
-it cannot be built here (PCL / FLANN / Eigen / PMC absent).  ONE stage can: teaser::Matcher — its own
-feature_matcher.cc is compiled in place into oracle/_ref/libref_matcher.so (oracle/Makefile, target `ref`) and the
-oracle's match() is checked against it (ref_match below, tests/test_ref_cpu.py, tests/golden/matcher_ref.npz).  For the
-other stages the oracle defines the deterministic semantics the HIP path is compared against: parity unpinned there.
+it cannot be built here (PCL / FLANN / Eigen / PMC absent).  Two parts can, and are compiled from the reference's own
+text where it lies (oracle/Makefile; outputs under oracle/_ref/):
+  * teaser::Matcher — src/teaser_utils/feature_matcher.cc — libref_matcher.so, checked against match() (ref_match);
+  * the Eigen-only member functions of class Quatro — computeTIMs, solveForScale, solveForRotation2D,
+    solveForTranslation, estimate — and teaser/utils.h's svdRot / svdRot2d — libref_solver.so (Eigen replaced by the
+    subset in ref_shim_solver/: the reference's formulae and control flow are pinned, Eigen's summation orders and SVD
+    are not), checked against build_graph(), gnc_rotation2d(), cote_estimate*() (ref_* functions below).
+tests/test_ref_cpu.py runs both; tests/golden/matcher_ref.npz and solver_ref.npz hold their outputs for the GPU box.
+Voxel grid, normals / FPFH (PCL) and the clique search (PMC) remain unpinned: there the oracle defines the semantics.
 """
 from __future__ import annotations
 
@@ -49,6 +54,101 @@ def build_ref(force: bool = False):
 
 def ref_available() -> bool:
     return os.path.exists(_REF_PATH)
+
+
+_REF_SOLVER_PATH = os.path.join(_HERE, "_ref", "libref_solver.so")
+_refs = None
+
+
+def build_ref_solver(force: bool = False):
+    """Compiles the Eigen-only member functions of the reference's class Quatro (see the module docstring)."""
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "include", "quatro.hpp")):
+        subprocess.check_call(["make", "-C", _HERE, "ref_solver", "REF=" + REFERENCE_ROOT] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+    return _REF_SOLVER_PATH if os.path.exists(_REF_SOLVER_PATH) else None
+
+
+def ref_solver_available() -> bool:
+    return os.path.exists(_REF_SOLVER_PATH)
+
+
+def _rs():
+    global _refs
+    if _refs is None:
+        _refs = C.CDLL(_REF_SOLVER_PATH)
+    return _refs
+
+
+def ref_compute_tims(v3):
+    """Quatro::computeTIMs (include/quatro.hpp:307-344): N x 3 points -> (K x 3 TIMs, K x 2 index map)."""
+    v = np.ascontiguousarray(np.asarray(v3, dtype=np.float64).T)  # 3 x N row-major
+    N = v.shape[1]
+    K = N * (N - 1) // 2
+    out = np.zeros((3, K))
+    mp = np.zeros((2, K), dtype=np.int32)
+    _rs().qref_compute_tims(_p(v, C.c_double), N, _p(out, C.c_double), _p(mp, C.c_int))
+    return out.T.copy(), mp.T.copy()
+
+
+def ref_scale_mask(src_tims, dst_tims, noise_bound=0.3, cbar2=1.0):
+    """Quatro::solveForScale's inlier mask (:355-386) over K x 3 TIM arrays."""
+    a = np.ascontiguousarray(np.asarray(src_tims, dtype=np.float64).T)
+    b = np.ascontiguousarray(np.asarray(dst_tims, dtype=np.float64).T)
+    K = a.shape[1]
+    mask = np.zeros(K, dtype=np.uint8)
+    _rs().qref_scale_mask(_p(a, C.c_double), _p(b, C.c_double), C.c_longlong(K), C.c_double(noise_bound), C.c_double(cbar2),
+                          _p(mask, C.c_ubyte))
+    return mask.astype(bool)
+
+
+REF_GNC_NOISE_BOUND = 0.6  # solveForRotation2D freezes its bound at the process's first call (a function-local static)
+
+
+def ref_gnc_rotation2d(src2, dst2, gnc_factor=1.4, max_iter=50, cost_thr=1.1e-4):
+    """Quatro::solveForRotation2D (:430-572) on M x 2 TIMs with noise bound REF_GNC_NOISE_BOUND -> (R, cost, inliers)."""
+    a = np.ascontiguousarray(np.asarray(src2, dtype=np.float64).T)
+    b = np.ascontiguousarray(np.asarray(dst2, dtype=np.float64).T)
+    M = a.shape[1]
+    R = np.zeros(4)
+    inl = np.zeros(M, dtype=np.uint8)
+    cost = C.c_double()
+    _rs().qref_gnc_rotation2d(_p(a, C.c_double), _p(b, C.c_double), M, C.c_double(REF_GNC_NOISE_BOUND), C.c_double(gnc_factor),
+                              int(max_iter), C.c_double(cost_thr), _p(R, C.c_double), _p(inl, C.c_ubyte), C.byref(cost))
+    return R.reshape(2, 2), cost.value, inl.astype(bool)
+
+
+def ref_cote_estimate(X, ranges, median=True):
+    """Quatro::estimate (:618-747): (estimate, inlier mask)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    R = np.ascontiguousarray(np.broadcast_to(np.asarray(ranges, dtype=np.float64), X.shape))
+    inl = np.zeros(X.shape[0], dtype=np.uint8)
+    est = C.c_double()
+    _rs().qref_cote_estimate(_p(X, C.c_double), _p(R, C.c_double), X.shape[0], int(median), C.byref(est), _p(inl, C.c_ubyte))
+    return est.value, inl.astype(bool)
+
+
+def ref_translation(src3, dst3, cote_noise_bound=0.3, cbar2=1.0, median=True):
+    """Quatro::solveForTranslation (:585-616) on N x 3 (rotated source, target) -> (t, inlier mask)."""
+    a = np.ascontiguousarray(np.asarray(src3, dtype=np.float64).T)
+    b = np.ascontiguousarray(np.asarray(dst3, dtype=np.float64).T)
+    N = a.shape[1]
+    t = np.zeros(3)
+    inl = np.zeros(N, dtype=np.uint8)
+    _rs().qref_translation(_p(a, C.c_double), _p(b, C.c_double), N, C.c_double(cote_noise_bound), C.c_double(cbar2),
+                           int(median), _p(t, C.c_double), _p(inl, C.c_ubyte))
+    return t, inl.astype(bool)
+
+
+def ref_svd_rot(X, Y, W):
+    """teaser::utils::svdRot2d / svdRot (include/teaser/utils.h:123-166) on N x 2 or N x 3 pairs."""
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64).T)
+    Y = np.ascontiguousarray(np.asarray(Y, dtype=np.float64).T)
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    d, N = X.shape
+    R = np.zeros(d * d)
+    (_rs().qref_svd_rot2d if d == 2 else _rs().qref_svd_rot3d)(_p(X, C.c_double), _p(Y, C.c_double), _p(W, C.c_double), N,
+                                                               _p(R, C.c_double))
+    return R.reshape(d, d)
 
 
 def ref_match(xyz_s, desc_s, xyz_t, desc_t, crosscheck=True, tuple_test=True, tuple_scale=0.95, seed=0):

@@ -4,11 +4,19 @@
 // cpu_baseline leg of bench.py may build, load or call it.  The product path (quatro_amd/ +
 // libquatro_hip.so) never links or calls anything in oracle/.
 //
-// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures, cannot be
-// compiled here (PCL / FLANN / Eigen / PMC absent) and is itself non-deterministic
-// (time-seeded tuple test, 12-thread racy clique heuristic, unstable sorts).  This file
-// therefore DEFINES the deterministic semantics the GPU path is compared against.  It follows the
-// reference's in-tree code line by line where that exists and restates the published algorithms of
+// PINNING STATUS.  The reference ships no tests, golden vectors or fixtures, cannot be built as a whole
+// here (PCL / FLANN / Eigen / PMC absent) and is itself non-deterministic (time-seeded tuple test,
+// 12-thread racy clique heuristic, unstable sorts).  Two parts of its own text DO compile here, against
+// stand-ins for the absent libraries, and pin the corresponding functions of this file (oracle/Makefile targets `ref`
+// and `ref_solver`, tests/test_ref_cpu.py, tests/golden/matcher_ref.npz and solver_ref.npz):
+//   * teaser::Matcher (src/teaser_utils/feature_matcher.cc)            -> match(): identical correspondence lists;
+//   * Quatro::computeTIMs / solveForScale / solveForRotation2D / solveForTranslation / estimate and
+//     teaser::utils::svdRot2d (include/quatro.hpp, include/teaser/utils.h, Eigen replaced by a small eager stand-in)
+//                                                                      -> build_graph(): identical edges; COTE and the
+//        translation: identical bits; GNC-TLS yaw: identical inlier sets, rotation / cost to rounding (D6).
+// PARITY UNPINNED for the rest — voxel grid, normals / FPFH (PCL), core numbers and the clique search (PMC), the
+// finalisation glue: there this file DEFINES the deterministic semantics the GPU path is compared against.  It follows
+// the reference's in-tree code line by line where that exists and restates the published algorithms of
 // the un-vendored dependencies (PCL 1.8.1, FLANN 1.9.1, Eigen 3.3, PMC tag `libpmc`) at the
 // reference's call sites.  Each function cites what it follows.  Declared divergences:
 //   D1 tuple-test RNG: counter-based qm_rand_u32(seed, 3*trial+k) instead of srand(time)/rand()

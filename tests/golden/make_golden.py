@@ -1,6 +1,7 @@
-"""Generates the committed fixtures under tests/golden/: matcher_ref.npz from the REFERENCE's own teaser::Matcher
-(compiled from /root/reference by oracle/Makefile, target `ref`), the others from the CPU oracle (the reference has no
-golden vectors and its other stages cannot run here — see oracle/quatro_oracle.cpp header).  They pin the oracle against
+"""Generates the committed fixtures under tests/golden/: matcher_ref.npz from the REFERENCE's own teaser::Matcher and
+solver_ref.npz from the reference's Eigen-only back-end functions (both compiled from /root/reference by
+oracle/Makefile, targets `ref` and `ref_solver`), the others from the CPU oracle (the reference has no golden vectors
+and its other stages cannot run here — see oracle/quatro_oracle.cpp header).  They pin the oracle against
 accidental drift and give the GPU tests inputs/outputs that do not depend on the oracle being rebuilt.
 
     python tests/golden/make_golden.py
@@ -60,6 +61,45 @@ def main():
                 "ab_notuple": (a2, da2, b2, db2, True, False, 15)}.items():
             out["corr_" + name] = qo.ref_match(x1, d1, x2, d2, crosscheck=cross, tuple_test=tup, seed=seed)
         np.savez_compressed(os.path.join(HERE, "matcher_ref.npz"), **out)
+    # --- the REFERENCE's own back-end functions (oracle/_ref/libref_solver.so: computeTIMs, solveForScale,
+    # solveForRotation2D, solveForTranslation, estimate of include/quatro.hpp, compiled from the header's text against an
+    # Eigen-subset stand-in): inputs and what they returned
+    if qo.build_ref_solver():
+        g = np.random.default_rng(2024)
+        out = {"gnc_noise_bound": qo.REF_GNC_NOISE_BOUND}
+        # consistency graph: TIMs of both clouds + scale test
+        src, tgt, _, _ = synth.correspondences(150, 0.3, seed=9, noise=0.05)
+        ts, mp = qo.ref_compute_tims(src[:, :3].astype(np.float64))
+        tt, _ = qo.ref_compute_tims(tgt[:, :3].astype(np.float64))
+        out.update(graph_src=src, graph_tgt=tgt, tims_src=ts, tims_tgt=tt, tims_map=mp,
+                   scale_mask=qo.ref_scale_mask(ts, tt, 0.3, 1.0))
+        # GNC-TLS yaw on TIM-like 2-D pairs, several sizes / outlier rates
+        for k, (M, frac) in enumerate(((6, 1.0), (40, 0.8), (150, 0.5), (400, 0.3))):
+            ang = 0.25 + 0.07 * k
+            Rt = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+            a = g.normal(0, 5, (M, 2))
+            b = a @ Rt.T + g.normal(0, 0.05, (M, 2))
+            bad = g.random(M) > frac
+            b[bad] = g.normal(0, 5, (int(bad.sum()), 2))
+            R, cost, inl = qo.ref_gnc_rotation2d(a, b)
+            out.update({f"gnc{k}_src": a, f"gnc{k}_dst": b, f"gnc{k}_R": R, f"gnc{k}_cost": cost, f"gnc{k}_inl": inl})
+        # COTE: estimate(), uniform and per-element ranges, both selection modes
+        for k, N in enumerate((2, 3, 10, 77, 300)):
+            X = g.normal(0, 1, N)
+            X[:max(2, N // 2)] = 0.5 + g.normal(0, 0.05, max(2, N // 2))
+            rg = g.uniform(0.05, 0.6, N)
+            out[f"cote{k}_X"], out[f"cote{k}_ranges"] = X, rg
+            for tag, ranges in (("u", np.full(N, 0.3)), ("r", rg)):
+                for median in (1, 0):
+                    e, m = qo.ref_cote_estimate(X, ranges, bool(median))
+                    out[f"cote{k}_{tag}{median}_est"], out[f"cote{k}_{tag}{median}_inl"] = e, m
+        # translation of a rotated cloud
+        a = g.normal(0, 5, (120, 3))
+        b = a + np.array([1.0, -2.0, 0.5]) + g.normal(0, 0.05, (120, 3))
+        b[::4] += 3.0
+        t, m = qo.ref_translation(a, b, 0.3, 1.0, True)
+        out.update(trans_src=a, trans_dst=b, trans_t=t, trans_inl=m)
+        np.savez_compressed(os.path.join(HERE, "solver_ref.npz"), **out)
     print("golden fixtures written to", HERE)
 
 

@@ -260,6 +260,33 @@ def test_register_pair_matches_oracle(hip, qo, pair_id):
     assert abs(np.arctan2(np.sin(d), np.cos(d))) < 0.02 and np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) < 0.3
 
 
+def test_back_end_stages_equal_reference_generated_golden(hip):
+    """The device's stage entry points against what the reference's OWN functions returned (tests/golden/solver_ref.npz,
+    made by the compiled include/quatro.hpp functions: computeTIMs, solveForScale, solveForRotation2D, estimate): TIMs,
+    index map, scale mask, COTE estimate and inliers bit for bit; the GNC-TLS yaw with the same inliers and the
+    rotation / cost to rounding (fixed 64-lane summation order, closed-form 2 x 2 rotation)."""
+    g = np.load(os.path.join(G, "solver_ref.npz"))
+    src, tgt = g["graph_src"], g["graph_tgt"]
+    ts, mp = hip.compute_tims(np.ascontiguousarray(src[:, :3].astype(np.float64).T))
+    tt, _ = hip.compute_tims(np.ascontiguousarray(tgt[:, :3].astype(np.float64).T))
+    assert np.array_equal(ts.T, g["tims_src"]) and np.array_equal(tt.T, g["tims_tgt"]) and np.array_equal(mp.T, g["tims_map"])
+    assert np.array_equal(hip.scale_mask(ts, tt, 0.3, 1.0), g["scale_mask"])
+    nb = float(g["gnc_noise_bound"])
+    for k in range(4):
+        R, cost, iters, inl = hip.gnc_rotation2d(g[f"gnc{k}_src"], g[f"gnc{k}_dst"], nb)
+        assert np.array_equal(inl, g[f"gnc{k}_inl"]), k
+        assert np.abs(R - g[f"gnc{k}_R"]).max() < 1e-12, k
+        rc = float(g[f"gnc{k}_cost"])
+        assert (cost == rc) or abs(cost - rc) <= 1e-9 * abs(rc) + 1e-18, k
+    for k in range(5):
+        X, rg = g[f"cote{k}_X"], g[f"cote{k}_ranges"]
+        for tag, ranges in (("u", np.full(X.shape[0], 0.3)), ("r", rg)):
+            for median in (1, 0):
+                e, m, _ = hip.cote_estimate_ranges(X, ranges, bool(median))
+                assert e == float(g[f"cote{k}_{tag}{median}_est"]), (k, tag, median)
+                assert np.array_equal(m, g[f"cote{k}_{tag}{median}_inl"]), (k, tag, median)
+
+
 def test_host_mirror_reads_like_the_reference_demo(hip, qo, small_pair):
     """examples/run_global_registration.cpp:103-108, 206-221, 243-246 through quatro_amd.api."""
     from quatro_amd import api

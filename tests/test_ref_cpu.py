@@ -2,6 +2,8 @@
 
 * the REFERENCE's teaser::Matcher, compiled from /root/reference (oracle/Makefile target `ref`): live comparison when
   oracle/_ref/libref_matcher.so is present, and the committed outputs it generated (tests/golden/matcher_ref.npz);
+* the REFERENCE's Eigen-only back-end functions (computeTIMs, solveForScale, solveForRotation2D, solveForTranslation,
+  estimate of include/quatro.hpp; target `ref_solver`): live, and their committed outputs (tests/golden/solver_ref.npz);
 * library cross-checks of the third-party semantics the oracle restates: scipy's cKDTree for the radius sets,
   numpy's eigh for pcl::eigen33, and a known answer of the published FPFH definition (Rusu 2009) on a plane.
 """
@@ -66,6 +68,102 @@ def test_oracle_matcher_equals_compiled_reference_live(qo):
     _, _, dt = qo.fpfh(vt, 0.7, 1.0)
     for (a, da, b, db, seed) in ((vs, ds, vt, dt, 1), (vt, dt, vs, ds, 2)):
         assert np.array_equal(qo.ref_match(a, da, b, db, seed=seed), qo.match(a, da, b, db, seed=seed))
+
+
+def _graph_from_reference_mask(L, mp, mask):
+    A = np.zeros((L, L), dtype=bool)
+    A[mp[:, 0], mp[:, 1]] = mask
+    return A | A.T
+
+
+def _oracle_adjacency(qo, src, tgt, noise_bound=0.3, cbar2=1.0):
+    L = src.shape[0]
+    bm = qo.build_graph(src, tgt, noise_bound, cbar2)
+    return np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :L].astype(bool)
+
+
+def test_oracle_back_end_equals_reference_generated_golden(qo):
+    """tests/golden/solver_ref.npz holds what the reference's OWN computeTIMs / solveForScale / solveForRotation2D /
+    solveForTranslation / estimate returned (include/quatro.hpp, compiled from its text by `make -C oracle ref_solver`).
+    The oracle's restatements have to agree: the consistency graph edge for edge, COTE and the translation bit for bit,
+    the GNC-TLS yaw with the same inlier set and the rotation / cost to rounding (the oracle sums in a fixed 64-lane
+    order and uses a closed-form 2 x 2 rotation — declared divergence D6)."""
+    g = np.load(os.path.join(G, "solver_ref.npz"))
+    A = _oracle_adjacency(qo, g["graph_src"], g["graph_tgt"])
+    assert np.array_equal(A, _graph_from_reference_mask(A.shape[0], g["tims_map"], g["scale_mask"]))
+    assert g["scale_mask"].sum() > 100
+    nb = float(g["gnc_noise_bound"])
+    for k in range(4):
+        R, cost, iters, inl = qo.gnc_rotation2d(g[f"gnc{k}_src"], g[f"gnc{k}_dst"], nb)
+        assert np.array_equal(inl, g[f"gnc{k}_inl"]), k
+        assert np.abs(R - g[f"gnc{k}_R"]).max() < 1e-12, k
+        rc = float(g[f"gnc{k}_cost"])
+        assert (cost == rc) or abs(cost - rc) <= 1e-9 * abs(rc) + 1e-18, k
+    for k in range(5):
+        X, rg = g[f"cote{k}_X"], g[f"cote{k}_ranges"]
+        for tag, ranges in (("u", np.full(X.shape[0], 0.3)), ("r", rg)):
+            for median in (1, 0):
+                e, m, _ = qo.cote_estimate_ranges(X, ranges, bool(median))
+                assert e == float(g[f"cote{k}_{tag}{median}_est"]), (k, tag, median)
+                assert np.array_equal(m, g[f"cote{k}_{tag}{median}_inl"]), (k, tag, median)
+    a, b = g["trans_src"], g["trans_dst"]
+    t, inl = [], np.ones(a.shape[0], dtype=bool)
+    for ax in range(3):
+        e, m, _ = qo.cote_estimate(b[:, ax] - a[:, ax], 0.3, True)
+        t.append(e)
+        inl &= m
+    assert np.array_equal(np.array(t), g["trans_t"]) and np.array_equal(inl, g["trans_inl"])
+
+
+def test_oracle_back_end_equals_compiled_reference_live(qo):
+    """The same comparisons against the compiled reference functions themselves, on fresh random inputs."""
+    if not (qo.build_ref_solver() and qo.ref_solver_available()):
+        pytest.skip("oracle/_ref/libref_solver.so is not available (no /root/reference, no prebuilt file)")
+    g = np.random.default_rng(77)
+    for L in (2, 3, 40, 260):
+        src, tgt, _, _ = synth.correspondences(L, 0.3, seed=100 + L, noise=0.05)
+        for nb, cbar2 in ((0.3, 1.0), (0.1, 2.0)):
+            ts, mp = qo.ref_compute_tims(src[:, :3].astype(np.float64))
+            tt, _ = qo.ref_compute_tims(tgt[:, :3].astype(np.float64))
+            mask = qo.ref_scale_mask(ts, tt, nb, cbar2)
+            assert np.array_equal(_oracle_adjacency(qo, src, tgt, nb, cbar2), _graph_from_reference_mask(L, mp, mask)), (L, nb)
+    for trial in range(12):
+        M = int(g.integers(3, 500))
+        ang = g.uniform(-3, 3)
+        Rt = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        a = g.normal(0, 5, (M, 2))
+        b = a @ Rt.T + g.normal(0, g.choice([0.0, 0.02, 0.2]), (M, 2))
+        bad = g.random(M) > g.choice([0.2, 0.6, 1.0])
+        b[bad] = g.normal(0, 5, (int(bad.sum()), 2))
+        Rr, cr, ir = qo.ref_gnc_rotation2d(a, b)
+        Ro, co, _, io = qo.gnc_rotation2d(a, b, qo.REF_GNC_NOISE_BOUND)
+        assert np.array_equal(io, ir), trial
+        assert np.abs(Ro - Rr).max() < 1e-11, trial
+        assert (co == cr) or abs(co - cr) <= 1e-9 * abs(cr) + 1e-18, trial  # (noise-free pairs: costs of 1e-29)
+    for trial in range(40):
+        N = int(g.integers(2, 400))
+        X = g.normal(0, g.choice([0.1, 1.0, 30.0]), N)
+        if trial % 3 == 0:
+            X[:max(2, N // 2)] = g.normal(0.5, 0.05, max(2, N // 2))
+        ranges = g.uniform(0.05, 0.6, N) if trial % 2 else np.full(N, float(g.choice([0.1, 0.3, 0.6])))
+        for median in (True, False):
+            er, mr = qo.ref_cote_estimate(X, ranges, median)
+            eo, mo, nc = qo.cote_estimate_ranges(X, ranges, median)
+            if median and nc < 2:
+                continue  # the reference reads past its candidate list for a consensus set of one (declared divergence D5)
+            assert eo == er and np.array_equal(mo, mr), (trial, N, median)
+    for d in (2, 3):  # teaser::utils::svdRot2d / svdRot against numpy's SVD construction
+        X = g.normal(0, 1, (60, d))
+        Q, _ = np.linalg.qr(g.normal(0, 1, (d, d)))
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        Y = X @ Q.T + g.normal(0, 0.01, (60, d))
+        W = g.random(60)
+        U, _, Vt = np.linalg.svd((X * W[:, None]).T @ Y)
+        V = Vt.T
+        if np.linalg.det(U) * np.linalg.det(V) < 0:
+            V[:, -1] *= -1
+        assert np.abs(qo.ref_svd_rot(X, Y, W) - V @ U.T).max() < 1e-12
 
 
 def test_radius_sets_against_scipy_ckdtree(qo):
