@@ -150,7 +150,7 @@ def test_oracle_back_end_equals_compiled_reference_live(qo):
             er, mr = qo.ref_cote_estimate(X, ranges, median)
             eo, mo, nc = qo.cote_estimate_ranges(X, ranges, median)
             if median and nc < 2:
-                continue  # the reference reads past its candidate list for a consensus set of one (declared divergence D5)
+                continue  # the reference reads past its candidate list for a consensus set of one (declared divergence D4)
             assert eo == er and np.array_equal(mo, mr), (trial, N, median)
     for d in (2, 3):  # teaser::utils::svdRot2d / svdRot against numpy's SVD construction
         X = g.normal(0, 1, (60, d))
