@@ -4,12 +4,14 @@ max-clique -> GNC-TLS -> COTE) on synthetic KITTI-64-shaped scan pairs resident 
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run, one rank per GPU.  A step = one registration of one scan pair (BASELINE.json
-configs[1]: a single KITTI-64 pair, whole path on the GPU).  The K timed steps are the pair ids [0, K),
-block-partitioned over the ranks (quatro_amd.dist.shard_range — BASELINE configs[3]'s partition, "strong"
-scaling: the id range is fixed, N only changes who runs which block); pair id -> synthetic pair is
-id % pool.  Pairs are independent, so there is no data-path collective; the only exchange is the gather of
-the fixed-size result records (RCCL) after the timed region plus the barrier / max-over-ranks of the contract.
-Prints ONE JSON line on rank 0.
+configs[1]: a single KITTI-64 pair, whole path on the GPU).  Every rank times exactly K steps: the pair ids
+[0, N*K) are block-partitioned over the ranks (quatro_amd.dist.shard_range, the partition of BASELINE configs[3]), rank r
+registers ids [r*K, (r+1)*K) one at a time — per-GPU work is fixed as N grows ("weak" scaling) and `value` is the
+whole job, N*K registrations over the slowest rank's time.  Pair id -> synthetic pair is id % pool.  Pairs are
+independent, so there is no data-path collective; the only exchange is the gather of the fixed-size result records
+(RCCL) after the timed region plus the barrier / max-over-ranks of the contract.  For N > 1 the line also carries
+`sharded_leg`: configs[3] itself — a FIXED set of 4096 pair ids block-partitioned over the ranks and streamed through
+the batched entry points (strong scaling).  Prints ONE JSON line on rank 0.
 
 Objects in the line next to the contract's keys:
   roofline      — dominant kernel k_nn_f16: the 33-D distance matrix nb' - 2 a.b evaluated on the f16 matrix pipe with
@@ -142,7 +144,7 @@ def main() -> None:
         step(p)
         p["n_src"], p["n_tgt"], p["L"], p["M"] = res.n_src, res.n_tgt, res.n_corr, res.n_clique
         p["n_hit"] = int(h.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[7])  # rows the second NN direction is asked for
-    lo, hi = qdist.shard_range(args.steps, rank, world)
+    lo, hi = qdist.shard_range(world * args.steps, rank, world)  # = [rank * K, (rank + 1) * K)
     for w in range(args.warmup):
         step(pool[w % len(pool)])
     torch.cuda.synchronize()
@@ -192,7 +194,7 @@ def main() -> None:
     extra = {}
     # ---- BASELINE configs[2]: a batch of independent pairs streamed through one GPU
     if "batch" in legs and hasattr(h, "register_batch_dev"):
-        extra["batch256_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist)
+        extra["batch256_leg" if world == 1 else "sharded_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist)
     # ---- solver alone at the metric's "~5k corr" (the matcher yields fewer on the synthetic scans)
     if "solver5k" in legs and rank == 0:
         extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
@@ -211,12 +213,12 @@ def main() -> None:
 
     p0 = pool[0]
     r0 = p0["result"]
-    value = args.steps / elapsed
+    value = world * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
         "metric": METRIC,
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (voxel grid, FPFH, 33-D matching: f16-split MFMA filter, exact f32 decision) / f64 (consistency graph, GNC-TLS, COTE)", "data": "synthetic",
         "config": {
             "workload": "synthetic KITTI-64-shaped single pair (quatro_amd.synth.kitti64_pair_16k), voxel 0.3 m, whole "
@@ -228,7 +230,8 @@ def main() -> None:
                       "n_hit": int(p["n_hit"])}
                      for p in pool],
             "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
-            "parallelism": f"pair ids [0,{args.steps}) block-partitioned over {world} GPU(s), one process per GPU, RCCL "
+            "parallelism": f"pair ids [0,{world * args.steps}) block-partitioned over {world} GPU(s) ({args.steps} per rank), one "
+                           "process per GPU, RCCL "
                            "gather of result records",
         },
         "stage_ms": {k: round(v / max(stage_n, 1), 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
