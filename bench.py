@@ -107,15 +107,24 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # QTR_BENCH_ONE_DEVICE=1 (test hook for single-GPU boxes): every rank computes on cuda:0 and the collectives go
+    # through gloo on host tensors, so that the N > 1 logic (partition, barriers, gather, sharded leg) can be exercised
+    one_dev = os.environ.get("QTR_BENCH_ONE_DEVICE") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
+    cdev = None if (world > 1 and one_dev) else dev  # where the collectives' tensors live
 
     from quatro_amd import dist as qdist
     from quatro_amd import lib as ql
@@ -164,7 +173,7 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = qdist.max_over_ranks(elapsed, dev)
+    elapsed = qdist.max_over_ranks(elapsed, cdev)
     my_steps = max(hi - lo, 1)
     nn_ms, nn_launches = h.nn_totals()
     nn_flop, alg_bytes, alg_flop = 0.0, 0.0, 0.0
@@ -189,12 +198,12 @@ def main() -> None:
         r = h.register_pair(p["src_h"], p["tgt_h"], p["fp"], prm)
         p["result"] = r
         recs.append(qdist.pack_record(p["id"], r))
-    gathered = qdist.gather_records(np.stack(recs), dev)
+    gathered = qdist.gather_records(np.stack(recs), cdev)
 
     extra = {}
     # ---- BASELINE configs[2]: a batch of independent pairs streamed through one GPU
     if "batch" in legs and hasattr(h, "register_batch_dev"):
-        extra["batch256_leg" if world == 1 else "sharded_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist)
+        extra["batch256_leg" if world == 1 else "sharded_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev)
     # ---- solver alone at the metric's "~5k corr" (the matcher yields fewer on the synthetic scans)
     if "solver5k" in legs and rank == 0:
         extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
@@ -288,7 +297,7 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist):
+def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev):
     """BASELINE configs[2] (and, for N > 1, configs[3]): B pair ids streamed through the batched entry points
     (qtr_submit_batch / qtr_wait), block-partitioned over the ranks."""
     B = args.batch_pairs if world == 1 else args.sharded_pairs
@@ -306,7 +315,7 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    el = qdist.max_over_ranks(time.perf_counter() - t0, dev)
+    el = qdist.max_over_ranks(time.perf_counter() - t0, cdev)
     same = all(bool(np.allclose(r["T"], pool[i % len(pool)]["result"]["T"], rtol=0, atol=0)) for i, r in zip(ids, results))
     hb.close()
     return {"what": f"{B} pair ids, block-partitioned over {world} GPU(s), batched launch chains "
