@@ -5,10 +5,11 @@ Pinning status (see quatro_oracle.cpp header and DESIGN.md section 4): the refer
 it cannot be built here (PCL / FLANN / Eigen / PMC absent).  Two parts can, and are compiled from the reference's own
 text where it lies (oracle/Makefile; outputs under oracle/_ref/):
   * teaser::Matcher — src/teaser_utils/feature_matcher.cc — libref_matcher.so, checked against match() (ref_match);
-  * the Eigen-only member functions of class Quatro — computeTIMs, solveForScale, solveForRotation2D,
-    solveForTranslation, estimate — and teaser/utils.h's svdRot / svdRot2d — libref_solver.so (Eigen replaced by the
-    subset in ref_shim_solver/: the reference's formulae and control flow are pinned, Eigen's summation orders and SVD
-    are not), checked against build_graph(), gnc_rotation2d(), cote_estimate*() (ref_* functions below).
+  * the back end of class Quatro — computeTIMs, solveForScale, solveForRotation[2D], solveForTranslation, estimate and
+    computeTransformation itself, with teaser::Graph and teaser/utils.h's svdRot / svdRot2d — libref_solver.so (Eigen
+    replaced by the subset in ref_shim_solver/: the reference's formulae and control flow are pinned, Eigen's summation
+    orders and SVD are not; PMC's clique search answered by max_clique() below through a callback), checked against
+    build_graph(), gnc_rotation2d(), cote_estimate*() and solve() (ref_* functions below).
 tests/test_ref_cpu.py runs both; tests/golden/matcher_ref.npz and solver_ref.npz hold their outputs for the GPU box.
 Voxel grid, normals / FPFH (PCL) and the clique search (PMC) remain unpinned: there the oracle defines the semantics.
 """
@@ -137,6 +138,45 @@ def ref_translation(src3, dst3, cote_noise_bound=0.3, cbar2=1.0, median=True):
     _rs().qref_translation(_p(a, C.c_double), _p(b, C.c_double), N, C.c_double(cote_noise_bound), C.c_double(cbar2),
                            int(median), _p(t, C.c_double), _p(inl, C.c_ubyte))
     return t, inl.astype(bool)
+
+
+_clique_cb_keepalive = None
+
+
+def ref_compute_transformation(src4, tgt4, noise_bound=0.3, cbar2=1.0, gnc_factor=1.4, max_iter=50, cost_thr=1.1e-4,
+                               inlier_selection_mode=1, kcore_thr=0.5, cote_noise_bound=0.3, cote_median=True,
+                               use_rot_inliers=False, clique_order=0):
+    """Quatro::computeTransformation (include/quatro.hpp:769-936) of the REFERENCE on L matched keypoint pairs.  Everything
+    is the reference's text except teaser::MaxCliqueSolver::findMaxClique (PMC is absent): that call is answered by THIS
+    module's max_clique() on the graph the reference code built.  The noise bound of the rotation stage is the first
+    call's in the process (a function-local static of the reference): keep noise_bound = REF_GNC_NOISE_BOUND / 2."""
+    global _clique_cb_keepalive
+    rs = _rs()
+    CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_ulonglong), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int))
+
+    def cb(bm, L, W, mode, thr, out):
+        bitmap = np.ctypeslib.as_array(bm, shape=(L, max(W, 1))).astype(np.uint64) if L > 0 else np.zeros((0, 1), np.uint64)
+        cl = max_clique(bitmap, mode, thr, clique_order)
+        for i, v in enumerate(cl):
+            out[i] = int(v)
+        return len(cl)
+    _clique_cb_keepalive = CB(cb)
+    rs.qref_set_clique_callback(_clique_cb_keepalive)
+    a = np.ascontiguousarray(np.asarray(src4, dtype=np.float32)[:, :3])
+    b = np.ascontiguousarray(np.asarray(tgt4, dtype=np.float32)[:, :3])
+    L = a.shape[0]
+    T = np.zeros(16)
+    cl = np.zeros(max(L, 1), dtype=np.int32)
+    rot = np.zeros(max(L, 1), dtype=np.int32)
+    fin = np.zeros(max(L, 1), dtype=np.int32)
+    ncl, nrot, nfin = C.c_int(), C.c_int(), C.c_int()
+    valid = rs.qref_compute_transformation(_p(a, C.c_float), _p(b, C.c_float), L, C.c_double(noise_bound), C.c_double(cbar2),
+                                           C.c_double(gnc_factor), int(max_iter), C.c_double(cost_thr),
+                                           int(inlier_selection_mode), C.c_double(kcore_thr), C.c_double(cote_noise_bound),
+                                           int(cote_median), int(use_rot_inliers), _p(T, C.c_double), _p(cl, C.c_int),
+                                           C.byref(ncl), _p(rot, C.c_int), C.byref(nrot), _p(fin, C.c_int), C.byref(nfin))
+    return {"valid": bool(valid), "T": T.reshape(4, 4), "clique": cl[:ncl.value].copy(), "rot_inliers": rot[:nrot.value].copy(),
+            "final_inliers": fin[:nfin.value].copy()}
 
 
 def ref_svd_rot(X, Y, W):

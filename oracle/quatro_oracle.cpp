@@ -10,12 +10,13 @@
 // stand-ins for the absent libraries, and pin the corresponding functions of this file (oracle/Makefile targets `ref`
 // and `ref_solver`, tests/test_ref_cpu.py, tests/golden/matcher_ref.npz and solver_ref.npz):
 //   * teaser::Matcher (src/teaser_utils/feature_matcher.cc)            -> match(): identical correspondence lists;
-//   * Quatro::computeTIMs / solveForScale / solveForRotation2D / solveForTranslation / estimate and
-//     teaser::utils::svdRot2d (include/quatro.hpp, include/teaser/utils.h, Eigen replaced by a small eager stand-in)
-//                                                                      -> build_graph(): identical edges; COTE and the
-//        translation: identical bits; GNC-TLS yaw: identical inlier sets, rotation / cost to rounding (D6).
-// PARITY UNPINNED for the rest — voxel grid, normals / FPFH (PCL), core numbers and the clique search (PMC), the
-// finalisation glue: there this file DEFINES the deterministic semantics the GPU path is compared against.  It follows
+//   * Quatro::computeTIMs / solveForScale / solveForRotation[2D] / solveForTranslation / estimate / computeTransformation,
+//     teaser::Graph and teaser::utils::svdRot2d (include/quatro.hpp, include/teaser/*.h; Eigen replaced by a small eager
+//     stand-in, PMC's clique search answered by this file's)            -> build_graph(): identical edges; COTE and the
+//        translation: identical bits; GNC-TLS yaw: identical inlier sets, rotation / cost to rounding (D6); solve():
+//        identical clique / rotation-inlier / final-inlier lists, the 4 x 4 to 4e-15.
+// PARITY UNPINNED for the rest — voxel grid, normals / FPFH (PCL), core numbers and the clique search (PMC): there this
+// file DEFINES the deterministic semantics the GPU path is compared against.  It follows
 // the reference's in-tree code line by line where that exists and restates the published algorithms of
 // the un-vendored dependencies (PCL 1.8.1, FLANN 1.9.1, Eigen 3.3, PMC tag `libpmc`) at the
 // reference's call sites.  Each function cites what it follows.  Declared divergences:

@@ -5,41 +5,68 @@
 // members they touch, and compiles against oracle/ref_shim_solver/ (an Eigen-subset stand-in: eager evaluation,
 // index-order reductions, its own small Jacobi SVD).  Test infrastructure: tests/ compare oracle/quatro_oracle.cpp's
 // restatement of the back end with this build, and tests/golden/make_golden.py stores its outputs as solver_ref.npz.
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <limits>
+#include <map>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include <Eigen/Core>
 #include <Eigen/SVD>
+#include <pcl/point_cloud.h>
+#include "teaser/graph.h"   // the reference's own (teaser::Graph; MaxCliqueSolver is only DECLARED there, see below)
 #include "teaser/macros.h"
 #include "teaser/utils.h"
 
+using namespace std;  // the reference header does the same (include/quatro.hpp:44)
+#include QREF_FREE_INC   // pcl2eigen, cut out of include/conversion.hpp
+
+// teaser::MaxCliqueSolver::findMaxClique lives in src/graph.cc and calls PMC, which is absent.  The stand-in hands the
+// graph the REFERENCE code built to a callback (the tests plug the oracle's clique search in) — so everything around
+// the clique search in computeTransformation is the reference's text, and the graph it searches is the reference's.
+typedef int (*qref_clique_fn)(const uint64_t* bitmap, int L, int W, int mode, double kcore_thr, int* out);
+static qref_clique_fn g_clique = nullptr;
+extern "C" void qref_set_clique_callback(qref_clique_fn f) { g_clique = f; }
+std::vector<int> teaser::MaxCliqueSolver::findMaxClique(teaser::Graph graph) {
+  const int L = graph.numVertices(), W = (L + 63) / 64;
+  std::vector<uint64_t> bm((size_t)L * (W > 0 ? W : 1), 0);
+  for (int i = 0; i < L; ++i)
+    for (int j : graph.getEdges(i)) bm[(size_t)i * W + (j >> 6)] |= 1ULL << (j & 63);
+  std::vector<int> out((size_t)(L > 0 ? L : 1));
+  const int n = g_clique ? g_clique(bm.data(), L, W, (int)params_.solver_mode, params_.kcore_heuristic_threshold, out.data()) : 0;
+  out.resize((size_t)n);
+  return out;
+}
+
 namespace {
 struct RefQuatro {
-  struct Params {  // the fields the functions read (include/quatro.hpp:202-268, same names)
-    double noise_bound = 0.3;
-    double cbar2 = 1;
-    double rotation_gnc_factor = 1.4;
-    size_t rotation_max_iterations = 100;
-    double rotation_cost_threshold = 1e-6;
-  };
-  Params params_;
-  double noise_bound_ = 0.3;  // :269
-  double cost_ = 0;           // :749
-  struct {
-    bool valid = true;
-    double scale = 1;
-    Eigen::Vector3d translation;
-    Eigen::Matrix3d rotation;
-  } solution_;
-  Eigen::Matrix<bool, 1, Eigen::Dynamic> scale_inliers_mask_, rotation_inliers_mask_, translation_inliers_mask_;
+  typedef pcl::PointXYZ PointType;
 #include QREF_MEMBERS_INC
+  // the members those definitions touch (declared at include/quatro.hpp:158-159, 269, 749, 1003-1036)
+  std::string reg_name_ = "Quatro";
+  bool using_pre_estimated_RyRx_ = false;
+  Eigen::Matrix3d estimated_RyRx_ = Eigen::Matrix3d::Identity();
+  RegistrationSolution solution_;
+  double noise_bound_ = 0.3;
+  double cost_ = 0;
+  pcl::PointCloud<pcl::PointXYZ>::ConstPtr input_, target_;
+  Eigen::Matrix<double, 3, Eigen::Dynamic> src_matched, tgt_matched;
+  Params params_;
+  int num_rot_inliers_ = 0, num_maxclique_ = 0;
+  teaser::Graph inlier_graph_;
+  Eigen::Matrix<bool, 1, Eigen::Dynamic> rotation_inliers_mask_, translation_inliers_mask_, scale_inliers_mask_;
+  Eigen::Matrix<double, 3, Eigen::Dynamic> src_tims_, dst_tims_, pruned_src_tims_, pruned_dst_tims_;
+  Eigen::Matrix<int, 2, Eigen::Dynamic> src_tims_map_, dst_tims_map_, src_tims_map_rotation_, dst_tims_map_rotation_;
+  std::vector<int> max_clique_, rotation_inliers_, translation_inliers_, final_inliers_;
 };
 
 struct Quiet {  // the functions narrate on std::cout
@@ -137,4 +164,45 @@ extern "C" void qref_svd_rot3d(const double* X, const double* Y, const double* W
   for (int j = 0; j < N; ++j) w(j) = W[j];
   const Eigen::Matrix3d R = teaser::utils::svdRot(A, B, w, 0);
   for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R9[3 * a + b] = R(a, b);
+}
+
+// The whole back end, Quatro::computeTransformation (:769-936): src / tgt are L x 3 row-major matched keypoints.
+// inlier_selection_mode 1 = PMC_HEU, 2 = KCORE_HEU (what the clique callback is asked for).  Outputs: T (4 x 4 row-major),
+// the sorted clique, rotation inliers (indices into the clique chain), final inliers (indices into the inputs).
+// Returns solution_.valid.  NOTE: the noise bound solveForRotation2D uses is the first call's (see above).
+extern "C" int qref_compute_transformation(const float* src, const float* tgt, int L, double noise_bound, double cbar2,
+                                           double gnc_factor, int max_iterations, double cost_threshold,
+                                           int inlier_selection_mode, double kcore_thr, double cote_noise_bound,
+                                           int cote_median, int use_rot_inliers, double* T16, int* clique, int* n_clique,
+                                           int* rot_inl, int* n_rot, int* final_inl, int* n_final) {
+  Quiet q;
+  RefQuatro r;
+  auto a = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>(), b = std::make_shared<pcl::PointCloud<pcl::PointXYZ>>();
+  for (int i = 0; i < L; ++i) {
+    a->points.push_back({src[3 * i], src[3 * i + 1], src[3 * i + 2]});
+    b->points.push_back({tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2]});
+  }
+  r.input_ = a;
+  r.target_ = b;
+  r.params_.noise_bound = noise_bound;
+  r.params_.cbar2 = cbar2;
+  r.params_.rotation_gnc_factor = gnc_factor;
+  r.params_.rotation_max_iterations = (size_t)max_iterations;
+  r.params_.rotation_cost_threshold = cost_threshold;
+  r.params_.inlier_selection_mode = (RefQuatro::INLIER_SELECTION_MODE)inlier_selection_mode;
+  r.params_.kcore_heuristic_threshold = kcore_thr;
+  r.params_.cote_mode = cote_median ? "median" : "weighted_mean";
+  r.params_.using_rot_inliers_when_estimating_cote = use_rot_inliers != 0;
+  r.noise_bound_ = cote_noise_bound;
+  Eigen::Matrix4d out = Eigen::Matrix4d::Identity();
+  r.solution_.valid = true;
+  r.computeTransformation(out);
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T16[4 * i + j] = out(i, j);
+  *n_clique = (int)r.max_clique_.size();
+  for (size_t i = 0; i < r.max_clique_.size(); ++i) clique[i] = r.max_clique_[i];
+  *n_rot = (int)r.rotation_inliers_.size();
+  for (size_t i = 0; i < r.rotation_inliers_.size(); ++i) rot_inl[i] = r.rotation_inliers_[i];
+  *n_final = r.solution_.valid ? (int)r.final_inliers_.size() : 0;
+  for (int i = 0; i < *n_final; ++i) final_inl[i] = r.final_inliers_[(size_t)i];
+  return r.solution_.valid ? 1 : 0;
 }

@@ -99,6 +99,21 @@ def main():
         b[::4] += 3.0
         t, m = qo.ref_translation(a, b, 0.3, 1.0, True)
         out.update(trans_src=a, trans_dst=b, trans_t=t, trans_inl=m)
+        # the whole back end: Quatro::computeTransformation of the reference (PMC's clique search answered by the
+        # oracle's on the graph the reference code built), several parameter sets
+        for k, (L, frac, noise, seed, kw) in enumerate((
+                (3, 1.0, 0.0, 1, {}), (60, 0.3, 0.05, 2, {}), (200, 0.2, 0.1, 3, {"cote_median": 0}),
+                (300, 0.2, 0.3, 42, {"using_rot_inliers_when_estimating_cote": 1}),
+                (150, 0.05, 0.05, 5, {"inlier_selection_mode": 2}), (4, 0.0, 0.0, 9, {}))):
+            src, tgt, _, _ = synth.correspondences(L, frac, seed=seed, noise=noise)
+            r = qo.ref_compute_transformation(src, tgt, cote_median=bool(kw.get("cote_median", 1)),
+                                              use_rot_inliers=bool(kw.get("using_rot_inliers_when_estimating_cote", 0)),
+                                              inlier_selection_mode=kw.get("inlier_selection_mode", 1))
+            out.update({f"ct{k}_src": src, f"ct{k}_tgt": tgt, f"ct{k}_valid": r["valid"], f"ct{k}_T": r["T"],
+                        f"ct{k}_clique": r["clique"], f"ct{k}_rot": r["rot_inliers"], f"ct{k}_final": r["final_inliers"],
+                        f"ct{k}_cote_median": int(kw.get("cote_median", 1)),
+                        f"ct{k}_use_rot": int(kw.get("using_rot_inliers_when_estimating_cote", 0)),
+                        f"ct{k}_mode": int(kw.get("inlier_selection_mode", 1))})
         np.savez_compressed(os.path.join(HERE, "solver_ref.npz"), **out)
     print("golden fixtures written to", HERE)
 

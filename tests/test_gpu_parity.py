@@ -287,6 +287,24 @@ def test_back_end_stages_equal_reference_generated_golden(hip):
                 assert np.array_equal(m, g[f"cote{k}_{tag}{median}_inl"]), (k, tag, median)
 
 
+def test_solve_equals_reference_compute_transformation_golden(hip):
+    """qtr_solve against the reference's OWN Quatro::computeTransformation (tests/golden/solver_ref.npz, ct* entries:
+    include/quatro.hpp:769-936 compiled from its text; only PMC's clique search was answered by the oracle's): the same
+    clique, rotation inliers, final inliers; the 4 x 4 to rounding; the same invalid case."""
+    g = np.load(os.path.join(G, "solver_ref.npz"))
+    for k in range(6):
+        kw = dict(cote_median=int(g[f"ct{k}_cote_median"]),
+                  using_rot_inliers_when_estimating_cote=int(g[f"ct{k}_use_rot"]), inlier_selection_mode=int(g[f"ct{k}_mode"]))
+        o = hip.solve(g[f"ct{k}_src"], g[f"ct{k}_tgt"], ql.demo_params(**kw))
+        assert o["valid"] == bool(g[f"ct{k}_valid"]), k
+        if not o["valid"]:
+            assert g[f"ct{k}_clique"].size <= 1  # "Clique size too small. Abort." (include/quatro.hpp:809-813)
+            continue
+        assert np.array_equal(np.sort(o["clique"]), g[f"ct{k}_clique"]), k
+        assert np.array_equal(o["rot_inliers"], g[f"ct{k}_rot"]) and np.array_equal(o["final_inliers"], g[f"ct{k}_final"]), k
+        assert np.abs(o["T"] - g[f"ct{k}_T"]).max() < 1e-12, k
+
+
 def test_host_mirror_reads_like_the_reference_demo(hip, qo, small_pair):
     """examples/run_global_registration.cpp:103-108, 206-221, 243-246 through quatro_amd.api."""
     from quatro_amd import api

@@ -115,6 +115,29 @@ def test_oracle_back_end_equals_reference_generated_golden(qo):
     assert np.array_equal(np.array(t), g["trans_t"]) and np.array_equal(inl, g["trans_inl"])
 
 
+def _ct_params(g, k):
+    return dict(cote_median=int(g[f"ct{k}_cote_median"]), using_rot_inliers_when_estimating_cote=int(g[f"ct{k}_use_rot"]),
+                inlier_selection_mode=int(g[f"ct{k}_mode"]))
+
+
+def test_oracle_solve_equals_reference_compute_transformation_golden(qo):
+    """Quatro::computeTransformation of the reference, compiled from its text with only PMC's clique search answered by the
+    oracle's (on the graph the reference code built): chain TIMs, yaw, the rotation-inlier rule, COTE, final inliers and
+    the 4 x 4 (tests/golden/solver_ref.npz, ct* entries).  The oracle's solve() has to return the same clique, the same
+    rotation / final inlier lists and the same transform to rounding — including the invalid case (clique of one)."""
+    g = np.load(os.path.join(G, "solver_ref.npz"))
+    for k in range(6):
+        o = qo.solve(g[f"ct{k}_src"], g[f"ct{k}_tgt"], qo.default_params(**_ct_params(g, k)))
+        assert o["valid"] == bool(g[f"ct{k}_valid"]), k
+        if not o["valid"]:
+            assert g[f"ct{k}_clique"].size <= 1  # "Clique size too small. Abort." (include/quatro.hpp:809-813)
+            continue
+        assert np.array_equal(np.sort(o["clique"]), g[f"ct{k}_clique"]), k
+        assert np.array_equal(o["rot_inliers"], g[f"ct{k}_rot"]) and np.array_equal(o["final_inliers"], g[f"ct{k}_final"]), k
+        assert np.abs(o["T"] - g[f"ct{k}_T"]).max() < 1e-12, k
+    assert not bool(g["ct5_valid"]) and bool(g["ct1_valid"])
+
+
 def test_oracle_back_end_equals_compiled_reference_live(qo):
     """The same comparisons against the compiled reference functions themselves, on fresh random inputs."""
     if not (qo.build_ref_solver() and qo.ref_solver_available()):
@@ -152,6 +175,23 @@ def test_oracle_back_end_equals_compiled_reference_live(qo):
             if median and nc < 2:
                 continue  # the reference reads past its candidate list for a consensus set of one (declared divergence D4)
             assert eo == er and np.array_equal(mo, mr), (trial, N, median)
+    for trial in range(10):  # the whole back end
+        L = int(g.integers(2, 260))
+        src, tgt, _, _ = synth.correspondences(L, float(g.choice([0.0, 0.1, 0.4, 1.0])), seed=300 + trial,
+                                               noise=float(g.choice([0.0, 0.05, 0.2])))
+        kw = [{}, {"cote_median": 0}, {"using_rot_inliers_when_estimating_cote": 1}, {"inlier_selection_mode": 2}][trial % 4]
+        o = qo.solve(src, tgt, qo.default_params(**kw))
+        r = qo.ref_compute_transformation(src, tgt, cote_median=bool(kw.get("cote_median", 1)),
+                                          use_rot_inliers=bool(kw.get("using_rot_inliers_when_estimating_cote", 0)),
+                                          inlier_selection_mode=kw.get("inlier_selection_mode", 1))
+        assert o["valid"] == r["valid"], (trial, L)
+        if o["valid"] and kw.get("cote_median", 1) and min(o["n_card"]) < 2:
+            continue  # a consensus set of one: the reference reads candidates[-1] (declared divergence D4)
+        if o["valid"]:
+            assert np.array_equal(np.sort(o["clique"]), r["clique"]), (trial, L)
+            assert np.array_equal(o["rot_inliers"], r["rot_inliers"]), (trial, L)
+            assert np.array_equal(o["final_inliers"], r["final_inliers"]), (trial, L)
+            assert np.abs(o["T"] - r["T"]).max() < 1e-11, (trial, L)
     for d in (2, 3):  # teaser::utils::svdRot2d / svdRot against numpy's SVD construction
         X = g.normal(0, 1, (60, d))
         Q, _ = np.linalg.qr(g.normal(0, 1, (d, d)))
