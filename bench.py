@@ -98,6 +98,7 @@ def main() -> None:
                     help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`)")
     ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
     ap.add_argument("--sharded-pairs", type=int, default=4096, help="pair ids of the N>1 sharded leg (configs[3])")
+    ap.add_argument("--batch-slots", type=int, default=32, help="stream slots of the batched legs (two lanes of half as many pairs)")
     args = ap.parse_args()
     legs = set(x for x in args.legs.split(",") if x)
 
@@ -303,7 +304,7 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev):
     B = args.batch_pairs if world == 1 else args.sharded_pairs
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = qdist.shard_range(B, rank, world)
-    hb = ql.Handle(torch.cuda.current_device(), max_points=131072, max_voxels=32768, max_corr=8192, n_slots=32)
+    hb = ql.Handle(torch.cuda.current_device(), max_points=131072, max_voxels=32768, max_corr=8192, n_slots=args.batch_slots)
     ids = list(range(lo, hi))
     pairs = [pool[i % len(pool)] for i in ids]
     hb.register_batch_dev(pairs[:64], prm)  # warm-up

@@ -320,7 +320,11 @@ static int create_impl(qtr_handle* h) {
   }
   // batch lanes: two groups of slots that alternate (one's kernels cover the other's host read-back)
   const int S = (int)h->slots.size();
-  const int NL = S >= 2 ? 2 : 1;
+  int NL = S >= 2 ? 2 : 1;
+  if (const char* e = getenv("QTR_BATCH_LANES")) {  // experiment knob: more, smaller groups in flight
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8 && v <= S) NL = v;
+  }
   h->lanes.resize((size_t)NL);
   for (int l = 0; l < NL; ++l) {
     Lane& ln = h->lanes[l];
