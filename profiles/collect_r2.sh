@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_batch -o batch -- 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_fetch -o fetch -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_write -o write -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
 cd $R
-python profiles/summarize_rocpd.py $(ls gpurun_out/prof_${TAG}_seq/*.db | head -1) 53 > gpurun_out/${TAG}_kernel_stats.txt
+python profiles/summarize_rocpd.py $(ls gpurun_out/prof_${TAG}_seq/*.db | head -1) 57 > gpurun_out/${TAG}_kernel_stats.txt
 python profiles/summarize_rocpd.py $(ls gpurun_out/prof_${TAG}_batch/*.db | head -1) > gpurun_out/${TAG}_batch_kernel_stats.txt
 python profiles/summarize_pmc.py $(ls gpurun_out/prof_${TAG}_fetch/*.db | head -1) $(ls gpurun_out/prof_${TAG}_write/*.db | head -1) "${NN_KERNEL:-void k_nn_f16}" > gpurun_out/${TAG}_pmc_nn.json
 rm -rf gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write
