@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_kcore_levels(ViewExt<SolverView> x, Sol
 // number, and thread 0 initialises the clique search — one launch instead of five (collect, memset, rank
 // partial, rank finish, clique init).
 template <bool EXT>
-__global__ __launch_bounds__(1024) void k_kcore_collect_rank(ViewExt<SolverView> x, SolverView one) {
+__global__ __launch_bounds__(1024) void k_kcore_collect_rank(ViewExt<SolverView> x, SolverView one, int first_batch) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const u64* __restrict__ M = V.adjP;
   const int L = V.L, W = V.W;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_kcore_collect_rank(ViewExt<SolverView>
     st->best_r = -1;
     st->pos = L - 1;
     st->done = (L <= 0) ? 1 : 0;
-    st->batch = 1;
+    st->batch = first_batch;
     st->t0 = 0;
     st->rounds = 0;
   }
@@ -1789,6 +1789,9 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
     const size_t kc_lds = (size_t)(q_in_lds ? 2 : 1) * L * sizeof(int);
     const size_t bm_bytes = (size_t)L * W * 8;
     const bool kc_single_wave = (L <= 256 * KCL_VPT);
+    // (see the clique rounds below) level-parallel core numbers and rows in LDS: the first round takes CLIQUE_BATCH starts
+    const bool merged_first_round = kc_single_wave && ((size_t)L * W * 8 + (size_t)4 * L * sizeof(int) <= (size_t)150 * 1024) &&
+                                    getenv("QTR_CLIQUE_ROUND0") == nullptr;
     if (kc_single_wave) {
       const dim3 kgrid(L > 1 ? L - 1 : 1, 1, G);
       if (W <= 4) LAUNCH_SV_T(k_kcore_levels, 1, a, kgrid, dim3(256), 0, stream);
@@ -1796,7 +1799,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       else if (W <= 12) LAUNCH_SV_T(k_kcore_levels, 3, a, kgrid, dim3(256), 0, stream);
       else if (W <= 16) LAUNCH_SV_T(k_kcore_levels, 4, a, kgrid, dim3(256), 0, stream);
       else LAUNCH_SV_T(k_kcore_levels, 5, a, kgrid, dim3(256), 0, stream);
-      LAUNCH_SV(k_kcore_collect_rank, a, dim3(1, 1, G), dim3(1024), 0, stream);
+      LAUNCH_SV(k_kcore_collect_rank, a, dim3(1, 1, G), dim3(1024), 0, stream, merged_first_round ? CLIQUE_BATCH : 1);
     } else {
       const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
       static const bool peel_only = [] {
@@ -1827,6 +1830,18 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       // round 0: the single top-ranked start; round 1..: BATCH starts each
       const size_t cl_lds = (size_t)L * W * 8 + (size_t)4 * L * sizeof(int);  // matrix + four per-wave pick lists
       const bool lds_rows = cl_lds <= (size_t)150 * 1024;
+      if (merged_first_round) {
+        // Small graphs (rows in LDS): the single start of round 0 is speculated together with the next BATCH - 1 — the
+        // replay in k_clique_scan gives the sequential result whatever bound the descents were started with (a descent
+        // that strays below the current bound cannot return more than that bound: every member of a clique of size s
+        // has K >= s), and a round of parallel descents costs what the one descent does.  Two launches instead of four.
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
+        LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+        if (L > BATCH) {  // (a second round only exists for more than BATCH vertices)
+          LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
+          LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+        }
+      } else {
       if (lds_rows)
         LAUNCH_SV(k_clique_batch_lds, a, dim3(1, 1, G), dim3(256), cl_lds, stream);
       else
@@ -1843,6 +1858,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         LAUNCH_SV(k_clique_batch, a, dim3(BATCH / 4, 1, G), dim3(256), 0, stream);
       CS_DBG("clique batch 1");
       LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+      }
       CS_DBG("clique scan 1");
     }
   }

@@ -449,6 +449,29 @@ def test_f16_filter_holds_on_adversarial_descriptors(qo, case):
     assert (got[3][12] != 0) == (case in ("big_values", "big_norm"))
 
 
+def test_instrumentation_entry_points(small_pair):
+    """qtr_set_stage_events / qtr_get_nn_totals: with the stage events off a registration gives the same record and the
+    nearest-neighbour launches keep being timed; the totals add up over calls and reset on request."""
+    s, t, _ = small_pair
+    h = ql.Handle(0)
+    fp = ql.default_frontend_params(seed=3)
+    a = h.register_pair(s, t, fp)
+    assert h.stage_times()["match"] > 0
+    h.nn_totals(reset=True)
+    h.set_stage_events(False)
+    for _ in range(3):
+        b = h.register_pair(s, t, fp)
+    ms, n = h.nn_totals()
+    assert n == 6 and 0.0 < ms < 50.0
+    assert h.nn_totals(reset=True)[1] == 6 and h.nn_totals()[1] == 0
+    h.set_stage_events(True)
+    c = h.register_pair(s, t, fp)
+    assert h.stage_times()["match"] > 0 and h.nn_totals()[1] == 2
+    for r in (b, c):
+        assert np.array_equal(a["T"], r["T"]) and np.array_equal(a["final_inliers"], r["final_inliers"])
+    h.close()
+
+
 def test_stream_slots_run_concurrently_and_agree(qo):
     """Three pairs in flight on three stream slots (one host thread each) give the answers of sequential runs."""
     import threading
