@@ -133,7 +133,6 @@ struct MatchView {
   float* recheck_thr;
   int2* recheck_span;          // per listed row: [first, last) column of the base cloud's norm-bin order that can hold its arg-min
   int* recheck_q;              // per listed row: its column of the direction's query table (k_recheck_filter)
-  int* rc_counts;              // [2 dirs][4]: [1] = the filter gave up, k_nn_exact_rows redoes the direction
   int* hit_rows;               // ascending rows of the larger cloud that direction 0 points at
   float* queryT_c;             // [34][pad_large] their columns of queryT_i
   float* norms_c;
@@ -174,7 +173,6 @@ struct FrontBufs {
   float* recheck_thr = nullptr; // [max_voxels] per listed row: approximate best + 2 eps (candidates above it cannot win)
   int2* recheck_span = nullptr; // [max_voxels]
   int* recheck_q = nullptr;    // [max_voxels]
-  int* rc_counts = nullptr;    // 8
   int* hit_rows = nullptr;     // [max_voxels]
   float* queryT_c = nullptr;   // [34][max_voxels_pad]
   float* norms_c = nullptr;    // [max_voxels_pad]

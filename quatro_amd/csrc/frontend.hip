@@ -1387,7 +1387,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * 8 + (size_t)dedup_slots(max_voxels) * 8 + 512;  // dd_hash, dd_table
   shared += vpad * 32 * 16 + 4 * ((size_t)max_voxels * 4 + 1024);     // nn_partial, recheck_rows, recheck_thr, recheck_span
   shared += (size_t)max_voxels * 4 + 34 * vpad * 4 + vpad * 4 + 1024;  // hit_rows, queryT_c, norms_c
-  shared += vpad * 224 + 2 * 7168 + 256 + (size_t)max_voxels * 4 + 1024;  // queryH_c, recheck_q, rc_counts
+  shared += vpad * 224 + 2 * 7168 + 256 + (size_t)max_voxels * 4 + 1024;  // queryH_c, recheck_q
   return 2 * per_cloud + shared + 64 * 256;
 }
 
@@ -1458,7 +1458,6 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.norms_c = (float*)take((((size_t)max_voxels + 511) / 512 * 512) * 4);
   F.queryH_c = (uint4*)take((((size_t)max_voxels + 511) / 512 * 512) * 224 + 2 * 7168);
   F.recheck_q = (int*)take((size_t)max_voxels * 4);
-  F.rc_counts = (int*)take(8 * 4);
   {
     const char* e = getenv("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "mfma32") == 0) ? 1 : 2;

@@ -714,23 +714,20 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
 // Re-check of the listed rows (f16 engine): the matrix pipe again.  A listed row's exact arg-min is among the base rows
 // whose filter value is at most the row's threshold (k_nn_finish: the leader's value plus twice the rounding bound) —
 // two or three near-ties, typically — so the listed rows go through the same 7-MFMA chain once more, this time
-// comparing every entry with the row's threshold; the (row, base row) pairs that pass are buffered in LDS and get the
-// exact flann::L2 evaluation by the same workgroup.  A workgroup takes 128 listed rows (32 per wave) and a slice of the
-// base tiles (fragments of the next tile prefetched).  If the buffer overflows, or a row has no finite threshold, or the
-// descriptors are outside the filter's range (MC_UNSAFE: the chain may produce NaN), the direction's flag makes
-// k_nn_exact_rows — the span scan, which needs no list — redo it.  grid (query groups, slices, pairs).
-#define RC_CAP 2048
+// comparing every entry with the row's threshold; the (row, base row) pairs that are not ABOVE it (a NaN entry — possible
+// when the descriptors are outside the filter's range — passes) are buffered in LDS and get the exact flann::L2
+// evaluation by the same workgroup.  A workgroup takes 128 listed rows (32 per wave) and a slice of the base tiles
+// (fragments of the next tile prefetched); the buffer is emptied whenever a further tile might not fit, so that the
+// kernel is complete whatever passes: with an infinite threshold (no leader, MC_UNSAFE) it degenerates into an exact
+// scan of every pair.  grid (query groups, slices, pairs).
+#define RC_CAP 8000   // (64000 bytes of LDS)
+#define RC_TILE_MAX 4096  // entries one tile can add: 4 waves x 64 lanes x 16 accumulator registers
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
-  int* __restrict__ fallback = V.rc_counts + 4 * dir + 1;
-  if (V.mcounts[MC_UNSAFE]) {
-    if (threadIdx.x == 0) *fallback = 1;
-    return;
-  }
   __shared__ int s_n;
   __shared__ int2 s_cand[RC_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -743,59 +740,13 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
   const int* __restrict__ qcol = V.recheck_q;  // listed row -> its column of the query table (k_nn_finish)
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
-  const int qgroups = (nrows + 127) / 128;
-  for (int qg = blockIdx.x; qg < qgroups; qg += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int qtile = qg * 4 + wave;
-    const int slot = qtile * 32 + col;
-    h8 q[7], m0[7], m1[7];
-    {
-      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; their threshold rejects everything)
-#pragma unroll
-      for (int m = 0; m < 7; ++m) q[m] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + half) * 32 + (qc & 31)];
-    }
-    float thr = -INFINITY;
-    if (slot < nrows) {
-      thr = V.recheck_thr[slot] * (NNH_S * NNH_S);
-      if (!(thr < INFINITY)) *fallback = 1;
-    }
-    auto load = [&](h8* m, int t) {
-#pragma unroll
-      for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];  // (padded: t1 may be read)
-    };
-    auto tile = [&](const h8* m, int t) {
-      f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (acc[r] <= thr) {
-          const int pos = atomicAdd(&s_n, 1);
-          if (pos < RC_CAP) s_cand[pos] = make_int2(slot, t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
-        }
-      }
-    };
-    if (t0 < t1) load(m0, t0);
-    for (int t = t0; t < t1; t += 2) {
-      load(m1, t + 1);
-      tile(m0, t);
-      if (t + 1 < t1) {
-        load(m0, t + 2);
-        tile(m1, t + 1);
-      }
-    }
-    __syncthreads();
+  const int nb = D.nb;
+  // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
+  auto flush = [&]() {
     const int n = s_n;
-    if (n > RC_CAP) {
-      if (threadIdx.x == 0) *fallback = 1;
-      continue;
-    }
-    // exact distance of every collected pair, folded into the row's packed (distance, base row) minimum
     for (int e = threadIdx.x; e < n; e += 256) {
       const int2 c = s_cand[e];
-      if (c.y >= D.nb) continue;  // a pad row of the last tile (cannot pass a finite threshold; belt and braces)
+      if (c.y >= nb) continue;  // a pad row of the last tile
       const int row = V.recheck_rows[c.x];
       const float* a = A + (size_t)row * 33;
       const float* b = B + (size_t)c.y * 33;
@@ -808,8 +759,54 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
       }
       const float dt = a[32] - b[32];
       result += dt * dt;
-      atomicMin(&D.best[row], ((u64)__float_as_uint(result) << 32) | (u32)c.y);
+      if (result == result) atomicMin(&D.best[row], ((u64)__float_as_uint(result) << 32) | (u32)c.y);  // (NaN never wins)
     }
+  };
+  const int qgroups = (nrows + 127) / 128;
+  for (int qg = blockIdx.x; qg < qgroups; qg += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int qtile = qg * 4 + wave;
+    const int slot = qtile * 32 + col;
+    h8 q[7], m0[7], m1[7];
+    {
+      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is buffered)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) q[m] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + half) * 32 + (qc & 31)];
+    }
+    const bool live = slot < nrows;
+    const float thr = live ? V.recheck_thr[slot] * (NNH_S * NNH_S) : 0.f;
+    auto load = [&](h8* m, int t) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];  // (padded: t1 may be read)
+    };
+    auto tile = [&](const h8* m, int t) {
+      f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (live && !(acc[r] > thr)) s_cand[atomicAdd(&s_n, 1)] = make_int2(slot, t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
+      }
+      __syncthreads();  // (uniform: every wave walks the same tiles)
+      if (s_n > RC_CAP - RC_TILE_MAX) {
+        flush();
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+      }
+    };
+    if (t0 < t1) load(m0, t0);
+    for (int t = t0; t < t1; t += 2) {
+      load(m1, t + 1);
+      tile(m0, t);
+      if (t + 1 < t1) {
+        load(m0, t + 2);
+        tile(m1, t + 1);
+      }
+    }
+    flush();
   }
 }
 
@@ -826,13 +823,11 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
 // grid (groups, slices, pairs).
 #define XR 8
 template <bool EXT>
-__global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, MatchView one, int dir,
-                                                         int after_filter /* 1: only if k_recheck_filter overflowed */) {
+__global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, MatchView one, int dir) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
-  if (after_filter && V.rc_counts[4 * dir + 1] == 0) return;
   __shared__ __attribute__((aligned(16))) float s_m2a[33][XR];  // [k][row]: -2 * a
   __shared__ __attribute__((aligned(16))) float s_a[XR][36];    // [row][k]
   __shared__ float s_thr[XR];
@@ -939,7 +934,6 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
-  if (gid < 8) V.rc_counts[gid] = 0;
   const int pv = V.tuple ? 0 : 1;
   const int np = V.crosscheck ? V.n_small : V.n_small + V.n_large;
   for (int i = gid; i < np; i += gsz) V.passed[i] = pv;
@@ -1468,7 +1462,6 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   V.recheck_thr = F.recheck_thr;
   V.recheck_span = F.recheck_span;
   V.recheck_q = F.recheck_q;
-  V.rc_counts = F.rc_counts;
   V.hit_rows = F.hit_rows;
   V.queryT_c = F.queryT_c;
   V.norms_c = F.norms_c;
@@ -1606,8 +1599,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       const int ey = G > 1 ? 4 : 16;
       int ex = 128;
       if (G > 1) ex = max(8, 384 / G);  // a group of pairs shares the device
-      if (f16) LAUNCH_MV(k_nn_exact_rows, a, dim3(32, 8, G), B256, 0, st, dir, 1);  // (returns at once unless the filter gave up)
-      else LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir, 0);
+      if (!f16) LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);  // (the f16 engine's filter is complete)
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
