@@ -1115,11 +1115,36 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     dbg[slot] = (int)((tc1 - tc0) >> 4);                 \
     tc0 = tc1;                                           \
   }
-  // ---- 1./2. bitonic sort of (key, position), ascending; keys/positions live in the (still unused) T area
+  // ---- 1./2. sort of (key, position), ascending; keys/positions live in the (still unused) T area.
+  // Up to 256 endpoints (cliques of up to 128 members) every thread RANKS its endpoint by counting the smaller ones —
+  // one pass over the keys in LDS (broadcast reads), one barrier — instead of the 28 - 36 barrier-separated stages of a
+  // bitonic network (measured, clocks / 16: 1591 -> 886 at 136 endpoints, 823 -> 358 at 42); the order is the same (ties
+  // by position).  Larger sets keep the network: counting is O(n^2) and the three axes share one compute unit (370
+  // endpoints: 2494 for the network, 3988 counting).
   int n2 = 1;
   while (n2 < nc) n2 <<= 1;
   double* ekey = T;
   int* epos = (int*)(T + n2);
+  if (nc <= 256) {
+    if (act)
+      for (int i = tl; i < nc; i += 256) {
+        const double ri = R ? R[i >> 1] : range;
+        ekey[i] = (i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri;
+      }
+    __syncthreads();
+    if (act)
+      for (int i = tl; i < nc; i += 256) {
+        const double ki = ekey[i];
+        int rank = 0;
+        for (int j = 0; j < nc; ++j) {
+          const double kj = ekey[j];
+          rank += (kj < ki) | ((kj == ki) & (j < i));
+        }
+        spos[rank] = i;
+        sxv[rank] = X[i >> 1];
+      }
+    __syncthreads();
+  } else {
   if (act)
     for (int i = tl; i < n2; i += 256) {
       const double ri = (R && i < nc) ? R[i >> 1] : range;
@@ -1153,6 +1178,7 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
       spos[i] = p;
       sxv[i] = X[p >> 1];
     }
+  }
   COTE_TICK(0)
   if (act && tl == 64) {  // sum of N ranges in the reference's order (:660), off the serial wave
     double r = 0;
