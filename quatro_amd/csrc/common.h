@@ -46,6 +46,29 @@ __device__ __forceinline__ double wave_sum64_f64(double v) {
   }
   return __shfl(v, 0, 64);
 }
+// The same fold — the same additions in the same tree — for partials that sit in BIT-REVERSED lane order: physical lane
+// p holds the partial of logical lane brev6(p) (callers walk their elements with sum64_slot(lane) instead of lane).
+// The fold's first four steps (logical offsets 32, 16, 8, 4 = physical offsets 1, 2, 4, 8) then stay inside a row of 16
+// lanes and run on DPP row shifts instead of six LDS-crossbar permutes of a double; the last two (physical 16, 32) only
+// concern four lanes, read as scalars.  The result is uniform.  (GNC-TLS: five such sums per iteration, ~17 iterations.)
+__device__ __forceinline__ int sum64_slot(int lane) { return (int)(__brev((unsigned)lane) >> 26); }
+template <int N>
+__device__ __forceinline__ double dpp_row_shl_f64(double v) {  // lane i reads lane i + N of its row (garbage past the row)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 | N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 | N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum64_f64_brev(double v) {
+  v = v + dpp_row_shl_f64<1>(v);  // logical p[l] += p[l + 32]
+  v = v + dpp_row_shl_f64<2>(v);  // += p[l + 16]
+  v = v + dpp_row_shl_f64<4>(v);  // += p[l + 8]
+  v = v + dpp_row_shl_f64<8>(v);  // += p[l + 4]
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  return (a + b) + (c + d);       // p[0] += p[2], p[1] += p[3]; p[0] += p[1]
+}
 __device__ __forceinline__ float wave_sum64_f32(float v) {  // qm_sum64_fold_f across one wavefront
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

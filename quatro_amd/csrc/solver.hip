@@ -950,10 +950,10 @@ __device__ __forceinline__ void gnc_wave(int lane, const double* X0, const doubl
       h2 = h2 + wx1 * Y0[j];
       h3 = h3 + wx1 * Y1[j];
     }
-    h0 = wave_sum64_f64(h0);
-    h1 = wave_sum64_f64(h1);
-    h2 = wave_sum64_f64(h2);
-    h3 = wave_sum64_f64(h3);
+    h0 = wave_sum64_f64_brev(h0);
+    h1 = wave_sum64_f64_brev(h1);
+    h2 = wave_sum64_f64_brev(h2);
+    h3 = wave_sum64_f64_brev(h3);
     {
       const double a = h0 + h3, b = h1 - h2;
       const double nrm = sqrt(a * a + b * b);
@@ -993,7 +993,7 @@ __device__ __forceinline__ void gnc_wave(int lane, const double* X0, const doubl
         w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
       Wt[j] = w;
     }
-    cost = wave_sum64_f64(cpart);
+    cost = wave_sum64_f64_brev(cpart);
     const double cost_diff = fabs(cost - prev_cost);
     mu = mu * gnc_factor;
     prev_cost = cost;
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void gnc3_wave(int lane, const double* X0, const doub
       H[8] = H[8] + wx2 * y2;
     }
 #pragma unroll
-    for (int a = 0; a < 9; ++a) H[a] = wave_sum64_f64(H[a]);
+    for (int a = 0; a < 9; ++a) H[a] = wave_sum64_f64_brev(H[a]);
     qm_rot3_from_h(H, R);
     if (it == 0) {
       double max_r = -INFINITY;
@@ -1070,7 +1070,7 @@ __device__ __forceinline__ void gnc3_wave(int lane, const double* X0, const doub
         w = sqrt(nb_sq * mu * (mu + 1) / r2) - mu;
       Wt[j] = w;
     }
-    cost = wave_sum64_f64(cpart);
+    cost = wave_sum64_f64_brev(cpart);
     const double cost_diff = fabs(cost - prev_cost);
     mu = mu * gnc_factor;
     prev_cost = cost;
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   if (wave == 0 && teaser) {
     double Rg[9], costg;
     int itersg;
-    gnc3_wave(lane, X0, X1, X2, Y0, Y1, Y2, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
+    gnc3_wave(sum64_slot(lane), X0, X1, X2, Y0, Y1, Y2, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
               prm.rotation_max_iterations, prm.rotation_cost_threshold, Rg, &costg, &itersg);
     if (lane == 0) {
       for (int a = 0; a < 9; ++a) s_R[a] = Rg[a];
@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   } else if (wave == 0) {
     double Rg[4], costg;
     int itersg;
-    gnc_wave(lane, X0, X1, Y0, Y1, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
+    gnc_wave(sum64_slot(lane), X0, X1, Y0, Y1, Wt, M, prm.noise_bound * (2 / 1.0), prm.rotation_gnc_factor,
              prm.rotation_max_iterations, prm.rotation_cost_threshold, Rg, &costg, &itersg);
     if (lane == 0) {
       s_R[0] = Rg[0];

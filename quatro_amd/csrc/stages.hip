@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_gnc_only(const double* __restrict__ src,
   __syncthreads();
   double R[4], cost;
   int iters;
-  gnc_wave(lane, src, src + M, dst, dst + M, wt, M, rot_nb, gnc_factor, max_it, cost_thr, R, &cost, &iters);
+  gnc_wave(sum64_slot(lane), src, src + M, dst, dst + M, wt, M, rot_nb, gnc_factor, max_it, cost_thr, R, &cost, &iters);
   __syncthreads();
   for (int j = lane; j < M; j += 64) inl[j] = (wt[j] >= 0.4) ? 1 : 0;  // reference :566-570
   if (lane == 0) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_gnc3d_only(const double* __restrict__ sr
   __syncthreads();
   double R[9], cost;
   int iters;
-  gnc3_wave(lane, src, src + M, src + 2 * (size_t)M, dst, dst + M, dst + 2 * (size_t)M, wt, M, rot_nb, gnc_factor, max_it,
+  gnc3_wave(sum64_slot(lane), src, src + M, src + 2 * (size_t)M, dst, dst + M, dst + 2 * (size_t)M, wt, M, rot_nb, gnc_factor, max_it,
             cost_thr, R, &cost, &iters);
   __syncthreads();
   for (int j = lane; j < M; j += 64) inl[j] = (wt[j] >= 0.4) ? 1 : 0;
