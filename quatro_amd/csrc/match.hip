@@ -717,11 +717,23 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
 // comparing every entry with the row's threshold; the (row, base row) pairs that are not ABOVE it (a NaN entry — possible
 // when the descriptors are outside the filter's range — passes) are buffered in LDS and get the exact flann::L2
 // evaluation by the same workgroup.  A workgroup takes 128 listed rows (32 per wave) and a slice of the base tiles
-// (fragments of the next tile prefetched); the buffer is emptied whenever a further tile might not fit, so that the
-// kernel is complete whatever passes: with an infinite threshold (no leader, MC_UNSAFE) it degenerates into an exact
-// scan of every pair.  grid (query groups, slices, pairs).
-#define RC_CAP 8000   // (64000 bytes of LDS)
-#define RC_TILE_MAX 4096  // entries one tile can add: 4 waves x 64 lanes x 16 accumulator registers
+// (fragments of the next tile prefetched).  If more pairs pass than the buffer holds (an infinite threshold: no leader,
+// MC_UNSAFE; clouds of near-identical rows) the workgroup walks its tiles a second time and evaluates every passing
+// pair on the spot, so the kernel is complete whatever passes — in the limit an exact scan of every pair.
+// grid (query groups, slices, pairs).
+#define RC_CAP 2048
+__device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, const float* __restrict__ b, u64* best, int base_row) {
+  float result = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
+                d3 = a[4 * g + 3] - b[4 * g + 3];
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  const float dt = a[32] - b[32];
+  result += dt * dt;
+  if (result == result) atomicMin(best, ((u64)__float_as_uint(result) << 32) | (u32)base_row);  // (NaN never wins)
+}
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -741,27 +753,6 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
-  // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
-  auto flush = [&]() {
-    const int n = s_n;
-    for (int e = threadIdx.x; e < n; e += 256) {
-      const int2 c = s_cand[e];
-      if (c.y >= nb) continue;  // a pad row of the last tile
-      const int row = V.recheck_rows[c.x];
-      const float* a = A + (size_t)row * 33;
-      const float* b = B + (size_t)c.y * 33;
-      float result = 0.f;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
-                    d3 = a[4 * g + 3] - b[4 * g + 3];
-        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-      }
-      const float dt = a[32] - b[32];
-      result += dt * dt;
-      if (result == result) atomicMin(&D.best[row], ((u64)__float_as_uint(result) << 32) | (u32)c.y);  // (NaN never wins)
-    }
-  };
   const int qgroups = (nrows + 127) / 128;
   for (int qg = blockIdx.x; qg < qgroups; qg += gridDim.x) {
     __syncthreads();
@@ -777,36 +768,54 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     }
     const bool live = slot < nrows;
     const float thr = live ? V.recheck_thr[slot] * (NNH_S * NNH_S) : 0.f;
-    auto load = [&](h8* m, int t) {
+    const int my_row = live ? V.recheck_rows[slot] : 0;
+    auto load = [&](h8 (&m)[7], int t) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];  // (padded: t1 may be read)
     };
-    auto tile = [&](const h8* m, int t) {
+    auto tile = [&](const h8 (&m)[7], int t, auto direct_tag) __attribute__((always_inline)) {
+      constexpr bool direct = decltype(direct_tag)::value;  // (two specialised copies: no run-time flag in the hot loop)
       f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (live && !(acc[r] > thr)) s_cand[atomicAdd(&s_n, 1)] = make_int2(slot, t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
-      }
-      __syncthreads();  // (uniform: every wave walks the same tiles)
-      if (s_n > RC_CAP - RC_TILE_MAX) {
-        flush();
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+        if (live && !(acc[r] > thr)) {
+          const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+          if (direct) {
+            if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
+          } else {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < RC_CAP) s_cand[pos] = make_int2(slot, brow);
+          }
+        }
       }
     };
-    if (t0 < t1) load(m0, t0);
-    for (int t = t0; t < t1; t += 2) {
-      load(m1, t + 1);
-      tile(m0, t);
-      if (t + 1 < t1) {
-        load(m0, t + 2);
-        tile(m1, t + 1);
+    auto sweep = [&](auto direct) __attribute__((always_inline)) {
+      if (t0 < t1) load(m0, t0);
+      for (int t = t0; t < t1; t += 2) {
+        load(m1, t + 1);
+        tile(m0, t, direct);
+        if (t + 1 < t1) {
+          load(m0, t + 2);
+          tile(m1, t + 1, direct);
+        }
       }
+    };
+    sweep(std::false_type{});
+    __syncthreads();
+    const int n = s_n;
+    if (n <= RC_CAP) {
+      // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
+      for (int e = threadIdx.x; e < n; e += 256) {
+        const int2 c = s_cand[e];
+        if (c.y >= nb) continue;  // a pad row of the last tile
+        const int row = V.recheck_rows[c.x];
+        recheck_exact_pair(A + (size_t)row * 33, B + (size_t)c.y * 33, &D.best[row], c.y);
+      }
+    } else {
+      sweep(std::true_type{});  // (uniform: n is the workgroup's count)
     }
-    flush();
   }
 }
 
