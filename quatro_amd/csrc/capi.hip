@@ -1206,7 +1206,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   {
     const int ns1[1] = {n};
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true, false));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -1343,7 +1343,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
     QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));

@@ -10,6 +10,7 @@
 // sorted by packed cell key and a query scans 9 contiguous key ranges.
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -80,9 +81,11 @@ __device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, 
 // pass's histogram into H[(p + 1) % 3] while it scatters (each key's destination tile and next digit are known at that
 // point: one fire-and-forget global atomic per key instead of a histogram launch per pass) and clears its tile's row of
 // H[(p + 2) % 3].  Only the first pass has a histogram kernel of its own.
-template <int BITS, int TILE>
-__device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, int shift, u32* __restrict__ hist,
-                                                   int nblk) {
+// key_of(i) yields key i: a load for a plain histogram, or the key computed from its point (then also stored to `store`,
+// which fuses the key kernel of a sort into its first histogram: one launch fewer on a chain of ~8 us launches)
+template <int BITS, int TILE, typename KeyOf>
+__device__ __forceinline__ void d_radix_hist(KeyOf key_of, u64* __restrict__ store, int n, int shift, u32* __restrict__ hist,
+                                             int nblk) {
   constexpr int NB = 1 << BITS;
   static_assert(NB == 256 && TILE == 1024, "256 threads: one digit and four keys each");
   __shared__ u32 cnt[NB];
@@ -96,7 +99,11 @@ __device__ __forceinline__ void d_radix_hist(const u64* __restrict__ in, int n, 
 #pragma unroll
   for (int s = 0; s < TILE / 256; ++s) {
     const int i = base + s * 256 + tid;
-    if (i < n) atomicAdd(&cnt[(u32)(in[i] >> shift) & (u32)(NB - 1)], 1u);
+    if (i < n) {
+      const u64 key = key_of(i);
+      if (store) store[i] = key;
+      atomicAdd(&cnt[(u32)(key >> shift) & (u32)(NB - 1)], 1u);
+    }
   }
   __syncthreads();
   hist[(size_t)blk * NB + tid] = cnt[tid];  // hist[blk][digit]: one coalesced 1 KB row per tile
@@ -129,12 +136,14 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   //   sum_{d'<d} total[d'] + sum_{b<blk} hist[b][d];   wave w adds up the rows b = w, w+4, ... (4 digits per lane)
   {
     u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
-    for (int b0 = wave; b0 < nblk; b0 += 32) {  // eight rows in flight per round trip
-      uint4 h[8];
+    // eight rows in flight per round trip (32, i.e. one round for a raw cloud's ~120 tiles, was measured: no faster)
+    constexpr int RIF = 8;
+    for (int b0 = wave; b0 < nblk; b0 += 4 * RIF) {
+      uint4 h[RIF];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = ((const uint4*)(hist + (size_t)min(b0 + 4 * q, nblk - 1) * NB))[lane];
+      for (int q = 0; q < RIF; ++q) h[q] = ((const uint4*)(hist + (size_t)min(b0 + 4 * q, nblk - 1) * NB))[lane];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < RIF; ++q) {
         const int b = b0 + 4 * q;
         const u32 live = (b < nblk) ? 0xffffffffu : 0u, m = (b < blk) ? 0xffffffffu : 0u;
         tot[0] += h[q].x & live;
@@ -190,10 +199,31 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
       const u64 b = __ballot(valid && one);
       m &= one ? b : ~b;
     }
-    if (valid) {
-      const u32 pos = cntw[wave][d] + (u32)__popcll(m & lanemask_lt());
-      out[pos] = key;
-      if (hist_next) atomicAdd(&hist_next[(size_t)(pos / TILE) * NB + ((u32)(key >> (shift + BITS)) & (u32)(NB - 1))], 1u);
+    const u32 pos = valid ? cntw[wave][d] + (u32)__popcll(m & lanemask_lt()) : 0u;
+    if (valid) out[pos] = key;
+    if (hist_next) {
+      // one atomic per group of lanes that agree on this digit, the next digit and the destination tile instead of one
+      // per key: the upper digits of a grid key take few values, and hundreds of device-scope atomics on one counter
+      // were what made the middle pass of a sort twice as long as the last (which has none)
+      const u32 d2 = (u32)(key >> (shift + BITS)) & (u32)(NB - 1);
+      u64 m2 = m;
+#pragma unroll
+      for (int bit = 0; bit < BITS; ++bit) {
+        const bool one = (d2 >> bit) & 1u;
+        const u64 b = __ballot(valid && one);
+        m2 &= one ? b : ~b;
+      }
+      // positions grow with the lane inside a group, so its tiles are those of its first and last lane
+      const u32 tile = pos / TILE;
+      const int first = valid ? __ffsll((unsigned long long)m2) - 1 : 0, lastl = valid ? 63 - __clzll((long long)m2) : 0;
+      const u32 tile_first = (u32)__shfl((int)tile, first, 64), tile_last = (u32)__shfl((int)tile, lastl, 64);
+      if (valid) {
+        if (tile_first == tile_last) {
+          if (lane == first) atomicAdd(&hist_next[(size_t)tile * NB + d2], (u32)__popcll(m2));
+        } else {
+          atomicAdd(&hist_next[(size_t)tile * NB + d2], 1u);
+        }
+      }
     }
     __syncthreads();  // orders the LDS reads above before the updates below (each wave only touches its own row)
     if (valid && (m & lanemask_lt()) == 0) cntw[wave][d] += (u32)__popcll(m);
@@ -284,24 +314,18 @@ __device__ __forceinline__ VoxGrid vox_grid(const u32* mm, float leaf) {
   return g;
 }
 
-__device__ __forceinline__ void d_vox_keys(const float4* __restrict__ pts, int P, float leaf,
-                                                  const u32* __restrict__ mm, u64* __restrict__ keys,
-                                                  int* __restrict__ counts) {
-  const VoxGrid g = vox_grid(mm, leaf);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (g.overflow) counts[CNT_VOX_OVERFLOW] = 1;
-    const long long cells = (long long)g.divb[0] * g.divb[1] * g.divb[2];  // every key is below this
-    counts[CNT_SORT_BITS] = (g.overflow || cells <= 1) ? (g.overflow ? 32 : 1) : 64 - __clzll(cells - 1);
-  }
-  const int mul1 = g.divb[0], mul2 = g.divb[0] * g.divb[1];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
-    const float4 p = pts[i];
-    const int i0 = (int)(floorf(p.x * g.inv) - (float)g.minb[0]);
-    const int i1 = (int)(floorf(p.y * g.inv) - (float)g.minb[1]);
-    const int i2 = (int)(floorf(p.z * g.inv) - (float)g.minb[2]);
-    const int idx = i0 + i1 * mul1 + i2 * mul2;
-    keys[i] = ((u64)(u32)idx << 32) | (u32)i;
-  }
+__device__ __forceinline__ u64 vox_key(const VoxGrid& g, const float4& p, int i) {
+  const int i0 = (int)(floorf(p.x * g.inv) - (float)g.minb[0]);
+  const int i1 = (int)(floorf(p.y * g.inv) - (float)g.minb[1]);
+  const int i2 = (int)(floorf(p.z * g.inv) - (float)g.minb[2]);
+  const int idx = i0 + i1 * g.divb[0] + i2 * (g.divb[0] * g.divb[1]);
+  return ((u64)(u32)idx << 32) | (u32)i;
+}
+// the flags a voxel grid hands to the rest of the chain (one thread of the key launch)
+__device__ __forceinline__ void vox_grid_counts(const VoxGrid& g, int* __restrict__ counts) {
+  if (g.overflow) counts[CNT_VOX_OVERFLOW] = 1;
+  const long long cells = (long long)g.divb[0] * g.divb[1] * g.divb[2];  // every key is below this
+  counts[CNT_SORT_BITS] = (g.overflow || cells <= 1) ? (g.overflow ? 32 : 1) : 64 - __clzll(cells - 1);
 }
 
 // heads per 1024-element block
@@ -329,7 +353,7 @@ __device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, in
 #define VOX_TILE 1024
 #define VOX_HALO 512
 __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
-                                                       int P, const int* __restrict__ blkoff, float4* __restrict__ out,
+                                                       int P, const int* __restrict__ blkcnt, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts,
                                                        int* __restrict__ mail, int* __restrict__ mail_seq_slot,
                                                        int seq) {
@@ -339,10 +363,30 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   if (blockIdx.x >= nblk) return;
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * VOX_TILE;
-  int running = blkoff[blockIdx.x];
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = blkoff[nblk];
+  // first output slot of this tile and the voxel count of the cloud, from the per-tile head counts (a scan launch of its
+  // own between the count and this kernel cost more than every workgroup adding up a few hundred integers)
+  __shared__ int s_before[4], s_all[4];
+  int running, total;
+  {
+    int before = 0, all = 0;
+    for (int t = threadIdx.x; t < nblk; t += 256) {
+      const int c = blkcnt[t];
+      all += c;
+      before += (t < (int)blockIdx.x) ? c : 0;
+    }
+    before = wave_sum_i32(before);
+    all = wave_sum_i32(all);
+    if (lane == 0) {
+      s_before[wave] = before;
+      s_all[wave] = all;
+    }
+    __syncthreads();
+    running = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    total = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = total;
   if (mail && blockIdx.x == 0 && threadIdx.x < 16) {  // this is the last voxelise kernel: hand the counters to the host
-    mail_store_line(mail, threadIdx.x, (threadIdx.x == CNT_NVOX) ? blkoff[nblk] : counts[threadIdx.x], seq);
+    mail_store_line(mail, threadIdx.x, (threadIdx.x == CNT_NVOX) ? total : counts[threadIdx.x], seq);
     __threadfence_system();
     if (threadIdx.x == 0) *mail_seq_slot = seq;
   }
@@ -457,18 +501,18 @@ __device__ __forceinline__ void cell_of(const CellGrid& g, const float4& p, int*
 }
 __device__ __forceinline__ u32 cell_key(int cx, int cy, int cz) { return ((u32)cz << 16) | ((u32)cy << 8) | (u32)cx; }
 
-__device__ __forceinline__ void d_cell_keys(const float4* __restrict__ pts, int n, const u32* __restrict__ mm,
-                                                   float cell, u64* __restrict__ keys) {
+__device__ __forceinline__ CellGrid cell_grid(const u32* __restrict__ mm, float cell) {
   CellGrid g;
   g.mn[0] = dec_f32(mm[0]);
   g.mn[1] = dec_f32(mm[1]);
   g.mn[2] = dec_f32(mm[2]);
   g.cell = cell;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int c[3];
-    cell_of(g, pts[i], c);
-    keys[i] = ((u64)cell_key(c[0], c[1], c[2]) << 32) | (u32)i;
-  }
+  return g;
+}
+__device__ __forceinline__ u64 cell_sort_key(const CellGrid& g, const float4& p, int i) {
+  int c[3];
+  cell_of(g, p, c);
+  return ((u64)cell_key(c[0], c[1], c[2]) << 32) | (u32)i;
 }
 
 __device__ __forceinline__ int lower_bound_hi(const u64* keys, int n, u32 k) {  // first i with hi(keys[i]) >= k
@@ -1062,22 +1106,27 @@ __global__ __launch_bounds__(256) void k2_minmax(ViewExt<CloudView> x, Clouds2 a
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm);
 }
+// first launch of a sort: the histogram of the lowest digit of the keys in keys_a — which, with make_keys, are made here
+// too: those of the voxel grid (use_vox = 0: raw points, cell side `side` = leaf) or of the neighbour-search grid
+// (use_vox = 1: voxel centroids)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k2_vox_keys(ViewExt<CloudView> x, Clouds2 a, float leaf) {
-  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_vox_keys(C.raw, C.P, leaf, C.mm, C.keys_a, C.counts);
-}
-template <bool EXT>
-__global__ __launch_bounds__(256) void k2_cell_keys(ViewExt<CloudView> x, Clouds2 a, float cell) {
-  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_cell_keys(C.vox, C.n, C.mm, cell, C.keys_a);
-}
-// src: which of keys_a (0) / keys_b (1) holds the input of this pass
-template <bool EXT>
-__global__ __launch_bounds__(256) void k2_radix_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int shift, int src) {
+__global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int make_keys, float side) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
-  d_radix_hist<8, RADIX_TILE>(keys_src(C, src), n, shift, C.hist, (n + RADIX_TILE - 1) / RADIX_TILE);
+  const int nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
+  if (!make_keys) {
+    const u64* __restrict__ keys = C.keys_a;
+    d_radix_hist<8, RADIX_TILE>([&](int i) { return keys[i]; }, (u64*)nullptr, n, 32, C.hist, nblk);
+  } else if (use_vox) {
+    const CellGrid g = cell_grid(C.mm, side);
+    const float4* __restrict__ pts = C.vox;
+    d_radix_hist<8, RADIX_TILE>([&](int i) { return cell_sort_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
+  } else {
+    const VoxGrid g = vox_grid(C.mm, side);
+    if (blockIdx.x == 0 && threadIdx.x == 0) vox_grid_counts(g, C.counts);
+    const float4* __restrict__ pts = C.raw;
+    d_radix_hist<8, RADIX_TILE>([&](int i) { return vox_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
+  }
 }
 // pass: 0-based; last: no pass follows; adaptive: the keys carry C.counts[CNT_SORT_BITS] significant bits (known on the
 // device only) and a pass whose digit lies wholly above them is skipped — the consumers pick the buffer with
@@ -1110,15 +1159,10 @@ __global__ __launch_bounds__(256) void k2_vox_headcount(ViewExt<CloudView> x, Cl
   d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
 }
 template <bool EXT>
-__global__ __launch_bounds__(1024) void k2_vox_blockscan(ViewExt<CloudView> x, Clouds2 a) {
-  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_scan_i32_copy(C.blkcnt, C.blkoff, (C.P + 1023) / 1024);
-}
-template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   if (src < 0) src = sorted_src(C, 4, 1);
-  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkoff, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
+  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkcnt, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
                   C.mail_seq_slot, C.seq);
 }
 template <bool EXT>
@@ -1232,13 +1276,14 @@ static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, V
 // stable LSD radix sort of keys_a by bits [32, 32+key_bits); returns which buffer holds the result (0: keys_a)
 // adaptive: the keys' significant bits are in counts[CNT_SORT_BITS]; passes above them return at once and the result's
 // buffer is only known on the device (the return value is then -1: consumers call sorted_src())
-static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false) {
+static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false, bool make_keys = false,
+                       float side = 0.f) {
   const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
   const int passes = key_bits / 8;
-  // one histogram launch for the first pass; every scatter accumulates the next pass's histogram (see d_radix_hist).
+  // one launch makes the keys and the first pass's histogram; every scatter accumulates the next pass's histogram (see d_radix_hist).
   // A single-launch pass (tiles exchanging offsets through flags) needs device-scope fences, which on this multi-XCD
   // part cost more than the launch boundary.
-  LAUNCH_CV(k2_radix_hist, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, 32, 0);
+  LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side);
   for (int p = 0; p < passes; ++p)
     LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
   return adaptive ? -1 : (passes & 1);
@@ -1249,11 +1294,9 @@ static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipSt
   const int g = min(1024, (S.maxP + 255) / 256);
   LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 0);
   LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 0);
-  LAUNCH_CV(k2_vox_keys, S.a, dim3(g, nc), dim3(256), 0, st, leaf);
-  const int where = radix_sort2(S, 0, 32, st, true);  // the fourth pass only runs for grids of more than 2^24 voxels
+  const int where = radix_sort2(S, 0, 32, st, true, true, leaf);  // the fourth pass only runs for grids of more than 2^24 voxels
   const int nblk = (S.maxP + 1023) / 1024;
   LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
-  LAUNCH_CV(k2_vox_blockscan, S.a, dim3(1, nc), dim3(1024), 0, st);
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
@@ -1318,16 +1361,20 @@ hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStag
 }
 
 // normals + SPFH + FPFH (+ the matcher's sequential mean) of the clouds of S
-static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean) {
+// origin_known: C.mm[0..2] already hold a lower bound of the points (the raw cloud's minimum, left there by the voxel
+// stage whose centroids these are) — the neighbour grid only needs an origin at or below every point (cell_of clamps, so
+// a centroid that rounds an ulp below it is still in cell 0), which saves two launches of a latency-bound chain
+static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean, bool origin_known) {
   const int nc = S.nc, maxn = S.maxn;
   const int g = min(1024, (maxn + 255) / 256);
   const float cell = r_fpfh * 1.001f;
   const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
   const float rn2 = (float)((double)r_normal * (double)r_normal);
-  LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 1);  // keeps the counters of the voxel stage
-  LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 1);
-  LAUNCH_CV(k2_cell_keys, S.a, dim3(g, nc), dim3(256), 0, st, cell);
-  const int where = radix_sort2(S, 1, 24, st);
+  if (!origin_known) {
+    LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 1);  // keeps the counters of the voxel stage
+    LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 1);
+  }
+  const int where = radix_sort2(S, 1, 24, st, false, true, cell);
   // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
   LAUNCH_CV(k2_ranges, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell, where);
   // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
@@ -1340,14 +1387,14 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
 }
 
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean) {
+                        bool with_mean, bool origin_known) {
   (void)hipGetLastError();
   CloudView v[2];
   for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, with_mean);
+  fpfh_launch(S, r_normal, r_fpfh, st, with_mean, origin_known);
   return hipGetLastError();
 }
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
@@ -1359,7 +1406,7 @@ hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, false);
+  fpfh_launch(S, r_normal, r_fpfh, st, false, true);  // always behind voxelize_enqueue_group
   return hipGetLastError();
 }
 

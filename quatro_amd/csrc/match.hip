@@ -571,20 +571,37 @@ __global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, Match
 // loop is the hand-scheduled block of nn_f16_core.inc (generated by gen_nn_f16_core.py: register map, schedule and the
 // wait states it has to respect are documented there).  ~250 VGPRs + 112 AGPRs: one workgroup per compute unit.
 #include "nn_f16_core.inc"
+// -DQTR_NN_TIMING (diagnostic build, tests/probe/nn_stamps.py): thread 0 of every workgroup records the shader clock and
+// the 100 MHz wall clock at five points of its first item
+#ifdef QTR_NN_TIMING
+__device__ unsigned long long g_nn_stamp[2][256][12];
+#define NN_STAMP(i)                                                          \
+  if (threadIdx.x == 0 && blockIdx.x < 256) {                                \
+    g_nn_stamp[dir][blockIdx.x][2 * (i)] = clock64();                        \
+    g_nn_stamp[dir][blockIdx.x][2 * (i) + 1] = wall_clock64();               \
+  }
+extern "C" int qtr_debug_nn_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stamp), sizeof(g_nn_stamp));
+}
+#else
+#define NN_STAMP(i)
+#endif
 template <bool EXT>
 __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G) {
+  NN_STAMP(0)
   NN_PLAN(G, dir, (int)gridDim.x)
+  NN_STAMP(1)
   __shared__ int s_item;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   int* counter = (EXT ? x.ext[0].mcounts : one.mcounts) + 14 + dir;  // zeroed by k_match_init
   const int total = s_off[G];
+  // the first item of a workgroup is its own index, later ones come from the counter (which therefore counts from
+  // gridDim.x on): a launch with no more items than workgroups — every single-pair launch — never touches it, and nobody
+  // waits for an atomic's round trip before the first load
+  int item = blockIdx.x;
 #pragma unroll 1
   while (true) {
-    if (threadIdx.x == 0) s_item = atomicAdd(counter, 1);
-    __syncthreads();
-    const int item = s_item;
-    __syncthreads();
     if (item >= total) break;
     int g = 0;
     while (g + 1 < G && item >= s_off[g + 1]) ++g;
@@ -599,9 +616,11 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     const int t_begin = slice * tps, t_end = min(ntiles, t_begin + tps);
     float b1[4], b2[4];
     int it1[4];  // tile of the best
+    NN_STAMP(2)
     if (t_begin < t_end) {
       nn_f16_core(D.queryH + (size_t)((qb * 4 + wave) * 4) * (NNH_CHUNKS * 32), D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32),
                   t_end - t_begin, t_begin, ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
+    NN_STAMP(3)
     } else {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -629,6 +648,15 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
         partial[(size_t)(qbase + 32 * c) * nsplit + slice] = p;
       }
     }
+    NN_STAMP(4)
+#ifdef QTR_NN_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_nn_stamp[dir][blockIdx.x][10] = (unsigned long long)(t_end - t_begin);
+#endif
+    if (total <= (int)gridDim.x) break;  // (uniform) nothing beyond the first round
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = (int)gridDim.x + atomicAdd(counter, 1);
+    __syncthreads();
+    item = s_item;
   }
 }
 
