@@ -576,11 +576,11 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
 
 // Runs the back end on device-resident matched clouds and brings the result record to the host.
 static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float4* d_tgt, int L, const qtr_params* prm,
-                        qtr_result* res) {
+                        qtr_result* res, bool reset_done = false) {
   s.last_L = L;
   s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, h->stage_events ? s.ev[2] : nullptr,
-                                h->stage_events ? s.ev[3] : nullptr));
+                                h->stage_events ? s.ev[3] : nullptr, reset_done));
   QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));  // k_finalize left the record and the state in the mailbox
   if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
@@ -1226,11 +1226,12 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 }
 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
-static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out) {
+static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out,
+                        bool init_done = false) {
   flush_nn_totals(s);
   s.nn_pending = (s.fb.nn_events && s.fb.nn_engine != 0) ? 1 : 0;
   s.fb.mail_seq = ++s.seq;
-  QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream));
+  QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream, init_done));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
   *L_out = s.mail[MAIL_MATCH + MC_NCORR];
   return QTR_OK;
@@ -1340,15 +1341,20 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
-    QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
-    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));  // overlaps the FPFH chain
-    QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
+    // the FPFH chain first: the device is idle until its first launch arrives
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true));
+    // beside it, on the second stream: the matcher's sequential means, and the matcher's and the solver's clean slates
+    // (they depend on the voxel counts alone)
+    QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
+    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
+    QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2));
+    QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
+    QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
-  rc = match_device(h, s, ns, nt, fp, &L);
+  rc = match_device(h, s, ns, nt, fp, &L, true);
   if (rc != QTR_OK) return res->status = rc;
   if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "neighbour list capacity (%d per point) exceeded: max k = %d / %d", QTR_KMAX,
@@ -1362,7 +1368,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   }
   QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, s.stream));
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
-  rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res);
+  rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res, true);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
   s.times_pending = 2;
   const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);

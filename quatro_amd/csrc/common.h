@@ -9,6 +9,25 @@
 #include "../../include/qtr_math.h"
 #include "../../include/quatro_hip.h"
 
+// -DQTR_NN_TIMING (diagnostic build, tests/probe/nn_stamps.py — never the shipped library): QTR_STAMP(kernel, point) lets
+// thread 0 of the first 32 workgroups (x) of a launch's (y, z) = (0, 0) plane record the shader clock and the 100 MHz wall
+// clock; the last launch of each kernel is what the probe reads back.
+#ifdef QTR_NN_TIMING
+#define QTR_STAMP_KERNELS 12
+#define QTR_STAMP_POINTS 8
+__device__ unsigned long long g_stamp[QTR_STAMP_KERNELS][32][QTR_STAMP_POINTS][2];
+#define QTR_STAMP(kid, pt)                                                                   \
+  if (threadIdx.x == 0 && blockIdx.x < 32 && blockIdx.y == 0 && blockIdx.z == 0) {          \
+    g_stamp[kid][blockIdx.x][pt][0] = clock64();                                             \
+    g_stamp[kid][blockIdx.x][pt][1] = wall_clock64();                                        \
+  }
+#else
+#define QTR_STAMP(kid, pt)
+#endif
+enum { STAMP_DESC_PREP = 0, STAMP_HALF_TABLES, STAMP_SCATTER, STAMP_RECHECK, STAMP_CENTROIDS, STAMP_HIT_COMPACT, STAMP_CROSS,
+       STAMP_NN_FINISH, STAMP_NEIGHBORS, STAMP_SPFH, STAMP_FPFH, STAMP_FINALIZE };
+
+
 #define QK_WAVE 64
 
 typedef unsigned long long u64;

@@ -27,6 +27,7 @@ enum { MAIL_VOX0 = 0, MAIL_VOX1 = 16, MAIL_MATCH = 32, MAIL_CNT0 = 48, MAIL_CNT1
 struct CloudBufs {
   int* counts = nullptr;       // 16
   u32* mm = nullptr;           // 8: order-preserving encodings of min x,y,z / max x,y,z
+  u32* mm_part = nullptr;      // one such record per workgroup of k2_minmax (folded by k2_keys_hist)
   float4* vox = nullptr;       // [max_voxels] down-sampled cloud (or the qtr_fpfh input)
   float4* normals = nullptr;   // [max_voxels] nx,ny,nz,curvature
   float* spfh = nullptr;       // [max_voxels][33]
@@ -62,6 +63,7 @@ struct CloudView {
   int n;               // voxel count (known on the host after the voxelise read-back)
   int* counts;
   u32* mm;
+  u32* mm_part;        // k2_minmax's per-workgroup records
   float4* vox;
   float4* normals;
   float* spfh;
@@ -205,7 +207,10 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
                         bool with_mean, bool origin_known);
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
-hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
+// init_done: match_init_enqueue already ran for this pair (same ns, nt, fp) — the whole-path driver issues it beside the
+// FPFH chain, which takes one launch off the critical path
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done = false);
+hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
 
 // The same stages for G pairs at once (qtr_submit_batch): one launch chain, the views of all pairs in device memory

@@ -31,7 +31,10 @@ __global__ void k_set_count(int* counts, int which, int value) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counts[which] = value;
 }
 
-__device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, u32* __restrict__ mm) {
+// Bounding box of a cloud, first half: workgroup b leaves the order-preserving encodings of its min x,y,z / max x,y,z in
+// part[8 b .. 8 b + 5].  The consumer (k2_keys_hist) folds the gridDim.x records: nothing has to be initialised first
+// — with atomics on one record a launch of its own had to reset it before every cloud.
+__device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, u32* __restrict__ part) {
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 p = pts[i];
@@ -64,11 +67,38 @@ __device__ __forceinline__ void d_minmax(const float4* __restrict__ pts, int n, 
     const int a = threadIdx.x;
     float v = red[0][a];
     for (int w = 1; w < 4; ++w) v = (a < 3) ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
-    if (a < 3)
-      atomicMin(&mm[a], enc_f32(v));
-    else
-      atomicMax(&mm[a], enc_f32(v));
+    part[8 * blockIdx.x + a] = enc_f32(v);
   }
+}
+// second half, by every workgroup of the consumer: fold `parts` records into s_mm[6] (LDS); ends with a barrier
+#define MM_MAX_PARTS 128
+__device__ __forceinline__ void mm_fold(const u32* __restrict__ part, int parts, u32* s_mm) {
+  if (threadIdx.x < 64) {
+    u32 lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    for (int p = threadIdx.x; p < parts; p += 64) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = min(lo[a], part[8 * p + a]);
+        hi[a] = max(hi[a], part[8 * p + 3 + a]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo[a] = min(lo[a], (u32)__shfl_xor((int)lo[a], off, 64));
+        hi[a] = max(hi[a], (u32)__shfl_xor((int)hi[a], off, 64));
+      }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s_mm[a] = lo[a];
+        s_mm[3 + a] = hi[a];
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // =================================================================================================
@@ -124,6 +154,8 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
   __shared__ u32 cntw[4][NB];                 // digit counts of each wave's quarter, then its running bases
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   if (blk >= nblk) return;
+#define SCATTER_STAMP(pt) if (hist_next && n > 30000) { QTR_STAMP(STAMP_SCATTER, pt) }
+  SCATTER_STAMP(0)
   if (hist_clear) hist_clear[(size_t)blk * NB + tid] = 0;
   const int tbase = blk * TILE + wave * 256;
   u64 keys[4];
@@ -164,6 +196,7 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
     }
   }
   __syncthreads();
+  SCATTER_STAMP(1)
 #pragma unroll
   for (int s = 0; s < 4; ++s)
     if (tbase + s * 64 + lane < n) atomicAdd(&cntw[wave][(u32)(keys[s] >> shift) & (u32)(NB - 1)], 1u);
@@ -186,6 +219,7 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
     }
   }
   __syncthreads();
+  SCATTER_STAMP(2)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int i = tbase + s * 64 + lane;
@@ -229,6 +263,8 @@ __device__ __forceinline__ void d_radix_scatter(const u64* __restrict__ in, u64*
     if (valid && (m & lanemask_lt()) == 0) cntw[wave][d] += (u32)__popcll(m);
     __syncthreads();
   }
+  SCATTER_STAMP(3)
+#undef SCATTER_STAMP
 }
 
 // out[0..n] = exclusive scan of f(in[0..n)); single workgroup of 1024 threads.  Up to 16384 elements each
@@ -336,9 +372,19 @@ __device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, in
   __syncthreads();
   int c = 0;
   const int base = blockIdx.x * 1024;
-  for (int t = threadIdx.x; t < 1024; t += 256) {
-    const int i = base + t;
-    if (i < P) c += (i == 0) || ((u32)(keys[i] >> 32) != (u32)(keys[i - 1] >> 32));
+  {
+    u32 cur[4], prev[4];  // (eight loads in flight, then the comparisons)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = min(base + q * 256 + (int)threadIdx.x, P - 1);
+      cur[q] = (u32)(keys[i] >> 32);
+      prev[q] = (u32)(keys[max(i - 1, 0)] >> 32);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + q * 256 + (int)threadIdx.x;
+      if (i < P) c += (i == 0) || (cur[q] != prev[q]);
+    }
   }
   c = wave_sum_i32(c);
   if (qk_lane() == 0) atomicAdd(&s, c);
@@ -363,6 +409,7 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   if (blockIdx.x >= nblk) return;
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * VOX_TILE;
+  QTR_STAMP(STAMP_CENTROIDS, 0)
   // first output slot of this tile and the voxel count of the cloud, from the per-tile head counts (a scan launch of its
   // own between the count and this kernel cost more than every workgroup adding up a few hundred integers)
   __shared__ int s_before[4], s_all[4];
@@ -412,8 +459,10 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
       s_p[t + 1] = pp[q];
     }
   }
+  QTR_STAMP(STAMP_CENTROIDS, 1)
   if (threadIdx.x == 0) s_p[0].w = __uint_as_float((base > 0) ? (u32)(keys[base - 1] >> 32) : 0xffffffffu);
   __syncthreads();
+  QTR_STAMP(STAMP_CENTROIDS, 2)
   for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
     const int t = t0 + threadIdx.x;
     const int i = base + t;
@@ -484,6 +533,7 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
     running += tot;
     __syncthreads();
   }
+  QTR_STAMP(STAMP_CENTROIDS, 3)
 }
 
 // =================================================================================================
@@ -1094,35 +1144,40 @@ __device__ __forceinline__ const u64* keys_src(const CloudView& C, int src) { re
 __device__ __forceinline__ u64* keys_dst(const CloudView& C, int src) { return src == 0 ? C.keys_b : C.keys_a; }
 
 template <bool EXT>
-__global__ void k2_cloud_init(ViewExt<CloudView> x, Clouds2 a, int keep_counts) {
+__global__ __launch_bounds__(256) void k2_minmax(ViewExt<CloudView> x, Clouds2 a, int use_vox, int zero_counts) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  const int t = threadIdx.x;
-  if (!keep_counts && t < 16) C.counts[t] = 0;
-  if (t < 3) C.mm[t] = 0xffffffffu;
-  if (t >= 3 && t < 6) C.mm[t] = 0u;
-}
-template <bool EXT>
-__global__ __launch_bounds__(256) void k2_minmax(ViewExt<CloudView> x, Clouds2 a, int use_vox) {
-  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm);
+  if (zero_counts && blockIdx.x == 0 && threadIdx.x < 16) C.counts[threadIdx.x] = 0;  // first launch of a voxel stage
+  d_minmax(use_vox ? C.vox : C.raw, use_vox ? C.n : C.P, C.mm_part);
 }
 // first launch of a sort: the histogram of the lowest digit of the keys in keys_a — which, with make_keys, are made here
 // too: those of the voxel grid (use_vox = 0: raw points, cell side `side` = leaf) or of the neighbour-search grid
 // (use_vox = 1: voxel centroids)
+// mm_parts: records k2_minmax left for this cloud (0: C.mm already holds the box / origin to use)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int make_keys, float side) {
+__global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int make_keys, float side,
+                                                    int mm_parts) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
   const int nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
+  __shared__ u32 s_mm[6];
+  if (make_keys) {
+    if (mm_parts > 0) {
+      mm_fold(C.mm_part, mm_parts, s_mm);
+      if (blockIdx.x == 0 && threadIdx.x < 6) C.mm[threadIdx.x] = s_mm[threadIdx.x];  // for the kernels further down the chain
+    } else {
+      if (threadIdx.x < 6) s_mm[threadIdx.x] = C.mm[threadIdx.x];
+      __syncthreads();
+    }
+  }
   if (!make_keys) {
     const u64* __restrict__ keys = C.keys_a;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return keys[i]; }, (u64*)nullptr, n, 32, C.hist, nblk);
   } else if (use_vox) {
-    const CellGrid g = cell_grid(C.mm, side);
+    const CellGrid g = cell_grid(s_mm, side);
     const float4* __restrict__ pts = C.vox;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return cell_sort_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
   } else {
-    const VoxGrid g = vox_grid(C.mm, side);
+    const VoxGrid g = vox_grid(s_mm, side);
     if (blockIdx.x == 0 && threadIdx.x == 0) vox_grid_counts(g, C.counts);
     const float4* __restrict__ pts = C.raw;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return vox_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
@@ -1227,6 +1282,7 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n, int* m
   v.n = n;
   v.counts = C.counts;
   v.mm = C.mm;
+  v.mm_part = C.mm_part;
   v.vox = C.vox;
   v.normals = C.normals;
   v.spfh = C.spfh;
@@ -1277,13 +1333,13 @@ static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, V
 // adaptive: the keys' significant bits are in counts[CNT_SORT_BITS]; passes above them return at once and the result's
 // buffer is only known on the device (the return value is then -1: consumers call sorted_src())
 static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false, bool make_keys = false,
-                       float side = 0.f) {
+                       float side = 0.f, int mm_parts = 0) {
   const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
   const int passes = key_bits / 8;
   // one launch makes the keys and the first pass's histogram; every scatter accumulates the next pass's histogram (see d_radix_hist).
   // A single-launch pass (tiles exchanging offsets through flags) needs device-scope fences, which on this multi-XCD
   // part cost more than the launch boundary.
-  LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side);
+  LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side, mm_parts);
   for (int p = 0; p < passes; ++p)
     LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
   return adaptive ? -1 : (passes & 1);
@@ -1292,9 +1348,9 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
 static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st) {
   const int nc = S.nc;
   const int g = min(1024, (S.maxP + 255) / 256);
-  LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 0);
-  LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 0);
-  const int where = radix_sort2(S, 0, 32, st, true, true, leaf);  // the fourth pass only runs for grids of more than 2^24 voxels
+  const int mm_parts = max(1, min(g, MM_MAX_PARTS));
+  LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 0, 1);
+  const int where = radix_sort2(S, 0, 32, st, true, true, leaf, mm_parts);  // the fourth pass only runs for grids of more than 2^24 voxels
   const int nblk = (S.maxP + 1023) / 1024;
   LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
@@ -1370,11 +1426,9 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   const float cell = r_fpfh * 1.001f;
   const float r2 = (float)((double)r_fpfh * (double)r_fpfh);
   const float rn2 = (float)((double)r_normal * (double)r_normal);
-  if (!origin_known) {
-    LAUNCH_CV(k2_cloud_init, S.a, dim3(1, nc), dim3(64), 0, st, 1);  // keeps the counters of the voxel stage
-    LAUNCH_CV(k2_minmax, S.a, dim3(min(g, 128), nc), dim3(256), 0, st, 1);
-  }
-  const int where = radix_sort2(S, 1, 24, st, false, true, cell);
+  const int mm_parts = origin_known ? 0 : max(1, min(g, MM_MAX_PARTS));
+  if (!origin_known) LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 1, 0);  // (keeps the counters)
+  const int where = radix_sort2(S, 1, 24, st, false, true, cell, mm_parts);
   // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
   LAUNCH_CV(k2_ranges, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell, where);
   // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
@@ -1418,7 +1472,7 @@ static int dedup_slots(int max_voxels) {
 }
 size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   size_t per_cloud = 0;
-  per_cloud += 4096;                                         // counts, mm, mean
+  per_cloud += 4096 + MM_MAX_PARTS * 32 + 256;               // counts, mm, mean, mm_part
   per_cloud += (size_t)max_voxels * (16 + 16 + 132 + 132);   // vox, normals, spfh, fpfh
   per_cloud += 2 * (size_t)max_points * 8;                   // keys
   per_cloud += (size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4 + 65536;  // hist
@@ -1451,6 +1505,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     CloudBufs& C = F.cloud[c];
     C.counts = (int*)take(16 * 4);
     C.mm = (u32*)take(8 * 4);
+    C.mm_part = (u32*)take(MM_MAX_PARTS * 8 * 4);
     C.mean = (float*)take(4 * 4);
     C.vox = (float4*)take((size_t)max_voxels * 16);
     C.normals = (float4*)take((size_t)max_voxels * 16);

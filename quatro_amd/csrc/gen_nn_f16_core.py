@@ -14,7 +14,7 @@ Register map (per lane)
   v[192:219]  base tile buffer 0 (7 fragments of 4 dwords), v[220:247] buffer 1
   v20-23 best, v24-27 second, v28-31 best before the tile, v32-35 tile of the best, v36 temp, v38 tile being folded,
   v39 lane byte offset inside a chunk pair, v40 = v39 + 4096
-  s[40:41] base-table cursor (next tile to load), s[44:45] query cursor, s42 tiles left to start, s43 pack mask
+  s[40:41] base-table cursor (next tile to load), s[44:45] query table, s42 tiles left to start, s43 pack mask
 Wait states that the assembler will not insert for us (gfx940/950): a VALU read of an MFMA result needs the MFMA to
 be 11 wait states old (8-pass) — every fold starts behind two MFMAs of the next tile; v_cmp -> v_cndmask through VCC
 needs 2 (s_nop 1).
@@ -104,11 +104,11 @@ A = asm.append
 # ---- prologue
 asm += ["s_mov_b32 s40, %[blo]", "s_mov_b32 s41, %[bhi]", "s_mov_b32 s44, %[qlo]", "s_mov_b32 s45, %[qhi]", "s_mov_b32 s42, %[nt]",
         "s_mov_b32 s43, 0xfffffff0", "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_mov_b32 v38, %[t0]"]
-for c in range(4):  # query fragments straight into AGPRs
+for c in range(4):  # query fragments straight into AGPRs; the lane's row of column block c starts at byte %[qc] of the table
+    asm.append("v_add_u32 v36, 0x1000, %%[q%d]" % c)
     for m in range(7):
-        va, off = ("v39", 1024 * m) if m < 4 else ("v40", 1024 * (m - 4))
+        va, off = ("%%[q%d]" % c, 1024 * m) if m < 4 else ("v36", 1024 * (m - 4))
         asm.append("global_load_dwordx4 a[%d:%d], %s, s[44:45] offset:%d" % ((7 * c + m) * 4, (7 * c + m) * 4 + 3, va, off))
-    asm += ["s_add_u32 s44, s44, %d" % TILE_BYTES, "s_addc_u32 s45, s45, 0"]
 for c in range(4):
     asm += ["v_mov_b32 v%d, 0x7f800000" % (20 + c), "v_mov_b32 v%d, 0x7f800000" % (24 + c), "v_mov_b32 v%d, 0x7f800000" % (28 + c),
             "v_mov_b32 v%d, -1" % (32 + c)]
@@ -141,9 +141,11 @@ clob = ['"v%d"' % i for i in list(range(20, 41)) + list(range(64, 248))] + ['"a%
 clob += ['"s40"', '"s41"', '"s42"', '"s43"', '"s44"', '"s45"', '"vcc"', '"scc"', '"memory"']
 
 print("// generated by gen_nn_f16_core.py — do not edit (see that file for the register map and the schedule)")
-print("// One item of k_nn_f16: 4 x 32 query columns of this wave against `ntiles` base tiles starting at `base`;")
+print("// One item of k_nn_f16: 4 x 32 query columns of this wave (the lane's row of column block c starts at byte qoff[c] of")
+print("// the query table: any row, so a list of rows needs no gathered copy) against `ntiles` base tiles starting at `base`;")
 print("// running best / second best (scaled, row index packed in the low mantissa bits) and the tile of the best, per block.")
-print("__device__ __forceinline__ void nn_f16_core(const uint4* query, const uint4* base, int ntiles, int t_begin, u32 frag_bytes,")
+print("__device__ __forceinline__ void nn_f16_core(const uint4* query, const u32 (&qoff)[4], const uint4* base, int ntiles, int t_begin,")
+print("                                            u32 frag_bytes,")
 print("                                            float (&b1)[4], float (&b2)[4], int (&it1)[4]) {")
 print("  const u32 qlo = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)query), qhi = __builtin_amdgcn_readfirstlane((u32)((uintptr_t)query >> 32));")
 print("  const u32 blo = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)base), bhi = __builtin_amdgcn_readfirstlane((u32)((uintptr_t)base >> 32));")
@@ -153,6 +155,7 @@ for a in asm:
     print('      "%s\\n"' % a)
 outs = ", ".join('[b1%d] "=&v"(b1[%d]), [b2%d] "=&v"(b2[%d]), [it%d] "=&v"(it1[%d])' % (c, c, c, c, c, c) for c in range(4))
 print("      : %s" % outs)
-print('      : [qlo] "s"(qlo), [qhi] "s"(qhi), [blo] "s"(blo), [bhi] "s"(bhi), [nt] "s"(nt), [t0] "s"(t0), [frag] "v"(frag_bytes)')
+print('      : [qlo] "s"(qlo), [qhi] "s"(qhi), [blo] "s"(blo), [bhi] "s"(bhi), [nt] "s"(nt), [t0] "s"(t0), [frag] "v"(frag_bytes),')
+print('        [q0] "v"(qoff[0]), [q1] "v"(qoff[1]), [q2] "v"(qoff[2]), [q3] "v"(qoff[3])')
 print("      : %s);" % ", ".join(clob))
 print("}")

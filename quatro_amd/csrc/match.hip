@@ -24,18 +24,19 @@
 #include "frontend.h"
 
 #define NN_TILE 64
+#define CROSS_LDS_BYTES (156 * 1024)  // dynamic LDS k_cross_fused may ask for (160 KB per CU, minus its static part)
 #define NN_STRIDE 36  // floats per staged descriptor row (33 + 3 zero pad; 16-byte aligned rows)
 
 // EXT (view in the kernel arguments / in device memory) is a template parameter, not a run-time select: a reference that
 // may point into either is a generic pointer, and every load behind it degrades to flat_load.  The pick itself is
 // written inline in every kernel — routed through a helper that takes the argument structs by reference, the compiler
 // loses the kernel-argument provenance again (see ViewExt in common.h).
-#define LAUNCH_MV_K(kern, K, a, grid, block, lds, st)                                                            \
+#define LAUNCH_MV_K(kern, K, a, grid, block, lds, st, ...)                                                       \
   do {                                                                                                          \
     if ((a).ext)                                                                                                \
-      hipLaunchKernelGGL((kern<true, K>), grid, block, lds, st, (ViewExt<MatchView>{(a).ext, {0, 0, 0}}), (a).one); \
+      hipLaunchKernelGGL((kern<true, K>), grid, block, lds, st, (ViewExt<MatchView>{(a).ext, {0, 0, 0}}), (a).one, ##__VA_ARGS__); \
     else                                                                                                        \
-      hipLaunchKernelGGL((kern<false, K>), grid, block, lds, st, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one); \
+      hipLaunchKernelGGL((kern<false, K>), grid, block, lds, st, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one, ##__VA_ARGS__); \
   } while (0)
 #define LAUNCH_MV(kern, a, grid, block, lds, st, ...)                                       \
   do {                                                                                      \
@@ -142,22 +143,36 @@ __device__ __forceinline__ u64 desc_hash(const float* d) {
   return h;
 }
 
+// the 256 rows of a workgroup, row-major table -> LDS: 33 coalesced loads per thread, all in flight before the first LDS
+// store (as a plain loop the compiler waits for every load: 33 round trips, 8 us of a 15 us kernel)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ desc, int row0, int n, float* s_rows) {
+  const size_t base = (size_t)row0 * 33, lim = (size_t)n * 33;
+  float t[33];
+#pragma unroll
+  for (int k = 0; k < 33; ++k) {
+    const size_t e = base + (size_t)(k * 256 + threadIdx.x);
+    t[k] = (e < lim) ? desc[e] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 33; ++k) s_rows[k * 256 + threadIdx.x] = t[k];
+}
+
 // desc[n][33] -> baseT[34][n_pad] (row 33 = scaled |b|^2; pad rows get 1e30 so they never win) and
 // queryT[34][n_pad] (-2 * desc, row 33 = 1); the norms (binary64 sum rounded once); and the row's entry in the
 // dedup table: slot sequence from the low hash bits, tag = high 32 bits, value = lowest row with that tag.
-__device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int n, int n_pad, float* __restrict__ baseT,
-                                            float* __restrict__ queryT /* null: the f16 engine does not read it */,
+__device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int n, int n_pad,
+                                            float* __restrict__ baseT /* null: the f16 engine builds its own tables */,
+                                            float* __restrict__ queryT /* null: only the f32 MFMA engine reads it */,
                                             float* __restrict__ norms, u64* __restrict__ hashes, u64* __restrict__ table,
                                             int mask, float* s_rows /* LDS, 256 x 33 */) {
   // the rows of this workgroup, staged through LDS: coalesced loads of the row-major table (a thread reading its own
   // 132-byte row costs one cache-line access per lane and instruction), then conflict-free row reads (stride 33)
   const int row0 = blockIdx.x * 256;
   if (row0 >= n_pad) return;
-  {
-    const size_t base = (size_t)row0 * 33, lim = (size_t)n * 33;
-    for (int e = threadIdx.x; e < 256 * 33; e += 256) s_rows[e] = (base + e < lim) ? desc[base + e] : 0.f;
-  }
+  QTR_STAMP(STAMP_DESC_PREP, 0)
+  stage_rows(desc, row0, n, s_rows);
   __syncthreads();
+  QTR_STAMP(STAMP_DESC_PREP, 1)
   const int i = row0 + threadIdx.x;
   if (i >= n_pad) return;
   if (i < n) {
@@ -166,17 +181,20 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
     for (int k = 0; k < 33; ++k) {
       v[k] = s_rows[threadIdx.x * 33 + k];
       acc += (double)v[k] * (double)v[k];
-      baseT[(size_t)k * n_pad + i] = v[k];
+      if (baseT) baseT[(size_t)k * n_pad + i] = v[k];
       if (queryT) queryT[(size_t)k * n_pad + i] = -2.0f * v[k];
     }
-    baseT[(size_t)33 * n_pad + i] = __double2float_rd(acc * NN_NORM_SCALE);
+    if (baseT) baseT[(size_t)33 * n_pad + i] = __double2float_rd(acc * NN_NORM_SCALE);
     if (queryT) queryT[(size_t)33 * n_pad + i] = 1.0f;
     norms[i] = (float)acc;
     const u64 h = desc_hash(v);
     hashes[i] = h;
+    QTR_STAMP(STAMP_DESC_PREP, 2)
     const u64 tag = h & 0xffffffff00000000ULL;
     u32 slot = (u32)h & (u32)mask;
     for (int probe = 0; probe <= mask; ++probe) {
+      // (load first: claiming the slot with the CAS straight away saves a round trip on an empty slot but was measured
+      // slower — thousands of identical descriptors then queue on one word)
       u64 cur = table[slot];
       if (cur == ~0ULL) {
         const u64 old = atomicCAS(&table[slot], ~0ULL, tag | (u32)i);
@@ -191,7 +209,8 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
       }
       slot = (slot + 1) & (u32)mask;
     }
-  } else {
+    QTR_STAMP(STAMP_DESC_PREP, 3)
+  } else if (baseT) {
     for (int k = 0; k < 33; ++k) {
       baseT[(size_t)k * n_pad + i] = 0.f;
       if (queryT) queryT[(size_t)k * n_pad + i] = 0.f;
@@ -201,16 +220,17 @@ __device__ __forceinline__ void d_desc_prep(const float* __restrict__ desc, int 
   }
 }
 // grid (pad_large_max / 256, 2, pairs): blockIdx.y = cloud (0: larger, 1: smaller)
+// tables: 0 none (f16 engine: norms, hashes and the dedup table only), 1 baseT (exact engine), 2 baseT + queryT (f32 MFMA)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one, int f32_tables) {
+__global__ __launch_bounds__(256) void k_desc_prep(ViewExt<MatchView> x, MatchView one, int tables) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   __shared__ float s_rows[256 * 33];
   if (blockIdx.y == 0)
-    d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, V.baseT_i, f32_tables ? V.queryT_i : nullptr, V.norms_i, V.hash_i, V.table_i,
-                V.dd_mask, s_rows);
+    d_desc_prep(V.fpfh_i, V.n_large, V.pad_large, tables >= 1 ? V.baseT_i : nullptr, tables >= 2 ? V.queryT_i : nullptr, V.norms_i,
+                V.hash_i, V.table_i, V.dd_mask, s_rows);
   else
-    d_desc_prep(V.fpfh_j, V.n_small, V.pad_small, V.baseT_j, f32_tables ? V.queryT_j : nullptr, V.norms_j, V.hash_j, V.table_j,
-                V.dd_mask, s_rows);
+    d_desc_prep(V.fpfh_j, V.n_small, V.pad_small, tables >= 1 ? V.baseT_j : nullptr, tables >= 2 ? V.queryT_j : nullptr, V.norms_j,
+                V.hash_j, V.table_j, V.dd_mask, s_rows);
 }
 
 // Hides base rows that duplicate a lower row bit for bit (see the header comment).  The table gives the lowest row
@@ -515,21 +535,62 @@ __device__ __forceinline__ _Float16 base_slot(const HalfRow& b, const _Float16* 
 __device__ __forceinline__ _Float16 query_slot(const HalfRow& q, int s) {
   return s < 33 ? q.h1[s] : s < 66 ? q.h1[s - 33] : s < 99 ? q.h2[s - 66] : s < 102 ? (_Float16)16384.f : (_Float16)0.f;
 }
-__device__ __forceinline__ void d_half_tables(const float* __restrict__ baseT, const float* __restrict__ norms, int n,
-                                              int n_pad, uint4* __restrict__ baseH, uint4* __restrict__ queryH,
-                                              int* __restrict__ unsafe) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// One launch after k_desc_prep (which filled the dedup table): the rows of this workgroup staged through LDS, a row's
+// representative looked up (a row that repeats a lower row bit for bit is hidden: norm slots 3 x 65504), the range
+// checks, and both operand tables written.  The engine has no other copy of the descriptors: the k-major f32 tables of
+// the other engines are not built.  grid (pad_large_max / 256, 2, pairs)
+__device__ __forceinline__ void d_half_tables(const float* __restrict__ desc, int n, int n_pad, const u64* __restrict__ hashes,
+                                              const u64* __restrict__ table, int mask, int* __restrict__ hidden_count,
+                                              uint4* __restrict__ baseH, uint4* __restrict__ queryH, int* __restrict__ unsafe,
+                                              float* s_rows /* LDS, 256 x 33 */) {
+  const int row0 = blockIdx.x * 256;
+  if (row0 >= n_pad) return;
+  QTR_STAMP(STAMP_HALF_TABLES, 0)
+  stage_rows(desc, row0, n, s_rows);
+  __syncthreads();
+  QTR_STAMP(STAMP_HALF_TABLES, 1)
+  const int i = row0 + threadIdx.x;
   if (i >= n_pad) return;
   float v[33];
   bool bad = false;
+  double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < 33; ++k) {
-    v[k] = baseT[(size_t)k * n_pad + i];
+    v[k] = s_rows[threadIdx.x * 33 + k];  // (zeros past the cloud)
+    acc += (double)v[k] * (double)v[k];
     bad = bad || !(fabsf(v[k]) <= 255.0f);
   }
-  const float nbp = baseT[(size_t)33 * n_pad + i];  // scaled-down |b|^2; 1e30: hidden duplicate or pad row
-  if (i < n) bad = bad || !(norms[i] < 65000.0f);
+  float nbp = 1e30f;  // scaled-down |b|^2 (the lower bound the chain works with); 1e30: hidden duplicate or pad row
+  bool hide = false;
+  if (i < n) {
+    bad = bad || !((float)acc < 65000.0f);
+    nbp = __double2float_rd(acc * NN_NORM_SCALE);
+    const u64 h = hashes[i];
+    const u64 tag = h & 0xffffffff00000000ULL;
+    u32 slot = (u32)h & (u32)mask;
+    int rep = i;
+    for (int probe = 0; probe <= mask; ++probe) {
+      const u64 cur = table[slot];
+      if (cur == ~0ULL) break;
+      if ((cur & 0xffffffff00000000ULL) == tag) {
+        rep = (int)(u32)cur;
+        break;
+      }
+      slot = (slot + 1) & (u32)mask;
+    }
+    QTR_STAMP(STAMP_HALF_TABLES, 2)
+    if (rep < i) {  // the 33 values are compared before a row is hidden: a hash collision only costs a missed merge
+      u32 diff = 0;  // (no early exit: 33 independent loads instead of a chain of 33 round trips)
+#pragma unroll
+      for (int k = 0; k < 33; ++k) diff |= __float_as_uint(v[k]) ^ __float_as_uint(desc[(size_t)rep * 33 + k]);
+      hide = diff == 0;
+      if (hide) nbp = 1e30f;
+    }
+    QTR_STAMP(STAMP_HALF_TABLES, 3)
+  }
   if (bad) *unsafe = 1;
+  const u64 bal = __ballot(hide);
+  if (qk_lane() == 0 && bal) atomicAdd(hidden_count, __popcll(bal));
   _Float16 c[3];
   if (!(nbp < 65000.0f)) {
     c[0] = c[1] = c[2] = (_Float16)65504.f;
@@ -555,14 +616,16 @@ __device__ __forceinline__ void d_half_tables(const float* __restrict__ baseT, c
     ((h8*)queryH)[t0 + (size_t)ch * 32] = q8;
   }
 }
-// after k_desc_dedup (hidden rows already carry 1e30 in the norm row).  grid (pad_large_max / 256, 2, pairs)
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  __shared__ float s_rows[256 * 33];
   if (blockIdx.y == 0)
-    d_half_tables(V.baseT_i, V.norms_i, V.n_large, V.pad_large, V.baseH_i, V.queryH_i, V.mcounts + MC_UNSAFE);
+    d_half_tables(V.fpfh_i, V.n_large, V.pad_large, V.hash_i, V.table_i, V.dd_mask, V.mcounts + MC_HIDDEN_I, V.baseH_i, V.queryH_i,
+                  V.mcounts + MC_UNSAFE, s_rows);
   else
-    d_half_tables(V.baseT_j, V.norms_j, V.n_small, V.pad_small, V.baseH_j, V.queryH_j, V.mcounts + MC_UNSAFE);
+    d_half_tables(V.fpfh_j, V.n_small, V.pad_small, V.hash_j, V.table_j, V.dd_mask, V.mcounts + MC_HIDDEN_J, V.baseH_j, V.queryH_j,
+                  V.mcounts + MC_UNSAFE, s_rows);
 }
 
 // Same items, queue and partial records as k_nn_mfma.  Per wave: 4 x 32 stationary query columns (4 x 7 fragments of
@@ -582,6 +645,9 @@ __device__ unsigned long long g_nn_stamp[2][256][12];
   }
 extern "C" int qtr_debug_nn_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stamp), sizeof(g_nn_stamp));
+}
+extern "C" int qtr_debug_stamps(unsigned long long* out) {  // [QTR_STAMP_KERNELS][32][QTR_STAMP_POINTS][2]
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp));
 }
 #else
 #define NN_STAMP(i)
@@ -618,8 +684,21 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     int it1[4];  // tile of the best
     NN_STAMP(2)
     if (t_begin < t_end) {
-      nn_f16_core(D.queryH + (size_t)((qb * 4 + wave) * 4) * (NNH_CHUNKS * 32), D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32),
-                  t_end - t_begin, t_begin, ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
+      // where this lane's four query rows start in the query table (direction 1: the hit rows, looked up in place —
+      // a list of rows needs no gathered copy of the table); columns past the list take row 0, nobody reads their result
+      u32 qoff[4];
+      {
+        const int nq = V.mcounts[D.nq_slot];
+        const int* __restrict__ qmap = D.qmap;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int qi = qbase + 32 * c;
+          const int row = qmap ? ((qi < nq) ? qmap[qi] : 0) : qi;
+          qoff[c] = ((u32)((row >> 5) * NNH_CHUNKS + half) * 32u + (u32)(row & 31)) * 16u;
+        }
+      }
+      nn_f16_core(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
+                  ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
     NN_STAMP(3)
     } else {
 #pragma unroll
@@ -674,25 +753,34 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
   if ((int)blockIdx.x * NN_FIN_THREADS >= nq) return;
   const int t = blockIdx.x * NN_FIN_THREADS + threadIdx.x;
   const bool valid = t < nq;
+  QTR_STAMP(STAMP_NN_FINISH, 0)
   // the queries are visited in norm-bin order (direction 0: qorder; direction 1: the hit list is built in that order)
   // and the re-check list is appended in visiting order, one block of 512 queries at a time: the eight rows a re-check
   // workgroup shares then have overlapping spans of the base cloud
-  const int q = valid ? (D.qorder ? D.qorder[t] : t) : 0;
+  const int q = valid ? ((D.qorder && !f16) ? D.qorder[t] : t) : 0;  // (the f16 engine's re-check has no spans: plain order)
   const int nsplit = s_ns[blockIdx.z];
   float b1 = INFINITY, b2 = INFINITY;
   int i1 = -1;
   const NnPartial* __restrict__ partial = V.partial;
   if (valid)
-    for (int sidx = 0; sidx < nsplit; ++sidx) {
-      const NnPartial p = partial[(size_t)q * nsplit + sidx];
-      const bool take = (p.b1 < b1) || (p.b1 == b1 && p.i1 >= 0 && (i1 < 0 || p.i1 < i1));
-      const float nb2 = fminf(fminf(b2, p.b2), take ? b1 : p.b1);
-      b1 = take ? p.b1 : b1;
-      i1 = take ? p.i1 : i1;
-      b2 = nb2;
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {  // the records of eight slices per round trip
+      NnPartial pp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pp[k] = partial[(size_t)q * nsplit + min(s0 + k, nsplit - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (s0 + k < nsplit) {
+          const NnPartial p = pp[k];
+          const bool take = (p.b1 < b1) || (p.b1 == b1 && p.i1 >= 0 && (i1 < 0 || p.i1 < i1));
+          const float nb2 = fminf(fminf(b2, p.b2), take ? b1 : p.b1);
+          b1 = take ? p.b1 : b1;
+          i1 = take ? p.i1 : i1;
+          b2 = nb2;
+        }
     }
+  QTR_STAMP(STAMP_NN_FINISH, 1)
   const int row = valid ? (D.qmap ? D.qmap[q] : q) : 0;
-  const float na = valid ? D.qnorm[q] : 0.f;
+  const float na = valid ? D.qnorm[f16 ? row : q] : 0.f;  // (the f16 engine's query tables are the cloud's own: by row)
   const float nb1 = (i1 >= 0) ? D.bnorm[i1] : 0.f;
   const float u = 5.9604645e-08f;
   const float d1 = fmaxf(na + b1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
@@ -726,17 +814,21 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
     // merge found nothing
     const float thr = (i1 >= 0) ? b1 + u * (144.0f * na + 280.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
     V.recheck_thr[slot] = thr;
-    // columns of the norm-bin order that can hold the arg-min: |sqrt|b|^2 - sqrt|a|^2| <= sqrt(d) and d <= |a|^2~ + thr
-    // (+ the rounding slack of the bound above, norms rounded to float: 0.02 and 0.1 % cover both generously)
-    int lo = 0, hi = NORM_BINS - 1;
-    if (i1 >= 0) {
-      const float sa = sqrtf(fmaxf(na, 0.f)), R = sqrtf(fmaxf(na + thr, 0.f) + 1.0f) * 1.001f + 0.02f;
-      lo = max(0, (int)floorf(sa - R));
-      hi = min(NORM_BINS - 1, (int)floorf(sa + R));
+    if (f16) {
+      V.recheck_q[slot] = row;  // where k_recheck_filter finds the row's f16 query fragments (row of D.queryH)
+    } else {
+      // columns of the norm-bin order that can hold the arg-min: |sqrt|b|^2 - sqrt|a|^2| <= sqrt(d) and d <= |a|^2~ + thr
+      // (+ the rounding slack of the bound above, norms rounded to float: 0.02 and 0.1 % cover both generously)
+      int lo = 0, hi = NORM_BINS - 1;
+      if (i1 >= 0) {
+        const float sa = sqrtf(fmaxf(na, 0.f)), R = sqrtf(fmaxf(na + thr, 0.f) + 1.0f) * 1.001f + 0.02f;
+        lo = max(0, (int)floorf(sa - R));
+        hi = min(NORM_BINS - 1, (int)floorf(sa + R));
+      }
+      V.recheck_span[slot] = make_int2(D.bstart[lo], D.bstart[hi + 1]);
     }
-    V.recheck_span[slot] = make_int2(D.bstart[lo], D.bstart[hi + 1]);
-    if (f16) V.recheck_q[slot] = q;  // where k_recheck_filter finds the row's f16 query fragments (column of D.queryH)
   }
+  QTR_STAMP(STAMP_NN_FINISH, 2)
 }
 
 // Re-check of the listed rows (f16 engine): the matrix pipe again.  A listed row's exact arg-min is among the base rows
@@ -768,6 +860,7 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
+  QTR_STAMP(STAMP_RECHECK, 0)
   __shared__ int s_n;
   __shared__ int2 s_cand[RC_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -777,7 +870,7 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
   const int t0 = blockIdx.y * per, t1 = min(ntiles, t0 + per);
   const h8* __restrict__ baseH = (const h8*)D.baseH;
   const h8* __restrict__ queryH = (const h8*)D.queryH;
-  const int* __restrict__ qcol = V.recheck_q;  // listed row -> its column of the query table (k_nn_finish)
+  const int* __restrict__ qcol = V.recheck_q;  // listed row -> its row of the query table (k_nn_finish)
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
@@ -832,6 +925,7 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     };
     sweep(std::false_type{});
     __syncthreads();
+    QTR_STAMP(STAMP_RECHECK, 1)
     const int n = s_n;
     if (n <= RC_CAP) {
       // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
@@ -844,6 +938,7 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     } else {
       sweep(std::true_type{});  // (uniform: n is the workgroup's count)
     }
+    QTR_STAMP(STAMP_RECHECK, 2)
   }
 }
 
@@ -987,30 +1082,45 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
 
 // Rows of the larger cloud that the (final) first direction points at, in the cloud's NORM-BIN order (k_norm_bins): a
 // bit set in LDS (one workgroup per pair), then a scan over the bin-ordered rows.  (The order only matters to the
-// re-check of direction 1, whose listed rows then share spans; the cross-check reads the NN tables by row.)
+// span re-check of direction 1 (k_nn_exact_rows), whose listed rows then share spans; the cross-check reads the NN
+// tables by row.  bin_order = 0 — the f16 engine, whose re-check sweeps every tile — lists them by row.)
 // grid (1, 1, pairs), 1024 threads.
 template <bool EXT>
-__global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one) {
+__global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one, int bin_order) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ u32 hit_bits[];  // ceil(n_large / 32) words
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = V.n_large, nw = (n + 31) / 32;
+  const int n = V.n_large, nw = (n + 31) / 32, ns = V.n_small;
+  QTR_STAMP(STAMP_HIT_COMPACT, 0)
   for (int w = tid; w < nw; w += 1024) hit_bits[w] = 0u;
   __syncthreads();
-  for (int j = tid; j < V.n_small; j += 1024) {
-    const u64 b = V.best_small[j];
-    const int i = (b == ~0ULL) ? 0 : (int)(u32)b;
-    atomicOr(&hit_bits[i >> 5], 1u << (i & 31));
+  for (int j0 = tid; j0 < ns; j0 += 16 * 1024) {  // one workgroup, a latency chain: sixteen loads in flight per thread
+    u64 b[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = (j0 + q * 1024 < ns) ? V.best_small[j0 + q * 1024] : 0ULL;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (j0 + q * 1024 < ns) {
+        const int i = (b[q] == ~0ULL) ? 0 : (int)(u32)b[q];
+        atomicOr(&hit_bits[i >> 5], 1u << (i & 31));
+      }
   }
   __syncthreads();
-  // positions of the bin order are dealt in contiguous runs so that the output keeps that order
-  const int per = (n + 1023) / 1024;
-  const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
+  QTR_STAMP(STAMP_HIT_COMPACT, 1)
+  // positions (of the bin order, or plain rows: then whole words of the bit set) are dealt in contiguous runs so that
+  // the output keeps that order
+  const int items = bin_order ? n : nw;
+  const int per = (items + 1023) / 1024;
+  const int p0 = min(items, tid * per), p1 = min(items, p0 + per);
   int cnt = 0;
-  for (int p = p0; p < p1; ++p) {
-    const int r = V.nb_row_i[p];
-    cnt += (hit_bits[r >> 5] >> (r & 31)) & 1u;
+  if (bin_order) {
+    for (int p = p0; p < p1; ++p) {
+      const int r = V.nb_row_i[p];
+      cnt += (hit_bits[r >> 5] >> (r & 31)) & 1u;
+    }
+  } else {
+    for (int w = p0; w < p1; ++w) cnt += __popc(hit_bits[w]);
   }
   int tot;
   const int ex = wave_excl_scan_i32(cnt, &tot);
@@ -1022,11 +1132,22 @@ __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, Matc
     run += (w < wave) ? wsum[w] : 0;
     total += wsum[w];
   }
-  for (int p = p0; p < p1; ++p) {
-    const int r = V.nb_row_i[p];
-    if ((hit_bits[r >> 5] >> (r & 31)) & 1u) V.hit_rows[run++] = r;
+  if (bin_order) {
+    for (int p = p0; p < p1; ++p) {
+      const int r = V.nb_row_i[p];
+      if ((hit_bits[r >> 5] >> (r & 31)) & 1u) V.hit_rows[run++] = r;
+    }
+  } else {
+    for (int w = p0; w < p1; ++w) {
+      u32 bits = hit_bits[w];
+      while (bits) {
+        V.hit_rows[run++] = 32 * w + (__ffs((int)bits) - 1);
+        bits &= bits - 1;
+      }
+    }
   }
   if (tid == 0) V.mcounts[MC_NHIT] = total;
+  QTR_STAMP(STAMP_HIT_COMPACT, 2)
 }
 
 // query columns of the hit rows, gathered into a compact k-major table (pad columns: zeros with the constant-1 row,
@@ -1302,25 +1423,60 @@ __global__ __launch_bounds__(256) void k_nc_emit(ViewExt<MatchView> x, MatchView
 // without the three-launch (flags, scan, compact) round trips.
 // K6: unpack both NN tables, mutual-NN test, cross pairs in ascending i.
 template <bool EXT, int KMAX>
-__global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, MatchView one) {
+__global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, MatchView one, int lds_gather) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ int fl_s[];  // [n_large] nn index | keep flag << 31, staged with coalesced (striped) accesses
+                                 // (+ [n_small] with lds_gather: the smaller cloud's table, see below)
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_large = V.n_large, n_small = V.n_small;
-  for (int j = tid; j < n_small; j += 1024) {
-    const u64 b = V.best_small[j];
-    V.nn_of_small[j] = (b == ~0ULL) ? 0 : (int)(u32)b;
+  QTR_STAMP(STAMP_CROSS, 0)
+  // (one workgroup walks both clouds: sixteen rows per thread and round trip, or the loop is a chain of ~2 x n / 1024
+  // dependent memory latencies)
+  // The mutual test looks the smaller cloud's answer up at a random row for every row of the larger one: ~18 k gathers
+  // of 8 bytes issued by ONE compute unit cost 64 address cycles per wave instruction (8 us).  When both tables fit, the
+  // smaller cloud's is therefore staged in LDS with coalesced loads and the gather runs there.
+  int* nn_s = lds_gather ? fl_s + n_large : nullptr;
+  for (int j0 = tid; j0 < n_small; j0 += 16 * 1024) {
+    u64 b[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = (j0 + q * 1024 < n_small) ? V.best_small[j0 + q * 1024] : ~0ULL;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (j0 + q * 1024 < n_small) {
+        const int v = (b[q] == ~0ULL) ? 0 : (int)(u32)b[q];
+        V.nn_of_small[j0 + q * 1024] = v;
+        if (nn_s) nn_s[j0 + q * 1024] = v;
+      }
   }
-  for (int i = tid; i < n_large; i += 1024) {
-    const u64 b = V.best_large[i];
-    const int j = (b == ~0ULL) ? 0 : (int)(u32)b;
-    V.nn_of_large[i] = (b == ~0ULL) ? -1 : j;
-    const u64 bs = V.best_small[j];
-    const int back = (bs == ~0ULL) ? 0 : (int)(u32)bs;
-    fl_s[i] = j | ((b != ~0ULL && back == i) ? (int)0x80000000 : 0);
+  if (nn_s) __syncthreads();  // (uniform)
+  for (int i0 = tid; i0 < n_large; i0 += 16 * 1024) {
+    u64 b[16];
+    int back[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = (i0 + q * 1024 < n_large) ? V.best_large[i0 + q * 1024] : ~0ULL;
+    if (nn_s) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) back[q] = nn_s[(b[q] == ~0ULL) ? 0 : (int)(u32)b[q]];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const u64 bs = V.best_small[(b[q] == ~0ULL) ? 0 : (int)(u32)b[q]];
+        back[q] = (bs == ~0ULL) ? 0 : (int)(u32)bs;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = i0 + q * 1024;
+      if (i < n_large) {
+        const int j = (b[q] == ~0ULL) ? 0 : (int)(u32)b[q];
+        V.nn_of_large[i] = (b[q] == ~0ULL) ? -1 : j;
+        fl_s[i] = j | ((b[q] != ~0ULL && back[q] == i) ? (int)0x80000000 : 0);
+      }
+    }
   }
   __syncthreads();
+  QTR_STAMP(STAMP_CROSS, 1)
   const int K = (n_large + 1023) >> 10, base = tid * K;
   int jj[KMAX];
   u32 keep = 0;
@@ -1356,6 +1512,7 @@ __global__ __launch_bounds__(1024) void k_cross_fused(ViewExt<MatchView> x, Matc
       ++run;
     }
   if (tid == 0) V.mcounts[MC_NCROSS] = total;
+  QTR_STAMP(STAMP_CROSS, 2)
 }
 
 // K8 + gather: passed cross pairs -> tgt_of_src, compaction in source order, the matched keypoint clouds
@@ -1365,24 +1522,32 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   __shared__ int wsum[16];
   __shared__ int s_ntuple;
+  extern __shared__ int tg_s[];  // [ns]: target of every source index, or -1 (the map lives in LDS only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int swapped = V.swapped, ns = V.ns;
   if (tid == 0) s_ntuple = 0;
+  for (int i = tid; i < ns; i += 1024) tg_s[i] = -1;
   __syncthreads();
   const int nc = V.mcounts[MC_NCROSS];
   int local = 0;
-  for (int c = tid; c < nc; c += 1024)
-    if (V.passed[c]) {
-      const int i = V.cross_i[c], j = V.cross_j[c];
-      V.tgt_of_src[swapped ? j : i] = swapped ? i : j;
-      ++local;
+  for (int c0 = tid; c0 < nc; c0 += 8 * 1024) {  // (eight per thread and round trip, as in k_cross_fused)
+    int pf[8], ci[8], cj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = min(c0 + q * 1024, nc - 1);
+      pf[q] = (c0 + q * 1024 < nc) ? (int)V.passed[c] : 0;
+      ci[q] = V.cross_i[c];
+      cj[q] = V.cross_j[c];
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (pf[q]) {
+        tg_s[swapped ? cj[q] : ci[q]] = swapped ? ci[q] : cj[q];  // (a source index occurs at most once after the cross-check)
+        ++local;
+      }
+  }
   local = wave_sum_i32(local);
   if (lane == 0 && local) atomicAdd(&s_ntuple, local);
-  __threadfence_block();
-  __syncthreads();  // the scattered targets are visible to the whole workgroup
-  extern __shared__ int tg_s[];  // [ns] staged with coalesced (striped) loads
-  for (int i = tid; i < ns; i += 1024) tg_s[i] = V.tgt_of_src[i];
   __syncthreads();
   const int K = (ns + 1023) >> 10, base = tid * K;
   int tt[KMAX];
@@ -1547,8 +1712,9 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
   d1.nb_pad = V.pad_small;
   d1.queryT = F.queryT_c;
   d1.baseH = Cj.baseH;
-  d1.queryH = F.queryH_c;
-  d1.qnorm = F.norms_c;
+  // (the f16 engine reads the hit rows' fragments and norms in place, by row; the f32 MFMA engine a gathered copy)
+  d1.queryH = (F.nn_engine == 2) ? Ci.queryH : F.queryH_c;
+  d1.qnorm = (F.nn_engine == 2) ? Ci.norms : F.norms_c;
   d1.qmap = F.hit_rows;
   d1.nq_pad = V.pad_large;
   d1.A = Ci.fpfh;
@@ -1567,7 +1733,7 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
 // Enqueues the matcher for the pairs of `views` (G of them; one travels in the kernel arguments).  ev: optional
 // brackets of the two k_nn_mfma launches (single pair only).
 static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int n_cu, ViewStage* stage,
-                               hipStream_t st, hipEvent_t const* ev) {
+                               hipStream_t st, hipEvent_t const* ev, bool init_done = false) {
   MatchArgs a;
   a.one = views[0];
   a.ext = nullptr;
@@ -1585,7 +1751,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     any_tuple = any_tuple || views[g].tuple;
   }
   const dim3 B256(256);
-  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st);
+  if (!init_done) LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st);
   // K5: NN of every small-cloud descriptor in the large cloud, then of the HIT rows of the large cloud in the small
   // one (the reference asks the latter lazily, feature_matcher.cc:113-122; the mutual test only reads hit rows)
   if (nn_engine == 0) {
@@ -1603,17 +1769,20 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     if (ev && ev[0]) (void)hipEventRecord(ev[0], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, 0);
     if (ev && ev[1]) (void)hipEventRecord(ev[1], st);
-    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, 1);
     if (ev && ev[2]) (void)hipEventRecord(ev[2], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, 1);
     if (ev && ev[3]) (void)hipEventRecord(ev[3], st);
   } else {
-    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, nn_engine == 2 ? 0 : 1);
-    LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
-    LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
-    LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     const bool f16 = nn_engine == 2;
-    if (f16) LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, f16 ? 0 : 2);
+    if (f16) {  // operand tables with the duplicates hidden, straight from the descriptors
+      LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+    } else {  // the norm-bin order serves the span re-check (k_nn_exact_rows); the f16 engine's filter sweeps every tile
+      LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
+      LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
+      LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
+    }
     // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second).
     // QTR_NN_WGS_PER_CU = 2 (experiment knob) launches both from this chain.
     static const int wgs_per_cu = [] {
@@ -1639,8 +1808,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       if (!f16) LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);  // (the f16 engine's filter is complete)
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st);
-    LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st, f16 ? 0 : 1);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, f16 ? 0 : 1);
+    if (!f16) LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st, 1);  // (f16: the rows are read in place)
     run_dir(1, max_large, max_small, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
@@ -1652,8 +1821,11 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
     LAUNCH_MV(k_nc_list, a, dim3(grid_for(max_large + max_small), 1, G), B256, 0, st);
   } else if (fused_tail) {
-    if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
-    else LAUNCH_MV_K(k_cross_fused, 32, a, dim3(1, 1, G), dim3(1024), (size_t)max_large * 4, st);
+    // (both nearest-neighbour tables in LDS when they fit: see the kernel)
+    const int lds_gather = ((size_t)max_large + (size_t)max_small) * 4 <= (size_t)CROSS_LDS_BYTES ? 1 : 0;
+    const size_t cross_lds = (size_t)max_large * 4 + (lds_gather ? (size_t)max_small * 4 : 0);
+    if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
+    else LAUNCH_MV_K(k_cross_fused, 32, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
   } else {
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -1681,13 +1853,21 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   return hipGetLastError();
 }
 
-hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
+hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
+  (void)hipGetLastError();
+  MatchArgs a;
+  a.one = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
+  a.ext = nullptr;
+  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(a.one.n_large, a.one.dd_mask + 1)), 1, 1), dim3(256), 0, st);
+  return hipGetLastError();
+}
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done) {
   (void)hipGetLastError();
   const MatchView V = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
   const bool fused_tail = V.crosscheck && V.n_large <= 32768 && ns <= 32768;
   F.gathered = fused_tail && F.m_src != nullptr;
   const bool evs = F.nn_events != 0;
-  return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr);
+  return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr, init_done);
 }
 
 hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
@@ -1712,15 +1892,19 @@ hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_
   return hipGetLastError();
 }
 
-// the 32-per-thread fused tails stage up to 32768 ints (128 KB) in dynamic LDS
+// the 32-per-thread fused tails stage up to 32768 ints (128 KB) in dynamic LDS; k_cross_fused (either variant) up to
+// CROSS_LDS_BYTES when both nearest-neighbour tables fit
 hipError_t match_init_attributes() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute((const void*)k_cross_fused<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)k_cross_fused<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)k_cross_fused<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)k_cross_fused<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
 #define SET_LDS2(kern)                                                                                                   \
   if ((e = hipFuncSetAttribute((const void*)kern<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess) \
     return e;                                                                                                            \
   if ((e = hipFuncSetAttribute((const void*)kern<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess)  \
     return e;
-  SET_LDS2(k_cross_fused)
   SET_LDS2(k_pairs_fused)
 #undef SET_LDS2
   return hipSuccess;

@@ -61,8 +61,11 @@ struct SolverArgs {
 
 size_t solver_scratch_bytes(int Lcap);
 void solver_carve(SolverBufs& B, void* base, int Lcap);
+// reset_done: solver_reset_enqueue already cleared the state for this run (on another stream, off the critical path)
 hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                          hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique);
+                          hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique,
+                          bool reset_done = false);
+hipError_t solver_reset_enqueue(const SolverBufs& B, hipStream_t stream);
 hipError_t solver_init_attributes();
 // the same for G pairs at once (qtr_submit_batch): B[g] is pair g's arena, views go through `stage`
 hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,

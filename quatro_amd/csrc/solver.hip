@@ -1956,14 +1956,14 @@ hipError_t clique_only_finish(const SolverBufs& B, int L, hipStream_t stream) {
 // The whole back end of the G pairs of `views` on `stream` (L known on the host).  The clique heuristic normally
 // terminates after the first two batches (see k_clique_batch); the host checks `done` with the result record.
 static hipError_t solver_launch(const SolverView* views, int G, const qtr_params& prm, ViewStage* stage,
-                                hipStream_t stream, hipEvent_t ev_graph, hipEvent_t ev_clique) {
+                                hipStream_t stream, hipEvent_t ev_graph, hipEvent_t ev_clique, bool reset_done = false) {
   hipError_t e;
   (void)hipGetLastError();  // a stale sticky error (e.g. timing query on an unrecorded event) is not ours
   SolverArgs a;
   if ((e = solver_args(a, views, G, stage, stream)) != hipSuccess) return e;
   int L = 0;
   for (int g = 0; g < G; ++g) L = max(L, views[g].L);
-  LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
+  if (!reset_done) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
@@ -1977,10 +1977,20 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
 }
 
 hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                          hipStream_t stream, int* pinned_state /* unused */, hipEvent_t ev_graph, hipEvent_t ev_clique) {
+                          hipStream_t stream, int* pinned_state /* unused */, hipEvent_t ev_graph, hipEvent_t ev_clique,
+                          bool reset_done) {
   (void)pinned_state;
   const SolverView V = make_solver_view(B, src, tgt, L);
-  return solver_launch(&V, 1, prm, nullptr, stream, ev_graph, ev_clique);
+  return solver_launch(&V, 1, prm, nullptr, stream, ev_graph, ev_clique, reset_done);
+}
+// the state reset of a run, for callers that can issue it early (the whole-path driver: beside the FPFH chain)
+__global__ void k_state_reset(SolverState* st) {
+  int* p = (int*)st;
+  if (threadIdx.x < (int)(sizeof(SolverState) / 4)) p[threadIdx.x] = 0;
+}
+hipError_t solver_reset_enqueue(const SolverBufs& B, hipStream_t stream) {
+  hipLaunchKernelGGL(k_state_reset, dim3(1), dim3(64), 0, stream, B.st);
+  return hipGetLastError();
 }
 
 hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,

@@ -61,3 +61,21 @@ for d in range(2):
     for i in range(4):
         dc = clk[:, i + 1] - clk[:, i]
         print("  %-16s -> %-16s clocks: median %8.0f  max %8.0f" % (names[i], names[i + 1], np.median(dc), dc.max()))
+
+# ---- the generic stamps (common.h QTR_STAMP): last launch of each instrumented kernel
+KERNELS = ["desc_prep", "half_tables", "radix_scatter (raw cloud, middle pass)", "recheck_filter", "vox_centroids", "hit_compact",
+           "cross_fused", "nn_finish", "neighbors", "spfh", "fpfh", "finalize"]
+g = np.zeros((12, 32, 8, 2), dtype=np.uint64)
+rc = lib.qtr_debug_stamps(C.c_void_p(g.ctypes.data))
+assert rc == 0, rc
+g = g.astype(np.int64)
+for k, name in enumerate(KERNELS):
+    pts = [p for p in range(8) if (g[k, :, p, 1] > 0).any()]
+    if not pts:
+        continue
+    blocks = [b for b in range(32) if g[k, b, pts[0], 1] > 0]
+    t0 = min(g[k, b, pts[0], 1] for b in blocks)
+    print("%s: %d workgroups stamped" % (name, len(blocks)))
+    for p in pts:
+        us = np.array([(g[k, b, p, 1] - t0) / 100.0 for b in blocks if g[k, b, p, 1] > 0])
+        print("  point %d: us since first entry  min %7.2f  median %7.2f  max %7.2f   (%d)" % (p, us.min(), np.median(us), us.max(), len(us)))
