@@ -25,7 +25,7 @@ __device__ unsigned long long g_stamp[QTR_STAMP_KERNELS][32][QTR_STAMP_POINTS][2
 #define QTR_STAMP(kid, pt)
 #endif
 enum { STAMP_DESC_PREP = 0, STAMP_HALF_TABLES, STAMP_SCATTER, STAMP_RECHECK, STAMP_CENTROIDS, STAMP_HIT_COMPACT, STAMP_CROSS,
-       STAMP_NN_FINISH, STAMP_NEIGHBORS, STAMP_SPFH, STAMP_FPFH, STAMP_FINALIZE };
+       STAMP_NN_FINISH, STAMP_RECHECK1, STAMP_SPFH, STAMP_FPFH, STAMP_FINALIZE };
 
 
 #define QK_WAVE 64

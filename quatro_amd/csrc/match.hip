@@ -337,13 +337,14 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
 // structs must not travel by reference (see ViewExt).
 #define NN_MAXG 64
 #define NN_PLAN(G_, dir_, X_)                                                                                   \
-  __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG];                                             \
+  __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG], s_nq[NN_MAXG];                              \
   if (threadIdx.x < 64) {                                                                                       \
     const int g_ = threadIdx.x;                                                                                 \
-    int qb_ = 0, nt_ = 1;                                                                                       \
+    int qb_ = 0, nt_ = 1, nq_ = 0;                                                                              \
     if (g_ < (G_)) {                                                                                            \
       const MatchView& P_ = EXT ? x.ext[g_] : one;                                                              \
-      qb_ = (P_.mcounts[P_.d[dir_].nq_slot] + NN_QPB - 1) / NN_QPB;                                             \
+      nq_ = P_.mcounts[P_.d[dir_].nq_slot];                                                                     \
+      qb_ = (nq_ + NN_QPB - 1) / NN_QPB;                                                                        \
       nt_ = P_.d[dir_].nb_pad / 32;                                                                             \
     }                                                                                                           \
     const int S_ = wave_sum_i32(qb_), W_ = wave_sum_i32(qb_ * nt_);                                             \
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
       s_off[g_] = ex_;                                                                                          \
       s_ns[g_] = sp_;                                                                                           \
       s_tps[g_] = tps_;                                                                                         \
+      s_nq[g_] = nq_;                                                                                           \
     }                                                                                                           \
     if (g_ == 0) s_off[(G_)] = tot_;                                                                            \
   }                                                                                                             \
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
       // a list of rows needs no gathered copy of the table); columns past the list take row 0, nobody reads their result
       u32 qoff[4];
       {
-        const int nq = V.mcounts[D.nq_slot];
+        const int nq = s_nq[g];  // (the plan read it)
         const int* __restrict__ qmap = D.qmap;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -855,12 +857,13 @@ __device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, 
   if (result == result) atomicMin(best, ((u64)__float_as_uint(result) << 32) | (u32)base_row);  // (NaN never wins)
 }
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
+__global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
   const int nrows = V.mcounts[D.rc_slot];
   if (nrows <= 0) return;
-  QTR_STAMP(STAMP_RECHECK, 0)
+#define RC_STAMP(pt) if (dir == 0) { QTR_STAMP(STAMP_RECHECK, pt) } else { QTR_STAMP(STAMP_RECHECK1, pt) }
+  RC_STAMP(0)
   __shared__ int s_n;
   __shared__ int2 s_cand[RC_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     __syncthreads();
     const int qtile = qg * 4 + wave;
     const int slot = qtile * 32 + col;
-    h8 q[7], m0[7], m1[7];
+    h8 q[7], m0[7], m1[7], m2[7];
     {
       const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is buffered)
 #pragma unroll
@@ -891,41 +894,57 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     const float thr = live ? V.recheck_thr[slot] * (NNH_S * NNH_S) : 0.f;
     const int my_row = live ? V.recheck_rows[slot] : 0;
     auto load = [&](h8 (&m)[7], int t) __attribute__((always_inline)) {
+      t = min(t, ntiles + 1);  // (the table is padded by two tiles: running ahead of the slice is harmless)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];  // (padded: t1 may be read)
+      for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];
     };
     auto tile = [&](const h8 (&m)[7], int t, auto direct_tag) __attribute__((always_inline)) {
       constexpr bool direct = decltype(direct_tag)::value;  // (two specialised copies: no run-time flag in the hot loop)
       f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
+      // which of the lane's 16 entries pass (two or three per listed row over the whole sweep): sixteen compares into a
+      // mask and ONE branch, instead of a compare and a branch per entry
+      u32 pass = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (live && !(acc[r] > thr)) {
-          const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-          if (direct) {
-            if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
-          } else {
-            const int pos = atomicAdd(&s_n, 1);
-            if (pos < RC_CAP) s_cand[pos] = make_int2(slot, brow);
-          }
+      for (int r = 0; r < 16; ++r) pass |= !(acc[r] > thr) ? (1u << r) : 0u;
+      if (!live) pass = 0;
+      while (pass) {
+        const int r = __ffs((int)pass) - 1;
+        pass &= pass - 1;
+        const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (direct) {
+          if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
+        } else {
+          const int pos = atomicAdd(&s_n, 1);
+          if (pos < RC_CAP) s_cand[pos] = make_int2(slot, brow);
         }
       }
     };
+    // three tiles in flight: a workgroup's slice is a handful of tiles and every one of them is an L2 round trip
     auto sweep = [&](auto direct) __attribute__((always_inline)) {
-      if (t0 < t1) load(m0, t0);
-      for (int t = t0; t < t1; t += 2) {
-        load(m1, t + 1);
+      if (t0 < t1) {
+        load(m0, t0);
+        load(m1, t0 + 1);
+      }
+      for (int t = t0; t < t1; t += 3) {
+        load(m2, t + 2);
         tile(m0, t, direct);
         if (t + 1 < t1) {
-          load(m0, t + 2);
+          load(m0, t + 3);
           tile(m1, t + 1, direct);
+        }
+        if (t + 2 < t1) {
+          load(m1, t + 4);
+          tile(m2, t + 2, direct);
         }
       }
     };
+    RC_STAMP(1)
     sweep(std::false_type{});
+    RC_STAMP(2)
     __syncthreads();
-    QTR_STAMP(STAMP_RECHECK, 1)
+    RC_STAMP(3)
     const int n = s_n;
     if (n <= RC_CAP) {
       // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
@@ -938,8 +957,9 @@ __global__ __launch_bounds__(256) void k_recheck_filter(ViewExt<MatchView> x, Ma
     } else {
       sweep(std::true_type{});  // (uniform: n is the workgroup's count)
     }
-    QTR_STAMP(STAMP_RECHECK, 2)
+    RC_STAMP(4)
   }
+#undef RC_STAMP
 }
 
 // exact re-decision of the listed rows (list length read on the device).  A workgroup takes EIGHT listed rows at a
@@ -1797,7 +1817,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       if (e1) (void)hipEventRecord(e1, st);
       LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
                 G, f16 ? 800.0f : 0.0f, f16 ? 1 : 0);
-      if (f16) LAUNCH_MV(k_recheck_filter, a, dim3(8, G > 1 ? 16 : 96, G), B256, 0, st, dir);
+      // (single pair: 8 x 64 workgroups = the 512 the device holds at two per compute unit — one round)
+      if (f16) LAUNCH_MV(k_recheck_filter, a, dim3(8, G > 1 ? 16 : 64, G), B256, 0, st, dir);
       // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
       (void)nb_max;
       // (most spans are a fraction of a per cent of the cloud, a few cover half of it: enough slices that the widest

@@ -63,8 +63,8 @@ for d in range(2):
         print("  %-16s -> %-16s clocks: median %8.0f  max %8.0f" % (names[i], names[i + 1], np.median(dc), dc.max()))
 
 # ---- the generic stamps (common.h QTR_STAMP): last launch of each instrumented kernel
-KERNELS = ["desc_prep", "half_tables", "radix_scatter (raw cloud, middle pass)", "recheck_filter", "vox_centroids", "hit_compact",
-           "cross_fused", "nn_finish", "neighbors", "spfh", "fpfh", "finalize"]
+KERNELS = ["desc_prep", "half_tables", "radix_scatter (raw cloud, middle pass)", "recheck_filter direction 0", "vox_centroids", "hit_compact",
+           "cross_fused", "nn_finish", "recheck_filter direction 1", "spfh", "fpfh", "finalize"]
 g = np.zeros((12, 32, 8, 2), dtype=np.uint64)
 rc = lib.qtr_debug_stamps(C.c_void_p(g.ctypes.data))
 assert rc == 0, rc
