@@ -1316,15 +1316,38 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   {
     const float4* raws[2] = {d_s, d_t};
     const int Ps2[2] = {Ps, Pt};
-    s.fb.mail_seq = ++s.seq;
-    QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream));
-    // block 0 of k2_vox_centroids publishes the counters while other blocks are still writing centroids: anything
-    // that reads the centroids from another stream has to wait for the kernel itself
-    QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
+    // The voxel sort needs ceil(bits / 8) radix passes, bits = significant bits of the grid's cell index — known on the
+    // device only.  A launch that returns at once still costs ~5 us on this chain, so the driver launches what the
+    // previous pair on this slot needed (3 for a lidar scan at 0.3 m) and checks: if this pair needs more, the stage
+    // runs again with enough (first call on a slot: 4, which always suffices).
+    for (int attempt = 0;; ++attempt) {
+      const int launched = s.fb.vox_passes;
+      s.fb.mail_seq = ++s.seq;
+      QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream, launched));
+      // block 0 of k2_vox_centroids publishes the counters while other blocks are still writing centroids: anything
+      // that reads the centroids from another stream has to wait for the kernel itself
+      QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
+      // k2_vox_centroids leaves both clouds' counters in the mailbox
+      if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
+        return res->status = rc;
+      const int bits = std::max(s.mail[MAIL_VOX0 + CNT_SORT_BITS], s.mail[MAIL_VOX1 + CNT_SORT_BITS]);
+      const int needed = std::min(4, std::max(1, (bits + 7) / 8));
+      if (needed > launched && attempt == 0) {  // under-launched: the centroids are garbage, run the stage again
+        s.fb.vox_passes = 4;
+        s.fb.vox_fewer = 0;
+        continue;
+      }
+      if (needed < launched) {  // step down only after a run of calls that agree (alternating scenes would thrash)
+        if (++s.fb.vox_fewer >= 4) {
+          s.fb.vox_passes = needed;
+          s.fb.vox_fewer = 0;
+        }
+      } else {
+        s.fb.vox_fewer = 0;
+      }
+      break;
+    }
   }
-  // k2_vox_centroids leaves both clouds' counters in the mailbox
-  if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
-    return res->status = rc;
   int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
   if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");

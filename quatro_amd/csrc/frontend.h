@@ -185,6 +185,8 @@ struct FrontBufs {
   float4* m_src = nullptr;     // where the matcher's last kernel should leave the matched keypoint clouds (or null)
   float4* m_tgt = nullptr;
   int m_cap = 0;               // capacity of m_src / m_tgt in points (the handle's max_corr)
+  int vox_passes = 4;          // whole-path driver: radix passes the voxel sort needed last time (speculation, see capi.hip)
+  int vox_fewer = 0;           // ... and for how many calls in a row fewer would have done
   bool gathered = false;       // set by match_enqueue when it did
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 2;           // 2 = f16-split MFMA filter + exact re-check (default), 1 = f32 MFMA + exact re-check
@@ -200,7 +202,12 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels);
 void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels);
 hipError_t frontend_init_attributes();
 
-hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st);
+// passes: radix passes of the voxel sort to launch.  The keys' significant bits (CNT_SORT_BITS, in the mailbox with the
+// voxel counts) are only known on the device: a caller that launches fewer than 4 must check them afterwards and run the
+// stage again with enough passes when ceil(bits / 8) exceeds what it launched (the output is then unsorted garbage inside
+// its bounds)
+hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st,
+                            int passes = 4);
 hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st);
 // origin_known: the clouds are the voxel centroids voxelize_enqueue just produced in the same CloudBufs (its bounding box
 // is still there and serves as the neighbour grid's origin)

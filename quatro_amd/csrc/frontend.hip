@@ -1210,13 +1210,13 @@ __device__ __forceinline__ int sorted_src(const CloudView& C, int passes, int ad
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_headcount(ViewExt<CloudView> x, Clouds2 a, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  if (src < 0) src = sorted_src(C, 4, 1);
+  if (src < 0) src = sorted_src(C, -src, 1);  // (-src = passes launched)
   d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  if (src < 0) src = sorted_src(C, 4, 1);
+  if (src < 0) src = sorted_src(C, -src, 1);
   d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkcnt, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
                   C.mail_seq_slot, C.seq);
 }
@@ -1331,7 +1331,8 @@ static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, V
 
 // stable LSD radix sort of keys_a by bits [32, 32+key_bits); returns which buffer holds the result (0: keys_a)
 // adaptive: the keys' significant bits are in counts[CNT_SORT_BITS]; passes above them return at once and the result's
-// buffer is only known on the device (the return value is then -1: consumers call sorted_src())
+// buffer is only known on the device (the return value is then minus the number of passes launched: consumers call
+// sorted_src())
 static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false, bool make_keys = false,
                        float side = 0.f, int mm_parts = 0) {
   const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
@@ -1342,22 +1343,25 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
   LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side, mm_parts);
   for (int p = 0; p < passes; ++p)
     LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
-  return adaptive ? -1 : (passes & 1);
+  return adaptive ? -passes : (passes & 1);
 }
 
-static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st) {
+// passes: radix passes to launch (4 covers every grid pcl::VoxelGrid accepts; a grid below 2^24 cells needs 3 — see
+// voxelize_enqueue)
+static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st, int passes = 4) {
   const int nc = S.nc;
   const int g = min(1024, (S.maxP + 255) / 256);
   const int mm_parts = max(1, min(g, MM_MAX_PARTS));
   LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 0, 1);
-  const int where = radix_sort2(S, 0, 32, st, true, true, leaf, mm_parts);  // the fourth pass only runs for grids of more than 2^24 voxels
+  const int where = radix_sort2(S, 0, 8 * passes, st, true, true, leaf, mm_parts);  // (a pass above the keys' bits returns at once)
   const int nblk = (S.maxP + 1023) / 1024;
   LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
 // voxel-grid down-sampling of nc (1 or 2) raw clouds
-hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st) {
+hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st,
+                            int passes) {
   (void)hipGetLastError();
   CloudView v[2];
   for (int c = 0; c < nc; ++c) {
@@ -1368,7 +1372,7 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  voxelize_launch(S, leaf, F.max_voxels, st);
+  voxelize_launch(S, leaf, F.max_voxels, st, min(4, max(1, passes)));
   return hipGetLastError();
 }
 

@@ -1588,6 +1588,9 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
     run += (w < wave) ? wsum[w] : 0;
     total += wsum[w];
   }
+  // the counters go to the host as soon as they are known: it enqueues the solver's launches (stream-ordered behind
+  // this kernel) while the list below is still being written
+  if (V.mail && tid < 48) match_mail(V, tid, total, s_ntuple);
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
     if (tt[k] >= 0) {
@@ -1606,7 +1609,6 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
     V.mcounts[MC_NCORR] = total;
     V.mcounts[MC_NTUPLE] = s_ntuple;
   }
-  if (V.mail && tid < 48) match_mail(V, tid, total, s_ntuple);
 }
 
 __global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __restrict__ vt,

@@ -1206,6 +1206,29 @@ def test_phase_counters_are_never_stale_across_calls(hip, qo):
 
 
 @pytest.mark.gpu
+def test_voxel_sort_pass_speculation_recovers(hip, qo):
+    """The whole-path driver launches as many radix passes for the voxel sort as the previous pair on the slot needed
+    (qtr_register_pair, capi.hip) and runs the stage again when a pair needs more.  A scan pair on a grid below 2^24
+    cells (3 passes) is registered until the driver has stepped down, then the same pair with two far outliers that
+    stretch the grid past 2^24 cells (4 passes), then the first one again: every record equals the oracle's."""
+    S, T, _ = synth.kitti64_pair(0)
+    rng = np.random.default_rng(5)
+    keep = rng.random(S.shape[0]) < 0.25
+    S, T = S[keep], T[rng.random(T.shape[0]) < 0.25]
+    far = np.array([[900.0, -900.0, 3.0, 0.0], [-900.0, 900.0, -2.0, 0.0]], dtype=np.float32)
+    Sw, Tw = np.concatenate([S, far]), np.concatenate([T, far])
+    span = Sw[:, :3].max(0) - Sw[:, :3].min(0)
+    assert np.prod(np.floor(span / 0.3) + 1) > 2 ** 24 > np.prod(np.floor((S[:, :3].max(0) - S[:, :3].min(0)) / 0.3) + 1)
+    fp = ql.default_frontend_params(seed=11)
+    o_narrow, o_wide = qo.register_pair(S, T, seed=11), qo.register_pair(Sw, Tw, seed=11)
+    for _ in range(7):  # (the driver steps down after four calls that needed fewer passes than it launched)
+        _assert_same_solution(hip.register_pair(S, T, fp), o_narrow)
+    for _ in range(2):
+        _assert_same_solution(hip.register_pair(Sw, Tw, fp), o_wide)
+        _assert_same_solution(hip.register_pair(S, T, fp), o_narrow)
+
+
+@pytest.mark.gpu
 def test_randomised_sweep_against_oracle():
     """Ten seconds of tests/gpu_fuzz.py (random solver / clique / pair / raw-scan stage / stand-alone stage cases against
     the oracle) in its own process; any mismatch fails."""
