@@ -874,7 +874,34 @@ __device__ __forceinline__ int bin11(double x) {
   if (fl >= 11.0) return 10;
   return (int)fl;
 }
-__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f) {
+// Bin of the first SPFH feature, bin11(11 (atan2f(y, x) + pi) d_pi) with d_pi = float(1 / (2 float(pi))), without the
+// arc tangent (four binary64 divisions, three square roots and a series): the bin changes at ten angles beta_k =
+// k / (11 d_pi) - pi, and which side of beta_k the direction (x, y) lies on is the sign of y cos(beta_k) - x sin(beta_k)
+// = r sin(theta - beta_k) — five of them for the half plane y is in.  The float result of atan2f is within 1.3e-7 of
+// theta and the bin arithmetic adds 1e-15, so whenever every |sin(theta - beta_k)| exceeds 1e-6 the count of boundaries
+// below theta IS the bin the reference arithmetic produces; the sliver in between (3e-6 of all directions), y = 0 and
+// non-finite input evaluate qm_atan2f as before.
+__device__ __forceinline__ int spfh_bin0(float yf, float xf, float d_pi) {
+  const double y = (double)yf, x = (double)xf;
+  const double m = 1e-6 * (fabs(x) + fabs(y));
+  if (yf != 0.f && m < (double)INFINITY) {  // (NaN fails the second test)
+    const bool up = y > 0;
+    // cos / sin of beta_6..beta_10 (y > 0: theta in (0, pi)) or beta_1..beta_5 (y < 0: theta in (-pi, 0))
+    const double c0 = up ? 0.9594929346621472 : -0.8412535203730152, s0 = up ? 0.2817326895009176 : -0.5406408368408818;
+    const double c1 = up ? 0.6548606120403585 : -0.41541497107998193, s1 = up ? 0.7557496799854613 : -0.9096320144996095;
+    const double c2 = up ? 0.14231465580301056 : 0.14231490669963703, s2 = up ? 0.9898214681161803 : -0.9898214320427062;
+    const double c3 = up ? -0.41541520165044565 : 0.6548608036052355, s3 = up ? 0.9096319092015844 : -0.755749513993562;
+    const double c4 = up ? -0.8412536574128168 : 0.9594930060747751, s4 = up ? 0.5406406236027397 : -0.2817324462918526;
+    const double r0 = y * c0 - x * s0, r1 = y * c1 - x * s1, r2 = y * c2 - x * s2, r3 = y * c3 - x * s3, r4 = y * c4 - x * s4;
+    const bool sure = fabs(r0) > m && fabs(r1) > m && fabs(r2) > m && fabs(r3) > m && fabs(r4) > m;
+    if (sure) return (up ? 5 : 0) + (r0 > 0) + (r1 > 0) + (r2 > 0) + (r3 > 0) + (r4 > 0);
+  }
+  const float f0 = qm_atan2f(yf, xf);
+  return bin11(11 * (((double)f0 + M_PI) * (double)d_pi));
+}
+// f[1], f[2] and the bin of f[0] (see spfh_bin0)
+__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f, int* bin0,
+                                  float d_pi) {
   float dp[3] = {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
   const float f4 = sqrtf(dot4_sse(dp, dp));
   if (f4 == 0.0f) return false;
@@ -882,7 +909,20 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   const float angle1 = dot4_sse(n1c, dp) / f4;
   const float angle2 = dot4_sse(n2c, dp) / f4;
   float f3;
-  if (qm_acosf(fabsf(angle1)) > qm_acosf(fabsf(angle2))) {
+  // The role swap asks whether acosf(|angle1|) > acosf(|angle2|) — two binary64 arc cosines (five divisions and four
+  // square roots each) for one bit.  acos falls with slope <= -1 on [0, 1]: arguments more than 5e-7 apart give values
+  // more than 5e-7 apart, four float ulps of a result below pi/2, so the rounded results are ordered like the arguments
+  // are (reversed); equal arguments give equal results.  Only the sliver in between (and arguments above 1 or NaN, where
+  // acosf is NaN) evaluates the functions — the answer is the same bit either way.
+  const float x1 = fabsf(angle1), x2 = fabsf(angle2);
+  bool swap_roles;
+  if (x1 == x2)
+    swap_roles = false;
+  else if (x1 <= 1.0f && x2 <= 1.0f && fabsf(x1 - x2) > 5e-7f)
+    swap_roles = x1 < x2;
+  else
+    swap_roles = qm_acosf(x1) > qm_acosf(x2);
+  if (swap_roles) {
     n1c[0] = nn2.x;
     n1c[1] = nn2.y;
     n1c[2] = nn2.z;
@@ -905,7 +945,7 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   float w[3];
   dev_cross(n1c, v, w);
   f[1] = dot4_sse(v, n2c);
-  f[0] = qm_atan2f(dot4_sse(w, n2c), dot4_sse(n1c, n2c));
+  *bin0 = spfh_bin0(dot4_sse(w, n2c), dot4_sse(n1c, n2c), d_pi);
   f[2] = f3;
   return true;
 }
@@ -952,8 +992,9 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
     const int j = nbr_idx[(size_t)i * QTR_KMAX + (t - s_off[pi])];
     if (j == i) continue;
     float f[3];
-    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f)) continue;
-    atomicAdd(&cnt[pi][bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))], 1);
+    int bin0;
+    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f, &bin0, d_pi)) continue;
+    atomicAdd(&cnt[pi][bin0], 1);
     atomicAdd(&cnt[pi][11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))], 1);
     atomicAdd(&cnt[pi][22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))], 1);
   }
