@@ -1522,15 +1522,19 @@ struct qo_result {
 void qo_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
 
 // host evaluation of include/qtr_math.h (pins host/device bit-equality in tests):
-// fn 0 atan2f(a,b), 1 acosf(a), 2 sinf(a), 3 cosf(a)
+// fn 0 atan2f(a,b), 1 acosf(a), 2 sinf(a), 3 cosf(a); 4 the SPFH bin of atan2f(a,b); 5 the role-swap decision
+// acosf(|a|) > acosf(|b|) exactly as the pair-feature code evaluates it (the device has a shortcut for it)
 void qo_math(int fn, const float* a, const float* b, float* out, int n) {
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
   for (int i = 0; i < n; ++i) {
     float s, c;
     switch (fn) {
       case 0: out[i] = qm_atan2f(a[i], b[i]); break;
       case 1: out[i] = qm_acosf(a[i]); break;
       case 2: qm_sincosf(a[i], &s, &c); out[i] = s; break;
-      default: qm_sincosf(a[i], &s, &c); out[i] = c; break;
+      case 3: qm_sincosf(a[i], &s, &c); out[i] = c; break;
+      case 4: out[i] = (float)bin11(11 * (((double)qm_atan2f(a[i], b[i]) + M_PI) * (double)d_pi)); break;
+      default: out[i] = (qm_acosf(fabsf(a[i])) > qm_acosf(fabsf(b[i]))) ? 1.f : 0.f; break;
     }
   }
 }

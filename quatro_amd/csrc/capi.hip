@@ -1770,6 +1770,8 @@ __global__ void k_debug_math(int fn, const float* a, const float* b, float* out,
     case 1: r = qm_acosf(a[i]); break;
     case 2: qm_sincosf(a[i], &s, &c); r = s; break;
     case 3: qm_sincosf(a[i], &s, &c); r = c; break;
+    case 5: r = spfh_swap_roles(a[i], b[i]) ? 1.f : 0.f; break;  // the SPFH kernel's shortcut (tests compare it with the
+                                                                 // plain arithmetic)
     default: break;
   }
   out[i] = r;

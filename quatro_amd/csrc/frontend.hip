@@ -641,6 +641,9 @@ __device__ __forceinline__ void d_neighbors(const float4* __restrict__ pts, int 
   const int total = pre[9];
   int k = 0;
   bool overflow = false;
+  // (candidates chunk by chunk: batching four chunks per round trip does not pay here — 32 single-wave workgroups per
+  // compute unit already cover each other's latency; the same change made k2_spfh slower, k2_normals — half a wave per
+  // SIMD — faster)
   for (int c0 = 0; c0 < total; c0 += 64) {
     const int c = c0 + lane;
     bool ok = false;
@@ -836,27 +839,54 @@ __device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n,
   const int kf = nbr_cnt[i];
   const int* idx = nbr_idx + (size_t)i * QTR_KMAX;
   const float* d2 = nbr_d2 + (size_t)i * QTR_KMAX;
+  // A thread walks its own list: written as `while (d2[k] < rn2) ++k` and `acc += pts[idx[t]]` the kernel is a chain of
+  // ~3 k dependent round trips (k ~ 8: most of its 16 us).  Eight entries per round trip instead — the additions stay in
+  // list order.
   int k = 0;
-  while (k < kf && d2[k] < rn2) ++k;
+  for (int t0 = 0; t0 < kf; t0 += 8) {  // length of the prefix with d2 < rn2 (the list is sorted by (d2, index))
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = d2[min(t0 + q, kf - 1)];
+    int c = 0;
+    bool run = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      run = run && (t0 + q < kf) && (v[q] < rn2);
+      c += run ? 1 : 0;
+    }
+    k += c;
+    if (c < 8) break;
+  }
   const float qnan = __uint_as_float(0x7fc00000u);
   if (k < 3) {
     normals[i] = make_float4(qnan, qnan, qnan, qnan);
     return;
   }
+  const float4 self = pts[i];
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < k; ++t) {
-    const float4 q = pts[idx[t]];
-    acc[0] += q.x * q.x;
-    acc[1] += q.x * q.y;
-    acc[2] += q.x * q.z;
-    acc[3] += q.y * q.y;
-    acc[4] += q.y * q.z;
-    acc[5] += q.z * q.z;
-    acc[6] += q.x;
-    acc[7] += q.y;
-    acc[8] += q.z;
+  for (int t0 = 0; t0 < k; t0 += 8) {
+    int jj[8];
+    float4 qq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) jj[q] = idx[min(t0 + q, k - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) qq[q] = pts[jj[q]];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t0 + q < k) {
+        const float4 p = qq[q];
+        acc[0] += p.x * p.x;
+        acc[1] += p.x * p.y;
+        acc[2] += p.x * p.z;
+        acc[3] += p.y * p.y;
+        acc[4] += p.y * p.z;
+        acc[5] += p.z * p.z;
+        acc[6] += p.x;
+        acc[7] += p.y;
+        acc[8] += p.z;
+      }
   }
-  normals[i] = normal_from_sums(acc, k, pts[i]);
+  normals[i] = normal_from_sums(acc, k, self);
 }
 
 // =================================================================================================
@@ -874,34 +904,14 @@ __device__ __forceinline__ int bin11(double x) {
   if (fl >= 11.0) return 10;
   return (int)fl;
 }
-// Bin of the first SPFH feature, bin11(11 (atan2f(y, x) + pi) d_pi) with d_pi = float(1 / (2 float(pi))), without the
-// arc tangent (four binary64 divisions, three square roots and a series): the bin changes at ten angles beta_k =
-// k / (11 d_pi) - pi, and which side of beta_k the direction (x, y) lies on is the sign of y cos(beta_k) - x sin(beta_k)
-// = r sin(theta - beta_k) — five of them for the half plane y is in.  The float result of atan2f is within 1.3e-7 of
-// theta and the bin arithmetic adds 1e-15, so whenever every |sin(theta - beta_k)| exceeds 1e-6 the count of boundaries
-// below theta IS the bin the reference arithmetic produces; the sliver in between (3e-6 of all directions), y = 0 and
-// non-finite input evaluate qm_atan2f as before.
-__device__ __forceinline__ int spfh_bin0(float yf, float xf, float d_pi) {
-  const double y = (double)yf, x = (double)xf;
-  const double m = 1e-6 * (fabs(x) + fabs(y));
-  if (yf != 0.f && m < (double)INFINITY) {  // (NaN fails the second test)
-    const bool up = y > 0;
-    // cos / sin of beta_6..beta_10 (y > 0: theta in (0, pi)) or beta_1..beta_5 (y < 0: theta in (-pi, 0))
-    const double c0 = up ? 0.9594929346621472 : -0.8412535203730152, s0 = up ? 0.2817326895009176 : -0.5406408368408818;
-    const double c1 = up ? 0.6548606120403585 : -0.41541497107998193, s1 = up ? 0.7557496799854613 : -0.9096320144996095;
-    const double c2 = up ? 0.14231465580301056 : 0.14231490669963703, s2 = up ? 0.9898214681161803 : -0.9898214320427062;
-    const double c3 = up ? -0.41541520165044565 : 0.6548608036052355, s3 = up ? 0.9096319092015844 : -0.755749513993562;
-    const double c4 = up ? -0.8412536574128168 : 0.9594930060747751, s4 = up ? 0.5406406236027397 : -0.2817324462918526;
-    const double r0 = y * c0 - x * s0, r1 = y * c1 - x * s1, r2 = y * c2 - x * s2, r3 = y * c3 - x * s3, r4 = y * c4 - x * s4;
-    const bool sure = fabs(r0) > m && fabs(r1) > m && fabs(r2) > m && fabs(r3) > m && fabs(r4) > m;
-    if (sure) return (up ? 5 : 0) + (r0 > 0) + (r1 > 0) + (r2 > 0) + (r3 > 0) + (r4 > 0);
-  }
-  const float f0 = qm_atan2f(yf, xf);
-  return bin11(11 * (((double)f0 + M_PI) * (double)d_pi));
+// acosf(|angle1|) > acosf(|angle2|), see dev_pair_features
+__device__ __forceinline__ bool spfh_swap_roles(float angle1, float angle2) {
+  const float x1 = fabsf(angle1), x2 = fabsf(angle2);
+  if (x1 == x2) return false;
+  if (x1 <= 1.0f && x2 <= 1.0f && fabsf(x1 - x2) > 5e-7f) return x1 < x2;
+  return qm_acosf(x1) > qm_acosf(x2);
 }
-// f[1], f[2] and the bin of f[0] (see spfh_bin0)
-__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f, int* bin0,
-                                  float d_pi) {
+__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f) {
   float dp[3] = {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
   const float f4 = sqrtf(dot4_sse(dp, dp));
   if (f4 == 0.0f) return false;
@@ -914,15 +924,7 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   // more than 5e-7 apart, four float ulps of a result below pi/2, so the rounded results are ordered like the arguments
   // are (reversed); equal arguments give equal results.  Only the sliver in between (and arguments above 1 or NaN, where
   // acosf is NaN) evaluates the functions — the answer is the same bit either way.
-  const float x1 = fabsf(angle1), x2 = fabsf(angle2);
-  bool swap_roles;
-  if (x1 == x2)
-    swap_roles = false;
-  else if (x1 <= 1.0f && x2 <= 1.0f && fabsf(x1 - x2) > 5e-7f)
-    swap_roles = x1 < x2;
-  else
-    swap_roles = qm_acosf(x1) > qm_acosf(x2);
-  if (swap_roles) {
+  if (spfh_swap_roles(angle1, angle2)) {
     n1c[0] = nn2.x;
     n1c[1] = nn2.y;
     n1c[2] = nn2.z;
@@ -945,7 +947,7 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   float w[3];
   dev_cross(n1c, v, w);
   f[1] = dot4_sse(v, n2c);
-  *bin0 = spfh_bin0(dot4_sse(w, n2c), dot4_sse(n1c, n2c), d_pi);
+  f[0] = qm_atan2f(dot4_sse(w, n2c), dot4_sse(n1c, n2c));
   f[2] = f3;
   return true;
 }
@@ -984,7 +986,7 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
   __syncthreads();
   const int total = s_off[SPFH_PB];
   const float d_pi = 1.0f / (2.0f * (float)M_PI);
-  for (int t = tid; t < total; t += 256) {
+  for (int t = tid; t < total; t += 256) {  // (four pairs per thread and round trip were measured: 20 -> 24 us)
     int pi = 0;  // the point this pair belongs to: largest pi with s_off[pi] <= t (5 halvings of 32)
 #pragma unroll
     for (int step = SPFH_PB / 2; step > 0; step >>= 1) pi += (s_off[pi + step] <= t) ? step : 0;
@@ -992,9 +994,10 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
     const int j = nbr_idx[(size_t)i * QTR_KMAX + (t - s_off[pi])];
     if (j == i) continue;
     float f[3];
-    int bin0;
-    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f, &bin0, d_pi)) continue;
-    atomicAdd(&cnt[pi][bin0], 1);
+    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f)) continue;
+    // (deciding this bin from five cross products instead of the arc tangent was measured: same kernel time — it is
+    // the role swap's two arc cosines that cost, see spfh_swap_roles)
+    atomicAdd(&cnt[pi][bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))], 1);
     atomicAdd(&cnt[pi][11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))], 1);
     atomicAdd(&cnt[pi][22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))], 1);
   }
@@ -1058,15 +1061,15 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
     __syncthreads();
     if (owner) {
       const int m = min(FPFH_CHUNK, k - t0);
-      for (int q0 = 0; q0 < m; q0 += 4) {
-        float x[4], w[4];
+      for (int q0 = 0; q0 < m; q0 += 16) {
+        float x[16], w[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // four independent gathers in flight (entries past m are staged as row 0, weight 0)
+        for (int u = 0; u < 16; ++u) {  // sixteen independent gathers in flight (entries past m are staged as row 0, weight 0)
           w[u] = s_w[pi][q0 + u];
           x[u] = spfh[(size_t)s_idx[pi][q0 + u] * 33 + b];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
           if (q0 + u < m && w[u] != 0.f) {
             const float val = x[u] * w[u];
             h += val;

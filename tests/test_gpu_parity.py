@@ -54,6 +54,23 @@ def test_device_math_is_bit_identical_to_host(hip, qo):
         assert np.array_equal(_b(hip.debug_math(fn, th)), _b(qo.math_fn(fn, th)))
 
 
+@pytest.mark.gpu
+def test_spfh_role_swap_shortcut_equals_the_reference_arithmetic(hip, qo):
+    """k2_spfh decides the Darboux-frame role swap, acosf(|a1|) > acosf(|a2|), from the arguments and evaluates the two
+    arc cosines only where rounding could matter (frontend.hip: spfh_swap_roles).  Against the oracle's plain arithmetic
+    on 600 k pairs, half of them with arguments at most 2e-6 apart, plus equal, out-of-range and non-finite ones."""
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, 1.0000005, 600000)
+    y = np.where(rng.random(600000) < 0.5, x + rng.uniform(-2e-6, 2e-6, 600000), rng.uniform(0, 1.0000005, 600000))
+    sg = rng.choice([-1.0, 1.0], 600000)
+    sp_a = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 0.0, 1e-40, 1.0, 0.5, 1.0000001, 2.0], dtype=np.float32)
+    sp_b = np.array([0.0, -0.0, -0.0, 0.0, np.inf, 1.0, 1.0, -1.0, 1e-40, 1.0, 0.5, 1.0, np.nan], dtype=np.float32)
+    a, b = np.concatenate([(x * sg).astype(np.float32), sp_a]), np.concatenate([y.astype(np.float32), sp_b])
+    d, o = hip.debug_math(5, a, b), qo.math_fn(5, a, b)
+    bad = np.nonzero(d != o)[0]
+    assert bad.size == 0, (a[bad[:5]], b[bad[:5]], d[bad[:5]], o[bad[:5]])
+
+
 # ---------------------------------------------------------------------------------------------- back end
 @pytest.mark.parametrize("L,frac,seed,noise", [
     (2, 1.0, 0, 0.1), (3, 0.0, 1, 0.1), (50, 0.3, 1, 0.1), (64, 0.5, 2, 0.2), (65, 0.5, 3, 0.2), (300, 0.2, 2, 0.3),

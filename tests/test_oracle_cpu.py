@@ -1183,3 +1183,19 @@ def test_tuple_test_against_a_second_restatement(qo):
         want = sorted((j, i) if swapped else (i, j) for i, j in kept)
         assert [tuple(v) for v in got.tolist()] == want, (ns, nt, seed)
         assert 0 < len(want) <= ncorr
+
+
+def test_spfh_role_swap_shortcut_logic_against_the_oracle_arithmetic(qo):
+    """numpy mirror of the device's role-swap shortcut (frontend.hip: spfh_swap_roles) against the oracle's plain
+    arithmetic (qo_math 5): wherever the shortcut claims to be sure it must give the oracle's answer; the rest falls
+    back to the two arc cosines on the device."""
+    rng = np.random.default_rng(3)
+    x1 = rng.uniform(0, 1.0000005, 300000).astype(np.float32)
+    x2 = np.where(rng.random(300000) < 0.5, x1 + rng.uniform(-2e-6, 2e-6, 300000), rng.uniform(0, 1.0000005, 300000)).astype(np.float32)
+    x2 = np.abs(x2)
+    want = qo.math_fn(5, x1, x2)
+    eq = x1 == x2
+    fast = (~eq) & (x1 <= 1) & (x2 <= 1) & (np.abs(x1 - x2) > np.float32(5e-7))
+    assert fast.mean() > 0.4
+    assert not want[eq].any()
+    assert np.array_equal((x1 < x2)[fast].astype(np.float32), want[fast])
