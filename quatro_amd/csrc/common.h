@@ -2,6 +2,7 @@
 // gfx950 only: wavefront = 64 lanes is hard-coded throughout.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>

@@ -38,6 +38,16 @@
     else                                                                                                        \
       hipLaunchKernelGGL((kern<false, K>), grid, block, lds, st, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one, ##__VA_ARGS__); \
   } while (0)
+// the same with a pair of timing events attached to the dispatch itself (hipExtLaunchKernelGGL: the events take the
+// kernel's own start / end timestamps) — two hipEventRecord calls around a launch put two barrier packets into the
+// queue, ~5.7 us each on this chain; e0 / e1 null: plain launch
+#define LAUNCH_MV_EV(kern, a, grid, block, lds, st, e0, e1, ...)                                                 \
+  do {                                                                                                          \
+    if ((a).ext)                                                                                                \
+      hipExtLaunchKernelGGL((kern<true>), grid, block, lds, st, e0, e1, 0, (ViewExt<MatchView>{(a).ext, {0, 0, 0}}), (a).one, ##__VA_ARGS__);  \
+    else                                                                                                        \
+      hipExtLaunchKernelGGL((kern<false>), grid, block, lds, st, e0, e1, 0, (ViewExt<MatchView>{nullptr, {0, 0, 0}}), (a).one, ##__VA_ARGS__); \
+  } while (0)
 #define LAUNCH_MV(kern, a, grid, block, lds, st, ...)                                       \
   do {                                                                                      \
     if ((a).ext)                                                                            \
@@ -1812,11 +1822,21 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       return (e && atoi(e) == 2) ? 2 : 1;
     }();
     const int X = n_cu * wgs_per_cu;
+    // QTR_NN_EVENTS=record: bracket the launch with two hipEventRecord calls instead of attaching the events to it
+    static const bool attach_events = [] {
+      const char* e = getenv("QTR_NN_EVENTS");
+      return !(e && strcmp(e, "record") == 0);
+    }();
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
-      if (e0) (void)hipEventRecord(e0, st);
-      if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G);
-      else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
-      if (e1) (void)hipEventRecord(e1, st);
+      if (e0 && e1 && attach_events) {
+        if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
+        else LAUNCH_MV_EV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
+      } else {
+        if (e0) (void)hipEventRecord(e0, st);
+        if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+        else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+        if (e1) (void)hipEventRecord(e1, st);
+      }
       LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
                 G, f16 ? 800.0f : 0.0f, f16 ? 1 : 0);
       // (single pair: 8 x 64 workgroups = the 512 the device holds at two per compute unit — one round)
