@@ -191,9 +191,7 @@ struct FrontBufs {
   int mail_seq = 0;            // sequence number the next phase-ending kernel publishes (set by the caller)
   int nn_engine = 2;           // 2 = f16-split MFMA filter + exact re-check (default), 1 = f32 MFMA + exact re-check
                                // (QTR_NN_ENGINE=mfma32), 0 = exact VALU only (QTR_NN_ENGINE=exact)
-  int nn_target_waves = 0;     // QTR_NN_WAVES: waves per k_nn_mfma launch to aim at; 0 = one workgroup per compute unit
   int n_cu = 256;              // compute units of the device
-  int nn_trace = 0;            // QTR_NN_TRACE=1: k_nn_mfma (first direction) leaves clocks per tile / workgroup lives in mcounts[12..15]
   int nn_events = 1;           // 0: do not bracket the nearest-neighbour launches with events
   hipEvent_t ev_nn[4] = {};    // brackets of the two nearest-neighbour launches (created by the handle)
 };

@@ -1611,10 +1611,6 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   {
     const char* e = getenv("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "mfma32") == 0) ? 1 : 2;
-    const char* w = getenv("QTR_NN_WAVES");
-    F.nn_target_waves = (w && atoi(w) > 0) ? atoi(w) : 0;
-    const char* tr = getenv("QTR_NN_TRACE");
-    F.nn_trace = (tr && atoi(tr) > 0) ? 1 : 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
