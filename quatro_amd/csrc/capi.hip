@@ -1364,12 +1364,21 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
-    // the FPFH chain first: the device is idle until its first launch arrives
+    // Beside the FPFH chain, on the second stream: the matcher's sequential means (70 us: the long pole over there), and
+    // the matcher's and the solver's clean slates (they depend on the voxel counts alone).  The device is idle until the
+    // FPFH chain's first launch arrives, so that chain goes first and the second stream's work after it; QTR_MEAN_FIRST=1
+    // issues the means before the chain (one launch of delay for the chain, ~20 us of head start for the means — for
+    // hosts slow enough that the second stream would otherwise finish last).
+    static const bool mean_first = getenv("QTR_MEAN_FIRST") != nullptr;
+    if (mean_first) {
+      QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
+      QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
+    }
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true));
-    // beside it, on the second stream: the matcher's sequential means, and the matcher's and the solver's clean slates
-    // (they depend on the voxel counts alone)
-    QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
-    QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
+    if (!mean_first) {
+      QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
+      QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
+    }
     QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2));
     QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
