@@ -4,6 +4,7 @@
 #   gpurun_out/TAG_kernel_stats.txt      rocprofv3 --kernel-trace of the headline loop (sequential single pairs)
 #   gpurun_out/TAG_batch_kernel_stats.txt  ... of the batched leg (256 pairs, groups of 16 per launch chain)
 #   gpurun_out/TAG_pmc_nn.json           FETCH_SIZE / WRITE_SIZE of k_nn_f16 (NN_KERNEL overrides the name), two separate --pmc passes
+#   (python profiles/timeline.py gpurun_out/prof_TAG_seq/seq_results.db > profiles/TAG_timeline.txt: one registration, dispatch by dispatch)
 # Copy what is to be judged into profiles/.
 TAG=${1:-r2}
 export TMPDIR=/tmp
