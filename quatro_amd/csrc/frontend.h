@@ -3,7 +3,7 @@
 #include "common.h"
 
 #define QTR_KMAX 256        // capacity of one point's radius-neighbour list (entries)
-#define RADIX_TILE 1024     // elements per radix-sort workgroup (one wavefront)
+#define RADIX_TILE 1024     // elements per radix-sort workgroup (four wavefronts, 256 keys each)
 #define NORM_BINS 192       // bins of width 1 over sqrt(|descriptor|^2) (<= sqrt(3 * 100^2) = 173.3)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
