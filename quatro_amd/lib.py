@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquatro_hip.so")
+# QTR_LIB: another build of the same library (the diagnostic / candidate builds of tests/probe); it has to exist like the default
+LIB_PATH = os.environ.get("QTR_LIB") or os.path.join(_HERE, "libquatro_hip.so")
 
 QTR_OK, QTR_ERR_BAD_ARG, QTR_ERR_CLIQUE_TOO_SMALL, QTR_ERR_CAPACITY, QTR_ERR_HIP, QTR_ERR_UNSUPPORTED = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
