@@ -58,6 +58,8 @@ extern "C" {
 #define QTR_ERR_HIP 4              /* HIP runtime error (message in qtr_last_error) */
 #define QTR_ERR_UNSUPPORTED 5      /* mode accepted by the reference's API but not built here */
 #define QTR_ERR_IO 6               /* file missing / unreadable / malformed (qtr_read_*, qtr_write_*) */
+#define QTR_ERR_NOT_RUN 7          /* batched pair whose record was never produced: the job failed before it was started
+                                      (qtr_submit_batch fills every record with this until the pair's result is final) */
 
 #define QTR_MEM_HOST 0
 #define QTR_MEM_DEVICE 1
@@ -261,6 +263,19 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
                       const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
                       int* final_inliers, int cap, int mem);
 
+/* Front end of one pair on one slot: raw scans -> matched keypoint clouds.  What the reference's caller does between
+ * loading two scans and handing the keypoints to Quatro (examples/run_global_registration.cpp:206-221): `voxelize` x2
+ * (include/quatro.hpp:49-68), FPFHManager::setFeaturePair (include/fpfh_manager.hpp:98-153: FPFH x2 + reciprocal
+ * matching with cross check and tuple test), getSrcKps / getTgtKps / getCorrespondences (:172-177,234).  The same
+ * launch chain as qtr_register_pair up to the solver.  n_src / n_tgt (optional) receive the voxelised cloud sizes, *L
+ * the number of correspondences; src_kps4 / tgt_kps4 (optional, capacity `cap` 16-byte records) the matched keypoints in
+ * correspondence order, corr2 (optional, cap x 2 ints) the (source, target) voxel indices.  mem = QTR_MEM_HOST: outputs
+ * complete on return; QTR_MEM_DEVICE: outputs are written on the slot's stream (qtr_slot_stream).  The matched clouds
+ * also stay in the slot, where a following qtr_solve on device pointers can be issued without a copy. */
+int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                     const qtr_frontend_params* fp, int* n_src, int* n_tgt, int* L, float* src_kps4, float* tgt_kps4,
+                     int* corr2, int cap, int mem);
+
 /* Batched registration (BASELINE configs[2] / [3]; the reference's usage is one Quatro object reused over many pairs,
  * examples/run_global_registration.cpp:97-108).  B independent pairs go through the SAME kernels as qtr_register_pair,
  * a group of pairs per launch (blockIdx.z = pair): the handle's stream slots are split into two lanes of
@@ -270,7 +285,9 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
  *   qtr_submit_batch  validates, records the job and enqueues the first chains; returns without waiting.
  *   qtr_wait          drives the job to completion (call it from the same thread).  results[i] receives pair i's
  *                     record (its own status: QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL, QTR_ERR_CAPACITY ...); the return
- *                     value is QTR_OK unless the job itself failed (HIP error, bad argument).
+ *                     value is QTR_OK unless the job itself failed (HIP error, bad argument) — then every pair that
+ *                     had finished keeps its record, pairs that were in flight read QTR_ERR_HIP, pairs never started
+ *                     QTR_ERR_NOT_RUN, and the handle is drained and usable.
  * pairs / results must stay valid until qtr_wait returns; one job at a time per handle; every slot of the handle is
  * used (do not run slot calls concurrently).  mem as elsewhere (raw scans and the optional index lists). */
 typedef struct qtr_pair_desc {
@@ -294,13 +311,21 @@ int qtr_wait(qtr_handle* h);
  *                        (MPI, a file, torch.distributed.broadcast ...)
  *   qtr_comm_init        joins the communicator on the handle's device (collective: every rank calls it)
  *   qtr_gather_results   all-gather: `all` receives world * n_local records in rank order on EVERY rank; n_local must
- *                        be the same on all ranks (pad the last block)
+ *                        be the same on all ranks (QTR_ERR_BAD_ARG on every rank otherwise — nothing is overrun)
+ *   qtr_gather_results_v the same for blocks of DIFFERENT lengths (a block partition of B pairs over `world` ranks
+ *                        differs by one record between ranks; BASELINE configs[3]: 4096 pairs over any world size):
+ *                        the counts are exchanged first, the blocks padded to the longest for the fixed-size
+ *                        collective and trimmed on the way out.  `all` (capacity cap_all records) receives the
+ *                        sum(counts) records in rank order, counts[world] (optional) every rank's count, *n_all
+ *                        (optional) the total.  Collective: every rank calls it, also with n_local = 0.
  * librccl is opened at run time (dlopen), so single-GPU users do not need it.  QTR_ERR_HIP with the RCCL message in
  * qtr_last_error on failure. */
 #define QTR_COMM_ID_BYTES 128
 int qtr_comm_unique_id(char id[QTR_COMM_ID_BYTES]);
 int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int world);
 int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all);
+int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
+                         int* n_all);
 void qtr_comm_destroy(qtr_handle* h);
 
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);

@@ -1074,6 +1074,10 @@ double cote_estimate_ranges(const std::vector<double>& X, const std::vector<doub
     h[2 * i] = Ev{X[i] - R[i], i + 1, 2 * i};
     h[2 * i + 1] = Ev{X[i] + R[i], -i - 1, 2 * i + 1};
   }
+  // a NaN endpoint (NaN coordinate in, which the reference's std::sort leaves undefined) sorts as +inf, ties by position:
+  // the order is total whatever comes in
+  for (auto& e : h)
+    if (e.v != e.v) e.v = INFINITY;
   std::sort(h.begin(), h.end(), [](const Ev& a, const Ev& b) { return a.v < b.v || (a.v == b.v && a.pos < b.pos); });
   const int nc = 2 * N;
   std::vector<double> x_hat((size_t)nc), x_cost((size_t)nc);

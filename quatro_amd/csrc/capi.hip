@@ -67,6 +67,7 @@ struct BatchJob {
   qtr_result* results = nullptr;
   int mem = QTR_MEM_HOST;
   bool active = false;
+  std::vector<unsigned char> finished;  // per pair: its record is final (result or per-pair failure)
 };
 
 struct qtr_handle {
@@ -85,6 +86,12 @@ struct qtr_handle {
   char err[512];
 };
 
+#define QTR_TRY(expr)                  \
+  do {                                 \
+    const int rc_ = (expr);            \
+    if (rc_ != QTR_OK) return rc_;     \
+  } while (0)
+
 // ---- RCCL, opened at run time (the soname torch ships resolves to the copy that is already loaded)
 struct RcclApi {
   void* lib = nullptr;
@@ -97,21 +104,31 @@ struct RcclApi {
 static RcclApi* rccl_api(char* err, size_t errn) {
   static RcclApi api;
   static int state = 0;  // 0 untried, 1 ok, -1 failed
+  static char why[256] = "symbols missing";  // dlerror() is read ONCE per failure (a second call returns NULL)
   if (state == 0) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
-      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* n : names) {
+      if (api.lib) break;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!api.lib) {
+        const char* e = dlerror();
+        if (e) snprintf(why, sizeof(why), "%s", e);
+      }
+    }
     if (api.lib) {
+      snprintf(why, sizeof(why), "symbols missing");
       api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
       api.CommInitRank = (int (*)(void**, int, RcclIdByValue, int))dlsym(api.lib, "ncclCommInitRank");
       api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
       api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
       api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+      const char* e = dlerror();
+      if (e) snprintf(why, sizeof(why), "%s", e);
     }
     state = (api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy) ? 1 : -1;
   }
   if (state != 1) {
-    if (err) snprintf(err, errn, "librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (err) snprintf(err, errn, "librccl could not be opened (%s)", why);
     return nullptr;
   }
   return &api;
@@ -144,36 +161,91 @@ int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int
   return QTR_OK;
 }
 
-int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all) {
-  if (!h || n_local < 0 || (n_local > 0 && (!local || !all))) return QTR_ERR_BAD_ARG;
-  if (!h->comm) {
-    snprintf(h->err, sizeof(h->err), "qtr_gather_results: call qtr_comm_init first");
-    return QTR_ERR_BAD_ARG;
-  }
-  if (n_local == 0) return QTR_OK;
-  RcclApi* a = rccl_api(h->err, sizeof(h->err));
-  if (!a) return QTR_ERR_HIP;
-  QTR_HIP_TRY(h, hipSetDevice(h->device));
-  const size_t mine = (size_t)n_local * sizeof(qtr_result), total = mine * (size_t)h->comm_world;
-  if (h->comm_bytes < mine + total) {
-    if (h->comm_buf) (void)hipFree(h->comm_buf);
-    h->comm_buf = nullptr;
-    h->comm_bytes = 0;
-    QTR_HIP_TRY(h, hipMalloc(&h->comm_buf, mine + total));
-    h->comm_bytes = mine + total;
-  }
-  hipStream_t st = h->slots[0].stream;
-  char* d_send = (char*)h->comm_buf;
-  char* d_recv = d_send + mine;
-  QTR_HIP_TRY(h, hipMemcpyAsync(d_send, local, mine, hipMemcpyHostToDevice, st));
-  const int rc = a->AllGather(d_send, d_recv, mine, /* ncclChar */ 0, h->comm, st);
+// one all-gather of `bytes` per rank from d_send into d_recv (rank order), on slot 0's stream
+static int comm_allgather(qtr_handle* h, RcclApi* a, const void* d_send, void* d_recv, size_t bytes, hipStream_t st) {
+  const int rc = a->AllGather(d_send, d_recv, bytes, /* ncclChar */ 0, h->comm, st);
   if (rc != 0) {
     snprintf(h->err, sizeof(h->err), "ncclAllGather: %s", a->GetErrorString ? a->GetErrorString(rc) : "error");
     return QTR_ERR_HIP;
   }
-  QTR_HIP_TRY(h, hipMemcpyAsync(all, d_recv, total, hipMemcpyDeviceToHost, st));
+  return QTR_OK;
+}
+
+int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
+                         int* n_all) {
+  if (!h || n_local < 0 || (n_local > 0 && !local) || cap_all < 0 || (cap_all > 0 && !all)) return QTR_ERR_BAD_ARG;
+  if (!h->comm) {
+    snprintf(h->err, sizeof(h->err), "qtr_gather_results: call qtr_comm_init first");
+    return QTR_ERR_BAD_ARG;
+  }
+  RcclApi* a = rccl_api(h->err, sizeof(h->err));
+  if (!a) return QTR_ERR_HIP;
+  QTR_HIP_TRY(h, hipSetDevice(h->device));
+  const int world = h->comm_world;
+  hipStream_t st = h->slots[0].stream;
+  auto reserve = [&](size_t bytes) -> int {
+    if (h->comm_bytes >= bytes) return QTR_OK;
+    if (h->comm_buf) (void)hipFree(h->comm_buf);
+    h->comm_buf = nullptr;
+    h->comm_bytes = 0;
+    QTR_HIP_TRY(h, hipMalloc(&h->comm_buf, bytes));
+    h->comm_bytes = bytes;
+    return QTR_OK;
+  };
+  // 1. every rank's record count (a collective: ranks with nothing to send take part too)
+  QTR_TRY(reserve(256 + 256 * (size_t)world));
+  std::vector<int> cnt((size_t)world * 64, 0);  // one 256-byte line per rank
+  int mine_line[64] = {n_local};
+  QTR_HIP_TRY(h, hipMemcpyAsync(h->comm_buf, mine_line, 256, hipMemcpyHostToDevice, st));
+  QTR_TRY(comm_allgather(h, a, h->comm_buf, (char*)h->comm_buf + 256, 256, st));
+  QTR_HIP_TRY(h, hipMemcpyAsync(cnt.data(), (char*)h->comm_buf + 256, 256 * (size_t)world, hipMemcpyDeviceToHost, st));
+  QTR_HIP_TRY(h, hipStreamSynchronize(st));
+  int nmax = 0;
+  long long total = 0;
+  for (int r = 0; r < world; ++r) {
+    const int c = cnt[(size_t)r * 64];
+    if (counts) counts[r] = c;
+    nmax = std::max(nmax, c);
+    total += c;
+  }
+  if (n_all) *n_all = (int)total;
+  if (total > cap_all) {  // every rank sees the same counts, so every rank leaves here together
+    snprintf(h->err, sizeof(h->err), "qtr_gather_results: %lld records, capacity %d", total, cap_all);
+    return QTR_ERR_CAPACITY;
+  }
+  if (nmax == 0) return QTR_OK;
+  // 2. the records, every block padded to the longest (fixed-size collective), trimmed on the way out
+  const size_t block = (size_t)nmax * sizeof(qtr_result);
+  QTR_TRY(reserve(block * (size_t)(world + 1)));
+  char* d_send = (char*)h->comm_buf;
+  char* d_recv = d_send + block;
+  QTR_HIP_TRY(h, hipMemsetAsync(d_send, 0, block, st));
+  if (n_local > 0)
+    QTR_HIP_TRY(h, hipMemcpyAsync(d_send, local, (size_t)n_local * sizeof(qtr_result), hipMemcpyHostToDevice, st));
+  QTR_TRY(comm_allgather(h, a, d_send, d_recv, block, st));
+  size_t off = 0;
+  for (int r = 0; r < world; ++r) {
+    const int c = cnt[(size_t)r * 64];
+    if (c > 0)
+      QTR_HIP_TRY(h, hipMemcpyAsync(all + off, d_recv + (size_t)r * block, (size_t)c * sizeof(qtr_result),
+                                    hipMemcpyDeviceToHost, st));
+    off += (size_t)c;
+  }
   QTR_HIP_TRY(h, hipStreamSynchronize(st));
   return QTR_OK;
+}
+
+int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all) {
+  if (!h || n_local < 0 || (n_local > 0 && (!local || !all))) return QTR_ERR_BAD_ARG;
+  std::vector<int> counts((size_t)std::max(h->comm_world, 1), 0);
+  int n_all = 0;
+  // the caller sized `all` for world * n_local records: blocks of another length are refused, not overrun
+  const int rc = qtr_gather_results_v(h, local, n_local, all, n_local * h->comm_world, counts.data(), &n_all);
+  if (rc == QTR_ERR_CAPACITY || (rc == QTR_OK && n_all != n_local * h->comm_world)) {
+    snprintf(h->err, sizeof(h->err), "qtr_gather_results: ranks hold different record counts (use qtr_gather_results_v)");
+    return QTR_ERR_BAD_ARG;
+  }
+  return rc;
 }
 
 void qtr_comm_destroy(qtr_handle* h) {
@@ -459,16 +531,23 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
   snprintf(h->err, sizeof(h->err), "mailbox payload of word %d does not match its tag (sequence %d)", idx, seq);
   return QTR_ERR_HIP;
 }
-#define QTR_TRY(expr)                  \
-  do {                                 \
-    const int rc_ = (expr);            \
-    if (rc_ != QTR_OK) return rc_;     \
-  } while (0)
 
 static void compute_times(Slot& s) {
   if (!s.times_pending) return;
-  (void)hipEventSynchronize(s.ev[4]);
   float ms = 0;
+  if (s.times_pending == 3) {  // qtr_feature_pair: the front end alone
+    (void)hipEventSynchronize(s.ev[7]);
+    s.times = qtr_stage_times{};
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) s.times.voxelize = ms;
+    if (hipEventElapsedTime(&ms, s.ev[1], s.ev[6]) == hipSuccess) s.times.fpfh = ms;
+    if (hipEventElapsedTime(&ms, s.ev[6], s.ev[7]) == hipSuccess) s.times.match = ms;
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[7]) == hipSuccess) s.times.total = ms;
+    fill_nn_times(s);
+    (void)hipGetLastError();
+    s.times_pending = 0;
+    return;
+  }
+  (void)hipEventSynchronize(s.ev[4]);
   s.times = qtr_stage_times{};
   if (s.times_pending == 1) {
     if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) s.times.graph = ms;
@@ -1282,26 +1361,25 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
   return QTR_OK;
 }
 
-int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
-                      const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
-                      int* final_inliers, int cap, int mem) {
-  Slot* sp = get_slot(h, slot);
-  if (!sp || !res || !fp) return QTR_ERR_BAD_ARG;
-  Slot& s = *sp;
-  memset(res, 0, sizeof(*res));
-  int rc = check_params(h, prm);
-  if (rc != QTR_OK) return res->status = rc;
+// Front end of one pair on one slot: voxel grid x2 -> FPFH x2 -> reciprocal matching -> matched keypoint clouds gathered
+// into s.m_src / s.m_tgt (device).  What the reference does in `voxelize` x2 (include/quatro.hpp:49-68) +
+// FPFHManager::setFeaturePair (include/fpfh_manager.hpp:98-153).  Counts go to *ns_out / *nt_out / *L_out; with
+// `for_solver` the solver's clean slate is enqueued beside the FPFH chain (qtr_register_pair).  An error return leaves
+// nothing in flight that still reads the caller's scans.
+static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                        const qtr_frontend_params* fp, int mem, bool for_solver, int* ns_out, int* nt_out, int* L_out) {
+  int rc = QTR_OK;
   if (fp->normal_radius > fp->fpfh_radius) {
     snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
-    return res->status = QTR_ERR_BAD_ARG;
+    return QTR_ERR_BAD_ARG;
   }
   if (Ps <= 0 || Pt <= 0 || !src_raw4 || !tgt_raw4) {
     snprintf(h->err, sizeof(h->err), "Invalid or empty point cloud dataset given!");
-    return res->status = QTR_ERR_BAD_ARG;
+    return QTR_ERR_BAD_ARG;
   }
   if (Ps > h->lim.max_points || Pt > h->lim.max_points) {
     snprintf(h->err, sizeof(h->err), "cloud exceeds max_points=%d", h->lim.max_points);
-    return res->status = QTR_ERR_CAPACITY;
+    return QTR_ERR_CAPACITY;
   }
   QTR_HIP_TRY(h, hipSetDevice(h->device));
   const float4 *d_s = (const float4*)src_raw4, *d_t = (const float4*)tgt_raw4;
@@ -1312,6 +1390,13 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
     d_t = s.in_tgt;
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  // k2_vox_centroids publishes the voxel counters from its first block while other blocks may still be reading the raw
+  // scans: an error return taken right after the mail must not hand the scans back to the caller (who may free them)
+  // before the stream has drained
+  auto fail_drained = [&](int code) {
+    (void)hipStreamSynchronize(s.stream);
+    return code;
+  };
   // both clouds go through every front-end kernel together (blockIdx.y = cloud)
   {
     const float4* raws[2] = {d_s, d_t};
@@ -1329,7 +1414,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
       QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
       // k2_vox_centroids leaves both clouds' counters in the mailbox
       if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
-        return res->status = rc;
+        return fail_drained(rc);
       const int bits = std::max(s.mail[MAIL_VOX0 + CNT_SORT_BITS], s.mail[MAIL_VOX1 + CNT_SORT_BITS]);
       const int needed = std::min(4, std::max(1, (bits + 7) / 8));
       if (needed > launched && attempt == 0) {  // under-launched: the centroids are garbage, run the stage again
@@ -1348,17 +1433,17 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
       break;
     }
   }
-  int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+  const int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
   if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
-    return res->status = QTR_ERR_CAPACITY;
+    return fail_drained(QTR_ERR_CAPACITY);
   }
   if (ns > h->lim.max_voxels || nt > h->lim.max_voxels) {
     snprintf(h->err, sizeof(h->err), "voxel count (%d,%d) exceeds max_voxels=%d", ns, nt, h->lim.max_voxels);
-    return res->status = QTR_ERR_CAPACITY;
+    return fail_drained(QTR_ERR_CAPACITY);
   }
-  res->n_src = ns;
-  res->n_tgt = nt;
+  *ns_out = ns;
+  *nt_out = nt;
   s.last_ns = ns;
   s.last_nt = nt;
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
@@ -1380,26 +1465,43 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
     QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2));
-    QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
+    if (for_solver) QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L, true);
-  if (rc != QTR_OK) return res->status = rc;
+  if (rc != QTR_OK) return rc;
   if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW]) {
     snprintf(h->err, sizeof(h->err), "neighbour list capacity (%d per point) exceeded: max k = %d / %d", QTR_KMAX,
              s.mail[MAIL_CNT0 + CNT_KMAX], s.mail[MAIL_CNT1 + CNT_KMAX]);
-    return res->status = QTR_ERR_CAPACITY;
+    return QTR_ERR_CAPACITY;
   }
-  res->n_corr = L;
+  *L_out = L;
+  s.last_L = L;
   if (L > h->lim.max_corr) {
     snprintf(h->err, sizeof(h->err), "L=%d exceeds max_corr=%d", L, h->lim.max_corr);
-    return res->status = QTR_ERR_CAPACITY;
+    return QTR_ERR_CAPACITY;
   }
   QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, s.stream));
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[7], s.stream));
+  return QTR_OK;
+}
+
+int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                      const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
+                      int* final_inliers, int cap, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !res || !fp) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  memset(res, 0, sizeof(*res));
+  int rc = check_params(h, prm);
+  if (rc != QTR_OK) return res->status = rc;
+  int L = 0;
+  rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, true, &res->n_src, &res->n_tgt, &L);
+  res->n_corr = L;
+  if (rc != QTR_OK) return res->status = rc;
   rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res, true);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
   s.times_pending = 2;
@@ -1408,13 +1510,64 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   return rc;
 }
 
+int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                     const qtr_frontend_params* fp, int* n_src, int* n_tgt, int* L_out, float* src_kps4, float* tgt_kps4,
+                     int* corr2, int cap, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !fp || !L_out) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  int ns = 0, nt = 0, L = 0;
+  *L_out = 0;
+  const int rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, false, &ns, &nt, &L);
+  if (n_src) *n_src = ns;
+  if (n_tgt) *n_tgt = nt;
+  *L_out = L;
+  if (rc != QTR_OK) return rc;
+  s.times_pending = 3;
+  if ((src_kps4 || tgt_kps4 || corr2) && L > cap) {
+    snprintf(h->err, sizeof(h->err), "L=%d exceeds output capacity %d", L, cap);
+    return QTR_ERR_CAPACITY;
+  }
+  const hipMemcpyKind kout = mem == QTR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (L > 0) {
+    if (src_kps4) QTR_HIP_TRY(h, hipMemcpyAsync(src_kps4, s.m_src, (size_t)L * 16, kout, s.stream));
+    if (tgt_kps4) QTR_HIP_TRY(h, hipMemcpyAsync(tgt_kps4, s.m_tgt, (size_t)L * 16, kout, s.stream));
+    if (corr2) QTR_HIP_TRY(h, hipMemcpyAsync(corr2, s.fb.corr, (size_t)L * 8, kout, s.stream));
+  }
+  // host outputs are complete on return; device outputs are ordered on the slot's stream (qtr_slot_stream), like the
+  // next call on this slot
+  if (mem == QTR_MEM_HOST) QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  return QTR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched registration: lanes of slots stepped through the three launch chains in lockstep
 static void batch_fail_pair(qtr_handle* h, int pair, int status) {
   qtr_result& r = h->job.results[pair];
   r.status = status;
   r.valid = 0;
+  h->job.finished[pair] = 1;
   ++h->job.done;
+}
+
+// The job failed (HIP error, a lane that never published): drain what is in flight so the handle stays usable, and make
+// every record say what happened to its pair — pairs that had been started but did not finish get QTR_ERR_HIP, pairs
+// that were never started QTR_ERR_NOT_RUN; finished pairs keep their records.
+static void batch_abort(qtr_handle* h) {
+  BatchJob& J = h->job;
+  for (auto& ln : h->lanes) {
+    Slot& lead = h->slots[ln.first_slot];
+    (void)hipStreamSynchronize(lead.stream);
+    (void)hipStreamSynchronize(lead.stream2);
+    ln.phase = 0;
+  }
+  (void)hipGetLastError();
+  for (int i = 0; i < J.B; ++i) {
+    if (J.finished[i]) continue;
+    memset(&J.results[i], 0, sizeof(qtr_result));
+    J.results[i].status = i < J.next ? QTR_ERR_HIP : QTR_ERR_NOT_RUN;
+  }
+  J.active = false;
 }
 
 static int lane_start_chunk(qtr_handle* h, Lane& ln) {
@@ -1574,6 +1727,15 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     const qtr_pair_desc& pd = J.pairs[pair];
     const int L = ln.L[g];
     int rc = QTR_OK;
+    // Follow-up work of ONE pair of the group runs on the lane's stream (the lane's chain owns the slot's arenas), and
+    // everything that waits for it — wait_mail's liveness check, exact_phase's enqueues — must look at THAT stream:
+    // the slot's own stream is idle, so a wait that queries it gives up before the kernels have run.
+    struct StreamSwap {
+      Slot& s;
+      hipStream_t keep;
+      StreamSwap(Slot& s_, hipStream_t st) : s(s_), keep(s_.stream) { s.stream = st; }
+      ~StreamSwap() { s.stream = keep; }
+    } on_lane_stream(s, lead.stream);
     if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
       s.sb.mail_seq = ++s.seq;
       QTR_HIP_TRY(h, solver_continue(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128));
@@ -1583,18 +1745,13 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       SolverState hs;
       memcpy(&hs, s.mail + MAIL_SOLVER + 64, sizeof(hs));
       bool improved = false;
-      hipStream_t keep_stream = s.stream;
-      s.stream = lead.stream;  // exact_phase enqueues on s.stream: the lane's chain owns this slot's arenas
       rc = exact_phase(h, s, L, hs, &improved);
-      if (rc == QTR_OK && improved) {
+      if (rc != QTR_OK) return rc;
+      if (improved) {
         s.sb.mail_seq = ++s.seq;
-        const hipError_t e = solver_refinalize(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream);
-        s.stream = keep_stream;
-        QTR_HIP_TRY(h, e);
+        QTR_HIP_TRY(h, solver_refinalize(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream));
         QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
       }
-      s.stream = keep_stream;
-      if (rc != QTR_OK) return rc;
     }
     const int keep_ns = r.n_src, keep_nt = r.n_tgt, keep_nc = r.n_corr;
     memcpy(&r, s.mail + MAIL_SOLVER, sizeof(qtr_result));
@@ -1616,6 +1773,7 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
         copies = true;
       }
     }
+    J.finished[pair] = 1;
     ++J.done;
   }
   if (copies) QTR_HIP_TRY(h, hipStreamSynchronize(lead.stream));
@@ -1654,10 +1812,15 @@ int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr
   J.results = results;
   J.mem = mem;
   J.active = true;
+  J.finished.assign((size_t)B, 0);
+  for (int i = 0; i < B; ++i) {  // until a pair's record is final it says so (a caller that looks only at the
+    memset(&results[i], 0, sizeof(qtr_result));  // per-pair status can tell "never ran" from "ran, no solution")
+    results[i].status = QTR_ERR_NOT_RUN;
+  }
   for (auto& ln : h->lanes) {
     const int r = lane_start_chunk(h, ln);
     if (r != QTR_OK) {
-      J.active = false;
+      batch_abort(h);  // earlier lanes may already have work in flight
       return r;
     }
   }
@@ -1710,14 +1873,7 @@ int qtr_wait(qtr_handle* h) {
       if (rc != QTR_OK) break;
     }
   }
-  if (rc != QTR_OK) {  // leave the handle usable: drain what is in flight
-    for (auto& ln : h->lanes) {
-      Slot& lead = h->slots[ln.first_slot];
-      (void)hipStreamSynchronize(lead.stream);
-      (void)hipStreamSynchronize(lead.stream2);
-      ln.phase = 0;
-    }
-  }
+  if (rc != QTR_OK) batch_abort(h);  // leave the handle usable, every record says what happened to its pair
   J.active = false;
   return rc;
 }

@@ -1129,7 +1129,8 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     if (act)
       for (int i = tl; i < nc; i += 256) {
         const double ri = R ? R[i >> 1] : range;
-        ekey[i] = (i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri;
+        const double k = (i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri;
+        ekey[i] = (k != k) ? INFINITY : k;  // NaN sorts as +inf (ties by position): the ranks below stay a permutation
       }
     __syncthreads();
     if (act)
@@ -1148,7 +1149,8 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
   if (act)
     for (int i = tl; i < n2; i += 256) {
       const double ri = (R && i < nc) ? R[i >> 1] : range;
-      ekey[i] = (i < nc) ? ((i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri) : INFINITY;
+      const double k = (i < nc) ? ((i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri) : INFINITY;
+      ekey[i] = (k != k) ? INFINITY : k;
       epos[i] = i;
     }
   for (int k = 2; k <= n2; k <<= 1) {

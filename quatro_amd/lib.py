@@ -84,13 +84,14 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
 
 
 QTR_ERR_IO = 6
+QTR_ERR_NOT_RUN = 7
 
 
 def read_kitti_bin(path: str, max_points: int = 250000) -> np.ndarray:
@@ -179,6 +180,9 @@ def load():
     lib.qtr_register_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.POINTER(FrontendParams), C.POINTER(Params), C.POINTER(Result), C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_feature_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.POINTER(FrontendParams), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
@@ -216,6 +220,8 @@ def load():
     lib.qtr_comm_unique_id.argtypes = [C.c_char_p]
     lib.qtr_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     lib.qtr_gather_results.argtypes = [C.c_void_p, C.POINTER(Result), C.c_int, C.POINTER(Result)]
+    lib.qtr_gather_results_v.argtypes = [C.c_void_p, C.POINTER(Result), C.c_int, C.POINTER(Result), C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.qtr_comm_destroy.argtypes = [C.c_void_p]
     lib.qtr_comm_destroy.restype = None
     _lib = lib
@@ -486,7 +492,31 @@ class Handle:
         self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
         return _result_dict(res, cl, None, fin)
 
+    def feature_pair(self, src_raw4, tgt_raw4, fp: FrontendParams | None = None, slot: int = 0):
+        """voxelize x2 + FPFHManager::setFeaturePair (reference include/fpfh_manager.hpp:98-153) in one launch chain:
+        raw scans -> {n_src, n_tgt, L, src_kps [L,4], tgt_kps [L,4], corr [L,2]}."""
+        src_raw4, tgt_raw4 = _f4(src_raw4), _f4(tgt_raw4)
+        fp = fp or default_frontend_params()
+        cap = int(self.limits.max_corr)
+        sk = np.zeros((cap, 4), dtype=np.float32)
+        tk = np.zeros((cap, 4), dtype=np.float32)
+        corr = np.zeros((cap, 2), dtype=np.int32)
+        ns, nt, L = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.qtr_feature_pair(self._h, slot, src_raw4.ctypes.data, src_raw4.shape[0],
+                                               tgt_raw4.ctypes.data, tgt_raw4.shape[0], C.byref(fp), C.byref(ns),
+                                               C.byref(nt), C.byref(L), sk.ctypes.data, tk.ctypes.data,
+                                               corr.ctypes.data, cap, MEM_HOST))
+        return {"n_src": ns.value, "n_tgt": nt.value, "L": L.value, "src_kps": sk[:L.value].copy(),
+                "tgt_kps": tk[:L.value].copy(), "corr": corr[:L.value].copy()}
+
     # ---- device-resident entry points (torch CUDA tensors or raw pointers) -----------------------
+    def feature_pair_dev(self, src_ptr: int, Ps: int, tgt_ptr: int, Pt: int, fp: FrontendParams, slot: int = 0):
+        """front end on device-resident scans; the matched clouds stay in the slot.  Returns (rc, n_src, n_tgt, L)."""
+        ns, nt, L = C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.qtr_feature_pair(self._h, slot, src_ptr, Ps, tgt_ptr, Pt, C.byref(fp), C.byref(ns), C.byref(nt),
+                                        C.byref(L), None, None, None, 0, MEM_DEVICE)
+        return rc, ns.value, nt.value, L.value
+
     def register_pair_dev(self, src_ptr: int, Ps: int, tgt_ptr: int, Pt: int, fp: FrontendParams, prm: Params,
                           res: Result, slot: int = 0) -> int:
         return self._lib.qtr_register_pair(self._h, slot, src_ptr, Ps, tgt_ptr, Pt, C.byref(fp), C.byref(prm),
@@ -554,6 +584,15 @@ class Handle:
         out = (Result * max(world * n, 1))()
         self._check(self._lib.qtr_gather_results(self._h, results, n, out))
         return out
+
+    def gather_results_v(self, results, n_local: int, world: int, cap_all: int):
+        """Blocks of different lengths (qtr_gather_results_v).  results: ctypes array holding at least n_local records
+        (None for n_local = 0).  Returns (array of the gathered records in rank order, per-rank counts)."""
+        out = (Result * max(cap_all, 1))()
+        counts = (C.c_int * max(world, 1))()
+        n_all = C.c_int()
+        self._check(self._lib.qtr_gather_results_v(self._h, results, n_local, out, cap_all, counts, C.byref(n_all)))
+        return out, [int(c) for c in counts[:world]], n_all.value
 
     def set_stage_events(self, on: bool) -> None:
         self._lib.qtr_set_stage_events(self._h, 1 if on else 0)

@@ -262,11 +262,9 @@ def correspondences(L: int = 5000, inlier_frac: float = 0.05, seed: int = 0, noi
     return src, tgt, T, inl
 
 
-def dense_pair(n: int = 50000, seed: int = 7, yaw: float = 0.7, t=(3.0, -2.0, 0.4)):
-    """BASELINE configs[4] front-end input (dense mode: n-point clouds, no voxel step): points on a few large planes and a
-    cylinder — surface-like, ~20-60 neighbours inside r = 0.75 m.  Returns (src, tgt, perm): tgt[i] is the moved copy of
-    src[perm[i]]."""
-    rng = np.random.default_rng(seed)
+def _dense_surfaces(n: int, rng: np.random.Generator) -> np.ndarray:
+    """n points sampled on six large planes (20 mm thick) and a cylinder — surface-like, ~20-60 neighbours inside
+    r = 0.75 m."""
     parts = []
     for k in range(6):
         u = rng.random((n // 8, 2)) * np.array([120.0, 25.0])
@@ -280,14 +278,31 @@ def dense_pair(n: int = 50000, seed: int = 7, yaw: float = 0.7, t=(3.0, -2.0, 0.
     th = rng.random(n - sum(p.shape[0] for p in parts)) * 2 * np.pi
     cyl = np.stack([40 * np.cos(th), 40 * np.sin(th), rng.random(th.size) * 20 - 2], axis=1)
     parts.append(cyl)
-    pts = np.concatenate(parts).astype(np.float32)
+    return np.concatenate(parts)
+
+
+def dense_pair(n: int = 50000, seed: int = 7, yaw: float = 0.7, t=(3.0, -2.0, 0.4), independent: bool = True):
+    """BASELINE configs[4] front-end input (dense mode: n-point clouds, no voxel step).  With `independent` (default) the
+    two clouds are two INDEPENDENT samplings of the same surfaces — two scans, no point of one is a moved copy of a point
+    of the other — and the call returns (src, tgt, T) with tgt ~ T @ src as surfaces.  independent=False is round 2's
+    input: tgt[i] is the moved copy of src[perm[i]]; returns (src, tgt, perm)."""
+    rng = np.random.default_rng(seed)
+    pts = _dense_surfaces(n, rng).astype(np.float32)
     src = np.zeros((n, 4), dtype=np.float32)
     src[:, :3] = pts
     R = yaw_matrix(yaw)[:3, :3]
-    perm = rng.permutation(n)
     tgt = np.zeros((n, 4), dtype=np.float32)
-    tgt[:, :3] = (pts[perm].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
-    return src, tgt, perm
+    if not independent:
+        perm = rng.permutation(n)
+        tgt[:, :3] = (pts[perm].astype(np.float64) @ R.T + np.asarray(t)).astype(np.float32)
+        return src, tgt, perm
+    other = _dense_surfaces(n, np.random.default_rng(seed + 7919))
+    other = other[np.random.default_rng(seed + 1).permutation(n)]
+    tgt[:, :3] = (other @ R.T + np.asarray(t)).astype(np.float32)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = np.asarray(t)
+    return src, tgt, T
 
 
 def save_kitti_bin(path: str, xyzi: np.ndarray) -> None:

@@ -1,0 +1,212 @@
+"""The BASELINE.json sizes against the ORACLE (not through properties): the 16-18 k-voxel scan pairs bench.py times, the
+front-end entry point of the composite step, a batch of 64 ids of that pool, the back end at L = 20000, and the full
+n = 50 k nearest-neighbour tables of dense mode.  Everything through the C ABI; integer outputs bit-exact."""
+import numpy as np
+import pytest
+
+from quatro_amd import lib as ql
+from quatro_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+LIMITS = dict(max_points=131072, max_voxels=32768, max_corr=8192)
+
+
+def _yaw(T):
+    return float(np.arctan2(T[1, 0], T[0, 0]))
+
+
+def _same(r, o):
+    assert r["valid"] == o["valid"]
+    assert np.array_equal(r["clique"], o["clique"])
+    assert np.array_equal(r["final_inliers"], o["final_inliers"])
+    if r["valid"]:
+        d = _yaw(r["T"]) - _yaw(o["T"])
+        assert abs(np.arctan2(np.sin(d), np.cos(d))) <= ROT_TOL
+        assert np.abs(r["T"][:3, 3] - o["T"][:3, 3]).max() <= TRANS_TOL
+        assert np.array_equal(r["T"], o["T"])
+
+
+@pytest.fixture(scope="module")
+def big():
+    h = ql.Handle(0, **LIMITS)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def qo16(qo):
+    qo.set_threads(min(16, qo.max_threads()))
+    yield qo
+    qo.set_threads(min(8, qo.max_threads()))
+
+
+@pytest.fixture(scope="module")
+def pool16k():
+    return [synth.kitti64_pair_16k(i) for i in range(4)]
+
+
+def _oracle_front(qo, s, t, seed):
+    vs, vt = qo.voxelize(s, 0.3), qo.voxelize(t, 0.3)
+    ds, dt = qo.fpfh(vs, 0.5, 0.75)[2], qo.fpfh(vt, 0.5, 0.75)[2]
+    return vs, vt, ds, dt, qo.match(vs, ds, vt, dt, True, True, 0.95, seed)
+
+
+@pytest.mark.parametrize("pid", [0, 1, 2, 3])
+def test_register_pair_on_the_bench_pool_matches_oracle(big, qo16, pool16k, pid):
+    """qtr_register_pair on every pair of the bench pool (n = 15-20 k voxels per cloud) against the oracle's whole path."""
+    s, t, Tgt = pool16k[pid]
+    r = big.register_pair(s, t, ql.default_frontend_params(seed=pid))
+    o = qo16.register_pair(s, t, seed=pid)
+    assert r["n_src"] >= 13000 and r["n_tgt"] >= 13000
+    assert (r["n_src"], r["n_tgt"], r["L"]) == (o["n_src"], o["n_tgt"], o["L"])
+    _same(r, o)
+    d = _yaw(r["T"]) - _yaw(Tgt)
+    assert abs(np.arctan2(np.sin(d), np.cos(d))) < 0.02 and np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) < 0.5
+
+
+@pytest.mark.parametrize("pid", [0, 3])
+def test_feature_pair_matches_oracle_stages_and_register_pair(big, qo16, pool16k, pid):
+    """qtr_feature_pair (voxelize x2 + FPFHManager::setFeaturePair, reference include/fpfh_manager.hpp:98-153): counts,
+    correspondence list and matched keypoints equal the oracle's stage functions; a qtr_solve on its keypoints equals
+    qtr_register_pair (the composite bench step is these two calls)."""
+    s, t, _ = pool16k[pid]
+    f = big.feature_pair(s, t, ql.default_frontend_params(seed=pid))
+    vs, vt, ds, dt, corr = _oracle_front(qo16, s, t, pid)
+    assert (f["n_src"], f["n_tgt"], f["L"]) == (vs.shape[0], vt.shape[0], corr.shape[0])
+    assert np.array_equal(f["corr"], corr)
+    assert np.array_equal(f["src_kps"][:, :3], vs[corr[:, 0], :3]) and np.array_equal(f["tgt_kps"][:, :3], vt[corr[:, 1], :3])
+    whole = big.register_pair(s, t, ql.default_frontend_params(seed=pid))
+    again = big.solve(f["src_kps"], f["tgt_kps"])
+    assert np.array_equal(again["clique"], whole["clique"]) and np.array_equal(again["T"], whole["T"])
+    # device-resident form: the counts come back, the matched clouds stay in the slot, the next call may follow at once
+    import torch
+    sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    rc, ns, nt, L = big.feature_pair_dev(sd.data_ptr(), s.shape[0], td.data_ptr(), t.shape[0],
+                                         ql.default_frontend_params(seed=pid))
+    assert (rc, ns, nt, L) == (ql.QTR_OK, f["n_src"], f["n_tgt"], f["L"])
+    assert np.array_equal(big.debug_fetch(ql.DBG_CORR, np.int32).reshape(-1, 2)[:L], corr)
+
+
+def test_feature_pair_rejects_what_the_reference_rejects(big):
+    s, t, _ = synth.kitti64_pair(1)
+    with pytest.raises(ql.QuatroHipError) as ei:  # fpfh_manager.hpp:101
+        big.feature_pair(s, t, ql.default_frontend_params(normal_radius=1.0, fpfh_radius=0.5))
+    assert ei.value.code == ql.QTR_ERR_BAD_ARG
+    with pytest.raises(ql.QuatroHipError):
+        big.feature_pair(np.zeros((0, 4), np.float32), t)
+
+
+def test_batch_of_64_ids_of_the_bench_pool_against_oracle_records(qo16, pool16k):
+    """qtr_submit_batch / qtr_wait on 64 pair ids of the 16 k pool (4 pairs x 4 tuple-test seeds) against the ORACLE's
+    records — not only against sequential device runs."""
+    ids = list(range(64))
+    ref = {}
+    for i in ids:
+        key = (i % 4, (i // 4) % 4)
+        if key not in ref:
+            s, t, _ = pool16k[key[0]]
+            ref[key] = qo16.register_pair(s, t, seed=key[1])
+    hb = ql.Handle(0, n_slots=16, **LIMITS)
+    try:
+        got = hb.register_batch([(pool16k[i % 4][0], pool16k[i % 4][1], (i // 4) % 4) for i in ids])
+        for i, g in zip(ids, got):
+            o = ref[(i % 4, (i // 4) % 4)]
+            assert (g["n_src"], g["n_tgt"], g["L"]) == (o["n_src"], o["n_tgt"], o["L"]), i
+            _same(g, o)
+    finally:
+        hb.close()
+
+
+def test_solver_at_L20000_matches_oracle(qo16):
+    """BASELINE configs[4]'s back end: 20000 correspondences, 2 % planted inliers — bit matrix (50 MB), core numbers,
+    clique, inlier sets and transform against the oracle."""
+    L = 20000
+    src, tgt, T, inl = synth.correspondences(L, 0.02, seed=7, noise=0.1)
+    h = ql.Handle(0, max_points=65536, max_voxels=65536, max_corr=24576)
+    try:
+        r = h.solve(src, tgt)
+        bm_g = h.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(L, -1)
+        core_g = h.debug_fetch(ql.DBG_CORE, np.int32)
+    finally:
+        h.close()
+    o = qo16.solve(src, tgt)
+    bm_o = qo16.build_graph(src, tgt, 0.3, 1.0)
+    assert np.array_equal(bm_g, bm_o)
+    assert np.array_equal(core_g, qo16.kcore(bm_o)[0])
+    assert r["max_core"] == o["max_core"] and r["n_edges"] == o["n_edges"]
+    _same(r, o)
+    assert np.array_equal(r["rot_inliers"], o["rot_inliers"]) and r["gnc_iters"] == o["gnc_iters"]
+    assert set(inl).issubset(set(r["clique"]))
+
+
+def test_dense_mode_front_end_at_50k_points_matches_oracle(qo16):
+    """BASELINE configs[4]'s front end: two INDEPENDENTLY sampled 50 000-point clouds (no voxel step) through FPFH and
+    matching — descriptors, both complete nearest-neighbour tables (50 k x 50 k brute force on the oracle's side) and the
+    correspondence list against the oracle."""
+    n = 50000
+    src, tgt, T = synth.dense_pair(n, seed=7)
+    h = ql.Handle(0, max_points=65536, max_voxels=65536, max_corr=24576)
+    try:
+        nsrc, ds = h.fpfh(src, 0.5, 0.75)
+        ntgt, dt = h.fpfh(tgt, 0.5, 0.75)
+        os_, ot_ = qo16.fpfh(src, 0.5, 0.75), qo16.fpfh(tgt, 0.5, 0.75)
+        for d, o in ((ds, os_[2]), (dt, ot_[2])):
+            assert np.array_equal(np.isnan(d), np.isnan(o))
+            assert np.array_equal(np.nan_to_num(d).view(np.uint32), np.nan_to_num(o).view(np.uint32))
+        corr = h.match(src, ds, tgt, dt, ql.default_frontend_params(seed=3))
+        nn_ij_g = h.debug_fetch(ql.DBG_NN_LARGE_OF_SMALL, np.int32)
+        nn_ji_g = h.debug_fetch(ql.DBG_NN_SMALL_OF_LARGE, np.int32)
+    finally:
+        h.close()
+    corr_o, nn_ij, nn_ji = qo16.match(src, os_[2], tgt, ot_[2], seed=3, debug=True)
+    assert np.array_equal(nn_ij_g, nn_ij)          # every row of one cloud against the other: 2.5e9 distances
+    assert np.array_equal(nn_ji_g, nn_ji)          # the rows the first direction pointed at (-1 elsewhere)
+    assert np.array_equal(corr, corr_o)
+
+
+def test_batch_of_mixed_sizes_in_one_lane_group_equals_sequential_calls():
+    """Group launches pick kernel variants (level-parallel / peeling / h-index core numbers, merged first clique round,
+    LDS sizing, fused matcher tails) from the LARGEST pair of the group, so a small pair batched with a large one runs
+    other code than in qtr_register_pair.  One lane group holding L = 0, L < 1280, 1280 < L < 3000 and L > 3000, clouds
+    on both sides of 16384 and 32768 voxels, against sequential calls."""
+    rng = np.random.default_rng(5)
+    s16, t16, _ = synth.kitti64_pair_16k(0)
+    s9, t9, _ = synth.kitti64_pair(1)
+
+    def jitter(a, sig):
+        b = a.copy()
+        b[:, :3] += rng.normal(0, sig, (a.shape[0], 3)).astype(np.float32)
+        return b
+    iso = np.zeros((3, 4), dtype=np.float32)
+    iso[:, 0] = [0.0, 50.0, 100.0]
+    wide = np.concatenate([s16, s16 + np.float32([300, 0, 0, 0]), s9 + np.float32([0, 300, 0, 0])])  # > 32768 voxels
+    pairs = [(s9, t9, 1), (s16, t16, 0), (s16, jitter(s16, 0.005), 2), (s16, jitter(s16, 0.02), 3), (iso, iso.copy(), 4),
+             (wide, jitter(wide, 0.01), 5), (s9, t9, 6), (iso, t9, 7)]
+    lim = dict(max_points=262144, max_voxels=65536, max_corr=24576)
+    h1 = ql.Handle(0, **lim)
+    try:
+        seq = []
+        for s, t, seed in pairs:
+            try:
+                seq.append(h1.register_pair(s, t, ql.default_frontend_params(seed=seed)))
+            except ql.QuatroHipError as e:
+                seq.append({"status": e.code})
+    finally:
+        h1.close()
+    Ls = [r.get("L", -1) for r in seq]
+    assert any(L == 0 for L in Ls) and any(0 < L < 1280 for L in Ls) and any(1280 < L < 3000 for L in Ls) and \
+        any(L > 3000 for L in Ls), Ls
+    assert any(r.get("n_src", 0) > 32768 for r in seq) and any(16384 < r.get("n_tgt", 0) < 32768 for r in seq)
+    hb = ql.Handle(0, n_slots=16, **lim)   # two lanes of 8: all eight pairs share one lane group
+    try:
+        got = hb.register_batch(pairs)
+    finally:
+        hb.close()
+    for i, (g, r) in enumerate(zip(got, seq)):
+        assert g["status"] == r["status"], (i, g["status"], r["status"])
+        if "T" not in r:
+            continue
+        assert (g["n_src"], g["n_tgt"], g["L"]) == (r["n_src"], r["n_tgt"], r["L"]), i
+        assert np.array_equal(g["clique"], r["clique"]) and np.array_equal(g["final_inliers"], r["final_inliers"]), i
+        assert np.array_equal(g["T"], r["T"]) or not r["valid"], i

@@ -695,7 +695,7 @@ def test_dense_mode_front_end_at_50k_points(qo):
     at n = 50 k via properties (descriptor blocks sum to 100 or 0, rigid-motion invariance of the matching) and
     a sampled exact check of the nearest-neighbour tables against brute force."""
     n = 50000
-    src, tgt, perm = synth.dense_pair(n, seed=7)
+    src, tgt, perm = synth.dense_pair(n, seed=7, independent=False)  # moved copy: the invariance properties need it
     rng = np.random.default_rng(70)
     h = ql.Handle(0, max_points=65536, max_voxels=65536, max_corr=24576)
     try:
@@ -1354,6 +1354,15 @@ def test_rccl_gather_of_result_records_through_the_c_abi():
                 res[i].T[k] = i + 0.5 * k
         out = h.gather_results(res, 1)
         assert bytes(C.string_at(C.addressof(out), C.sizeof(res))) == bytes(C.string_at(C.addressof(res), C.sizeof(res)))
+        # the variable-length form (uneven block partitions): counts first, then the records; a rank may hold none
+        out2, counts, n_all = h.gather_results_v(res, 2, 1, 8)
+        assert counts == [2] and n_all == 2
+        assert bytes(C.string_at(C.addressof(out2), 2 * C.sizeof(ql.Result))) == bytes(C.string_at(C.addressof(res), 2 * C.sizeof(ql.Result)))
+        _, counts, n_all = h.gather_results_v(None, 0, 1, 8)
+        assert counts == [0] and n_all == 0
+        with pytest.raises(ql.QuatroHipError) as ei:   # more records than the caller made room for: refused, not overrun
+            h.gather_results_v(res, 3, 1, 2)
+        assert ei.value.code == ql.QTR_ERR_CAPACITY
         src, tgt, _, _ = synth.correspondences(300, 0.2, seed=1, noise=0.2)   # the handle still registers afterwards
         assert h.solve(src, tgt)["valid"]
     finally:

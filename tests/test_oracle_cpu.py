@@ -1199,3 +1199,39 @@ def test_spfh_role_swap_shortcut_logic_against_the_oracle_arithmetic(qo):
     assert fast.mean() > 0.4
     assert not want[eq].any()
     assert np.array_equal((x1 < x2)[fast].astype(np.float32), want[fast])
+
+
+def test_shared_math_header_against_an_independent_libm(qo):
+    """include/qtr_math.h (atan2f / acosf / sinf / cosf) is compiled into BOTH the HIP library and the oracle, so their
+    agreement is self-agreement; this pins the header itself against numpy's float64 functions rounded once to float32
+    — what a correctly rounded libm returns.  2e6 inputs per function, including the quadrant borders and tiny
+    arguments; at most 1e-6 of them may differ (0 were seen), and never by more than 1 ulp."""
+    rng = np.random.default_rng(20260925)
+    n = 2_000_000
+
+    def ulp_diff(got, want):
+        g = np.ascontiguousarray(got, dtype=np.float32).view(np.int32).astype(np.int64)
+        w = np.ascontiguousarray(want, dtype=np.float32).view(np.int32).astype(np.int64)
+        g = np.where(g < 0, -(g & 0x7fffffff), g)
+        w = np.where(w < 0, -(w & 0x7fffffff), w)
+        return np.abs(g - w)
+
+    y = np.concatenate([rng.uniform(-1.5, 1.5, n - 4000), rng.uniform(-1e-6, 1e-6, 2000), rng.uniform(-1e3, 1e3, 1992),
+                        [0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 1e-30, -1e-30]]).astype(np.float32)
+    x = np.concatenate([rng.uniform(-1.5, 1.5, n - 4000), rng.uniform(-1e-6, 1e-6, 2000), rng.uniform(-1e3, 1e3, 1992),
+                        [1.0, 1.0, 0.0, 0.0, -1.0, -1.0, -1.0, -1.0]]).astype(np.float32)
+    cases = [
+        ("atan2f", qo.math_fn(0, y, x), np.arctan2(y.astype(np.float64), x.astype(np.float64))),
+    ]
+    a = np.concatenate([rng.uniform(-1.0, 1.0, n - 6), [1.0, -1.0, 0.0, -0.0, 0.99999994, -0.99999994]]).astype(np.float32)
+    cases.append(("acosf", qo.math_fn(1, a), np.arccos(a.astype(np.float64))))
+    th = np.concatenate([rng.uniform(-np.pi, np.pi, n - 4), [0.0, -0.0, 1.5707964, 3.1415927]]).astype(np.float32)
+    cases.append(("sinf", qo.math_fn(2, th), np.sin(th.astype(np.float64))))
+    cases.append(("cosf", qo.math_fn(3, th), np.cos(th.astype(np.float64))))
+    for name, got, want64 in cases:
+        want = want64.astype(np.float32)
+        d = ulp_diff(got, want)
+        # +0 / -0 results (atan2 of signed zeros) are compared as values
+        d = np.where((got == 0) & (want == 0), 0, d)
+        assert d.max() <= 1, (name, int(d.max()))
+        assert (d > 0).mean() <= 1e-6, (name, int((d > 0).sum()))
