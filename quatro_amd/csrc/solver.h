@@ -53,6 +53,11 @@ struct SolverView {
   qtr_result* res;
   int* mail;
   int seq;
+  // degrees as k_graph_build leaves them: one byte per (64-column block k, vertex v) = popcount of word k of row v, at
+  // degp[k * Lp + v] (every entry has exactly one writer: no atomics); null when V.deg already holds the degrees
+  // (qtr_max_clique).  Readers go through solver_degree().
+  const unsigned char* degp;
+  int Lp;
 };
 struct SolverArgs {
   SolverView one;

@@ -13,15 +13,25 @@
 #include "solver.h"
 
 // =================================================================================================
-// K9+K10+K11: consistency graph.  One wavefront per row; lane l evaluates column w*64+l and the 64
-// predicate bits are packed with __ballot.  Every lane keeps "its" word of a 64-word group so the row
-// is written back as coalesced 512-byte segments.
+// K9+K10+K11: consistency graph, 64 x 64 tiles of the UPPER triangle, one per workgroup (its four waves take 16 rows
+// each).  The 64 points of the row block are staged in LDS; a lane holds ITS column's point pair in
+// registers, the 64 row points are broadcast from LDS one after the other, the 64 predicate bits of a row are packed
+// with __ballot (-> word `cb` of row i) and every lane collects its own column's bits over the 64 rows (-> word `rb` of
+// row j: the transposed tile, so the lower triangle is never evaluated).  Degrees: every (64-column block, vertex) pair is
+// one word of the matrix and has exactly one writer, which leaves that word's popcount as a byte in degp; the kernels that
+// need degrees add a row's bytes up (solver_degree) — no atomics (device-scope atomics on this 8-XCD part cost the first
+// version of this kernel more than the tiles themselves), nothing to zero.
 //
 // Predicate (reference :372-385): |b/a - 1| <= beta/a  AND  |a/b - 1| <= beta/b, a=|src TIM|, b=|tgt TIM|.
-// In exact arithmetic both sides are |b - a| <= beta, i.e. (a^2+b^2-beta^2)^2 <= 4 a^2 b^2 when the
-// left base is positive.  That division/sqrt-free form decides every pair whose margin is > 1e-9
-// relative; the remaining (borderline) pairs run the reference expression verbatim, so the result is
-// bit-identical to evaluating the reference expression everywhere.
+// In exact arithmetic both sides are |a - b| <= beta, i.e. with s = a^2, t = b^2 and s + t > beta^2:
+//     (s - t)^2 <= 2 beta^2 (s + t) - beta^4.
+// The tile loop SCREENS in binary32 — source and target ride in the two halves of packed registers (v_pk_add / v_pk_mul /
+// v_pk_fma: 6 instructions for both squared lengths) — and decides a pair only when the two sides differ by more than
+// `margin` relative (a rigorous bound on the binary32 error, see graph_margin(): ~4e-4 for beta = 0.6, which puts
+// ~1 pair in 10^5 inside the band); everything else — the band, s + t <= beta^2 (short TIMs, zero-length TIMs with
+// their inf/NaN in the reference expression), s + t > 65536, non-finite input — is decided by pair_consistent(), the
+// reference expression in binary64 evaluated verbatim.  The result is bit-identical to evaluating the reference
+// expression everywhere (the margin is orders of magnitude wider than its own rounding).
 __device__ __forceinline__ bool pair_consistent(double s, double t, double beta, double beta2) {
   if (s > 0.0 && t > 0.0) {
     const double u = s + t - beta2;
@@ -36,46 +46,178 @@ __device__ __forceinline__ bool pair_consistent(double s, double t, double beta,
   const bool rev = fabs(a / b - 1.0) <= beta * (1.0 / b);
   return fwd && rev;
 }
+// degree of vertex v: the sum of its row's per-block popcounts (see SolverView::degp)
+__device__ __forceinline__ int solver_degree(const SolverView& V, int v) {
+  if (!V.degp) return V.deg[v];
+  const unsigned char* __restrict__ p = V.degp + v;
+  const int nb = (V.L + 63) >> 6, Lp = V.Lp;
+  int d = 0;
+  int k = 0;
+  for (; k + 4 <= nb; k += 4) {
+    const int a = p[(size_t)k * Lp], b = p[(size_t)(k + 1) * Lp], c = p[(size_t)(k + 2) * Lp], e = p[(size_t)(k + 3) * Lp];
+    d += (a + b) + (c + e);
+  }
+  for (; k < nb; ++k) d += p[(size_t)k * Lp];
+  return d;
+}
+#define GB_SMAX 65536.0f  // s + t above this (TIMs longer than ~180 m) are left to the binary64 path
+// Relative half-width of the band the binary32 screen leaves undecided.  With u = 2^-24: s and t carry a relative error
+// <= 5u (difference 1u, square 2u, three fused accumulations), so D = fl(s - t) is off by <= 5u (s + t) + u |D| and, where
+// the decision is close (D^2 ~ G = 2 beta^2 (s+t) - beta^4 >= beta^2 (s+t)), D^2 by <= 2 sqrt(2) beta 5u (s+t)^1.5, i.e.
+// <= 2 sqrt(2) 5u sqrt(s+t) / beta relative to G; G itself is off by <= 18u G and the final subtraction by u.  Three
+// times that bound is used.  A margin above 0.05 (beta below ~0.01) switches the screen off (margin < 0).
+static float graph_margin(double beta) {
+  const double u = 1.0 / 16777216.0;
+  const double m = 3.0 * (2.0 * sqrt(2.0) * 5.0 * u * sqrt((double)GB_SMAX) / beta + 20.0 * u);
+  return (m > 0.05 || !(beta > 0.0)) ? -1.0f : (float)m;
+}
+typedef float gb_f2 __attribute__((ext_vector_type(2)));
 
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta) {
+__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta, float margin) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L, W = V.W;
+  const int nb = (L + 63) >> 6;
+  // workgroup t -> tile (rb, cb), rb <= cb, row by row over the upper triangle: row rb starts at rb nb - rb (rb - 1) / 2.
+  // (Grouping the tiles into 8 x 8 super-tiles dealt to one XCD each, so that the eight writers of a 64-byte line of the
+  // matrix meet in one L2, was tried: 125 -> 136 us at L = 20000.  The kernel is bound by instruction issue, not by its
+  // 8-byte stores.)
+  int rb, cb;
+  {
+    const int t = blockIdx.x;
+    if (t >= nb * (nb + 1) / 2) return;
+    const float q = (float)(2 * nb + 1);  // (binary32 estimate, corrected by the two loops below)
+    rb = (int)((q - __builtin_sqrtf(fmaxf(q * q - 8.0f * (float)t, 0.0f))) * 0.5f);
+    rb = max(0, min(rb, nb - 1));
+    while (rb > 0 && rb * nb - rb * (rb - 1) / 2 > t) --rb;
+    while (rb + 1 < nb && (rb + 1) * nb - (rb + 1) * rb / 2 <= t) ++rb;
+    cb = rb + (t - (rb * nb - rb * (rb - 1) / 2));
+  }
   const float4* __restrict__ src = V.src;
   const float4* __restrict__ tgt = V.tgt;
-  const int L = V.L, W = V.W;
   u64* __restrict__ bm = V.bm;
-  int* __restrict__ deg = V.deg;
-  const int lane = qk_lane();
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= L) return;
-  const float4 si = src[row], ti = tgt[row];
-  const double six = si.x, siy = si.y, siz = si.z, tix = ti.x, tiy = ti.y, tiz = ti.z;
-  const double beta2 = beta * beta;
-  int degacc = 0;
-  for (int w0 = 0; w0 < W; w0 += 64) {
-    u64 myword = 0;
-    const int wend = min(64, W - w0);
-    for (int ww = 0; ww < wend; ++ww) {
-      const int j = (w0 + ww) * 64 + lane;
-      bool e = false;
-      if (j < L && j != row) {
-        const float4 sj = src[j], tj = tgt[j];
-        const double dx = (double)sj.x - six, dy = (double)sj.y - siy, dz = (double)sj.z - siz;
-        const double ex = (double)tj.x - tix, ey = (double)tj.y - tiy, ez = (double)tj.z - tiz;
-        const double s = dx * dx + (dy * dy + dz * dz);
-        const double t = ex * ex + (ey * ey + ez * ez);
-        e = pair_consistent(s, t, beta, beta2);
-      }
-      const u64 b = __ballot(e);
-      if (lane == ww) myword = b;
+  unsigned char* __restrict__ degp = const_cast<unsigned char*>(V.degp);
+  const int Lp = V.Lp;
+  // A single wavefront issues one vector instruction every ~8 clocks (tests/probe/clk_probe.hip), so a tile walked by
+  // one wave takes ~10 us whatever the machine is doing; the tile's 64 rows are dealt to the four waves of the
+  // workgroup, 16 each.  Row points: per row (sx, tx, sy, ty) and (sz, tz) in LDS — one 16-byte and one 8-byte broadcast
+  // read per row; every wave stages its own 16 rows (no workgroup barrier in front of the arithmetic).
+  __shared__ __attribute__((aligned(16))) float4 rxy[64];
+  __shared__ __attribute__((aligned(8))) gb_f2 rz[64];
+  __shared__ unsigned short colpart[4][64];
+  // (readfirstlane: tells the compiler that the wave index — and every lane mask derived from it — is wave-uniform, so
+  // the masks stay in scalar registers and the branches on them are scalar branches)
+  const int lane = qk_lane(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i0 = rb * 64, r0 = wave * 16;
+  const int j = cb * 64 + lane;
+  const bool jvalid = j < L;
+  gb_f2 cx, cy, cz;
+  {
+    const int jj = min(j, L - 1);
+    const float4 a = src[jj], b = tgt[jj];
+    if (lane < 16) {
+      const int i = min(i0 + r0 + lane, L - 1);
+      const float4 ra = src[i], rbp = tgt[i];
+      rxy[r0 + lane] = make_float4(ra.x, rbp.x, ra.y, rbp.y);
+      rz[r0 + lane] = gb_f2{ra.z, rbp.z};
     }
-    if (lane < wend) {
-      bm[(size_t)row * W + w0 + lane] = myword;
-      degacc += __popcll(myword);
+    cx = gb_f2{a.x, b.x};
+    cy = gb_f2{a.y, b.y};
+    cz = gb_f2{a.z, b.z};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float fb2 = (float)(beta * beta);
+  const float c1 = 2.0f * fb2, c2 = fb2 * fb2;
+  const float smin = fb2 * 1.01f;  // above it s + t - beta^2 > 0 holds in exact arithmetic too: the squared form is valid
+  const double beta2 = beta * beta;
+  const int nrows = min(64, L - i0);
+  const bool diag = cb == rb;
+  // lane masks live in scalar registers.  `act`: the columns that exist.  The row's own column (diagonal tile) and the
+  // rows past the end of the last block go through the loop like everything else — their bits are cleared afterwards.
+  const u64 act = __ballot(jvalid);
+  u32 row_lo = 0, row_hi = 0, cacc = 0;
+  for (int rr = r0; rr < r0 + 16; rr += 8) {
+    // eight rows at a time: the arithmetic of the eight is independent (the scheduler interleaves it), and the one
+    // scalar branch per group asks whether ANY of the 512 pairs fell into the band the binary32 screen leaves undecided
+    u64 m_lt[8], need[8];
+    u64 any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 pxy = rxy[rr + k];
+      const gb_f2 pz = rz[rr + k];
+      const gb_f2 dx = cx - gb_f2{pxy.x, pxy.y}, dy = cy - gb_f2{pxy.z, pxy.w}, dz = cz - pz;
+      gb_f2 q = dx * dx;
+      q = __builtin_elementwise_fma(dy, dy, q);
+      q = __builtin_elementwise_fma(dz, dz, q);  // (s, t): squared TIM lengths of (source, target)
+      const float S = q.x + q.y, D = q.x - q.y;
+      const float G = __builtin_fmaf(S, c1, -c2);
+      const float z = __builtin_fmaf(D, D, -G);  // < 0: consistent
+      m_lt[k] = __ballot(z < 0.0f);
+      const u64 sure = __ballot(__builtin_fabsf(z) > margin * G) & __ballot(S > smin) & __ballot(S < GB_SMAX);
+      need[k] = act & ~sure;
+      any |= need[k];
+    }
+    if (any != 0) {  // rare: the band is ~1e-5 of the pairs, plus TIMs shorter than beta
+      // Not to be decided at all (their bits are cleared below; a zero-length TIM would cost a binary64 evaluation every
+      // time): a vertex paired with itself on the diagonal tile, and the rows past the end of the last block.
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (diag) need[k] &= ~(1ULL << (rr + k));
+        if (rr + k >= nrows) need[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (need[k] != 0) {
+          bool ex = false;
+          if ((need[k] >> lane) & 1) {
+            const float4 pxy = rxy[rr + k];
+            const gb_f2 pz = rz[rr + k];
+            const double ex_ = (double)cx.x - (double)pxy.x, ey = (double)cy.x - (double)pxy.z, ez = (double)cz.x - (double)pz.x;
+            const double fx = (double)cx.y - (double)pxy.y, fy = (double)cy.y - (double)pxy.w, fz = (double)cz.y - (double)pz.y;
+            const double s = ex_ * ex_ + (ey * ey + ez * ez);
+            const double t = fx * fx + (fy * fy + fz * fz);
+            ex = pair_consistent(s, t, beta, beta2);
+          }
+          m_lt[k] = (m_lt[k] & ~need[k]) | (__ballot(ex) & need[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 e = m_lt[k] & act;
+      // lane (r mod 16) keeps row r's word (lane select through m0: a second scalar register would break the
+      // one-constant-bus operand rule of this instruction set)
+      asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                   : "+v"(row_lo), "+v"(row_hi)
+                   : "s"((u32)e), "s"((u32)(e >> 32)), "s"(rr + k - r0)
+                   : "m0");
+      u64 junk;
+      // every lane shifts its own bit of `e` into its column word: cacc = 2 cacc + e[lane] (bit order reversed below)
+      asm volatile("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(cacc), "=s"(junk) : "s"(e));
     }
   }
-  const int d = wave_sum_i32(degacc);
-  if (lane == 0) deg[row] = d;  // the edge total is reduced in k_kcore (no hot-address atomics here)
+  // rows: lane l < 16 of wave w holds the word of row 16 w + l
+  {
+    u64 roww = ((u64)row_hi << 32) | row_lo;
+    const int r = r0 + lane;
+    if (diag) roww &= ~(1ULL << (r & 63));  // a vertex is not its own neighbour (the row word covers both triangles)
+    if (lane < 16 && r < nrows) {
+      bm[(size_t)(i0 + r) * W + cb] = roww;
+      degp[(size_t)cb * Lp + i0 + r] = (unsigned char)__popcll(roww);
+    }
+  }
+  if (diag) return;  // (uniform over the workgroup) the diagonal tile's row words already hold both triangles
+  // columns: the wave's 16 bits (first row in bit 15 after the shifts) — four pieces per column, put together by wave 0
+  colpart[wave][lane] = (unsigned short)(__brev(cacc) >> 16);
+  __syncthreads();
+  if (wave == 0 && jvalid) {
+    u64 colw = (u64)colpart[0][lane] | ((u64)colpart[1][lane] << 16) | ((u64)colpart[2][lane] << 32) |
+               ((u64)colpart[3][lane] << 48);
+    if (nrows < 64) colw &= (1ULL << nrows) - 1ULL;  // rows past the end of the last block
+    bm[(size_t)j * W + rb] = colw;
+    degp[(size_t)rb * Lp + j] = (unsigned char)__popcll(colw);
+  }
 }
 
 // =================================================================================================
@@ -118,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverVie
   {
     int esum = 0;
     for (int v = tid; v < L; v += nthr) {
-      const int d = deg_in[v];
+      const int d = solver_degree(V, v);
       deg[v] = d;
       esum += d;
     }
@@ -212,7 +354,9 @@ __global__ __launch_bounds__(256) void k_hcore_init(ViewExt<SolverView> x, Solve
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v < V.L) {
-    V.core[v] = V.deg[v];
+    const int d = solver_degree(V, v);
+    V.deg[v] = d;  // k_hcore_finish adds them up
+    V.core[v] = d;
     V.Kp[v] = 0;  // the sweep from which on the vertex has to be looked at again (Kp is not in use yet)
   }
   if (v < HC_MAXIT + 1) V.perm[v] = 0;  // per-sweep "something changed" flags (perm is not in use yet)
@@ -379,7 +523,7 @@ __global__ __launch_bounds__(256) void k_kcore_levels(ViewExt<SolverView> x, Sol
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
       const int v = i * 256 + tid;
-      mydeg[i] = (v < L) ? deg_in[v] : -1;
+      mydeg[i] = (v < L) ? solver_degree(V, v) : -1;
       const bool a = mydeg[i] >= k;
       amask |= a ? (1u << i) : 0u;
       const u64 mk = __ballot(a);
@@ -457,7 +601,7 @@ __global__ __launch_bounds__(1024) void k_kcore_collect_rank(ViewExt<SolverView>
   for (int i = 0; i < 2; ++i) {
     const int v = i * 1024 + tid;
     if (v < L) {
-      const int dv = deg_in[v];
+      const int dv = solver_degree(V, v);
       int lo = 0, hi = min(dv, K);  // invariant: member at lo (k = 0: everybody), not above hi
       const u64* col = M + (v >> 6);
       const int bv = v & 63;
@@ -1750,6 +1894,10 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
 static SolverView make_solver_view(const SolverBufs& B, const float4* src, const float4* tgt, int L) {
   SolverView V;
   memset(&V, 0, sizeof(V));
+  // per-block degree bytes live in the clique search's pick lists (unused until the descents start): ceil(L / 64) x Lp
+  // bytes of its 4096 L; a view without points (qtr_max_clique) carries finished degrees in deg instead
+  V.Lp = (L + 63) & ~63;
+  V.degp = src ? (const unsigned char*)B.picks_buf : nullptr;
   V.src = src;
   V.tgt = tgt;
   V.L = L;
@@ -1969,7 +2117,10 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
-    LAUNCH_SV(k_graph_build, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, beta);
+    {
+      const int nb = (L + 63) / 64;  // 64 x 64 tiles of the upper triangle, one per workgroup
+      LAUNCH_SV(k_graph_build, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta));
+    }
     if (ev_graph) hipEventRecord(ev_graph, stream);
     clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream);
   }
