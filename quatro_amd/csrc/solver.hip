@@ -451,15 +451,224 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
     }
   }
 }
+// K12d: the same fixed-point iteration in ONE launch.  The sweeps above are 20 - 35 dependent launches of a few
+// microseconds of work each (plus the ones that find nothing left to do): half of the whole solve at L = 5000, two
+// thirds at L = 20000.  Here the workgroups of one launch stay resident and iterate WITHOUT barriers between them:
+//   * workgroup w owns a contiguous block of rows, kept in LDS when they fit (the bit matrix is read once);
+//   * the current values live in a global array of 16-bit words that is read and written with device-scope relaxed
+//     atomics only (every access goes to the coherence point of the 8 XCDs; no fences, so no L2 write-back/invalidate —
+//     which is what made a grid barrier cost more than a launch on this part).  An iteration of a workgroup = snapshot
+//     of all L values into LDS (vertices whose value moved since the previous snapshot are marked dirty), h-index of
+//     those of its own rows that have a dirty neighbour, new values stored.  A stale value is an upper bound, values only decrease, and the iteration from
+//     any upper bounds converges to the core numbers (Montresor et al. 2013), so no ordering between workgroups is needed;
+//   * termination without a contended word (256 workgroups doing compare-and-swap on one address cost milliseconds:
+//     a device-scope atomic is a round trip to memory): every workgroup has its own version counter ver[w], bumped after
+//     it stored lowered values, and its own mark done[w].  The "epoch" is the vector ver[] (its sum E is monotone).  An
+//     iteration reads ver[] BEFORE its snapshot; if nothing changed it reads ver[] again, and if the two reads agree no
+//     workgroup published a change in between: the workgroup's rows are a fixed point of a snapshot taken at epoch E.
+//     It writes done[w] = E + 1 and polls: ver[] moved -> iterate again; every done[u] == E + 1 -> finished.  (No
+//     workgroup can register at E after the first bump beyond E became visible, and the first workgroup to bump beyond
+//     E cannot have registered at E — it would have had to be woken by an earlier bump.  So "all marks equal E + 1"
+//     means everybody verified its rows against the values that stand.)  All workgroups of a pair must be co-resident
+//     (the host sizes the grid for that: at most one workgroup per compute unit).
+// If HCA_MAXITER iterations do not suffice (never seen) the failure flag sends the pair to the peeling kernel.
+#define HCA_THREADS 1024
+#define HCA_MAXITER 4096
+#define HCA_CTL_FAILED 2   // ints of V.perm: [2] failed, [3] iterations of the slowest workgroup,
+#define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
+#define HCA_MAXWG 1024
+#define HCA_CTL_VER 64
+#define HCA_CTL_DONE (64 + HCA_MAXWG)
+__device__ __forceinline__ unsigned hca_load_u32(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 hca_load_u64(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_hcore_async_init(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < V.L) {
+    const int d = solver_degree(V, v);
+    V.deg[v] = d;  // k_hcore_finish adds them up
+    ((unsigned short*)V.Kp)[v] = (unsigned short)min(d, 65535);  // the values (Kp is not in use yet)
+  }
+  if (v < HCA_CTL_DONE + HCA_MAXWG) V.perm[v] = 0;  // control words, versions, marks (perm is not in use yet; L > 3000)
+}
+template <bool EXT>
+__global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int rows_in_lds) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const int NWG = gridDim.x, w = blockIdx.x;
+  const int R = (L + NWG - 1) / NWG;
+  const int r_lo = min(L, w * R), r_hi = min(L, r_lo + R), nown = r_hi - r_lo;
+  const u64* __restrict__ bm = V.bm;
+  unsigned short* gvals = (unsigned short*)V.Kp;
+  unsigned* ver = (unsigned*)V.perm + HCA_CTL_VER;
+  unsigned* done = (unsigned*)V.perm + HCA_CTL_DONE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hca_lds[];
+  const int Lp = (L + 63) & ~63;
+  unsigned short* vals = (unsigned short*)hca_lds;                 // [Lp] the snapshot
+  u64* dirty = (u64*)(hca_lds + (size_t)2 * Lp);                   // [W] vertices whose value moved since my last snapshot
+  u64* rows = (u64*)(hca_lds + (size_t)2 * Lp + (size_t)8 * W);    // [nown][W] when rows_in_lds
+  __shared__ unsigned s_sum[HCA_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (rows_in_lds)
+    for (int e = tid; e < nown * W; e += HCA_THREADS) rows[e] = bm[(size_t)r_lo * W + e];
+  for (int i = tid; i < (Lp >> 1); i += HCA_THREADS) ((unsigned*)vals)[i] = 0xffffffffu;  // "everything moved" the first time
+  unsigned myver = 0;  // (thread 0) this workgroup's version counter
+  unsigned v0 = 0, E0 = 0;
+  bool bump = false;      // values were lowered in the previous iteration: ver[w] has to follow once they have landed
+  bool v0_valid = false;  // v0 / E0 were read before the snapshot of THIS iteration (only then may it claim a fixed point)
+  int iter = 0;
+  bool finished = false;
+  __syncthreads();
+  for (; iter < HCA_MAXITER && !finished; ++iter) {
+    // 1. snapshot of all values (four per load); a vertex whose value differs from the previous snapshot is dirty
+    for (int i = tid; i < W; i += HCA_THREADS) dirty[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
+      const u64 nv = hca_load_u64((const u64*)gvals + i), ov = ((u64*)vals)[i];
+      if (nv != ov) {
+        ((u64*)vals)[i] = nv;
+        const u64 df = nv ^ ov;
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m |= ((df >> (16 * q)) & 0xffffu) ? (1u << q) : 0u;
+        atomicOr((unsigned*)dirty + (i >> 3), m << ((i & 7) * 4));  // vertices 4 i .. 4 i + 3
+      }
+    }
+    // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
+    // the coherence point as well: only now may the version say so)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bump = false;
+    // 2. own rows with a dirty neighbour: one wavefront per row
+    bool changed = false;
+    for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
+      const int v = r_lo + rl;
+      const int cv = vals[v];
+      if (cv <= 0) continue;
+      const u64* rowp = rows_in_lds ? rows + (size_t)rl * W : bm + (size_t)v * W;
+      // the row's words stay in registers for every pass below (five words per lane serve L <= 20480; beyond, re-read)
+      u64 rw[5];
+      bool touched = false;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int wd = lane + 64 * q;
+        rw[q] = wd < W ? rowp[wd] : 0;
+        touched |= wd < W && (rw[q] & dirty[wd]) != 0;
+      }
+      for (int wd = lane + 320; wd < W; wd += 64) touched |= (rowp[wd] & dirty[wd]) != 0;
+      if (!__any(touched)) continue;  // no neighbour moved: the value stands
+      auto count_ge = [&](int th) {  // neighbours holding a value >= th
+        int cc = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          u64 bits = rw[q];
+          const int base = (lane + 64 * q) * 64;
+          while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            cc += vals[base + b] >= th;
+          }
+        }
+        for (int wd = lane + 320; wd < W; wd += 64) {
+          u64 bits = rowp[wd];
+          while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            cc += vals[wd * 64 + b] >= th;
+          }
+        }
+        return wave_sum_i32(cc);
+      };
+      // h = the largest t <= cv with #(values >= t) >= t (monotone in t).  Values drop in small steps: probe cv, cv - 1,
+      // cv - 3, cv - 7 ... until one holds, then bisect the last gap.
+      if (count_ge(cv) >= cv) continue;
+      int bad = cv, good = 0;  // invariant: predicate holds at `good` (t = 0 always), fails at `bad`
+      for (int step = 1; bad - step > 0; step <<= 1) {
+        const int t = bad - step;
+        if (count_ge(t) >= t) {
+          good = t;
+          break;
+        }
+        bad = t;
+      }
+      while (good + 1 < bad) {
+        const int mid = (good + bad) >> 1;
+        if (count_ge(mid) >= mid) good = mid;
+        else bad = mid;
+      }
+      // (the LDS copy keeps the old value: the next snapshot then finds v dirty, which is what sends the rows of v's
+      // neighbours — mine included — through this loop again)
+      if (lane == 0) __hip_atomic_store(gvals + v, (unsigned short)good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      changed = true;
+    }
+    // 3. something lowered: straight into the next snapshot (the version is bumped there, once the stores have landed)
+    if (__syncthreads_or(changed ? 1 : 0)) {
+      bump = true;
+      v0_valid = false;
+      continue;
+    }
+    // nothing changed.  A fixed point may only be claimed for a snapshot taken AFTER the version vector was read:
+    // read it now (thread t reads ver[t]; E0 = its sum) and go round once more — with nothing dirty that is one snapshot
+    if (!v0_valid) {
+      v0 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
+      const unsigned ws = (unsigned)wave_sum_i32((int)v0);
+      if (lane == 0) s_sum[wave] = ws;
+      __syncthreads();
+      E0 = 0;
+#pragma unroll
+      for (int q = 0; q < HCA_THREADS / 64; ++q) E0 += s_sum[q];
+      v0_valid = true;
+      continue;
+    }
+    // did anybody publish while I was looking?
+    {
+      const unsigned v1 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
+      if (!__syncthreads_and(v1 == v0 ? 1 : 0)) {
+        v0_valid = false;
+        continue;
+      }
+    }
+    // my rows are a fixed point of a snapshot taken at epoch E0: say so, and wait for the verdict
+    if (tid == 0) __hip_atomic_store(done + w, E0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int verdict = 0;  // 1: somebody lowered a value, iterate again; 2: everybody idle at E0: fixed point; 3: gave up
+    for (unsigned polls = 0; verdict == 0; ++polls) {
+      const unsigned v1 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
+      const unsigned d1 = tid < NWG ? hca_load_u32(done + tid) : E0 + 1u;
+      if (!__syncthreads_and(v1 == v0 ? 1 : 0)) verdict = 1;
+      else if (__syncthreads_and(d1 == E0 + 1u ? 1 : 0)) verdict = 2;
+      // (bounded: if the workgroups of this pair are not all resident — a device with fewer usable compute units than
+      // it reports — the wait gives up after a few seconds and the peeling kernel runs)
+      else if (polls > (1u << 21)) verdict = 3;
+      else __builtin_amdgcn_s_sleep(16);
+    }
+    v0_valid = false;
+    if (verdict == 2) finished = true;
+    if (verdict == 3) break;
+  }
+  if (tid == 0) {
+    if (!finished) V.perm[HCA_CTL_FAILED] = 1;
+    atomicMax(&V.perm[HCA_CTL_ITERS], iter);
+  }
+  // my rows' final values (the LDS copy is current for them)
+  for (int rl = tid; rl < nown; rl += HCA_THREADS) V.core[r_lo + rl] = vals[r_lo + rl];
+}
+
 // what k_kcore leaves behind besides the core numbers: edge total, largest core, the zeroed rank accumulator
 template <bool EXT>
-__global__ __launch_bounds__(1024) void k_hcore_finish(ViewExt<SolverView> x, SolverView one) {
+__global__ __launch_bounds__(1024) void k_hcore_finish(ViewExt<SolverView> x, SolverView one, int async_mode) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L;
   if (L <= 0) return;
   SolverState* __restrict__ st = V.st;
   const int* __restrict__ flags = V.perm;
-  if (flags[HC_MAXIT - 1] != 0) {  // not converged: the peeling kernel takes over
+  if (async_mode ? flags[HCA_CTL_FAILED] != 0 : flags[HC_MAXIT - 1] != 0) {  // not converged: the peeling kernel takes over
     if (threadIdx.x == 0) st->pad[5] = 1;
     return;
   }
@@ -478,7 +687,8 @@ __global__ __launch_bounds__(1024) void k_hcore_finish(ViewExt<SolverView> x, So
     atomicMax(&s_max, mx);
     atomicAdd(&s_edges, es);
   }
-  if (threadIdx.x < HC_MAXIT && flags[threadIdx.x]) atomicAdd(&s_iters, 1);
+  if (!async_mode && threadIdx.x < HC_MAXIT && flags[threadIdx.x]) atomicAdd(&s_iters, 1);
+  if (async_mode && threadIdx.x == 0) s_iters = flags[HCA_CTL_ITERS] - 1;
   __syncthreads();
   if (threadIdx.x == 0) {
     st->n_edges2 = s_edges;
@@ -1835,6 +2045,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
       hipLaunchKernelGGL((kern<false, T>), grid, block, lds, st, (ViewExt<SolverView>{nullptr, {0, 0, 0}}), (a).one); \
   } while (0)
 
+// workgroups of k_hcore_async that are certainly co-resident: one per compute unit
+static int hca_max_workgroups() {
+  static int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+      cus = 64;
+    (void)hipGetLastError();
+    return cus;
+  }();
+  return n;
+}
+
 hipError_t solver_init_attributes() {
   hipError_t e;
 #define SET_LDS(kern, bytes)                                                                                         \
@@ -1844,6 +2067,7 @@ hipError_t solver_init_attributes() {
     return e;
   SET_LDS(k_finalize, FIN_LDS_BYTES)
   SET_LDS(k_kcore, 156 * 1024)
+  SET_LDS(k_hcore_async, 156 * 1024)
   SET_LDS(k_clique_batch_lds, 156 * 1024)
   SET_LDS(k_permute, 64 * 1024)
 #undef SET_LDS
@@ -1983,10 +2207,24 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         return e && strcmp(e, "peel") == 0;
       }();
       const bool hcore = !peel_only && L > 3000;
-      if (hcore) {
+      static const bool hc_sweeps = [] {
+        const char* e = getenv("QTR_KCORE");
+        return e && strcmp(e, "sweeps") == 0;
+      }();
+      if (hcore && !hc_sweeps) {
+        // one resident workgroup per compute unit at most (they wait for one another); a group of pairs shares the device
+        int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
+        if (G > 1) nwg = max(8, min(nwg, hca_max_workgroups() / min(G, 4)));
+        const int Lp = (L + 63) & ~63, R = (L + nwg - 1) / nwg;
+        const size_t base = (size_t)2 * Lp + (size_t)8 * W, rows_b = (size_t)R * W * 8;
+        const int rows_in_lds = base + rows_b <= (size_t)150 * 1024 ? 1 : 0;
+        LAUNCH_SV(k_hcore_async_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
+        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), base + (rows_in_lds ? rows_b : 0), stream, rows_in_lds);
+        LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 1);
+      } else if (hcore) {
         LAUNCH_SV(k_hcore_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         for (int it = 0; it < HC_MAXIT; ++it) LAUNCH_SV(k_hcore_sweep, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, it);
-        LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream);
+        LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 0);
       }
       LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, q_in_lds ? 0 : 1,
                 lds_bitmap, hcore ? 1 : 0);

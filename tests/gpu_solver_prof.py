@@ -34,5 +34,7 @@ for k in range(reps):
         acc[key] = acc.get(key, 0.0) + float(v)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print(f"L={L} reps={reps} ms_per_solve={1e3 * el / reps:.4f} n_clique={res.n_clique} stage_ms=" +
+import numpy as np  # noqa: E402
+stt = h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+print(f"L={L} reps={reps} kcore_iters={int(stt[10])} clique_rounds={int(stt[9])} ms_per_solve={1e3 * el / reps:.4f} n_clique={res.n_clique} stage_ms=" +
       str({k: round(v / reps, 4) for k, v in acc.items() if v}))
