@@ -972,6 +972,116 @@ __global__ __launch_bounds__(256) void k_rank_finish(ViewExt<SolverView> x, Solv
   }
 }
 
+// K12b': the same ranks by a stable counting sort on the core number, one workgroup, one launch (the quadratic count
+// above, its finish and k_clique_init took 29 + 5 + 5 us at L = 5000).  Wave w owns a contiguous block of vertex ids:
+// per-wave counts per core value in LDS, exclusive prefix over (core, wave) = where wave w's first vertex of core c goes;
+// then every wave walks its ids 64 at a time in id order and ranks the lanes that share a core value among themselves
+// (ballot per distinct value), so equal cores keep ascending ids — the (core, id) order.  Core numbers above RS_BINS - 2
+// (a clique of more than a thousand members) take the quadratic count inside this kernel.
+#define RS_THREADS 1024
+#define RS_BINS 1024
+template <bool EXT>
+__global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L;
+  SolverState* __restrict__ st = V.st;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {  // what k_clique_init sets
+    st->mc = 0;
+    st->best_r = -1;
+    st->pos = L - 1;
+    st->done = (L <= 0) ? 1 : 0;
+    st->batch = 1;
+    st->t0 = 0;
+    st->rounds = 0;
+  }
+  if (L <= 0) return;
+  const int* __restrict__ core = V.core;
+  int* __restrict__ perm = V.perm;
+  int* __restrict__ Kp = V.Kp;
+  extern __shared__ __attribute__((aligned(16))) int rs_lds[];  // [16][RS_BINS] counts, then offsets
+  __shared__ int s_wtot[RS_THREADS / 64];
+  const int NB = st->max_core + 1;  // core values 0 .. max_core
+  if (NB > RS_BINS) {
+    // rare: rank = #{u : (core u, u) < (core v, v)}, tiles of the core array through LDS
+    int* tile = rs_lds;
+    for (int v0 = 0; v0 < L; v0 += RS_THREADS) {
+      const int v = v0 + tid;
+      const int c = v < L ? core[v] : 0;
+      int r = 0;
+      for (int base = 0; base < L; base += 4096) {
+        __syncthreads();
+        for (int t = tid; t < 4096; t += RS_THREADS) tile[t] = (base + t < L) ? core[base + t] : 0x7fffffff;
+        __syncthreads();
+        const int lim = min(4096, L - base);
+        for (int t = 0; t < lim; ++t) {
+          const int cu = tile[t], u = base + t;
+          r += (cu < c) || (cu == c && u < v);
+        }
+      }
+      if (v < L) {
+        perm[r] = v;
+        Kp[r] = c + 1;
+      }
+    }
+    return;
+  }
+  for (int i = tid; i < 16 * RS_BINS; i += RS_THREADS) rs_lds[i] = 0;
+  __syncthreads();
+  const int chunk = (((L + 15) / 16) + 63) & ~63;  // ids per wave, a multiple of 64
+  const int id0 = wave * chunk, id1 = min(L, id0 + chunk);
+  int* mycnt = rs_lds + wave * RS_BINS;
+  for (int v = id0 + lane; v < id1; v += 64) atomicAdd(&mycnt[core[v]], 1);
+  __syncthreads();
+  // thread c: exclusive prefix over the waves for core value c, total of c
+  int total = 0;
+  if (tid < NB) {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int n = rs_lds[w * RS_BINS + tid];
+      rs_lds[w * RS_BINS + tid] = total;
+      total += n;
+    }
+  }
+  // exclusive prefix of the totals over the core values (one per thread)
+  int wtot;
+  const int ex = wave_excl_scan_i32(total, &wtot);
+  if (lane == 0) s_wtot[wave] = wtot;
+  __syncthreads();
+  int wbase = 0;
+  for (int q = 0; q < wave; ++q) wbase += s_wtot[q];
+  if (tid < NB) {
+    const int start = wbase + ex;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) rs_lds[w * RS_BINS + tid] += start;
+  }
+  __syncthreads();
+  // placement: lanes of equal core value rank among themselves in id order; the wave's running offsets are private
+  for (int v0 = id0; v0 < id1; v0 += 64) {
+    const int v = v0 + lane;
+    const bool valid = v < id1;
+    const int c = valid ? core[v] : -1;
+    int pos = -1;
+    u64 todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lc = __builtin_amdgcn_readlane(c, leader);
+      const u64 m = __ballot(valid && c == lc);
+      const int off = mycnt[lc];  // (uniform address: broadcast)
+      if (c == lc) pos = off + __popcll(m & lanemask_lt());
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) mycnt[lc] = off + __popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~m;
+    }
+    if (valid) {
+      perm[pos] = v;
+      Kp[pos] = c + 1;
+    }
+  }
+}
+
 // K12c: adjacency in rank labels: adjP[r][s] = adj[perm[r]][perm[s]].  One workgroup per output row:
 // the source row is staged in LDS, each wave builds output words with one LDS bit probe per lane and
 // a ballot.
@@ -1089,6 +1199,135 @@ __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, in
   if (W <= 128) return greedy_descent<2>(adjP, W, r, t0, lane, picks);
   if (W <= 256) return greedy_descent<4>(adjP, W, r, t0, lane, picks);
   return greedy_descent<8>(adjP, W, r, t0, lane, picks);  // W <= 512  (L <= 32768)
+}
+
+// Round 0 of the heuristic on a matrix that does not fit LDS: ONE start, whose descent is a chain of |clique| dependent
+// steps "highest set bit of the candidate set, AND with its row" (an L2 round trip each, and ~40 instructions of a lone
+// wavefront at ~8 clocks apiece: 106 us for a clique of 250 at L = 5000, 305 us at L = 20000).  Here the whole workgroup
+// takes the picks a word at a time:
+//   1. the top non-empty word of the candidate set holds the next up-to-64 candidates; their rows are fetched into LDS
+//      together (one round trip);
+//   2. which of them does the descent pick?  Candidate b (a bit position of that word) is picked iff it is adjacent to
+//      every PICKED candidate above it — a question about one 64-bit word per candidate (its row's word at the same
+//      position).  Lane b iterates  P <- { b : no picked bit above b is missing from row_b }  from P = all candidates;
+//      the status of the highest candidate is final after one pass, of the next after two, ..., and candidates from one
+//      clique settle in two or three passes (one ballot each) instead of one dependent step per member;
+//   3. the picked rows are ANDed into the candidate set by all threads (a word per thread), the picks are written out
+//      in descending order.  Every other set bit lies below the whole word, so this is exactly greedy_descent's sequence.
+#define CF_THREADS 512
+#define CF_LDS_BYTES (144 * 1024)
+template <bool EXT>
+__global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const SolverState* __restrict__ st = V.st;
+  if (st->done) return;
+  extern __shared__ __attribute__((aligned(16))) u64 cf_lds[];
+  u64* cur = cf_lds;         // [W] the candidate set
+  u64* rowbuf = cf_lds + W;  // [K][W] rows of the candidates of the current word
+  __shared__ int s_top, s_np, s_idx[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* __restrict__ picks = V.picks_buf;
+  const int r = st->pos, t0 = st->t0;  // batch == 1: the single start of round 0
+  int depth = 1;
+  if (r >= 0 && V.Kp[r] > st->mc) {  // (uniform over the workgroup)
+    const int K = max(1, min(64, (int)((CF_LDS_BYTES / 8 - W - (CF_THREADS / 64) * W) / W)));
+    for (int w = tid; w < W; w += CF_THREADS) {
+      u64 xw = adjP[(size_t)r * W + w];
+      const int lo = w * 64;
+      if (lo + 63 < t0)
+        xw = 0;
+      else if (lo < t0)
+        xw &= ~((1ULL << (t0 - lo)) - 1ULL);
+      cur[w] = xw;
+    }
+    if (tid == 0) s_top = -1;
+    __syncthreads();
+    while (true) {
+      // 1. the top non-empty word
+      {
+        int mine = -1;
+        for (int w = tid; w < W; w += CF_THREADS)
+          if (cur[w] != 0) mine = w;
+        mine = wave_max_i32(mine);
+        if (lane == 0 && mine >= 0) atomicMax(&s_top, mine);
+      }
+      __syncthreads();
+      const int topw = s_top;
+      if (topw < 0) break;
+      const u64 word = cur[topw];
+      u64 cand = word;  // its highest (up to K) set bits
+      if (__popcll(word) > K) {
+        u64 xw = word;
+        cand = 0;
+        for (int q = 0; q < K; ++q) {
+          const u64 b = 1ULL << (63 - __clzll((long long)xw));
+          cand |= b;
+          xw &= ~b;
+        }
+      }
+      // row index of a candidate = the number of candidate bits above it; wave g fetches the rows with index = g (mod 8)
+      {
+        const bool mine = ((cand >> lane) & 1ULL) &&
+                          (__popcll(lane < 63 ? (cand >> (lane + 1)) : 0ULL) & (CF_THREADS / 64 - 1)) == wave;
+        u64 m = __ballot(mine);
+        while (m) {
+          const int b = 63 - __clzll((long long)m);
+          m &= ~(1ULL << b);
+          const int i = __popcll(b < 63 ? (cand >> (b + 1)) : 0ULL);
+          const u64* __restrict__ rp = adjP + (size_t)(topw * 64 + b) * W;
+          for (int w = lane; w < W; w += 64) rowbuf[(size_t)i * W + w] = rp[w];
+        }
+      }
+      __syncthreads();
+      // 2. the picked subset (wave 0, lane = bit position)
+      if (wave == 0) {
+        const bool isc = (cand >> lane) & 1ULL;
+        const int ib = __popcll(lane < 63 ? (cand >> (lane + 1)) : 0ULL);
+        const u64 arow = isc ? rowbuf[(size_t)ib * W + topw] : 0ULL;
+        const u64 above = lane < 63 ? ~((2ULL << lane) - 1ULL) : 0ULL;
+        u64 P = cand;
+        for (int pass = 0; pass < 64; ++pass) {
+          const u64 Pn = __ballot(isc && (P & above & ~arow) == 0);
+          if (Pn == P) break;
+          P = Pn;
+        }
+        if ((P >> lane) & 1ULL) {
+          const int k = __popcll(lane < 63 ? (P >> (lane + 1)) : 0ULL);  // k-th pick of this word, descending
+          picks[depth - 1 + k] = topw * 64 + lane;
+          s_idx[k] = ib;
+        }
+        if (lane == 0) {
+          s_np = __popcll(P);
+          s_top = -1;  // for the next round's maximum
+        }
+      }
+      __syncthreads();
+      const int np = s_np;
+      depth += np;
+      // 3. AND the picked rows into the candidate set: wave g folds the picks k = g (mod 8) over all words, the eight
+      //    partial results meet in LDS
+      {
+        u64* part = rowbuf + (size_t)K * W;  // [8][W]
+        for (int w = lane; w < W; w += 64) {
+          u64 acc = ~0ULL;
+          for (int k = wave; k < np; k += CF_THREADS / 64) acc &= rowbuf[(size_t)s_idx[k] * W + w];
+          part[(size_t)wave * W + w] = acc;
+        }
+        __syncthreads();
+        for (int w = tid; w < W; w += CF_THREADS) {
+          u64 acc = cur[w];
+#pragma unroll
+          for (int g = 0; g < CF_THREADS / 64; ++g) acc &= part[(size_t)g * W + w];
+          cur[w] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) V.gsz[0] = (r >= 0 && V.Kp[r] > st->mc) ? depth : 0;
 }
 
 template <bool EXT>
@@ -2068,6 +2307,8 @@ hipError_t solver_init_attributes() {
   SET_LDS(k_finalize, FIN_LDS_BYTES)
   SET_LDS(k_kcore, 156 * 1024)
   SET_LDS(k_hcore_async, 156 * 1024)
+  SET_LDS(k_rank_sort, 64 * 1024)
+  SET_LDS(k_clique_first, CF_LDS_BYTES)
   SET_LDS(k_clique_batch_lds, 156 * 1024)
   SET_LDS(k_permute, 64 * 1024)
 #undef SET_LDS
@@ -2231,9 +2472,14 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
-      LAUNCH_SV(k_rank_partial, a, dim3((L + 255) / 256, slices, G), dim3(256), 0, stream);
-      LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
-      LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
+      static const bool rank_quadratic = getenv("QTR_RANK_QUADRATIC") != nullptr;
+      if (rank_quadratic) {
+        LAUNCH_SV(k_rank_partial, a, dim3((L + 255) / 256, slices, G), dim3(256), 0, stream);
+        LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
+        LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
+      } else {
+        LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), (size_t)16 * RS_BINS * 4, stream);
+      }
       CS_DBG("rank");
     }
     LAUNCH_SV(k_permute, a, dim3(L, 1, G), dim3(256), (size_t)W * 8, stream);
@@ -2259,7 +2505,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       if (lds_rows)
         LAUNCH_SV(k_clique_batch_lds, a, dim3(1, 1, G), dim3(256), cl_lds, stream);
       else
-        LAUNCH_SV(k_clique_batch, a, dim3(1, 1, G), dim3(256), 0, stream);
+        LAUNCH_SV(k_clique_first, a, dim3(1, 1, G), dim3(CF_THREADS), (size_t)CF_LDS_BYTES, stream);
       CS_DBG("clique batch 0");
       LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
       CS_DBG("clique scan 0");
