@@ -1082,9 +1082,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   }
 }
 
-// K12c: adjacency in rank labels: adjP[r][s] = adj[perm[r]][perm[s]].  One workgroup per output row:
-// the source row is staged in LDS, each wave builds output words with one LDS bit probe per lane and
-// a ballot.
+// K12c: adjacency in rank labels: adjP[r][s] = adj[perm[r]][perm[s]].  One workgroup per PM_ROWS output rows: the source
+// rows are staged in LDS, a lane looks perm[s] up ONCE and probes its bit in every staged row (one workgroup per row
+// re-read the whole perm array for each row: L^2 * 4 bytes of L2 traffic, 257 us at L = 20000), a ballot per row builds
+// the output words.
+#define PM_ROWS 8
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_permute(ViewExt<SolverView> x, SolverView one) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -1092,22 +1094,29 @@ __global__ __launch_bounds__(256) void k_permute(ViewExt<SolverView> x, SolverVi
   const int* __restrict__ perm = V.perm;
   const int L = V.L, W = V.W;
   u64* __restrict__ adjP = V.adjP;
-  extern __shared__ u64 prow[];
-  const int r = blockIdx.x;
-  if (r >= L) return;
-  const int v = perm[r];
-  for (int w = threadIdx.x; w < W; w += 256) prow[w] = bm[(size_t)v * W + w];
+  extern __shared__ u64 prow[];  // [PM_ROWS][W]
+  const int r0 = blockIdx.x * PM_ROWS;
+  if (r0 >= L) return;
+  const int nr = min(PM_ROWS, L - r0);
+  for (int e = threadIdx.x; e < nr * W; e += 256) {
+    const int i = e / W, w = e - i * W;
+    prow[e] = bm[(size_t)perm[r0 + i] * W + w];
+  }
   __syncthreads();
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   for (int w = wave; w < W; w += 4) {
     const int s = w * 64 + lane;
-    bool bit = false;
-    if (s < L) {
-      const int u = perm[s];
-      bit = (prow[u >> 6] >> (u & 63)) & 1ULL;
+    const int u = s < L ? perm[s] : -1;
+    const int uw = u >> 6;
+    const u64 ub = 1ULL << (u & 63);
+    u64 mine = 0;  // lane i keeps row i's word
+#pragma unroll
+    for (int i = 0; i < PM_ROWS; ++i) {
+      const bool bit = (i < nr) && (u >= 0) && (prow[i * W + uw] & ub);
+      const u64 word = __ballot(bit);
+      if (lane == i) mine = word;
     }
-    const u64 word = __ballot(bit);
-    if (lane == 0) adjP[(size_t)r * W + w] = word;
+    if (lane < nr) adjP[(size_t)(r0 + lane) * W + w] = mine;
   }
 }
 
@@ -2482,7 +2491,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       }
       CS_DBG("rank");
     }
-    LAUNCH_SV(k_permute, a, dim3(L, 1, G), dim3(256), (size_t)W * 8, stream);
+    LAUNCH_SV(k_permute, a, dim3((L + PM_ROWS - 1) / PM_ROWS, 1, G), dim3(256), (size_t)PM_ROWS * W * 8, stream);
     CS_DBG("k_permute");
     if (mode == QTR_INLIER_KCORE_HEU) LAUNCH_SV(k_kcore_heu, a, dim3(1, 1, G), dim3(256), 0, stream, kcore_thr);
     {

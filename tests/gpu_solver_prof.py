@@ -36,5 +36,7 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 import numpy as np  # noqa: E402
 stt = h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+print("k_finalize phase clocks/16 (members+TIMs, GNC, rot-inliers+raw, COTE+rest):", [int(a) for a in stt[11:15]],
+      "COTE steps:", [int(a) for a in stt[16:22]])
 print(f"L={L} reps={reps} kcore_iters={int(stt[10])} clique_rounds={int(stt[9])} ms_per_solve={1e3 * el / reps:.4f} n_clique={res.n_clique} stage_ms=" +
       str({k: round(v / reps, 4) for k, v in acc.items() if v}))
