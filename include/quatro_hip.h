@@ -77,6 +77,10 @@ typedef struct qtr_limits {
   int max_voxels; /* down-sampled points per cloud   (default 65536) */
   int max_corr;   /* correspondences into the solver (default 24576) */
   int n_slots;    /* independent stream slots        (default 1) */
+  int max_long_neighbors; /* per cloud: total entries of the radius-neighbour lists that are LONGER than 256 entries
+                             (dense / un-voxelised clouds; a list of up to 256 entries costs nothing here).
+                             0 = default = 128 * max_voxels.  pcl's radius search has no cap
+                             (reference src/teaser_utils/fpfh.cc:58-72): exceeding this returns QTR_ERR_CAPACITY */
 } qtr_limits;
 
 /* The fields of Quatro::Params that the path consumes (reference include/quatro.hpp:202-268), plus the

@@ -58,6 +58,7 @@ struct Lane {
   int first_pair = 0, count = 0;  // pairs [first_pair, first_pair + count) of the job are on this lane
   std::vector<int> active;      // indices g (0..count) of the pairs still alive after each chain's checks
   std::vector<int> ns, nt, L;   // per g
+  bool long_lists = false;      // the chunk's FPFH chain included k2_neighbors_big
 };
 struct BatchJob {
   const qtr_pair_desc* pairs = nullptr;
@@ -82,6 +83,8 @@ struct qtr_handle {
   size_t comm_bytes = 0;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
   double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
+  bool long_lists = false;  // some cloud of the whole-path entry points had a point with more than QTR_KMAX neighbours:
+                            // from then on their FPFH chains include k2_neighbors_big (see front_device)
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   char err[512];
 };
@@ -278,6 +281,7 @@ void qtr_default_limits(qtr_limits* l) {
   l->max_voxels = 65536;
   l->max_corr = 24576;
   l->n_slots = 1;
+  l->max_long_neighbors = 0;  // = 128 * max_voxels
 }
 
 void qtr_default_params(qtr_params* p) {  // Quatro::Params defaults, reference include/quatro.hpp:202-268
@@ -335,6 +339,10 @@ void qtr_destroy(qtr_handle* h) {
       if (e) (void)hipEventDestroy(e);
     if (s.solver_arena) (void)hipFree(s.solver_arena);
     if (s.front_arena) (void)hipFree(s.front_arena);
+    for (int c = 0; c < 2; ++c) {
+      if (s.fb.cloud[c].nbr_big_idx) (void)hipFree(s.fb.cloud[c].nbr_big_idx);
+      if (s.fb.cloud[c].nbr_big_d2) (void)hipFree(s.fb.cloud[c].nbr_big_d2);
+    }
     if (s.in_src) (void)hipFree(s.in_src);
     if (s.in_tgt) (void)hipFree(s.in_tgt);
     if (s.m_src) (void)hipFree(s.m_src);
@@ -371,6 +379,12 @@ static int create_impl(qtr_handle* h) {
       frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
       for (int q = 0; q < 4; ++q) s.fb.ev_nn[q] = keep[q];
       s.fb.nn_events = h->stage_events;
+    }
+    for (int c = 0; c < 2; ++c) {  // long-list arenas (lists of more than QTR_KMAX neighbours)
+      CloudBufs& cb = s.fb.cloud[c];
+      cb.nbr_big_cap = h->lim.max_long_neighbors;
+      QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_idx, (size_t)cb.nbr_big_cap * 4));
+      QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_d2, (size_t)cb.nbr_big_cap * 4));
     }
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_src, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_tgt, (size_t)h->lim.max_points * 16));
@@ -427,10 +441,13 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   else
     qtr_default_limits(&h->lim);
   if (h->lim.max_points < 64 || h->lim.max_voxels < 64 || h->lim.max_corr < 64 || h->lim.n_slots < 1 ||
-      h->lim.max_corr > 32768 || h->lim.max_voxels > h->lim.max_points) {
+      h->lim.max_corr > 32768 || h->lim.max_voxels > h->lim.max_points || h->lim.max_long_neighbors < 0) {
     delete h;
     return QTR_ERR_BAD_ARG;
   }
+  if (h->lim.max_long_neighbors == 0)
+    h->lim.max_long_neighbors = (int)std::min<long long>(128LL * h->lim.max_voxels, 1LL << 30);
+  h->lim.max_long_neighbors = (h->lim.max_long_neighbors + 63) & ~63;
   h->slots.resize((size_t)h->lim.n_slots);
   const int rc = create_impl(h);
   *out = h;  // returned even on failure so that qtr_last_error can be read; caller destroys it
@@ -1285,13 +1302,16 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   {
     const int ns1[1] = {n};
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true, false));
+    // an arbitrary cloud (dense mode: no voxel grid in front): lists of any length
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true, false, true));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  if (s.pinned_i32[CNT_NBR_OVERFLOW]) {
-    snprintf(h->err, sizeof(h->err), "neighbour list capacity exceeded (total %d)", s.pinned_i32[CNT_NBR_TOTAL]);
+  if (s.pinned_i32[CNT_NBR_CAPACITY]) {
+    snprintf(h->err, sizeof(h->err), "radius-neighbour lists longer than %d entries need %d entries of the long-list arena "
+             "(longest list %d); qtr_limits.max_long_neighbors is %d", QTR_KMAX, s.pinned_i32[CNT_NBR_ARENA],
+             s.pinned_i32[CNT_KMAX], h->lim.max_long_neighbors);
     return QTR_ERR_CAPACITY;
   }
   if (normals4) QTR_HIP_TRY(h, hipMemcpyAsync(normals4, cb.normals, (size_t)n * 16, kout, s.stream));
@@ -1459,7 +1479,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists));
     if (!mean_first) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
@@ -1473,10 +1493,18 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L, true);
   if (rc != QTR_OK) return rc;
-  if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW]) {
-    snprintf(h->err, sizeof(h->err), "neighbour list capacity (%d per point) exceeded: max k = %d / %d", QTR_KMAX,
-             s.mail[MAIL_CNT0 + CNT_KMAX], s.mail[MAIL_CNT1 + CNT_KMAX]);
+  if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY]) {
+    snprintf(h->err, sizeof(h->err), "radius-neighbour lists longer than %d entries (longest %d / %d) exceed the long-list "
+             "arena: qtr_limits.max_long_neighbors is %d", QTR_KMAX, s.mail[MAIL_CNT0 + CNT_KMAX],
+             s.mail[MAIL_CNT1 + CNT_KMAX], h->lim.max_long_neighbors);
     return QTR_ERR_CAPACITY;
+  }
+  if (!h->long_lists && (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW])) {
+    // A point with more than QTR_KMAX neighbours, and the chain ran without k2_neighbors_big (voxel-grid centroids at
+    // the demo's leaf never have that many, so the launch is left out until a cloud needs it): descriptors and matches
+    // of this call are not usable.  From now on the handle's chains include it; this pair goes round again.
+    h->long_lists = true;
+    return front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, for_solver, ns_out, nt_out, L_out);
   }
   *L_out = L;
   s.last_L = L;
@@ -1668,7 +1696,9 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream2, lead.ev_vox, 0));
     QTR_HIP_TRY(h, mean_enqueue_group(F.data(), G, n2.data(), &ln.stage, lead.stream2));  // beside the FPFH chain
     QTR_HIP_TRY(h, hipEventRecord(lead.ev[5], lead.stream2));
-    QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream));
+    ln.long_lists = h->long_lists;
+    QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream,
+                                      ln.long_lists));
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, lead.ev[5], 0));
     for (int g : ln.active) {
       Slot& s = h->slots[ln.first_slot + g];
@@ -1692,8 +1722,23 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       qtr_result& r = J.results[ln.first_pair + g];
       const int L = s.mail[MAIL_MATCH + MC_NCORR];
       r.n_corr = L;
-      if (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW] || L > h->lim.max_corr) {
+      if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY] || L > h->lim.max_corr) {
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
+        continue;
+      }
+      if (!ln.long_lists && (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW])) {
+        // a point with more than QTR_KMAX neighbours and a chain without k2_neighbors_big (see front_device): this pair
+        // goes through the per-pair entry point on its own slot (whose arenas the group is done with), and the
+        // handle's later chains include the launch
+        h->long_lists = true;
+        const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+        qtr_frontend_params f1 = J.fp;
+        f1.seed = pd.seed;
+        const int rc1 = qtr_register_pair(h, ln.first_slot + g, pd.src_raw4, pd.n_src, pd.tgt_raw4, pd.n_tgt, &f1, &J.prm, &r,
+                                          pd.clique, pd.final_inliers, pd.cap, J.mem);
+        if (rc1 == QTR_ERR_HIP) return rc1;
+        J.finished[ln.first_pair + g] = 1;
+        ++J.done;
         continue;
       }
       QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail

@@ -2,13 +2,18 @@
 #pragma once
 #include "common.h"
 
-#define QTR_KMAX 256        // capacity of one point's radius-neighbour list (entries)
+#define QTR_KMAX 256        // entries of a point's radius-neighbour list kept in its own fixed-stride slot; a longer list
+                            // lives in the cloud's long-list arena (nbr_big_*), its offset in word 0 of the slot
+#define NBIG_LDS_KEYS 8192  // longest list k2_neighbors_big sorts in LDS (longer ones are sorted in the arena itself)
 #define RADIX_TILE 1024     // elements per radix-sort workgroup (four wavefronts, 256 keys each)
 #define NORM_BINS 192       // bins of width 1 over sqrt(|descriptor|^2) (<= sqrt(3 * 100^2) = 173.3)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5,
-       CNT_SORT_BITS = 6 /* significant bits of the voxel sort's keys */ };
+       CNT_SORT_BITS = 6 /* significant bits of the voxel sort's keys */,
+       CNT_NBR_ARENA = 7 /* entries of the long-list arena handed out */, CNT_NBR_CAPACITY = 8 /* ... it was too small */ };
+// CNT_NBR_OVERFLOW: some point of the cloud has more than QTR_KMAX neighbours (k2_neighbors_big has work to do);
+// CNT_KMAX: the longest such list
 // matcher device counters (FrontBufs::mcounts, 16 ints)
 // MC_RECHECKx: rows sent to the exact re-check; MC_RECHECKx + 2: rows settled by the two-candidate exact compare
 // MC_NQ0 / MC_NHIT: query counts of the two nearest-neighbour directions (device-side: the second direction only asks
@@ -39,6 +44,9 @@ struct CloudBufs {
   int* nbr_off = nullptr;      // [max_voxels+1] CSR view (exclusive scan of nbr_cnt) for inspection
   int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
   float* nbr_d2 = nullptr;     // [max_voxels][QTR_KMAX]
+  int* nbr_big_idx = nullptr;  // [nbr_big_cap] long-list arena (lists of more than QTR_KMAX entries), separately allocated
+  float* nbr_big_d2 = nullptr;
+  int nbr_big_cap = 0;
   float4* spts = nullptr;      // [max_voxels] points in cell-sorted order, w = original index
   float4* raw_sorted = nullptr; // [max_points] raw scan gathered into voxel-sorted order
   int* ranges = nullptr;       // [max_voxels][9][2] candidate key ranges
@@ -80,6 +88,9 @@ struct CloudView {
   int* nbr_off;
   int* nbr_idx;
   float* nbr_d2;
+  int* nbr_big_idx;
+  float* nbr_big_d2;
+  int nbr_big_cap;
   float4* spts;
   int* ranges;
   float* mean;
@@ -210,7 +221,7 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 // origin_known: the clouds are the voxel centroids voxelize_enqueue just produced in the same CloudBufs (its bounding box
 // is still there and serves as the neighbour grid's origin)
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known);
+                        bool with_mean, bool origin_known, bool long_lists);
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
 // init_done: match_init_enqueue already ran for this pair (same ns, nt, fp) — the whole-path driver issues it beside the
 // FPFH chain, which takes one launch off the critical path
@@ -224,7 +235,7 @@ hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* cons
                                   ViewStage* stage, hipStream_t st);
 hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st);
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st);
+                              hipStream_t st, bool long_lists);
 hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
                                const unsigned long long* seeds, ViewStage* stage, hipStream_t st);
 

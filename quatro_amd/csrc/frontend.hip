@@ -674,11 +674,18 @@ __device__ __forceinline__ void d_neighbors(const float4* __restrict__ pts, int 
     k += __popcll(bal);
   }
   if (__ballot(overflow) || k > QTR_KMAX) {
+    // more neighbours than the slot holds (a dense, un-voxelised cloud): only the count is left behind; k2_neighbors_big
+    // searches this point again and keeps its list in the long-list arena (pcl's radius search has no cap, reference
+    // src/teaser_utils/fpfh.cc:58-72)
+    // (the count is left NEGATIVE: "list pending".  Readers take a negative count as an empty list, so a chain that
+    // runs without k2_neighbors_big, or whose arena is too small, stays inside its buffers until the host has seen
+    // the flag.)
     if (lane == 0) {
       counts[CNT_NBR_OVERFLOW] = 1;
       atomicMax(&counts[CNT_KMAX], k);
+      nbr_cnt[i] = -k;
     }
-    k = QTR_KMAX;
+    return;
   }
   int n2 = 8;  // (most lists are shorter than 32: 10 - 15 compare stages instead of the 21 a 64-key network needs)
   while (n2 < k) n2 <<= 1;
@@ -831,14 +838,144 @@ __device__ __forceinline__ float4 normal_from_sums(float (&acc)[9], int k, const
   }
   return make_float4(vx, vy, vz, curv);
 }
+// The list of point i (k entries): its fixed-stride slot, or — longer than QTR_KMAX — the long-list arena at the offset
+// the slot's first word holds.
+struct NbrLists {
+  const int* idx;
+  const float* d2;
+  const int* big_idx;
+  const float* big_d2;
+};
+__device__ __forceinline__ const int* nbr_list_idx(const NbrLists& N, int i, int k) {
+  return k <= QTR_KMAX ? N.idx + (size_t)i * QTR_KMAX : N.big_idx + (size_t)N.idx[(size_t)i * QTR_KMAX];
+}
+__device__ __forceinline__ const float* nbr_list_d2(const NbrLists& N, int i, int k) {
+  return k <= QTR_KMAX ? N.d2 + (size_t)i * QTR_KMAX : N.big_d2 + (size_t)N.idx[(size_t)i * QTR_KMAX];
+}
+
+// Lists longer than QTR_KMAX: one 256-thread workgroup per such point (every other workgroup returns at once, and the
+// launch is skipped altogether when the cloud comes from this library's voxel grid with a leaf that bounds the count).
+// The candidates of the nine cell ranges are tested again, the hits appended to a buffer — LDS up to NBIG_LDS_KEYS,
+// beyond that the arena itself —, sorted by (d2, index) with the same bitonic network as the short lists, and stored at
+// an offset handed out by one atomic per long list.
+template <typename KeyPtr>
+__device__ __forceinline__ void nbig_bitonic(KeyPtr buf, int n2, int tid) {
+  for (int kk = 2; kk <= n2; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < n2; t += 256) {
+        const int x = t ^ j;
+        if (x > t) {
+          const u64 a = buf[t], b = buf[x];
+          const bool up = ((t & kk) == 0);
+          if ((a > b) == up) {
+            buf[t] = b;
+            buf[x] = a;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void d_neighbors_big(const float4* __restrict__ pts, int n, const float4* __restrict__ spts,
+                                                const int* __restrict__ ranges, float r2, int* __restrict__ nbr_cnt,
+                                                int* __restrict__ nbr_idx, int* __restrict__ big_idx,
+                                                float* __restrict__ big_d2, int big_cap, int* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) u64 nbig_buf[];  // [NBIG_LDS_KEYS]
+  __shared__ int rs[9], pre[10], s_k, s_off;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int i = blockIdx.x;
+  if (i >= n || counts[CNT_NBR_OVERFLOW] == 0) return;
+  const int k = -nbr_cnt[i];  // negative count: a list k2_neighbors left pending
+  if (k <= QTR_KMAX) return;
+  int n2 = 512;
+  while (n2 < k) n2 <<= 1;
+  const int kpad = (k + 63) & ~63;
+  const bool in_lds = n2 <= NBIG_LDS_KEYS;
+  if (tid == 0) {
+    // the arena holds the list (k entries, padded to 64) and — for lists too long for LDS — the sort buffer behind it
+    // (n2 eight-byte keys = 2 n2 entries of the index array)
+    const int need = kpad + (in_lds ? 0 : 2 * n2);
+    const int off = atomicAdd(&counts[CNT_NBR_ARENA], need);
+    s_off = (off >= 0 && off <= big_cap - need) ? off : -1;
+    s_k = 0;
+  }
+  if (tid < 64) {
+    int len = 0, s = 0;
+    if (lane < 9) {
+      s = ranges[18 * i + 2 * lane];
+      len = ranges[18 * i + 2 * lane + 1] - s;
+      rs[lane] = s;
+    }
+    int tot;
+    const int ex = wave_excl_scan_i32(len, &tot);
+    if (lane < 9) pre[lane] = ex;
+    if (lane == 9) pre[9] = tot;
+  }
+  __syncthreads();
+  const int off = s_off;
+  if (off < 0) {  // arena exhausted: the host reports QTR_ERR_CAPACITY (qtr_limits.max_long_neighbors)
+    if (tid == 0) counts[CNT_NBR_CAPACITY] = 1;
+    return;
+  }
+  u64* gbuf = (u64*)(big_idx + off + kpad);  // (8-byte aligned: off and kpad are multiples of 64 four-byte entries)
+  const float4 p = pts[i];
+  const int total = pre[9];
+  for (int c0 = 0; c0 < total; c0 += 256) {
+    const int c = c0 + tid;
+    bool ok = false;
+    u64 key = 0;
+    if (c < total) {
+      int r = 0;
+#pragma unroll
+      for (int q = 1; q < 9; ++q) r += (c >= pre[q]);
+      const float4 qp = spts[rs[r] + (c - pre[r])];
+      float d2 = 0.f, d;
+      d = p.x - qp.x;
+      d2 += d * d;
+      d = p.y - qp.y;
+      d2 += d * d;
+      d = p.z - qp.z;
+      d2 += d * d;
+      ok = d2 < r2;
+      key = ((u64)__float_as_uint(d2) << 32) | __float_as_uint(qp.w);
+    }
+    const u64 bal = __ballot(ok);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&s_k, __popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (ok) {
+      const int pos = base + __popcll(bal & lanemask_lt());  // (any order: the sort below defines it)
+      if (in_lds) nbig_buf[pos] = key;
+      else gbuf[pos] = key;
+    }
+  }
+  __syncthreads();
+  for (int t = k + tid; t < n2; t += 256) {
+    if (in_lds) nbig_buf[t] = ~0ULL;
+    else gbuf[t] = ~0ULL;
+  }
+  if (in_lds) nbig_bitonic(nbig_buf, n2, tid);
+  else nbig_bitonic(gbuf, n2, tid);
+  for (int t = tid; t < k; t += 256) {
+    const u64 key = in_lds ? nbig_buf[t] : gbuf[t];
+    big_idx[off + t] = (int)(u32)key;
+    big_d2[off + t] = __uint_as_float((u32)(key >> 32));
+  }
+  if (tid == 0) {
+    nbr_idx[(size_t)i * QTR_KMAX] = off;
+    nbr_cnt[i] = k;
+  }
+}
+
 __device__ __forceinline__ void d_normals(const float4* __restrict__ pts, int n, const int* __restrict__ nbr_cnt,
-                                                 const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
-                                                 float rn2, float4* __restrict__ normals) {
+                                                 const NbrLists NL, float rn2, float4* __restrict__ normals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int kf = nbr_cnt[i];
-  const int* idx = nbr_idx + (size_t)i * QTR_KMAX;
-  const float* d2 = nbr_d2 + (size_t)i * QTR_KMAX;
+  const int kf = max(nbr_cnt[i], 0);
+  const int* idx = nbr_list_idx(NL, i, kf);
+  const float* d2 = nbr_list_d2(NL, i, kf);
   // A thread walks its own list: written as `while (d2[k] < rn2) ++k` and `acc += pts[idx[t]]` the kernel is a chain of
   // ~3 k dependent round trips (k ~ 8: most of its 16 us).  Eight entries per round trip instead — the additions stay in
   // list order.
@@ -960,7 +1097,7 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
 // reference's accumulation.
 #define SPFH_PB 32
 __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const float4* __restrict__ normals, int n,
-                                             const int* __restrict__ nbr_cnt, const int* __restrict__ nbr_idx,
+                                             const int* __restrict__ nbr_cnt, const NbrLists NL,
                                              float* __restrict__ spfh) {
   __shared__ int cnt[SPFH_PB][33];
   __shared__ int s_off[SPFH_PB + 1], s_k[SPFH_PB];
@@ -970,7 +1107,7 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
   const int np = min(SPFH_PB, n - i0);
   for (int e = tid; e < SPFH_PB * 33; e += 256) (&cnt[0][0])[e] = 0;
   if (tid < 64) {
-    const int k = (tid < np) ? nbr_cnt[i0 + tid] : 0;
+    const int k = (tid < np) ? max(nbr_cnt[i0 + tid], 0) : 0;
     int tot;
     const int ex = wave_excl_scan_i32(k, &tot);
     if (tid < SPFH_PB) {
@@ -991,7 +1128,7 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
 #pragma unroll
     for (int step = SPFH_PB / 2; step > 0; step >>= 1) pi += (s_off[pi + step] <= t) ? step : 0;
     const int i = i0 + pi;
-    const int j = nbr_idx[(size_t)i * QTR_KMAX + (t - s_off[pi])];
+    const int j = nbr_list_idx(NL, i, s_k[pi])[t - s_off[pi]];
     if (j == i) continue;
     float f[3];
     if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f)) continue;
@@ -1024,8 +1161,7 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
 #define FPFH_PB 7
 #define FPFH_CHUNK 32
 __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
-                                             const int* __restrict__ nbr_idx, const float* __restrict__ nbr_d2,
-                                             float* __restrict__ fpfh) {
+                                             const NbrLists NL, float* __restrict__ fpfh) {
   __shared__ int s_idx[FPFH_PB][FPFH_CHUNK];
   __shared__ float s_w[FPFH_PB][FPFH_CHUNK];  // 1 / d^2, or 0 for an entry the reference skips (d^2 == 0)
   __shared__ int s_k[FPFH_PB];
@@ -1037,7 +1173,7 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
   const int pi = tid / 33, b = tid - pi * 33;      // this thread's (point, bin); tid >= 231: staging only
   const bool owner = pi < np;
   const int lp = tid >> 5, lq = tid & 31;          // staging role: (point, entry of the chunk); 7 x 32 = 224 threads
-  if (tid < FPFH_PB) s_k[tid] = (tid < np) ? nbr_cnt[i0 + tid] : 0;
+  if (tid < FPFH_PB) s_k[tid] = (tid < np) ? max(nbr_cnt[i0 + tid], 0) : 0;
   __syncthreads();
   int kmax = 0;
 #pragma unroll
@@ -1051,8 +1187,8 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
       int j = 0;
       float w = 0.f;
       if (lp < np && t0 + lq < s_k[lp]) {
-        j = nbr_idx[(size_t)(i0 + lp) * QTR_KMAX + t0 + lq];
-        const float d2 = nbr_d2[(size_t)(i0 + lp) * QTR_KMAX + t0 + lq];
+        j = nbr_list_idx(NL, i0 + lp, s_k[lp])[t0 + lq];
+        const float d2 = nbr_list_d2(NL, i0 + lp, s_k[lp])[t0 + lq];
         w = (d2 == 0) ? 0.f : 1.0f / d2;
       }
       s_idx[lp][lq] = j;
@@ -1099,15 +1235,21 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
   }
   // exponent fields (denormals count as exponent 1: their unit in the last place is that of the smallest normal)
   const int e_hi = (int)((__float_as_uint(hi) >> 23) & 255u), e_lo = max(1, (int)((__float_as_uint(lo) >> 23) & 255u));
-  const bool exact = !(hi > 0.f) || (hi < INFINITY && e_hi - e_lo <= 17);
+  // (11 k terms: their count takes ceil(log2(11 k)) bits off the 53 - 24 a binary64 sum has to spare — 17 for the lists
+  // of up to 256 entries the argument above is written for, fewer for the long lists of dense clouds)
+  int cnt_bits = 12;
+  while ((11 * k) >> cnt_bits) ++cnt_bits;
+  const bool exact = !(hi > 0.f) || (hi < INFINITY && e_hi - e_lo <= 29 - cnt_bits);
   if (!exact) {  // the reference's nested order, straight from memory
     sum = 0.0;
     const int i = i0 + pi;
+    const int* lidx = nbr_list_idx(NL, i, k);
+    const float* ld2 = nbr_list_d2(NL, i, k);
     for (int q = 0; q < k; ++q) {
-      const float d2 = nbr_d2[(size_t)i * QTR_KMAX + q];
+      const float d2 = ld2[q];
       if (d2 == 0) continue;
       const float w = 1.0f / d2;
-      const float* row = spfh + (size_t)nbr_idx[(size_t)i * QTR_KMAX + q] * 33 + 11 * blk;
+      const float* row = spfh + (size_t)lidx[q] * 33 + 11 * blk;
       for (int c = 0; c < 11; ++c) {
         const float val = row[c] * w;
         sum += val;
@@ -1310,6 +1452,12 @@ __global__ __launch_bounds__(64) void k2_neighbors(ViewExt<CloudView> x, Clouds2
   d_neighbors(C.vox, C.n, C.spts, C.ranges, r2, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.counts);
 }
 template <bool EXT>
+__global__ __launch_bounds__(256) void k2_neighbors_big(ViewExt<CloudView> x, Clouds2 a, float r2) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  d_neighbors_big(C.vox, C.n, C.spts, C.ranges, r2, C.nbr_cnt, C.nbr_idx, C.nbr_big_idx, C.nbr_big_d2, C.nbr_big_cap,
+                  C.counts);
+}
+template <bool EXT>
 __global__ __launch_bounds__(1024) void k2_nbr_scan(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   d_scan_i32_copy(C.nbr_cnt, C.nbr_off, C.n);
@@ -1317,17 +1465,17 @@ __global__ __launch_bounds__(1024) void k2_nbr_scan(ViewExt<CloudView> x, Clouds
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_normals(ViewExt<CloudView> x, Clouds2 a, float rn2) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_normals(C.vox, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, rn2, C.normals);
+  d_normals(C.vox, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, rn2, C.normals);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_spfh(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, C.nbr_idx, C.spfh);
+  d_spfh(C.vox, C.normals, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, C.spfh);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_fpfh(C.spfh, C.n, C.nbr_cnt, C.nbr_idx, C.nbr_d2, C.fpfh);
+  d_fpfh(C.spfh, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, C.fpfh);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_seq_mean(ViewExt<CloudView> x, Clouds2 a) {
@@ -1368,6 +1516,9 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n, int* m
   v.nbr_off = C.nbr_off;
   v.nbr_idx = C.nbr_idx;
   v.nbr_d2 = C.nbr_d2;
+  v.nbr_big_idx = C.nbr_big_idx;
+  v.nbr_big_d2 = C.nbr_big_d2;
+  v.nbr_big_cap = C.nbr_big_cap;
   v.spts = C.spts;
   v.ranges = C.ranges;
   v.mean = C.mean;
@@ -1493,7 +1644,8 @@ hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStag
 // origin_known: C.mm[0..2] already hold a lower bound of the points (the raw cloud's minimum, left there by the voxel
 // stage whose centroids these are) — the neighbour grid only needs an origin at or below every point (cell_of clamps, so
 // a centroid that rounds an ulp below it is still in cell 0), which saves two launches of a latency-bound chain
-static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean, bool origin_known) {
+static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean, bool origin_known,
+                        bool long_lists) {
   const int nc = S.nc, maxn = S.maxn;
   const int g = min(1024, (maxn + 255) / 256);
   const float cell = r_fpfh * 1.001f;
@@ -1507,25 +1659,30 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
   // thread and the launch went from 21 + 14 us to 51 us)
   LAUNCH_CV(k2_neighbors, S.a, dim3(maxn, nc), dim3(64), 0, st, r2);
+  // lists of more than QTR_KMAX entries (one workgroup per such point; returns at once when the cloud has none)
+  if (long_lists) LAUNCH_CV(k2_neighbors_big, S.a, dim3(maxn, nc), dim3(256), (size_t)NBIG_LDS_KEYS * 8, st, r2);
   LAUNCH_CV(k2_normals, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, rn2);
   LAUNCH_CV(k2_spfh, S.a, dim3((maxn + SPFH_PB - 1) / SPFH_PB, nc), dim3(256), 0, st);
   LAUNCH_CV(k2_fpfh, S.a, dim3((maxn + FPFH_PB - 1) / FPFH_PB, nc), dim3(256), 0, st);
   if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
 }
 
+// long_lists: also launch k2_neighbors_big, which serves the points with more than QTR_KMAX neighbours inside r_fpfh.
+// Voxel-grid centroids at the demo's leaf never have that many, so the whole-path drivers leave it out (one launch
+// fewer on the chain) and check CNT_NBR_OVERFLOW afterwards: if it is set the stage is run again with long_lists.
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known) {
+                        bool with_mean, bool origin_known, bool long_lists) {
   (void)hipGetLastError();
   CloudView v[2];
   for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, with_mean, origin_known);
+  fpfh_launch(S, r_normal, r_fpfh, st, with_mean, origin_known, long_lists);
   return hipGetLastError();
 }
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st) {
+                              hipStream_t st, bool long_lists) {
   (void)hipGetLastError();
   std::vector<CloudView> v((size_t)2 * G);
   for (int g = 0; g < G; ++g)
@@ -1533,7 +1690,7 @@ hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, false, true);  // always behind voxelize_enqueue_group
+  fpfh_launch(S, r_normal, r_fpfh, st, false, true, long_lists);  // always behind voxelize_enqueue_group
   return hipGetLastError();
 }
 
@@ -1644,4 +1801,13 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
 }
 
 hipError_t match_init_attributes();
-hipError_t frontend_init_attributes() { return match_init_attributes(); }
+hipError_t frontend_init_attributes() {
+  hipError_t e;
+  if ((e = hipFuncSetAttribute((const void*)k2_neighbors_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NBIG_LDS_KEYS * 8)) != hipSuccess)
+    return e;
+  if ((e = hipFuncSetAttribute((const void*)k2_neighbors_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NBIG_LDS_KEYS * 8)) != hipSuccess)
+    return e;
+  return match_init_attributes();
+}

@@ -25,7 +25,8 @@ DBG_SOLVER_STATE = 14
 
 
 class Limits(C.Structure):
-    _fields_ = [("max_points", C.c_int), ("max_voxels", C.c_int), ("max_corr", C.c_int), ("n_slots", C.c_int)]
+    _fields_ = [("max_points", C.c_int), ("max_voxels", C.c_int), ("max_corr", C.c_int), ("n_slots", C.c_int),
+                ("max_long_neighbors", C.c_int)]
 
 
 class Params(C.Structure):
@@ -285,9 +286,9 @@ class Handle:
     """One device + n_slots stream slots (qtr_handle)."""
 
     def __init__(self, device: int = 0, max_points: int = 262144, max_voxels: int = 65536, max_corr: int = 24576,
-                 n_slots: int = 1):
+                 n_slots: int = 1, max_long_neighbors: int = 0):
         self._lib = load()
-        lim = Limits(max_points, max_voxels, max_corr, n_slots)
+        lim = Limits(max_points, max_voxels, max_corr, n_slots, max_long_neighbors)
         self._h = C.c_void_p()
         rc = self._lib.qtr_create(device, C.byref(lim), C.byref(self._h))
         if rc != QTR_OK:

@@ -210,3 +210,68 @@ def test_batch_of_mixed_sizes_in_one_lane_group_equals_sequential_calls():
         assert (g["n_src"], g["n_tgt"], g["L"]) == (r["n_src"], r["n_tgt"], r["L"]), i
         assert np.array_equal(g["clique"], r["clique"]) and np.array_equal(g["final_inliers"], r["final_inliers"]), i
         assert np.array_equal(g["T"], r["T"]) or not r["valid"], i
+
+
+def _near_field_patch(n, seed, side=6.0):
+    """An un-voxelised near-field patch: n points on a gently curved, slightly thick surface of side x side metres —
+    hundreds to thousands of neighbours inside r = 0.75 m."""
+    g = np.random.default_rng(seed)
+    p = np.zeros((n, 4), dtype=np.float32)
+    p[:, 0] = g.uniform(0, side, n)
+    p[:, 1] = g.uniform(0, side, n)
+    p[:, 2] = 0.15 * np.sin(1.3 * p[:, 0]) * np.cos(0.9 * p[:, 1]) + g.normal(0, 0.01, n)
+    return p
+
+
+@pytest.mark.parametrize("n,side", [(12000, 6.0), (20000, 4.0), (9000, 1.4)])
+def test_fpfh_with_neighbour_lists_longer_than_256_matches_oracle(qo16, n, side):
+    """pcl's radius search has no cap (reference src/teaser_utils/fpfh.cc:58-72): an un-voxelised near-field patch with
+    ~300 - 2000 neighbours per point goes through qtr_fpfh — lists of more than 256 entries live in the long-list arena —
+    and normals, SPFH and FPFH equal the oracle's bit for bit."""
+    pts = _near_field_patch(n, 5 + n, side)
+    off_o, idx_o, d2_o = qo16.radius_neighbors(pts, 0.75)
+    cnt = np.diff(off_o)
+    assert cnt.max() > 256 and np.median(cnt) > 256, (int(cnt.max()), float(np.median(cnt)))
+    h = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=8192, max_long_neighbors=int(off_o[-1] * 1.2) + 65536)
+    try:
+        nrm_g, de_g = h.fpfh(pts, 0.5, 0.75)
+        off_g = h.debug_fetch(ql.DBG_NBR_OFFSETS, np.int32)
+        sp_g = h.debug_fetch(ql.DBG_SPFH, np.float32).reshape(n, 33)
+    finally:
+        h.close()
+    nrm_o, sp_o, de_o = qo16.fpfh(pts, 0.5, 0.75)
+    assert np.array_equal(off_g.astype(np.int64), off_o)
+
+    def same(a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        return np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+    assert same(nrm_g, nrm_o) and same(sp_g, sp_o) and same(de_g, de_o)
+
+
+def test_register_pair_on_dense_patches_switches_to_long_lists(qo16):
+    """The whole-path entry point leaves k2_neighbors_big out of its chain until a cloud needs it: a pair of dense
+    patches voxelised at a 5 cm leaf (hundreds of centroids inside r = 0.75 m) makes it run the stage again with the
+    long lists — same answer as the oracle, no QTR_ERR_CAPACITY — and an arena that is too small is reported as such."""
+    s = _near_field_patch(30000, 3, 5.0)
+    R = synth.yaw_matrix(0.3)
+    t = s.copy()
+    t[:, :3] = (s[:, :3].astype(np.float64) @ R.T + np.array([0.4, -0.2, 0.05])).astype(np.float32)
+    t[:, :3] += np.random.default_rng(9).normal(0, 0.002, (t.shape[0], 3)).astype(np.float32)
+    fp = ql.default_frontend_params(seed=2, voxel_size=0.05)
+    h = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=16384, max_long_neighbors=24 << 20)
+    try:
+        r = h.register_pair(s, t, fp)
+        r2 = h.register_pair(s, t, fp)  # now with the launch in the chain from the start
+    finally:
+        h.close()
+    o = qo16.register_pair(s, t, leaf=0.05, seed=2)
+    assert (r["n_src"], r["n_tgt"], r["L"]) == (o["n_src"], o["n_tgt"], o["L"])
+    _same(r, o)
+    assert np.array_equal(r2["T"], r["T"]) and np.array_equal(r2["clique"], r["clique"])
+    hs = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=16384, max_long_neighbors=4096)
+    try:
+        with pytest.raises(ql.QuatroHipError) as ei:
+            hs.register_pair(s, t, fp)
+        assert ei.value.code == ql.QTR_ERR_CAPACITY and "max_long_neighbors" in str(ei.value)
+    finally:
+        hs.close()
