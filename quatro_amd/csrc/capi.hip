@@ -1842,10 +1842,6 @@ int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr
     snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
     return QTR_ERR_BAD_ARG;
   }
-  if (!fp->use_crosscheck) {
-    snprintf(h->err, sizeof(h->err), "use_crosscheck = 0 is not supported by the batched path");
-    return QTR_ERR_UNSUPPORTED;
-  }
   QTR_HIP_TRY(h, hipSetDevice(h->device));
   BatchJob& J = h->job;
   J.pairs = pairs;

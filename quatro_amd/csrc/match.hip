@@ -1859,7 +1859,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   const bool crosscheck = views[0].crosscheck != 0;
   const bool fused_tail = crosscheck && max_large <= 32768 && max_ns <= 32768;
   const bool fused16 = max_large <= 16384 && max_ns <= 16384;
-  if (!crosscheck) {  // single pair (qtr_submit_batch refuses it): the unfiltered list, see k_nc_list
+  if (!crosscheck) {  // the unfiltered list, see k_nc_list
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
     LAUNCH_MV(k_nc_list, a, dim3(grid_for(max_large + max_small), 1, G), B256, 0, st);
@@ -1923,7 +1923,7 @@ hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const q
     max_large = max(max_large, v[g].n_large);
     max_ns = max(max_ns, v[g].ns);
   }
-  const bool fused_tail = max_large <= 32768 && max_ns <= 32768;
+  const bool fused_tail = fp->use_crosscheck && max_large <= 32768 && max_ns <= 32768;  // (as match_launch decides)
   for (int g = 0; g < G; ++g) F[g]->gathered = fused_tail && F[g]->m_src != nullptr;
   return match_launch(v.data(), G, F[0]->nn_engine, F[0]->n_cu, stage, st, nullptr);
 }

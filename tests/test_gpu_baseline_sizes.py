@@ -275,3 +275,39 @@ def test_register_pair_on_dense_patches_switches_to_long_lists(qo16):
         assert ei.value.code == ql.QTR_ERR_CAPACITY and "max_long_neighbors" in str(ei.value)
     finally:
         hs.close()
+
+
+@pytest.mark.parametrize("tuple_test", [1, 0])
+def test_batch_without_cross_check_equals_sequential_calls_and_oracle(qo16, tuple_test):
+    """calculateCorrespondences(..., use_crosscheck = false, ...) (reference feature_matcher.cc:146-181) through the batched
+    entry points: corres_ij + corres_ji, with and without the tuple test, for a group of pairs — the records equal the
+    per-pair entry point's and the oracle's."""
+    pairs = [synth.kitti64_pair(i) for i in (1, 2)]
+    fp = ql.default_frontend_params(use_crosscheck=0, use_tuple_test=tuple_test)
+    lim = dict(max_points=131072, max_voxels=32768, max_corr=24576)
+    h1 = ql.Handle(0, **lim)
+    try:
+        seq = []
+        for i, (s, t, _) in enumerate(pairs):
+            f = ql.default_frontend_params(use_crosscheck=0, use_tuple_test=tuple_test, seed=10 + i)
+            seq.append(h1.register_pair(s, t, f))
+    finally:
+        h1.close()
+    hb = ql.Handle(0, n_slots=4, **lim)
+    try:
+        got = hb.register_batch([(s, t, 10 + i) for i, (s, t, _) in enumerate(pairs)], fp)
+    finally:
+        hb.close()
+    for i, (g, r) in enumerate(zip(got, seq)):
+        assert (g["n_src"], g["n_tgt"], g["L"]) == (r["n_src"], r["n_tgt"], r["L"]), i
+        assert r["L"] > (5000 if not tuple_test else 100)
+        assert np.array_equal(g["clique"], r["clique"]) and np.array_equal(g["final_inliers"], r["final_inliers"]), i
+        assert np.array_equal(g["T"], r["T"]), i
+    # the oracle on the first pair: the same list length and solution
+    s, t, _ = pairs[0]
+    vs, vt = qo16.voxelize(s, 0.3), qo16.voxelize(t, 0.3)
+    ds, dt = qo16.fpfh(vs, 0.5, 0.75)[2], qo16.fpfh(vt, 0.5, 0.75)[2]
+    corr = qo16.match(vs, ds, vt, dt, False, bool(tuple_test), 0.95, 10)
+    assert corr.shape[0] == got[0]["L"]
+    o = qo16.solve(vs[corr[:, 0]], vt[corr[:, 1]])
+    assert np.array_equal(got[0]["clique"], o["clique"]) and np.array_equal(got[0]["T"], o["T"])
