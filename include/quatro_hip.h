@@ -307,6 +307,12 @@ typedef struct qtr_pair_desc {
 int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,
                      const qtr_params* prm, qtr_result* results, int mem);
 int qtr_wait(qtr_handle* h);
+/* Raw sweeps through the batched entry: with parameters set here qtr_submit_batch runs the demo's STEP 2 and 3 in front of
+ * the voxel grid on every scan it is given (reference examples/run_global_registration.cpp:136-160:
+ * PatchWork::estimate_ground -> non-ground points -> ImageProjection::segmentCloud -> getValidSegments), i.e. the pair
+ * descriptors then carry raw scans WITH their ground returns and a batch reproduces the demo's whole sequence per pair.
+ * pw = ip = NULL switches it off again (the default).  A scan that is all ground gets QTR_ERR_BAD_ARG in its own record. */
+int qtr_set_batch_preprocess(qtr_handle* h, const qtr_pw_params* pw, const qtr_ip_params* ip);
 
 /* Multi-GPU (BASELINE configs[3]): pairs are independent, so every process / device registers its own block of pair
  * ids and the ONLY exchange is the final gather of the fixed-size result records — RCCL over xGMI (one ncclAllGather of

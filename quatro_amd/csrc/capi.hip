@@ -83,6 +83,9 @@ struct qtr_handle {
   size_t comm_bytes = 0;
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
   double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
+  bool pre_on = false;      // qtr_set_batch_preprocess: the batched entry takes RAW sweeps (ground removal + range-image
+  qtr_pw_params pre_pw;     // segmentation in front of the voxel grid)
+  qtr_ip_params pre_ip;
   bool long_lists = false;  // some cloud of the whole-path entry points had a point with more than QTR_KMAX neighbours:
                             // from then on their FPFH chains include k2_neighbors_big (see front_device)
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
@@ -1631,7 +1634,39 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
       continue;
     }
     const float4 *d_s = (const float4*)pd.src_raw4, *d_t = (const float4*)pd.tgt_raw4;
-    if (J.mem == QTR_MEM_HOST) {
+    int P_s = pd.n_src, P_t = pd.n_tgt;
+    if (h->pre_on) {
+      // The demo's STEP 2 and 3 on raw sweeps (reference examples/run_global_registration.cpp:136-160):
+      // PatchWork::estimate_ground -> non-ground points -> ImageProjection::segmentCloud -> valid segments, per scan, on
+      // this pair's slot (these stages read their counts back, so they run pair by pair; the chains behind them are
+      // shared by the group).  The valid segments land in the slot's staging buffers and are the voxel grid's input.
+      int status = QTR_OK;
+      // (target first: the stages stage a host-resident scan in in_src, which is where the SOURCE's result goes last)
+      for (int c = 1; c >= 0 && status == QTR_OK; --c) {
+        const float* raw = c == 0 ? pd.src_raw4 : pd.tgt_raw4;
+        const int P = c == 0 ? pd.n_src : pd.n_tgt;
+        float4* stage = c == 0 ? s.in_src : s.in_tgt;
+        int ng = 0, nn = 0, nv = 0;
+        status = qtr_patchwork(h, ln.first_slot + g, raw, P, &h->pre_pw, nullptr, 0, &ng, nullptr, 0, &nn, J.mem);
+        if (status == QTR_OK)
+          status = qtr_segment_cloud(h, ln.first_slot + g, (const float*)s.pwb.out_n, nn, &h->pre_ip, nullptr, 0, &nv, nullptr,
+                                     0, nullptr, nullptr, nullptr, QTR_MEM_DEVICE);
+        if (status == QTR_OK && nv > h->lim.max_points) status = QTR_ERR_CAPACITY;
+        // (on the slot's own stream: the next scan's stages, which reuse the buffers this copy reads, queue up behind it)
+        if (status == QTR_OK && nv > 0)
+          QTR_HIP_TRY(h, hipMemcpyAsync(stage, s.seg.out_valid, (size_t)nv * 16, hipMemcpyDeviceToDevice, s.stream));
+        (c == 0 ? P_s : P_t) = nv;
+      }
+      if (status == QTR_ERR_HIP) return status;
+      QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // the group's chain (lane stream) reads the staging buffers
+      if (status == QTR_OK && (P_s <= 0 || P_t <= 0)) status = QTR_ERR_BAD_ARG;  // nothing but ground: an empty cloud
+      if (status != QTR_OK) {
+        batch_fail_pair(h, ln.first_pair + g, status);
+        continue;
+      }
+      d_s = s.in_src;
+      d_t = s.in_tgt;
+    } else if (J.mem == QTR_MEM_HOST) {
       QTR_HIP_TRY(h, hipMemcpyAsync(s.in_src, pd.src_raw4, (size_t)pd.n_src * 16, hipMemcpyHostToDevice, lead.stream));
       QTR_HIP_TRY(h, hipMemcpyAsync(s.in_tgt, pd.tgt_raw4, (size_t)pd.n_tgt * 16, hipMemcpyHostToDevice, lead.stream));
       d_s = s.in_src;
@@ -1643,8 +1678,8 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
     F.push_back(&s.fb);
     raws.push_back(d_s);
     raws.push_back(d_t);
-    Ps.push_back(pd.n_src);
-    Ps.push_back(pd.n_tgt);
+    Ps.push_back(P_s);
+    Ps.push_back(P_t);
   }
   if (ln.active.empty()) return lane_start_chunk(h, ln);  // nothing valid in this chunk: take the next one
   QTR_HIP_TRY(h, voxelize_enqueue_group(F.data(), (int)F.size(), raws.data(), Ps.data(), J.fp.voxel_size, &ln.stage,
@@ -1823,6 +1858,20 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
   }
   if (copies) QTR_HIP_TRY(h, hipStreamSynchronize(lead.stream));
   return lane_start_chunk(h, ln);
+}
+
+int qtr_set_batch_preprocess(qtr_handle* h, const qtr_pw_params* pw, const qtr_ip_params* ip) {
+  if (!h || (pw == nullptr) != (ip == nullptr)) return QTR_ERR_BAD_ARG;
+  if (h->job.active) {
+    snprintf(h->err, sizeof(h->err), "a batch is in flight on this handle (call qtr_wait first)");
+    return QTR_ERR_BAD_ARG;
+  }
+  h->pre_on = pw != nullptr;
+  if (pw) {
+    h->pre_pw = *pw;
+    h->pre_ip = *ip;
+  }
+  return QTR_OK;
 }
 
 int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,

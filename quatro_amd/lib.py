@@ -85,7 +85,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -184,6 +184,7 @@ def load():
     lib.qtr_feature_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.POINTER(FrontendParams), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_set_batch_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
@@ -558,6 +559,15 @@ class Handle:
                             "cost": r.cost, "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr,
                             "n_clique": r.n_clique, "n_final": r.n_final, "n_rot_inliers": r.n_rot_inliers})
         return out
+
+    def set_batch_preprocess(self, pw: "PwParams | None" = None, ip: "IpParams | None" = None, on: bool = True):
+        """Raw sweeps through register_batch: Patchwork ground removal + range-image segmentation in front of the voxel
+        grid (qtr_set_batch_preprocess); on=False switches it off again."""
+        if not on:
+            self._check(self._lib.qtr_set_batch_preprocess(self._h, None, None))
+            return
+        self._pre = (pw or pw_params(), ip or ip_params())
+        self._check(self._lib.qtr_set_batch_preprocess(self._h, C.byref(self._pre[0]), C.byref(self._pre[1])))
 
     def register_batch_dev(self, items, prm: Params, fp: FrontendParams | None = None):
         """items: dicts with device tensors "src" / "tgt" and a FrontendParams "fp" (its seed is the pair's seed).

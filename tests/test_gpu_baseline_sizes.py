@@ -311,3 +311,27 @@ def test_batch_without_cross_check_equals_sequential_calls_and_oracle(qo16, tupl
     assert corr.shape[0] == got[0]["L"]
     o = qo16.solve(vs[corr[:, 0]], vt[corr[:, 1]])
     assert np.array_equal(got[0]["clique"], o["clique"]) and np.array_equal(got[0]["T"], o["T"])
+
+
+def test_batch_on_raw_sweeps_runs_the_demo_sequence(qo16):
+    """qtr_set_batch_preprocess: the batched entry on raw sweeps WITH their ground returns — per scan
+    PatchWork::estimate_ground -> ImageProjection::segmentCloud -> valid segments, then the usual chain (reference
+    examples/run_global_registration.cpp:136-160, 206-246) — against the same sequence through the oracle."""
+    scans = [synth.kitti64_raw_scan(i)[0] for i in range(3)]
+    pairs = [(scans[0], scans[1], 4), (scans[1], scans[2], 5), (scans[2], scans[0], 6)]
+    ref = []
+    for a, b, seed in pairs:
+        clouds = [qo16.segment_cloud(qo16.patchwork(raw)["nonground"])["valid"] for raw in (a, b)]
+        ref.append(qo16.register_pair(clouds[0], clouds[1], seed=seed))
+    hb = ql.Handle(0, n_slots=4, max_points=131072, max_voxels=32768, max_corr=8192)
+    try:
+        hb.set_batch_preprocess()
+        got = hb.register_batch(pairs)
+        hb.set_batch_preprocess(on=False)
+        plain = hb.register_batch([(scans[0], scans[1], 4)])  # the same handle without it: the raw sweep as it is
+    finally:
+        hb.close()
+    for i, (g, o) in enumerate(zip(got, ref)):
+        assert (g["n_src"], g["n_tgt"], g["L"]) == (o["n_src"], o["n_tgt"], o["L"]), i
+        _same(g, o)
+    assert plain[0]["n_src"] != got[0]["n_src"]
