@@ -680,16 +680,47 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
   int item = blockIdx.x;
 #pragma unroll 1
   while (true) {
-    if (item >= total) break;
+    // A single pair's one round of items: consecutive workgroup ids go to the eight XCDs in turn, and with item =
+    // (query block, slice) numbered slice-fastest every XCD would stream ALL query blocks against one eighth of the
+    // base (8 x (Q + B / 8) of L2 fill: 33 MB for direction 0's 7.6 MB of tables).  Instead the (query block, slice)
+    // grid is cut into 2 x 4 rectangles, enumerated rectangle by rectangle, and XCD x takes the x-th eighth of that
+    // enumeration (workgroup 8 j + x its j-th cell): every XCD then meets about half of the query blocks and a quarter
+    // of the base, 8 x (Q / 2 + B / 4).
+    const bool dealt = G == 1 && total <= (int)gridDim.x && (gridDim.x & 7) == 0;
+    int cell = item;
+    if (dealt) {
+      const int per = (total + 7) >> 3, j = item >> 3;
+      cell = (j < per) ? (item & 7) * per + j : total;
+    }
+    if (cell >= total) break;
     int g = 0;
-    while (g + 1 < G && item >= s_off[g + 1]) ++g;
+    while (g + 1 < G && cell >= s_off[g + 1]) ++g;
     const MatchView& V = EXT ? x.ext[g] : one;  // (inline on purpose: see ViewExt)
     const NnDir& D = V.d[dir];
     const int ntiles = D.nb_pad / 32;
     const int nsplit = s_ns[g], tps = s_tps[g];
     NnPartial* __restrict__ partial = V.partial;
-    const int local = item - s_off[g];
-    const int qb = local / nsplit, slice = local - qb * nsplit;
+    const int local = cell - s_off[g];
+    int qb = local / nsplit, slice = local - qb * nsplit;
+    if (dealt) {
+      const int nqb = total / nsplit, qh = (nqb + 1) >> 1, sq = (nsplit + 3) >> 2;
+      int rem = cell;
+      bool found = false;
+#pragma unroll
+      for (int A = 0; A < 2; ++A) {
+        const int rows = A == 0 ? qh : nqb - qh;
+#pragma unroll
+        for (int B = 0; B < 4; ++B) {
+          const int cols = min(sq, max(0, nsplit - B * sq)), cells = rows * cols;
+          if (!found && rem < cells) {
+            qb = A * qh + rem / cols;
+            slice = B * sq + rem % cols;
+            found = true;
+          }
+          if (!found) rem -= cells;
+        }
+      }
+    }
     const int qbase = (qb * 4 + wave) * NN_QPW + col;
     const int t_begin = slice * tps, t_end = min(ntiles, t_begin + tps);
     float b1[4], b2[4];
