@@ -58,7 +58,7 @@ class FPFHManager {
     if (normal_radius_ > fpfh_radius_)
       throw std::invalid_argument("[FPFHManager]: Normal should be lower than fpfh_radius!!!!");  // :99-102
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
     if (is_initial_ && !is_odometry_test_) {
       src_cloud_.assign(src->points.begin(), src->points.end());  // PCL's storage has its own allocator type
       compute(h, src_cloud_, obj_desc_);
@@ -77,7 +77,7 @@ class FPFHManager {
     const int ns = static_cast<int>(src_cloud_.size()), nt = static_cast<int>(tgt_cloud_.size());
     std::vector<int> c2(2 * static_cast<size_t>(ns < nt ? ns : nt) + 2);
     int L = 0;
-    quatro_hip::check(h, qtr_match(h, 0, quatro_hip::xyz4(src_cloud_), ns, obj_desc_.data(), quatro_hip::xyz4(tgt_cloud_),
+    quatro_hip::check(h, qtr_match(h, slot_lease.slot, quatro_hip::xyz4(src_cloud_), ns, obj_desc_.data(), quatro_hip::xyz4(tgt_cloud_),
                                    nt, scene_desc_.data(), &fp, c2.data(), static_cast<int>(c2.size() / 2), &L,
                                    QTR_MEM_HOST));
     corr.clear();
@@ -137,7 +137,8 @@ class FPFHManager {
   std::string savedir_, loaddir_;
   void compute(qtr_handle* h, const std::vector<PointType>& cloud, std::vector<float>& desc) {
     desc.assign(33 * cloud.size(), 0.f);
-    quatro_hip::check(h, qtr_fpfh(h, 0, quatro_hip::xyz4(cloud), static_cast<int>(cloud.size()),
+    quatro_hip::SlotLease slot_lease;  // (the caller's lease, when it holds one: setFeaturePair)
+    quatro_hip::check(h, qtr_fpfh(h, slot_lease.slot, quatro_hip::xyz4(cloud), static_cast<int>(cloud.size()),
                                   static_cast<float>(normal_radius_), static_cast<float>(fpfh_radius_), nullptr,
                                   desc.data(), QTR_MEM_HOST));
   }

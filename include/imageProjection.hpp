@@ -49,8 +49,8 @@ class ImageProjection {
     outl_.assign(4 * NP, 0.f);
     labelmat_.assign(NP, -1);
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_segment_cloud(h, 0, reinterpret_cast<const float*>(pcPtr->points.data()), P, &ip_,
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_segment_cloud(h, slot_lease.slot, reinterpret_cast<const float*>(pcPtr->points.data()), P, &ip_,
                                            valid_.data(), static_cast<int>(NP), &n_valid_, outl_.data(),
                                            static_cast<int>(NP), &n_outl_, &n_segments_, labelmat_.data(), QTR_MEM_HOST));
   }

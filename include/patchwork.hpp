@@ -84,9 +84,9 @@ class PatchWork {
     n_.resize(4 * cap);
     int ng = 0, nn = 0;
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
     const float* in = pack(cloudIn);
-    quatro_hip::check(h, qtr_patchwork(h, 0, in, P, &pw_, g_.data(), static_cast<int>(cap), &ng, n_.data(),
+    quatro_hip::check(h, qtr_patchwork(h, slot_lease.slot, in, P, &pw_, g_.data(), static_cast<int>(cap), &ng, n_.data(),
                                        static_cast<int>(cap), &nn, QTR_MEM_HOST));
     unpack(g_, ng, cloudOut);
     unpack(n_, nn, cloudNonground);

@@ -152,8 +152,8 @@ void voxelize(const QUATRO_SHARED_PTR<pcl::PointCloud<T>> srcPtr, QUATRO_SHARED_
   decltype(dstPtr->points) out(static_cast<size_t>(P), T());  // a temporary, like pcl::Filter::filter: dstPtr may alias srcPtr
   int n = 0;
   {
-    std::lock_guard<std::recursive_mutex> lock(quatro_hip::default_slot_mutex());
-    quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(srcPtr->points), P, static_cast<float>(voxelSize),
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_voxelize(h, slot_lease.slot, quatro_hip::xyz4(srcPtr->points), P, static_cast<float>(voxelSize),
                                       reinterpret_cast<float*>(out.data()), P, &n, QTR_MEM_HOST));
   }
   out.resize(static_cast<size_t>(n));
@@ -166,8 +166,8 @@ void voxelize(pcl::PointCloud<T>& src, QUATRO_SHARED_PTR<pcl::PointCloud<T>> dst
   decltype(dstPtr->points) out(static_cast<size_t>(P), T());  // dstPtr may point at src
   int n = 0;
   {
-    std::lock_guard<std::recursive_mutex> lock(quatro_hip::default_slot_mutex());
-    quatro_hip::check(h, qtr_voxelize(h, 0, quatro_hip::xyz4(src.points), P, static_cast<float>(voxelSize),
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_voxelize(h, slot_lease.slot, quatro_hip::xyz4(src.points), P, static_cast<float>(voxelSize),
                                       reinterpret_cast<float*>(out.data()), P, &n, QTR_MEM_HOST));
   }
   out.resize(static_cast<size_t>(n));
@@ -272,7 +272,7 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     if (params_.cote_mode != "median" && params_.cote_mode != "weighted_mean")
       throw std::invalid_argument("[COTE]: Wrong parameter comes!");  // :911
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
     qtr_params p;
     qtr_default_params(&p);
     p.noise_bound = params_.noise_bound;
@@ -293,9 +293,9 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     p.reg_mode = reg_name_ == "TEASER" ? QTR_REG_TEASER : QTR_REG_QUATRO;
     qtr_result res;
     {
-      std::lock_guard<std::recursive_mutex> lock(quatro_hip::default_slot_mutex());
+      quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
       qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
-      const int rc = qtr_solve(h, 0, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
+      const int rc = qtr_solve(h, slot_lease.slot, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
                                clique.data(), rot.data(), fin.data(), static_cast<int>(clique.size()), QTR_MEM_HOST);
       quatro_hip::check(h, rc);
     }
@@ -338,8 +338,8 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < N; ++c) in[static_cast<size_t>(r) * N + c] = v(r, c);
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_compute_tims(h, 0, in.data(), N, out.data(), mp.data()));
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_compute_tims(h, slot_lease.slot, in.data(), N, out.data(), mp.data()));
     for (int r = 0; r < 3; ++r)
       for (long long c = 0; c < K; ++c) vtilde(r, static_cast<int>(c)) = out[static_cast<size_t>(r) * K + c];
     if (map)
@@ -372,8 +372,8 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       }
     std::vector<unsigned char> mask(static_cast<size_t>(K));
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_scale_mask(h, 0, a.data(), b.data(), K, params_.noise_bound, params_.cbar2, mask.data()));
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_scale_mask(h, slot_lease.slot, a.data(), b.data(), K, params_.noise_bound, params_.cbar2, mask.data()));
     for (long long c = 0; c < K; ++c) (*inliers)(0, static_cast<int>(c)) = mask[static_cast<size_t>(c)] != 0;
   }
 
@@ -397,8 +397,8 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
       int iters = 0;
       std::vector<unsigned char> inl(static_cast<size_t>(M));
       qtr_handle* h = quatro_hip::default_handle();
-      std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-      quatro_hip::check(h, qtr_gnc_rotation3d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
+      quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+      quatro_hip::check(h, qtr_gnc_rotation3d(h, slot_lease.slot, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
                                               static_cast<int>(params_.rotation_max_iterations),
                                               params_.rotation_cost_threshold, R9, &cost, &iters, inl.data()));
       cost_ = cost;
@@ -448,8 +448,8 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     int iters = 0;
     std::vector<unsigned char> inl(static_cast<size_t>(M));
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_gnc_rotation2d(h, 0, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_gnc_rotation2d(h, slot_lease.slot, a.data(), b.data(), M, params_.noise_bound, params_.rotation_gnc_factor,
                                             static_cast<int>(params_.rotation_max_iterations),
                                             params_.rotation_cost_threshold, R4, &cost, &iters, inl.data()));
     cost_ = cost;
@@ -500,12 +500,12 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     double e = 0;
     int ncard = 0;
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
     if (uniform)
-      quatro_hip::check(h, qtr_cote_estimate(h, 0, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e,
+      quatro_hip::check(h, qtr_cote_estimate(h, slot_lease.slot, x.data(), N, ranges(0, 0), using_median_selection ? 1 : 0, &e,
                                              inl.data(), &ncard));
     else
-      quatro_hip::check(h, qtr_cote_estimate_ranges(h, 0, x.data(), r.data(), N, using_median_selection ? 1 : 0, &e,
+      quatro_hip::check(h, qtr_cote_estimate_ranges(h, slot_lease.slot, x.data(), r.data(), N, using_median_selection ? 1 : 0, &e,
                                                     inl.data(), &ncard));
     if (estimate_out) *estimate_out = e;
     if (inliers) {

@@ -44,8 +44,8 @@ class Matcher {
     std::vector<int> corr2(static_cast<size_t>(2) * cap);
     int L = 0;
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_match(h, 0, xs.data(), ns, ds.data(), xt.data(), nt, dt.data(), &fp, corr2.data(), cap, &L,
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_match(h, slot_lease.slot, xs.data(), ns, ds.data(), xt.data(), nt, dt.data(), &fp, corr2.data(), cap, &L,
                                    QTR_MEM_HOST));
     corres_.reserve(static_cast<size_t>(L));
     for (int c = 0; c < L; ++c) corres_.emplace_back(corr2[2 * static_cast<size_t>(c)], corr2[2 * static_cast<size_t>(c) + 1]);

@@ -53,8 +53,8 @@ class FPFHEstimation {
       xyz4[4 * static_cast<size_t>(i) + 2] = input_cloud[static_cast<size_t>(i)].z;
     }
     qtr_handle* h = quatro_hip::default_handle();
-    std::lock_guard<std::recursive_mutex> slot_lock(quatro_hip::default_slot_mutex());  // slot 0 is shared
-    quatro_hip::check(h, qtr_fpfh(h, 0, xyz4.data(), n, static_cast<float>(normal_search_radius),
+    quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
+    quatro_hip::check(h, qtr_fpfh(h, slot_lease.slot, xyz4.data(), n, static_cast<float>(normal_search_radius),
                                   static_cast<float>(fpfh_search_radius), nrm.data(), desc.data(), QTR_MEM_HOST));
     for (int i = 0; i < n; ++i) {
       pcl::Normal& q = normals.points[static_cast<size_t>(i)];

@@ -690,6 +690,37 @@ def test_cpp_teaser_graph_dropin(hip, qo, tmp_path):
     assert [int(x) for x in out[7:]] == np.sort(qo.max_clique(bm, 0)).tolist()
 
 
+def test_cpp_objects_on_several_threads_use_their_own_slots(hip, tmp_path):
+    """Independent drop-in objects driven from four threads at once (tests/cpp/threads_demo.cpp): every wrapper call
+    leases a free stream slot of the process-wide handle instead of queueing behind one mutex, and every thread gets the
+    answers it gets alone."""
+    import subprocess
+
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    bm, A = _random_graph_bitmap(500, 0.05, 5, 20)
+    ii, jj = np.nonzero(np.triu(A, 1))
+    with open(tmp_path / "edges.txt", "w") as f:
+        f.write("500\n")
+        for a, b in zip(ii, jj):
+            f.write(f"{a} {b}\n")
+    exe = str(tmp_path / "threads_demo")
+    libdir = os.path.join(root, "quatro_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "threads_demo.cpp"), "-o", exe, "-L", libdir,
+                           "-lquatro_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    p = None
+    for extra in ("", os.path.join(os.path.dirname(torch.__file__), "lib")):
+        env = dict(os.environ)
+        if extra:
+            env["LD_LIBRARY_PATH"] = extra + ":" + env.get("LD_LIBRARY_PATH", "")
+        p = subprocess.run([exe, str(tmp_path / "edges.txt"), "4", "25"], env=env, capture_output=True, text=True, timeout=300)
+        if p.returncode == 0:
+            break
+    assert p.returncode == 0, (p.stdout[-300:], p.stderr[-500:])
+    assert "mismatches 0 slots 4" in p.stdout
+
+
 def test_dense_mode_front_end_at_50k_points(qo):
     """BASELINE configs[4] (dense mode: 50 000-point clouds, no voxel step) through the front end: FPFH + matching
     at n = 50 k via properties (descriptor blocks sum to 100 or 0, rigid-motion invariance of the matching) and
