@@ -1815,6 +1815,25 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     int i = 0;
     // sixteen terms per round: the loads go out back to back, the additions stay a dependent chain in the reference's
     // order, the stores follow (one wavefront issues an instruction every ~5 clocks, so instructions per event matter)
+    // (the arrays start 16-byte aligned — nc is even and the carving rounds to 16 — so two terms travel per LDS access:
+    // the wave issues one instruction every ~8 clocks, and it is the instruction count that bounds this chain)
+    typedef double cote_d2 __attribute__((ext_vector_type(2)));
+    if ((((size_t)t) & 15) == 0) {
+      for (; i + 16 <= nc; i += 16) {
+        cote_d2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *(const cote_d2*)(t + i + 2 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc += v[q].x;
+          v[q].x = acc;
+          acc += v[q].y;
+          v[q].y = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(cote_d2*)(t + i + 2 * q) = v[q];
+      }
+    }
     for (; i + 16 <= nc; i += 16) {
       double v[16];
 #pragma unroll
