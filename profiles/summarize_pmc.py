@@ -24,5 +24,5 @@ out = dict(kernel=pat, fetch=f, write=w,
            correction=("FETCH_SIZE x 2 (16 B/lane streaming reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE raw" if wide else
                        "none applied (dword loads; FETCH_SIZE x2 rule is calibrated for 16 B/lane reads only)"),
            command="rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 8 --warmup 2 "
-                   "--legs '' --cpu-seconds 0 (two separate passes; profiles/collect_r2.sh)")
+                   "--legs '' --cpu-seconds 0 (two separate passes; profiles/collect_r3.sh)")
 print(json.dumps(out, indent=1))
