@@ -37,20 +37,48 @@ typedef unsigned int u32;
 // ---- wave-level helpers ------------------------------------------------------------------------
 __device__ __forceinline__ int qk_lane() { return (int)(threadIdx.x & 63); }
 
+// Integer reductions across a wave whose 64 lanes are ALL active (every caller's case), on DPP row shifts and four
+// scalar reads: ~11 instructions.  The shuffle form (seven __shfl_down, each an LDS-crossbar permute plus its index
+// arithmetic: ~50 instructions and seven LDS round trips) cost 0.4 us wherever a wave was alone on a dependent chain —
+// k_hcore_async's rows spent most of their time in it.  Results are uniform.
+#define QK_DPP_SHR(n) (0x110 | (n))
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
+  v += __builtin_amdgcn_update_dpp(0, v, QK_DPP_SHR(1), 0xf, 0xf, true);  // lanes shifted in from outside the row read 0
+  v += __builtin_amdgcn_update_dpp(0, v, QK_DPP_SHR(2), 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, QK_DPP_SHR(4), 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, QK_DPP_SHR(8), 0xf, 0xf, true);  // lane 15 of every row of 16 holds the row's sum
+  return (__builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31)) +
+         (__builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(1), 0xf, 0xf, false));  // (outside the row: the lane's own value)
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(2), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(4), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(8), 0xf, 0xf, false));
+  return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+             max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(1), 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(2), 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(4), 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, QK_DPP_SHR(8), 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+             min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+// exclusive prefix sum of one int per lane across the wave (all 64 lanes active)
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int* total) {
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, QK_DPP_SHR(1), 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, QK_DPP_SHR(2), 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, QK_DPP_SHR(4), 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, QK_DPP_SHR(8), 0xf, 0xf, true);  // inclusive inside every row of 16
+  const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47),
+            t3 = __builtin_amdgcn_readlane(x, 63);
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  x += row == 0 ? 0 : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2;
+  *total = (t0 + t1) + (t2 + t3);
+  return x - v;
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
@@ -98,18 +126,6 @@ __device__ __forceinline__ float wave_sum64_f32(float v) {  // qm_sum64_fold_f a
   return __shfl(v, 0, 64);
 }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << qk_lane()) - 1ULL; }
-
-// exclusive prefix sum of one int per lane across the wave
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int* total) {
-  int x = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int y = __shfl_up(x, off, 64);
-    if (qk_lane() >= off) x += y;
-  }
-  *total = __shfl(x, 63, 64);
-  return x - v;
-}
 
 // Views of a batched launch that live in device memory reach the kernels through this small by-value struct (NOT a
 // bare pointer parameter and NOT a member of a large argument struct): with this shape the compiler's kernel-argument

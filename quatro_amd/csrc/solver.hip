@@ -7,6 +7,7 @@
 // solveForRotation2D (:430-572) + svdRot2d (include/teaser/utils.h:151-166), solveForTranslation /
 // estimate (:585-747).  No TIM is ever materialised: the L x L predicate is evaluated tile-wise and
 // ballot-packed into a bit matrix (L^2/8 bytes instead of the reference's ~32.5 L^2 bytes).
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -479,6 +480,24 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
 #define HCA_MAXWG 1024
 #define HCA_CTL_VER 64
 #define HCA_CTL_DONE (64 + HCA_MAXWG)
+#ifdef QTR_HCA_PROF  // diagnostic build only (tests/gpu_hca_prof.py): where an iteration's time goes, per workgroup
+__device__ unsigned g_hca_prof[HCA_MAXWG * 8];
+#define HCA_MARK(k)                                   \
+  do {                                                \
+    if (tid == 0) {                                   \
+      const unsigned long long now_ = wall_clock64(); \
+      prof_acc[k] += (unsigned)(now_ - prof_last);    \
+      prof_last = now_;                               \
+    }                                                 \
+  } while (0)
+#define HCA_COUNT(k) \
+  do {               \
+    if (tid == 0) ++prof_acc[k]; \
+  } while (0)
+#else
+#define HCA_MARK(k)
+#define HCA_COUNT(k)
+#endif
 __device__ __forceinline__ unsigned hca_load_u32(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -497,12 +516,12 @@ __global__ __launch_bounds__(256) void k_hcore_async_init(ViewExt<SolverView> x,
   if (v < HCA_CTL_DONE + HCA_MAXWG) V.perm[v] = 0;  // control words, versions, marks (perm is not in use yet; L > 3000)
 }
 template <bool EXT>
-__global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int rows_in_lds) {
+__global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int pool_entries) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L, W = V.W;
   if (L <= 0) return;
   const int NWG = gridDim.x, w = blockIdx.x;
-  const int R = (L + NWG - 1) / NWG;
+  const int R = (L + NWG - 1) / NWG, Rp = (R + 3) & ~3;
   const int r_lo = min(L, w * R), r_hi = min(L, r_lo + R), nown = r_hi - r_lo;
   const u64* __restrict__ bm = V.bm;
   unsigned short* gvals = (unsigned short*)V.Kp;
@@ -510,14 +529,55 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   unsigned* done = (unsigned*)V.perm + HCA_CTL_DONE;
   extern __shared__ __attribute__((aligned(16))) unsigned char hca_lds[];
   const int Lp = (L + 63) & ~63;
-  unsigned short* vals = (unsigned short*)hca_lds;                 // [Lp] the snapshot
-  u64* dirty = (u64*)(hca_lds + (size_t)2 * Lp);                   // [W] vertices whose value moved since my last snapshot
-  u64* rows = (u64*)(hca_lds + (size_t)2 * Lp + (size_t)8 * W);    // [nown][W] when rows_in_lds
+  unsigned char* lp = hca_lds;
+  unsigned short* vals = (unsigned short*)lp;  // [Lp] the snapshot
+  lp += (size_t)2 * Lp;
+  int* nb_off = (int*)lp;  // [Rp + 4] where my rows' neighbour lists start in the pool (entry nown: the end of the last)
+  lp += (size_t)4 * (Rp + 4);
+  int* mine = (int*)lp;  // [Rp] my rows' current values (what I stored last)
+  lp += (size_t)4 * Rp;
+  unsigned short* pool = (unsigned short*)lp;  // [pool_entries] neighbour ids of my rows, row after row
   __shared__ unsigned s_sum[HCA_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (rows_in_lds)
-    for (int e = tid; e < nown * W; e += HCA_THREADS) rows[e] = bm[(size_t)r_lo * W + e];
+  // ---- set-up: my rows as neighbour LISTS.  A wave issues an instruction every ~8 clocks however many of its lanes are
+  // busy, and every iteration of every workgroup waits for its slowest wave: what an iteration costs is the NUMBER of
+  // instructions a row takes.  Off the bit row, a neighbour's value costs a find-first-set / clear-lowest / address /
+  // read chain of ~17 instructions and most lanes hold no neighbour at all; off a list it is two LDS reads per lane and
+  // a row of 80 neighbours is two per lane.  (Rows whose list does not fit the pool keep the bit row, read from memory.)
   for (int i = tid; i < (Lp >> 1); i += HCA_THREADS) ((unsigned*)vals)[i] = 0xffffffffu;  // "everything moved" the first time
+  if (wave == 0) {
+    int run = 0;
+    for (int base = 0; base < nown; base += 64) {
+      const int rl = base + lane;
+      const int d = rl < nown ? V.deg[r_lo + rl] : 0;  // (k_hcore_async_init left the degrees there)
+      int tot = 0;
+      const int ex = wave_excl_scan_i32(d, &tot);
+      if (rl < nown) {
+        nb_off[rl] = run + ex;
+        mine[rl] = min(d, 65535);  // = what k_hcore_async_init stored
+      }
+      run += tot;
+    }
+    if (lane == 0) nb_off[nown] = run;
+  }
+  __syncthreads();
+  for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
+    if (nb_off[rl + 1] > pool_entries) continue;
+    const u64* rowp = bm + (size_t)(r_lo + rl) * W;
+    int run = nb_off[rl];
+    for (int base = 0; base < W; base += 64) {
+      const int wd = base + lane;
+      u64 bits = wd < W ? rowp[wd] : 0;
+      int tot = 0;
+      int at = run + wave_excl_scan_i32(__popcll(bits), &tot);
+      while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        pool[at++] = (unsigned short)(wd * 64 + b);
+      }
+      run += tot;
+    }
+  }
   unsigned myver = 0;  // (thread 0) this workgroup's version counter
   unsigned v0 = 0, E0 = 0;
   bool bump = false;      // values were lowered in the previous iteration: ver[w] has to follow once they have landed
@@ -525,58 +585,68 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   int iter = 0;
   bool finished = false;
   __syncthreads();
-  for (; iter < HCA_MAXITER && !finished; ++iter) {
-    // 1. snapshot of all values (four per load); a vertex whose value differs from the previous snapshot is dirty
-    for (int i = tid; i < W; i += HCA_THREADS) dirty[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
-      const u64 nv = hca_load_u64((const u64*)gvals + i), ov = ((u64*)vals)[i];
-      if (nv != ov) {
-        ((u64*)vals)[i] = nv;
-        const u64 df = nv ^ ov;
-        unsigned m = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m |= ((df >> (16 * q)) & 0xffffu) ? (1u << q) : 0u;
-        atomicOr((unsigned*)dirty + (i >> 3), m << ((i & 7) * 4));  // vertices 4 i .. 4 i + 3
+#ifdef QTR_HCA_PROF
+  unsigned prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 10 ns ticks: [0] set-up, [1] snapshots, [2] rows, [3] protocol; counts: [4] iterations
+  unsigned long long prof_last = wall_clock64();     // that lowered something, [5] idle ones; [2] is wave 0 alone, [6] / [7] the wait for the other waves after it (lowering / idle)
+#endif
+  // the h-index of a row, given how to count: the largest t <= cv with count_ge(t) >= t (monotone in t).  Values drop in
+  // small steps: probe cv, cv - 1, cv - 3, cv - 7 ... until one holds, then bisect the last gap.  Returns cv if it stands.
+  auto h_index = [&](int cv, auto&& count_ge) __attribute__((always_inline)) -> int {
+    if (count_ge(cv) >= cv) return cv;
+    int bad = cv, good = 0;  // invariant: predicate holds at `good` (t = 0 always), fails at `bad`
+    for (int step = 1; bad - step > 0; step <<= 1) {
+      const int t = bad - step;
+      if (count_ge(t) >= t) {
+        good = t;
+        break;
       }
+      bad = t;
     }
-    // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
-    // the coherence point as well: only now may the version say so)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bump = false;
-    // 2. own rows with a dirty neighbour: one wavefront per row
-    bool changed = false;
-    for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
-      const int v = r_lo + rl;
-      const int cv = vals[v];
-      if (cv <= 0) continue;
-      const u64* rowp = rows_in_lds ? rows + (size_t)rl * W : bm + (size_t)v * W;
-      // the row's words stay in registers for every pass below (five words per lane serve L <= 20480; beyond, re-read)
-      u64 rw[5];
-      bool touched = false;
+    while (good + 1 < bad) {
+      const int mid = (good + bad) >> 1;
+      if (count_ge(mid) >= mid) good = mid;
+      else bad = mid;
+    }
+    return good;
+  };
+  // a row of at most 64 S neighbours: their values into S registers per lane, a probe is S compares and a wave sum
+  auto row_by_list = [&](int cv, int off, int deg, auto s_tag) __attribute__((always_inline)) -> int {
+    constexpr int S = decltype(s_tag)::value;
+    int xv[S];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const int wd = lane + 64 * q;
-        rw[q] = wd < W ? rowp[wd] : 0;
-        touched |= wd < W && (rw[q] & dirty[wd]) != 0;
-      }
-      for (int wd = lane + 320; wd < W; wd += 64) touched |= (rowp[wd] & dirty[wd]) != 0;
-      if (!__any(touched)) continue;  // no neighbour moved: the value stands
-      auto count_ge = [&](int th) {  // neighbours holding a value >= th
+    for (int k = 0; k < S; ++k) {
+      const int e = lane + 64 * k;
+      xv[k] = e < deg ? (int)vals[pool[off + e]] : 0;
+    }
+    return h_index(cv, [&](int th) __attribute__((always_inline)) {  // (th >= 1: the padding zeros never count)
+      int cc = 0;
+#pragma unroll
+      for (int k = 0; k < S; ++k) cc += xv[k] >= th ? 1 : 0;
+      return wave_sum_i32(cc);
+    });
+  };
+  // One row (a whole wave).  Returns whether the value was lowered.
+  auto evaluate = [&](int rl) __attribute__((always_inline)) -> bool {
+    const int cv = mine[rl];
+    if (cv <= 0) return false;
+    const int v = r_lo + rl;
+    const int off = nb_off[rl], end = nb_off[rl + 1], deg = end - off;
+    int h;
+    if (end <= pool_entries) {
+      if (deg <= 128) h = row_by_list(cv, off, deg, std::integral_constant<int, 2>{});
+      else if (deg <= 384) h = row_by_list(cv, off, deg, std::integral_constant<int, 6>{});
+      else if (deg <= 1024) h = row_by_list(cv, off, deg, std::integral_constant<int, 16>{});
+      else
+        h = h_index(cv, [&](int th) __attribute__((always_inline)) {  // longer lists are re-read for every probe
+          int cc = 0;
+          for (int e = lane; e < deg; e += 64) cc += vals[pool[off + e]] >= th ? 1 : 0;
+          return wave_sum_i32(cc);
+        });
+    } else {  // no list: the bit row, from memory, walked for every probe
+      const u64* rowp = bm + (size_t)v * W;
+      h = h_index(cv, [&](int th) __attribute__((always_inline)) {
         int cc = 0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          u64 bits = rw[q];
-          const int base = (lane + 64 * q) * 64;
-          while (bits) {
-            const int b = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            cc += vals[base + b] >= th;
-          }
-        }
-        for (int wd = lane + 320; wd < W; wd += 64) {
+        for (int wd = lane; wd < W; wd += 64) {
           u64 bits = rowp[wd];
           while (bits) {
             const int b = __ffsll((long long)bits) - 1;
@@ -585,37 +655,52 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
           }
         }
         return wave_sum_i32(cc);
-      };
-      // h = the largest t <= cv with #(values >= t) >= t (monotone in t).  Values drop in small steps: probe cv, cv - 1,
-      // cv - 3, cv - 7 ... until one holds, then bisect the last gap.
-      if (count_ge(cv) >= cv) continue;
-      int bad = cv, good = 0;  // invariant: predicate holds at `good` (t = 0 always), fails at `bad`
-      for (int step = 1; bad - step > 0; step <<= 1) {
-        const int t = bad - step;
-        if (count_ge(t) >= t) {
-          good = t;
-          break;
-        }
-        bad = t;
-      }
-      while (good + 1 < bad) {
-        const int mid = (good + bad) >> 1;
-        if (count_ge(mid) >= mid) good = mid;
-        else bad = mid;
-      }
-      // (the LDS copy keeps the old value: the next snapshot then finds v dirty, which is what sends the rows of v's
-      // neighbours — mine included — through this loop again)
-      if (lane == 0) __hip_atomic_store(gvals + v, (unsigned short)good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      changed = true;
+      });
     }
+    if (h == cv) return false;
+    // (the snapshot keeps the old value of v: the next one then finds v moved, so this workgroup looks at its rows again)
+    if (lane == 0) {
+      mine[rl] = h;
+      __hip_atomic_store(gvals + v, (unsigned short)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+  };
+  for (; iter < HCA_MAXITER && !finished; ++iter) {
+    HCA_MARK(iter == 0 ? 0 : 3);
+    // 1. snapshot of all values (four per load)
+    // (16-byte loads and two 8-byte loads in flight per thread were both tried: no faster)
+    bool moved = false;
+    for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
+      const u64 nv = hca_load_u64((const u64*)gvals + i);
+      if (nv != ((u64*)vals)[i]) {
+        ((u64*)vals)[i] = nv;
+        moved = true;
+      }
+    }
+    // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
+    // the coherence point as well: only now may the version say so)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool any_moved = __syncthreads_or(moved ? 1 : 0) != 0;
+    if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bump = false;
+    HCA_MARK(1);
+    // 2. my rows, each counted afresh (one wave per row) — unless nothing at all moved
+    bool changed = false;
+    if (any_moved)
+      for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) changed |= evaluate(rl);
     // 3. something lowered: straight into the next snapshot (the version is bumped there, once the stores have landed)
+    HCA_MARK(2);
     if (__syncthreads_or(changed ? 1 : 0)) {
+      HCA_MARK(6);
+      HCA_COUNT(4);
       bump = true;
       v0_valid = false;
       continue;
     }
+    HCA_MARK(7);
+    HCA_COUNT(5);
     // nothing changed.  A fixed point may only be claimed for a snapshot taken AFTER the version vector was read:
-    // read it now (thread t reads ver[t]; E0 = its sum) and go round once more — with nothing dirty that is one snapshot
+    // read it now (thread t reads ver[t]; E0 = its sum) and go round once more — with nothing moved that is one snapshot
     if (!v0_valid) {
       v0 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
       const unsigned ws = (unsigned)wave_sum_i32((int)v0);
@@ -656,8 +741,14 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     if (!finished) V.perm[HCA_CTL_FAILED] = 1;
     atomicMax(&V.perm[HCA_CTL_ITERS], iter);
   }
-  // my rows' final values (the LDS copy is current for them)
-  for (int rl = tid; rl < nown; rl += HCA_THREADS) V.core[r_lo + rl] = vals[r_lo + rl];
+#ifdef QTR_HCA_PROF
+  HCA_MARK(3);
+  if (tid == 0 && w < HCA_MAXWG)
+    for (int q = 0; q < 8; ++q) g_hca_prof[w * 8 + q] = prof_acc[q];
+#endif
+  // my rows' final values
+  __syncthreads();
+  for (int rl = tid; rl < nown; rl += HCA_THREADS) V.core[r_lo + rl] = mine[rl];
 }
 
 // what k_kcore leaves behind besides the core numbers: edge total, largest core, the zeroed rank accumulator
@@ -2475,7 +2566,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         const char* e = getenv("QTR_KCORE");
         return e && strcmp(e, "peel") == 0;
       }();
-      const bool hcore = !peel_only && L > 3000;
+      const bool hcore = !peel_only && L > 3000 && L <= 65536;  // (16-bit vertex ids and values in k_hcore_async)
       static const bool hc_sweeps = [] {
         const char* e = getenv("QTR_KCORE");
         return e && strcmp(e, "sweeps") == 0;
@@ -2485,10 +2576,12 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
         if (G > 1) nwg = max(8, min(nwg, hca_max_workgroups() / min(G, 4)));
         const int Lp = (L + 63) & ~63, R = (L + nwg - 1) / nwg;
-        const size_t base = (size_t)2 * Lp + (size_t)8 * W, rows_b = (size_t)R * W * 8;
-        const int rows_in_lds = base + rows_b <= (size_t)150 * 1024 ? 1 : 0;
+        const int Rp = (R + 3) & ~3;
+        const size_t fixed = (size_t)2 * Lp + (size_t)4 * (Rp + 4) + (size_t)4 * Rp;
+        // the pool of neighbour lists takes what the compute unit's LDS has left (the workgroups run one per unit anyway)
+        const int pool_entries = (int)(((size_t)150 * 1024 - fixed) / 2) & ~7;
         LAUNCH_SV(k_hcore_async_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
-        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), base + (rows_in_lds ? rows_b : 0), stream, rows_in_lds);
+        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries);
         LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 1);
       } else if (hcore) {
         LAUNCH_SV(k_hcore_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
@@ -2664,3 +2757,9 @@ hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const
   for (int g = 0; g < G; ++g) v[g] = make_solver_view(*B[g], src[g], tgt[g], L[g]);
   return solver_launch(v.data(), G, prm, stage, stream, nullptr, nullptr);
 }
+
+#ifdef QTR_HCA_PROF
+extern "C" int qtr_debug_hca_prof(unsigned* out, int n_wg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hca_prof), (size_t)n_wg * 32);
+}
+#endif
