@@ -538,7 +538,10 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   lp += (size_t)4 * Rp;
   unsigned short* pool = (unsigned short*)lp;  // [pool_entries] neighbour ids of my rows, row after row
   __shared__ unsigned s_sum[HCA_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (uniform on purpose: what is indexed by the wave — a row's value, where its list starts — then lives in scalar
+  // registers and the branches on it are scalar branches instead of exec-mask games)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- set-up: my rows as neighbour LISTS.  A wave issues an instruction every ~8 clocks however many of its lanes are
   // busy, and every iteration of every workgroup waits for its slowest wave: what an iteration costs is the NUMBER of
   // instructions a row takes.  Off the bit row, a neighbour's value costs a find-first-set / clear-lowest / address /
@@ -614,9 +617,10 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     constexpr int S = decltype(s_tag)::value;
     int xv[S];
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-      const int e = lane + 64 * k;
-      xv[k] = e < deg ? (int)vals[pool[off + e]] : 0;
+    for (int k = 0; k < S; ++k) {  // (unconditional reads — the last entry stands in past the end — so that the S index
+      const int e = lane + 64 * k;   // reads, then the S value reads, are in flight together)
+      const int x = vals[pool[off + min(e, deg - 1)]];
+      xv[k] = e < deg ? x : 0;
     }
     return h_index(cv, [&](int th) __attribute__((always_inline)) {  // (th >= 1: the padding zeros never count)
       int cc = 0;
@@ -627,10 +631,10 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   };
   // One row (a whole wave).  Returns whether the value was lowered.
   auto evaluate = [&](int rl) __attribute__((always_inline)) -> bool {
-    const int cv = mine[rl];
+    const int cv = __builtin_amdgcn_readfirstlane(mine[rl]);
     if (cv <= 0) return false;
     const int v = r_lo + rl;
-    const int off = nb_off[rl], end = nb_off[rl + 1], deg = end - off;
+    const int off = __builtin_amdgcn_readfirstlane(nb_off[rl]), end = __builtin_amdgcn_readfirstlane(nb_off[rl + 1]), deg = end - off;
     int h;
     if (end <= pool_entries) {
       if (deg <= 128) h = row_by_list(cv, off, deg, std::integral_constant<int, 2>{});
@@ -1177,6 +1181,46 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
 // rows are staged in LDS, a lane looks perm[s] up ONCE and probes its bit in every staged row (one workgroup per row
 // re-read the whole perm array for each row: L^2 * 4 bytes of L2 traffic, 257 us at L = 20000), a ballot per row builds
 // the output words.
+// The same permutation by SCATTER, for L <= 32768: a row of the consistency graph has a few hundred neighbours out of
+// thousands of columns, so instead of asking for every output bit (r, s) "is (perm r, perm s) an edge?" — L bit tests per
+// row, 21 us at L = 5000 — the set bits of row perm[r] are walked and each lands at its neighbour's rank, read from an
+// inverse of perm that every workgroup keeps in LDS (16-bit entries).  One wave per row, PM2_ROWS rows per workgroup.
+#define PM2_ROWS 8
+#define PM2_MAXL 32768
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_permute_scatter(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ bm = V.bm;
+  const int* __restrict__ perm = V.perm;
+  const int L = V.L, W = V.W;
+  u64* __restrict__ adjP = V.adjP;
+  const int r0 = blockIdx.x * PM2_ROWS;
+  if (r0 >= L) return;
+  extern __shared__ u64 pm2_lds[];  // [4][W] the row a wave is assembling, then the ranks
+  const int lane = qk_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u64* outw = pm2_lds + (size_t)wave * W;
+  unsigned short* rk = (unsigned short*)(pm2_lds + (size_t)4 * W);
+  for (int s0 = threadIdx.x; s0 < L; s0 += 256) rk[perm[s0]] = (unsigned short)s0;
+  __syncthreads();
+  for (int i = wave; i < PM2_ROWS && r0 + i < L; i += 4) {
+    const int r = r0 + i;
+    const u64* __restrict__ rowp = bm + (size_t)perm[r] * W;
+    for (int w = lane; w < W; w += 64) outw[w] = 0;
+    for (int w = lane; w < W; w += 64) {
+      u64 bits = rowp[w];
+      while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const unsigned q = rk[w * 64 + b];
+        atomicOr((unsigned*)outw + (q >> 5), 1u << (q & 31));
+      }
+    }
+    // (the wave's LDS operations complete in program order: its reads below see every lane's atomics above)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int w = lane; w < W; w += 64) adjP[(size_t)r * W + w] = outw[w];
+  }
+}
+
 #define PM_ROWS 8
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_permute(ViewExt<SolverView> x, SolverView one) {
@@ -2430,6 +2474,7 @@ hipError_t solver_init_attributes() {
   SET_LDS(k_clique_first, CF_LDS_BYTES)
   SET_LDS(k_clique_batch_lds, 156 * 1024)
   SET_LDS(k_permute, 64 * 1024)
+  SET_LDS(k_permute_scatter, 96 * 1024)
 #undef SET_LDS
   return hipSuccess;
 }
@@ -2603,7 +2648,11 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       }
       CS_DBG("rank");
     }
-    LAUNCH_SV(k_permute, a, dim3((L + PM_ROWS - 1) / PM_ROWS, 1, G), dim3(256), (size_t)PM_ROWS * W * 8, stream);
+    if (L <= PM2_MAXL)
+      LAUNCH_SV(k_permute_scatter, a, dim3((L + PM2_ROWS - 1) / PM2_ROWS, 1, G), dim3(256),
+                (size_t)4 * W * 8 + (size_t)2 * ((L + 63) & ~63), stream);
+    else
+      LAUNCH_SV(k_permute, a, dim3((L + PM_ROWS - 1) / PM_ROWS, 1, G), dim3(256), (size_t)PM_ROWS * W * 8, stream);
     CS_DBG("k_permute");
     if (mode == QTR_INLIER_KCORE_HEU) LAUNCH_SV(k_kcore_heu, a, dim3(1, 1, G), dim3(256), 0, stream, kcore_thr);
     {
