@@ -74,11 +74,29 @@ static float graph_margin(double beta) {
 }
 typedef float gb_f2 __attribute__((ext_vector_type(2)));
 
+// control words of k_hcore_async (below) in V.perm, cleared here when the graph is built for it
+#define HCA_CTL_FAILED 2   // ints of V.perm: [2] failed, [3] iterations of the slowest workgroup,
+#define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
+#define HCA_MAXWG 1024
+#define HCA_CTL_VER 64
+#define HCA_CTL_DONE (64 + HCA_MAXWG)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta, float margin) {
+__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta, float margin,
+                                                     int prep) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L, W = V.W;
   const int nb = (L + 63) >> 6;
+  // Chores of launches that used to follow or precede this one (~5 us each on the chain), done by the first threads of
+  // the grid: bit 0 — k_hcore_async's clean slate (every value at 0xffff, an upper bound of any degree; control words 0;
+  // Kp and perm are not in use before the ranking); bit 1 — the solver state starts from zero (k_solver_reset).
+  if (prep) {
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (prep & 1) {
+      if (gi < (((L + 63) & ~63) >> 1)) ((unsigned*)V.Kp)[gi] = 0xffffffffu;
+      if (gi < HCA_CTL_DONE + HCA_MAXWG) V.perm[gi] = 0;
+    }
+    if ((prep & 2) && gi < (int)(sizeof(SolverState) / 4)) ((int*)V.st)[gi] = 0;
+  }
   // workgroup t -> tile (rb, cb), rb <= cb, row by row over the upper triangle: row rb starts at rb nb - rb (rb - 1) / 2.
   // (Grouping the tiles into 8 x 8 super-tiles dealt to one XCD each, so that the eight writers of a 64-byte line of the
   // matrix meet in one L2, was tried: 125 -> 136 us at L = 20000.  The kernel is bound by instruction issue, not by its
@@ -238,7 +256,9 @@ __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverVie
   const u64* __restrict__ bm = V.bm;
   const int L = V.L, W = V.W;
   if (L <= 0) return;
-  if (after_hcore && V.st->pad[5] == 0) return;
+  // (1: the sweep chain's k_hcore_finish left its verdict in pad[5]; 2: k_hcore_async's failure flag, still in perm)
+  if (after_hcore == 1 && V.st->pad[5] == 0) return;
+  if (after_hcore == 2 && V.perm[HCA_CTL_FAILED] == 0) return;
   const int* __restrict__ deg_in = V.deg;
   int* __restrict__ core_out = V.core;
   SolverState* __restrict__ st = V.st;
@@ -475,11 +495,6 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
 // If HCA_MAXITER iterations do not suffice (never seen) the failure flag sends the pair to the peeling kernel.
 #define HCA_THREADS 1024
 #define HCA_MAXITER 4096
-#define HCA_CTL_FAILED 2   // ints of V.perm: [2] failed, [3] iterations of the slowest workgroup,
-#define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
-#define HCA_MAXWG 1024
-#define HCA_CTL_VER 64
-#define HCA_CTL_DONE (64 + HCA_MAXWG)
 #ifdef QTR_HCA_PROF  // diagnostic build only (tests/gpu_hca_prof.py): where an iteration's time goes, per workgroup
 __device__ unsigned g_hca_prof[HCA_MAXWG * 8];
 #define HCA_MARK(k)                                   \
@@ -504,16 +519,13 @@ __device__ __forceinline__ unsigned hca_load_u32(const unsigned* p) {
 __device__ __forceinline__ u64 hca_load_u64(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (the clean slate for graphs that were handed in as bit matrices; k_graph_build prepares its own, see there)
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_hcore_async_init(ViewExt<SolverView> x, SolverView one) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v < V.L) {
-    const int d = solver_degree(V, v);
-    V.deg[v] = d;  // k_hcore_finish adds them up
-    ((unsigned short*)V.Kp)[v] = (unsigned short)min(d, 65535);  // the values (Kp is not in use yet)
-  }
-  if (v < HCA_CTL_DONE + HCA_MAXWG) V.perm[v] = 0;  // control words, versions, marks (perm is not in use yet; L > 3000)
+  const int gi = blockIdx.x * 256 + threadIdx.x;
+  if (gi < (((V.L + 63) & ~63) >> 1)) ((unsigned*)V.Kp)[gi] = 0xffffffffu;
+  if (gi < HCA_CTL_DONE + HCA_MAXWG) V.perm[gi] = 0;
 }
 template <bool EXT>
 __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int pool_entries) {
@@ -548,17 +560,35 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   // read chain of ~17 instructions and most lanes hold no neighbour at all; off a list it is two LDS reads per lane and
   // a row of 80 neighbours is two per lane.  (Rows whose list does not fit the pool keep the bit row, read from memory.)
   for (int i = tid; i < (Lp >> 1); i += HCA_THREADS) ((unsigned*)vals)[i] = 0xffffffffu;  // "everything moved" the first time
+  // my rows' degrees (a wave per row adds up the row's per-block counts) are their first values: published at once — the
+  // values everybody starts from are 0xffff, an upper bound like any other, so a workgroup that looks before its
+  // neighbours have published loses nothing but a little tightness in its first iteration
+  for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
+    const int v = r_lo + rl;
+    int d;
+    if (V.degp) {
+      int part = 0;
+      for (int k = lane; k < ((L + 63) >> 6); k += 64) part += V.degp[(size_t)k * V.Lp + v];
+      d = wave_sum_i32(part);
+    } else {
+      d = V.deg[v];
+    }
+    if (lane == 0) {
+      nb_off[rl] = d;  // (turned into offsets below)
+      mine[rl] = min(d, 65535);
+      if (V.degp) V.deg[v] = d;  // k_rank_sort adds them up
+      __hip_atomic_store(gvals + v, (unsigned short)min(d, 65535), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
   if (wave == 0) {
     int run = 0;
     for (int base = 0; base < nown; base += 64) {
       const int rl = base + lane;
-      const int d = rl < nown ? V.deg[r_lo + rl] : 0;  // (k_hcore_async_init left the degrees there)
+      const int d = rl < nown ? nb_off[rl] : 0;
       int tot = 0;
       const int ex = wave_excl_scan_i32(d, &tot);
-      if (rl < nown) {
-        nb_off[rl] = run + ex;
-        mine[rl] = min(d, 65535);  // = what k_hcore_async_init stored
-      }
+      if (rl < nown) nb_off[rl] = run + ex;
       run += tot;
     }
     if (lane == 0) nb_off[nown] = run;
@@ -583,7 +613,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   }
   unsigned myver = 0;  // (thread 0) this workgroup's version counter
   unsigned v0 = 0, E0 = 0;
-  bool bump = false;      // values were lowered in the previous iteration: ver[w] has to follow once they have landed
+  bool bump = true;       // values were stored (set-up) or lowered in the previous iteration: ver[w] has to follow once they have landed
   bool v0_valid = false;  // v0 / E0 were read before the snapshot of THIS iteration (only then may it claim a fixed point)
   int iter = 0;
   bool finished = false;
@@ -1076,11 +1106,50 @@ __global__ __launch_bounds__(256) void k_rank_finish(ViewExt<SolverView> x, Solv
 #define RS_THREADS 1024
 #define RS_BINS 1024
 template <bool EXT>
-__global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x, SolverView one) {
+__global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x, SolverView one, int after_async) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L;
   SolverState* __restrict__ st = V.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_nb;
+  if (after_async && L > 0) {
+    // what a k_hcore_finish launch used to do behind k_hcore_async: edge total, largest core, statistics (when the
+    // iteration gave up, k_kcore has just run and left them)
+    __shared__ int s_red[2][RS_THREADS / 64];
+    const int failed = V.perm[HCA_CTL_FAILED], iters = V.perm[HCA_CTL_ITERS];  // (perm is overwritten further down)
+    int mx = 0, es = 0;
+    if (!failed)
+      for (int v = tid; v < L; v += RS_THREADS) {
+        mx = max(mx, V.core[v]);
+        es += V.deg[v];
+      }
+    mx = wave_max_i32(mx);
+    es = wave_sum_i32(es);
+    if (lane == 0) {
+      s_red[0][wave] = mx;
+      s_red[1][wave] = es;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (!failed) {
+        mx = 0, es = 0;
+        for (int q = 0; q < RS_THREADS / 64; ++q) {
+          mx = max(mx, s_red[0][q]);
+          es += s_red[1][q];
+        }
+        st->n_edges2 = es;
+        st->max_core = mx;
+        st->ub = mx + 1;
+        st->pad[0] = iters;  // statistics: iterations of the slowest workgroup
+        s_nb = mx + 1;
+      } else {
+        s_nb = st->max_core + 1;
+      }
+    }
+    __syncthreads();
+  } else if (tid == 0) {
+    s_nb = L > 0 ? st->max_core + 1 : 0;
+  }
   if (tid == 0) {  // what k_clique_init sets
     st->mc = 0;
     st->best_r = -1;
@@ -1096,7 +1165,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   int* __restrict__ Kp = V.Kp;
   extern __shared__ __attribute__((aligned(16))) int rs_lds[];  // [16][RS_BINS] counts, then offsets
   __shared__ int s_wtot[RS_THREADS / 64];
-  const int NB = st->max_core + 1;  // core values 0 .. max_core
+  __syncthreads();
+  const int NB = s_nb;  // core values 0 .. max_core
   if (NB > RS_BINS) {
     // rare: rank = #{u : (core u, u) < (core v, v)}, tiles of the core array through LDS
     int* tile = rs_lds;
@@ -2579,7 +2649,27 @@ static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, h
 // K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds, for the G pairs of `a` (Lmax = the
 // largest L among them: grids, LDS sizes and kernel variants are chosen for it; every kernel reads its own pair's L).
 // Expects the bit matrices in bm and the degrees in deg; everything stays on `stream`.
-static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream) {
+// which core-number path a graph of L vertices takes (QTR_KCORE=peel | sweeps: the older ones, kept for comparison)
+static bool kcore_peel_only() {
+  static const bool v = [] {
+    const char* e = getenv("QTR_KCORE");
+    return e && strcmp(e, "peel") == 0;
+  }();
+  return v;
+}
+static bool kcore_sweeps() {
+  static const bool v = [] {
+    const char* e = getenv("QTR_KCORE");
+    return e && strcmp(e, "sweeps") == 0;
+  }();
+  return v;
+}
+static bool hcore_planned(int L) { return !kcore_peel_only() && L > 3000 && L <= 65536; }  // (16-bit ids and values in k_hcore_async)
+static bool hcore_async_planned(int L) { return hcore_planned(L) && !kcore_sweeps(); }
+
+// hcore_prepared: k_graph_build has left k_hcore_async's clean slate (values, control words)
+static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream,
+                                bool hcore_prepared) {
   const int W = (L + 63) / 64;
   static const bool dbg_sync = getenv("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
 #define CS_DBG(name)                                                                                   \
@@ -2607,15 +2697,8 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
       LAUNCH_SV(k_kcore_collect_rank, a, dim3(1, 1, G), dim3(1024), 0, stream, merged_first_round ? CLIQUE_BATCH : 1);
     } else {
       const int lds_bitmap = (q_in_lds && kc_lds + 8 + bm_bytes <= (size_t)150 * 1024) ? 1 : 0;
-      static const bool peel_only = [] {
-        const char* e = getenv("QTR_KCORE");
-        return e && strcmp(e, "peel") == 0;
-      }();
-      const bool hcore = !peel_only && L > 3000 && L <= 65536;  // (16-bit vertex ids and values in k_hcore_async)
-      static const bool hc_sweeps = [] {
-        const char* e = getenv("QTR_KCORE");
-        return e && strcmp(e, "sweeps") == 0;
-      }();
+      const bool hcore = hcore_planned(L), hc_sweeps = kcore_sweeps();
+      bool after_async = false;
       if (hcore && !hc_sweeps) {
         // one resident workgroup per compute unit at most (they wait for one another); a group of pairs shares the device
         int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
@@ -2625,16 +2708,16 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         const size_t fixed = (size_t)2 * Lp + (size_t)4 * (Rp + 4) + (size_t)4 * Rp;
         // the pool of neighbour lists takes what the compute unit's LDS has left (the workgroups run one per unit anyway)
         const int pool_entries = (int)(((size_t)150 * 1024 - fixed) / 2) & ~7;
-        LAUNCH_SV(k_hcore_async_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
+        if (!hcore_prepared) LAUNCH_SV(k_hcore_async_init, a, dim3((max(L, 4096) + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries);
-        LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 1);
+        after_async = true;
       } else if (hcore) {
         LAUNCH_SV(k_hcore_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         for (int it = 0; it < HC_MAXIT; ++it) LAUNCH_SV(k_hcore_sweep, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, it);
         LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 0);
       }
       LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, q_in_lds ? 0 : 1,
-                lds_bitmap, hcore ? 1 : 0);
+                lds_bitmap, after_async ? 2 : hcore ? 1 : 0);
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
@@ -2644,7 +2727,7 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
       } else {
-        LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), (size_t)16 * RS_BINS * 4, stream);
+        LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), (size_t)16 * RS_BINS * 4, stream, after_async ? 1 : 0);
       }
       CS_DBG("rank");
     }
@@ -2745,7 +2828,7 @@ hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int
     const SolverView V = make_solver_view(B, nullptr, nullptr, L);
     SolverArgs a;
     if ((e = solver_args(a, &V, 1, nullptr, stream)) != hipSuccess) return e;
-    clique_stage_launch(a, 1, L, mode, kcore_thr, stream);
+    clique_stage_launch(a, 1, L, mode, kcore_thr, stream, false);
   }
   return hipGetLastError();
 }
@@ -2767,16 +2850,19 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
   if ((e = solver_args(a, views, G, stage, stream)) != hipSuccess) return e;
   int L = 0;
   for (int g = 0; g < G; ++g) L = max(L, views[g].L);
-  if (!reset_done) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
+  // (the state's clean slate rides on k_graph_build when there is one: a launch fewer on the chain)
+  if (!reset_done && L <= 0) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
+  const bool prep_hcore = L > 0 && hcore_async_planned(L);
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
     {
       const int nb = (L + 63) / 64;  // 64 x 64 tiles of the upper triangle, one per workgroup
-      LAUNCH_SV(k_graph_build, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta));
+      LAUNCH_SV(k_graph_build, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta),
+                (prep_hcore ? 1 : 0) | (reset_done ? 0 : 2));
     }
     if (ev_graph) hipEventRecord(ev_graph, stream);
-    clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream);
+    clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream, prep_hcore);
   }
   if (ev_clique) hipEventRecord(ev_clique, stream);
   launch_finalize(a, G, prm, stream);

@@ -140,6 +140,27 @@ def test_solver_at_L20000_matches_oracle(qo16):
     assert set(inl).issubset(set(r["clique"]))
 
 
+@pytest.mark.parametrize("L,p,planted", [(3500, 0.2, 40), (4000, 0.45, 0), (8000, 0.4, 0)])
+def test_core_numbers_of_dense_graphs_match_oracle(qo16, L, p, planted):
+    """k_hcore_async beyond the consistency graphs of the benches (a few hundred neighbours per row): rows of 700
+    neighbours (16 list entries per lane), of 1800 (lists longer than the registers hold, re-read per probe) and — at
+    L = 8000, 3200 neighbours per row — more neighbours per workgroup than its LDS pool holds, so that the last rows of
+    every workgroup fall back to their bit rows.  KCORE_HEU with threshold 0 returns the top core: a function of the core
+    numbers alone, and cheap on the oracle's side."""
+    from test_gpu_parity import _random_graph_bitmap
+    bm, _ = _random_graph_bitmap(L, p, 1000 + L, planted)
+    h = ql.Handle(0, max_points=4096, max_voxels=4096, max_corr=8192)
+    try:
+        got, max_core = h.max_clique(bm, 2, 0.0)
+        core_g = h.debug_fetch(ql.DBG_CORE, np.int32)[:L]
+    finally:
+        h.close()
+    core_o, _, mc = qo16.kcore(bm)
+    assert max_core == mc
+    assert np.array_equal(core_g, core_o)
+    assert np.array_equal(got, qo16.max_clique(bm, 2, 0.0))
+
+
 def test_dense_mode_front_end_at_50k_points_matches_oracle(qo16):
     """BASELINE configs[4]'s front end: two INDEPENDENTLY sampled 50 000-point clouds (no voxel step) through FPFH and
     matching — descriptors, both complete nearest-neighbour tables (50 k x 50 k brute force on the oracle's side) and the

@@ -789,9 +789,19 @@ def test_stage_entry_points_match_oracle_and_numpy(hip, qo):
         Rg, cg, ig, mg = hip.gnc_rotation2d(a, b, 0.6)
         assert np.array_equal(Rg, Ro) and cg == co and ig == io and np.array_equal(mg, mo)
     # estimate (COTE)
-    for seed, Nn in enumerate([2, 3, 50, 301, 700]):
+    # (129 .. 256 members: the split ranking + merge of the interval endpoints; the "ties" cases put lower and upper
+    # endpoints of different members, and members themselves, on exactly equal keys: X on a 0.5 grid, range 0.25)
+    for seed, Nn in enumerate([2, 3, 50, 130, 200, 256, 301, 700, -180, -256]):
         g = np.random.default_rng(100 + seed)
+        ties = Nn < 0
+        Nn = abs(Nn)
         X = np.concatenate([1.5 + 0.1 * g.standard_normal(Nn - Nn // 3), g.uniform(-20, 20, Nn // 3)])
+        if ties:
+            X = np.round(X * 2) / 2
+            for median in (True, False):
+                eo, mo, no = qo.cote_estimate(X, 0.25, median)
+                eg, mg, ng = hip.cote_estimate(X, 0.25, median)
+                assert eg == eo and ng == no and np.array_equal(mg, mo), (Nn, median, "ties")
         for median in (True, False):
             eo, mo, no = qo.cote_estimate(X, 0.3, median)
             eg, mg, ng = hip.cote_estimate(X, 0.3, median)
