@@ -1428,15 +1428,16 @@ __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, in
 //      clique settle in two or three passes (one ballot each) instead of one dependent step per member;
 //   3. the picked rows are ANDed into the candidate set by all threads (a word per thread), the picks are written out
 //      in descending order.  Every other set bit lies below the whole word, so this is exactly greedy_descent's sequence.
+__device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batch);  // (below)
 #define CF_THREADS 512
 #define CF_LDS_BYTES (144 * 1024)
 template <bool EXT>
-__global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView> x, SolverView one) {
+__global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView> x, SolverView one, int then_scan) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const u64* __restrict__ adjP = V.adjP;
   const int L = V.L, W = V.W;
   if (L <= 0) return;
-  const SolverState* __restrict__ st = V.st;
+  const SolverState* st = V.st;
   if (st->done) return;
   extern __shared__ __attribute__((aligned(16))) u64 cf_lds[];
   u64* cur = cf_lds;         // [W] the candidate set
@@ -1542,6 +1543,11 @@ __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView>
     }
   }
   if (tid == 0) V.gsz[0] = (r >= 0 && V.Kp[r] > st->mc) ? depth : 0;
+  // the round's replay (was its own launch): one workgroup wrote everything it reads, a barrier is all it takes
+  if (then_scan) {
+    __syncthreads();
+    if (wave == 0) d_clique_scan(V, then_scan);
+  }
 }
 
 template <bool EXT>
@@ -1583,14 +1589,12 @@ __global__ __launch_bounds__(256) void k_clique_batch(ViewExt<SolverView> x, Sol
 // Round 0 of the heuristic is a single start (the top-ranked vertex) whose greedy descent is one long
 // dependent chain (one row AND per clique member).  When the rank-labelled bit matrix fits in LDS the
 // chain runs out of LDS (~100 cycles per step instead of an L2 round trip).
-template <bool EXT>
-__global__ __launch_bounds__(256) void k_clique_batch_lds(ViewExt<SolverView> x, SolverView one) {
-  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+__device__ __forceinline__ void d_clique_batch_lds(const SolverView& V) {
   const u64* __restrict__ adjP = V.adjP;
   const int* __restrict__ Kp = V.Kp;
   const int L = V.L, W = V.W;
   if (L <= 0) return;
-  const SolverState* __restrict__ st = V.st;
+  const SolverState* st = V.st;
   int* __restrict__ gsz = V.gsz;
   int* __restrict__ picks_buf = V.picks_buf;
   extern __shared__ __attribute__((aligned(16))) u64 cl_rows[];
@@ -1620,11 +1624,21 @@ __global__ __launch_bounds__(256) void k_clique_batch_lds(ViewExt<SolverView> x,
   }
   if (lane == 0 && wid < batch) gsz[wid] = g;
 }
+// then_scan (a launch of ONE workgroup only): the round's replay follows in the same launch
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_clique_batch_lds(ViewExt<SolverView> x, SolverView one, int then_scan) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  d_clique_batch_lds(V);
+  if (then_scan) {
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0) d_clique_scan(V, then_scan);
+  }
+}
 
 // Sequential replay of pmc_heu::search_bounds over one batch (single wavefront).
-template <bool EXT>
-__global__ __launch_bounds__(64) void k_clique_scan(ViewExt<SolverView> x, SolverView one, int next_batch) {
-  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+// (one wavefront; a device function so that the launches on either side of a round can take it in: a dependent launch
+// costs ~4.5 us on this chain whatever it does)
+__device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batch) {
   const u64* __restrict__ adjP = V.adjP;
   const int* __restrict__ Kp = V.Kp;
   const int L = V.L, W = V.W;
@@ -1694,6 +1708,11 @@ __global__ __launch_bounds__(64) void k_clique_scan(ViewExt<SolverView> x, Solve
     st->batch = next_batch;
     st->rounds += 1;
   }
+}
+template <bool EXT>
+__global__ __launch_bounds__(64) void k_clique_scan(ViewExt<SolverView> x, SolverView one, int next_batch) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  d_clique_scan(V, next_batch);
 }
 
 // KCORE_HEU shortcut (reference src/graph.cc:67-82, including its shifted indexing): decided on device.
@@ -2255,7 +2274,8 @@ __global__ __launch_bounds__(256) void k_row_degrees(u64* __restrict__ bm, int L
 }
 
 template <bool EXT>
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x, SolverView one, qtr_params prm) {
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x, SolverView one, qtr_params prm,
+                                                          int scan_batch) {
   const SolverView& A = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ __attribute__((aligned(16))) double fin_lds[];
   __shared__ int s_M, s_N, s_nrot, s_nfinal, s_minidx, s_ncard, s_iters;
@@ -2264,6 +2284,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   const int L = A.L, W = A.W;
   SolverState* st = A.st;
   qtr_result* res = A.res;
+  // scan_batch: the replay of the clique round launched just before (k_clique_scan's job, without its launch)
+  if (scan_batch) {
+    if (wave == 0) d_clique_scan(A, scan_batch);
+    __syncthreads();
+  }
   const int mc = st->mc;
   const long long t_fin0 = clock64();
 
@@ -2642,8 +2667,8 @@ __global__ void k_solver_reset(ViewExt<SolverView> x, SolverView one) {
   if (threadIdx.x < (int)(sizeof(SolverState) / 4)) p[threadIdx.x] = 0;
 }
 
-static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, hipStream_t stream) {
-  LAUNCH_SV(k_finalize, a, dim3(1, 1, G), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, prm);
+static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, hipStream_t stream, int scan_batch = 0) {
+  LAUNCH_SV(k_finalize, a, dim3(1, 1, G), dim3(FIN_THREADS), (size_t)FIN_LDS_BYTES, stream, prm, scan_batch);
 }
 
 // K-core -> rank relabelling -> permuted adjacency -> the first two clique rounds, for the G pairs of `a` (Lmax = the
@@ -2668,8 +2693,11 @@ static bool hcore_planned(int L) { return !kcore_peel_only() && L > 3000 && L <=
 static bool hcore_async_planned(int L) { return hcore_planned(L) && !kcore_sweeps(); }
 
 // hcore_prepared: k_graph_build has left k_hcore_async's clean slate (values, control words)
-static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream,
-                                bool hcore_prepared) {
+// defer_last_scan: the caller's next launch (k_finalize) replays the last round itself; returns that round's next_batch
+// argument (0: nothing left to replay)
+static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream,
+                               bool hcore_prepared, bool defer_last_scan) {
+  int deferred = 0;
   const int W = (L + 63) / 64;
   static const bool dbg_sync = getenv("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
 #define CS_DBG(name)                                                                                   \
@@ -2748,34 +2776,36 @@ static void clique_stage_launch(const SolverArgs& a, int G, int L, int mode, dou
         // replay in k_clique_scan gives the sequential result whatever bound the descents were started with (a descent
         // that strays below the current bound cannot return more than that bound: every member of a clique of size s
         // has K >= s), and a round of parallel descents costs what the one descent does.  Two launches instead of four.
-        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
-        LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream, 0);
         if (L > BATCH) {  // (a second round only exists for more than BATCH vertices)
-          LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
           LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+          LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream, 0);
         }
+        if (defer_last_scan) deferred = BATCH;
+        else LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
       } else {
+      // (round 0 is one workgroup: its replay rides in the same launch)
       if (lds_rows)
-        LAUNCH_SV(k_clique_batch_lds, a, dim3(1, 1, G), dim3(256), cl_lds, stream);
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(1, 1, G), dim3(256), cl_lds, stream, BATCH);
       else
-        LAUNCH_SV(k_clique_first, a, dim3(1, 1, G), dim3(CF_THREADS), (size_t)CF_LDS_BYTES, stream);
-      CS_DBG("clique batch 0");
-      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
-      CS_DBG("clique scan 0");
+        LAUNCH_SV(k_clique_first, a, dim3(1, 1, G), dim3(CF_THREADS), (size_t)CF_LDS_BYTES, stream, BATCH);
+      CS_DBG("clique round 0");
       // Rounds 0 and 1 are enqueued unconditionally: the heuristic nearly always terminates within them (the
       // first start finds the large clique, the second batch only confirms that no start can beat it).  The
       // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
       if (lds_rows)
-        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream);
+        LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream, 0);
       else
         LAUNCH_SV(k_clique_batch, a, dim3(BATCH / 4, 1, G), dim3(256), 0, stream);
       CS_DBG("clique batch 1");
-      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
+      if (defer_last_scan) deferred = BATCH;
+      else LAUNCH_SV(k_clique_scan, a, dim3(1, 1, G), dim3(64), 0, stream, BATCH);
       }
       CS_DBG("clique scan 1");
     }
   }
 #undef CS_DBG
+  return deferred;
 }
 
 // Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host
@@ -2828,7 +2858,7 @@ hipError_t clique_only_enqueue(const SolverBufs& B, const u64* d_adj, int L, int
     const SolverView V = make_solver_view(B, nullptr, nullptr, L);
     SolverArgs a;
     if ((e = solver_args(a, &V, 1, nullptr, stream)) != hipSuccess) return e;
-    clique_stage_launch(a, 1, L, mode, kcore_thr, stream, false);
+    clique_stage_launch(a, 1, L, mode, kcore_thr, stream, false, false);
   }
   return hipGetLastError();
 }
@@ -2854,6 +2884,7 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
   if (!reset_done && L <= 0) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   const bool prep_hcore = L > 0 && hcore_async_planned(L);
+  int scan_batch = 0;
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
     {
@@ -2862,10 +2893,10 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
                 (prep_hcore ? 1 : 0) | (reset_done ? 0 : 2));
     }
     if (ev_graph) hipEventRecord(ev_graph, stream);
-    clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream, prep_hcore);
+    scan_batch = clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream, prep_hcore, true);
   }
   if (ev_clique) hipEventRecord(ev_clique, stream);
-  launch_finalize(a, G, prm, stream);
+  launch_finalize(a, G, prm, stream, scan_batch);
   return hipGetLastError();
 }
 
