@@ -9,24 +9,25 @@
 #   gpurun_out/TAG_dense_frontend_kernel_stats.txt ... of the dense legs (50 k-point front end + L = 20000 solver)
 #   gpurun_out/TAG_pmc_nn.json                FETCH_SIZE / WRITE_SIZE of k_nn_f16, two separate --pmc passes
 #   gpurun_out/TAG_pmc_graph.json             ... of k_graph_build at L = 5000 and 20000 (+ TCC hit / miss)
-# Copy what is to be judged into profiles/.
+# Copy what is to be judged into profiles/.  (Every rocprofv3 run sits under `timeout`: one of them once stayed alive for
+# a quarter of an hour after its "tool finalization" line; the database is complete by then.)
 TAG=${1:-r3}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 python $R/bench.py --steps 40 --warmup 5 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_seq -o seq -- python $R/bench.py --steps 40 --warmup 5 --legs "" --cpu-seconds 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_batch -o batch -- python $R/bench.py --steps 2 --warmup 1 --legs batch --cpu-seconds 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_s5k -o s5k -- python $R/tests/gpu_solver_prof.py 5000 20 > $R/gpurun_out/${TAG}_solver5k_run.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_s20k -o s20k -- python $R/tests/gpu_solver_prof.py 20000 6 > $R/gpurun_out/${TAG}_solver20k_run.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_dense -o dense -- python $R/bench.py --steps 2 --warmup 1 --legs dense --cpu-seconds 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_fetch -o fetch -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_write -o write -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_seq -o seq -- python $R/bench.py --steps 40 --warmup 5 --legs "" --cpu-seconds 0 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_batch -o batch -- python $R/bench.py --steps 2 --warmup 1 --legs batch --cpu-seconds 0 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_s5k -o s5k -- python $R/tests/gpu_solver_prof.py 5000 20 > $R/gpurun_out/${TAG}_solver5k_run.txt 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_s20k -o s20k -- python $R/tests/gpu_solver_prof.py 20000 6 > $R/gpurun_out/${TAG}_solver20k_run.txt 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_dense -o dense -- python $R/bench.py --steps 2 --warmup 1 --legs dense --cpu-seconds 0 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_fetch -o fetch -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_write -o write -- python $R/bench.py --steps 8 --warmup 2 --legs "" --cpu-seconds 0 > /dev/null 2>&1
 for L in 5000 20000; do
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_gf$L -o f -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_gw$L -o w -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $R/gpurun_out/prof_${TAG}_gh$L -o h -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_${TAG}_gf$L -o f -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_${TAG}_gw$L -o w -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $R/gpurun_out/prof_${TAG}_gh$L -o h -- python $R/tests/gpu_solver_prof.py $L 4 > /dev/null 2>&1
 done
 cd $R
 db() { ls gpurun_out/prof_${TAG}_$1/*.db | head -1; }

@@ -77,7 +77,7 @@ typedef float gb_f2 __attribute__((ext_vector_type(2)));
 // control words of k_hcore_async (below) in V.perm, cleared here when the graph is built for it
 #define HCA_CTL_FAILED 2   // ints of V.perm: [2] failed, [3] iterations of the slowest workgroup,
 #define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
-#define HCA_MAXWG 1024
+#define HCA_MAXWG 512      // (one workgroup per compute unit: 256 on this part)
 #define HCA_CTL_VER 64
 #define HCA_CTL_DONE (64 + HCA_MAXWG)
 template <bool EXT>
@@ -248,17 +248,13 @@ __global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, Solv
 // workgroup barrier that orders LDS traffic only: the core_out stores issued inside the peeling loop are
 // never read by this kernel, and waiting for their HBM acknowledgement would cost ~1.5 us per round
 #define KC_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
-template <bool EXT>
-__global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverView one,
-                                                int use_gqueue /* the queue does not fit LDS */, int lds_bitmap_max,
-                                                int after_hcore /* 1: only needed if the h-index iteration gave up */) {
-  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+// (a device function: k_rank_sort runs it in its own launch — always for the graphs that have no other core-number
+// kernel, or when k_hcore_async gave up — and the kernel k_kcore below wraps it for the older chains)
+__device__ __forceinline__ void d_kcore(const SolverView& V, int use_gqueue /* the queue does not fit LDS */,
+                                        int lds_bitmap_max) {
   const u64* __restrict__ bm = V.bm;
   const int L = V.L, W = V.W;
   if (L <= 0) return;
-  // (1: the sweep chain's k_hcore_finish left its verdict in pad[5]; 2: k_hcore_async's failure flag, still in perm)
-  if (after_hcore == 1 && V.st->pad[5] == 0) return;
-  if (after_hcore == 2 && V.perm[HCA_CTL_FAILED] == 0) return;
   const int* __restrict__ deg_in = V.deg;
   int* __restrict__ core_out = V.core;
   SolverState* __restrict__ st = V.st;
@@ -353,6 +349,14 @@ __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverVie
     st->pad[0] = kc_rounds;  // statistics
   }
   for (int v = tid; v < L; v += nthr) V.rankof[v] = 0;  // k_rank_partial accumulates into it
+}
+template <bool EXT>
+__global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverView one, int use_gqueue, int lds_bitmap_max,
+                                                int after_hcore /* 1: only needed if the h-index sweeps gave up */) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  if (V.L <= 0) return;
+  if (after_hcore == 1 && V.st->pad[5] == 0) return;  // (k_hcore_finish left its verdict there)
+  d_kcore(V, use_gqueue, lds_bitmap_max);
 }
 
 // =================================================================================================
@@ -1106,12 +1110,21 @@ __global__ __launch_bounds__(256) void k_rank_finish(ViewExt<SolverView> x, Solv
 #define RS_THREADS 1024
 #define RS_BINS 1024
 template <bool EXT>
-__global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x, SolverView one, int after_async) {
+__global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x, SolverView one, int after_async,
+                                                          int kcore_mode /* 0: the core numbers are there; 1: peel first;
+                                                                            2: peel if k_hcore_async gave up */,
+                                                          int kc_gqueue, int kc_lds_bitmap) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L;
-  SolverState* __restrict__ st = V.st;
+  SolverState* st = V.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int s_nb;
+  // the peeling kernel's work, without its launch (RS_THREADS = its 1024 threads; the dynamic LDS is sized for both)
+  const bool gave_up = after_async && L > 0 && V.perm[HCA_CTL_FAILED] != 0;  // (uniform)
+  if (L > 0 && (kcore_mode == 1 || (kcore_mode == 2 && gave_up))) {
+    d_kcore(V, kc_gqueue, kc_lds_bitmap);
+    __syncthreads();
+  }
   if (after_async && L > 0) {
     // what a k_hcore_finish launch used to do behind k_hcore_async: edge total, largest core, statistics (when the
     // iteration gave up, k_kcore has just run and left them)
@@ -2565,7 +2578,7 @@ hipError_t solver_init_attributes() {
   SET_LDS(k_finalize, FIN_LDS_BYTES)
   SET_LDS(k_kcore, 156 * 1024)
   SET_LDS(k_hcore_async, 156 * 1024)
-  SET_LDS(k_rank_sort, 64 * 1024)
+  SET_LDS(k_rank_sort, 156 * 1024)
   SET_LDS(k_clique_first, CF_LDS_BYTES)
   SET_LDS(k_clique_batch_lds, 156 * 1024)
   SET_LDS(k_permute, 64 * 1024)
@@ -2689,7 +2702,15 @@ static bool kcore_sweeps() {
   }();
   return v;
 }
-static bool hcore_planned(int L) { return !kcore_peel_only() && L > 3000 && L <= 65536; }  // (16-bit ids and values in k_hcore_async)
+static int hcore_min_l() {  // (the control words sit in V.perm: L must exceed HCA_CTL_DONE + HCA_MAXWG = 1088 in any case)
+  static const int v = [] {
+    const char* e = getenv("QTR_HCORE_MIN_L");
+    return max(1280, e ? atoi(e) : 1280);  // (measured, ms per solve, peel against this: 0.174 / 0.159 at L = 1500,
+                                            // 0.213 / 0.174 at 2000, 0.259 / 0.199 at 2500, 0.304 / 0.200 at 3000)
+  }();
+  return v;
+}
+static bool hcore_planned(int L) { return !kcore_peel_only() && L > hcore_min_l() && L <= 65536; }  // (16-bit ids and values in k_hcore_async)
 static bool hcore_async_planned(int L) { return hcore_planned(L) && !kcore_sweeps(); }
 
 // hcore_prepared: k_graph_build has left k_hcore_async's clean slate (values, control words)
@@ -2744,18 +2765,24 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         for (int it = 0; it < HC_MAXIT; ++it) LAUNCH_SV(k_hcore_sweep, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, it);
         LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 0);
       }
-      LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_lds + (lds_bitmap ? bm_bytes + 8 : 0), stream, q_in_lds ? 0 : 1,
-                lds_bitmap, after_async ? 2 : hcore ? 1 : 0);
+      static const bool rank_quadratic = getenv("QTR_RANK_QUADRATIC") != nullptr;
+      const size_t kc_bytes = kc_lds + (lds_bitmap ? bm_bytes + 8 : 0);
+      // the peeling workgroup rides in k_rank_sort's launch (it is the fallback behind k_hcore_async, and the core-number
+      // kernel of the graphs in between); the older chains keep its own launch
+      const bool own_kcore_launch = rank_quadratic || (hcore && !after_async);
+      if (own_kcore_launch)
+        LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_bytes, stream, q_in_lds ? 0 : 1, lds_bitmap, hcore ? 1 : 0);
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
-      static const bool rank_quadratic = getenv("QTR_RANK_QUADRATIC") != nullptr;
       if (rank_quadratic) {
         LAUNCH_SV(k_rank_partial, a, dim3((L + 255) / 256, slices, G), dim3(256), 0, stream);
         LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
       } else {
-        LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), (size_t)16 * RS_BINS * 4, stream, after_async ? 1 : 0);
+        const int kcore_mode = own_kcore_launch ? 0 : after_async ? 2 : 1;
+        LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), max((size_t)16 * RS_BINS * 4, kcore_mode ? kc_bytes : (size_t)0),
+                  stream, after_async ? 1 : 0, kcore_mode, q_in_lds ? 0 : 1, lds_bitmap);
       }
       CS_DBG("rank");
     }

@@ -74,7 +74,7 @@ def test_spfh_role_swap_shortcut_equals_the_reference_arithmetic(hip, qo):
 # ---------------------------------------------------------------------------------------------- back end
 @pytest.mark.parametrize("L,frac,seed,noise", [
     (2, 1.0, 0, 0.1), (3, 0.0, 1, 0.1), (50, 0.3, 1, 0.1), (64, 0.5, 2, 0.2), (65, 0.5, 3, 0.2), (300, 0.2, 2, 0.3),
-    (1000, 0.1, 3, 0.35), (3000, 0.0, 6, 0.1), (5000, 0.05, 4, 0.1), (5000, 0.05, 7, 0.3), (5000, 0.02, 5, 0.4),
+    (1000, 0.1, 3, 0.35), (1281, 0.1, 10, 0.2), (2000, 0.05, 11, 0.2), (3000, 0.0, 6, 0.1), (5000, 0.05, 4, 0.1), (5000, 0.05, 7, 0.3), (5000, 0.02, 5, 0.4),
     (8192, 0.1, 8, 0.3), (8193, 0.03, 9, 0.3)])
 def test_solver_matches_oracle(hip, qo, L, frac, seed, noise):
     src, tgt, T, inl = synth.correspondences(L, frac, seed, noise=noise)
