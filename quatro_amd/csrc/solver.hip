@@ -1444,6 +1444,7 @@ __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, in
 __device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batch);  // (below)
 #define CF_THREADS 512
 #define CF_LDS_BYTES (144 * 1024)
+#define CF_WPL 2  // row words per lane the batched row fetch holds in registers (rows of up to 128 words: L <= 8192)
 template <bool EXT>
 __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView> x, SolverView one, int then_scan) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -1501,7 +1502,32 @@ __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView>
         const bool mine = ((cand >> lane) & 1ULL) &&
                           (__popcll(lane < 63 ? (cand >> (lane + 1)) : 0ULL) & (CF_THREADS / 64 - 1)) == wave;
         u64 m = __ballot(mine);
-        while (m) {
+        if (W <= 64 * CF_WPL) {
+          // all of this wave's rows (at most 64 / 8 = 8) are requested before any is stored: written as a loop of
+          // load-then-store per row, every row waited for the one before — eight memory round trips per round
+          u64 v[8][CF_WPL];
+          int dst[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            dst[q] = -1;
+            if (m) {  // (uniform)
+              const int b = 63 - __clzll((long long)m);
+              m &= ~(1ULL << b);
+              dst[q] = __popcll(b < 63 ? (cand >> (b + 1)) : 0ULL);
+              const u64* __restrict__ rp = adjP + (size_t)(topw * 64 + b) * W;
+#pragma unroll
+              for (int e = 0; e < CF_WPL; ++e) v[q][e] = (lane + 64 * e < W) ? rp[lane + 64 * e] : 0;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (dst[q] >= 0) {
+#pragma unroll
+              for (int e = 0; e < CF_WPL; ++e)
+                if (lane + 64 * e < W) rowbuf[(size_t)dst[q] * W + lane + 64 * e] = v[q][e];
+            }
+        }
+        while (m) {  // (rows of more than 64 CF_WPL words, or more than eight rows for this wave)
           const int b = 63 - __clzll((long long)m);
           m &= ~(1ULL << b);
           const int i = __popcll(b < 63 ? (cand >> (b + 1)) : 0ULL);
@@ -1992,9 +2018,17 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
       ekey[i] = (k != k) ? INFINITY : k;
       epos[i] = i;
     }
+  // A stage whose partner distance j is at most 64 only exchanges inside blocks of 128 consecutive endpoints, and a
+  // block belongs to one wave in every stage (pair t -> thread t mod 256): those stages need no workgroup barrier — a
+  // wave's LDS operations complete in program order — only the stages that cross blocks (j > 64) and the one after such
+  // a stage do.  6 barriers instead of 45 at 512 endpoints, where the barrier (three axes, twelve waves, one compute
+  // unit) was most of a stage's time.
+  bool crossed = true;  // (the keys were written by other waves)
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
+      if (crossed || j > 64) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      crossed = j > 64;
       if (act) {
         for (int t = tl; t < (n2 >> 1); t += 256) {
           const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
