@@ -1971,7 +1971,8 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
                                               int median_sel, double* sxv, int* spos,
                                               double* T /* 6 arrays of nc; first holds the sort keys/positions */,
                                               double* s_bcast /* [4] per axis */, double* s_redc /* [4] */,
-                                              int* s_redi /* [4] */, int* dbg) {
+                                              int* s_redi /* [4] */, int* dbg,
+                                              int sw /* which of the group's four waves runs the serial parts */) {
   const int lane = tl & 63, gw = tl >> 6;
   long long tc0 = clock64(), tc1;
 #define COTE_TICK(slot)                                  \
@@ -2055,7 +2056,7 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     }
   }
   COTE_TICK(0)
-  if (act && tl == 64) {  // sum of N ranges in the reference's order (:660), off the serial wave
+  if (act && tl == 64 * ((sw + 1) & 3)) {  // sum of N ranges in the reference's order (:660), off the serial wave
     double r = 0;
     for (int i = 0; i < N; ++i) r += R ? R[i] : range;
     s_bcast[2] = r;
@@ -2080,7 +2081,10 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
   __syncthreads();
   COTE_TICK(1)
   // ---- 4. running sums, in place: lane c of wave 0 owns array c
-  if (act && gw == 0 && lane < 6) {
+  // (wave sw of the group: the three axes' groups are waves 0-3, 4-7, 8-11 of one workgroup and a wave's SIMD is its
+  // index mod 4 — with wave 0 of every group the three serial chains shared one SIMD's issue slots and ran at half speed:
+  // clocks / 16 of this step at 500 endpoints, 1660 with three axes against 835 with one)
+  if (act && gw == sw && lane < 6) {
     double* t = T + (size_t)lane * nc;
     double acc = (lane == 2) ? s_bcast[2] : 0.0;
     int i = 0;
@@ -2513,12 +2517,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   if (3 * a_total <= (size_t)FIN_LDS_BYTES) {
     char* base = (char*)fin_lds + (size_t)axc * a_total;  // LDS: pointers derive from the shared array
     co = cote_axis4(act, tl, X, N, nc, range, nullptr, prm.cote_median, (double*)base, (int*)(base + a_spos),
-                    (double*)(base + a_T), s_bc[axc], s_redc[axc], s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
+                    (double*)(base + a_T), s_bc[axc], s_redc[axc], s_redi[axc], ax == 0 ? st->pad + 6 : nullptr, axc);
   } else {
     double* gf = A.f64 + 8 * (size_t)L + (size_t)axc * 20 * (size_t)L;  // 20 L doubles of global scratch per axis
     int* gi = A.i32 + 2 * (size_t)L + (size_t)axc * 6 * (size_t)L;     // 6 L ints per axis
     co = cote_axis4(act, tl, X, N, nc, range, nullptr, prm.cote_median, gf, gi, gf + 2 * (size_t)L, s_bc[axc], s_redc[axc],
-                    s_redi[axc], ax == 0 ? st->pad + 6 : nullptr);
+                    s_redi[axc], ax == 0 ? st->pad + 6 : nullptr, axc);
   }
   if (act && tl == 0) {
     s_axis_est[ax] = co.est;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_cote_only(const double* __restrict__ X,
   __shared__ int s_redi[4];
   const int nc = 2 * N;
   const CoteOut co = cote_axis4(true, (int)threadIdx.x, X, N, nc, range, R, median_sel, scratch_f, scratch_i,
-                                scratch_f + 2 * (size_t)N, s_bc, s_redc, s_redi, nullptr);
+                                scratch_f + 2 * (size_t)N, s_bc, s_redc, s_redi, nullptr, 0);
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += 256) inl[i] = (fabs(X[i] - co.est) <= (R ? R[i] : range)) ? 1 : 0;  // :741-744
   if (threadIdx.x == 0) {
