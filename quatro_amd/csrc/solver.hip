@@ -554,6 +554,12 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   lp += (size_t)4 * Rp;
   unsigned short* pool = (unsigned short*)lp;  // [pool_entries] neighbour ids of my rows, row after row
   __shared__ unsigned s_sum[HCA_THREADS / 64];
+  // "does any thread of the workgroup ...": ONE barrier per vote.  (__syncthreads_or / _and compile to three — the flag
+  // is initialised, or-ed and read between barriers of its own — and an iteration takes two votes: six barriers of sixteen
+  // waves in a ~2 us iteration.)  Four words take turns; a vote clears the word of the next one, which was last read
+  // three votes — at least two barriers — ago.
+  __shared__ unsigned s_vote[4];
+  int vote_ix = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   // (uniform on purpose: what is indexed by the wave — a row's value, where its list starts — then lives in scalar
   // registers and the branches on it are scalar branches instead of exec-mask games)
@@ -564,6 +570,15 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   // read chain of ~17 instructions and most lanes hold no neighbour at all; off a list it is two LDS reads per lane and
   // a row of 80 neighbours is two per lane.  (Rows whose list does not fit the pool keep the bit row, read from memory.)
   for (int i = tid; i < (Lp >> 1); i += HCA_THREADS) ((unsigned*)vals)[i] = 0xffffffffu;  // "everything moved" the first time
+  if (tid < 4) s_vote[tid] = 0;
+  auto wg_any = [&](bool p) __attribute__((always_inline)) -> bool {
+    const int me = vote_ix & 3;
+    ++vote_ix;
+    if (tid == 0) s_vote[(me + 1) & 3] = 0;
+    if (__any(p) && lane == 0) atomicOr(&s_vote[me], 1u);
+    __syncthreads();
+    return s_vote[me] != 0;
+  };
   // my rows' degrees (a wave per row adds up the row's per-block counts) are their first values: published at once — the
   // values everybody starts from are 0xffff, an upper bound like any other, so a workgroup that looks before its
   // neighbours have published loses nothing but a little tightness in its first iteration
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
     // the coherence point as well: only now may the version say so)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool any_moved = __syncthreads_or(moved ? 1 : 0) != 0;
+    const bool any_moved = wg_any(moved);
     if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bump = false;
     HCA_MARK(1);
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
       for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) changed |= evaluate(rl);
     // 3. something lowered: straight into the next snapshot (the version is bumped there, once the stores have landed)
     HCA_MARK(2);
-    if (__syncthreads_or(changed ? 1 : 0)) {
+    if (wg_any(changed)) {
       HCA_MARK(6);
       HCA_COUNT(4);
       bump = true;
@@ -753,7 +768,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     // did anybody publish while I was looking?
     {
       const unsigned v1 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
-      if (!__syncthreads_and(v1 == v0 ? 1 : 0)) {
+      if (wg_any(v1 != v0)) {
         v0_valid = false;
         continue;
       }
@@ -764,8 +779,8 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     for (unsigned polls = 0; verdict == 0; ++polls) {
       const unsigned v1 = tid < NWG ? hca_load_u32(ver + tid) : 0u;
       const unsigned d1 = tid < NWG ? hca_load_u32(done + tid) : E0 + 1u;
-      if (!__syncthreads_and(v1 == v0 ? 1 : 0)) verdict = 1;
-      else if (__syncthreads_and(d1 == E0 + 1u ? 1 : 0)) verdict = 2;
+      if (wg_any(v1 != v0)) verdict = 1;
+      else if (!wg_any(d1 != E0 + 1u)) verdict = 2;
       // (bounded: if the workgroups of this pair are not all resident — a device with fewer usable compute units than
       // it reports — the wait gives up after a few seconds and the peeling kernel runs)
       else if (polls > (1u << 21)) verdict = 3;
