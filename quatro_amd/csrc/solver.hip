@@ -1250,28 +1250,31 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   }
   __syncthreads();
   // placement: lanes of equal core value rank among themselves in id order; the wave's running offsets are private
+  int nbits = 1;
+  while ((1 << nbits) < NB) ++nbits;
   for (int v0 = id0; v0 < id1; v0 += 64) {
     const int v = v0 + lane;
     const bool valid = v < id1;
     const int c = valid ? core[v] : -1;
-    int pos = -1;
-    u64 todo = __ballot(valid);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int lc = __builtin_amdgcn_readlane(c, leader);
-      const u64 m = __ballot(valid && c == lc);
-      const int off = mycnt[lc];  // (uniform address: broadcast)
-      if (c == lc) pos = off + __popcll(m & lanemask_lt());
-      __builtin_amdgcn_wave_barrier();
-      if (lane == leader) mycnt[lc] = off + __popcll(m);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      todo &= ~m;
+    // m = the lanes holding my core value, bit by bit of the value (a ballot per bit: ~3 instructions each, whatever the
+    // number of distinct values in the chunk — the loop over distinct values this replaces ran up to 64 times per chunk
+    // and was most of the kernel)
+    u64 m = __ballot(valid);
+    for (int bit = 0; bit < nbits; ++bit) {
+      const bool one = (c >> bit) & 1;
+      const u64 b = __ballot(valid && one);
+      m &= one ? b : ~b;
     }
+    int pos = -1;
     if (valid) {
+      const int off = mycnt[c];
+      pos = off + __popcll(m & lanemask_lt());
+      // (the wave's LDS operations complete in program order: every lane has read its offset before a leader moves it)
+      if ((m & lanemask_lt()) == 0) mycnt[c] = off + __popcll(m);
       perm[pos] = v;
       Kp[pos] = c + 1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next chunk reads what the leaders stored
   }
 }
 
