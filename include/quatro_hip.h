@@ -343,8 +343,11 @@ int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
  * examples/run_global_registration.cpp:206-246).  qtr_set_stage_events(0) stops recording the per-stage events (the
  * stage fields of qtr_stage_times then read 0); the two nearest-neighbour launches keep their event pairs, whose
  * elapsed times accumulate per slot: qtr_get_nn_totals returns (and optionally resets) the sum and the launch count
- * without a per-call query. */
+ * without a per-call query.  An event pair attached to a launch costs ~5 us of queue time on either side of it (four
+ * such gaps per registration): qtr_set_nn_event_stride(h, n) attaches the pairs to every n-th match of a slot only
+ * (default 1: every match; 0: never) — the totals then cover the launches that were timed. */
 int qtr_set_stage_events(qtr_handle* h, int on);
+int qtr_set_nn_event_stride(qtr_handle* h, int every);
 int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset);
 
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to

@@ -85,7 +85,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -187,6 +187,7 @@ def load():
     lib.qtr_set_batch_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
+    lib.qtr_set_nn_event_stride.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     lib.qtr_max_clique.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
@@ -607,6 +608,10 @@ class Handle:
 
     def set_stage_events(self, on: bool) -> None:
         self._lib.qtr_set_stage_events(self._h, 1 if on else 0)
+
+    def set_nn_event_stride(self, every: int) -> None:
+        """every n-th match of a slot carries the nearest-neighbour event pairs (1: all, 0: none)"""
+        self._check(self._lib.qtr_set_nn_event_stride(self._h, int(every)))
 
     def nn_totals(self, slot: int = 0, reset: bool = False):
         """(summed milliseconds, launches) of the nearest-neighbour kernel since the last reset"""

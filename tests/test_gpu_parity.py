@@ -484,7 +484,17 @@ def test_instrumentation_entry_points(small_pair):
     h.set_stage_events(True)
     c = h.register_pair(s, t, fp)
     assert h.stage_times()["match"] > 0 and h.nn_totals()[1] == 2
-    for r in (b, c):
+    # qtr_set_nn_event_stride: every second match carries the event pairs (the first one after the call does), none at 0
+    h.set_nn_event_stride(2)
+    h.nn_totals(reset=True)
+    for _ in range(4):
+        d = h.register_pair(s, t, fp)
+    assert h.nn_totals(reset=True)[1] == 4
+    h.set_nn_event_stride(0)
+    e = h.register_pair(s, t, fp)
+    assert h.nn_totals()[1] == 0 and h.stage_times()["nn_kernel"] == 0
+    h.set_nn_event_stride(1)
+    for r in (b, c, d, e):
         assert np.array_equal(a["T"], r["T"]) and np.array_equal(a["final_inliers"], r["final_inliers"])
     h.close()
 
