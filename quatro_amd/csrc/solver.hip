@@ -1462,7 +1462,6 @@ __device__ __forceinline__ int greedy_dispatch(const u64* adjP, int W, int r, in
 __device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batch);  // (below)
 #define CF_THREADS 512
 #define CF_LDS_BYTES (144 * 1024)
-#define CF_WPL 2  // row words per lane the batched row fetch holds in registers (rows of up to 128 words: L <= 8192)
 template <bool EXT>
 __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView> x, SolverView one, int then_scan) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -1520,10 +1519,11 @@ __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView>
         const bool mine = ((cand >> lane) & 1ULL) &&
                           (__popcll(lane < 63 ? (cand >> (lane + 1)) : 0ULL) & (CF_THREADS / 64 - 1)) == wave;
         u64 m = __ballot(mine);
-        if (W <= 64 * CF_WPL) {
-          // all of this wave's rows (at most 64 / 8 = 8) are requested before any is stored: written as a loop of
-          // load-then-store per row, every row waited for the one before — eight memory round trips per round
-          u64 v[8][CF_WPL];
+        // all of this wave's rows (at most 64 / 8 = 8) are requested before any is stored: written as a loop of
+        // load-then-store per row, every row waited for the one before — eight memory round trips per round
+        auto fetch_rows = [&](auto wpl_tag) __attribute__((always_inline)) {
+          constexpr int WPL = decltype(wpl_tag)::value;  // row words per lane held in registers
+          u64 v[8][WPL];
           int dst[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -1534,18 +1534,20 @@ __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView>
               dst[q] = __popcll(b < 63 ? (cand >> (b + 1)) : 0ULL);
               const u64* __restrict__ rp = adjP + (size_t)(topw * 64 + b) * W;
 #pragma unroll
-              for (int e = 0; e < CF_WPL; ++e) v[q][e] = (lane + 64 * e < W) ? rp[lane + 64 * e] : 0;
+              for (int e = 0; e < WPL; ++e) v[q][e] = (lane + 64 * e < W) ? rp[lane + 64 * e] : 0;
             }
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (dst[q] >= 0) {
 #pragma unroll
-              for (int e = 0; e < CF_WPL; ++e)
+              for (int e = 0; e < WPL; ++e)
                 if (lane + 64 * e < W) rowbuf[(size_t)dst[q] * W + lane + 64 * e] = v[q][e];
             }
-        }
-        while (m) {  // (rows of more than 64 CF_WPL words, or more than eight rows for this wave)
+        };
+        if (W <= 128) fetch_rows(std::integral_constant<int, 2>{});       // L <= 8192
+        else if (W <= 320) fetch_rows(std::integral_constant<int, 5>{});  // L <= 20480
+        while (m) {  // (longer rows, or more than eight rows for this wave)
           const int b = 63 - __clzll((long long)m);
           m &= ~(1ULL << b);
           const int i = __popcll(b < 63 ? (cand >> (b + 1)) : 0ULL);
