@@ -1294,30 +1294,6 @@ __device__ __forceinline__ void d_seq_mean(const float4* __restrict__ pts, int n
       const float* b = buf[slot][tid];
       const float4* b4 = (const float4*)b;
       int t = 0;
-#ifdef QTR_NEXT
-      // candidate for the next round (built only with -DQTR_NEXT, see tests/probe/next_round.md): the reads of the NEXT
-      // 32 values are issued before the 32 dependent additions of the current ones, so the chain never waits for LDS
-      // (today: 69 us for 18 k additions = 8.5 clocks each against ~4.2 for a dependent VALU chain)
-      if (cnt >= 32) {
-        float4 cur[8], nxt[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = b4[q];
-        for (; t + 32 <= cnt; t += 32) {
-          const bool more = t + 64 <= cnt;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) nxt[q] = b4[(more ? (t >> 2) + 8 : (t >> 2)) + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            m = m + cur[q].x;
-            m = m + cur[q].y;
-            m = m + cur[q].z;
-            m = m + cur[q].w;
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
-        }
-      }
-#else
       for (; t + 32 <= cnt; t += 32) {  // eight 16-byte LDS reads in flight ahead of 32 dependent additions
         float4 v[8];
 #pragma unroll
@@ -1330,7 +1306,6 @@ __device__ __forceinline__ void d_seq_mean(const float4* __restrict__ pts, int n
           m = m + v[q].w;
         }
       }
-#endif
       for (; t < cnt; ++t) m = m + b[t];
     }
     __syncthreads();
