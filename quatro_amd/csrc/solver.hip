@@ -371,7 +371,8 @@ __global__ __launch_bounds__(1024) void k_kcore(ViewExt<SolverView> x, SolverVie
 // HC_MAXIT sweeps are enqueued; a sweep returns at once when the one before it changed nothing (14 - 35 do something on
 // the synthetic correspondence sets of 2000 - 20000 pairs; the rest cost ~1 us each).  If the last one still changed
 // something (long chains could do it) k_kcore runs after all.  Measured against the peeling kernel, whole solve:
-// L = 5000 0.80 -> 0.62 ms, 8192 1.63 -> 1.09 ms, 20000 6.95 -> 3.1 ms; no gain at 2000, so it is used above 3000.
+// L = 5000 0.80 -> 0.62 ms, 8192 1.63 -> 1.09 ms, 20000 6.95 -> 3.1 ms.  (Round 2's chain: since round 3 the default is
+// k_hcore_async below — one launch — and these kernels run under QTR_KCORE=sweeps only.)
 #define HC_MAXIT 64
 #define HC_BINS 2048
 template <bool EXT>
@@ -479,13 +480,14 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
 // K12d: the same fixed-point iteration in ONE launch.  The sweeps above are 20 - 35 dependent launches of a few
 // microseconds of work each (plus the ones that find nothing left to do): half of the whole solve at L = 5000, two
 // thirds at L = 20000.  Here the workgroups of one launch stay resident and iterate WITHOUT barriers between them:
-//   * workgroup w owns a contiguous block of rows, kept in LDS when they fit (the bit matrix is read once);
+//   * workgroup w owns a contiguous block of rows, kept in LDS as neighbour LISTS (built once from the bit rows);
 //   * the current values live in a global array of 16-bit words that is read and written with device-scope relaxed
 //     atomics only (every access goes to the coherence point of the 8 XCDs; no fences, so no L2 write-back/invalidate —
 //     which is what made a grid barrier cost more than a launch on this part).  An iteration of a workgroup = snapshot
-//     of all L values into LDS (vertices whose value moved since the previous snapshot are marked dirty), h-index of
-//     those of its own rows that have a dirty neighbour, new values stored.  A stale value is an upper bound, values only decrease, and the iteration from
-//     any upper bounds converges to the core numbers (Montresor et al. 2013), so no ordering between workgroups is needed;
+//     of all L values into LDS, h-index of its own rows (unless nothing at all moved), new values stored.  A stale value
+//     is an upper bound, values only decrease, and the iteration from any upper bounds converges to the core numbers
+//     (Montresor et al. 2013), so no ordering between workgroups is needed — not even for the start: the values are
+//     0xffff until their owner has published its degrees;
 //   * termination without a contended word (256 workgroups doing compare-and-swap on one address cost milliseconds:
 //     a device-scope atomic is a round trip to memory): every workgroup has its own version counter ver[w], bumped after
 //     it stored lowered values, and its own mark done[w].  The "epoch" is the vector ver[] (its sum E is monotone).  An
@@ -496,7 +498,8 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
 //     E cannot have registered at E — it would have had to be woken by an earlier bump.  So "all marks equal E + 1"
 //     means everybody verified its rows against the values that stand.)  All workgroups of a pair must be co-resident
 //     (the host sizes the grid for that: at most one workgroup per compute unit).
-// If HCA_MAXITER iterations do not suffice (never seen) the failure flag sends the pair to the peeling kernel.
+// If HCA_MAXITER iterations do not suffice (never seen) the failure flag sends the pair to the peeling workgroup
+// (d_kcore, inside k_rank_sort's launch).
 #define HCA_THREADS 1024
 #define HCA_MAXITER 4096
 #ifdef QTR_HCA_PROF  // diagnostic build only (tests/gpu_hca_prof.py): where an iteration's time goes, per workgroup
