@@ -340,8 +340,9 @@ void qtr_comm_destroy(qtr_handle* h);
 
 int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 /* Instrumentation (no reference counterpart; the demo times its stages with std::chrono around the calls,
- * examples/run_global_registration.cpp:206-246).  qtr_set_stage_events(0) stops recording the per-stage events (the
- * stage fields of qtr_stage_times then read 0); the two nearest-neighbour launches keep their event pairs, whose
+ * examples/run_global_registration.cpp:206-246).  qtr_set_stage_events(0) stops recording events altogether (every
+ * stage field of qtr_stage_times and its total then read 0: an event record is a marker the queue retires before the
+ * next launch starts, and a call recorded three to six of them); the two nearest-neighbour launches keep their event pairs, whose
  * elapsed times accumulate per slot: qtr_get_nn_totals returns (and optionally resets) the sum and the launch count
  * without a per-call query.  An event pair attached to a launch costs ~5 us of queue time on either side of it (four
  * such gaps per registration): qtr_set_nn_event_stride(h, n) attaches the pairs to every n-th match of a slot only

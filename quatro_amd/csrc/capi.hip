@@ -560,6 +560,13 @@ static int wait_mail(qtr_handle* h, Slot& s, int idx, int seq) {
 static void compute_times(Slot& s) {
   if (!s.times_pending) return;
   float ms = 0;
+  if (s.times_pending == 4) {  // the call ran with the stage events off: nothing was recorded
+    s.times = qtr_stage_times{};
+    fill_nn_times(s);
+    (void)hipGetLastError();
+    s.times_pending = 0;
+    return;
+  }
   if (s.times_pending == 3) {  // qtr_feature_pair: the front end alone
     (void)hipEventSynchronize(s.ev[7]);
     s.times = qtr_stage_times{};
@@ -685,12 +692,12 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
   s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, h->stage_events ? s.ev[2] : nullptr,
                                 h->stage_events ? s.ev[3] : nullptr, reset_done));
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+  if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));  // k_finalize left the record and the state in the mailbox
   if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
     s.sb.mail_seq = ++s.seq;
     QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
-    QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+    if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
     QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
   }
   if (L > 0 && prm->inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
@@ -701,7 +708,7 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
     if (improved) {  // estimate again from the larger clique
       s.sb.mail_seq = ++s.seq;
       QTR_HIP_TRY(h, solver_refinalize(s.sb, d_src, d_tgt, L, *prm, s.stream));
-      QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
+      if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
       QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
     }
   }
@@ -751,18 +758,21 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
   }
   QTR_HIP_TRY(h, hipSetDevice(h->device));
   const float4 *d_src = (const float4*)src4, *d_tgt = (const float4*)tgt4;
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  // (an event record is a marker packet the queue has to retire before the next launch starts: with the stage events
+  // off a call records none at all, and every field of qtr_stage_times reads 0)
+  const bool ev_on = h->stage_events != 0;
+  if (ev_on) QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   if (mem == QTR_MEM_HOST && L > 0) {
     QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, src4, (size_t)L * 16, hipMemcpyHostToDevice, s.stream));
     QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, tgt4, (size_t)L * 16, hipMemcpyHostToDevice, s.stream));
     d_src = s.m_src;
     d_tgt = s.m_tgt;
   }
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  if (ev_on) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   res->n_corr = L;
   rc = solve_device(h, s, d_src, d_tgt, L, prm, res);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
-  s.times_pending = 1;
+  s.times_pending = ev_on ? 1 : 4;
   const int rc2 = copy_out_lists(h, s, res, clique, rot_inliers, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
   return rc;
@@ -1429,7 +1439,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     d_s = s.in_src;
     d_t = s.in_tgt;
   }
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
+  if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   // k2_vox_centroids publishes the voxel counters from its first block while other blocks may still be reading the raw
   // scans: an error return taken right after the mail must not hand the scans back to the caller (who may free them)
   // before the stream has drained
@@ -1552,7 +1562,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
   if (rc != QTR_OK) return res->status = rc;
   rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res, true);
   if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
-  s.times_pending = 2;
+  s.times_pending = h->stage_events ? 2 : 4;
   const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
   if (rc2 != QTR_OK) return res->status = rc2;
   return rc;
@@ -1571,7 +1581,7 @@ int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, con
   if (n_tgt) *n_tgt = nt;
   *L_out = L;
   if (rc != QTR_OK) return rc;
-  s.times_pending = 3;
+  s.times_pending = h->stage_events ? 3 : 4;
   if ((src_kps4 || tgt_kps4 || corr2) && L > cap) {
     snprintf(h->err, sizeof(h->err), "L=%d exceeds output capacity %d", L, cap);
     return QTR_ERR_CAPACITY;
