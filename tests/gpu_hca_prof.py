@@ -1,6 +1,12 @@
-"""Diagnostic (GPU box, needs a library built with -DQTR_HCA_PROF; see profiles/collect_r3.sh): where k_hcore_async's time
-goes.  Every workgroup accumulates 10 ns ticks per phase; this prints the average and the slowest workgroup.
-usage: QTR_LIB=quatro_amd/libquatro_hip_prof.so [QTR_HCA_VARIANT=v] python tests/gpu_hca_prof.py L [reps]"""
+"""Diagnostic (GPU box): where k_hcore_async's time goes.  Needs a library built with -DQTR_HCA_PROF, in which every
+workgroup accumulates 10 ns ticks per phase of its iterations:
+
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+        -fno-fast-math -Wno-unused-value -DQTR_HCA_PROF quatro_amd/csrc/unity.hip -ldl -o quatro_amd/libquatro_hip_prof.so
+  QTR_LIB=$PWD/quatro_amd/libquatro_hip_prof.so python tests/gpu_hca_prof.py L [reps]
+
+Prints the average over the workgroups and the slowest one: set-up, snapshots, the own rows (wave 0 alone, and the wait for
+the other waves after it in lowering / idle iterations), the termination protocol, and the iteration counts."""
 import ctypes as C
 import os
 import sys
@@ -40,7 +46,7 @@ for r in range(reps + 2):
 m = acc.mean(axis=0)  # per workgroup
 busy = m[:, 4] + m[:, 5] > 0
 stt = h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
-print(f"L={L} variant={os.environ.get('QTR_HCA_VARIANT', '0')} ms_per_solve={1e3 * tot / reps:.4f} kcore_iters={int(stt[10])} "
+print(f"L={L} ms_per_solve={1e3 * tot / reps:.4f} kcore_iters={int(stt[10])} "
       f"clique={res.n_clique} workgroups={int(busy.sum())}")
 for k, nm in enumerate(names):
     col = m[busy, k]
