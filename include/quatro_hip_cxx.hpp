@@ -35,6 +35,14 @@ inline qtr_handle* default_handle() {
       if (hh) qtr_destroy(hh);
       throw std::runtime_error("[quatro_hip] " + msg);
     }
+    // The reference's classes have no stage timers (the demo brackets its calls with std::chrono): the drop-in objects
+    // record no events — each record is a marker the GPU queue retires before the next launch, ~17 us per registration.
+    // QUATRO_HIP_TIMING=1 keeps them for callers that read qtr_get_stage_times on default_handle() themselves.
+    const char* keep = std::getenv("QUATRO_HIP_TIMING");
+    if (!(keep && keep[0] == '1')) {
+      qtr_set_stage_events(hh, 0);
+      qtr_set_nn_event_stride(hh, 0);
+    }
     return hh;
   }();
   return h;
