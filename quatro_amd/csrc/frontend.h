@@ -127,6 +127,7 @@ struct NnPartial {
   int pad;
 };
 // Everything the matcher kernels need for one pair; picked with blockIdx.z (see MatchArgs).
+#define TAIL_MAXWG 256  // look-back words per multi-workgroup compaction of the matcher's tail (two of them, in MatchView::scan)
 struct MatchView {
   NnDir d[2];                  // 0: rows of the smaller cloud ask the larger one; 1: hit rows of the larger ask the smaller
   const float4 *vox_i, *vox_j; // i = larger cloud (fi), j = smaller (fj), reference feature_matcher.cc:84-92

@@ -1685,7 +1685,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
   per_cloud += (size_t)max_points * 16 + 256;                // raw_sorted
-  size_t shared = (size_t)max_voxels * 64 + 16384;
+  size_t shared = (size_t)max_voxels * 64 + 16384 + 2 * TAIL_MAXWG * 4;
   shared += (size_t)max_voxels * (4 + 4 + 4 + 8) + (size_t)max_voxels * 4 * 6 + 4096;  // doubled pair lists + nc_* (cross-check off)
   const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
   per_cloud += 3 * 34 * vpad * 4 + (size_t)max_voxels * 8 + 4096;  // baseT, queryT, baseTb, norms, nb_row, nb_start, max_norm
@@ -1747,7 +1747,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.cross_i = (int*)take((size_t)max_voxels * 8);  // 2 x max_voxels: without the cross-check the list is corres_ij + corres_ji
   F.cross_j = (int*)take((size_t)max_voxels * 8);
   F.flags = (int*)take((size_t)max_voxels * 4);
-  F.scan = (int*)take((size_t)(max_voxels + 1) * 4);
+  F.scan = (int*)take((size_t)max(max_voxels + 1, 2 * TAIL_MAXWG) * 4);  // (also the tail kernels' look-back words)
   F.passed = (int*)take((size_t)max_voxels * 8);
   F.tgt_of_src = (int*)take((size_t)max_voxels * 4);
   F.corr = (int*)take((size_t)max_voxels * 16);

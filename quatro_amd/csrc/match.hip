@@ -1122,6 +1122,30 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
 
 // one launch instead of a handful of memsets/fills: counters, tuple-test flags, source->target table, NN tables,
 // dedup tables.  grid (g, 1, pairs)
+// Multi-workgroup compactions of the matcher's tail (k_cross_multi, k_pairs_multi): every workgroup publishes the number
+// of entries it keeps in its own word (count + 1; k_match_init zeroes the words) and reads its predecessors' words as
+// they appear — device-scope relaxed atomics, no chain: a workgroup only ever waits for counts, which every workgroup
+// publishes before it waits for anything, and workgroups are dispatched in index order.
+__device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* s_red /* [5] LDS */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) __hip_atomic_store(words + w, total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int sum = 0;
+  for (int u = tid; u < w; u += 256) {
+    int v = 0;
+    for (unsigned polls = 0; polls < (1u << 22); ++polls) {  // (bounded: a word that never appears cannot hang the device)
+      v = __hip_atomic_load(words + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    sum += max(v - 1, 0);
+  }
+  sum = wave_sum_i32(sum);
+  __syncthreads();  // (s_red may still be read from an earlier use)
+  if (lane == 0) s_red[wave] = sum;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
@@ -1139,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
     V.table_i[i] = ~0ULL;
     V.table_j[i] = ~0ULL;
   }
+  for (int i = gid; i < 2 * TAIL_MAXWG; i += gsz) V.scan[i] = 0;  // look-back words of k_cross_multi / k_pairs_multi
 }
 
 // Rows of the larger cloud that the (final) first direction points at, in the cloud's NORM-BIN order (k_norm_bins): a
@@ -1652,6 +1677,152 @@ __global__ __launch_bounds__(1024) void k_pairs_fused(ViewExt<MatchView> x, Matc
   }
 }
 
+// K6 on many compute units (see TAIL_MAXWG above): a workgroup takes CM_ROWS consecutive rows of the larger cloud — their
+// answers, the answers' answers (a gather of 8 bytes per row, spread over all workgroups instead of funnelled through one
+// unit's address pipeline), the mutual test — and a slice of the smaller cloud's table; the cross pairs land in
+// ascending i behind the pairs of the workgroups before it.
+#define CM_ROWS 512
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_cross_multi(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int n_large = V.n_large, n_small = V.n_small;
+  const int nwg = (n_large + CM_ROWS - 1) / CM_ROWS, w = blockIdx.x;
+  if (w >= nwg) return;
+  __shared__ int s_w[4], s_red[5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int per = (n_small + nwg - 1) / nwg, j0 = w * per, j1 = min(n_small, j0 + per);
+    for (int j = j0 + tid; j < j1; j += 256) {
+      const u64 bsm = V.best_small[j];
+      V.nn_of_small[j] = (bsm == ~0ULL) ? 0 : (int)(u32)bsm;
+    }
+  }
+  const int base = w * CM_ROWS + 2 * tid;  // two consecutive rows per thread: thread order = row order
+  u64 b[2], bs[2];
+  int jj[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) b[k] = (base + k < n_large) ? V.best_large[base + k] : ~0ULL;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    jj[k] = (b[k] == ~0ULL) ? 0 : (int)(u32)b[k];
+    bs[k] = V.best_small[jj[k]];
+  }
+  bool keep[2];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = base + k;
+    const int back = (bs[k] == ~0ULL) ? 0 : (int)(u32)bs[k];
+    keep[k] = i < n_large && b[k] != ~0ULL && back == i;
+    if (i < n_large) V.nn_of_large[i] = (b[k] == ~0ULL) ? -1 : jj[k];
+    cnt += keep[k] ? 1 : 0;
+  }
+  int tot;
+  const int ex = wave_excl_scan_i32(cnt, &tot);
+  if (lane == 0) s_w[wave] = tot;
+  __syncthreads();
+  int run = ex, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    run += (q < wave) ? s_w[q] : 0;
+    total += s_w[q];
+  }
+  const int before = tail_lookback(V.scan, w, total, s_red);
+  run += before;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (keep[k]) {
+      V.cross_i[run] = base + k;
+      V.cross_j[run] = jj[k];
+      ++run;
+    }
+  if (w == nwg - 1 && tid == 0) V.mcounts[MC_NCROSS] = before + total;
+}
+
+// K8 on many compute units: a workgroup owns PM_SRC consecutive SOURCE indices; it walks the whole list of cross pairs
+// (a few thousand entries) for the tuple-test survivors whose source falls into its range, and writes them — in source
+// order — behind the correspondences of the workgroups before it.  The last workgroup knows the totals and tells the host.
+#define PM_SRC 512
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_pairs_multi(ViewExt<MatchView> x, MatchView one) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int ns = V.ns, swapped = V.swapped;
+  const int nwg = max(1, (ns + PM_SRC - 1) / PM_SRC), w = blockIdx.x;
+  if (w >= nwg) return;
+  __shared__ int s_tg[PM_SRC];
+  __shared__ int s_w[4], s_red[5], s_ntuple;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = w * PM_SRC;
+  s_tg[2 * tid] = -1;
+  s_tg[2 * tid + 1] = -1;
+  if (tid == 0) s_ntuple = 0;
+  __syncthreads();
+  const int nc = V.mcounts[MC_NCROSS];
+  int local = 0;
+  for (int c0 = tid; c0 < nc; c0 += 8 * 256) {  // (eight per thread and round trip)
+    int pf[8], ci[8], cj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = min(c0 + q * 256, nc - 1);
+      pf[q] = (c0 + q * 256 < nc) ? (int)V.passed[c] : 0;
+      ci[q] = V.cross_i[c];
+      cj[q] = V.cross_j[c];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (pf[q]) {
+        const int src = (swapped ? cj[q] : ci[q]) - s0;  // (a source index occurs at most once after the cross-check)
+        if (src >= 0 && src < PM_SRC) s_tg[src] = swapped ? ci[q] : cj[q];
+        ++local;
+      }
+  }
+  local = wave_sum_i32(local);
+  if (lane == 0 && local) atomicAdd(&s_ntuple, local);
+  __syncthreads();
+  int tt[2], cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    tt[k] = (s0 + 2 * tid + k < ns) ? s_tg[2 * tid + k] : -1;
+    cnt += tt[k] >= 0 ? 1 : 0;
+  }
+  int tot;
+  const int ex = wave_excl_scan_i32(cnt, &tot);
+  if (lane == 0) s_w[wave] = tot;
+  __syncthreads();
+  int run = ex, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    run += (q < wave) ? s_w[q] : 0;
+    total += s_w[q];
+  }
+  const int before = tail_lookback(V.scan + TAIL_MAXWG, w, total, s_red);
+  run += before;
+  // the counters go to the host as soon as they are known: it enqueues the solver's launches (stream-ordered behind this
+  // kernel) while the lists are still being written
+  if (w == nwg - 1) {
+    if (V.mail && tid < 48) match_mail(V, tid, before + total, s_ntuple);
+    if (tid == 0) {
+      V.mcounts[MC_NCORR] = before + total;
+      V.mcounts[MC_NTUPLE] = s_ntuple;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (tt[k] >= 0) {
+      const int src = s0 + 2 * tid + k;
+      V.corr[2 * run] = src;
+      V.corr[2 * run + 1] = tt[k];
+      if (V.m_src && run < V.m_cap) {  // the count is still reported: the host raises QTR_ERR_CAPACITY past m_cap
+        float4 pa = V.vox_s[src], pb = V.vox_t[tt[k]];
+        pa.w = 0.f;
+        pb.w = 0.f;
+        V.m_src[run] = pa;
+        V.m_tgt[run] = pb;
+      }
+      ++run;
+    }
+}
+
 __global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __restrict__ vt,
                                  const int* __restrict__ corr, int L, float4* __restrict__ ms, float4* __restrict__ mt) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < L; c += gridDim.x * blockDim.x) {
@@ -1890,6 +2061,12 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   const bool crosscheck = views[0].crosscheck != 0;
   const bool fused_tail = crosscheck && max_large <= 32768 && max_ns <= 32768;
   const bool fused16 = max_large <= 16384 && max_ns <= 16384;
+  // the multi-workgroup compactions (QTR_MATCH_TAIL=single: the one-workgroup kernels of round 2, kept for comparison)
+  static const bool tail_single = [] {
+    const char* e = getenv("QTR_MATCH_TAIL");
+    return e && strcmp(e, "single") == 0;
+  }();
+  const bool tail_multi = fused_tail && !tail_single;
   if (!crosscheck) {  // the unfiltered list, see k_nc_list
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -1898,7 +2075,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     // (both nearest-neighbour tables in LDS when they fit: see the kernel)
     const int lds_gather = ((size_t)max_large + (size_t)max_small) * 4 <= (size_t)CROSS_LDS_BYTES ? 1 : 0;
     const size_t cross_lds = (size_t)max_large * 4 + (lds_gather ? (size_t)max_small * 4 : 0);
-    if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
+    if (tail_multi) LAUNCH_MV(k_cross_multi, a, dim3((max_large + CM_ROWS - 1) / CM_ROWS, 1, G), B256, 0, st);
+    else if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
     else LAUNCH_MV_K(k_cross_fused, 32, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
   } else {
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
@@ -1917,7 +2095,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_nc_scan, a, dim3(1, 1, G), dim3(1024), 0, st, 1);
     LAUNCH_MV(k_nc_emit, a, dim3(gs, 1, G), B256, 0, st);
   } else if (fused_tail) {
-    if (fused16) LAUNCH_MV_K(k_pairs_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
+    if (tail_multi) LAUNCH_MV(k_pairs_multi, a, dim3(max(1, (max_ns + PM_SRC - 1) / PM_SRC), 1, G), B256, 0, st);
+    else if (fused16) LAUNCH_MV_K(k_pairs_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
     else LAUNCH_MV_K(k_pairs_fused, 32, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
   } else {
     LAUNCH_MV(k_scatter_pairs, a, dim3(grid_for(max_small), 1, G), B256, 0, st);
