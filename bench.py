@@ -117,7 +117,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--nn-event-stride", type=int, default=5,
                     help="every n-th step of the timed region carries the nearest-neighbour launches' event pairs (1 = all)")
-    ap.add_argument("--legs", default="pair,solver5k,batch,dense,segment,patchwork",
+    ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,segment,patchwork",
                     help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`); "
                          "`refdense` adds the reference's own back-end text at L = 20000 on the CPU (minutes, > 16 GB)")
     ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
@@ -228,6 +228,19 @@ def main() -> None:
     elapsed = qdist.max_over_ranks(elapsed, cdev)
     my_steps = max(hi - lo, 1)
     nn_ms, nn_launches = h.nn_totals()
+    # the contract's region is the one above; the same region four more times shows how noisy the box is (extra key)
+    repeats = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for p in todo:
+            step(p)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        repeats.append(qdist.max_over_ranks(time.perf_counter() - t1, cdev))
     h.set_nn_event_stride(1)
     nn_flop, alg_bytes, alg_flop = 0.0, 0.0, 0.0
     for k, p in enumerate(todo):
@@ -293,21 +306,30 @@ def main() -> None:
             "n_corr": [int(p["L"]) for p in pool]}
     # ---- BASELINE configs[2]: a batch of independent pairs streamed through one GPU
     if "batch" in legs and hasattr(h, "register_batch_dev"):
-        extra["batch256_leg" if world == 1 else "sharded_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev)
+        extra["batch256_leg" if world == 1 else "sharded_leg"] = batch_leg(args, torch, ql, h, pool, prm, dev, world, dist,
+                                                                         qdist, cdev, composite, LC)
     # ---- solver alone at the metric's "~5k corr"
     if "solver5k" in legs and rank == 0:
         extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
     if "dense" in legs and rank == 0 and world == 1:
         extra.update(dense_legs(args, torch, ql, synth, prm, dev, local_rank))
+    if "connected" in legs and rank == 0 and world == 1:
+        extra["connected_leg"] = connected_leg(args, torch, ql, synth, pool, prm, dev, local_rank)
     seg = pwl = None
     if world == 1 and "segment" in legs:
         seg = segment_leg(args, torch, ql, h, pool, dev)
     if world == 1 and "patchwork" in legs:
         pwl = patchwork_leg(args, torch, ql, synth, h, dev)
 
+    hung = any(isinstance(v, dict) and v.pop("_hung", False) for v in extra.values())
+    # every GPU leg is done: the ranks part here (rank 0 goes on to the CPU baseline / parity legs on the host cores and
+    # prints the line; nothing below is a collective)
+    if world > 1 and not hung:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        if hung:
+            os._exit(0)
         return
 
     p0 = pool[0]
@@ -349,6 +371,11 @@ def main() -> None:
                            "gather of result records",
         },
         "stage_ms": {k: round(v / max(stage_n, 1), 4) for k, v in stage_acc.items() if k not in ("nn_launches",)},
+        "repeat_regions": {"what": "the timed region run four more times after the contract's one (same steps, same barriers)",
+                           "ms_per_step": [round(1e3 * r / args.steps, 5) for r in repeats],
+                           "min": round(1e3 * min(repeats) / args.steps, 5),
+                           "median": round(1e3 * float(np.median(repeats)) / args.steps, 5),
+                           "max": round(1e3 * max(repeats) / args.steps, 5)},
     }
     out.update(extra)
     if seg is not None:
@@ -404,37 +431,156 @@ def main() -> None:
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc[-1])
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample; also the parity check
-    if world == 1 and args.cpu_seconds > 0:
+    # (for N > 1 too: north_star wants the CPU path timed in the same run next to the multi-GPU numbers — rank 0's host)
+    if args.cpu_seconds > 0:
         out.update(cpu_baseline_leg(args, ql, h, pool, composite, LC, value, seg, pwl, raw0, legs, extra))
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if hung:
+        os._exit(0)
 
 
-def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev):
+def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, composite, LC):
     """BASELINE configs[2] (and, for N > 1, configs[3]): B pair ids streamed through the batched entry points
-    (qtr_submit_batch / qtr_wait), block-partitioned over the ranks."""
+    (qtr_submit_batch / qtr_wait), block-partitioned over the ranks.  With the composite workload every pair id is the
+    headline's unit of work: the scan pair's front end AND the back end on the pair's --corr given correspondences
+    (qtr_pair_desc.src_corr4 / tgt_corr4: the reference's loop hands Quatro whatever matched clouds its caller has,
+    examples/run_global_registration.cpp:97-108,243-246).  `scan_pairs` repeats the leg on the scans alone (the
+    matcher's own few hundred correspondences — the previous rounds' batch256 number).  For N > 1 the per-rank record
+    blocks are gathered through the LIBRARY's RCCL path (qtr_comm_init / qtr_gather_results_v), torch's as fallback."""
     B = args.batch_pairs if world == 1 else args.sharded_pairs
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = qdist.shard_range(B, rank, world)
-    hb = ql.Handle(torch.cuda.current_device(), max_points=131072, max_voxels=32768, max_corr=8192, n_slots=args.batch_slots)
+    hb = ql.Handle(torch.cuda.current_device(), max_points=131072, max_voxels=32768, max_corr=max(8192, LC + 64),
+                   n_slots=args.batch_slots)
     ids = list(range(lo, hi))
     pairs = [pool[i % len(pool)] for i in ids]
-    hb.register_batch_dev(pairs[:64], prm)  # warm-up
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    results = hb.register_batch_dev(pairs, prm)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = qdist.max_over_ranks(time.perf_counter() - t0, cdev)
-    same = all(bool(np.allclose(r["T"], pool[i % len(pool)]["whole"]["T"], rtol=0, atol=0)) for i, r in zip(ids, results))
+
+    def run(corr):
+        hb.register_batch_dev(pairs[:64], prm, corr=corr)  # warm-up
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        results = hb.register_batch_dev(pairs, prm, corr=corr)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return qdist.max_over_ranks(time.perf_counter() - t0, cdev), results
+    out = {"what": f"{B} pair ids, block-partitioned over {world} GPU(s), batched launch chains "
+                   "(qtr_submit_batch / qtr_wait)", "pairs": B}
+    if composite:
+        el, results = run(True)
+        # identical to the sequential calls of the headline's step: the solver's record on the same correspondences,
+        # the front end's voxel counts
+        same = all(bool(np.array_equal(r["T"], pool[i % len(pool)]["result"]["T"])) and r["L"] == LC and
+                   r["n_clique"] == pool[i % len(pool)]["result"]["clique"].size and
+                   r["n_final"] == pool[i % len(pool)]["result"]["final_inliers"].size and
+                   (r["n_src"], r["n_tgt"]) == (pool[i % len(pool)]["front"]["n_src"], pool[i % len(pool)]["front"]["n_tgt"])
+                   for i, r in zip(ids, results))
+        out.update({"unit_of_work": f"front end of the scan pair (n ~ 16-18 k voxels per cloud) + back end on {LC} given "
+                                    "correspondences per pair id — the headline step's unit, batched",
+                    "n_corr": LC, "value": B / el, "unit": "registrations/s", "ms_per_pair": 1e3 * el / B,
+                    "identical_to_sequential": same})
+    el2, results2 = run(False)
+    same2 = all(bool(np.array_equal(r["T"], pool[i % len(pool)]["whole"]["T"])) for i, r in zip(ids, results2))
+    scan = {"what": "the same ids on the scans alone: the matcher's own correspondences feed the back end",
+            "n_corr": [int(p["L"]) for p in pool], "value": B / el2, "unit": "registrations/s",
+            "ms_per_pair": 1e3 * el2 / B, "identical_to_sequential": same2}
+    if composite:
+        out["scan_pairs"] = scan
+    else:
+        out.update(scan)
+    hung = False
+    if world > 1 and cdev is not None:  # the gather that closes configs[3]: through the library's own RCCL path
+        g = {"path": "qtr_comm_init + qtr_gather_results_v (RCCL via the C ABI, dlopen)"}
+        src_results = results if composite else results2
+
+        def lib_gather():
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(ql.comm_unique_id()), dtype=torch.uint8).to(cdev)
+                dist.broadcast(uid, 0)
+                hb.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                n_loc = len(ids)
+                loc = (ql.Result * max(n_loc, 1))()
+                for k, r in enumerate(src_results):
+                    loc[k].status, loc[k].valid, loc[k].n_clique, loc[k].n_final = r["status"], int(r["valid"]), r["n_clique"], r["n_final"]
+                    loc[k].n_corr, loc[k].n_src, loc[k].n_tgt, loc[k].cost = r["L"], r["n_src"], r["n_tgt"], r["cost"]
+                    for q in range(16):
+                        loc[k].T[q] = float(r["T"].reshape(-1)[q])
+                t0 = time.perf_counter()
+                allr, counts, n_all = hb.gather_results_v(loc if n_loc else None, n_loc, world, B)
+                want = [qdist.shard_range(B, r_, world)[1] - qdist.shard_range(B, r_, world)[0] for r_ in range(world)]
+                g.update({"ok": bool(n_all == B and counts == want), "records": int(n_all),
+                          "seconds": time.perf_counter() - t0,
+                          "all_valid": bool(all(allr[i].valid for i in range(n_all)))})
+            except Exception as e:  # the bench line must survive a site whose RCCL cannot be opened from the library
+                g.update({"ok": False, "error": repr(e)[:300]})
+        import threading
+        th = threading.Thread(target=lib_gather, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        if th.is_alive():  # (a rank that never arrives must not cost the line: report and leave without joining)
+            g.update({"ok": False, "error": "timed out after 120 s"})
+            hung = True
+        out["gather"] = g
+    if hung:
+        out["_hung"] = True
+        return out
     hb.close()
-    return {"what": f"{B} pair ids, block-partitioned over {world} GPU(s), batched launch chains "
-                    "(qtr_submit_batch / qtr_wait)", "pairs": B, "value": B / el, "unit": "registrations/s",
-            "ms_per_pair": 1e3 * el / B, "identical_to_sequential": same}
+    return out
+
+
+def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
+    """Data-connected registrations whose back end runs on THOUSANDS of the matcher's own correspondences — ONE
+    qtr_register_pair call each, timed one at a time like the headline:
+      mutual_nn   the 16-18 k-voxel pool pairs with use_tuple_test = 0 (reference feature_matcher.cc:187-247 skipped):
+                  every mutual nearest-neighbour pair, L ~ 2 k
+      no_cross    use_crosscheck = 0 as well (:124-181: corres_ij + corres_ji, de-duplicated): L ~ n_s + n_hit ~ 20 k
+      dense       BASELINE configs[4] end to end: two independently sampled 50 000-point clouds, a leaf so small that
+                  the voxel grid would overflow int32 (pcl::VoxelGrid then passes the cloud through — "no voxel
+                  downsample"), FPFH, matching with cross check and tuple test (L ~ 1.1 k) and the back end
+    (parity of each against the oracle: tests/test_gpu_baseline_sizes.py)."""
+    hc = ql.Handle(device_index, max_points=131072, max_voxels=65536, max_corr=32768)
+    res = ql.Result()
+    out = {}
+    a, b, Td = synth.dense_pair(50000)
+    dense = {"src": torch.from_numpy(a).to(dev), "tgt": torch.from_numpy(b).to(dev), "Tgt": Td}
+    cases = [("mutual_nn", dict(use_tuple_test=0), pool, 12),
+             ("no_cross", dict(use_crosscheck=0, use_tuple_test=0), pool, 8),
+             ("dense", dict(voxel_size=0.001), [dense], 4)]
+    hc.set_stage_events(False)
+    hc.set_nn_event_stride(0)
+    for name, kw, items, n in cases:
+        fps = [ql.default_frontend_params(seed=k, **kw) for k in range(len(items))]
+        recs = []
+        for k, it in enumerate(items):  # warm-up (also switches the handle to long neighbour lists for the dense clouds)
+            rc = hc.register_pair_dev(it["src"].data_ptr(), it["src"].shape[0], it["tgt"].data_ptr(), it["tgt"].shape[0],
+                                      fps[k], prm, res)
+            if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+                raise ql.QuatroHipError(rc, hc.last_error())
+            T = np.array(res.T[:]).reshape(4, 4)
+            yaw_gt = float(np.arctan2(it["Tgt"][1, 0], it["Tgt"][0, 0]))
+            yaw = float(np.arctan2(T[1, 0], T[0, 0]))
+            recs.append({"n_src": int(res.n_src), "n_tgt": int(res.n_tgt), "n_corr": int(res.n_corr),
+                         "n_clique": int(res.n_clique), "n_final": int(res.n_final), "valid": bool(res.valid),
+                         "rot_err_vs_gt_rad": abs(float(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt)))),
+                         "trans_err_vs_gt_m": float(np.linalg.norm(T[:3, 3] - it["Tgt"][:3, 3]))})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            it = items[k % len(items)]
+            hc.register_pair_dev(it["src"].data_ptr(), it["src"].shape[0], it["tgt"].data_ptr(), it["tgt"].shape[0],
+                                 fps[k % len(items)], prm, res)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[name] = {"frontend_params": kw, "value": n / el, "unit": "registrations/s", "ms_per_registration": 1e3 * el / n,
+                     "n_corr": [r["n_corr"] for r in recs], "pairs": recs}
+    hc.close()
+    out["what"] = ("qtr_register_pair, one call per registration, the matcher's own correspondences into the back end "
+                   "(no generator in between)")
+    return out
 
 
 def solver_leg(args, torch, ql, synth, h, prm, dev, L):

@@ -292,9 +292,8 @@ class Quatro : public pcl::Registration<PointSource, PointTarget, Scalar> {
     std::vector<int> clique(static_cast<size_t>(L > 0 ? L : 1)), rot(clique.size()), fin(clique.size());
     p.reg_mode = reg_name_ == "TEASER" ? QTR_REG_TEASER : QTR_REG_QUATRO;
     qtr_result res;
+    p.max_clique_time_limit = params_.max_clique_time_limit;  // :800 (PMC_EXACT only); travels with THIS call
     {
-      quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
-      qtr_set_clique_time_limit(h, params_.max_clique_time_limit);  // :800 (PMC_EXACT only)
       const int rc = qtr_solve(h, slot_lease.slot, quatro_hip::xyz4(input_->points), quatro_hip::xyz4(target_->points), L, &p, &res,
                                clique.data(), rot.data(), fin.data(), static_cast<int>(clique.size()), QTR_MEM_HOST);
       quatro_hip::check(h, rc);

@@ -51,6 +51,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#define QTR_API __attribute__((visibility("default")))
+#else
+#define QTR_API
+#endif
+
 #define QTR_OK 0
 #define QTR_ERR_BAD_ARG 1          /* std::invalid_argument in the reference */
 #define QTR_ERR_CLIQUE_TOO_SMALL 2 /* reference: solution_.valid = false, output untouched (quatro.hpp:809-813) */
@@ -101,6 +108,10 @@ typedef struct qtr_params {
   int using_rot_inliers_when_estimating_cote; /* 0 */
   int using_pre_estimated_ryrx;     /* 0 */
   int reg_mode;                     /* QTR_REG_QUATRO (Params::reg_name "Quatro", yaw) or QTR_REG_TEASER (3-DoF, row (f)4) */
+  double max_clique_time_limit;     /* 3600 s (include/quatro.hpp:267,800).  PMC_EXACT only; <= 0 = none.  When the limit
+                                       is hit the heuristic's clique is returned (the reference returns PMC's best so far)
+                                       and qtr_exact_stats reports it.  Per call: two threads with different limits on
+                                       different slots do not see each other's */
 } qtr_params;
 
 /* Front-end knobs of the demo (reference examples/run_global_registration.cpp:37-55, config/params.yaml:22-25)
@@ -139,33 +150,33 @@ typedef struct qtr_stage_times {
   float graph_kernel; /* k_graph_build alone */
 } qtr_stage_times;
 
-int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);
-void qtr_destroy(qtr_handle* h);
-const char* qtr_last_error(const qtr_handle* h);
-void qtr_default_limits(qtr_limits* l);
-void qtr_default_params(qtr_params* p);                   /* Quatro::Params defaults */
-void qtr_demo_params(qtr_params* p);                      /* config/params.yaml values */
-void qtr_default_frontend_params(qtr_frontend_params* p);
-int qtr_num_slots(const qtr_handle* h);
-void* qtr_slot_stream(qtr_handle* h, int slot); /* hipStream_t of a slot */
+QTR_API int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);
+QTR_API void qtr_destroy(qtr_handle* h);
+QTR_API const char* qtr_last_error(const qtr_handle* h);
+QTR_API void qtr_default_limits(qtr_limits* l);
+QTR_API void qtr_default_params(qtr_params* p);                   /* Quatro::Params defaults */
+QTR_API void qtr_demo_params(qtr_params* p);                      /* config/params.yaml values */
+QTR_API void qtr_default_frontend_params(qtr_frontend_params* p);
+QTR_API int qtr_num_slots(const qtr_handle* h);
+QTR_API void* qtr_slot_stream(qtr_handle* h, int slot); /* hipStream_t of a slot */
 
 /* K1.  out_xyz4 capacity `cap` points; *n_out receives the voxel count (output order = ascending
  * linear voxel index, as PCL).  If the grid would overflow int32 PCL passes the input through; so
  * does this call (then *n_out == P). */
-int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, float* out_xyz4, int cap, int* n_out,
+QTR_API int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, float* out_xyz4, int cap, int* n_out,
                  int mem);
 
 /* K2-K4.  normals4 (nx,ny,nz,curvature; may be NULL) and desc33 (n x 33 floats) */
-int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, float r_fpfh, float* normals4,
+QTR_API int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, float r_fpfh, float* normals4,
              float* desc33, int mem);
 
 /* K5-K8.  corr2 = L x (src index, tgt index), sorted lexicographically, capacity `cap` pairs. */
-int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float* desc33_s, const float* xyz4_t,
+QTR_API int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float* desc33_s, const float* xyz4_t,
               int n_t, const float* desc33_t, const qtr_frontend_params* fp, int* corr2, int cap, int* L_out, int mem);
 
 /* K9-K16.  src4/tgt4: the two equal-length matched keypoint clouds (setInputSource / setInputTarget).
  * clique / rot_inliers / final_inliers: optional int buffers of capacity `cap` (counts in *res). */
-int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int L, const qtr_params* prm,
+QTR_API int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int L, const qtr_params* prm,
               qtr_result* res, int* clique, int* rot_inliers, int* final_inliers, int cap, int mem);
 
 /* K10-K12 alone: the clique search on a caller-supplied graph.  adj = symmetric bit matrix, L rows of
@@ -175,7 +186,8 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
  * maximum clique in the canonical depth-first order; at most 32768 vertices.  clique receives
  * the member ids in ascending order (capacity cap); *n_out their count; *max_core_out (may be NULL) the
  * largest core number. */
-int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
+QTR_API int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
+                   double time_limit /* PMC_EXACT: MaxCliqueSolver::Params::time_limit, seconds; <= 0 = none */,
                    int* clique, int cap, int* n_out, int* max_core_out, int mem);
 
 /* The reference class keeps its stages individually callable (computeTIMs :307, solveForScale :355,
@@ -183,29 +195,28 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
  * path uses.  Host buffers only; matrices are ROW-major (3 x N means three rows of N doubles).
  * Capacity: every call stages through the slot's solver arena — K (TIM columns) and M / N are limited to what
  * max_corr provides (3 K doubles <= 36 * max_corr doubles per operand); QTR_ERR_CAPACITY otherwise. */
-int qtr_compute_tims(qtr_handle* h, int slot, const double* v3n, int N, double* tims3k /* 3 x N(N-1)/2 */,
+QTR_API int qtr_compute_tims(qtr_handle* h, int slot, const double* v3n, int N, double* tims3k /* 3 x N(N-1)/2 */,
                      int* map2k /* 2 x N(N-1)/2: (i, j) of every column */);
-int qtr_scale_mask(qtr_handle* h, int slot, const double* tims_src3k, const double* tims_dst3k, long long K,
+QTR_API int qtr_scale_mask(qtr_handle* h, int slot, const double* tims_src3k, const double* tims_dst3k, long long K,
                    double noise_bound, double cbar2, unsigned char* mask /* K */);
-int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const double* dst2m, int M, double noise_bound,
+QTR_API int qtr_gnc_rotation2d(qtr_handle* h, int slot, const double* src2m, const double* dst2m, int M, double noise_bound,
                        double gnc_factor, int max_iterations, double cost_threshold, double* R4 /* row-major 2x2 */,
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
 /* "Next" row (f)4, second half: the 3-DoF rotation of reg_name "TEASER" (solveForRotation throws for it in the
  * reference, include/quatro.hpp:409-411; teaser::utils::svdRot, include/teaser/utils.h:123-149, is what it would
  * call): TEASER++'s GNC-TLS loop over 3-D TIMs.  Also reachable through qtr_solve with reg_mode = QTR_REG_TEASER. */
-int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const double* dst3m, int M, double noise_bound,
+QTR_API int qtr_gnc_rotation3d(qtr_handle* h, int slot, const double* src3m, const double* dst3m, int M, double noise_bound,
                        double gnc_factor, int max_iterations, double cost_threshold, double* R9 /* row-major 3x3 */,
                        double* cost, int* iterations, unsigned char* inliers /* M, weight >= 0.4 */);
-int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
+QTR_API int qtr_cote_estimate(qtr_handle* h, int slot, const double* X, int N, double range /* uniform */, int median_selection,
                       double* estimate, unsigned char* inliers /* N */, int* n_card);
 /* the same with one range per element (estimate() takes a RowVectorXd of ranges, include/quatro.hpp:618-630) */
-int qtr_cote_estimate_ranges(qtr_handle* h, int slot, const double* X, const double* ranges, int N, int median_selection,
+QTR_API int qtr_cote_estimate_ranges(qtr_handle* h, int slot, const double* X, const double* ranges, int N, int median_selection,
                              double* estimate, unsigned char* inliers /* N */, int* n_card);
 
-/* PMC_EXACT only: Params::max_clique_time_limit (include/quatro.hpp:267, default 3600 s; <= 0 = none).  When the limit
- * is hit the heuristic's clique is returned (the reference returns PMC's best so far) and qtr_exact_stats reports it. */
-void qtr_set_clique_time_limit(qtr_handle* h, double seconds);
-int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* aborted);
+/* PMC_EXACT only: search-tree nodes of the slot's last exact search and whether its time limit
+ * (qtr_params.max_clique_time_limit / qtr_max_clique's time_limit) was hit. */
+QTR_API int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* aborted);
 
 /* "Next" row (f)3: on-disk formats either side of the path (host code, no GPU work, no handle).
  *   qtr_read_kitti_bin <- getCloud, examples/run_global_registration.cpp:377-402: float32 x,y,z,intensity records,
@@ -216,9 +227,9 @@ int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* abo
  *                         ascii, binary and binary_compressed files and picks x, y, z by field name.
  * Points are 16-byte x,y,z,w records like everywhere else in this ABI (w: intensity for .bin, 0 for PCD).
  * qtr_read_pcd_xyz always reports the file's point count; QTR_ERR_CAPACITY when cap is smaller. */
-int qtr_read_kitti_bin(const char* path, float* xyzi, int max_points, int* n_points);
-int qtr_write_pcd_xyz(const char* path, const float* xyz4, int n, int binary);
-int qtr_read_pcd_xyz(const char* path, float* xyz4, int cap, int* n_points);
+QTR_API int qtr_read_kitti_bin(const char* path, float* xyzi, int max_points, int* n_points);
+QTR_API int qtr_write_pcd_xyz(const char* path, const float* xyz4, int n, int binary);
+QTR_API int qtr_read_pcd_xyz(const char* path, float* xyz4, int cap, int* n_points);
 
 /* "Next" row (f)2: Patchwork ground segmentation, the first stage of the reference demo on raw scans
  * (PatchWork::estimate_ground, include/patchwork.hpp:329-476; parameters config/patchwork_params.yaml).
@@ -236,8 +247,8 @@ typedef struct qtr_pw_params {
   int num_thr;                              /* size of the two threshold vectors (<= 8) */
   double elevation_thr[8], flatness_thr[8];
 } qtr_pw_params;
-void qtr_pw_default_params(qtr_pw_params* p); /* config/patchwork_params.yaml */
-int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
+QTR_API void qtr_pw_default_params(qtr_pw_params* p); /* config/patchwork_params.yaml */
+QTR_API int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
                   int cap_ground, int* n_ground, float* nonground_xyzw, int cap_nonground, int* n_nonground, int mem);
 
 /* "Next" row (f)1: range-image projection + sub-cluster rejection, the stage before voxelisation in the reference
@@ -257,13 +268,13 @@ typedef struct qtr_ip_params {
 } qtr_ip_params;
 /* lidar_type: "Velodyne-64-HDE", "VLP-16", "HDL-32E", "Ouster-OS1-16", "Ouster-OS1-64"; neighbor_mode: as above.
  * Returns QTR_ERR_BAD_ARG for names the reference's constructor rejects (:131, :140). */
-int qtr_ip_default_params(const char* lidar_type, const char* neighbor_mode, qtr_ip_params* p);
-int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
+QTR_API int qtr_ip_default_params(const char* lidar_type, const char* neighbor_mode, qtr_ip_params* p);
+QTR_API int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
                       int cap_valid, int* n_valid, float* outl_xyzi, int cap_outl, int* n_outl, int* n_segments,
                       int* labelmat, int mem);
 
 /* Whole path on one slot: raw scans -> transform. */
-int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+QTR_API int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
                       const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
                       int* final_inliers, int cap, int mem);
 
@@ -276,7 +287,7 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
  * correspondence order, corr2 (optional, cap x 2 ints) the (source, target) voxel indices.  mem = QTR_MEM_HOST: outputs
  * complete on return; QTR_MEM_DEVICE: outputs are written on the slot's stream (qtr_slot_stream).  The matched clouds
  * also stay in the slot, where a following qtr_solve on device pointers can be issued without a copy. */
-int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+QTR_API int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
                      const qtr_frontend_params* fp, int* n_src, int* n_tgt, int* L, float* src_kps4, float* tgt_kps4,
                      int* corr2, int cap, int mem);
 
@@ -295,7 +306,7 @@ int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, con
  * pairs / results must stay valid until qtr_wait returns; one job at a time per handle; every slot of the handle is
  * used (do not run slot calls concurrently).  mem as elsewhere (raw scans and the optional index lists). */
 typedef struct qtr_pair_desc {
-  const float* src_raw4; /* raw source scan, 16-byte x,y,z,* records */
+  const float* src_raw4; /* raw source scan, 16-byte x,y,z,* records (NULL together with tgt_raw4: no front end, see below) */
   int n_src;
   const float* tgt_raw4;
   int n_tgt;
@@ -303,16 +314,32 @@ typedef struct qtr_pair_desc {
   int* clique;             /* optional: getMaxCliques indices, capacity `cap` ints (NULL: not wanted) */
   int* final_inliers;      /* optional: getFinalInliersIndices */
   int cap;
+  /* Pre-matched correspondences (optional; all three zero: the matcher's own output feeds the back end).  The
+   * reference's loop hands Quatro whatever matched keypoint clouds its caller has — setInputSource / setInputTarget /
+   * computeTransformation, examples/run_global_registration.cpp:243-246, include/quatro.hpp:769 — so a pair may bring
+   * them along: src_corr4[i] <-> tgt_corr4[i], n_corr 16-byte records each, same `mem` as the scans.
+   *   scans NULL, correspondences given : the back end alone (qtr_solve's work, batched); n_src / n_tgt ignored
+   *   scans AND correspondences given   : the front end runs on the scans (result.n_src / n_tgt report its voxel
+   *                                       counts) and the back end runs on the GIVEN correspondences instead of the
+   *                                       matcher's — the unit of work BASELINE's metric is quoted on (a KITTI-64
+   *                                       pair's front end + a ~5 k-correspondence back end) for callers whose
+   *                                       correspondences come from elsewhere (a cache: FPFHManager::loadFeaturePair,
+   *                                       include/fpfh_manager.hpp:211-232)
+   * result.n_corr reports the correspondences the back end ran on.  n_corr = 0 with both pointers set is the
+   * reference's "clique too small" outcome; n_corr > max_corr is QTR_ERR_CAPACITY in the pair's record. */
+  const float* src_corr4;
+  const float* tgt_corr4;
+  int n_corr;
 } qtr_pair_desc;
-int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,
+QTR_API int qtr_submit_batch(qtr_handle* h, const qtr_pair_desc* pairs, int B, const qtr_frontend_params* fp,
                      const qtr_params* prm, qtr_result* results, int mem);
-int qtr_wait(qtr_handle* h);
+QTR_API int qtr_wait(qtr_handle* h);
 /* Raw sweeps through the batched entry: with parameters set here qtr_submit_batch runs the demo's STEP 2 and 3 in front of
  * the voxel grid on every scan it is given (reference examples/run_global_registration.cpp:136-160:
  * PatchWork::estimate_ground -> non-ground points -> ImageProjection::segmentCloud -> getValidSegments), i.e. the pair
  * descriptors then carry raw scans WITH their ground returns and a batch reproduces the demo's whole sequence per pair.
  * pw = ip = NULL switches it off again (the default).  A scan that is all ground gets QTR_ERR_BAD_ARG in its own record. */
-int qtr_set_batch_preprocess(qtr_handle* h, const qtr_pw_params* pw, const qtr_ip_params* ip);
+QTR_API int qtr_set_batch_preprocess(qtr_handle* h, const qtr_pw_params* pw, const qtr_ip_params* ip);
 
 /* Multi-GPU (BASELINE configs[3]): pairs are independent, so every process / device registers its own block of pair
  * ids and the ONLY exchange is the final gather of the fixed-size result records — RCCL over xGMI (one ncclAllGather of
@@ -327,18 +354,20 @@ int qtr_set_batch_preprocess(qtr_handle* h, const qtr_pw_params* pw, const qtr_i
  *                        the counts are exchanged first, the blocks padded to the longest for the fixed-size
  *                        collective and trimmed on the way out.  `all` (capacity cap_all records) receives the
  *                        sum(counts) records in rank order, counts[world] (optional) every rank's count, *n_all
- *                        (optional) the total.  Collective: every rank calls it, also with n_local = 0.
+ *                        (optional) the total.  Collective: every rank calls it, also with n_local = 0.  When the
+ *                        records do not fit SOME rank's cap_all, EVERY rank returns QTR_ERR_CAPACITY (the capacities
+ *                        travel with the counts, so no rank is left waiting in the second collective).
  * librccl is opened at run time (dlopen), so single-GPU users do not need it.  QTR_ERR_HIP with the RCCL message in
  * qtr_last_error on failure. */
 #define QTR_COMM_ID_BYTES 128
-int qtr_comm_unique_id(char id[QTR_COMM_ID_BYTES]);
-int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int world);
-int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all);
-int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
+QTR_API int qtr_comm_unique_id(char id[QTR_COMM_ID_BYTES]);
+QTR_API int qtr_comm_init(qtr_handle* h, const char id[QTR_COMM_ID_BYTES], int rank, int world);
+QTR_API int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all);
+QTR_API int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
                          int* n_all);
-void qtr_comm_destroy(qtr_handle* h);
+QTR_API void qtr_comm_destroy(qtr_handle* h);
 
-int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
+QTR_API int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 /* Instrumentation (no reference counterpart; the demo times its stages with std::chrono around the calls,
  * examples/run_global_registration.cpp:206-246).  qtr_set_stage_events(0) stops recording events altogether (every
  * stage field of qtr_stage_times and its total then read 0: an event record is a marker the queue retires before the
@@ -347,9 +376,9 @@ int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
  * without a per-call query.  An event pair attached to a launch costs ~5 us of queue time on either side of it (four
  * such gaps per registration): qtr_set_nn_event_stride(h, n) attaches the pairs to every n-th match of a slot only
  * (default 1: every match; 0: never) — the totals then cover the launches that were timed. */
-int qtr_set_stage_events(qtr_handle* h, int on);
-int qtr_set_nn_event_stride(qtr_handle* h, int every);
-int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset);
+QTR_API int qtr_set_stage_events(qtr_handle* h, int on);
+QTR_API int qtr_set_nn_event_stride(qtr_handle* h, int every);
+QTR_API int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset);
 
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to
  * `bytes` bytes to host memory `dst`; returns the number of bytes the item holds, or <0 on error. */
@@ -370,11 +399,11 @@ int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* laun
                                     two-candidate exact compare */
 #define QTR_DBG_SOLVER_STATE 14  /* int32[32]: mc, best_r, pos, done, t0, ub, batch, max_core, n_edges2, clique rounds,
                                     [10] k-core peeling rounds */
-long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
+QTR_API long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
 
 /* Evaluates the shared deterministic math (include/qtr_math.h) ON THE DEVICE, for the test that pins
  * host/device bit-equality: fn 0 atan2f(a,b), 1 acosf(a), 2 sinf(a) (theta in [0,1.2]), 3 cosf(a). */
-int qtr_debug_math(qtr_handle* h, int fn, const float* a, const float* b, float* out, int n);
+QTR_API int qtr_debug_math(qtr_handle* h, int fn, const float* a, const float* b, float* out, int n);
 
 #ifdef __cplusplus
 }

@@ -127,10 +127,10 @@ class MaxCliqueSolver {
     if (params_.solver_mode == CLIQUE_SOLVER_MODE::KCORE_HEU) mode = QTR_INLIER_KCORE_HEU;
     qtr_handle* h = quatro_hip::default_handle();
     quatro_hip::SlotLease slot_lease;  // a free stream slot of the process-wide handle
-    qtr_set_clique_time_limit(h, params_.time_limit);
     const std::vector<unsigned long long> bm = graph.bitMatrix();
     int n = 0, max_core = 0;
-    quatro_hip::check(h, qtr_max_clique(h, slot_lease.slot, bm.data(), N, mode, params_.kcore_heuristic_threshold, clique.data(),
+    quatro_hip::check(h, qtr_max_clique(h, slot_lease.slot, bm.data(), N, mode, params_.kcore_heuristic_threshold, params_.time_limit,
+                                        clique.data(),
                                         static_cast<int>(clique.size()), &n, &max_core, QTR_MEM_HOST));
     clique.resize(static_cast<size_t>(n));
     max_core_ = max_core;

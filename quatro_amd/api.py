@@ -379,7 +379,7 @@ class Quatro:
             raise ValueError("source and target keypoint clouds must have equal length")
         h = self._h or _handle()
         cp = self._c_params()
-        h.set_clique_time_limit(self.params_.max_clique_time_limit)  # :800 (PMC_EXACT only)
+        cp.max_clique_time_limit = float(self.params_.max_clique_time_limit)  # :800 (PMC_EXACT only)
         r = h.solve(self.input_, self.target_, cp)
         # the reference persists params_.noise_bound *= 2/scale for later calls (:850-852)
         self.params_.noise_bound = self.params_.noise_bound * 2.0

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libquatro_hip.so")
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".map"))) + [
     os.path.join("..", "..", "include", "qtr_math.h"), os.path.join("..", "..", "include", "quatro_hip.h")]
 
 
@@ -30,7 +30,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wno-unused-value",
+           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wno-unused-value", "-fvisibility=hidden",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
            os.path.join(CSRC, "unity.hip"), "-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -2,6 +2,7 @@
 // Host-side orchestration only: arenas, stream slots, staging copies, kernel sequencing.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -60,6 +61,10 @@ struct Lane {
   int first_pair = 0, count = 0;  // pairs [first_pair, first_pair + count) of the job are on this lane
   std::vector<int> active;      // indices g (0..count) of the pairs still alive after each chain's checks
   std::vector<int> ns, nt, L;   // per g
+  std::vector<int> corr_only;   // g of the pairs that bring their own correspondences and no scans: solver chain only
+  std::vector<const float4*> csrc, ctgt;  // per g: the matched clouds the solver reads (slot's m_src / m_tgt or the caller's)
+  std::vector<const float4*> raw_s, raw_t;  // per g: the clouds the voxel grid read (device pointers) and their sizes
+  std::vector<int> Ps, Pt;
   bool long_lists = false;      // the chunk's FPFH chain included k2_neighbors_big
 };
 struct BatchJob {
@@ -83,8 +88,8 @@ struct qtr_handle {
   int comm_rank = 0, comm_world = 1;
   void* comm_buf = nullptr;    // device staging of the gather
   size_t comm_bytes = 0;
+  std::atomic<int> solves_in_flight{0};  // back-end chains enqueued and not yet read back (slot calls from several threads)
   int spin_wait = 1;  // QTR_HOST_WAIT=block turns the mailbox polling off
-  double clique_time_limit = 3600;  // Params::max_clique_time_limit (reference include/quatro.hpp:267), seconds
   bool pre_on = false;      // qtr_set_batch_preprocess: the batched entry takes RAW sweeps (ground removal + range-image
   qtr_pw_params pre_pw;     // segmentation in front of the voxel grid)
   qtr_ip_params pre_ip;
@@ -115,9 +120,12 @@ static RcclApi* rccl_api(char* err, size_t errn) {
   static int state = 0;  // 0 untried, 1 ok, -1 failed
   static char why[256] = "symbols missing";  // dlerror() is read ONCE per failure (a second call returns NULL)
   if (state == 0) {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // QTR_RCCL_LIB: a site's own RCCL build, tried first (tests/test_gpu_multi.py points it at a transport double so
+    // that several processes sharing one GPU can run the gather end to end)
+    const char* names[] = {getenv("QTR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
       if (api.lib) break;
+      if (!n || !*n) continue;
       api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (!api.lib) {
         const char* e = dlerror();
@@ -180,8 +188,11 @@ static int comm_allgather(qtr_handle* h, RcclApi* a, const void* d_send, void* d
   return QTR_OK;
 }
 
-int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
-                         int* n_all) {
+// require_equal: qtr_gather_results — blocks of different lengths are refused.  Every decision to leave before the second
+// collective is taken from the GATHERED line (counts, capacities, flags: identical on every rank), never from a rank's
+// own arguments: a rank that bailed out alone would leave the others waiting in ncclAllGather for good.
+static int gather_impl(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
+                       int* n_all, bool require_equal) {
   if (!h || n_local < 0 || (n_local > 0 && !local) || cap_all < 0 || (cap_all > 0 && !all)) return QTR_ERR_BAD_ARG;
   if (!h->comm) {
     snprintf(h->err, sizeof(h->err), "qtr_gather_results: call qtr_comm_init first");
@@ -201,27 +212,38 @@ int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qt
     h->comm_bytes = bytes;
     return QTR_OK;
   };
-  // 1. every rank's record count (a collective: ranks with nothing to send take part too)
+  // 1. every rank's record count, the room it has for the result and whether it insists on equal blocks (a collective:
+  //    ranks with nothing to send take part too)
   QTR_TRY(reserve(256 + 256 * (size_t)world));
   std::vector<int> cnt((size_t)world * 64, 0);  // one 256-byte line per rank
-  int mine_line[64] = {n_local};
+  int mine_line[64] = {n_local, cap_all, require_equal ? 1 : 0};
   QTR_HIP_TRY(h, hipMemcpyAsync(h->comm_buf, mine_line, 256, hipMemcpyHostToDevice, st));
   QTR_TRY(comm_allgather(h, a, h->comm_buf, (char*)h->comm_buf + 256, 256, st));
   QTR_HIP_TRY(h, hipMemcpyAsync(cnt.data(), (char*)h->comm_buf + 256, 256 * (size_t)world, hipMemcpyDeviceToHost, st));
   QTR_HIP_TRY(h, hipStreamSynchronize(st));
-  int nmax = 0;
+  int nmax = 0, nmin = 0x7fffffff;
   long long total = 0;
+  bool want_equal = false;
   for (int r = 0; r < world; ++r) {
     const int c = cnt[(size_t)r * 64];
     if (counts) counts[r] = c;
     nmax = std::max(nmax, c);
+    nmin = std::min(nmin, c);
     total += c;
+    want_equal = want_equal || cnt[(size_t)r * 64 + 2] != 0;
   }
   if (n_all) *n_all = (int)total;
-  if (total > cap_all) {  // every rank sees the same counts, so every rank leaves here together
-    snprintf(h->err, sizeof(h->err), "qtr_gather_results: %lld records, capacity %d", total, cap_all);
-    return QTR_ERR_CAPACITY;
+  if (want_equal && nmin != nmax) {  // (the same verdict on every rank)
+    snprintf(h->err, sizeof(h->err), "qtr_gather_results: ranks hold different record counts (%d .. %d; use qtr_gather_results_v)",
+             nmin, nmax);
+    return QTR_ERR_BAD_ARG;
   }
+  for (int r = 0; r < world; ++r)
+    if (total > cnt[(size_t)r * 64 + 1]) {  // some rank has no room: every rank leaves here, together
+      snprintf(h->err, sizeof(h->err), "qtr_gather_results: %lld records, rank %d has room for %d", total, r,
+               cnt[(size_t)r * 64 + 1]);
+      return QTR_ERR_CAPACITY;
+    }
   if (nmax == 0) return QTR_OK;
   // 2. the records, every block padded to the longest (fixed-size collective), trimmed on the way out
   const size_t block = (size_t)nmax * sizeof(qtr_result);
@@ -244,17 +266,16 @@ int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qt
   return QTR_OK;
 }
 
+int qtr_gather_results_v(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all, int cap_all, int* counts,
+                         int* n_all) {
+  return gather_impl(h, local, n_local, all, cap_all, counts, n_all, false);
+}
+
 int qtr_gather_results(qtr_handle* h, const qtr_result* local, int n_local, qtr_result* all) {
   if (!h || n_local < 0 || (n_local > 0 && (!local || !all))) return QTR_ERR_BAD_ARG;
-  std::vector<int> counts((size_t)std::max(h->comm_world, 1), 0);
-  int n_all = 0;
-  // the caller sized `all` for world * n_local records: blocks of another length are refused, not overrun
-  const int rc = qtr_gather_results_v(h, local, n_local, all, n_local * h->comm_world, counts.data(), &n_all);
-  if (rc == QTR_ERR_CAPACITY || (rc == QTR_OK && n_all != n_local * h->comm_world)) {
-    snprintf(h->err, sizeof(h->err), "qtr_gather_results: ranks hold different record counts (use qtr_gather_results_v)");
-    return QTR_ERR_BAD_ARG;
-  }
-  return rc;
+  // the caller sized `all` for world * n_local records: blocks of another length are refused (on every rank), not overrun
+  const long long room = (long long)n_local * std::max(h->comm_world, 1);
+  return gather_impl(h, local, n_local, all, (int)std::min<long long>(room, 0x7fffffff), nullptr, nullptr, true);
 }
 
 void qtr_comm_destroy(qtr_handle* h) {
@@ -269,10 +290,6 @@ void qtr_comm_destroy(qtr_handle* h) {
     h->comm_buf = nullptr;
     h->comm_bytes = 0;
   }
-}
-
-void qtr_set_clique_time_limit(qtr_handle* h, double seconds) {
-  if (h) h->clique_time_limit = seconds;
 }
 
 int qtr_exact_stats(qtr_handle* h, int slot, unsigned long long* nodes, int* aborted) {
@@ -302,6 +319,7 @@ void qtr_default_params(qtr_params* p) {  // Quatro::Params defaults, reference 
   p->rotation_max_iterations = 100;
   p->inlier_selection_mode = QTR_INLIER_PMC_HEU;
   p->cote_median = 1;
+  p->max_clique_time_limit = 3600;
 }
 
 void qtr_demo_params(qtr_params* p) {  // reference config/params.yaml:22-44
@@ -633,7 +651,8 @@ static int check_params(qtr_handle* h, const qtr_params* prm) {
 
 // PMC_EXACT after the heuristic has finished (state `hs` = the device SolverState as the host last saw it): proves the
 // heuristic clique maximum or replaces it (exact.hip).  *improved tells the caller that st->mc / best_r / picks changed.
-static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, bool* improved) {
+// time_limit: Params::max_clique_time_limit of THIS call, seconds (reference include/quatro.hpp:267,800; <= 0: none).
+static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, bool* improved, double time_limit) {
   *improved = false;
   s.exact_nodes = 0;
   s.exact_aborted = 0;
@@ -657,7 +676,7 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
     s.ex_bytes = need;
   }
   exact_carve(s.exb, s.ex_arena, depth_cap, nwaves);
-  const long long ticks = h->clique_time_limit > 0 ? (long long)(h->clique_time_limit * 1e8) : 0;  // 100 MHz counter
+  const long long ticks = time_limit > 0 ? (long long)(time_limit * 1e8) : 0;  // 100 MHz counter
   hipLaunchKernelGGL(k_exact_init, dim3(1), dim3(1), 0, s.stream, s.sb.Kp, L, s.sb.st, s.exb.ctl);
   exact_launch_search(s.sb, s.exb, L, depth_cap, nwaves, 0, ticks, s.stream, hs.t0, small_lds);
   ExactCtl* hc = (ExactCtl*)(s.pinned_i32 + 192);
@@ -685,11 +704,23 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
   return QTR_OK;
 }
 
+struct InFlight {
+  qtr_handle* h;
+  explicit InFlight(qtr_handle* h_) : h(h_) {
+    const int others = h->solves_in_flight.fetch_add(1, std::memory_order_acq_rel);
+    solver_set_hca_share(others > 0 ? (int)h->slots.size() : 1);
+  }
+  ~InFlight() { h->solves_in_flight.fetch_sub(1, std::memory_order_acq_rel); }
+};
+
 // Runs the back end on device-resident matched clouds and brings the result record to the host.
 static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float4* d_tgt, int L, const qtr_params* prm,
                         qtr_result* res, bool reset_done = false) {
   s.last_L = L;
   s.sb.mail_seq = ++s.seq;
+  // k_hcore_async's workgroups have to be resident together: a chain that starts while another slot's is in flight (calls
+  // from several threads) takes its share of the compute units only (solver.hip, solver_set_hca_share)
+  InFlight in_flight(h);
   QTR_HIP_TRY(h, solver_enqueue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32, h->stage_events ? s.ev[2] : nullptr,
                                 h->stage_events ? s.ev[3] : nullptr, reset_done));
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
@@ -704,7 +735,7 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
     SolverState hs;
     memcpy(&hs, s.mail + MAIL_SOLVER + 64, sizeof(hs));
     bool improved = false;
-    QTR_TRY(exact_phase(h, s, L, hs, &improved));
+    QTR_TRY(exact_phase(h, s, L, hs, &improved, prm->max_clique_time_limit));
     if (improved) {  // estimate again from the larger clique
       s.sb.mail_seq = ++s.seq;
       QTR_HIP_TRY(h, solver_refinalize(s.sb, d_src, d_tgt, L, *prm, s.stream));
@@ -779,7 +810,7 @@ int qtr_solve(qtr_handle* h, int slot, const float* src4, const float* tgt4, int
 }
 
 int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L, int mode, double kcore_thr,
-                   int* clique, int cap, int* n_out, int* max_core_out, int mem) {
+                   double time_limit, int* clique, int cap, int* n_out, int* max_core_out, int mem) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !n_out || L < 0 || (L > 0 && (!adj || !clique))) return QTR_ERR_BAD_ARG;
   Slot& s = *sp;
@@ -802,6 +833,7 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     d_adj = s.sb.bm;
   }
   s.last_L = L;
+  InFlight in_flight(h);
   QTR_HIP_TRY(h, clique_only_enqueue(s.sb, d_adj, L, mode, kcore_thr, s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 128, s.sb.st, sizeof(SolverState), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
@@ -814,7 +846,7 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     SolverState hs;
     memcpy(&hs, s.pinned_i32 + 128, sizeof(hs));
     bool improved = false;
-    QTR_TRY(exact_phase(h, s, L, hs, &improved));
+    QTR_TRY(exact_phase(h, s, L, hs, &improved, time_limit));
   }
   s.sb.mail_seq = ++s.seq;
   QTR_HIP_TRY(h, clique_only_finish(s.sb, L, s.stream));
@@ -1363,6 +1395,12 @@ static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_fronte
   QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream, init_done));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
   *L_out = s.mail[MAIL_MATCH + MC_NCORR];
+  if (*L_out < 0) {  // a multi-workgroup compaction of the tail gave up waiting for a predecessor's count (match.hip)
+    *L_out = 0;
+    (void)hipStreamSynchronize(s.stream);
+    snprintf(h->err, sizeof(h->err), "matcher tail: look-back timed out (no correspondences were written)");
+    return QTR_ERR_HIP;
+  }
   return QTR_OK;
 }
 
@@ -1483,10 +1521,28 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       break;
     }
   }
-  const int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
-  if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW]) {
-    snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small); use qtr_fpfh on the raw cloud");
-    return fail_drained(QTR_ERR_CAPACITY);
+  int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+  {
+    // pcl::VoxelGrid::applyFilter: "Leaf size is too small for the input dataset. Integer indices would overflow" ->
+    // output = input.  So does `voxelize` of the reference (include/quatro.hpp:49-68 calls it unconditionally), and the
+    // demo goes on with the cloud as it is — BASELINE's dense mode ("no voxel downsample") through the whole-path entry.
+    const bool pass[2] = {s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] != 0, s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] != 0};
+    if (pass[0] || pass[1]) {
+      if ((pass[0] && Ps > h->lim.max_voxels) || (pass[1] && Pt > h->lim.max_voxels)) {
+        snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small): the cloud passes through as it "
+                 "is (pcl::VoxelGrid), and its %d / %d points exceed max_voxels=%d", Ps, Pt, h->lim.max_voxels);
+        return fail_drained(QTR_ERR_CAPACITY);
+      }
+      if (pass[0]) {
+        QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[0].vox, d_s, (size_t)Ps * 16, hipMemcpyDeviceToDevice, s.stream));
+        ns = Ps;
+      }
+      if (pass[1]) {
+        QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[1].vox, d_t, (size_t)Pt * 16, hipMemcpyDeviceToDevice, s.stream));
+        nt = Pt;
+      }
+      QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));  // (the second stream's means wait for the clouds)
+    }
   }
   if (ns > h->lim.max_voxels || nt > h->lim.max_voxels) {
     snprintf(h->err, sizeof(h->err), "voxel count (%d,%d) exceeds max_voxels=%d", ns, nt, h->lim.max_voxels);
@@ -1547,25 +1603,40 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
   return QTR_OK;
 }
 
+// The whole path on one slot.  mem_in: where the scans live; mem_out: where the index lists go.  corr_src / corr_tgt
+// (device pointers, n_corr >= 0): the back end runs on THESE matched clouds instead of the matcher's output (the batched
+// entry's "scans + pre-matched correspondences" pairs); n_corr < 0: the matcher's own correspondences.
+static int register_pair_impl(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                              const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
+                              int* final_inliers, int cap, int mem_in, int mem_out, const float4* corr_src,
+                              const float4* corr_tgt, int n_corr) {
+  int L = 0;
+  int rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem_in, true, &res->n_src, &res->n_tgt, &L);
+  res->n_corr = L;
+  if (rc != QTR_OK) return res->status = rc;
+  if (n_corr >= 0) {
+    res->n_corr = n_corr;
+    rc = solve_device(h, s, corr_src, corr_tgt, n_corr, prm, res, true);
+  } else {
+    rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res, true);
+  }
+  if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
+  s.times_pending = h->stage_events ? 2 : 4;
+  const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem_out);
+  if (rc2 != QTR_OK) return res->status = rc2;
+  return rc;
+}
+
 int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
                       const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
                       int* final_inliers, int cap, int mem) {
   Slot* sp = get_slot(h, slot);
   if (!sp || !res || !fp) return QTR_ERR_BAD_ARG;
-  Slot& s = *sp;
   memset(res, 0, sizeof(*res));
-  int rc = check_params(h, prm);
+  const int rc = check_params(h, prm);
   if (rc != QTR_OK) return res->status = rc;
-  int L = 0;
-  rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, true, &res->n_src, &res->n_tgt, &L);
-  res->n_corr = L;
-  if (rc != QTR_OK) return res->status = rc;
-  rc = solve_device(h, s, s.m_src, s.m_tgt, L, prm, res, true);
-  if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
-  s.times_pending = h->stage_events ? 2 : 4;
-  const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
-  if (rc2 != QTR_OK) return res->status = rc2;
-  return rc;
+  return register_pair_impl(h, *sp, src_raw4, Ps, tgt_raw4, Pt, fp, prm, res, clique, final_inliers, cap, mem, mem, nullptr,
+                            nullptr, -1);
 }
 
 int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
@@ -1628,6 +1699,45 @@ static void batch_abort(qtr_handle* h) {
   J.active = false;
 }
 
+// What a pair descriptor asks for: scans (front end + back end), pre-matched correspondences (back end only — the
+// reference's setInputSource / setInputTarget / computeTransformation on what it is handed,
+// examples/run_global_registration.cpp:243-246), or both (front end of the scans, back end on the given correspondences).
+static inline bool pair_has_scans(const qtr_pair_desc& pd) { return pd.src_raw4 != nullptr || pd.tgt_raw4 != nullptr; }
+static inline bool pair_has_corr(const qtr_pair_desc& pd) {
+  return pd.src_corr4 != nullptr || pd.tgt_corr4 != nullptr || pd.n_corr != 0;
+}
+
+static int lane_start_chunk(qtr_handle* h, Lane& ln);
+
+// Solver chain of the chunk: the pairs of `from_match` (survivors of the matching chain, ln.L / ln.csrc / ln.ctgt set)
+// plus the chunk's correspondence-only pairs.
+static int lane_enqueue_solver(qtr_handle* h, Lane& ln, const std::vector<int>& from_match) {
+  BatchJob& J = h->job;
+  Slot& lead = h->slots[ln.first_slot];
+  std::vector<int> all(from_match);
+  all.insert(all.end(), ln.corr_only.begin(), ln.corr_only.end());
+  ln.corr_only.clear();
+  ln.active.swap(all);
+  if (ln.active.empty()) return lane_start_chunk(h, ln);
+  std::vector<int> Ls;
+  std::vector<SolverBufs*> SB;
+  std::vector<const float4*> srcs, tgts;
+  for (int g : ln.active) {
+    Slot& s = h->slots[ln.first_slot + g];
+    s.last_L = ln.L[g];
+    s.sb.mail_seq = ++s.seq;
+    SB.push_back(&s.sb);
+    srcs.push_back(ln.csrc[g]);
+    tgts.push_back(ln.ctgt[g]);
+    Ls.push_back(ln.L[g]);
+  }
+  solver_set_hca_share((int)h->lanes.size());  // the lanes' solver chains overlap: each keeps to its share of the device
+  QTR_HIP_TRY(h, solver_enqueue_group(SB.data(), (int)SB.size(), srcs.data(), tgts.data(), Ls.data(), J.prm, &ln.stage,
+                                      lead.stream));
+  ln.phase = 3;
+  return QTR_OK;
+}
+
 static int lane_start_chunk(qtr_handle* h, Lane& ln) {
   BatchJob& J = h->job;
   if (J.next >= J.B) {
@@ -1640,9 +1750,16 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
   J.next += ln.count;
   ln.stage.off = 0;
   ln.active.clear();
+  ln.corr_only.clear();
   ln.ns.assign((size_t)ln.count, 0);
   ln.nt.assign((size_t)ln.count, 0);
   ln.L.assign((size_t)ln.count, 0);
+  ln.csrc.assign((size_t)ln.count, nullptr);
+  ln.ctgt.assign((size_t)ln.count, nullptr);
+  ln.raw_s.assign((size_t)ln.count, nullptr);
+  ln.raw_t.assign((size_t)ln.count, nullptr);
+  ln.Ps.assign((size_t)ln.count, 0);
+  ln.Pt.assign((size_t)ln.count, 0);
   Slot& lead = h->slots[ln.first_slot];
   std::vector<FrontBufs*> F;
   std::vector<const float4*> raws;
@@ -1652,12 +1769,34 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
     Slot& s = h->slots[ln.first_slot + g];
     qtr_result& r = J.results[ln.first_pair + g];
     memset(&r, 0, sizeof(r));
-    if (pd.n_src <= 0 || pd.n_tgt <= 0 || !pd.src_raw4 || !pd.tgt_raw4) {
+    const bool scans = pair_has_scans(pd), corr = pair_has_corr(pd);
+    if ((!scans && !corr) || (scans && (pd.n_src <= 0 || pd.n_tgt <= 0 || !pd.src_raw4 || !pd.tgt_raw4)) ||
+        (corr && (pd.n_corr < 0 || !pd.src_corr4 || !pd.tgt_corr4))) {
       batch_fail_pair(h, ln.first_pair + g, QTR_ERR_BAD_ARG);
       continue;
     }
-    if (pd.n_src > h->lim.max_points || pd.n_tgt > h->lim.max_points) {
+    if ((scans && (pd.n_src > h->lim.max_points || pd.n_tgt > h->lim.max_points)) || (corr && pd.n_corr > h->lim.max_corr)) {
       batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
+      continue;
+    }
+    s.times_pending = 0;
+    if (corr) {
+      r.n_corr = pd.n_corr;
+      ln.L[g] = pd.n_corr;
+    }
+    if (!scans) {  // correspondences only: nothing to do before the solver chain
+      if (J.mem == QTR_MEM_HOST) {
+        if (pd.n_corr > 0) {
+          QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, pd.src_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, lead.stream));
+          QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, pd.tgt_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, lead.stream));
+        }
+        ln.csrc[g] = s.m_src;
+        ln.ctgt[g] = s.m_tgt;
+      } else {
+        ln.csrc[g] = (const float4*)pd.src_corr4;
+        ln.ctgt[g] = (const float4*)pd.tgt_corr4;
+      }
+      ln.corr_only.push_back(g);
       continue;
     }
     const float4 *d_s = (const float4*)pd.src_raw4, *d_t = (const float4*)pd.tgt_raw4;
@@ -1700,7 +1839,10 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
       d_t = s.in_tgt;
     }
     s.fb.mail_seq = ++s.seq;
-    s.times_pending = 0;
+    ln.raw_s[g] = d_s;  // (device pointers: what the voxel grid of this pair reads)
+    ln.raw_t[g] = d_t;
+    ln.Ps[g] = P_s;
+    ln.Pt[g] = P_t;
     ln.active.push_back(g);
     F.push_back(&s.fb);
     raws.push_back(d_s);
@@ -1708,7 +1850,7 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
     Ps.push_back(P_s);
     Ps.push_back(P_t);
   }
-  if (ln.active.empty()) return lane_start_chunk(h, ln);  // nothing valid in this chunk: take the next one
+  if (ln.active.empty()) return lane_enqueue_solver(h, ln, {});  // no scans in this chunk (or nothing valid at all)
   QTR_HIP_TRY(h, voxelize_enqueue_group(F.data(), (int)F.size(), raws.data(), Ps.data(), J.fp.voxel_size, &ln.stage,
                                         lead.stream));
   QTR_HIP_TRY(h, hipEventRecord(lead.ev_vox, lead.stream));
@@ -1727,6 +1869,7 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       if (!mail_ready(s, MAIL_SEQ_VOX0, s.seq) || !mail_ready(s, MAIL_SEQ_VOX1, s.seq)) return QTR_OK;
     }
     *progress = true;
+    bool passed_through = false;
     std::vector<int> keep;
     std::vector<FrontBufs*> F;
     std::vector<int> n2;
@@ -1734,11 +1877,22 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     for (int g : ln.active) {
       Slot& s = h->slots[ln.first_slot + g];
       qtr_result& r = J.results[ln.first_pair + g];
-      const int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+      int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+      // (a grid that would overflow int32 passes its cloud through, as pcl::VoxelGrid does: see front_device)
+      const bool pass_s = s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] != 0, pass_t = s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] != 0;
+      if (pass_s) ns = ln.Ps[g];
+      if (pass_t) nt = ln.Pt[g];
+      if (pass_s && ns <= h->lim.max_voxels) {
+        QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[0].vox, ln.raw_s[g], (size_t)ns * 16, hipMemcpyDeviceToDevice, lead.stream));
+        passed_through = true;
+      }
+      if (pass_t && nt <= h->lim.max_voxels) {
+        QTR_HIP_TRY(h, hipMemcpyAsync(s.fb.cloud[1].vox, ln.raw_t[g], (size_t)nt * 16, hipMemcpyDeviceToDevice, lead.stream));
+        passed_through = true;
+      }
       r.n_src = ns;
       r.n_tgt = nt;
-      if (s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] || s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] || ns > h->lim.max_voxels ||
-          nt > h->lim.max_voxels || ns <= 0 || nt <= 0) {
+      if (ns > h->lim.max_voxels || nt > h->lim.max_voxels || ns <= 0 || nt <= 0) {
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
         continue;
       }
@@ -1753,8 +1907,9 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       seeds.push_back(J.pairs[ln.first_pair + g].seed);
     }
     ln.active.swap(keep);
-    if (ln.active.empty()) return lane_start_chunk(h, ln);
+    if (ln.active.empty()) return lane_enqueue_solver(h, ln, {});
     const int G = (int)F.size();
+    if (passed_through) QTR_HIP_TRY(h, hipEventRecord(lead.ev_vox, lead.stream));
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream2, lead.ev_vox, 0));
     QTR_HIP_TRY(h, mean_enqueue_group(F.data(), G, n2.data(), &ln.stage, lead.stream2));  // beside the FPFH chain
     QTR_HIP_TRY(h, hipEventRecord(lead.ev[5], lead.stream2));
@@ -1776,49 +1931,97 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       if (!mail_ready(s, MAIL_SEQ_MATCH, s.seq)) return QTR_OK;
     }
     *progress = true;
-    std::vector<int> keep, Ls;
-    std::vector<SolverBufs*> SB;
-    std::vector<const float4*> srcs, tgts;
+    std::vector<int> keep;
+    bool drained = false;  // lead.stream has been synchronised by a fallback below
     for (int g : ln.active) {
       Slot& s = h->slots[ln.first_slot + g];
       qtr_result& r = J.results[ln.first_pair + g];
-      const int L = s.mail[MAIL_MATCH + MC_NCORR];
-      r.n_corr = L;
-      if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY] || L > h->lim.max_corr) {
+      const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+      const bool given = pair_has_corr(pd);  // the back end runs on the caller's correspondences, not the matcher's
+      const int Lm = s.mail[MAIL_MATCH + MC_NCORR];
+      if (!given) r.n_corr = Lm;
+      if (Lm < 0) {  // the tail's look-back timed out (match.hip): nothing usable was written for this pair
+        r.n_corr = 0;
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_HIP);
+        continue;
+      }
+      if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY] || Lm > h->lim.max_corr) {
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
         continue;
       }
       if (!ln.long_lists && (s.mail[MAIL_CNT0 + CNT_NBR_OVERFLOW] || s.mail[MAIL_CNT1 + CNT_NBR_OVERFLOW])) {
-        // a point with more than QTR_KMAX neighbours and a chain without k2_neighbors_big (see front_device): this pair
-        // goes through the per-pair entry point on its own slot (whose arenas the group is done with), and the
-        // handle's later chains include the launch
+        // A point with more than QTR_KMAX neighbours and a chain without k2_neighbors_big (see front_device): this pair
+        // goes through the per-pair path on its own slot, and the handle's later chains include the launch.  The
+        // group's chain (lane stream) may still be writing this slot's lists — the mail is published before the
+        // kernel's last workgroup is done — so the lane stream is drained first; the pair is registered on the clouds
+        // the group's voxel grid read (the pre-processed sweeps when qtr_set_batch_preprocess is on, the staged copies
+        // of host scans: device pointers either way), and on the caller's correspondences when it brought some.
         h->long_lists = true;
-        const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+        if (!drained) QTR_HIP_TRY(h, hipStreamSynchronize(lead.stream));
+        drained = true;
         qtr_frontend_params f1 = J.fp;
         f1.seed = pd.seed;
-        const int rc1 = qtr_register_pair(h, ln.first_slot + g, pd.src_raw4, pd.n_src, pd.tgt_raw4, pd.n_tgt, &f1, &J.prm, &r,
-                                          pd.clique, pd.final_inliers, pd.cap, J.mem);
+        const float4 *cs = nullptr, *ct = nullptr;
+        if (given) {
+          cs = (const float4*)pd.src_corr4;
+          ct = (const float4*)pd.tgt_corr4;
+          if (J.mem == QTR_MEM_HOST) {  // (front_device overwrites m_src / m_tgt: the copy goes behind it, see below)
+            cs = s.m_src;
+            ct = s.m_tgt;
+          }
+        }
+        int rc1;
+        if (given && J.mem == QTR_MEM_HOST) {
+          // front end first, then the caller's correspondences into the (now free) matched-cloud buffers, then the back end
+          int L1 = 0;
+          rc1 = front_device(h, s, (const float*)ln.raw_s[g], ln.Ps[g], (const float*)ln.raw_t[g], ln.Pt[g], &f1,
+                             QTR_MEM_DEVICE, true, &r.n_src, &r.n_tgt, &L1);
+          if (rc1 == QTR_OK) {
+            if (pd.n_corr > 0) {
+              QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, pd.src_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, s.stream));
+              QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, pd.tgt_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, s.stream));
+            }
+            r.n_corr = pd.n_corr;
+            rc1 = solve_device(h, s, s.m_src, s.m_tgt, pd.n_corr, &J.prm, &r, true);
+            if (rc1 == QTR_OK || rc1 == QTR_ERR_CLIQUE_TOO_SMALL) {
+              const int rc2 = copy_out_lists(h, s, &r, pd.clique, nullptr, pd.final_inliers, pd.cap, J.mem);
+              if (rc2 != QTR_OK) r.status = rc1 = rc2;
+            }
+          } else {
+            r.status = rc1;
+          }
+        } else {
+          rc1 = register_pair_impl(h, s, (const float*)ln.raw_s[g], ln.Ps[g], (const float*)ln.raw_t[g], ln.Pt[g], &f1, &J.prm,
+                                   &r, pd.clique, pd.final_inliers, pd.cap, QTR_MEM_DEVICE, J.mem, cs, ct,
+                                   given ? pd.n_corr : -1);
+        }
         if (rc1 == QTR_ERR_HIP) return rc1;
         J.finished[ln.first_pair + g] = 1;
         ++J.done;
         continue;
       }
-      QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, L, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail
-      ln.L[g] = L;
-      s.last_L = L;
-      s.sb.mail_seq = ++s.seq;
+      QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, Lm, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail
+      if (given) {
+        if (J.mem == QTR_MEM_HOST) {  // behind the matching chain on the lane's stream: the matched clouds are not needed
+          if (pd.n_corr > 0) {
+            QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, pd.src_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, lead.stream));
+            QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, pd.tgt_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, lead.stream));
+          }
+          ln.csrc[g] = s.m_src;
+          ln.ctgt[g] = s.m_tgt;
+        } else {
+          ln.csrc[g] = (const float4*)pd.src_corr4;
+          ln.ctgt[g] = (const float4*)pd.tgt_corr4;
+        }
+        ln.L[g] = pd.n_corr;
+      } else {
+        ln.csrc[g] = s.m_src;
+        ln.ctgt[g] = s.m_tgt;
+        ln.L[g] = Lm;
+      }
       keep.push_back(g);
-      SB.push_back(&s.sb);
-      srcs.push_back(s.m_src);
-      tgts.push_back(s.m_tgt);
-      Ls.push_back(L);
     }
-    ln.active.swap(keep);
-    if (ln.active.empty()) return lane_start_chunk(h, ln);
-    QTR_HIP_TRY(h, solver_enqueue_group(SB.data(), (int)SB.size(), srcs.data(), tgts.data(), Ls.data(), J.prm, &ln.stage,
-                                        lead.stream));
-    ln.phase = 3;
-    return QTR_OK;
+    return lane_enqueue_solver(h, ln, keep);
   }
   // phase 3
   for (int g : ln.active) {
@@ -1833,6 +2036,7 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     qtr_result& r = J.results[pair];
     const qtr_pair_desc& pd = J.pairs[pair];
     const int L = ln.L[g];
+    const float4 *c_src = ln.csrc[g], *c_tgt = ln.ctgt[g];
     int rc = QTR_OK;
     // Follow-up work of ONE pair of the group runs on the lane's stream (the lane's chain owns the slot's arenas), and
     // everything that waits for it — wait_mail's liveness check, exact_phase's enqueues — must look at THAT stream:
@@ -1845,18 +2049,18 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     } on_lane_stream(s, lead.stream);
     if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
       s.sb.mail_seq = ++s.seq;
-      QTR_HIP_TRY(h, solver_continue(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128));
+      QTR_HIP_TRY(h, solver_continue(s.sb, c_src, c_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128));
       QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
     }
     if (L > 0 && J.prm.inlier_selection_mode == QTR_INLIER_PMC_EXACT) {
       SolverState hs;
       memcpy(&hs, s.mail + MAIL_SOLVER + 64, sizeof(hs));
       bool improved = false;
-      rc = exact_phase(h, s, L, hs, &improved);
+      rc = exact_phase(h, s, L, hs, &improved, J.prm.max_clique_time_limit);
       if (rc != QTR_OK) return rc;
       if (improved) {
         s.sb.mail_seq = ++s.seq;
-        QTR_HIP_TRY(h, solver_refinalize(s.sb, s.m_src, s.m_tgt, L, J.prm, lead.stream));
+        QTR_HIP_TRY(h, solver_refinalize(s.sb, c_src, c_tgt, L, J.prm, lead.stream));
         QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
       }
     }

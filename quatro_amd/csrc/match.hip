@@ -1125,7 +1125,9 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
 // Multi-workgroup compactions of the matcher's tail (k_cross_multi, k_pairs_multi): every workgroup publishes the number
 // of entries it keeps in its own word (count + 1; k_match_init zeroes the words) and reads its predecessors' words as
 // they appear — device-scope relaxed atomics, no chain: a workgroup only ever waits for counts, which every workgroup
-// publishes before it waits for anything, and workgroups are dispatched in index order.
+// publishes before it waits for anything, and workgroups are dispatched in index order.  Returns the number of entries
+// in front of workgroup w, or -1 when a predecessor's word never appeared (bounded wait): the caller then writes NOTHING
+// (its offsets would be wrong) and the failure travels to the host in the counters (MC_TAILERR -> MC_NCORR = -1).
 __device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* s_red /* [5] LDS */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) __hip_atomic_store(words + w, total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1137,13 +1139,15 @@ __device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* 
       if (v != 0) break;
       __builtin_amdgcn_s_sleep(2);
     }
+    if (v == 0) sum -= (1 << 28);  // (counts stay far below 2^26: one missing word makes the total negative)
     sum += max(v - 1, 0);
   }
   sum = wave_sum_i32(sum);
   __syncthreads();  // (s_red may still be read from an earlier use)
   if (lane == 0) s_red[wave] = sum;
   __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  const int before = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  return before < 0 ? -1 : before;
 }
 
 template <bool EXT>
@@ -1728,6 +1732,13 @@ __global__ __launch_bounds__(256) void k_cross_multi(ViewExt<MatchView> x, Match
     total += s_w[q];
   }
   const int before = tail_lookback(V.scan, w, total, s_red);
+  if (before < 0) {  // look-back timed out: no writes at unknown offsets; the next kernel reports the failure
+    if (tid == 0) {
+      V.mcounts[MC_TAILERR] = 1;
+      if (w == nwg - 1) V.mcounts[MC_NCROSS] = 0;
+    }
+    return;
+  }
   run += before;
 #pragma unroll
   for (int k = 0; k < 2; ++k)
@@ -1796,16 +1807,18 @@ __global__ __launch_bounds__(256) void k_pairs_multi(ViewExt<MatchView> x, Match
     total += s_w[q];
   }
   const int before = tail_lookback(V.scan + TAIL_MAXWG, w, total, s_red);
+  const bool tail_err = before < 0 || V.mcounts[MC_TAILERR] != 0;  // (this look-back or k_cross_multi's timed out)
   run += before;
   // the counters go to the host as soon as they are known: it enqueues the solver's launches (stream-ordered behind this
-  // kernel) while the lists are still being written
+  // kernel) while the lists are still being written.  A failed look-back reports -1 correspondences: QTR_ERR_HIP.
   if (w == nwg - 1) {
-    if (V.mail && tid < 48) match_mail(V, tid, before + total, s_ntuple);
+    if (V.mail && tid < 48) match_mail(V, tid, tail_err ? -1 : before + total, s_ntuple);
     if (tid == 0) {
-      V.mcounts[MC_NCORR] = before + total;
+      V.mcounts[MC_NCORR] = tail_err ? -1 : before + total;
       V.mcounts[MC_NTUPLE] = s_ntuple;
     }
   }
+  if (tail_err) return;
 #pragma unroll
   for (int k = 0; k < 2; ++k)
     if (tt[k] >= 0) {

@@ -71,6 +71,9 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
                           hipStream_t stream, int* pinned_state, hipEvent_t ev_graph, hipEvent_t ev_clique,
                           bool reset_done = false);
 hipError_t solver_reset_enqueue(const SolverBufs& B, hipStream_t stream);
+// how many back-end launch chains may run side by side on the device with the calling thread's next enqueue (1: it has
+// the device to itself): bounds k_hcore_async's resident workgroups per pair (thread-local, see solver.hip)
+void solver_set_hca_share(int share);
 hipError_t solver_init_attributes();
 // the same for G pairs at once (qtr_submit_batch): B[g] is pair g's arena, views go through `stage`
 hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,

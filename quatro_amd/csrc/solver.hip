@@ -540,6 +540,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   const int L = V.L, W = V.W;
   if (L <= 0) return;
   const int NWG = gridDim.x, w = blockIdx.x;
+  const unsigned long long t_start = wall_clock64();
   const int R = (L + NWG - 1) / NWG, Rp = (R + 3) & ~3;
   const int r_lo = min(L, w * R), r_hi = min(L, r_lo + R), nown = r_hi - r_lo;
   const u64* __restrict__ bm = V.bm;
@@ -784,10 +785,14 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
       const unsigned d1 = tid < NWG ? hca_load_u32(done + tid) : E0 + 1u;
       if (wg_any(v1 != v0)) verdict = 1;
       else if (!wg_any(d1 != E0 + 1u)) verdict = 2;
-      // (bounded: if the workgroups of this pair are not all resident — a device with fewer usable compute units than
-      // it reports — the wait gives up after a few seconds and the peeling kernel runs)
-      else if (polls > (1u << 21)) verdict = 3;
-      else __builtin_amdgcn_s_sleep(16);
+      // Bounded by the 100 MHz wall clock: a workgroup whose version is still 0 has not finished its set-up — 2 ms after
+      // my own start that means it is not RESIDENT (launches sharing the device beyond what the host planned for, a
+      // device with fewer usable compute units than it reports), and it may be waiting for the unit I occupy: give up,
+      // the peeling workgroup runs instead.  Whatever else keeps the verdict away: 250 ms.
+      else if ((polls & 15) == 15) {
+        const unsigned long long waited = wall_clock64() - t_start;  // (per thread: the vote makes the decision uniform)
+        if (wg_any(waited > 25000000ull || (waited > 200000ull && tid < NWG && v1 == 0u))) verdict = 3;
+      } else __builtin_amdgcn_s_sleep(16);
     }
     v0_valid = false;
     if (verdict == 2) finished = true;
@@ -2616,6 +2621,15 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
       hipLaunchKernelGGL((kern<false, T>), grid, block, lds, st, (ViewExt<SolverView>{nullptr, {0, 0, 0}}), (a).one); \
   } while (0)
 
+// k_hcore_async's workgroups wait for one another, so all workgroups of a pair have to be resident together.  A launch
+// that has the device to itself may use every compute unit; `share` launches that may run side by side (the lanes of a
+// batch, the slots of a handle driven from several threads) each take at most 1 / share of them: with in-order dispatch
+// inside a launch at most ONE pair per launch is partly resident at any time, so share x nwg <= compute units means some
+// pair is always complete and makes progress.  (If the promise is broken — another process on the device — the kernel's
+// own residency timeout sends the pair to the peeling workgroup: slower, never wrong.)
+static thread_local int t_hca_share = 1;
+void solver_set_hca_share(int share) { t_hca_share = share < 1 ? 1 : share; }
+
 // workgroups of k_hcore_async that are certainly co-resident: one per compute unit
 static int hca_max_workgroups() {
   static int n = [] {
@@ -2813,6 +2827,7 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         // one resident workgroup per compute unit at most (they wait for one another); a group of pairs shares the device
         int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
         if (G > 1) nwg = max(8, min(nwg, hca_max_workgroups() / min(G, 4)));
+        nwg = max(1, min(nwg, hca_max_workgroups() / t_hca_share));
         const int Lp = (L + 63) & ~63, R = (L + nwg - 1) / nwg;
         const int Rp = (R + 3) & ~3;
         const size_t fixed = (size_t)2 * Lp + (size_t)4 * (Rp + 4) + (size_t)4 * Rp;

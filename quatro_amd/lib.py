@@ -36,7 +36,7 @@ class Params(C.Structure):
         ("cote_noise_bound", C.c_double), ("ryrx", C.c_double * 9),
         ("rotation_max_iterations", C.c_int), ("inlier_selection_mode", C.c_int), ("cote_median", C.c_int),
         ("using_rot_inliers_when_estimating_cote", C.c_int), ("using_pre_estimated_ryrx", C.c_int),
-        ("reg_mode", C.c_int),
+        ("reg_mode", C.c_int), ("max_clique_time_limit", C.c_double),
     ]
 
 
@@ -57,7 +57,8 @@ class Result(C.Structure):
 
 class PairDesc(C.Structure):
     _fields_ = [("src_raw4", C.c_void_p), ("n_src", C.c_int), ("tgt_raw4", C.c_void_p), ("n_tgt", C.c_int),
-                ("seed", C.c_ulonglong), ("clique", C.c_void_p), ("final_inliers", C.c_void_p), ("cap", C.c_int)]
+                ("seed", C.c_ulonglong), ("clique", C.c_void_p), ("final_inliers", C.c_void_p), ("cap", C.c_int),
+                ("src_corr4", C.c_void_p), ("tgt_corr4", C.c_void_p), ("n_corr", C.c_int)]
 
 
 class StageTimes(C.Structure):
@@ -85,7 +86,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_set_clique_time_limit", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -189,7 +190,7 @@ def load():
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_set_nn_event_stride.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
-    lib.qtr_max_clique.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+    lib.qtr_max_clique.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     lib.qtr_compute_tims.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.qtr_scale_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_double, C.c_double,
@@ -202,8 +203,6 @@ def load():
                                       C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
     lib.qtr_cote_estimate_ranges.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
-    lib.qtr_set_clique_time_limit.argtypes = [C.c_void_p, C.c_double]
-    lib.qtr_set_clique_time_limit.restype = None
     lib.qtr_exact_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
     lib.qtr_read_kitti_bin.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     lib.qtr_write_pcd_xyz.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
@@ -300,6 +299,7 @@ class Handle:
                 self._h = C.c_void_p()
             raise QuatroHipError(rc, msg)
         self.limits = lim
+        self._time_limit = 3600.0  # MaxCliqueSolver::Params::time_limit default (reference include/teaser/graph.h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -370,19 +370,22 @@ class Handle:
         self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
         return _result_dict(res, cl, rot, fin)
 
-    def max_clique(self, bitmap, mode: int = 1, kcore_thr: float = 0.5, slot: int = 0):
+    def max_clique(self, bitmap, mode: int = 1, kcore_thr: float = 0.5, slot: int = 0, time_limit=None):
         """teaser::MaxCliqueSolver::findMaxClique on a bit-matrix graph [L][ceil(L/64)] uint64 -> (ids, max_core)."""
         bitmap = np.ascontiguousarray(bitmap, dtype=np.uint64)
         L = bitmap.shape[0]
         assert bitmap.ndim == 2 and (L == 0 or bitmap.shape[1] == (L + 63) // 64)
         cl = np.zeros(max(L, 1), dtype=np.int32)
         n, mcore = C.c_int(), C.c_int()
-        self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, cl.ctypes.data,
+        tl = self._time_limit if time_limit is None else float(time_limit)
+        self._check(self._lib.qtr_max_clique(self._h, slot, bitmap.ctypes.data, L, mode, kcore_thr, tl, cl.ctypes.data,
                                              cl.size, C.byref(n), C.byref(mcore), MEM_HOST))
         return cl[: n.value].copy(), mcore.value
 
     def set_clique_time_limit(self, seconds: float):
-        self._lib.qtr_set_clique_time_limit(self._h, float(seconds))
+        """default MaxCliqueSolver::Params::time_limit of this wrapper's max_clique() calls (the C ABI takes the limit per
+        call: qtr_max_clique's time_limit, qtr_params.max_clique_time_limit)"""
+        self._time_limit = float(seconds)
 
     def exact_stats(self, slot: int = 0):
         n, a = C.c_ulonglong(), C.c_int()
@@ -531,8 +534,10 @@ class Handle:
 
     # ---- batched registration (qtr_submit_batch / qtr_wait): every slot of the handle is used
     def register_batch(self, pairs, fp: FrontendParams | None = None, params: Params | None = None, want_lists=True):
-        """pairs: sequence of (src [n,4] float32, tgt [m,4] float32, seed).  Returns one result dict per pair, in
-        order — the same dicts register_pair returns."""
+        """pairs: sequence of (src [n,4] float32, tgt [m,4] float32, seed) — or (src, tgt, seed, corr_src [L,4], corr_tgt
+        [L,4]) for a pair that brings pre-matched correspondences (qtr_pair_desc.src_corr4 / tgt_corr4): src = tgt = None
+        runs the back end alone on them, scans AND correspondences run the scans' front end and the back end on the given
+        correspondences.  Returns one result dict per pair, in order — the same dicts register_pair returns."""
         fp = fp or default_frontend_params()
         prm = params or demo_params()
         B = len(pairs)
@@ -540,18 +545,26 @@ class Handle:
         results = (Result * max(B, 1))()
         keep = []
         cap = int(self.limits.max_corr)
-        for i, (s_, t_, seed) in enumerate(pairs):
-            s_, t_ = _f4(s_), _f4(t_)
+        for i, item in enumerate(pairs):
+            s_, t_, seed = item[0], item[1], item[2]
+            cs_, ct_ = (item[3], item[4]) if len(item) > 3 else (None, None)
+            s_, t_ = (None if s_ is None else _f4(s_)), (None if t_ is None else _f4(t_))
+            cs_, ct_ = (None if cs_ is None else _f4(cs_)), (None if ct_ is None else _f4(ct_))
+            n_c = 0 if cs_ is None else cs_.shape[0]
+            if cs_ is not None and n_c == 0:  # (an empty array may have no address: "zero correspondences" needs pointers)
+                cs_, ct_ = np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32)
             cl = np.zeros(cap if want_lists else 1, dtype=np.int32)
             fin = np.zeros(cap if want_lists else 1, dtype=np.int32)
-            keep.append((s_, t_, cl, fin))
-            descs[i] = PairDesc(s_.ctypes.data, s_.shape[0], t_.ctypes.data, t_.shape[0], int(seed),
-                                cl.ctypes.data if want_lists else None, fin.ctypes.data if want_lists else None, cap)
+            keep.append((s_, t_, cl, fin, cs_, ct_))
+            descs[i] = PairDesc(None if s_ is None else s_.ctypes.data, 0 if s_ is None else s_.shape[0],
+                                None if t_ is None else t_.ctypes.data, 0 if t_ is None else t_.shape[0], int(seed),
+                                cl.ctypes.data if want_lists else None, fin.ctypes.data if want_lists else None, cap,
+                                None if cs_ is None else cs_.ctypes.data, None if ct_ is None else ct_.ctypes.data, n_c)
         self._check(self._lib.qtr_submit_batch(self._h, descs, B, C.byref(fp), C.byref(prm), results, MEM_HOST))
         self._check(self._lib.qtr_wait(self._h))
         out = []
         for i in range(B):
-            _, _, cl, fin = keep[i]
+            cl, fin = keep[i][2], keep[i][3]
             r = results[i]
             if want_lists and r.status in (QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL):
                 out.append(_result_dict(r, cl, None, fin))
@@ -570,20 +583,27 @@ class Handle:
         self._pre = (pw or pw_params(), ip or ip_params())
         self._check(self._lib.qtr_set_batch_preprocess(self._h, C.byref(self._pre[0]), C.byref(self._pre[1])))
 
-    def register_batch_dev(self, items, prm: Params, fp: FrontendParams | None = None):
-        """items: dicts with device tensors "src" / "tgt" and a FrontendParams "fp" (its seed is the pair's seed).
-        Inputs stay in HBM; only the result records come back.  Returns a list of dicts (status, valid, T, sizes)."""
+    def register_batch_dev(self, items, prm: Params, fp: FrontendParams | None = None, scans: bool = True,
+                           corr: bool = False):
+        """items: dicts with device tensors "src" / "tgt" and a FrontendParams "fp" (its seed is the pair's seed), and —
+        with corr=True — the pre-matched correspondences "cs" / "ct" the back end runs on (scans=False: the back end
+        alone).  Inputs stay in HBM; only the result records come back.  Returns a list of dicts (status, valid, T,
+        sizes)."""
         fp = fp or default_frontend_params()
         B = len(items)
         descs = (PairDesc * max(B, 1))()
         results = (Result * max(B, 1))()
         for i, it in enumerate(items):
-            descs[i] = PairDesc(it["src"].data_ptr(), it["src"].shape[0], it["tgt"].data_ptr(), it["tgt"].shape[0],
-                                int(it["fp"].seed), None, None, 0)
+            descs[i] = PairDesc(it["src"].data_ptr() if scans else None, it["src"].shape[0] if scans else 0,
+                                it["tgt"].data_ptr() if scans else None, it["tgt"].shape[0] if scans else 0,
+                                int(it["fp"].seed), None, None, 0,
+                                it["cs"].data_ptr() if corr else None, it["ct"].data_ptr() if corr else None,
+                                it["cs"].shape[0] if corr else 0)
         self._check(self._lib.qtr_submit_batch(self._h, descs, B, C.byref(fp), C.byref(prm), results, MEM_DEVICE))
         self._check(self._lib.qtr_wait(self._h))
         return [{"status": r.status, "valid": bool(r.valid), "T": np.array(r.T[:]).reshape(4, 4), "cost": r.cost,
-                 "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr, "n_clique": r.n_clique, "n_final": r.n_final}
+                 "n_src": r.n_src, "n_tgt": r.n_tgt, "L": r.n_corr, "n_clique": r.n_clique, "n_final": r.n_final,
+                 "n_rot_inliers": r.n_rot_inliers, "gnc_iters": r.gnc_iters}
                 for r in results[:B]]
 
     # ---- multi-GPU: RCCL all-gather of the result records through the C ABI (one handle = one rank)

@@ -30,6 +30,17 @@ def test_library_exports_every_declared_symbol(libpath):
     assert set(ql.EXPORTS) == set(declared)
 
 
+def test_dynamic_symbol_table_is_exactly_the_declared_c_abi(libpath):
+    """-fvisibility=hidden + the linker version script (csrc/exports.map): the library's dynamic symbol table holds the
+    entry points of include/quatro_hip.h and nothing else — no mangled internals, kernel handles or device stubs."""
+    hdr = open(os.path.join(ROOT, "include", "quatro_hip.h")).read()
+    declared = set(re.findall(r"^QTR_API [^\n(]*?\b(qtr_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(re.findall(r"\b(qtr_[a-z_0-9]+)\s*\(", hdr)), "an entry point without QTR_API"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+
+
 def test_struct_layouts_match_header(libpath):
     """ctypes mirrors must have the C sizes (checked by compiling a tiny C program against the header)."""
     src = r'''

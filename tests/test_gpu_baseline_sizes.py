@@ -356,3 +356,205 @@ def test_batch_on_raw_sweeps_runs_the_demo_sequence(qo16):
         assert (g["n_src"], g["n_tgt"], g["L"]) == (o["n_src"], o["n_tgt"], o["L"]), i
         _same(g, o)
     assert plain[0]["n_src"] != got[0]["n_src"]
+
+
+# ------------------------------------------------------------------------------------------------
+# batched entry on pre-matched correspondences (qtr_pair_desc.src_corr4 / tgt_corr4 / n_corr): the reference's loop is one
+# Quatro object, reset(), setInputSource / setInputTarget / computeTransformation on whatever it is handed
+# (examples/run_global_registration.cpp:97-108,243-246; include/quatro.hpp:769)
+def _same_back_end(g, r):
+    assert g["status"] == r["status"] and g["valid"] == r["valid"]
+    assert g["L"] == r["L"]
+    assert np.array_equal(g["clique"], r["clique"]) and np.array_equal(g["final_inliers"], r["final_inliers"])
+    assert np.array_equal(g["T"], r["T"]) or not r["valid"]
+
+
+def test_batch_of_composite_pairs_at_the_metrics_size_against_sequential_calls_and_oracle(qo16, pool16k):
+    """BASELINE configs[2] in the unit of work the metric is quoted on: every pair id = the front end of a 16-18 k-voxel
+    scan pair AND the back end on 5000 given correspondences (5 % planted inliers).  64 ids through qtr_submit_batch /
+    qtr_wait against (a) sequential qtr_feature_pair + qtr_solve and (b) the ORACLE's solve on the same correspondences."""
+    LC = 5000
+    corr = [synth.correspondences(LC, 0.05, seed=k, noise=0.1) for k in range(8)]
+    ids = list(range(64))
+    h1 = ql.Handle(0, **LIMITS)
+    try:
+        seq_front = [h1.feature_pair(s, t, ql.default_frontend_params(seed=0)) for (s, t, _) in pool16k]
+        seq_back = [h1.solve(c[0], c[1]) for c in corr]
+    finally:
+        h1.close()
+    ora = [qo16.solve(c[0], c[1]) for c in corr]
+    hb = ql.Handle(0, n_slots=16, **LIMITS)
+    try:
+        got = hb.register_batch([(pool16k[i % 4][0], pool16k[i % 4][1], 0, corr[i % 8][0], corr[i % 8][1]) for i in ids])
+    finally:
+        hb.close()
+    for i, g in zip(ids, got):
+        f, b, o = seq_front[i % 4], seq_back[i % 8], ora[i % 8]
+        assert (g["n_src"], g["n_tgt"], g["L"]) == (f["n_src"], f["n_tgt"], LC), i
+        _same_back_end(g, dict(b, L=LC))
+        _same(g, o)
+        assert g["valid"] and np.intersect1d(g["final_inliers"], corr[i % 8][3]).size >= 0.9 * corr[i % 8][3].size
+
+
+def test_batch_of_correspondence_only_pairs_of_mixed_sizes_against_sequential_calls_and_oracle(qo16):
+    """Pair descriptors without scans: the back end alone, batched.  One lane group mixing L = 0, 3, 100, 1281 (the lower
+    end of the h-index kernel), 2000, 5000 and 8000 — kernel variants are picked from the LARGEST pair of a group —
+    against sequential qtr_solve calls and the oracle; PMC_HEU and KCORE_HEU."""
+    sizes = [5000, 100, 0, 1281, 8000, 3, 2000, 5000, 640, 1279]
+    sets = []
+    for k, L in enumerate(sizes):
+        if L == 0:
+            z = np.zeros((0, 4), dtype=np.float32)
+            sets.append((z, z.copy()))
+        else:
+            c = synth.correspondences(max(L, 3), 0.06 if L >= 100 else 1.0, seed=40 + k, noise=0.1)
+            sets.append((c[0][:L], c[1][:L]))
+    h1 = ql.Handle(0, **LIMITS)
+    hb = ql.Handle(0, n_slots=24, **LIMITS)   # two lanes of 12: the ten pairs share one lane group
+    try:
+        for mode in (ql.INLIER_PMC_HEU, ql.INLIER_KCORE_HEU):
+            prm = ql.demo_params(inlier_selection_mode=mode)
+            seq = [h1.solve(s, t, prm) for (s, t) in sets]
+            got = hb.register_batch([(None, None, 0, s, t) for (s, t) in sets], params=prm)
+            for i, (g, r) in enumerate(zip(got, seq)):
+                assert (g["n_src"], g["n_tgt"]) == (0, 0)
+                _same_back_end(g, dict(r, L=sizes[i]))
+            if mode == ql.INLIER_PMC_HEU:
+                for i in (0, 3, 4, 6):
+                    _same(got[i], qo16.solve(*sets[i]))
+    finally:
+        h1.close()
+        hb.close()
+
+
+def test_batch_mixing_the_three_kinds_of_pairs_and_per_pair_failures(qo16):
+    """One batch holding scan-only pairs (the matcher's own correspondences), correspondence-only pairs and pairs with
+    both, plus descriptors the entry has to refuse pair by pair: each record equals the matching sequential call, the
+    failures carry their own status and the rest of the batch is unaffected.  Host memory (the staging copies)."""
+    s9, t9, _ = synth.kitti64_pair(1)
+    c1 = synth.correspondences(1500, 0.1, seed=3, noise=0.1)
+    c2 = synth.correspondences(400, 0.2, seed=4, noise=0.1)
+    too_many = synth.correspondences(9000, 0.05, seed=5, noise=0.1)
+    pairs = [(s9, t9, 7), (None, None, 0, c1[0], c1[1]), (s9, t9, 7, c2[0], c2[1]), (None, None, 0, too_many[0], too_many[1]),
+             (s9, t9, 8), (s9, t9, 7, c1[0], c1[1]), (None, None, 0, c2[0], c2[1])]
+    h1 = ql.Handle(0, **LIMITS)
+    hb = ql.Handle(0, n_slots=4, **LIMITS)    # two lanes of 2: several chunks, both lanes
+    try:
+        whole7 = h1.register_pair(s9, t9, ql.default_frontend_params(seed=7))
+        whole8 = h1.register_pair(s9, t9, ql.default_frontend_params(seed=8))
+        b1, b2 = h1.solve(c1[0], c1[1]), h1.solve(c2[0], c2[1])
+        got = hb.register_batch(pairs)
+        assert got[3]["status"] == ql.QTR_ERR_CAPACITY
+        for g, r in ((got[0], whole7), (got[4], whole8)):
+            assert (g["n_src"], g["n_tgt"], g["L"]) == (r["n_src"], r["n_tgt"], r["L"])
+            _same_back_end(g, r)
+        for g, r, L in ((got[1], b1, 1500), (got[6], b2, 400)):
+            assert (g["n_src"], g["n_tgt"]) == (0, 0)
+            _same_back_end(g, dict(r, L=L))
+        for g, r, L in ((got[2], b2, 400), (got[5], b1, 1500)):
+            assert (g["n_src"], g["n_tgt"]) == (whole7["n_src"], whole7["n_tgt"])
+            _same_back_end(g, dict(r, L=L))
+        _same(got[1], qo16.solve(c1[0], c1[1]))
+        # descriptors with half a correspondence set, or nothing at all: QTR_ERR_BAD_ARG in the pair's own record
+        import ctypes as C
+        descs = (ql.PairDesc * 3)()
+        res = (ql.Result * 3)()
+        a, b = np.ascontiguousarray(c2[0]), np.ascontiguousarray(c2[1])
+        descs[0] = ql.PairDesc(None, 0, None, 0, 0, None, None, 0, a.ctypes.data, None, 400)
+        descs[1] = ql.PairDesc(None, 0, None, 0, 0, None, None, 0, None, None, 0)
+        descs[2] = ql.PairDesc(None, 0, None, 0, 0, None, None, 0, a.ctypes.data, b.ctypes.data, 400)
+        fp, prm = ql.default_frontend_params(), ql.demo_params()
+        assert hb._lib.qtr_submit_batch(hb._h, descs, 3, C.byref(fp), C.byref(prm), res, ql.MEM_HOST) == ql.QTR_OK
+        assert hb._lib.qtr_wait(hb._h) == ql.QTR_OK
+        assert [res[i].status for i in range(3)] == [ql.QTR_ERR_BAD_ARG, ql.QTR_ERR_BAD_ARG, ql.QTR_OK]
+        assert res[2].n_clique == b2["clique"].size and res[2].n_corr == 400
+    finally:
+        h1.close()
+        hb.close()
+
+
+def test_batch_on_device_resident_scans_and_correspondences(pool16k):
+    """The same through QTR_MEM_DEVICE (what bench.py's batch256 leg runs): torch tensors in HBM, nothing staged."""
+    import torch
+    dev = torch.device("cuda", 0)
+    items = []
+    for k in range(6):
+        s, t, _ = pool16k[k % 4]
+        c = synth.correspondences(5000, 0.05, seed=k, noise=0.1)
+        items.append({"src": torch.from_numpy(s).to(dev), "tgt": torch.from_numpy(t).to(dev),
+                      "fp": ql.default_frontend_params(seed=k), "cs": torch.from_numpy(c[0]).to(dev),
+                      "ct": torch.from_numpy(c[1]).to(dev), "host": c})
+    torch.cuda.synchronize()
+    h1 = ql.Handle(0, **LIMITS)
+    hb = ql.Handle(0, n_slots=8, **LIMITS)
+    try:
+        prm = ql.demo_params()
+        seq = [h1.solve(it["host"][0], it["host"][1], prm) for it in items]
+        for kw in (dict(scans=True, corr=True), dict(scans=False, corr=True)):
+            got = hb.register_batch_dev(items, prm, **kw)
+            for g, r in zip(got, seq):
+                assert g["status"] == r["status"] and g["L"] == 5000 and g["n_clique"] == r["clique"].size
+                assert g["n_final"] == r["final_inliers"].size and np.array_equal(g["T"], r["T"])
+                assert (g["n_src"] > 15000) == kw["scans"]
+    finally:
+        h1.close()
+        hb.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# data-connected registrations with L in the thousands: the matcher's OWN output feeds the back end
+def _oracle_connected(qo, s, t, leaf, crosscheck, tuple_test, seed):
+    vs, vt = qo.voxelize(s, leaf), qo.voxelize(t, leaf)
+    ds, dt = qo.fpfh(vs, 0.5, 0.75)[2], qo.fpfh(vt, 0.5, 0.75)[2]
+    corr = qo.match(vs, ds, vt, dt, crosscheck, tuple_test, 0.95, seed)
+    return vs, vt, corr, qo.solve(vs[corr[:, 0]], vt[corr[:, 1]])
+
+
+@pytest.mark.parametrize("crosscheck,lo,hi", [(1, 1200, 6000), (0, 12000, 32768)])
+def test_connected_registration_without_tuple_test_on_the_bench_pool_matches_oracle(qo16, pool16k, crosscheck, lo, hi):
+    """qtr_register_pair on a 16-18 k-voxel pair with use_tuple_test = 0 (mutual nearest neighbours: L ~ 2 k,
+    feature_matcher.cc:187-247 skipped) and with use_crosscheck = 0 as well (corres_ij + corres_ji de-duplicated,
+    :124-181: L ~ n_s + n_hit ~ 20 k): ONE registration whose back end runs on thousands of the matcher's own
+    correspondences, against the oracle's stages composed the same way."""
+    s, t, _ = pool16k[0]
+    h = ql.Handle(0, max_points=131072, max_voxels=32768, max_corr=32768)
+    try:
+        fp = ql.default_frontend_params(use_crosscheck=crosscheck, use_tuple_test=0, seed=0)
+        g = h.register_pair(s, t, fp)
+    finally:
+        h.close()
+    vs, vt, corr, o = _oracle_connected(qo16, s, t, 0.3, bool(crosscheck), False, 0)
+    assert lo < corr.shape[0] < hi, corr.shape
+    assert (g["n_src"], g["n_tgt"], g["L"]) == (vs.shape[0], vt.shape[0], corr.shape[0])
+    _same(g, o)
+
+
+def test_dense_mode_end_to_end_through_the_whole_path_entry_matches_oracle(qo16):
+    """BASELINE configs[4] as ONE registration: two independently sampled 50 000-point clouds and a leaf so small that the
+    voxel grid would overflow int32 — pcl::VoxelGrid passes the cloud through unchanged, and so does the reference's
+    `voxelize` (include/quatro.hpp:49-68) — then FPFH, matching (its own ~1.1 k correspondences) and the back end.
+    Per pair and through the batched entry, against the oracle's stages."""
+    a, b, T = synth.dense_pair(50000)
+    lim = dict(max_points=65536, max_voxels=65536, max_corr=24576)
+    fp = ql.default_frontend_params(voxel_size=0.001, seed=1)
+    h = ql.Handle(0, **lim)
+    try:
+        g = h.register_pair(a, b, fp)
+    finally:
+        h.close()
+    assert (g["n_src"], g["n_tgt"]) == (50000, 50000) and g["L"] > 500
+    assert np.array_equal(qo16.voxelize(a, 0.001), a)          # the oracle's voxel grid passes through too
+    ds, dt = qo16.fpfh(a, 0.5, 0.75)[2], qo16.fpfh(b, 0.5, 0.75)[2]
+    corr = qo16.match(a, ds, b, dt, True, True, 0.95, 1)
+    assert corr.shape[0] == g["L"]
+    o = qo16.solve(a[corr[:, 0]], b[corr[:, 1]])
+    _same(g, o)
+    assert g["valid"] and abs(_yaw(g["T"]) - _yaw(T)) < 2e-2 and np.abs(g["T"][:3, 3] - T[:3, 3]).max() < 0.3
+    hb = ql.Handle(0, n_slots=2, **lim)
+    try:
+        gb = hb.register_batch([(a, b, 1), (a[:30000], b[:30000], 1)], fp)
+    finally:
+        hb.close()
+    assert (gb[0]["n_src"], gb[0]["n_tgt"], gb[0]["L"]) == (50000, 50000, g["L"])
+    assert np.array_equal(gb[0]["clique"], g["clique"]) and np.array_equal(gb[0]["T"], g["T"])
+    assert (gb[1]["n_src"], gb[1]["n_tgt"]) == (30000, 30000)
