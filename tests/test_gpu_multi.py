@@ -1,7 +1,7 @@
 """The library's OWN multi-process path (qtr_comm_unique_id / qtr_comm_init / qtr_gather_results[_v], include/quatro_hip.h
 "Multi-GPU") with more than one rank — SURVEY section 8(e), BASELINE configs[3]:
   * on a box with >= 2 GPUs: one process per GPU over real RCCL;
-  * on a 1-GPU box: three processes sharing the GPU over a transport double (tests/cpp/mock_rccl.cpp, selected with
+  * on a 1-GPU box: three processes sharing the GPU over a transport double (tests/mock/mock_rccl.cpp, selected with
     QTR_RCCL_LIB; real RCCL refuses two ranks on one device) — everything of the library's path except RCCL itself:
     the count exchange, blocks of different lengths padded and trimmed, the rank-uniform early-outs, and a sharded batch
     of composite pairs whose gathered records equal a single-process run.
@@ -77,6 +77,6 @@ def test_library_gather_over_real_rccl_one_process_per_gpu(tmp_path):
 def test_library_gather_across_three_processes_sharing_one_gpu(tmp_path):
     so = os.path.join(str(tmp_path), "libmock_rccl.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-std=c++17", "--offload-arch=gfx950",
-                           os.path.join(ROOT, "tests", "cpp", "mock_rccl.cpp"), "-o", so, "-lrt"])
+                           os.path.join(ROOT, "tests", "mock", "mock_rccl.cpp"), "-o", so, "-lrt"])
     world = 3
     _check(world, _run_ranks(world, [0] * world, tmp_path, {"QTR_RCCL_LIB": so}))
