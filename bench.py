@@ -117,7 +117,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--nn-event-stride", type=int, default=5,
                     help="every n-th step of the timed region carries the nearest-neighbour launches' event pairs (1 = all)")
-    ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,segment,patchwork",
+    ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,cpp,segment,patchwork",
                     help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`); "
                          "`refdense` adds the reference's own back-end text at L = 20000 on the CPU (minutes, > 16 GB)")
     ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
@@ -313,6 +313,8 @@ def main() -> None:
         extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
     if "dense" in legs and rank == 0 and world == 1:
         extra.update(dense_legs(args, torch, ql, synth, prm, dev, local_rank))
+    if "cpp" in legs and composite and rank == 0 and world == 1:
+        extra["cpp_driver_leg"] = cpp_driver_leg(args, pool, LC)
     if "connected" in legs and rank == 0 and world == 1:
         extra["connected_leg"] = connected_leg(args, torch, ql, synth, pool, prm, dev, local_rank)
     seg = pwl = None
@@ -581,6 +583,41 @@ def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
     out["what"] = ("qtr_register_pair, one call per registration, the matcher's own correspondences into the back end "
                    "(no generator in between)")
     return out
+
+
+def cpp_driver_leg(args, pool, LC):
+    """The headline's composite step driven by a compiled caller (tests/bench_cpp/bench_step.cpp, built here with hipcc):
+    the same two C-ABI calls per step without the Python harness in between."""
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="qtr_cpp_")
+    try:
+        for k, p in enumerate(pool):
+            for name, arr in (("src", p["src_h"]), ("tgt", p["tgt_h"]), ("cs", p["cs_h"]), ("ct", p["ct_h"])):
+                np.ascontiguousarray(arr, dtype=np.float32).tofile(os.path.join(d, f"pair{k}_{name}.bin"))
+        exe = os.path.join(d, "bench_step")
+        libdir = os.path.join(ROOT, "quatro_amd")
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "--offload-arch=gfx950",
+                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "bench_cpp", "bench_step.cpp"),
+                               "-o", exe, "-L", libdir, "-lquatro_hip", "-Wl,-rpath," + libdir],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        n = max(args.steps, 40)
+        best = None
+        for _ in range(3):  # (three processes: the first pays the image's cold start)
+            o = subprocess.run([exe, d, str(len(pool)), str(n), str(max(args.warmup, 8))], capture_output=True, text=True,
+                               timeout=300)
+            if o.returncode != 0:
+                return {"error": (o.stderr or o.stdout)[-300:]}
+            j = json.loads(o.stdout.strip().splitlines()[-1])
+            if best is None or j["ms_per_step"] < best["ms_per_step"]:
+                best = j
+        best["runs"] = 3
+        return best
+    except Exception as e:  # a box without hipcc: the leg is informative only
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def solver_leg(args, torch, ql, synth, h, prm, dev, L):
