@@ -431,7 +431,7 @@ static int create_impl(qtr_handle* h) {
   // batch lanes: two groups of slots that alternate (one's kernels cover the other's host read-back)
   const int S = (int)h->slots.size();
   int NL = S >= 2 ? 2 : 1;
-  if (const char* e = getenv("QTR_BATCH_LANES")) {  // experiment knob: more, smaller groups in flight
+  if (const char* e = QTR_ENGINE_ENV("QTR_BATCH_LANES")) {  // experiment knob: more, smaller groups in flight
     const int v = atoi(e);
     if (v >= 1 && v <= 8 && v <= S) NL = v;
   }
@@ -1560,7 +1560,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     // FPFH chain's first launch arrives, so that chain goes first and the second stream's work after it; QTR_MEAN_FIRST=1
     // issues the means before the chain (one launch of delay for the chain, ~20 us of head start for the means — for
     // hosts slow enough that the second stream would otherwise finish last).
-    static const bool mean_first = getenv("QTR_MEAN_FIRST") != nullptr;
+    static const bool mean_first = QTR_ENGINE_ENV("QTR_MEAN_FIRST") != nullptr;
     if (mean_first) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));

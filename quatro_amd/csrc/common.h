@@ -1,6 +1,15 @@
 // common.h — shared declarations for the gfx950 kernels and the C-ABI implementation.
 // gfx950 only: wavefront = 64 lanes is hard-coded throughout.
 #pragma once
+// QTR_TEST_ENGINES (quatro_amd/build.py: libquatro_hip_testengines.so only): the comparison engines — all-exact and f32-MFMA
+// nearest-neighbour search, the one-workgroup matcher tails, the peeling / sweep core-number kernels, the quadratic
+// ranking — and the experiment knobs that select them through environment variables.  The product library is built
+// WITHOUT it: one path, nothing of the above instantiated, the variables not even read.
+#ifdef QTR_TEST_ENGINES
+#define QTR_ENGINE_ENV(name) getenv(name)
+#else
+#define QTR_ENGINE_ENV(name) ((const char*)nullptr)
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>

@@ -1766,7 +1766,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
   F.queryH_c = (uint4*)take((((size_t)max_voxels + 511) / 512 * 512) * 224 + 2 * 7168);
   F.recheck_q = (int*)take((size_t)max_voxels * 4);
   {
-    const char* e = getenv("QTR_NN_ENGINE");
+    const char* e = QTR_ENGINE_ENV("QTR_NN_ENGINE");
     F.nn_engine = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "mfma32") == 0) ? 1 : 2;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&

@@ -2001,6 +2001,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   if (!init_done) LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st);
   // K5: NN of every small-cloud descriptor in the large cloud, then of the HIT rows of the large cloud in the small
   // one (the reference asks the latter lazily, feature_matcher.cc:113-122; the mutual test only reads hit rows)
+#ifdef QTR_TEST_ENGINES
   if (nn_engine == 0) {
     auto nsplit = [](int nq, int nb) {
       int blocks_x = (nq + 255) / 256;
@@ -2020,36 +2021,50 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     if (ev && ev[2]) (void)hipEventRecord(ev[2], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, 1);
     if (ev && ev[3]) (void)hipEventRecord(ev[3], st);
-  } else {
+  } else
+#endif
+  {
+#ifdef QTR_TEST_ENGINES
     const bool f16 = nn_engine == 2;
+#else
+    (void)nn_engine;
+    constexpr bool f16 = true;
+#endif
     LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, f16 ? 0 : 2);
     if (f16) {  // operand tables with the duplicates hidden, straight from the descriptors
       LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
-    } else {  // the norm-bin order serves the span re-check (k_nn_exact_rows); the f16 engine's filter sweeps every tile
+    }
+#ifdef QTR_TEST_ENGINES
+    else {  // the norm-bin order serves the span re-check (k_nn_exact_rows); the f16 engine's filter sweeps every tile
       LAUNCH_MV(k_desc_dedup, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
       LAUNCH_MV(k_norm_bins, a, dim3(1, 2, G), dim3(1024), 0, st);
       LAUNCH_MV(k_norm_gather, a, dim3((max_large + 255) / 256, 2, G), B256, 0, st);
     }
+#endif
     // persistent workgroups: one per compute unit (two fit; the other lane's launch may be the second).
     // QTR_NN_WGS_PER_CU = 2 (experiment knob) launches both from this chain.
     static const int wgs_per_cu = [] {
-      const char* e = getenv("QTR_NN_WGS_PER_CU");
+      const char* e = QTR_ENGINE_ENV("QTR_NN_WGS_PER_CU");
       return (e && atoi(e) == 2) ? 2 : 1;
     }();
     const int X = n_cu * wgs_per_cu;
     // QTR_NN_EVENTS=record: bracket the launch with two hipEventRecord calls instead of attaching the events to it
     static const bool attach_events = [] {
-      const char* e = getenv("QTR_NN_EVENTS");
+      const char* e = QTR_ENGINE_ENV("QTR_NN_EVENTS");
       return !(e && strcmp(e, "record") == 0);
     }();
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0 && e1 && attach_events) {
         if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
+#ifdef QTR_TEST_ENGINES
         else LAUNCH_MV_EV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
+#endif
       } else {
         if (e0) (void)hipEventRecord(e0, st);
         if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+#ifdef QTR_TEST_ENGINES
         else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+#endif
         if (e1) (void)hipEventRecord(e1, st);
       }
       LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
@@ -2063,11 +2078,18 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       const int ey = G > 1 ? 4 : 16;
       int ex = 128;
       if (G > 1) ex = max(8, 384 / G);  // a group of pairs shares the device
+#ifdef QTR_TEST_ENGINES
       if (!f16) LAUNCH_MV(k_nn_exact_rows, a, dim3(ex, ey, G), B256, 0, st, dir);  // (the f16 engine's filter is complete)
+#else
+      (void)ex;
+      (void)ey;
+#endif
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, f16 ? 0 : 1);
+#ifdef QTR_TEST_ENGINES
     if (!f16) LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st, 1);  // (f16: the rows are read in place)
+#endif
     run_dir(1, max_large, max_small, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
   // K6 cross-check -> pairs in ascending i
@@ -2076,7 +2098,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   const bool fused16 = max_large <= 16384 && max_ns <= 16384;
   // the multi-workgroup compactions (QTR_MATCH_TAIL=single: the one-workgroup kernels of round 2, kept for comparison)
   static const bool tail_single = [] {
-    const char* e = getenv("QTR_MATCH_TAIL");
+    const char* e = QTR_ENGINE_ENV("QTR_MATCH_TAIL");
     return e && strcmp(e, "single") == 0;
   }();
   const bool tail_multi = fused_tail && !tail_single;
@@ -2089,8 +2111,13 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     const int lds_gather = ((size_t)max_large + (size_t)max_small) * 4 <= (size_t)CROSS_LDS_BYTES ? 1 : 0;
     const size_t cross_lds = (size_t)max_large * 4 + (lds_gather ? (size_t)max_small * 4 : 0);
     if (tail_multi) LAUNCH_MV(k_cross_multi, a, dim3((max_large + CM_ROWS - 1) / CM_ROWS, 1, G), B256, 0, st);
+#ifdef QTR_TEST_ENGINES
     else if (fused16) LAUNCH_MV_K(k_cross_fused, 16, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
     else LAUNCH_MV_K(k_cross_fused, 32, a, dim3(1, 1, G), dim3(1024), cross_lds, st, lds_gather);
+#else
+    (void)cross_lds;
+    (void)fused16;
+#endif
   } else {
     LAUNCH_MV(k_cross_flags2, a, dim3(grid_for(max_large), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_flags, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -2109,8 +2136,10 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     LAUNCH_MV(k_nc_emit, a, dim3(gs, 1, G), B256, 0, st);
   } else if (fused_tail) {
     if (tail_multi) LAUNCH_MV(k_pairs_multi, a, dim3(max(1, (max_ns + PM_SRC - 1) / PM_SRC), 1, G), B256, 0, st);
+#ifdef QTR_TEST_ENGINES
     else if (fused16) LAUNCH_MV_K(k_pairs_fused, 16, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
     else LAUNCH_MV_K(k_pairs_fused, 32, a, dim3(1, 1, G), dim3(1024), (size_t)max_ns * 4, st);
+#endif
   } else {
     LAUNCH_MV(k_scatter_pairs, a, dim3(grid_for(max_small), 1, G), B256, 0, st);
     LAUNCH_MV(k_scan_nonneg, a, dim3(1, 1, G), dim3(1024), 0, st);
@@ -2162,6 +2191,7 @@ hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_
 // CROSS_LDS_BYTES when both nearest-neighbour tables fit
 hipError_t match_init_attributes() {
   hipError_t e;
+#ifdef QTR_TEST_ENGINES  // (the one-workgroup tails: comparison engines)
   if ((e = hipFuncSetAttribute((const void*)k_cross_fused<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)k_cross_fused<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)k_cross_fused<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
@@ -2173,5 +2203,8 @@ hipError_t match_init_attributes() {
     return e;
   SET_LDS2(k_pairs_fused)
 #undef SET_LDS2
+#else
+  (void)e;
+#endif
   return hipSuccess;
 }

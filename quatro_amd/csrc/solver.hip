@@ -2651,7 +2651,9 @@ hipError_t solver_init_attributes() {
   if ((e = hipFuncSetAttribute((const void*)kern<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess)  \
     return e;
   SET_LDS(k_finalize, FIN_LDS_BYTES)
+#ifdef QTR_TEST_ENGINES
   SET_LDS(k_kcore, 156 * 1024)
+#endif
   SET_LDS(k_hcore_async, 156 * 1024)
   SET_LDS(k_rank_sort, 156 * 1024)
   SET_LDS(k_clique_first, CF_LDS_BYTES)
@@ -2765,21 +2767,21 @@ static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, h
 // which core-number path a graph of L vertices takes (QTR_KCORE=peel | sweeps: the older ones, kept for comparison)
 static bool kcore_peel_only() {
   static const bool v = [] {
-    const char* e = getenv("QTR_KCORE");
+    const char* e = QTR_ENGINE_ENV("QTR_KCORE");
     return e && strcmp(e, "peel") == 0;
   }();
   return v;
 }
 static bool kcore_sweeps() {
   static const bool v = [] {
-    const char* e = getenv("QTR_KCORE");
+    const char* e = QTR_ENGINE_ENV("QTR_KCORE");
     return e && strcmp(e, "sweeps") == 0;
   }();
   return v;
 }
 static int hcore_min_l() {  // (the control words sit in V.perm: L must exceed HCA_CTL_DONE + HCA_MAXWG = 1088 in any case)
   static const int v = [] {
-    const char* e = getenv("QTR_HCORE_MIN_L");
+    const char* e = QTR_ENGINE_ENV("QTR_HCORE_MIN_L");
     return max(1280, e ? atoi(e) : 1280);  // (measured, ms per solve, peel against this: 0.174 / 0.159 at L = 1500,
                                             // 0.213 / 0.174 at 2000, 0.259 / 0.199 at 2500, 0.304 / 0.200 at 3000)
   }();
@@ -2795,7 +2797,7 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
                                bool hcore_prepared, bool defer_last_scan) {
   int deferred = 0;
   const int W = (L + 63) / 64;
-  static const bool dbg_sync = getenv("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
+  static const bool dbg_sync = QTR_ENGINE_ENV("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
 #define CS_DBG(name)                                                                                   \
   do {                                                                                                 \
     if (dbg_sync) {                                                                                    \
@@ -2810,7 +2812,7 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
     const bool kc_single_wave = (L <= 256 * KCL_VPT);
     // (see the clique rounds below) level-parallel core numbers and rows in LDS: the first round takes CLIQUE_BATCH starts
     const bool merged_first_round = kc_single_wave && ((size_t)L * W * 8 + (size_t)4 * L * sizeof(int) <= (size_t)150 * 1024) &&
-                                    getenv("QTR_CLIQUE_ROUND0") == nullptr;
+                                    QTR_ENGINE_ENV("QTR_CLIQUE_ROUND0") == nullptr;
     if (kc_single_wave) {
       const dim3 kgrid(L > 1 ? L - 1 : 1, 1, G);
       if (W <= 4) LAUNCH_SV_T(k_kcore_levels, 1, a, kgrid, dim3(256), 0, stream);
@@ -2836,26 +2838,36 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         if (!hcore_prepared) LAUNCH_SV(k_hcore_async_init, a, dim3((max(L, 4096) + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries);
         after_async = true;
-      } else if (hcore) {
+      }
+#ifdef QTR_TEST_ENGINES
+      else if (hcore) {
         LAUNCH_SV(k_hcore_init, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         for (int it = 0; it < HC_MAXIT; ++it) LAUNCH_SV(k_hcore_sweep, a, dim3((L + 3) / 4, 1, G), dim3(256), 0, stream, it);
         LAUNCH_SV(k_hcore_finish, a, dim3(1, 1, G), dim3(1024), 0, stream, 0);
       }
-      static const bool rank_quadratic = getenv("QTR_RANK_QUADRATIC") != nullptr;
+#endif
+      static const bool rank_quadratic = QTR_ENGINE_ENV("QTR_RANK_QUADRATIC") != nullptr;
       const size_t kc_bytes = kc_lds + (lds_bitmap ? bm_bytes + 8 : 0);
       // the peeling workgroup rides in k_rank_sort's launch (it is the fallback behind k_hcore_async, and the core-number
       // kernel of the graphs in between); the older chains keep its own launch
       const bool own_kcore_launch = rank_quadratic || (hcore && !after_async);
+#ifdef QTR_TEST_ENGINES
       if (own_kcore_launch)
         LAUNCH_SV(k_kcore, a, dim3(1, 1, G), dim3(1024), kc_bytes, stream, q_in_lds ? 0 : 1, lds_bitmap, hcore ? 1 : 0);
+#endif
       CS_DBG("k_kcore");
       int slices = (L + 1023) / 1024;
       if (slices > 32) slices = 32;
+#ifdef QTR_TEST_ENGINES
       if (rank_quadratic) {
         LAUNCH_SV(k_rank_partial, a, dim3((L + 255) / 256, slices, G), dim3(256), 0, stream);
         LAUNCH_SV(k_rank_finish, a, dim3((L + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_clique_init, a, dim3(1, 1, G), dim3(64), 0, stream);
-      } else {
+      } else
+#else
+      (void)slices;
+#endif
+      {
         const int kcore_mode = own_kcore_launch ? 0 : after_async ? 2 : 1;
         LAUNCH_SV(k_rank_sort, a, dim3(1, 1, G), dim3(RS_THREADS), max((size_t)16 * RS_BINS * 4, kcore_mode ? kc_bytes : (size_t)0),
                   stream, after_async ? 1 : 0, kcore_mode, q_in_lds ? 0 : 1, lds_bitmap);

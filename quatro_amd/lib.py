@@ -150,11 +150,17 @@ class QuatroHipError(RuntimeError):
         self.code = code
 
 
-def load():
-    """Loads libquatro_hip.so.  Raises if it has not been built — there is no software fallback."""
+_libs = {}
+TEST_ENGINES_LIB_PATH = os.path.join(_HERE, "libquatro_hip_testengines.so")  # the -DQTR_TEST_ENGINES build (tests only)
+
+
+def load(path: str | None = None):
+    """Loads libquatro_hip.so (or another build of it: the tests' comparison-engine build, a probe's candidate).  Raises
+    if it has not been built — there is no software fallback."""
     global _lib
-    if _lib is not None:
-        return _lib
+    LIB_PATH = path or globals()["LIB_PATH"]
+    if LIB_PATH in _libs:
+        return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m quatro_amd.build` "
@@ -226,7 +232,9 @@ def load():
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.qtr_comm_destroy.argtypes = [C.c_void_p]
     lib.qtr_comm_destroy.restype = None
-    _lib = lib
+    _libs[LIB_PATH] = lib
+    if path is None:
+        _lib = lib
     return lib
 
 
@@ -287,8 +295,8 @@ class Handle:
     """One device + n_slots stream slots (qtr_handle)."""
 
     def __init__(self, device: int = 0, max_points: int = 262144, max_voxels: int = 65536, max_corr: int = 24576,
-                 n_slots: int = 1, max_long_neighbors: int = 0):
-        self._lib = load()
+                 n_slots: int = 1, max_long_neighbors: int = 0, lib_path: str | None = None):
+        self._lib = load(lib_path)
         lim = Limits(max_points, max_voxels, max_corr, n_slots, max_long_neighbors)
         self._h = C.c_void_p()
         rc = self._lib.qtr_create(device, C.byref(lim), C.byref(self._h))

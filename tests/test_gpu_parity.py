@@ -386,10 +386,12 @@ def test_cpp_dropin_demo_matches_python_path(hip, qo, small_pair, tmp_path, pcl_
 
 
 def _nn_tables(engine, vs, ds, vt, dt, seed=4):
+    """engine "" = the product library (one path: the f16-split filter); "exact" / "mfma32" = the comparison engines, which
+    only exist in the -DQTR_TEST_ENGINES build (quatro_amd/build.py) and are selected there with QTR_NN_ENGINE"""
     if engine:
         os.environ["QTR_NN_ENGINE"] = engine
     try:
-        h = ql.Handle(0)
+        h = ql.Handle(0, lib_path=ql.TEST_ENGINES_LIB_PATH if engine else None)
     finally:
         os.environ.pop("QTR_NN_ENGINE", None)
     corr = h.match(vs, ds, vt, dt, ql.default_frontend_params(seed=seed))
