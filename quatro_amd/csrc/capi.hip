@@ -48,6 +48,7 @@ struct Slot {
   long long nn_total_launches = 0;
   qtr_stage_times times = {};
   int last_L = 0;  // correspondences of the last solve
+  int last_Wb = 0; // row stride (words) of the bit matrix it left behind (solver.h SolverView::Wb)
   int last_n = 0;  // points of the last qtr_fpfh
   int last_ns = 0, last_nt = 0;
 };
@@ -717,6 +718,7 @@ struct InFlight {
 static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float4* d_tgt, int L, const qtr_params* prm,
                         qtr_result* res, bool reset_done = false) {
   s.last_L = L;
+  s.last_Wb = (((L + 63) / 64) + 3) & ~3;
   s.sb.mail_seq = ++s.seq;
   // k_hcore_async's workgroups have to be resident together: a chain that starts while another slot's is in flight (calls
   // from several threads) takes its share of the compute units only (solver.hip, solver_set_hca_share)
@@ -833,6 +835,7 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
     d_adj = s.sb.bm;
   }
   s.last_L = L;
+  s.last_Wb = (L + 63) / 64;  // the caller's packed layout
   InFlight in_flight(h);
   QTR_HIP_TRY(h, clique_only_enqueue(s.sb, d_adj, L, mode, kcore_thr, s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32 + 128, s.sb.st, sizeof(SolverState), hipMemcpyDeviceToHost, s.stream));
@@ -1725,6 +1728,7 @@ static int lane_enqueue_solver(qtr_handle* h, Lane& ln, const std::vector<int>& 
   for (int g : ln.active) {
     Slot& s = h->slots[ln.first_slot + g];
     s.last_L = ln.L[g];
+    s.last_Wb = (((ln.L[g] + 63) / 64) + 3) & ~3;
     s.sb.mail_seq = ++s.seq;
     SB.push_back(&s.sb);
     srcs.push_back(ln.csrc[g]);
@@ -2242,7 +2246,14 @@ long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t b
   const size_t n = have < bytes ? have : bytes;
   if (dst && n > 0) {
     if (hipStreamSynchronize(s.stream) != hipSuccess) return -1;
-    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (what == QTR_DBG_GRAPH_BITMAP && s.last_Wb > W) {  // rows start on 32-byte boundaries on the device: pack them
+      const size_t rows = n / ((size_t)W * 8);
+      if (rows > 0 && hipMemcpy2D(dst, (size_t)W * 8, src, (size_t)s.last_Wb * 8, (size_t)W * 8, rows, hipMemcpyDeviceToHost) !=
+                          hipSuccess)
+        return -1;
+    } else if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) {
+      return -1;
+    }
   }
   return (long long)have;
 }

@@ -42,6 +42,7 @@ struct SolverView {
   const float4* src;  // matched keypoint clouds (L each)
   const float4* tgt;
   int L, W;           // correspondences, words per bit-matrix row
+  int Wb;             // row stride of bm in words (>= W; a multiple of four for matrices built by k_graph_build)
   u64* bm;
   u64* adjP;
   int *deg, *core, *perm, *rankof, *Kp, *picks, *gsz, *clique, *rot_inl, *final_inl;

@@ -66,11 +66,12 @@ __device__ __forceinline__ int solver_degree(const SolverView& V, int v) {
 // <= 5u (difference 1u, square 2u, three fused accumulations), so D = fl(s - t) is off by <= 5u (s + t) + u |D| and, where
 // the decision is close (D^2 ~ G = 2 beta^2 (s+t) - beta^4 >= beta^2 (s+t)), D^2 by <= 2 sqrt(2) beta 5u (s+t)^1.5, i.e.
 // <= 2 sqrt(2) 5u sqrt(s+t) / beta relative to G; G itself is off by <= 18u G and the final subtraction by u.  Three
-// times that bound is used.  A margin above 0.05 (beta below ~0.01) switches the screen off (margin < 0).
+// times that bound is used.  A margin above 0.05 (beta below ~0.01) switches the screen off (margin = +inf: until round 4
+// it was -1, which made |z| > margin G hold for every pair and left the binary32 screen to decide ALL of them).
 static float graph_margin(double beta) {
   const double u = 1.0 / 16777216.0;
   const double m = 3.0 * (2.0 * sqrt(2.0) * 5.0 * u * sqrt((double)GB_SMAX) / beta + 20.0 * u);
-  return (m > 0.05 || !(beta > 0.0)) ? -1.0f : (float)m;
+  return (m > 0.05 || !(beta > 0.0)) ? INFINITY : (float)m;  // (inf: |z| > inf G never holds — every pair goes to binary64)
 }
 typedef float gb_f2 __attribute__((ext_vector_type(2)));
 
@@ -80,11 +81,238 @@ typedef float gb_f2 __attribute__((ext_vector_type(2)));
 #define HCA_MAXWG 512      // (one workgroup per compute unit: 256 on this part)
 #define HCA_CTL_VER 64
 #define HCA_CTL_DONE (64 + HCA_MAXWG)
+// 64 x 64 bit-matrix transpose inside a wavefront: lane j holds word j (lo, hi); afterwards lane r holds the word made
+// of bit r of every lane's word.  Six independent swaps "lane-index bit s <-> bit-index bit s": the 32-step exchanges
+// the two halves between lanes 32 apart, the others rotate the partner's word by s and merge under a per-lane mask.
+__device__ __forceinline__ void wave_transpose64(u32& lo, u32& hi, int lane) {
+  {
+    const bool low = lane < 32;
+    const u32 send = low ? hi : lo;
+    const u32 recv = (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)send);
+    const u32 nlo = low ? lo : recv, nhi = low ? recv : hi;
+    lo = nlo;
+    hi = nhi;
+  }
+#pragma unroll
+  for (int s = 16; s >= 1; s >>= 1) {
+    const u32 M0 = s == 16 ? 0x0000FFFFu : s == 8 ? 0x00FF00FFu : s == 4 ? 0x0F0F0F0Fu : s == 2 ? 0x33333333u : 0x55555555u;
+    const bool up = (lane & s) != 0;
+    const u32 keep = up ? ~M0 : M0;
+    const int sh = up ? s : 32 - s;  // rotate right by s (upper lane of the pair) or left by s
+    const int addr = (lane ^ s) << 2;
+    u32 ylo = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)lo), yhi = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)hi);
+    ylo = __builtin_amdgcn_alignbit(ylo, ylo, sh);
+    yhi = __builtin_amdgcn_alignbit(yhi, yhi, sh);
+    lo = (lo & keep) | (ylo & ~keep);
+    hi = (hi & keep) | (yhi & ~keep);
+  }
+}
+
+// K9+K10+K11 (default): 64-row x 256-column STRIPS of the upper triangle, one workgroup of four waves each; wave ct owns
+// the 64 x 64 tile (rb, 4 C + ct).  What changed against the tile-per-workgroup kernel (k_graph_build_tiles, kept as a
+// comparison engine) and why (tests/probe/issue_probe.hip and profiles/r4_graph_sq.txt have the numbers — the kernel is
+// bound by VECTOR INSTRUCTIONS: a SIMD retires one wave64 instruction in four clocks, the tile kernel spent 24 per row of
+// 64 predicates and kept the SIMDs 100 % busy with them):
+//   * NO value travels through a scalar register in the row loop.  The tile kernel did four compares, a ballot AND and two
+//     v_writelane per row; a v_cmp whose mask is consumed by a scalar instruction or as the carry-in of a v_addc also costs
+//     the issuing wave ~28 clocks (the result has to come back from the scalar register file).  Here the decision z < 0
+//     IS the sign bit of z and is shifted into the lane's column word by one v_alignbit ({cacc, z} >> 31); "the screen is
+//     sure" is the sign bit of margin c1 (s + t) - |z|, collected the same way; the range test on s + t is an unsigned
+//     min3 / max3 over the bit patterns (NaN and inf sort above every finite value).  Eight rows go by without a branch;
+//     per 32 rows ONE vote asks whether any lane has a pair the screen could not decide, and those lanes walk their
+//     undecided rows through the binary64 expression;
+//   * the packed binary32 arithmetic pairs TWO ROWS (one register half each) instead of (source, target), so the
+//     operations behind the two squared lengths (S, D, c2 - c1 S, z) are packed as well: 8 packed + 4 plain vector
+//     instructions per row of 64 predicates;
+//   * the row words are not collected at all: they come out of a 64 x 64 bit transpose of the column words
+//     (wave_transpose64), and the four tiles' words of a row leave as ONE 32-byte store (a whole memory sector — rows
+//     start 32-byte aligned: the bit matrix's row stride Wb is a multiple of four words).  The transposed words are still
+//     8-byte stores, one row each: WRITE_SIZE 2.5x the matrix instead of 4x.  (256 x 256 super-tiles, sixteen tiles per
+//     workgroup, store whole sectors in both directions — built and measured in three shapes, 16 waves x 1 tile, 16 x 2
+//     half tiles, 8 x 2 tiles: 118 / 172 / 114 us at L = 20000 against 132 for the tile kernel, and 19 - 22 us against
+//     17 at L = 5000: workgroups that long leave the unit idle while they load, meet at barriers and exchange lanes —
+//     45 % of their wave-cycles were parked.  The 8 x 2 form is kept in tests/probe/k_graph_build_supertile.txt.)
+// The screen and the binary64 decision are the tile kernel's (the "sure" threshold is margin c1 (s + t) instead of
+// margin (c1 (s + t) - c2): a little wider, never narrower): the bit matrix is identical.
+#define GB2_THREADS 256
+#define GB_TILES_MAX_L 8192  // up to here the tile kernel (k_graph_build_tiles, below) builds the graph
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta, float margin,
+__global__ __launch_bounds__(GB2_THREADS, 8) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta,
+                                                                float margin, int prep) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L, Wb = V.Wb;
+  const int nb = (L + 63) >> 6;
+  if (prep) {  // chores of neighbouring launches, see k_graph_build_tiles
+    const int nthreads = gridDim.x * gridDim.y * GB2_THREADS;
+    const int gi = (blockIdx.y * gridDim.x + blockIdx.x) * GB2_THREADS + threadIdx.x;
+    if (prep & 1) {
+      for (int e = gi; e < (((L + 63) & ~63) >> 1); e += nthreads) ((unsigned*)V.Kp)[e] = 0xffffffffu;
+      for (int e = gi; e < HCA_CTL_DONE + HCA_MAXWG; e += nthreads) V.perm[e] = 0;
+    }
+    if ((prep & 2) && gi < (int)(sizeof(SolverState) / 4)) ((int*)V.st)[gi] = 0;
+  }
+  const int rb = blockIdx.y, C = blockIdx.x;
+  if (rb >= nb || 4 * C + 3 < rb || 4 * C >= nb) return;  // strips of the upper triangle only
+  const float4* __restrict__ src = V.src;
+  const float4* __restrict__ tgt = V.tgt;
+  u64* __restrict__ bm = V.bm;
+  unsigned char* __restrict__ degp = const_cast<unsigned char*>(V.degp);
+  const int Lp = V.Lp;
+  // the 64 row points, two rows to a record of twelve floats: (sx, sx'), (sy, sy'), (sz, sz'), (tx, tx'), (ty, ty'),
+  // (tz, tz') — three 16-byte broadcast reads per pair of rows
+  __shared__ __attribute__((aligned(16))) float rowpts[32 * 12];
+  __shared__ __attribute__((aligned(16))) u64 rowbuf[64 * 4];  // [row][column tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = 4 * C + ct;
+  if (tid < 64) {
+    const int i = min(rb * 64 + tid, L - 1);
+    const float4 a = src[i], b = tgt[i];
+    float* rp = rowpts + (tid >> 1) * 12 + (tid & 1);
+    rp[0] = a.x;
+    rp[2] = a.y;
+    rp[4] = a.z;
+    rp[6] = b.x;
+    rp[8] = b.y;
+    rp[10] = b.z;
+  }
+  const int j = cb * 64 + lane;
+  const bool mine = cb < nb && cb >= rb;  // my tile exists and lies in the upper triangle
+  const bool jvalid = mine && j < L;
+  float csx, csy, csz, ctx, cty, ctz;
+  {
+    const int jj = max(0, min(j, L - 1));
+    const float4 a = src[jj], b = tgt[jj];
+    csx = a.x;
+    csy = a.y;
+    csz = a.z;
+    ctx = b.x;
+    cty = b.y;
+    ctz = b.z;
+  }
+  __syncthreads();
+  const int nrows = min(64, L - rb * 64);  // rows of the strip that exist
+  if (mine) {
+    const bool diag = rb == cb;
+    const float fb2 = (float)(beta * beta);
+    const float c1 = 2.0f * fb2, c2 = fb2 * fb2;
+    // s + t in (smin, GB_SMAX): above smin the squared form is valid (s + t - beta^2 > 0 in exact arithmetic too); as
+    // unsigned integers the bit patterns of non-negative floats order like the floats, NaN / inf / anything negative above
+    const u32 smin_bits = __float_as_uint(fb2 * 1.01f), smax_bits = __float_as_uint(GB_SMAX);
+    const double beta2 = beta * beta;
+    const float mc1 = margin * c1;  // (inf when the screen is switched off)
+    u32 acc[2] = {0, 0};
+    // `DG` (a tile on the diagonal of the matrix): a lane meets its own vertex in one row (s = t = 0), which the range
+    // test would take for a short TIM; there the own row's s + t is replaced by 1 for the test (its bit is cleared below)
+    auto sweep = [&](auto dg_tag) __attribute__((always_inline)) {
+      constexpr bool DG = decltype(dg_tag)::value;
+      const gb_f2 sx2 = {csx, csx}, sy2 = {csy, csy}, sz2 = {csz, csz}, tx2 = {ctx, ctx}, ty2 = {cty, cty}, tz2 = {ctz, ctz};
+      const gb_f2 nc1_2 = {-c1, -c1}, c2_2 = {c2, c2};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        u32 cacc = 0;  // decision bits of my column, one row per shift (first row ends up in bit 31)
+        u32 sacc = 0;  // "the screen is sure" bits, same order
+        u32 oacc = 0;  // one bit per group of eight rows: s + t out of range somewhere in the group
+        const u32 selfw = DG ? ((lane >> 5) == half ? (1u << (lane & 31)) : 0u) : 0u;  // my own row within this half
+#pragma unroll 1
+        for (int g8 = 0; g8 < 4; ++g8) {
+          u32 s_lo = 0xffffffffu, s_hi = 0u;
+#pragma unroll 2
+          for (int k = 0; k < 4; ++k) {
+            const float4* rp = (const float4*)(rowpts + (half * 16 + g8 * 4 + k) * 12);
+            const float4 p0 = rp[0], p1 = rp[1], p2 = rp[2];
+            const gb_f2 dxs = sx2 - gb_f2{p0.x, p0.y}, dys = sy2 - gb_f2{p0.z, p0.w}, dzs = sz2 - gb_f2{p1.x, p1.y};
+            const gb_f2 dxt = tx2 - gb_f2{p1.z, p1.w}, dyt = ty2 - gb_f2{p2.x, p2.y}, dzt = tz2 - gb_f2{p2.z, p2.w};
+            gb_f2 qs = dxs * dxs;
+            qs = __builtin_elementwise_fma(dys, dys, qs);
+            qs = __builtin_elementwise_fma(dzs, dzs, qs);  // squared source TIM lengths of the two rows
+            gb_f2 qt = dxt * dxt;
+            qt = __builtin_elementwise_fma(dyt, dyt, qt);
+            qt = __builtin_elementwise_fma(dzt, dzt, qt);
+            const gb_f2 S = qs + qt, D = qs - qt;
+            const gb_f2 nG = __builtin_elementwise_fma(S, nc1_2, c2_2);  // -(c1 S - c2)
+            const gb_f2 z = __builtin_elementwise_fma(D, D, nG);          // < 0: consistent
+            // < 0: the screen is sure (|z| above margin c1 S >= margin G)
+            const float t0 = __builtin_fmaf(S.x, mc1, -__builtin_fabsf(z.x)), t1 = __builtin_fmaf(S.y, mc1, -__builtin_fabsf(z.y));
+            cacc = __builtin_amdgcn_alignbit(cacc, __float_as_uint(z.x), 31);
+            cacc = __builtin_amdgcn_alignbit(cacc, __float_as_uint(z.y), 31);
+            sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(t0), 31);
+            sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(t1), 31);
+            u32 b0 = __float_as_uint(S.x), b1 = __float_as_uint(S.y);
+            if (DG) {
+              const int rr = g8 * 8 + 2 * k;  // row within the half
+              b0 |= (0u - ((selfw >> rr) & 1u)) & 0x3f800000u;
+              b1 |= (0u - ((selfw >> (rr + 1)) & 1u)) & 0x3f800000u;
+            }
+            s_lo = min(min(b0, b1), s_lo);
+            s_hi = max(max(b0, b1), s_hi);
+          }
+          oacc = (oacc << 1) | ((s_lo > smin_bits && s_hi < smax_bits) ? 0u : 1u);
+        }
+        // one vote per 32 rows: does any lane hold a pair the screen could not decide?
+        u32 pend = ~sacc;  // bit 31 - i: row i of this half is undecided
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8) pend |= ((oacc >> (3 - g8)) & 1u) ? (0xff000000u >> (8 * g8)) : 0u;
+        {
+          // rows past the end of the last block and a vertex paired with itself are never decided (cleared below)
+          const int live = nrows - half * 32;  // rows of this half that exist
+          const u32 rowmask = live >= 32 ? 0xffffffffu : live <= 0 ? 0u : ~(0xffffffffu >> live);
+          pend &= rowmask;
+          if (DG) pend &= ~__brev(selfw);
+          if (!jvalid) pend = 0;
+        }
+        while (__any(pend != 0)) {  // rare: the band is ~1e-5 of the pairs, plus TIMs shorter than beta
+          if (pend != 0) {
+            const int i = __clz(pend);  // my first undecided row of this half
+            const int r = half * 32 + i;
+            const float* rp = rowpts + (r >> 1) * 12 + (r & 1);
+            const double ex_ = (double)csx - (double)rp[0], ey = (double)csy - (double)rp[2], ez = (double)csz - (double)rp[4];
+            const double fx = (double)ctx - (double)rp[6], fy = (double)cty - (double)rp[8], fz = (double)ctz - (double)rp[10];
+            const double s = ex_ * ex_ + (ey * ey + ez * ez);
+            const double t = fx * fx + (fy * fy + fz * fz);
+            const u32 bit = 0x80000000u >> i;
+            cacc = pair_consistent(s, t, beta, beta2) ? (cacc | bit) : (cacc & ~bit);
+            pend &= ~bit;
+          }
+        }
+        acc[half] = cacc;
+      }
+    };
+    if (diag) sweep(std::true_type{});
+    else sweep(std::false_type{});
+    // 32 shifts put the first row of a half into bit 31
+    u64 colw = ((u64)__brev(acc[1]) << 32) | (u64)__brev(acc[0]);
+    if (nrows < 64) colw &= (1ULL << nrows) - 1ULL;  // rows past the end of the last block
+    if (diag) colw &= ~(1ULL << lane);                // a vertex is not its own neighbour
+    if (!jvalid) colw = 0;                             // columns past the end of the matrix
+    if (!diag && jvalid) {  // the transposed word (the lower triangle is never evaluated)
+      bm[(size_t)j * Wb + rb] = colw;
+      degp[(size_t)rb * Lp + j] = (unsigned char)__popcll(colw);
+    }
+    u32 lo = (u32)colw, hi = (u32)(colw >> 32);
+    wave_transpose64(lo, hi, lane);
+    rowbuf[lane * 4 + ct] = ((u64)hi << 32) | lo;  // lane r: the word of row rb * 64 + r (diagonal tile: both triangles)
+  }
+  __syncthreads();
+  // the four tiles' words of a row as one 32-byte store (one memory sector): thread t -> row t / 4, word t % 4; and the
+  // word's popcount as the (64-column block, vertex) degree byte — every such pair has exactly one writer
+  {
+    const int row = tid >> 2, wi = 4 * C + (tid & 3);
+    if (row < nrows && wi < nb && wi >= rb) {
+      const u64 w = rowbuf[tid];
+      bm[(size_t)(rb * 64 + row) * Wb + wi] = w;
+      degp[(size_t)wi * Lp + rb * 64 + row] = (unsigned char)__popcll(w);
+    }
+  }
+}
+
+// The tile-per-workgroup kernel (rounds 2-3): four waves x 16 rows per tile, many short workgroups — the LATENCY form, used up
+// to GB_TILES_MAX_L correspondences (a registration graph of the metric size is a single wave of workgroups).
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_graph_build_tiles(ViewExt<SolverView> x, SolverView one, double beta, float margin,
                                                      int prep) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  const int L = V.L, W = V.W;
+  const int L = V.L, Wb = V.Wb;
   const int nb = (L + 63) >> 6;
   // Chores of launches that used to follow or precede this one (~5 us each on the chain), done by the first threads of
   // the grid: bit 0 — k_hcore_async's clean slate (every value at 0xffff, an upper bound of any degree; control words 0;
@@ -222,7 +450,7 @@ __global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, Solv
     const int r = r0 + lane;
     if (diag) roww &= ~(1ULL << (r & 63));  // a vertex is not its own neighbour (the row word covers both triangles)
     if (lane < 16 && r < nrows) {
-      bm[(size_t)(i0 + r) * W + cb] = roww;
+      bm[(size_t)(i0 + r) * Wb + cb] = roww;
       degp[(size_t)cb * Lp + i0 + r] = (unsigned char)__popcll(roww);
     }
   }
@@ -234,7 +462,7 @@ __global__ __launch_bounds__(256) void k_graph_build(ViewExt<SolverView> x, Solv
     u64 colw = (u64)colpart[0][lane] | ((u64)colpart[1][lane] << 16) | ((u64)colpart[2][lane] << 32) |
                ((u64)colpart[3][lane] << 48);
     if (nrows < 64) colw &= (1ULL << nrows) - 1ULL;  // rows past the end of the last block
-    bm[(size_t)j * W + rb] = colw;
+    bm[(size_t)j * Wb + rb] = colw;
     degp[(size_t)rb * Lp + j] = (unsigned char)__popcll(colw);
   }
 }
@@ -288,7 +516,7 @@ __device__ __forceinline__ void d_kcore(const SolverView& V, int use_gqueue /* t
   const u64* rows = bm;
   if (lds_bitmap) {
     u64* lb = (u64*)(kc_lds + ((2 * L + 1) & ~1));
-    for (size_t e = tid; e < (size_t)L * W; e += nthr) lb[e] = bm[e];
+    for (size_t e = tid; e < (size_t)L * W; e += nthr) lb[e] = bm[(e / W) * (size_t)V.Wb + (e % W)];
     rows = lb;
   }
   __syncthreads();
@@ -331,9 +559,10 @@ __device__ __forceinline__ void d_kcore(const SolverView& V, int use_gqueue /* t
       // (frontier vertex, word) items are independent: flattened over all threads so that the row loads of
       // a round overlap; each lane walks the set bits of its word (up to 64 conflict-tolerant LDS atomics per
       // step across the wave, whatever the density)
+      const int Wr = lds_bitmap ? W : V.Wb;  // (row stride of `rows`: the LDS copy is packed)
       for (int item = tid; item < n * W; item += nthr) {
         const int qi = item / W, w = item - qi * W;
-        u64 x = rows[(size_t)queue[qi] * W + w];
+        u64 x = rows[(size_t)queue[qi] * Wr + w];
         while (x) {
           const int b = __ffsll((long long)x) - 1;
           x &= x - 1;
@@ -402,7 +631,7 @@ __global__ __launch_bounds__(256) void k_hcore_sweep(ViewExt<SolverView> x, Solv
   // a value can only drop after a neighbour's did: whoever lowers its value stamps its neighbours "due next sweep", and
   // a vertex nobody stamped since its last visit is skipped (the late sweeps touch a few hundred rows, not all L)
   if (due[row] < it) return;
-  const u64* __restrict__ rowp = V.bm + (size_t)row * W;
+  const u64* __restrict__ rowp = V.bm + (size_t)row * V.Wb;
   const int cv = core[row];
   if (cv <= 0) return;
   int h;
@@ -619,7 +848,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   __syncthreads();
   for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
     if (nb_off[rl + 1] > pool_entries) continue;
-    const u64* rowp = bm + (size_t)(r_lo + rl) * W;
+    const u64* rowp = bm + (size_t)(r_lo + rl) * V.Wb;
     int run = nb_off[rl];
     for (int base = 0; base < W; base += 64) {
       const int wd = base + lane;
@@ -700,7 +929,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
           return wave_sum_i32(cc);
         });
     } else {  // no list: the bit row, from memory, walked for every probe
-      const u64* rowp = bm + (size_t)v * W;
+      const u64* rowp = bm + (size_t)v * V.Wb;
       h = h_index(cv, [&](int th) __attribute__((always_inline)) {
         int cc = 0;
         for (int wd = lane; wd < W; wd += 64) {
@@ -900,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_kcore_levels(ViewExt<SolverView> x, Sol
     u64 row[VT][WT];
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
-      const u64* src = bm + (size_t)(i * 256 + tid) * W;
+      const u64* src = bm + (size_t)(i * 256 + tid) * V.Wb;
       const bool a = (amask >> i) & 1u;
 #pragma unroll
       for (int w = 0; w < WT; ++w) row[i][w] = (a && w < W) ? src[w] : 0ULL;
@@ -1313,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_permute_scatter(ViewExt<SolverView> x, 
   __syncthreads();
   for (int i = wave; i < PM2_ROWS && r0 + i < L; i += 4) {
     const int r = r0 + i;
-    const u64* __restrict__ rowp = bm + (size_t)perm[r] * W;
+    const u64* __restrict__ rowp = bm + (size_t)perm[r] * V.Wb;
     for (int w = lane; w < W; w += 64) outw[w] = 0;
     for (int w = lane; w < W; w += 64) {
       u64 bits = rowp[w];
@@ -1344,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_permute(ViewExt<SolverView> x, SolverVi
   const int nr = min(PM_ROWS, L - r0);
   for (int e = threadIdx.x; e < nr * W; e += 256) {
     const int i = e / W, w = e - i * W;
-    prow[e] = bm[(size_t)perm[r0 + i] * W + w];
+    prow[e] = bm[(size_t)perm[r0 + i] * V.Wb + w];
   }
   __syncthreads();
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
@@ -2666,7 +2895,7 @@ hipError_t solver_init_attributes() {
 size_t solver_scratch_bytes(int Lcap) {
   const size_t W = (size_t)(Lcap + 63) / 64;
   size_t b = 0;
-  b += 2 * (size_t)Lcap * W * 8;        // bm, adjP
+  b += 2 * (size_t)Lcap * ((W + 3) & ~(size_t)3) * 8;  // bm (row stride: a multiple of four words), adjP
   b += 8 * (size_t)Lcap * 4;            // deg, core, perm, rankof, Kp, picks, gsz, (spare)
   b += 3 * (size_t)Lcap * 4;            // clique, rot_inl, final_inl
   b += 72 * (size_t)Lcap * 8;           // f64
@@ -2685,7 +2914,7 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
     return (void*)r;
   };
   B.Lcap = Lcap;
-  B.bm = (u64*)take((size_t)Lcap * W * 8);
+  B.bm = (u64*)take((size_t)Lcap * ((W + 3) & ~(size_t)3) * 8);
   B.adjP = (u64*)take((size_t)Lcap * W * 8);
   B.deg = (int*)take((size_t)Lcap * 4);
   B.core = (int*)take((size_t)Lcap * 4);
@@ -2716,6 +2945,9 @@ static SolverView make_solver_view(const SolverBufs& B, const float4* src, const
   V.tgt = tgt;
   V.L = L;
   V.W = (L + 63) / 64;
+  // row stride of bm: rows built by k_graph_build start on 32-byte boundaries (it stores four words at a time); a matrix
+  // that was handed in (qtr_max_clique) keeps the caller's packed layout
+  V.Wb = src ? ((V.W + 3) & ~3) : V.W;
   V.bm = B.bm;
   V.adjP = B.adjP;
   V.deg = B.deg;
@@ -3003,9 +3235,19 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
   if (L > 0) {
     const double beta = 2 * prm.noise_bound * sqrt(prm.cbar2);
     {
-      const int nb = (L + 63) / 64;  // 64 x 64 tiles of the upper triangle, one per workgroup
-      LAUNCH_SV(k_graph_build, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta),
-                (prep_hcore ? 1 : 0) | (reset_done ? 0 : 2));
+      const int nb = (L + 63) / 64, nsb = (nb + 3) / 4;
+      const int prep = (prep_hcore ? 1 : 0) | (reset_done ? 0 : 2);
+      // Two forms of one computation (identical bit matrices).  Tiles: 64 x 64 per workgroup, four waves x 16 rows — many
+      // short workgroups, the lower latency while the whole graph is one wave of workgroups (same-box A/B at L = 5000 and
+      // at the matcher's L ~ 300: 10 us per registration in its favour).  Strips: 64 x 256 per workgroup, one wave per
+      // tile — 30 % fewer vector instructions and sector-sized row stores, the higher throughput once the device is
+      // full (L = 20000: 107 against 132 us).
+      bool tiles = L <= GB_TILES_MAX_L;
+      if (const char* e = QTR_ENGINE_ENV("QTR_GRAPH")) tiles = strcmp(e, "tiles") == 0;
+      if (tiles)
+        LAUNCH_SV(k_graph_build_tiles, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta), prep);
+      else  // (grid: column group x row block; the lower-left half returns at once)
+        LAUNCH_SV(k_graph_build, a, dim3(nsb, nb, G), dim3(GB2_THREADS), 0, stream, beta, graph_margin(beta), prep);
     }
     if (ev_graph) hipEventRecord(ev_graph, stream);
     scan_batch = clique_stage_launch(a, G, L, prm.inlier_selection_mode, prm.kcore_heuristic_threshold, stream, prep_hcore, true);
