@@ -114,6 +114,9 @@ def main() -> None:
                          "correspondences (the metric's '~5k corr'); pair: qtr_register_pair on the scan pair alone "
                          "(its matcher yields a few hundred correspondences)")
     ap.add_argument("--corr", type=int, default=5000, help="correspondences of the composite step's back end")
+    ap.add_argument("--composite-calls", type=int, default=1, choices=(1, 2),
+                    help="1 (default): the composite step is ONE call, qtr_register_pair_corr (front end of the scans, back end "
+                         "on the given correspondences); 2: qtr_feature_pair then qtr_solve, as in rounds 2-3")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--nn-event-stride", type=int, default=5,
                     help="every n-th step of the timed region carries the nearest-neighbour launches' event pairs (1 = all)")
@@ -178,7 +181,15 @@ def main() -> None:
         if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
             raise ql.QuatroHipError(rc, handle.last_error())
 
-    def step_composite(p, handle=h, r=res, slot=0):
+    def step_composite_1(p, handle=h, r=res, slot=0):
+        # voxelize x2 + FPFHManager::setFeaturePair on the scans, then Quatro::computeTransformation on the metric's ~5k
+        # correspondences — one call through the C ABI, nothing between the two halves but the library's own hand-over
+        rc = handle.register_pair_corr_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
+                                           p["fp"], p["cs"].data_ptr(), p["ct"].data_ptr(), LC, prm, r, slot)
+        if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+            raise ql.QuatroHipError(rc, handle.last_error())
+
+    def step_composite_2(p, handle=h, r=res, slot=0):
         # FPFHManager::setFeaturePair on the scans (voxel grid, FPFH, reciprocal matching, tuple test) ...
         rc, p["_ns"], p["_nt"], p["_Lm"] = handle.feature_pair_dev(p["src"].data_ptr(), p["src"].shape[0],
                                                                    p["tgt"].data_ptr(), p["tgt"].shape[0], p["fp"], slot)
@@ -189,6 +200,7 @@ def main() -> None:
         if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
             raise ql.QuatroHipError(rc, handle.last_error())
 
+    step_composite = step_composite_1 if args.composite_calls == 1 else step_composite_2
     step = step_composite if composite else step_pair
 
     # sizes of every pool pair (one untimed registration each): needed for the per-launch FLOP accounting
@@ -278,6 +290,7 @@ def main() -> None:
             p["front"] = h.feature_pair(p["src_h"], p["tgt_h"], p["fp"])
             p["result"] = h.solve(p["cs_h"], p["ct_h"], prm)
             p["result"]["L"] = LC
+            p["one_call"] = h.register_pair_corr(p["src_h"], p["tgt_h"], p["cs_h"], p["ct_h"], p["fp"], prm)
         else:
             p["result"] = p["whole"]
         recs.append(qdist.pack_record(p["id"], p["result"]))
@@ -342,12 +355,14 @@ def main() -> None:
         workload = (f"composite (BASELINE configs[1]: single KITTI-64 pair, ~5k correspondences): front end + matcher of a "
                     f"synthetic KITTI-64-shaped scan pair (quatro_amd.synth.kitti64_pair_16k, voxel 0.3 m, n ~ 16-18 k "
                     f"per cloud) through qtr_feature_pair [voxelize x2 + FPFHManager::setFeaturePair], then "
-                    f"Quatro::computeTransformation through qtr_solve on {LC} synthetic correspondences with 5 % planted "
+                    f"Quatro::computeTransformation [qtr_solve] on {LC} synthetic correspondences with 5 % planted "
                     f"inliers (quatro_amd.synth.correspondences, SURVEY 8(d) config 2) INSTEAD of the matcher's own "
                     f"output: FPFH on synthetic scans keeps only ~250-650 tuple-consistent correspondences for any "
                     f"physically plausible scene (DESIGN.md section 5; tests/probe/synth_L_probe.py), so the metric's "
-                    f"'~5k corr' back end is fed from the solver-only generator; one step = both calls, one pair at a "
-                    f"time, inputs resident in HBM")
+                    f"'~5k corr' back end is fed from the solver-only generator; one step = " +
+                    ("ONE call, qtr_register_pair_corr (the back end is enqueued when the matcher's counters arrive and runs "
+                     "after the front end)" if args.composite_calls == 1 else "both calls, qtr_feature_pair then qtr_solve") +
+                    ", one pair at a time, inputs resident in HBM")
     else:
         workload = ("synthetic KITTI-64-shaped single pair (quatro_amd.synth.kitti64_pair_16k), voxel 0.3 m, whole "
                     "path on GPU through qtr_register_pair, one registration at a time; NOTE n_corr is the matcher's "
@@ -898,11 +913,17 @@ def cpu_baseline_leg(args, ql, h, pool, composite, LC, value, seg, pwl, raw0, le
                 "final_inliers_bit_exact": bool(np.array_equal(r["final_inliers"], so["final_inliers"])),
                 "planted_inliers_recovered": int(np.intersect1d(r["final_inliers"], p["planted"]).size),
                 "planted": int(p["planted"].size)}
+            oc = p["one_call"]  # the timed step's own entry point: the same record as the two stage calls
+            e["one_call"] = {
+                "counts_equal": bool((oc["n_src"], oc["n_tgt"], oc["L"], oc["n_matched"]) == (f["n_src"], f["n_tgt"], LC, f["L"])),
+                "clique_bit_exact": bool(np.array_equal(oc["clique"], so["clique"])),
+                "final_inliers_bit_exact": bool(np.array_equal(oc["final_inliers"], so["final_inliers"])),
+                "transform_bit_exact": bool(np.array_equal(oc["T"], r["T"]))}
         par.append(e)
 
     def all_ok(e):
         ok = True
-        for part in ("whole_path", "front_end", "back_end"):
+        for part in ("whole_path", "front_end", "back_end", "one_call"):
             if part in e:
                 d = e[part]
                 ok = ok and all(v for k, v in d.items() if k.endswith("_exact") or k.endswith("_equal"))

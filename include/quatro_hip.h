@@ -278,6 +278,19 @@ QTR_API int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, in
                       const qtr_frontend_params* fp, const qtr_params* prm, qtr_result* res, int* clique,
                       int* final_inliers, int cap, int mem);
 
+/* The whole path of one pair whose back end runs on correspondences the CALLER brings (a cache of matched keypoints:
+ * FPFHManager::loadFeaturePair, include/fpfh_manager.hpp:211-232; another matcher) while the scans still go through the
+ * front end — the single-pair form of a qtr_pair_desc with both scans and src_corr4 / tgt_corr4 set (see
+ * qtr_submit_batch), and the unit of work BASELINE's metric is quoted on: a KITTI-64 pair's voxel grid + FPFH + matching
+ * AND a ~5 k-correspondence computeTransformation, as ONE call (the back end is enqueued as soon as the matcher's counters
+ * arrive; it starts after the front end like in qtr_register_pair — nothing overlaps that a registration would
+ * serialise).  res->n_src / n_tgt report the voxel counts, res->n_corr = n_corr; n_matched (optional) receives the
+ * matcher's own correspondence count.  corr_*4: n_corr 16-byte records each, same `mem` as the scans. */
+QTR_API int qtr_register_pair_corr(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                                   const qtr_frontend_params* fp, const float* corr_src4, const float* corr_tgt4, int n_corr,
+                                   const qtr_params* prm, qtr_result* res, int* n_matched, int* clique, int* final_inliers,
+                                   int cap, int mem);
+
 /* Front end of one pair on one slot: raw scans -> matched keypoint clouds.  What the reference's caller does between
  * loading two scans and handing the keypoints to Quatro (examples/run_global_registration.cpp:206-221): `voxelize` x2
  * (include/quatro.hpp:49-68), FPFHManager::setFeaturePair (include/fpfh_manager.hpp:98-153: FPFH x2 + reciprocal

@@ -1642,6 +1642,45 @@ int qtr_register_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, co
                             nullptr, -1);
 }
 
+int qtr_register_pair_corr(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
+                           const qtr_frontend_params* fp, const float* corr_src4, const float* corr_tgt4, int n_corr,
+                           const qtr_params* prm, qtr_result* res, int* n_matched, int* clique, int* final_inliers, int cap,
+                           int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !res || !fp) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  memset(res, 0, sizeof(*res));
+  if (n_matched) *n_matched = 0;
+  int rc = check_params(h, prm);
+  if (rc != QTR_OK) return res->status = rc;
+  if (n_corr < 0 || (n_corr > 0 && (!corr_src4 || !corr_tgt4))) {
+    snprintf(h->err, sizeof(h->err), "bad correspondence clouds");
+    return res->status = QTR_ERR_BAD_ARG;
+  }
+  if (n_corr > h->lim.max_corr) {
+    snprintf(h->err, sizeof(h->err), "n_corr=%d exceeds max_corr=%d", n_corr, h->lim.max_corr);
+    return res->status = QTR_ERR_CAPACITY;
+  }
+  int Lm = 0;
+  rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, true, &res->n_src, &res->n_tgt, &Lm);
+  if (n_matched) *n_matched = Lm;
+  res->n_corr = n_corr;
+  if (rc != QTR_OK) return res->status = rc;
+  const float4 *cs = (const float4*)corr_src4, *ct = (const float4*)corr_tgt4;
+  if (mem == QTR_MEM_HOST && n_corr > 0) {  // (the matcher's own matched clouds in m_src / m_tgt are not needed: behind it)
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, corr_src4, (size_t)n_corr * 16, hipMemcpyHostToDevice, s.stream));
+    QTR_HIP_TRY(h, hipMemcpyAsync(s.m_tgt, corr_tgt4, (size_t)n_corr * 16, hipMemcpyHostToDevice, s.stream));
+    cs = s.m_src;
+    ct = s.m_tgt;
+  }
+  rc = solve_device(h, s, cs, ct, n_corr, prm, res, true);
+  if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) return rc;
+  s.times_pending = h->stage_events ? 2 : 4;
+  const int rc2 = copy_out_lists(h, s, res, clique, nullptr, final_inliers, cap, mem);
+  if (rc2 != QTR_OK) return res->status = rc2;
+  return rc;
+}
+
 int qtr_feature_pair(qtr_handle* h, int slot, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
                      const qtr_frontend_params* fp, int* n_src, int* n_tgt, int* L_out, float* src_kps4, float* tgt_kps4,
                      int* corr2, int cap, int mem) {

@@ -86,7 +86,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_register_pair_corr", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -188,6 +188,9 @@ def load(path: str | None = None):
     lib.qtr_register_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.POINTER(FrontendParams), C.POINTER(Params), C.POINTER(Result), C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int]
+    lib.qtr_register_pair_corr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.POINTER(FrontendParams), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params),
+                                           C.POINTER(Result), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.qtr_feature_pair.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.POINTER(FrontendParams), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -535,6 +538,33 @@ class Handle:
                           res: Result, slot: int = 0) -> int:
         return self._lib.qtr_register_pair(self._h, slot, src_ptr, Ps, tgt_ptr, Pt, C.byref(fp), C.byref(prm),
                                            C.byref(res), None, None, 0, MEM_DEVICE)
+
+    def register_pair_corr_dev(self, src_ptr: int, Ps: int, tgt_ptr: int, Pt: int, fp: FrontendParams, cs_ptr: int,
+                               ct_ptr: int, n_corr: int, prm: Params, res: Result, slot: int = 0) -> int:
+        """qtr_register_pair_corr on device-resident scans and correspondences: front end of the scans, back end on the given
+        correspondences, one call"""
+        return self._lib.qtr_register_pair_corr(self._h, slot, src_ptr, Ps, tgt_ptr, Pt, C.byref(fp), cs_ptr, ct_ptr, n_corr,
+                                                C.byref(prm), C.byref(res), None, None, None, 0, MEM_DEVICE)
+
+    def register_pair_corr(self, src_raw4, tgt_raw4, corr_src4, corr_tgt4, fp: FrontendParams | None = None,
+                           params: Params | None = None, slot: int = 0):
+        src_raw4, tgt_raw4, corr_src4, corr_tgt4 = _f4(src_raw4), _f4(tgt_raw4), _f4(corr_src4), _f4(corr_tgt4)
+        fp = fp or default_frontend_params()
+        prm = params or demo_params()
+        res = Result()
+        L = corr_src4.shape[0]
+        cap = max(L, 1)
+        cl = np.zeros(cap, dtype=np.int32)
+        fin = np.zeros(cap, dtype=np.int32)
+        nm = C.c_int()
+        rc = self._lib.qtr_register_pair_corr(self._h, slot, src_raw4.ctypes.data, src_raw4.shape[0], tgt_raw4.ctypes.data,
+                                              tgt_raw4.shape[0], C.byref(fp), corr_src4.ctypes.data, corr_tgt4.ctypes.data, L,
+                                              C.byref(prm), C.byref(res), C.addressof(nm), cl.ctypes.data, fin.ctypes.data, cap,
+                                              MEM_HOST)
+        self._check(rc, ok=(QTR_OK, QTR_ERR_CLIQUE_TOO_SMALL))
+        out = _result_dict(res, cl, None, fin)
+        out["n_matched"] = nm.value
+        return out
 
     def solve_dev(self, src_ptr: int, tgt_ptr: int, L: int, prm: Params, res: Result, slot: int = 0) -> int:
         return self._lib.qtr_solve(self._h, slot, src_ptr, tgt_ptr, L, C.byref(prm), C.byref(res), None, None, None,

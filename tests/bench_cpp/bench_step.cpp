@@ -1,5 +1,5 @@
-// bench_step.cpp — the composite step of bench.py (qtr_feature_pair on a scan pair + qtr_solve on given correspondences,
-// inputs resident in HBM) driven from C++ through the C ABI: what a compiled caller — the reference is one — pays per
+// bench_step.cpp — the composite step of bench.py (qtr_register_pair_corr: front end of a scan pair + back end on given
+// correspondences, inputs resident in HBM) driven from C++ through the C ABI: what a compiled caller — the reference is one — pays per
 // registration, without the two ctypes transitions of the Python harness.  Built with hipcc (it allocates the device
 // buffers itself); bench.py's `cpp` leg builds and runs it and quotes its line.
 //
@@ -76,17 +76,14 @@ int main(int argc, char** argv) {
     qtr_frontend_params fp;
     qtr_default_frontend_params(&fp);
     fp.seed = (unsigned long long)(k % (int)P.size());
-    int ns = 0, nt = 0, Lm = 0;
-    int rc = qtr_feature_pair(h, 0, p.src, p.Ps, p.tgt, p.Pt, &fp, &ns, &nt, &Lm, nullptr, nullptr, nullptr, 0, QTR_MEM_DEVICE);
-    if (rc != QTR_OK) {
-      fprintf(stderr, "qtr_feature_pair: %s\n", qtr_last_error(h));
-      exit(4);
-    }
-    rc = qtr_solve(h, 0, p.cs, p.ct, p.L, &prm, &res, nullptr, nullptr, nullptr, 0, QTR_MEM_DEVICE);
+    int Lm = 0;
+    const int rc = qtr_register_pair_corr(h, 0, p.src, p.Ps, p.tgt, p.Pt, &fp, p.cs, p.ct, p.L, &prm, &res, &Lm, nullptr, nullptr,
+                                          0, QTR_MEM_DEVICE);
     if (rc != QTR_OK && rc != QTR_ERR_CLIQUE_TOO_SMALL) {
-      fprintf(stderr, "qtr_solve: %s\n", qtr_last_error(h));
+      fprintf(stderr, "qtr_register_pair_corr: %s\n", qtr_last_error(h));
       exit(4);
     }
+    const int ns = res.n_src, nt = res.n_tgt;
     checksum += ns + nt + Lm + res.n_clique + res.n_final;
   };
   for (int k = 0; k < warmup; ++k) step(k);

@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol(libpath):
     assert set(ql.EXPORTS) == set(declared)
 
 
+def test_every_entry_point_with_pointer_arguments_declares_its_ctypes_signature(libpath):
+    """ctypes passes a bare Python int as a 32-bit C int: an entry point called with data pointers but without argtypes
+    truncates them (a crash on the GPU box, nothing on a CPU run).  Only the four one-struct-by-reference helpers may go
+    without."""
+    from quatro_amd import lib as ql
+    lib = ql.load()
+    bare = {n for n in ql.EXPORTS if getattr(lib, n).argtypes is None}
+    assert bare <= {"qtr_default_limits", "qtr_default_params", "qtr_demo_params", "qtr_default_frontend_params"}, bare
+
+
 def test_dynamic_symbol_table_is_exactly_the_declared_c_abi(libpath):
     """-fvisibility=hidden + the linker version script (csrc/exports.map): the library's dynamic symbol table holds the
     entry points of include/quatro_hip.h and nothing else — no mangled internals, kernel handles or device stubs."""

@@ -557,3 +557,30 @@ def test_dense_mode_end_to_end_through_the_whole_path_entry_matches_oracle(qo16)
     assert (gb[0]["n_src"], gb[0]["n_tgt"], gb[0]["L"]) == (50000, 50000, g["L"])
     assert np.array_equal(gb[0]["clique"], g["clique"]) and np.array_equal(gb[0]["T"], g["T"])
     assert (gb[1]["n_src"], gb[1]["n_tgt"]) == (30000, 30000)
+
+
+def test_single_call_composite_equals_the_two_stage_calls_and_the_batched_entry(qo16, pool16k):
+    """qtr_register_pair_corr (front end of the scans + back end on given correspondences, ONE call — the bench's step) gives
+    the voxel counts / matcher count of qtr_feature_pair and the record of qtr_solve on the same correspondences, on host
+    and device memory, and refuses what the two calls refuse."""
+    s, t, _ = pool16k[1]
+    c = synth.correspondences(5000, 0.05, seed=3, noise=0.1)
+    h = ql.Handle(0, **LIMITS)
+    try:
+        fp = ql.default_frontend_params(seed=1)
+        f = h.feature_pair(s, t, fp)
+        b = h.solve(c[0], c[1])
+        g = h.register_pair_corr(s, t, c[0], c[1], fp)
+        assert (g["n_src"], g["n_tgt"], g["n_matched"], g["L"]) == (f["n_src"], f["n_tgt"], f["L"], 5000)
+        _same_back_end(g, dict(b, L=5000))
+        _same(g, qo16.solve(c[0], c[1]))
+        g0 = h.register_pair_corr(s, t, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), fp)
+        assert g0["status"] == ql.QTR_ERR_CLIQUE_TOO_SMALL and not g0["valid"] and g0["n_src"] == f["n_src"]
+        big = synth.correspondences(9000, 0.05, seed=5, noise=0.1)
+        with pytest.raises(ql.QuatroHipError) as ei:
+            h.register_pair_corr(s, t, big[0], big[1], fp)
+        assert ei.value.code == ql.QTR_ERR_CAPACITY
+        with pytest.raises(ql.QuatroHipError):
+            h.register_pair_corr(np.zeros((0, 4), np.float32), t, c[0], c[1], fp)
+    finally:
+        h.close()
