@@ -3060,8 +3060,17 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
       if (hcore && !hc_sweeps) {
         // one resident workgroup per compute unit at most (they wait for one another); a group of pairs shares the device
         int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
-        if (G > 1) nwg = max(8, min(nwg, hca_max_workgroups() / min(G, 4)));
         nwg = max(1, min(nwg, hca_max_workgroups() / t_hca_share));
+        if (G > 1) {
+          // A group of pairs: an iteration of a workgroup is one snapshot round trip (~1.2 us, whatever it owns) plus its
+          // rows (~0.6 us per sixteen), so the device does the most work per microsecond when ALL pairs of the launch are
+          // resident (or nearly) with few, large workgroups each.  Measured on 256 composite pairs (L = 5000, two lanes of
+          // sixteen pairs), registrations/s by workgroups per pair: 64 -> 4408, 32 -> 4828, 16 -> 4887, 8 -> 4797, 4 -> 3708
+          // (95 us of k_hcore_async per pair at 64, profiles/r4a_batch_kernel_stats.txt).
+          int per_pair = max(16, hca_max_workgroups() / (t_hca_share * G));
+          if (const char* e = QTR_ENGINE_ENV("QTR_HCA_GROUP_WGS")) per_pair = max(1, atoi(e));
+          nwg = max(1, min(nwg, per_pair));
+        }
         const int Lp = (L + 63) & ~63, R = (L + nwg - 1) / nwg;
         const int Rp = (R + 3) & ~3;
         const size_t fixed = (size_t)2 * Lp + (size_t)4 * (Rp + 4) + (size_t)4 * Rp;
