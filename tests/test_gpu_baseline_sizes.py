@@ -584,3 +584,45 @@ def test_single_call_composite_equals_the_two_stage_calls_and_the_batched_entry(
             h.register_pair_corr(np.zeros((0, 4), np.float32), t, c[0], c[1], fp)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("host_mem", [True, False])
+def test_batch_long_list_fallback_with_given_correspondences_and_preprocessed_input(qo16, host_mem):
+    """A fresh handle's batch chains leave k2_neighbors_big out until a cloud needs it; the pair that does is registered on
+    its own slot — on the CLOUDS THE GROUP'S VOXEL GRID READ and on the caller's correspondences when it brought some (the
+    fallback of round 3 went back to the descriptor's raw scans and the matcher's own list).  Dense patches at a 5 cm
+    leaf force the fallback; the pair brings 1500 correspondences; host and device memory."""
+    s = _near_field_patch(30000, 3, 5.0)
+    R = synth.yaw_matrix(0.3)
+    t = s.copy()
+    t[:, :3] = (s[:, :3].astype(np.float64) @ R.T + np.array([0.4, -0.2, 0.05])).astype(np.float32)
+    t[:, :3] += np.random.default_rng(9).normal(0, 0.002, (t.shape[0], 3)).astype(np.float32)
+    c = synth.correspondences(1500, 0.1, seed=3, noise=0.1)
+    s9, t9, _ = synth.kitti64_pair(1)
+    fp = ql.default_frontend_params(seed=2, voxel_size=0.05)
+    lim = dict(max_points=65536, max_voxels=32768, max_corr=16384, max_long_neighbors=24 << 20)
+    h1 = ql.Handle(0, **lim)
+    try:
+        whole = h1.register_pair(s, t, fp)      # (switches h1 to long lists on the way)
+        back = h1.solve(c[0], c[1])
+    finally:
+        h1.close()
+    hb = ql.Handle(0, n_slots=4, **lim)           # fresh: its first chains run without the long-list launch
+    try:
+        if host_mem:
+            got = hb.register_batch([(s, t, 2, c[0], c[1]), (s, t, 2)], fp)
+        else:
+            import torch
+            dev = torch.device("cuda", 0)
+            it = {"src": torch.from_numpy(s).to(dev), "tgt": torch.from_numpy(t).to(dev), "fp": fp,
+                  "cs": torch.from_numpy(c[0]).to(dev), "ct": torch.from_numpy(c[1]).to(dev)}
+            torch.cuda.synchronize()
+            got = hb.register_batch_dev([it], ql.demo_params(), fp, corr=True) + hb.register_batch_dev([it], ql.demo_params(), fp)
+    finally:
+        hb.close()
+    assert (got[0]["n_src"], got[0]["n_tgt"], got[0]["L"]) == (whole["n_src"], whole["n_tgt"], 1500)
+    assert got[0]["valid"] == back["valid"] and np.array_equal(got[0]["T"], back["T"])
+    assert (got[1]["n_src"], got[1]["n_tgt"], got[1]["L"]) == (whole["n_src"], whole["n_tgt"], whole["L"])
+    assert np.array_equal(got[1]["T"], whole["T"])
+    if host_mem:
+        assert np.array_equal(got[0]["clique"], back["clique"]) and np.array_equal(got[1]["clique"], whole["clique"])

@@ -80,3 +80,47 @@ def test_library_gather_across_three_processes_sharing_one_gpu(tmp_path):
                            os.path.join(ROOT, "tests", "mock", "mock_rccl.cpp"), "-o", so, "-lrt"])
     world = 3
     _check(world, _run_ranks(world, [0] * world, tmp_path, {"QTR_RCCL_LIB": so}))
+
+
+def test_two_processes_solving_side_by_side_stay_correct_and_bounded(tmp_path):
+    """k_hcore_async's workgroups wait for one another and want a compute unit each: two PROCESSES (two handles that know
+    nothing of each other) solving L = 5000 back to back on one GPU can leave both launches partly resident.  The
+    residency timeout (2 ms) then hands the pair to the peeling workgroup: every result stays the oracle's, and no solve
+    takes anywhere near the seconds the round-3 kernel waited."""
+    code = r'''
+import sys, time, json, numpy as np
+sys.path.insert(0, %r)
+import torch
+from quatro_amd import lib as ql, synth
+h = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=8192)
+s, t, _, _ = synth.correspondences(5000, 0.05, seed=int(sys.argv[1]), noise=0.1)
+first = h.solve(s, t)
+worst, same = 0.0, True
+t_end = time.time() + 6.0
+n = 0
+while time.time() < t_end:
+    t0 = time.perf_counter()
+    r = h.solve(s, t)
+    worst = max(worst, time.perf_counter() - t0)
+    same = same and np.array_equal(r["T"], first["T"]) and np.array_equal(r["clique"], first["clique"])
+    n += 1
+st = h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+json.dump({"n": n, "worst_ms": 1e3 * worst, "same": bool(same), "clique": int(first["clique"].size),
+           "T": first["T"].tolist()}, open(sys.argv[2], "w"))
+h.close()
+''' % ROOT
+    outs = [os.path.join(str(tmp_path), f"p{i}.json") for i in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", code, "7", outs[i]], cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for i in range(2)]
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+    res = [json.load(open(f)) for f in outs]
+    from oracle import oracle as qo
+    from quatro_amd import synth
+    s, t, _, _ = synth.correspondences(5000, 0.05, seed=7, noise=0.1)
+    o = qo.solve(s, t)
+    for r in res:
+        assert r["same"] and r["n"] > 50
+        assert r["clique"] == o["clique"].size and np.array_equal(np.array(r["T"]), o["T"])
+        assert r["worst_ms"] < 250.0, r   # (round 3: a partly resident pair spun for seconds before it fell back)
