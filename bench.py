@@ -120,7 +120,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--nn-event-stride", type=int, default=5,
                     help="every n-th step of the timed region carries the nearest-neighbour launches' event pairs (1 = all)")
-    ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,cpp,segment,patchwork",
+    ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,cpp,rawbatch,segment,patchwork",
                     help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`); "
                          "`refdense` adds the reference's own back-end text at L = 20000 on the CPU (minutes, > 16 GB)")
     ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
@@ -326,6 +326,8 @@ def main() -> None:
         extra["solver_L5000_leg"] = solver_leg(args, torch, ql, synth, h, prm, dev, 5000)
     if "dense" in legs and rank == 0 and world == 1:
         extra.update(dense_legs(args, torch, ql, synth, prm, dev, local_rank))
+    if "rawbatch" in legs and rank == 0 and world == 1:
+        extra["raw_batch_leg"] = raw_batch_leg(args, torch, ql, synth, prm, dev, local_rank)
     if "cpp" in legs and composite and rank == 0 and world == 1:
         extra["cpp_driver_leg"] = cpp_driver_leg(args, pool, LC)
     if "connected" in legs and rank == 0 and world == 1:
@@ -598,6 +600,31 @@ def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
     out["what"] = ("qtr_register_pair, one call per registration, the matcher's own correspondences into the back end "
                    "(no generator in between)")
     return out
+
+
+def raw_batch_leg(args, torch, ql, synth, prm, dev, device_index):
+    """The demo's WHOLE sequence per pair (examples/run_global_registration.cpp:136-160,206-246) batched: raw 64-beam sweeps
+    with their ground returns -> PatchWork::estimate_ground -> ImageProjection::segmentCloud -> voxel grid -> FPFH ->
+    matching -> Quatro, through qtr_set_batch_preprocess + qtr_submit_batch.  The two raw-sweep stages run for all pairs
+    of a chunk side by side (one slot each), the rest as launch chains over the group."""
+    scans = [torch.from_numpy(synth.kitti64_raw_scan(i)[0]).to(dev) for i in range(4)]
+    B = 64
+    items = [{"src": scans[i % 4], "tgt": scans[(i + 1) % 4], "fp": ql.default_frontend_params(seed=i % 7)} for i in range(B)]
+    hb = ql.Handle(device_index, max_points=131072, max_voxels=32768, max_corr=8192, n_slots=args.batch_slots)
+    try:
+        hb.set_batch_preprocess()
+        hb.register_batch_dev(items[:32], prm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = hb.register_batch_dev(items, prm)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        hb.close()
+    return {"what": f"{B} raw-sweep pairs ({int(scans[0].shape[0])} points per sweep, ground included) through "
+                    "qtr_set_batch_preprocess + qtr_submit_batch", "pairs": B, "value": B / el, "unit": "registrations/s",
+            "ms_per_pair": 1e3 * el / B, "valid": int(sum(1 for r in res if r["valid"])),
+            "n_src_after_preprocessing_and_voxel_grid": int(res[0]["n_src"])}
 
 
 def cpp_driver_leg(args, pool, LC):

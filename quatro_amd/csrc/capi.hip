@@ -1043,12 +1043,11 @@ void qtr_pw_default_params(qtr_pw_params* p) {  // reference config/patchwork_pa
   p->num_thr = 4;
 }
 
-int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
-                  int cap_ground, int* n_ground, float* nonground_xyzw, int cap_nonground, int* n_nonground, int mem) {
-  Slot* sp = get_slot(h, slot);
-  if (!sp || !pw || !n_ground || !n_nonground || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
-  Slot& s = *sp;
-  *n_ground = *n_nonground = 0;
+// Ground segmentation of one scan in two halves, so that a batch can keep several slots' scans in flight: pw_begin
+// validates and enqueues (the two output counts follow the kernels into the slot's pinned words, s.ev[1] marks the end),
+// pw_end reads them once the stream has got there.
+static int pw_begin(qtr_handle* h, Slot& s, const float* xyz4, int P, const qtr_pw_params* pw, int mem) {
+  if (!pw || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
   // check_input_parameters_are_correct (:588-614) + what the kernels rely on
   bool ok = pw->num_zones >= 1 && pw->num_zones <= 4 && pw->num_thr >= 0 && pw->num_thr <= 8 && pw->num_iter >= 1 &&
             pw->num_lpr >= 1 && pw->min_range == pw->min_ranges[0] && pw->max_range > pw->min_range;
@@ -1115,10 +1114,25 @@ int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_p
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   QTR_HIP_TRY(h, patchwork_enqueue(s.fb, s.pwb, d_in, P, d, s.stream));
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, s.pwb.offs + 2 * 1024, 2 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  return QTR_OK;
+}
+static void pw_end(Slot& s, int* n_ground, int* n_nonground) {  // (after s.ev[1] has completed)
+  *n_ground = s.pinned_i32[0];
+  *n_nonground = s.pinned_i32[1];
+}
+
+int qtr_patchwork(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_pw_params* pw, float* ground_xyzw,
+                  int cap_ground, int* n_ground, float* nonground_xyzw, int cap_nonground, int* n_nonground, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !pw || !n_ground || !n_nonground || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_ground = *n_nonground = 0;
+  QTR_TRY(pw_begin(h, s, xyz4, P, pw, mem));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
-  const int ng = s.pinned_i32[0], nn = s.pinned_i32[1];
+  int ng = 0, nn = 0;
+  pw_end(s, &ng, &nn);
   *n_ground = ng;
   *n_nonground = nn;
   if ((ground_xyzw && ng > cap_ground) || (nonground_xyzw && nn > cap_nonground)) {
@@ -1173,15 +1187,9 @@ int qtr_ip_default_params(const char* lidar, const char* nbr, qtr_ip_params* p) 
   return QTR_OK;
 }
 
-int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
-                      int cap_valid, int* n_valid, float* outl_xyzi, int cap_outl, int* n_outl, int* n_segments,
-                      int* labelmat, int mem) {
-  Slot* sp = get_slot(h, slot);
-  if (!sp || !ip || !n_valid || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
-  Slot& s = *sp;
-  *n_valid = 0;
-  if (n_outl) *n_outl = 0;
-  if (n_segments) *n_segments = 0;
+// (the same split as pw_begin / pw_end: three counts — valid points, outliers, segments — into the slot's pinned words)
+static int seg_begin(qtr_handle* h, Slot& s, const float* xyz4, int P, const qtr_ip_params* ip, int mem) {
+  if (!ip || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
   if (ip->n_scan < 1 || ip->n_scan > 64 || ip->horizon_scan < 4 || ip->horizon_scan > 8192 || !(ip->ang_res_x > 0) ||
       !(ip->ang_res_y > 0) || ip->neighbor_mode < 0 || ip->neighbor_mode > 2) {
     snprintf(h->err, sizeof(h->err), "[ImageProjection]:Check your paramter. (n_scan <= 64, horizon_scan <= 8192)");
@@ -1223,9 +1231,23 @@ int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const q
   QTR_HIP_TRY(h, hipEventRecord(s.ev[0], s.stream));
   int* d_tot = s.seg.blk + 3 * ((NP + 1023) / 1024 + 1);
   QTR_HIP_TRY(h, segment_enqueue(s.seg, d_in, P, d, d_tot, s.stream));
-  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, d_tot, 3 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+  return QTR_OK;
+}
+
+int qtr_segment_cloud(qtr_handle* h, int slot, const float* xyz4, int P, const qtr_ip_params* ip, float* valid_xyzl,
+                      int cap_valid, int* n_valid, float* outl_xyzi, int cap_outl, int* n_outl, int* n_segments,
+                      int* labelmat, int mem) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp || !ip || !n_valid || P < 0 || (P > 0 && !xyz4)) return QTR_ERR_BAD_ARG;
+  Slot& s = *sp;
+  *n_valid = 0;
+  if (n_outl) *n_outl = 0;
+  if (n_segments) *n_segments = 0;
+  QTR_TRY(seg_begin(h, s, xyz4, P, ip, mem));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
+  const int NP = ip->n_scan * ip->horizon_scan;
   const int nv = s.pinned_i32[0], no = s.pinned_i32[1], nseg = s.pinned_i32[2];
   *n_valid = nv;
   if (n_outl) *n_outl = no;
@@ -1807,6 +1829,96 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
   std::vector<FrontBufs*> F;
   std::vector<const float4*> raws;
   std::vector<int> Ps;
+  // The demo's STEP 2 and 3 on raw sweeps (reference examples/run_global_registration.cpp:136-160): per scan
+  // PatchWork::estimate_ground -> non-ground points -> ImageProjection::segmentCloud -> valid segments.  Both stages hand a
+  // count to the next one through the host, so a scan is a chain of four host-visible steps — run for ALL pairs of the
+  // chunk side by side, every pair on its own slot's stream and arenas (target first, then source: the two scans of a pair
+  // share the slot), the host advancing whichever slot's step has finished.  (Rounds 2-3 ran them pair after pair with a
+  // blocking read-back per step: a chunk of sixteen raw pairs waited 64 times.)  The valid segments land in the slot's
+  // staging buffers, which are the voxel grid's input; the lane's stream waits for the copies, not the host.
+  struct PreScan {
+    int stage = 0;  // 0 start, 1 ground segmentation of scan c in flight, 2 range-image stage in flight, 3 done
+    int c = 1;      // scan being processed: 1 target, then 0 source
+    int status = QTR_OK;
+    int n[2] = {0, 0};  // valid points of source / target
+  };
+  std::vector<PreScan> pre((size_t)ln.count);
+  if (h->pre_on) {
+    int open = 0;
+    for (int g = 0; g < ln.count; ++g) {
+      const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+      const bool usable = pair_has_scans(pd) && pd.src_raw4 && pd.tgt_raw4 && pd.n_src > 0 && pd.n_tgt > 0 &&
+                          pd.n_src <= h->lim.max_points && pd.n_tgt <= h->lim.max_points;
+      if (!usable) pre[(size_t)g].stage = 3;  // (refused by the checks below, or a pair without scans)
+      else ++open;
+    }
+    unsigned long spins = 0;
+    while (open > 0) {
+      bool moved = false;
+      for (int g = 0; g < ln.count; ++g) {
+        PreScan& q = pre[(size_t)g];
+        if (q.stage == 3) continue;
+        const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
+        Slot& s = h->slots[ln.first_slot + g];
+        int rc = QTR_OK;
+        if (q.stage == 0) {
+          rc = pw_begin(h, s, q.c ? pd.tgt_raw4 : pd.src_raw4, q.c ? pd.n_tgt : pd.n_src, &h->pre_pw, J.mem);
+          q.stage = 1;
+          moved = true;
+        } else {
+          const hipError_t e = hipEventQuery(s.ev[1]);
+          if (e == hipErrorNotReady) continue;
+          if (e != hipSuccess) {
+            snprintf(h->err, sizeof(h->err), "batch pre-processing: %s", hipGetErrorString(e));
+            return QTR_ERR_HIP;
+          }
+          moved = true;
+          if (q.stage == 1) {  // ground removed: its non-ground points go through the range image
+            int ng = 0, nn = 0;
+            pw_end(s, &ng, &nn);
+            rc = seg_begin(h, s, (const float*)s.pwb.out_n, nn, &h->pre_ip, QTR_MEM_DEVICE);
+            q.stage = 2;
+          } else {  // valid segments known: into the staging buffer; next scan, or done
+            const int nv = s.pinned_i32[0];
+            q.n[q.c] = nv;
+            if (nv > h->lim.max_points) rc = QTR_ERR_CAPACITY;
+            else if (nv > 0)
+              // (on the slot's own stream: the next scan's stages, which reuse the buffers this copy reads, queue up behind it)
+              QTR_HIP_TRY(h, hipMemcpyAsync(q.c ? s.in_tgt : s.in_src, s.seg.out_valid, (size_t)nv * 16, hipMemcpyDeviceToDevice,
+                                            s.stream));
+            if (rc == QTR_OK && q.c == 1) {
+              q.c = 0;
+              q.stage = 0;
+            } else {
+              if (rc == QTR_OK) {  // the group's chain (lane stream) reads the staging buffers: it waits for this slot
+                QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
+                QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, s.ev[1], 0));
+              }
+              q.stage = 3;
+              --open;
+            }
+          }
+        }
+        if (rc == QTR_ERR_HIP) return rc;
+        if (rc != QTR_OK && q.stage != 3) {  // this pair's own failure (capacity, a scan the stage refuses)
+          q.status = rc;
+          q.stage = 3;
+          --open;
+        } else if (rc != QTR_OK) {
+          q.status = rc;
+        }
+      }
+      if (!moved) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xffffff) == 0) {  // nothing moved for a long while: a lost device must not hang the host
+          for (int g = 0; g < ln.count; ++g)
+            if (pre[(size_t)g].stage != 3) QTR_HIP_TRY(h, hipStreamSynchronize(h->slots[ln.first_slot + g].stream));
+        }
+      } else {
+        spins = 0;
+      }
+    }
+  }
   for (int g = 0; g < ln.count; ++g) {
     const qtr_pair_desc& pd = J.pairs[ln.first_pair + g];
     Slot& s = h->slots[ln.first_slot + g];
@@ -1845,34 +1957,19 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
     const float4 *d_s = (const float4*)pd.src_raw4, *d_t = (const float4*)pd.tgt_raw4;
     int P_s = pd.n_src, P_t = pd.n_tgt;
     if (h->pre_on) {
-      // The demo's STEP 2 and 3 on raw sweeps (reference examples/run_global_registration.cpp:136-160):
-      // PatchWork::estimate_ground -> non-ground points -> ImageProjection::segmentCloud -> valid segments, per scan, on
-      // this pair's slot (these stages read their counts back, so they run pair by pair; the chains behind them are
-      // shared by the group).  The valid segments land in the slot's staging buffers and are the voxel grid's input.
-      int status = QTR_OK;
-      // (target first: the stages stage a host-resident scan in in_src, which is where the SOURCE's result goes last)
-      for (int c = 1; c >= 0 && status == QTR_OK; --c) {
-        const float* raw = c == 0 ? pd.src_raw4 : pd.tgt_raw4;
-        const int P = c == 0 ? pd.n_src : pd.n_tgt;
-        float4* stage = c == 0 ? s.in_src : s.in_tgt;
-        int ng = 0, nn = 0, nv = 0;
-        status = qtr_patchwork(h, ln.first_slot + g, raw, P, &h->pre_pw, nullptr, 0, &ng, nullptr, 0, &nn, J.mem);
-        if (status == QTR_OK)
-          status = qtr_segment_cloud(h, ln.first_slot + g, (const float*)s.pwb.out_n, nn, &h->pre_ip, nullptr, 0, &nv, nullptr,
-                                     0, nullptr, nullptr, nullptr, QTR_MEM_DEVICE);
-        if (status == QTR_OK && nv > h->lim.max_points) status = QTR_ERR_CAPACITY;
-        // (on the slot's own stream: the next scan's stages, which reuse the buffers this copy reads, queue up behind it)
-        if (status == QTR_OK && nv > 0)
-          QTR_HIP_TRY(h, hipMemcpyAsync(stage, s.seg.out_valid, (size_t)nv * 16, hipMemcpyDeviceToDevice, s.stream));
-        (c == 0 ? P_s : P_t) = nv;
-      }
-      if (status == QTR_ERR_HIP) return status;
-      QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));  // the group's chain (lane stream) reads the staging buffers
-      if (status == QTR_OK && (P_s <= 0 || P_t <= 0)) status = QTR_ERR_BAD_ARG;  // nothing but ground: an empty cloud
-      if (status != QTR_OK) {
-        batch_fail_pair(h, ln.first_pair + g, status);
+      // (the sweeps were pre-processed above, all slots of the chunk side by side: the valid segments are in the slot's
+      // staging buffers, the lane's stream already waits for the copies)
+      const PreScan& q = pre[(size_t)g];
+      if (q.status == QTR_OK && (q.n[0] <= 0 || q.n[1] <= 0)) {  // nothing but ground: an empty cloud
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_BAD_ARG);
         continue;
       }
+      if (q.status != QTR_OK) {
+        batch_fail_pair(h, ln.first_pair + g, q.status);
+        continue;
+      }
+      P_s = q.n[0];
+      P_t = q.n[1];
       d_s = s.in_src;
       d_t = s.in_tgt;
     } else if (J.mem == QTR_MEM_HOST) {

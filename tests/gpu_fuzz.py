@@ -34,6 +34,7 @@ if not DRY:
     h.set_clique_time_limit(5.0)
 qo.build()
 qo.set_threads(qo.max_threads())
+hb = None  # a second handle with eight slots, for the batched cases
 bad, n_cases, t_end = 0, 0, time.time() + budget
 faulthandler.dump_traceback_later(int(budget) + 90, exit=True)  # a hung kernel must not eat the GPU budget
 
@@ -65,7 +66,7 @@ def same_solution(g, o):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["solve", "solve", "clique", "pair", "match", "match", "patchwork", "segment", "gnc3", "cote"])
+    kind = rng.choice(["solve", "solve", "clique", "pair", "match", "match", "patchwork", "segment", "gnc3", "cote", "batch"])
     n_cases += 1
     print(f"case {n_cases} {kind}", file=sys.stderr, flush=True)
     try:
@@ -97,6 +98,30 @@ while time.time() < t_end:
                     report(kind, desc, f"NN table differs in {int((g_ij != nn_ij).sum())} of {nn_ij.size} rows")
                 elif not np.array_equal(cg, co):
                     report(kind, desc, f"correspondences {cg.shape[0]} vs {co.shape[0]}")
+        elif kind == "batch":
+            # correspondence-only pair descriptors through qtr_submit_batch: groups of mixed sizes (the group picks kernel
+            # variants from its largest pair; above 8192 correspondences the strip form of the graph kernel), small noise
+            # bounds (the binary32 screen narrows, then switches off), against the oracle pair by pair
+            if hb is None and not DRY:
+                hb = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=12288, n_slots=8)
+            nb_ = float(rng.choice([0.3, 0.3, 0.05, 0.004]))
+            sizes = [int(rng.choice([0, 2, 64, 65, 300, 1279, 1281, 2500, 5000, 8200, 9000])) for _ in range(int(rng.integers(2, 7)))]
+            sets = []
+            for L in sizes:
+                if L == 0:
+                    sets.append((np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)))
+                else:
+                    c = synth.correspondences(max(L, 3), float(rng.choice([0.03, 0.2, 1.0])), seed=int(rng.integers(1 << 30)),
+                                              noise=nb_ / 3)
+                    sets.append((c[0][:L].copy(), c[1][:L].copy()))
+            desc = f"sizes={sizes} noise_bound={nb_}"
+            outs = [qo.solve(a_, b_, qo.default_params(noise_bound=nb_)) for a_, b_ in sets]
+            if not DRY:
+                got = hb.register_batch([(None, None, 0, a_, b_) for a_, b_ in sets], params=ql.demo_params(noise_bound=nb_))
+                for i, (g, o) in enumerate(zip(got, outs)):
+                    w = same_solution(dict(g, rot_inliers=None), o) if "clique" in g else f"status {g['status']}"
+                    if w:
+                        report(kind, desc + f" pair {i}", w)
         elif kind == "solve":
             L = int(rng.choice([2, 3, 5, 17, 64, 65, 300, 1281, 2000, 4097, 7000]))
             frac = float(rng.choice([0.0, 0.02, 0.1, 0.5, 0.9, 1.0]))

@@ -340,6 +340,7 @@ def test_batch_on_raw_sweeps_runs_the_demo_sequence(qo16):
     examples/run_global_registration.cpp:136-160, 206-246) — against the same sequence through the oracle."""
     scans = [synth.kitti64_raw_scan(i)[0] for i in range(3)]
     pairs = [(scans[0], scans[1], 4), (scans[1], scans[2], 5), (scans[2], scans[0], 6)]
+    # (four slots = two lanes of two: the pre-processing of a chunk's pairs runs side by side, one slot each)
     ref = []
     for a, b, seed in pairs:
         clouds = [qo16.segment_cloud(qo16.patchwork(raw)["nonground"])["valid"] for raw in (a, b)]
@@ -356,6 +357,39 @@ def test_batch_on_raw_sweeps_runs_the_demo_sequence(qo16):
         assert (g["n_src"], g["n_tgt"], g["L"]) == (o["n_src"], o["n_tgt"], o["L"]), i
         _same(g, o)
     assert plain[0]["n_src"] != got[0]["n_src"]
+
+
+def test_batch_on_raw_sweeps_many_pairs_in_flight_and_a_scan_that_is_all_ground(qo16):
+    """Eight slots: the raw-sweep stages of four pairs per lane advance side by side (a host-driven step per scan and
+    stage).  Every record equals the same pair registered alone through the same entry; a sweep that is nothing but ground
+    fails in its own record (QTR_ERR_BAD_ARG: an empty cloud) without disturbing its neighbours; host memory."""
+    scans = [synth.kitti64_raw_scan(i)[0] for i in range(3)]
+    flat = np.zeros((20000, 4), dtype=np.float32)   # a ground plane at the sensor's height and nothing else
+    g = np.random.default_rng(3)
+    flat[:, 0] = g.uniform(-30, 30, 20000)
+    flat[:, 1] = g.uniform(-30, 30, 20000)
+    flat[:, 2] = -1.723 + g.normal(0, 0.01, 20000)
+    pairs = [(scans[i % 3], scans[(i + 1) % 3], 10 + i) for i in range(7)]
+    pairs.insert(3, (scans[0], flat, 99))
+    h1 = ql.Handle(0, n_slots=2, max_points=131072, max_voxels=32768, max_corr=8192)
+    hb = ql.Handle(0, n_slots=8, max_points=131072, max_voxels=32768, max_corr=8192)
+    try:
+        h1.set_batch_preprocess()
+        hb.set_batch_preprocess()
+        alone = [h1.register_batch([p])[0] for p in pairs]
+        got = hb.register_batch(pairs)
+    finally:
+        h1.close()
+        hb.close()
+    assert got[3]["status"] == ql.QTR_ERR_BAD_ARG and alone[3]["status"] == ql.QTR_ERR_BAD_ARG
+    for i, (a, b) in enumerate(zip(got, alone)):
+        if i == 3:
+            continue
+        assert (a["n_src"], a["n_tgt"], a["L"]) == (b["n_src"], b["n_tgt"], b["L"]), i
+        assert np.array_equal(a["clique"], b["clique"]) and np.array_equal(a["T"], b["T"]), i
+    o = qo16.register_pair(qo16.segment_cloud(qo16.patchwork(pairs[5][0])["nonground"])["valid"],
+                           qo16.segment_cloud(qo16.patchwork(pairs[5][1])["nonground"])["valid"], seed=pairs[5][2])
+    _same(got[5], o)
 
 
 # ------------------------------------------------------------------------------------------------
