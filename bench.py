@@ -4,26 +4,28 @@ max-clique -> GNC-TLS -> COTE) on synthetic KITTI-64-shaped scan pairs resident 
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run, one rank per GPU.  A step = one registration at the size BASELINE.json's metric is quoted on
-(configs[1]: a single KITTI-64 pair, ~5k correspondences, whole path on the GPU), timed as ONE step:
-  1. qtr_feature_pair on a synthetic 64-beam scan pair (n ~ 16-18 k voxels per cloud at 0.3 m): voxel grid x2, FPFH x2,
+(configs[1]: a single KITTI-64 pair, ~5k correspondences, whole path on the GPU), timed as ONE step and, since round 4,
+issued as ONE call — qtr_register_pair_corr:
+  1. the front end of a synthetic 64-beam scan pair (n ~ 16-18 k voxels per cloud at 0.3 m): voxel grid x2, FPFH x2,
      reciprocal 33-D matching with cross check and tuple test — the reference's voxelize + FPFHManager::setFeaturePair;
-  2. qtr_solve on 5000 synthetic correspondences with 5 % planted inliers — Quatro::computeTransformation at the
-     metric's "~5k corr".
+  2. the back end on 5000 synthetic correspondences with 5 % planted inliers — Quatro::computeTransformation at the
+     metric's "~5k corr" — enqueued when the matcher's counters arrive and run after the front end.
 The step is a COMPOSITE because FPFH matching on synthetic scans does not produce 5000 correspondences for any
 physically plausible scene: the mutual-NN + tuple test keeps ~250-650 (DESIGN.md section 5 and
 tests/probe/synth_L_probe.py list what was tried: baselines from 0 to 10 m, porous / solid clutter, near facades, range
 noise down to 5 mm; only a jittered COPY of the same sweep gets there, and that is not a second scan).  So the back end
 of the step is fed from the solver-only generator SURVEY.md section 8(d) defines for this configuration, not from the
-matcher's output; `--workload pair` times qtr_register_pair on the scan pair alone (the previous rounds' headline, now
-the `whole_pair_leg`).
+matcher's output; `--workload pair` times qtr_register_pair on the scan pair alone (the `whole_pair_leg`), and the
+`connected_leg` times registrations whose back end runs on thousands of the matcher's OWN correspondences.
 Every rank times exactly K steps: the pair ids [0, N*K) are block-partitioned over the ranks
 (quatro_amd.dist.shard_range, the partition of BASELINE configs[3]), rank r registers ids [r*K, (r+1)*K) one at a time —
 per-GPU work is fixed as N grows ("weak" scaling) and `value` is the whole job, N*K registrations over the slowest
 rank's time.  Pair id -> synthetic pair is id % pool.  Pairs are independent, so there is no data-path collective; the
 only exchange is the gather of the fixed-size result records (RCCL) after the timed region plus the barrier /
 max-over-ranks of the contract.  For N > 1 the line also carries `sharded_leg`: configs[3] itself — a FIXED set of 4096
-pair ids block-partitioned over the ranks and streamed through the batched entry points (strong scaling).  Prints ONE
-JSON line on rank 0.
+pair ids, each the headline's unit of work (scan pair + 5000 given correspondences), block-partitioned over the ranks,
+streamed through the batched entry points (strong scaling) and gathered through the LIBRARY's RCCL path
+(qtr_comm_init / qtr_gather_results_v).  Prints ONE JSON line on rank 0.
 
 Objects in the line next to the contract's keys:
   roofline      — dominant kernel k_nn_f16: the 33-D distance matrix nb' - 2 a.b evaluated on the f16 matrix pipe with
@@ -37,13 +39,17 @@ Objects in the line next to the contract's keys:
                   (`frac_on_f16_pipe`), over the measured time per step.
   cpu_baseline  — the CPU oracle (a port: the reference cannot be built here; brute-force NN instead of FLANN
                   kd-trees) running the SAME composite step on this box's host cores, swept over OMP thread counts on
-                  a bounded sample; `value` is the best setting, `omp4` the reference README's 4-thread setting.
+                  a bounded sample; `value` is the best setting, `omp4` the reference README's 4-thread setting.  At
+                  N > 1 too (rank 0's host, after the ranks have parted).
   cpu_reference_text — the reference's OWN back-end text (oracle/_ref/libref_solver.so) on the step's 5000
                   correspondences, one thread.  Reported baselines, not the target.
   parity_vs_oracle — every pool pair: front end (counts, correspondence list, keypoints), back end (clique, rotation /
-                  final inliers, transform) and the scan pair's whole path against the oracle.
-  whole_pair_leg, solver_L5000_leg, batch256_leg, dense_*_leg, sharded_leg — the other configurations, never part of
-                  `value`.
+                  final inliers, transform), the timed entry point's own record and the scan pair's whole path against
+                  the oracle.
+  repeat_regions — the timed region four more times after the contract's one: how noisy the box is.
+  whole_pair_leg, connected_leg, solver_L5000_leg, batch256_leg (composite pairs; `scan_pairs` = the scans alone),
+  raw_batch_leg (raw sweeps through Patchwork + range image + the rest, batched), cpp_driver_leg (the step from a
+  compiled caller), dense_*_leg, sharded_leg — the other configurations, never part of `value`.
 """
 from __future__ import annotations
 

@@ -3075,7 +3075,18 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         const int Rp = (R + 3) & ~3;
         const size_t fixed = (size_t)2 * Lp + (size_t)4 * (Rp + 4) + (size_t)4 * Rp;
         // the pool of neighbour lists takes what the compute unit's LDS has left (the workgroups run one per unit anyway)
-        const int pool_entries = (int)(((size_t)150 * 1024 - fixed) / 2) & ~7;
+        size_t lds_budget = (size_t)150 * 1024;
+        if (G > 1) {
+          // In a group the launch of one lane shares the device with the OTHER lane's chain: a workgroup that claims the
+          // unit's whole LDS keeps every kernel that needs some out of its unit for as long as it runs (k_rank_sort of the
+          // other lane showed 626 us in the trace, all of it waiting for a unit).  Its rows' lists need ~2 bytes per edge
+          // endpoint; what does not fit the smaller pool keeps its bit row (slower, same result).  256 composite pairs,
+          // registrations/s by budget: 150 KB 4771, 128 KB 4833, 104 KB 4854, 88 KB 4891, 72 KB 4886.
+          lds_budget = (size_t)88 * 1024;
+          if (const char* e = QTR_ENGINE_ENV("QTR_HCA_GROUP_LDS_KB")) lds_budget = (size_t)max(32, atoi(e)) * 1024;
+          lds_budget = max(lds_budget, fixed + 4096);
+        }
+        const int pool_entries = (int)((lds_budget - fixed) / 2) & ~7;
         if (!hcore_prepared) LAUNCH_SV(k_hcore_async_init, a, dim3((max(L, 4096) + 255) / 256, 1, G), dim3(256), 0, stream);
         LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries);
         after_async = true;
