@@ -405,12 +405,8 @@ static int create_impl(qtr_handle* h) {
       for (int q = 0; q < 4; ++q) s.fb.ev_nn[q] = keep[q];
       s.fb.nn_events = h->stage_events;
     }
-    for (int c = 0; c < 2; ++c) {  // long-list arenas (lists of more than QTR_KMAX neighbours)
-      CloudBufs& cb = s.fb.cloud[c];
-      cb.nbr_big_cap = h->lim.max_long_neighbors;
-      QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_idx, (size_t)cb.nbr_big_cap * 4));
-      QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_d2, (size_t)cb.nbr_big_cap * 4));
-    }
+    // (the long-list arenas — lists of more than QTR_KMAX neighbours: 8 bytes x max_long_neighbors per cloud, 134 MB per
+    // slot at the defaults — are allocated the first time a chain with k2_neighbors_big is enqueued: ensure_long_arenas)
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_src, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.in_tgt, (size_t)h->lim.max_points * 16));
     QTR_HIP_TRY(h, hipMalloc((void**)&s.m_src, (size_t)h->lim.max_corr * 16));
@@ -614,6 +610,19 @@ static void compute_times(Slot& s) {
   if (hipEventElapsedTime(&ms, s.ev[0], s.ev[4]) == hipSuccess) s.times.total = ms;
   (void)hipGetLastError();
   s.times_pending = 0;
+}
+
+// The long-list arenas of a slot's two clouds, allocated on first need: voxel-grid centroids at the demo's leaf never have
+// more than QTR_KMAX neighbours, so most handles never pay for them.
+static int ensure_long_arenas(qtr_handle* h, Slot& s) {
+  for (int c = 0; c < 2; ++c) {
+    CloudBufs& cb = s.fb.cloud[c];
+    if (cb.nbr_big_idx && cb.nbr_big_d2) continue;
+    QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_idx, (size_t)h->lim.max_long_neighbors * 4));
+    QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_d2, (size_t)h->lim.max_long_neighbors * 4));
+    cb.nbr_big_cap = h->lim.max_long_neighbors;
+  }
+  return QTR_OK;
 }
 
 static Slot* get_slot(qtr_handle* h, int slot) {
@@ -1385,6 +1394,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
   {
     const int ns1[1] = {n};
     // an arbitrary cloud (dense mode: no voxel grid in front): lists of any length
+    QTR_TRY(ensure_long_arenas(h, s));
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 1, ns1, r_normal, r_fpfh, s.stream, true, false, true));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
@@ -1590,6 +1600,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
+    if (h->long_lists) QTR_TRY(ensure_long_arenas(h, s));
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists));
     if (!mean_first) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
@@ -2054,6 +2065,8 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     QTR_HIP_TRY(h, mean_enqueue_group(F.data(), G, n2.data(), &ln.stage, lead.stream2));  // beside the FPFH chain
     QTR_HIP_TRY(h, hipEventRecord(lead.ev[5], lead.stream2));
     ln.long_lists = h->long_lists;
+    if (ln.long_lists)
+      for (int g : ln.active) QTR_TRY(ensure_long_arenas(h, h->slots[ln.first_slot + g]));
     QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream,
                                       ln.long_lists));
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, lead.ev[5], 0));
