@@ -396,7 +396,9 @@ QTR_API int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long lo
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to
  * `bytes` bytes to host memory `dst`; returns the number of bytes the item holds, or <0 on error. */
 #define QTR_DBG_GRAPH_BITMAP 1   /* uint64[L][ceil(L/64)] adjacency, original labels */
-#define QTR_DBG_CORE 2           /* int32[L] core numbers */
+#define QTR_DBG_CORE 2           /* int32[L] core numbers: exact at or above QTR_DBG_SOLVER_STATE[29] (the floor of the last
+                                    solve, 0 = all exact; always 0 in the k-core heuristic mode), below it an upper bound
+                                    that is itself below the floor */
 #define QTR_DBG_PERM 3           /* int32[L] vertex id at each rank of the (core,id) order */
 #define QTR_DBG_NBR_OFFSETS 4    /* int32[n+1] CSR offsets of the sorted radius-neighbour lists (last qtr_fpfh) */
 #define QTR_DBG_NBR_INDEX 5      /* int32[...] neighbour indices */
@@ -411,7 +413,8 @@ QTR_API int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long lo
                                     [8],[9] rows sent to the exact NN re-check (dir 0/1), [10],[11] rows settled by the
                                     two-candidate exact compare */
 #define QTR_DBG_SOLVER_STATE 14  /* int32[32]: mc, best_r, pos, done, t0, ub, batch, max_core, n_edges2, clique rounds,
-                                    [10] k-core peeling rounds */
+                                    [10] k-core peeling rounds / iterations, [22] 1: the clique stage ran twice (second
+                                    time with exact core numbers), [29] floor of the core numbers (0: all exact) */
 QTR_API long long qtr_debug_fetch(qtr_handle* h, int slot, int what, void* dst, size_t bytes);
 
 /* Evaluates the shared deterministic math (include/qtr_math.h) ON THE DEVICE, for the test that pins

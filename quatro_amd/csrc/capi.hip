@@ -738,7 +738,8 @@ static int solve_device(qtr_handle* h, Slot& s, const float4* d_src, const float
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));  // k_finalize left the record and the state in the mailbox
   if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
     s.sb.mail_seq = ++s.seq;
-    QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128));
+    QTR_HIP_TRY(h, solver_continue(s.sb, d_src, d_tgt, L, *prm, s.stream, s.pinned_i32 + 128,
+                                   ((const SolverState*)(s.mail + MAIL_SOLVER + 64))->redo_cores));
     if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[4], s.stream));
     QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
   }
@@ -852,7 +853,8 @@ int qtr_max_clique(qtr_handle* h, int slot, const unsigned long long* adj, int L
   if (!((const SolverState*)(s.pinned_i32 + 128))->done) {
     qtr_params dummy;
     qtr_default_params(&dummy);
-    QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128));
+    QTR_HIP_TRY(h, solver_continue(s.sb, nullptr, nullptr, L, dummy, s.stream, s.pinned_i32 + 128,
+                                   ((const SolverState*)(s.pinned_i32 + 128))->redo_cores));
   }
   if (mode == QTR_INLIER_PMC_EXACT) {
     SolverState hs;
@@ -2202,7 +2204,8 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     } on_lane_stream(s, lead.stream);
     if (L > 0 && !((const SolverState*)(s.mail + MAIL_SOLVER + 64))->done) {  // rare: more clique rounds needed
       s.sb.mail_seq = ++s.seq;
-      QTR_HIP_TRY(h, solver_continue(s.sb, c_src, c_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128));
+      QTR_HIP_TRY(h, solver_continue(s.sb, c_src, c_tgt, L, J.prm, lead.stream, s.pinned_i32 + 128,
+                                     ((const SolverState*)(s.mail + MAIL_SOLVER + 64))->redo_cores));
       QTR_TRY(wait_mail(h, s, MAIL_SEQ_SOLVE, s.seq));
     }
     if (L > 0 && J.prm.inlier_selection_mode == QTR_INLIER_PMC_EXACT) {

@@ -16,7 +16,12 @@ struct SolverState {  // device resident; mirrored to pinned host memory between
   int max_core;
   int n_edges2;  // sum of degrees
   int rounds;
-  int pad[22];   // [0] k-core peeling rounds, [1..4] k_finalize phase clocks / 16, [6..11] COTE step clocks / 16
+  int pad[19];   // [0] k-core peeling rounds, [1..4] k_finalize phase clocks / 16, [6..11] COTE step clocks / 16,
+                 // [12] 1: the clique stage ran twice (second time with exact core numbers, see solver_continue)
+  int core_floor;  // k_hcore_async stopped lowering values below this (0: every core number is exact); the clique search then
+                   // runs with this many members as an injected lower bound, see k_rank_sort
+  int tainted;     // ... and a start was turned down by the |P| > mc rule while the bound was the injected one
+  int redo_cores;  // the search under the injected bound found nothing it can vouch for: the host runs the stage again, exact
 };
 
 struct SolverBufs {
@@ -80,7 +85,7 @@ hipError_t solver_init_attributes();
 hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,
                                 const int* L, const qtr_params& prm, ViewStage* stage, hipStream_t stream);
 hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                           hipStream_t stream, int* pinned_state);
+                           hipStream_t stream, int* pinned_state, int redo_cores);
 hipError_t solver_refinalize(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
                              hipStream_t stream);
 // clique search alone (qtr_max_clique): enqueue, [solver_continue(src = nullptr) if !done], finish

@@ -78,6 +78,9 @@ typedef float gb_f2 __attribute__((ext_vector_type(2)));
 // control words of k_hcore_async (below) in V.perm, cleared here when the graph is built for it
 #define HCA_CTL_FAILED 2   // ints of V.perm: [2] failed, [3] iterations of the slowest workgroup,
 #define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
+#define HCA_CTL_FLOOR 4    // [4] (floor << 1) | decided: values below the floor are not lowered any further,
+#define HCA_CTL_FROZE 5    // [5] some row was actually left alone for that reason
+#define HCA_FLOOR_MIN 8
 #define HCA_MAXWG 512      // (one workgroup per compute unit: 256 on this part)
 #define HCA_CTL_VER 64
 #define HCA_CTL_DONE (64 + HCA_MAXWG)
@@ -764,7 +767,8 @@ __global__ __launch_bounds__(256) void k_hcore_async_init(ViewExt<SolverView> x,
   if (gi < HCA_CTL_DONE + HCA_MAXWG) V.perm[gi] = 0;
 }
 template <bool EXT>
-__global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int pool_entries) {
+__global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView> x, SolverView one, int pool_entries,
+                                                              int allow_floor) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L, W = V.W;
   if (L <= 0) return;
@@ -864,6 +868,25 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     }
   }
   unsigned myver = 0;  // (thread 0) this workgroup's version counter
+  // The floor.  Only the vertices whose core number can reach the size of the clique the search will find matter to it
+  // (a member of a clique of s vertices has core number >= s - 1; everything else is cut away by the K > mc tests), but
+  // MOST of the iteration's length is the slow settling of the graph's bulk (random consistencies: thousands of vertices
+  // of degree ~70 creeping down to core ~57 over twenty dependent rounds) far below the planted clique.  Workgroup 0
+  // takes the h-index H of the first snapshot in which every vertex has published its degree (H - 1 bounds every clique
+  // from above) and publishes floor = H / 2; from then on a value that has dropped below the floor is left where it is:
+  // an upper bound of its core number below the floor.  Values at or above the floor still converge to the exact core
+  // numbers (a neighbour below the floor never counts at a threshold at or above it, wherever below it stands).  What
+  // the clique search makes of this — it starts from the floor as an injected lower bound and the host repeats the stage
+  // without a floor if that search comes back empty — is described at k_rank_sort.
+  unsigned* ctl_floor = (unsigned*)V.perm + HCA_CTL_FLOOR;
+  __shared__ unsigned s_floor;
+  __shared__ int s_froze;
+  __shared__ int s_hcnt[2][HCA_THREADS / 64];
+  if (tid == 0) s_froze = 0;  // (barriers follow before anybody evaluates a row)
+  int my_floor = 0;                    // (uniform)
+  bool floor_known = allow_floor == 0;  // no further look at the control word
+  bool floor_decided = !(allow_floor != 0 && w == 0);  // (workgroup 0) nothing left to decide
+  bool froze_said = false;
   unsigned v0 = 0, E0 = 0;
   bool bump = true;       // values were stored (set-up) or lowered in the previous iteration: ver[w] has to follow once they have landed
   bool v0_valid = false;  // v0 / E0 were read before the snapshot of THIS iteration (only then may it claim a fixed point)
@@ -915,6 +938,13 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   auto evaluate = [&](int rl) __attribute__((always_inline)) -> bool {
     const int cv = __builtin_amdgcn_readfirstlane(mine[rl]);
     if (cv <= 0) return false;
+    if (cv < my_floor) {  // below the floor: left alone (an upper bound, which is all anybody needs of it)
+      if (!froze_said) {  // (noted in LDS, stored once per workgroup at the end: four thousand waves storing to one word that
+        froze_said = true;  // every workgroup's snapshot polls the neighbour of took 45 us of everybody's time)
+        if (lane == 0) s_froze = 1;
+      }
+      return false;
+    }
     const int v = r_lo + rl;
     const int off = __builtin_amdgcn_readfirstlane(nb_off[rl]), end = __builtin_amdgcn_readfirstlane(nb_off[rl + 1]), deg = end - off;
     int h;
@@ -955,20 +985,57 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     HCA_MARK(iter == 0 ? 0 : 3);
     // 1. snapshot of all values (four per load)
     // (16-byte loads and two 8-byte loads in flight per thread were both tried: no faster)
-    bool moved = false;
+    bool moved = false, open = false;
+    unsigned fl = 0;
+    if (!floor_known && tid == 0) fl = hca_load_u32(ctl_floor);  // (rides with the snapshot's loads)
     for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
       const u64 nv = hca_load_u64((const u64*)gvals + i);
       if (nv != ((u64*)vals)[i]) {
         ((u64*)vals)[i] = nv;
         moved = true;
       }
+      if (!floor_decided) {  // (workgroup 0) has every vertex published its degree?
+#pragma unroll
+        for (int k = 0; k < 4; ++k) open = open || (4 * i + k < L && ((nv >> (16 * k)) & 0xffffu) == 0xffffu);
+      }
     }
     // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
     // the coherence point as well: only now may the version say so)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!floor_known && tid == 0) s_floor = fl;
     const bool any_moved = wg_any(moved);
     if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bump = false;
+    if (!floor_known) {
+      const unsigned f = __builtin_amdgcn_readfirstlane(s_floor);  // (tid 0 writes it again behind the next vote at the earliest)
+      if (f & 1u) {
+        my_floor = (int)(f >> 1);
+        floor_known = true;
+      }
+    }
+    if (!floor_decided && !wg_any(open)) {
+      // H = the largest h with at least h values >= h, by bisection (all sixteen waves count, one barrier per probe)
+      int lo = 0, hi = min(L, 65534), probe = 0;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        int c = 0;
+        for (int i = tid; i < L; i += HCA_THREADS) c += vals[i] >= mid ? 1 : 0;
+        c = wave_sum_i32(c);
+        if (lane == 0) s_hcnt[probe & 1][wave] = c;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < HCA_THREADS / 64; ++q) tot += s_hcnt[probe & 1][q];
+        ++probe;
+        if (tot >= mid) lo = mid;
+        else hi = mid - 1;
+      }
+      int f = lo >> 1;
+      if (f < HCA_FLOOR_MIN) f = 0;
+      if (tid == 0) __hip_atomic_store(ctl_floor, ((unsigned)f << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      my_floor = f;
+      floor_decided = floor_known = true;
+    }
     HCA_MARK(1);
     // 2. my rows, each counted afresh (one wave per row) — unless nothing at all moved
     bool changed = false;
@@ -1029,6 +1096,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   }
   if (tid == 0) {
     if (!finished) V.perm[HCA_CTL_FAILED] = 1;
+    if (s_froze) V.perm[HCA_CTL_FROZE] = 1;
     atomicMax(&V.perm[HCA_CTL_ITERS], iter);
   }
 #ifdef QTR_HCA_PROF
@@ -1370,7 +1438,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   const int L = V.L;
   SolverState* st = V.st;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ int s_nb;
+  __shared__ int s_nb, s_cf;
   // the peeling kernel's work, without its launch (RS_THREADS = its 1024 threads; the dynamic LDS is sized for both)
   const bool gave_up = after_async && L > 0 && V.perm[HCA_CTL_FAILED] != 0;  // (uniform)
   if (L > 0 && (kcore_mode == 1 || (kcore_mode == 2 && gave_up))) {
@@ -1382,6 +1450,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
     // iteration gave up, k_kcore has just run and left them)
     __shared__ int s_red[2][RS_THREADS / 64];
     const int failed = V.perm[HCA_CTL_FAILED], iters = V.perm[HCA_CTL_ITERS];  // (perm is overwritten further down)
+    // the floor counts only if some value was in fact left standing below it (and the iteration itself went through)
+    const int floor_w = V.perm[HCA_CTL_FLOOR], froze = V.perm[HCA_CTL_FROZE];
     int mx = 0, es = 0;
     if (!failed)
       for (int v = tid; v < L; v += RS_THREADS) {
@@ -1407,16 +1477,31 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
         st->ub = mx + 1;
         st->pad[0] = iters;  // statistics: iterations of the slowest workgroup
         s_nb = mx + 1;
+        s_cf = froze ? (floor_w >> 1) : 0;
       } else {
         s_nb = st->max_core + 1;
+        s_cf = 0;  // (the peeling workgroup's numbers are exact)
       }
     }
     __syncthreads();
   } else if (tid == 0) {
     s_nb = L > 0 ? st->max_core + 1 : 0;
+    s_cf = 0;
   }
+  // A floor F > 0 (k_hcore_async): core numbers below F are upper bounds, not values, so the search may not look at those
+  // vertices at all — it starts as if a clique of F vertices were already known: mc = F with no clique behind it, t0 = the
+  // first rank with K > F.  Every test it makes (K[r] > mc, the candidates' K > mc, |P| > mc) then involves exact numbers
+  // only.  Against the search that starts from mc = 0 on exact numbers: that one may pick up cliques of at most F vertices
+  // on the way (a descent that leaves the K > F region ends in a clique holding a vertex with K <= F, i.e. of at most F
+  // vertices), keeps mc_exact <= mc_here, and whatever this search accepts (size > mc_here) it accepts too, with the same
+  // members (the members' K exceed the bound in both, the picks go from the top rank down, and nothing below can extend a
+  // clique beyond its own K) — after which the two agree for good.  The converse needs |P| > mc to hold here whenever it
+  // holds there: d_clique_scan notes a start that passed the size test and failed that one (`tainted`), and with a taint
+  // or without any accepted clique the stage is run again without a floor (`redo_cores`, solver_continue): the result is
+  // either identical to the exact search's or not used.
   if (tid == 0) {  // what k_clique_init sets
-    st->mc = 0;
+    st->mc = s_cf;
+    st->core_floor = s_cf;
     st->best_r = -1;
     st->pos = L - 1;
     st->done = (L <= 0) ? 1 : 0;
@@ -1432,7 +1517,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   __shared__ int s_wtot[RS_THREADS / 64];
   __syncthreads();
   const int NB = s_nb;  // core values 0 .. max_core
+  const int cf = s_cf;  // t0 = the number of vertices with core number < cf
+  if (cf >= NB && tid == 0) st->t0 = L;
   if (NB > RS_BINS) {
+    if (cf > 0 && cf < NB) {
+      int below = 0;
+      for (int v = tid; v < L; v += RS_THREADS) below += core[v] < cf ? 1 : 0;
+      below = wave_sum_i32(below);
+      if (lane == 0 && below) atomicAdd(&st->t0, below);
+    }
     // rare: rank = #{u : (core u, u) < (core v, v)}, tiles of the core array through LDS
     int* tile = rs_lds;
     for (int v0 = 0; v0 < L; v0 += RS_THREADS) {
@@ -1482,6 +1575,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   for (int q = 0; q < wave; ++q) wbase += s_wtot[q];
   if (tid < NB) {
     const int start = wbase + ex;
+    if (cf > 0 && tid == cf) st->t0 = start;
 #pragma unroll
     for (int w = 0; w < 16; ++w) rs_lds[w * RS_BINS + tid] += start;
   }
@@ -1945,8 +2039,8 @@ __device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batc
   int* __restrict__ best_picks = V.picks;
   if (st->done) return;
   const int lane = qk_lane();
-  const int B = st->batch, pos = st->pos, ub = st->ub;
-  int mc = st->mc, t = st->t0, best = st->best_r, done = 0;
+  const int B = st->batch, pos = st->pos, ub = st->ub, cf = st->core_floor;
+  int mc = st->mc, t = st->t0, best = st->best_r, done = 0, tainted = st->tainted;
   int cursor = 0;
   while (cursor < B) {
     const int wid = cursor + lane;
@@ -1990,12 +2084,21 @@ __device__ __forceinline__ void d_clique_scan(const SolverView& V, int next_batc
         done = 1;
         break;
       }
+    } else if (cf > 0) {
+      tainted = 1;  // (see k_rank_sort: under an injected bound this rule may not be what turns a start down)
     }
     cursor = wsel + 1;
   }
   const int newpos = pos - B;
   if (newpos < 0 || Kp[newpos] <= mc) done = 1;
+  if (done && cf > 0 && (best < 0 || tainted)) {  // nothing this search can vouch for: again, with exact core numbers
+    done = 0;
+    mc = 0;
+    best = -1;
+    if (lane == 0) st->redo_cores = 1;
+  }
   if (lane == 0) {
+    st->tainted = tainted;
     st->mc = mc;
     st->best_r = best;
     st->t0 = t;
@@ -2983,10 +3086,11 @@ static hipError_t solver_args(SolverArgs& a, const SolverView* views, int G, Vie
 
 // the solver state of every pair starts from zero (was a hipMemsetAsync per pair)
 template <bool EXT>
-__global__ void k_solver_reset(ViewExt<SolverView> x, SolverView one) {
+__global__ void k_solver_reset(ViewExt<SolverView> x, SolverView one, int second_run) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;
   int* p = (int*)V.st;
   if (threadIdx.x < (int)(sizeof(SolverState) / 4)) p[threadIdx.x] = 0;
+  if (threadIdx.x == 0) V.st->pad[12] = second_run;  // statistics: this is the stage's second run (see solver_continue)
 }
 
 static void launch_finalize(const SolverArgs& a, int G, const qtr_params& prm, hipStream_t stream, int scan_batch = 0) {
@@ -3025,8 +3129,10 @@ static bool hcore_async_planned(int L) { return hcore_planned(L) && !kcore_sweep
 // hcore_prepared: k_graph_build has left k_hcore_async's clean slate (values, control words)
 // defer_last_scan: the caller's next launch (k_finalize) replays the last round itself; returns that round's next_batch
 // argument (0: nothing left to replay)
+// exact_cores: k_hcore_async without its floor (the second run of a pair whose first came back empty; the k-core
+// heuristic, which reads every core number)
 static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, double kcore_thr, hipStream_t stream,
-                               bool hcore_prepared, bool defer_last_scan) {
+                               bool hcore_prepared, bool defer_last_scan, bool exact_cores = false) {
   int deferred = 0;
   const int W = (L + 63) / 64;
   static const bool dbg_sync = QTR_ENGINE_ENV("QTR_DEBUG_SYNC") != nullptr;  // name every kernel as it completes
@@ -3088,7 +3194,13 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         }
         const int pool_entries = (int)((lds_budget - fixed) / 2) & ~7;
         if (!hcore_prepared) LAUNCH_SV(k_hcore_async_init, a, dim3((max(L, 4096) + 255) / 256, 1, G), dim3(256), 0, stream);
-        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries);
+        static const bool no_floor = [] {  // (QTR_HCORE_FLOOR=0: comparison runs of the test build)
+          const char* e = QTR_ENGINE_ENV("QTR_HCORE_FLOOR");
+          return e && atoi(e) == 0;
+        }();
+        const int allow_floor = (exact_cores || no_floor || mode == QTR_INLIER_KCORE_HEU) ? 0 : 1;
+        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries,
+                  allow_floor);
         after_async = true;
       }
 #ifdef QTR_TEST_ENGINES
@@ -3177,20 +3289,36 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
 
 // Rare path: the two unconditional clique rounds did not finish the search.  Runs further rounds (one host
 // check per round) and the finalisation again.
+// redo_cores (the state's flag of that name): the search ran under k_hcore_async's floor and found nothing it can vouch
+// for — the whole stage again from the bit matrix, with exact core numbers, before any further round.
 hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4* tgt, int L, const qtr_params& prm,
-                           hipStream_t stream, int* pinned_state) {
+                           hipStream_t stream, int* pinned_state, int redo_cores) {
   hipError_t e;
   int guard = 0;
-  const SolverView V = make_solver_view(B, src, tgt, L);
+  SolverView V = make_solver_view(B, src, tgt, L);
+  V.degp = nullptr;  // (the degrees are finished and in deg; the per-block counts lay where the pick lists are now)
   SolverArgs a;
   if ((e = solver_args(a, &V, 1, nullptr, stream)) != hipSuccess) return e;
+  bool redo = redo_cores != 0;
   while (true) {
-    LAUNCH_SV(k_clique_batch, a, dim3(CLIQUE_BATCH / 4, 1, 1), dim3(256), 0, stream);
-    LAUNCH_SV(k_clique_scan, a, dim3(1, 1, 1), dim3(64), 0, stream, CLIQUE_BATCH);
+    if (redo) {  // (at most once: the second run has no floor)
+      redo = false;
+      LAUNCH_SV(k_solver_reset, a, dim3(1, 1, 1), dim3(64), 0, stream, 1);
+      clique_stage_launch(a, 1, L, QTR_INLIER_PMC_HEU, 0.0, stream, false, false, true);
+    } else {
+      LAUNCH_SV(k_clique_batch, a, dim3(CLIQUE_BATCH / 4, 1, 1), dim3(256), 0, stream);
+      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, 1), dim3(64), 0, stream, CLIQUE_BATCH);
+    }
     if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
       return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-    if (((const SolverState*)pinned_state)->done) break;
+    const SolverState* hs = (const SolverState*)pinned_state;
+    if (hs->done) break;
+    if (hs->redo_cores) {  // the rounds under the floor's bound ended empty-handed
+      redo = true;
+      guard = 0;
+      continue;
+    }
     if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
   }
   if (src) launch_finalize(a, 1, prm, stream);
@@ -3248,7 +3376,7 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
   int L = 0;
   for (int g = 0; g < G; ++g) L = max(L, views[g].L);
   // (the state's clean slate rides on k_graph_build when there is one: a launch fewer on the chain)
-  if (!reset_done && L <= 0) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream);
+  if (!reset_done && L <= 0) LAUNCH_SV(k_solver_reset, a, dim3(1, 1, G), dim3(64), 0, stream, 0);
   if (L <= 0 && ev_graph) hipEventRecord(ev_graph, stream);
   const bool prep_hcore = L > 0 && hcore_async_planned(L);
   int scan_batch = 0;

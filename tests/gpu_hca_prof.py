@@ -54,3 +54,5 @@ for k, nm in enumerate(names):
         print(f"  {nm:12s} mean {col.mean() / 100:8.2f} us   max {col.max() / 100:8.2f} us")
     else:
         print(f"  {nm:12s} mean {col.mean():8.1f}      max {col.max():8.1f}")
+for wg in (0, int(np.argmax(m[:, 1])), int(np.argmax(m[:, 2])), int(np.argmax(m[:, 3]))):
+    print(f"  workgroup {wg:3d}: " + "  ".join(f"{nm} {m[wg, k] / (100 if k in (0, 1, 2, 3, 6, 7) else 1):.1f}" for k, nm in enumerate(names)))

@@ -128,12 +128,16 @@ def test_solver_at_L20000_matches_oracle(qo16):
         r = h.solve(src, tgt)
         bm_g = h.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(L, -1)
         core_g = h.debug_fetch(ql.DBG_CORE, np.int32)
+        floor = int(h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)[29])
     finally:
         h.close()
     o = qo16.solve(src, tgt)
     bm_o = qo16.build_graph(src, tgt, 0.3, 1.0)
     assert np.array_equal(bm_g, bm_o)
-    assert np.array_equal(core_g, qo16.kcore(bm_o)[0])
+    core_o = qo16.kcore(bm_o)[0]  # (exact at or above the floor k_hcore_async worked with, upper bounds under it)
+    hi = core_o >= floor
+    assert np.array_equal(core_g[:L][hi], core_o[hi])
+    assert np.all(core_g[:L][~hi] >= core_o[~hi]) and np.all(core_g[:L][~hi] < floor)
     assert r["max_core"] == o["max_core"] and r["n_edges"] == o["n_edges"]
     _same(r, o)
     assert np.array_equal(r["rot_inliers"], o["rot_inliers"]) and r["gnc_iters"] == o["gnc_iters"]

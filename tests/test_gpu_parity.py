@@ -72,6 +72,19 @@ def test_spfh_role_swap_shortcut_equals_the_reference_arithmetic(hip, qo):
 
 
 # ---------------------------------------------------------------------------------------------- back end
+def assert_cores(h, core_o):
+    """QTR_DBG_CORE against the oracle's core numbers: equal at or above the floor the solve worked with (k_hcore_async
+    stops lowering values below it; QTR_DBG_SOLVER_STATE[29], 0 = everything exact), an upper bound below the floor under
+    it.  Returns the floor."""
+    core_o = np.asarray(core_o)
+    core_g = h.debug_fetch(ql.DBG_CORE, np.int32)[:core_o.size]
+    floor = int(h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)[29])
+    hi = core_o >= floor
+    assert np.array_equal(core_g[hi], core_o[hi])
+    assert np.all(core_g[~hi] >= core_o[~hi]) and np.all(core_g[~hi] < floor)
+    return floor
+
+
 @pytest.mark.parametrize("L,frac,seed,noise", [
     (2, 1.0, 0, 0.1), (3, 0.0, 1, 0.1), (50, 0.3, 1, 0.1), (64, 0.5, 2, 0.2), (65, 0.5, 3, 0.2), (300, 0.2, 2, 0.3),
     (1000, 0.1, 3, 0.35), (1281, 0.1, 10, 0.2), (2000, 0.05, 11, 0.2), (3000, 0.0, 6, 0.1), (5000, 0.05, 4, 0.1), (5000, 0.05, 7, 0.3), (5000, 0.02, 5, 0.4),
@@ -82,7 +95,7 @@ def test_solver_matches_oracle(hip, qo, L, frac, seed, noise):
     bm_g = hip.debug_fetch(ql.DBG_GRAPH_BITMAP, np.uint64).reshape(L, -1)
     bm_o = qo.build_graph(src, tgt, 0.3, 1.0)
     assert np.array_equal(bm_g, bm_o)
-    assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32), qo.kcore(bm_o)[0])
+    assert_cores(hip, qo.kcore(bm_o)[0])
     assert r["max_core"] == o["max_core"] and r["n_edges"] == o["n_edges"]
     _assert_same_solution(r, o)
     assert r["gnc_iters"] == o["gnc_iters"] and r["n_card"] == o["n_card"]
@@ -638,6 +651,75 @@ def test_max_clique_entry_matches_oracle(hip, qo, L, p, planted, seed):
             sub = A[np.ix_(got, got)]
             assert sub.sum() == got.size * (got.size - 1) or (mode == 2)  # KCORE_HEU returns the top core, not a clique
     assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32)[:L], core)
+
+
+def test_core_number_floor_and_second_run(hip, qo):
+    """k_hcore_async's floor (values below half the h-index of the degrees are not lowered any further) and what the clique
+    search makes of it.  (a) a planted clique far above the graph's bulk: the floor is in force, the bulk's numbers are
+    upper bounds, the clique and the largest core are the oracle's.  (b) a graph whose largest clique is far BELOW the
+    floor, with a few vertices of small degree that the floor leaves standing: the search under the injected bound comes
+    back empty and the stage runs a second time with exact numbers — the oracle's clique again."""
+    bm, _ = _random_graph_bitmap(4000, 0.01, 31, planted=300)
+    core, _, mc = qo.kcore(bm)
+    got, max_core = hip.max_clique(bm, 1)
+    st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+    assert st[29] >= 100 and st[22] == 0, st
+    assert assert_cores(hip, core) == st[29]
+    assert np.array_equal(got, qo.max_clique(bm, 1, 0.5)) and max_core == mc and got.size >= 300
+    L = 3000
+    rng = np.random.default_rng(5)
+    A = np.triu(rng.random((L, L)) < 0.02, 1)
+    A[:, :12] = False  # a dozen vertices of (nearly) no degree ...
+    A[:12, :] = False
+    for v in range(12):  # ... joined to three others each
+        A[v, 100 + 3 * v:103 + 3 * v] = True
+    A = np.triu(A, 1)
+    A = A | A.T
+    bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
+    bits[:, :L] = A
+    bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+    core, _, mc = qo.kcore(bm)
+    got, max_core = hip.max_clique(bm, 1)
+    st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+    assert st[22] == 1 and st[29] == 0, st  # second run, exact
+    assert np.array_equal(got, qo.max_clique(bm, 1, 0.5)) and max_core == mc
+    assert_cores(hip, core)
+
+
+def test_clique_search_under_the_floor_sweep(hip, qo):
+    """The regime the floor's argument has to carry: cliques planted AROUND the floor (half the h-index of the degrees) in
+    graphs of the size k_hcore_async takes, over a sweep of densities — below it (second run), just above it, far above it,
+    several cliques of similar size, and none.  Every clique must be the oracle's, whichever way the stage went."""
+    rng = np.random.default_rng(77)
+    ways = {"floor": 0, "second run": 0, "exact": 0}
+    for case in range(48):
+        L = int(rng.integers(1300, 3400))
+        p = float(rng.choice([0.004, 0.01, 0.02, 0.04, 0.08]))
+        A = np.triu(rng.random((L, L)) < p, 1)
+        half_h = max(4, int(p * L / 2))  # ~ the floor of the bulk alone
+        sizes = [[], [half_h - 3], [half_h], [half_h + 1], [half_h + 2], [half_h + 6], [2 * half_h], [4 * half_h],
+                 [half_h + 2, half_h + 2], [2 * half_h, 2 * half_h - 1, half_h]][case % 10]
+        for sz in sizes:
+            mem = rng.choice(L, min(sz, L), replace=False)
+            A[np.ix_(mem, mem)] = True
+        if case % 3 == 0:  # a few vertices the floor leaves standing whatever the bulk does
+            A[:, :6] = False
+            A[:6, :] = False
+            A[np.arange(6), 50 + np.arange(6)] = True
+        A = np.triu(A, 1)
+        A = A | A.T
+        bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
+        bits[:, :L] = A
+        bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+        got, max_core = hip.max_clique(bm, 1)
+        st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+        ref = qo.max_clique(bm, 1, 0.5)
+        assert np.array_equal(got, ref), (case, L, p, sizes, st[22], st[29])
+        core, _, mc = qo.kcore(bm)
+        assert max_core == mc, (case, L, p, sizes)
+        assert_cores(hip, core)
+        ways["second run" if st[22] else "floor" if st[29] else "exact"] += 1
+    assert ways["floor"] >= 5 and ways["second run"] >= 3, ways
 
 
 def test_max_clique_entry_hygiene_and_errors(hip, qo):

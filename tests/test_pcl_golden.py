@@ -140,7 +140,7 @@ def test_live_device_path_against_pcl_and_pmc_output():
     h = ql.Handle(0)
     try:
         compare(REF, {"voxelize": h.voxelize, "fpfh": lambda c, rn, rf: (lambda r: (r[0], None, r[1]))(h.fpfh(c, rn, rf)),
-                      "kcore": lambda bm: (h.max_clique(bm, 1), h.debug_fetch(ql.DBG_CORE, np.int32)[: bm.shape[0]])[1],
+                      "kcore": lambda bm: (h.max_clique(bm, 2, 0.0), h.debug_fetch(ql.DBG_CORE, np.int32)[: bm.shape[0]])[1],  # (mode 2: every core number exact)
                       "max_clique": lambda bm, mode: h.max_clique(bm, mode)[0]})
     finally:
         h.close()
