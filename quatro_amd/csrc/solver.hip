@@ -873,7 +873,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   // MOST of the iteration's length is the slow settling of the graph's bulk (random consistencies: thousands of vertices
   // of degree ~70 creeping down to core ~57 over twenty dependent rounds) far below the planted clique.  Workgroup 0
   // takes the h-index H of the first snapshot in which every vertex has published its degree (H - 1 bounds every clique
-  // from above) and publishes floor = H / 2; from then on a value that has dropped below the floor is left where it is:
+  // from above) and publishes floor = H / 2 (if H stands clear of the mean degree, see there); from then on a value that has dropped below the floor is left where it is:
   // an upper bound of its core number below the floor.  Values at or above the floor still converge to the exact core
   // numbers (a neighbour below the floor never counts at a threshold at or above it, wherever below it stands).  What
   // the clique search makes of this — it starts from the floor as an injected lower bound and the host repeats the stage
@@ -1030,7 +1030,22 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
         if (tot >= mid) lo = mid;
         else hi = mid - 1;
       }
+      // ... and only where H stands clear of the bulk: with H below 2.5 x the mean degree it is the bulk's own tail that
+      // sets it (no planted clique, or one of a per cent of the vertices: consistency graphs of random correspondences have
+      // degrees of mean 66 and h-index ~100 at L = 5000), half of it lies around the bulk's core numbers, and the search
+      // under that bound would come back empty or tied — a second run of the whole stage instead of a shorter first one
       int f = lo >> 1;
+      {
+        int sum = 0;
+        for (int i = tid; i < L; i += HCA_THREADS) sum += vals[i];
+        sum = wave_sum_i32(sum);
+        if (lane == 0) s_hcnt[probe & 1][wave] = sum;
+        __syncthreads();
+        long long tot = 0;
+#pragma unroll
+        for (int q = 0; q < HCA_THREADS / 64; ++q) tot += s_hcnt[probe & 1][q];
+        if (2ll * lo * L < 5ll * tot) f = 0;
+      }
       if (f < HCA_FLOOR_MIN) f = 0;
       if (tid == 0) __hip_atomic_store(ctl_floor, ((unsigned)f << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       my_floor = f;

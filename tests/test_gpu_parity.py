@@ -653,12 +653,22 @@ def test_max_clique_entry_matches_oracle(hip, qo, L, p, planted, seed):
     assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32)[:L], core)
 
 
+def _bitmap_of(A):
+    L = A.shape[0]
+    A = np.triu(A, 1)
+    A = A | A.T
+    bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
+    bits[:, :L] = A
+    return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+
+
 def test_core_number_floor_and_second_run(hip, qo):
-    """k_hcore_async's floor (values below half the h-index of the degrees are not lowered any further) and what the clique
-    search makes of it.  (a) a planted clique far above the graph's bulk: the floor is in force, the bulk's numbers are
-    upper bounds, the clique and the largest core are the oracle's.  (b) a graph whose largest clique is far BELOW the
-    floor, with a few vertices of small degree that the floor leaves standing: the search under the injected bound comes
-    back empty and the stage runs a second time with exact numbers — the oracle's clique again."""
+    """k_hcore_async's floor (values below half the h-index H of the degrees are not lowered any further, where H stands
+    clear of the mean degree) and what the clique search makes of it.  (a) a planted clique far above the graph's bulk:
+    the floor is in force, the bulk's numbers are upper bounds, the clique and the largest core are the oracle's.  (b) a
+    dense block that is NOT a clique (200 vertices, every other pair joined) lifts H to ~100 while the largest clique has
+    a dozen members: the search under the injected bound comes back empty and the stage runs a second time with exact
+    numbers — the oracle's clique again.  (c) no structure at all: H is the bulk's own, no floor, one run."""
     bm, _ = _random_graph_bitmap(4000, 0.01, 31, planted=300)
     core, _, mc = qo.kcore(bm)
     got, max_core = hip.max_clique(bm, 1)
@@ -668,49 +678,48 @@ def test_core_number_floor_and_second_run(hip, qo):
     assert np.array_equal(got, qo.max_clique(bm, 1, 0.5)) and max_core == mc and got.size >= 300
     L = 3000
     rng = np.random.default_rng(5)
-    A = np.triu(rng.random((L, L)) < 0.02, 1)
-    A[:, :12] = False  # a dozen vertices of (nearly) no degree ...
-    A[:12, :] = False
-    for v in range(12):  # ... joined to three others each
-        A[v, 100 + 3 * v:103 + 3 * v] = True
-    A = np.triu(A, 1)
-    A = A | A.T
-    bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
-    bits[:, :L] = A
-    bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+    A = np.triu(rng.random((L, L)) < 0.005, 1)
+    blk = rng.choice(L, 200, replace=False)
+    A[np.ix_(blk, blk)] |= rng.random((200, 200)) < 0.5
+    bm = _bitmap_of(A)
     core, _, mc = qo.kcore(bm)
     got, max_core = hip.max_clique(bm, 1)
     st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
     assert st[22] == 1 and st[29] == 0, st  # second run, exact
     assert np.array_equal(got, qo.max_clique(bm, 1, 0.5)) and max_core == mc
     assert_cores(hip, core)
+    bm, _ = _random_graph_bitmap(3000, 0.02, 8)
+    got, max_core = hip.max_clique(bm, 1)
+    st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+    assert st[22] == 0 and st[29] == 0, st
+    assert np.array_equal(got, qo.max_clique(bm, 1, 0.5))
 
 
 def test_clique_search_under_the_floor_sweep(hip, qo):
-    """The regime the floor's argument has to carry: cliques planted AROUND the floor (half the h-index of the degrees) in
-    graphs of the size k_hcore_async takes, over a sweep of densities — below it (second run), just above it, far above it,
-    several cliques of similar size, and none.  Every clique must be the oracle's, whichever way the stage went."""
+    """The regime the floor's argument has to carry: a dense block (not a clique) sets the floor F ~ 0.75 x its size / 2,
+    and cliques are planted AROUND F — F - 1, F, F + 1, F + 2 (the search under the injected bound accepts sizes above
+    F only), far above it, several of similar size, none — in graphs of the size k_hcore_async takes, over a sweep of
+    densities.  Every clique must be the oracle's, whichever way the stage went."""
     rng = np.random.default_rng(77)
     ways = {"floor": 0, "second run": 0, "exact": 0}
-    for case in range(48):
+    for case in range(60):
         L = int(rng.integers(1300, 3400))
-        p = float(rng.choice([0.004, 0.01, 0.02, 0.04, 0.08]))
+        p = float(rng.choice([0.004, 0.01, 0.02, 0.04]))
+        m = max(6, int(p * L))  # ~ the bulk's mean degree
         A = np.triu(rng.random((L, L)) < p, 1)
-        half_h = max(4, int(p * L / 2))  # ~ the floor of the bulk alone
-        sizes = [[], [half_h - 3], [half_h], [half_h + 1], [half_h + 2], [half_h + 6], [2 * half_h], [4 * half_h],
-                 [half_h + 2, half_h + 2], [2 * half_h, 2 * half_h - 1, half_h]][case % 10]
+        B = 6 * m  # the block: degrees ~ 3 m + m inside, h-index ~ 3.5 m, floor ~ 1.75 m
+        blk = rng.choice(L, min(B, L), replace=False)
+        if case % 6 != 5:
+            A[np.ix_(blk, blk)] |= rng.random((blk.size, blk.size)) < 0.5
+        bm0 = _bitmap_of(A)
+        deg = np.unpackbits(bm0.view(np.uint8), axis=1).sum(1)
+        H = int(np.sum(np.sort(deg)[::-1] >= np.arange(1, L + 1)))
+        F = H // 2
+        sizes = [[], [F - 1], [F], [F + 1], [F + 2], [F + 5], [2 * F], [F + 1, F + 1], [F + 2, F, F - 1], [3 * F]][case % 10]
         for sz in sizes:
-            mem = rng.choice(L, min(sz, L), replace=False)
+            mem = rng.choice(L, max(2, min(sz, L)), replace=False)
             A[np.ix_(mem, mem)] = True
-        if case % 3 == 0:  # a few vertices the floor leaves standing whatever the bulk does
-            A[:, :6] = False
-            A[:6, :] = False
-            A[np.arange(6), 50 + np.arange(6)] = True
-        A = np.triu(A, 1)
-        A = A | A.T
-        bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
-        bits[:, :L] = A
-        bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+        bm = _bitmap_of(A)
         got, max_core = hip.max_clique(bm, 1)
         st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
         ref = qo.max_clique(bm, 1, 0.5)
@@ -719,7 +728,7 @@ def test_clique_search_under_the_floor_sweep(hip, qo):
         assert max_core == mc, (case, L, p, sizes)
         assert_cores(hip, core)
         ways["second run" if st[22] else "floor" if st[29] else "exact"] += 1
-    assert ways["floor"] >= 5 and ways["second run"] >= 3, ways
+    assert ways["floor"] >= 10 and ways["second run"] >= 5, ways
 
 
 def test_max_clique_entry_hygiene_and_errors(hip, qo):
