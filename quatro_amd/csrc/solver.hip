@@ -837,21 +837,127 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     }
   }
   __syncthreads();
+  // ---- the floor.  Only the vertices whose core number can reach the size of the clique the search will find matter to
+  // it (a member of a clique of s vertices has core number >= s - 1; everything else is cut away by the K > mc tests), but
+  // MOST of the iteration's length is the slow settling of the graph's bulk (random consistencies: thousands of vertices
+  // of degree ~70 creeping down to core ~57 over twenty dependent rounds) far below the planted clique.  Workgroup 0 waits
+  // until every vertex has published its degree, takes the h-index H of the degrees (H - 1 bounds every clique from above)
+  // and publishes floor = H / 2 (if H stands clear of the mean degree, see there); the others wait for that word.  A value
+  // below the floor is left where it is: an upper bound of its core number below the floor — such a row is never counted,
+  // a row whose DEGREE is below the floor not even listed.  Values at or above the floor still converge to the exact core
+  // numbers (a neighbour below the floor never counts at a threshold at or above it, wherever below it stands).  What the
+  // clique search makes of this — it starts from the floor as an injected lower bound and the host repeats the stage
+  // without a floor if that search comes back empty — is described at k_rank_sort.
+  __shared__ unsigned s_floor;
+  __shared__ int s_froze;
+  __shared__ int s_hcnt[2][HCA_THREADS / 64];
+  __shared__ unsigned s_hist[HCA_THREADS];
+  if (tid == 0) s_froze = 0;  // (barriers follow before anybody evaluates a row)
+  int my_floor = 0;            // (uniform)
+  if (allow_floor) {
+    unsigned* ctl_floor = (unsigned*)V.perm + HCA_CTL_FLOOR;
+    if (w == 0) {
+      // every vertex's degree: snapshots until none is missing (they double as the iteration's first snapshot).  A
+      // workgroup that has not published 200 us after my start is not resident (see the verdict loop below): no floor.
+      bool complete = false;
+      while (!complete) {
+        bool open = false;
+        for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
+          const u64 nv = hca_load_u64((const u64*)gvals + i);
+          ((u64*)vals)[i] = nv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) open = open || (4 * i + k < L && ((nv >> (16 * k)) & 0xffffu) == 0xffffu);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        complete = !wg_any(open);
+        if (!complete && wg_any(wall_clock64() - t_start > 20000ull)) break;
+      }
+      int f = 0;
+      if (complete) {
+        // H = the largest h with at least h values >= h: a histogram of the values (clamped to HCA_THREADS - 1: a larger H
+        // only means a lower floor than it could be), thread h then holds #{values >= h} after a suffix sum and the largest
+        // h that passes is found by a maximum.  (A bisection of thirteen probes, one barrier each, took 7 us.)
+        s_hist[tid] = 0;
+        __syncthreads();
+        int sum = 0;
+        for (int i = tid; i < L; i += HCA_THREADS) {
+          const int x = vals[i];
+          sum += x;
+          atomicAdd(&s_hist[min(x, HCA_THREADS - 1)], 1u);
+        }
+        sum = wave_sum_i32(sum);
+        __syncthreads();
+        // inclusive suffix sum: lane order reversed inside the wave, then the waves above mine
+        const int mine_h = (int)s_hist[tid];
+        int wtot = 0;
+        const int below_incl = wave_excl_scan_i32(mine_h, &wtot) + mine_h;  // bins of my wave up to and including mine
+        if (lane == 0) {
+          s_hcnt[0][wave] = wtot;
+          s_hcnt[1][wave] = sum;
+        }
+        __syncthreads();
+        int above = 0;  // bins of the waves above mine
+        long long tot = 0;
+#pragma unroll
+        for (int q = 0; q < HCA_THREADS / 64; ++q) {
+          above += q > wave ? s_hcnt[0][q] : 0;
+          tot += s_hcnt[1][q];
+        }
+        const int cnt_ge = above + (wtot - below_incl) + mine_h;  // #{values >= tid} (the last bin: >= HCA_THREADS - 1)
+        int lo = wave_max_i32(cnt_ge >= tid ? tid : 0);
+        __syncthreads();  // (s_hcnt[0] is read above)
+        if (lane == 0) s_hcnt[0][wave] = lo;
+        __syncthreads();
+        lo = 0;
+#pragma unroll
+        for (int q = 0; q < HCA_THREADS / 64; ++q) lo = max(lo, s_hcnt[0][q]);
+        // ... and only where H stands clear of the bulk: with H below 2.5 x the mean degree it is the bulk's own tail that
+        // sets it (no planted clique, or one of a per cent of the vertices: consistency graphs of random correspondences
+        // have degrees of mean 66 and h-index ~100 at L = 5000), half of it lies around the bulk's core numbers, and the
+        // search under that bound would come back empty or tied — a second run of the whole stage instead of a shorter
+        // first one
+        f = lo >> 1;
+        if (2ll * lo * L < 5ll * tot) f = 0;
+        if (f < HCA_FLOOR_MIN) f = 0;
+      }
+      if (tid == 0) __hip_atomic_store(ctl_floor, ((unsigned)f << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      my_floor = f;
+    } else {
+      // (one thread polls; a workgroup that gives up — 250 us — goes on without a floor: its rows are then lowered all the
+      // way, which costs time and nothing else)
+      unsigned f = 0;
+      while (true) {
+        if (tid == 0) s_floor = hca_load_u32(ctl_floor);
+        __syncthreads();
+        f = __builtin_amdgcn_readfirstlane(s_floor);
+        const bool late = wall_clock64() - t_start > 25000ull;
+        __syncthreads();  // (everybody has read the word before thread 0 writes it again)
+        if ((f & 1u) || wg_any(late)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      my_floor = (f & 1u) ? (int)(f >> 1) : 0;
+    }
+  }
+  // my rows as neighbour lists — those whose degree reaches the floor
   if (wave == 0) {
     int run = 0;
+    bool below = false;
     for (int base = 0; base < nown; base += 64) {
       const int rl = base + lane;
-      const int d = rl < nown ? nb_off[rl] : 0;
+      const bool listed = rl < nown && mine[rl] >= my_floor;
+      below = below || (rl < nown && !listed);
+      const int d = listed ? nb_off[rl] : 0;
       int tot = 0;
       const int ex = wave_excl_scan_i32(d, &tot);
       if (rl < nown) nb_off[rl] = run + ex;
       run += tot;
     }
     if (lane == 0) nb_off[nown] = run;
+    if (__any(below) && lane == 0) s_froze = 1;
   }
   __syncthreads();
   for (int rl = wave; rl < nown; rl += HCA_THREADS / 64) {
-    if (nb_off[rl + 1] > pool_entries) continue;
+    if (mine[rl] < my_floor || nb_off[rl + 1] > pool_entries) continue;
     const u64* rowp = bm + (size_t)(r_lo + rl) * V.Wb;
     int run = nb_off[rl];
     for (int base = 0; base < W; base += 64) {
@@ -868,24 +974,6 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     }
   }
   unsigned myver = 0;  // (thread 0) this workgroup's version counter
-  // The floor.  Only the vertices whose core number can reach the size of the clique the search will find matter to it
-  // (a member of a clique of s vertices has core number >= s - 1; everything else is cut away by the K > mc tests), but
-  // MOST of the iteration's length is the slow settling of the graph's bulk (random consistencies: thousands of vertices
-  // of degree ~70 creeping down to core ~57 over twenty dependent rounds) far below the planted clique.  Workgroup 0
-  // takes the h-index H of the first snapshot in which every vertex has published its degree (H - 1 bounds every clique
-  // from above) and publishes floor = H / 2 (if H stands clear of the mean degree, see there); from then on a value that has dropped below the floor is left where it is:
-  // an upper bound of its core number below the floor.  Values at or above the floor still converge to the exact core
-  // numbers (a neighbour below the floor never counts at a threshold at or above it, wherever below it stands).  What
-  // the clique search makes of this — it starts from the floor as an injected lower bound and the host repeats the stage
-  // without a floor if that search comes back empty — is described at k_rank_sort.
-  unsigned* ctl_floor = (unsigned*)V.perm + HCA_CTL_FLOOR;
-  __shared__ unsigned s_floor;
-  __shared__ int s_froze;
-  __shared__ int s_hcnt[2][HCA_THREADS / 64];
-  if (tid == 0) s_froze = 0;  // (barriers follow before anybody evaluates a row)
-  int my_floor = 0;                    // (uniform)
-  bool floor_known = allow_floor == 0;  // no further look at the control word
-  bool floor_decided = !(allow_floor != 0 && w == 0);  // (workgroup 0) nothing left to decide
   bool froze_said = false;
   unsigned v0 = 0, E0 = 0;
   bool bump = true;       // values were stored (set-up) or lowered in the previous iteration: ver[w] has to follow once they have landed
@@ -895,7 +983,7 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   __syncthreads();
 #ifdef QTR_HCA_PROF
   unsigned prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 10 ns ticks: [0] set-up, [1] snapshots, [2] rows, [3] protocol; counts: [4] iterations
-  unsigned long long prof_last = wall_clock64();     // that lowered something, [5] idle ones; [2] is wave 0 alone, [6] / [7] the wait for the other waves after it (lowering / idle)
+  unsigned long long prof_last = t_start;            // that lowered something, [5] idle ones; [2] is wave 0 alone, [6] / [7] the wait for the other waves after it (lowering / idle)
 #endif
   // the h-index of a row, given how to count: the largest t <= cv with count_ge(t) >= t (monotone in t).  Values drop in
   // small steps: probe cv, cv - 1, cv - 3, cv - 7 ... until one holds, then bisect the last gap.  Returns cv if it stands.
@@ -985,72 +1073,20 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     HCA_MARK(iter == 0 ? 0 : 3);
     // 1. snapshot of all values (four per load)
     // (16-byte loads and two 8-byte loads in flight per thread were both tried: no faster)
-    bool moved = false, open = false;
-    unsigned fl = 0;
-    if (!floor_known && tid == 0) fl = hca_load_u32(ctl_floor);  // (rides with the snapshot's loads)
+    bool moved = false;
     for (int i = tid; i < (Lp >> 2); i += HCA_THREADS) {
       const u64 nv = hca_load_u64((const u64*)gvals + i);
       if (nv != ((u64*)vals)[i]) {
         ((u64*)vals)[i] = nv;
         moved = true;
       }
-      if (!floor_decided) {  // (workgroup 0) has every vertex published its degree?
-#pragma unroll
-        for (int k = 0; k < 4; ++k) open = open || (4 * i + k < L && ((nv >> (16 * k)) & 0xffffu) == 0xffffu);
-      }
     }
     // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
     // the coherence point as well: only now may the version say so)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!floor_known && tid == 0) s_floor = fl;
     const bool any_moved = wg_any(moved);
     if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bump = false;
-    if (!floor_known) {
-      const unsigned f = __builtin_amdgcn_readfirstlane(s_floor);  // (tid 0 writes it again behind the next vote at the earliest)
-      if (f & 1u) {
-        my_floor = (int)(f >> 1);
-        floor_known = true;
-      }
-    }
-    if (!floor_decided && !wg_any(open)) {
-      // H = the largest h with at least h values >= h, by bisection (all sixteen waves count, one barrier per probe)
-      int lo = 0, hi = min(L, 65534), probe = 0;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        int c = 0;
-        for (int i = tid; i < L; i += HCA_THREADS) c += vals[i] >= mid ? 1 : 0;
-        c = wave_sum_i32(c);
-        if (lane == 0) s_hcnt[probe & 1][wave] = c;
-        __syncthreads();
-        int tot = 0;
-#pragma unroll
-        for (int q = 0; q < HCA_THREADS / 64; ++q) tot += s_hcnt[probe & 1][q];
-        ++probe;
-        if (tot >= mid) lo = mid;
-        else hi = mid - 1;
-      }
-      // ... and only where H stands clear of the bulk: with H below 2.5 x the mean degree it is the bulk's own tail that
-      // sets it (no planted clique, or one of a per cent of the vertices: consistency graphs of random correspondences have
-      // degrees of mean 66 and h-index ~100 at L = 5000), half of it lies around the bulk's core numbers, and the search
-      // under that bound would come back empty or tied — a second run of the whole stage instead of a shorter first one
-      int f = lo >> 1;
-      {
-        int sum = 0;
-        for (int i = tid; i < L; i += HCA_THREADS) sum += vals[i];
-        sum = wave_sum_i32(sum);
-        if (lane == 0) s_hcnt[probe & 1][wave] = sum;
-        __syncthreads();
-        long long tot = 0;
-#pragma unroll
-        for (int q = 0; q < HCA_THREADS / 64; ++q) tot += s_hcnt[probe & 1][q];
-        if (2ll * lo * L < 5ll * tot) f = 0;
-      }
-      if (f < HCA_FLOOR_MIN) f = 0;
-      if (tid == 0) __hip_atomic_store(ctl_floor, ((unsigned)f << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      my_floor = f;
-      floor_decided = floor_known = true;
-    }
     HCA_MARK(1);
     // 2. my rows, each counted afresh (one wave per row) — unless nothing at all moved
     bool changed = false;
@@ -1643,6 +1679,10 @@ __global__ __launch_bounds__(256) void k_permute_scatter(ViewExt<SolverView> x, 
   u64* __restrict__ adjP = V.adjP;
   const int r0 = blockIdx.x * PM2_ROWS;
   if (r0 >= L) return;
+  // under a floor (k_rank_sort) nobody ever reads a row below the first rank above it — starts, candidates and the exact
+  // search's roots all have K > mc >= floor: those rows are left as they are (down to a multiple of 64: the exact search
+  // stages rows from the word boundary)
+  if (V.st->core_floor > 0 && r0 + PM2_ROWS <= (V.st->t0 & ~63)) return;
   extern __shared__ u64 pm2_lds[];  // [4][W] the row a wave is assembling, then the ranks
   const int lane = qk_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   u64* outw = pm2_lds + (size_t)wave * W;
@@ -3001,7 +3041,7 @@ hipError_t solver_init_attributes() {
 #ifdef QTR_TEST_ENGINES
   SET_LDS(k_kcore, 156 * 1024)
 #endif
-  SET_LDS(k_hcore_async, 156 * 1024)
+  SET_LDS(k_hcore_async, 152 * 1024)  // (150 KB are used; 4.4 KB are static)
   SET_LDS(k_rank_sort, 156 * 1024)
   SET_LDS(k_clique_first, CF_LDS_BYTES)
   SET_LDS(k_clique_batch_lds, 156 * 1024)
