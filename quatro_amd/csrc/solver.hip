@@ -1864,6 +1864,59 @@ __global__ __launch_bounds__(CF_THREADS) void k_clique_first(ViewExt<SolverView>
   int* __restrict__ picks = V.picks_buf;
   const int r = st->pos, t0 = st->t0;  // batch == 1: the single start of round 0
   int depth = 1;
+  // Under a floor (k_rank_sort) the candidates are the few hundred ranks from t0 up: a window of Wn = W - (t0 >> 6) words.
+  // When the rows of the whole window fit LDS (64 Wn rows of Wn words: Wn <= 16) they are fetched ONCE — one round trip
+  // instead of one per word of candidates — and wave 0 runs the whole descent on them alone, no barrier in it: per word
+  // of candidates the picked subset as below, then every candidate of the lower words asks ITS OWN row whether it holds
+  // all the picks (the matrix is symmetric: one LDS read and a ballot per word instead of an AND of every picked row).
+  const int w0 = st->core_floor > 0 ? (t0 >> 6) : 0, Wn = W - w0;
+  if (r >= 0 && V.Kp[r] > st->mc && Wn <= 16) {  // (uniform over the workgroup)
+    u64* rows = cf_lds;                              // [64 Wn][Wn]: row of rank 64 w0 + i, words w0 ..
+    u64* curw = cf_lds + (size_t)64 * Wn * Wn;       // [Wn] the candidate set
+    const int base = w0 * 64;
+    for (int e = tid; e < 64 * Wn * Wn; e += CF_THREADS) {
+      const int i = e / Wn, w = e - i * Wn;
+      rows[e] = (base + i < L) ? adjP[(size_t)(base + i) * W + w0 + w] : 0ULL;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < Wn) {
+        u64 xw = rows[(size_t)(r - base) * Wn + lane];
+        const int lo = (w0 + lane) * 64;
+        if (lo + 63 < t0)
+          xw = 0;
+        else if (lo < t0)
+          xw &= ~((1ULL << (t0 - lo)) - 1ULL);
+        curw[lane] = xw;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const u64 above = lane < 63 ? ~((2ULL << lane) - 1ULL) : 0ULL;
+      for (int tw = Wn - 1; tw >= 0; --tw) {
+        const u64 cand = curw[tw];  // (uniform: every lane reads the same word)
+        if (cand == 0) continue;
+        const bool isc = (cand >> lane) & 1ULL;
+        const u64 arow = isc ? rows[(size_t)(tw * 64 + lane) * Wn + tw] : 0ULL;
+        u64 P = cand;
+        for (int pass = 0; pass < 64; ++pass) {
+          const u64 Pn = __ballot(isc && (P & above & ~arow) == 0);
+          if (Pn == P) break;
+          P = Pn;
+        }
+        if ((P >> lane) & 1ULL) picks[depth - 1 + __popcll(lane < 63 ? (P >> (lane + 1)) : 0ULL)] = base + tw * 64 + lane;
+        depth += __popcll(P);
+        for (int w = tw - 1; w >= 0; --w) {
+          const u64 cw = curw[w];
+          if (cw == 0) continue;
+          bool alive = (cw >> lane) & 1ULL;
+          const u64 rw = alive ? rows[(size_t)(w * 64 + lane) * Wn + tw] : 0ULL;
+          alive = alive && (rw & P) == P;
+          const u64 nb = __ballot(alive);
+          if (lane == 0) curw[w] = nb;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next word reads what lane 0 stored
+      }
+    }
+  } else
   if (r >= 0 && V.Kp[r] > st->mc) {  // (uniform over the workgroup)
     const int K = max(1, min(64, (int)((CF_LDS_BYTES / 8 - W - (CF_THREADS / 64) * W) / W)));
     for (int w = tid; w < W; w += CF_THREADS) {

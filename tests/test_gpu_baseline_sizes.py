@@ -465,6 +465,46 @@ def test_batch_of_correspondence_only_pairs_of_mixed_sizes_against_sequential_ca
         hb.close()
 
 
+def _noisy_block_correspondences(L, nblk, amp, seed):
+    """nblk correspondences that follow one transform up to a displacement of up to `amp` metres (every other pair of them
+    consistent at amp = 1.2: a dense block of the consistency graph that is not a clique), the rest random."""
+    src, tgt, _, inl = synth.correspondences(L, nblk / L, seed, noise=0.05)
+    rng = np.random.default_rng(seed + 100)
+    e = rng.normal(size=(len(inl), 3))
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    e *= amp * rng.random((len(inl), 1)) ** (1 / 3)
+    tgt = tgt.copy()
+    tgt[inl, :3] += e.astype(np.float32)
+    return src, tgt
+
+
+def test_second_run_of_the_clique_stage_single_and_inside_a_batch(qo16):
+    """A dense block that is not a clique lifts the h-index of the degrees (floor ~ 94) far above the largest clique (41):
+    the clique search under k_hcore_async's floor comes back empty and the stage runs a second time with exact core numbers
+    — as a single call (the state says so) and for pairs in the middle of a lane group of a batch, beside pairs that keep
+    their floor; every record equals the sequential call's and the oracle's."""
+    blk = _noisy_block_correspondences(3000, 300, 1.2, 3)
+    blk2 = _noisy_block_correspondences(4000, 360, 1.3, 9)
+    good = synth.correspondences(5000, 0.05, seed=4, noise=0.1)
+    good2 = synth.correspondences(3000, 0.1, seed=5, noise=0.2)
+    sets = [good[:2], blk, good2[:2], blk2, good[:2]]
+    h1 = ql.Handle(0, **LIMITS)
+    hb = ql.Handle(0, n_slots=12, **LIMITS)   # two lanes of 6: the five pairs share one lane group
+    try:
+        seq = []
+        for k, (s, t) in enumerate(sets):
+            seq.append(h1.solve(s, t))
+            st = h1.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+            assert (st[22] == 1 and st[29] == 0) if k in (1, 3) else (st[22] == 0 and st[29] > 0), (k, st[22], st[29])
+            _same(seq[-1], qo16.solve(s, t))
+        got = hb.register_batch([(None, None, 0, s, t) for (s, t) in sets])
+        for i, (g, r) in enumerate(zip(got, seq)):
+            _same_back_end(g, dict(r, L=len(sets[i][0])))
+    finally:
+        h1.close()
+        hb.close()
+
+
 def test_batch_mixing_the_three_kinds_of_pairs_and_per_pair_failures(qo16):
     """One batch holding scan-only pairs (the matcher's own correspondences), correspondence-only pairs and pairs with
     both, plus descriptors the entry has to refuse pair by pair: each record equals the matching sequential call, the
