@@ -2450,79 +2450,72 @@ __device__ __forceinline__ CoteOut cote_axis4(bool act, int tl, const double* __
     dbg[slot] = (int)((tc1 - tc0) >> 4);                 \
     tc0 = tc1;                                           \
   }
-  // ---- 1./2. sort of (key, position), ascending; keys/positions live in the (still unused) T area.
-  // Up to 256 endpoints (cliques of up to 128 members) every thread RANKS its endpoint by counting the smaller ones —
-  // one pass over the keys in LDS (broadcast reads), one barrier — instead of the 28 - 36 barrier-separated stages of a
-  // bitonic network (measured, clocks / 16: 1591 -> 886 at 136 endpoints, 823 -> 358 at 42); the order is the same (ties
-  // by position).  Larger sets keep the network: counting is O(n^2) and the three axes share one compute unit (370
-  // endpoints: 2494 for the network, 3988 counting).
+  // ---- 1./2. sort of (key, position), ascending; keys/positions live in the (still unused) T area (two buffers).
+  // A merge sort by RANKS: sorted blocks of B endpoints are merged pairwise by letting every endpoint find, by binary
+  // search, how many endpoints of the partner block precede it — its place in the merged block is that plus its place in
+  // its own — log2(n) rounds of one barrier each, ~45 dependent LDS reads per endpoint in all.  (Rounds 2 - 3: a bitonic
+  // network, 45 barrier-separated stages at 512 endpoints, 15.9 us; up to 256 endpoints every endpoint counted the
+  // smaller ones, 11 us at 248.)  (key, position) is a strict total order, so there are no ties to break between blocks.
   int n2 = 1;
   while (n2 < nc) n2 <<= 1;
-  double* ekey = T;
-  int* epos = (int*)(T + n2);
-  if (nc <= 256) {
-    if (act)
-      for (int i = tl; i < nc; i += 256) {
-        const double ri = R ? R[i >> 1] : range;
-        const double k = (i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri;
-        ekey[i] = (k != k) ? INFINITY : k;  // NaN sorts as +inf (ties by position): the ranks below stay a permutation
+  {
+    double* k0 = T;
+    int* p0 = (int*)(T + n2);
+    double* k1 = T + n2 + (n2 >> 1) + 1;
+    int* p1 = (int*)(k1 + n2);
+    if (act && nc > 0)  // (no endpoints: not even the padding is written — the scratch may be empty)
+      for (int i = tl; i < n2; i += 256) {
+        const double ri = (R && i < nc) ? R[i >> 1] : range;
+        const double k = (i < nc) ? ((i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri) : INFINITY;
+        k0[i] = (k != k) ? INFINITY : k;  // NaN sorts as +inf (ties by position); the padding follows every endpoint
+        p0[i] = i;
       }
     __syncthreads();
-    if (act)
-      for (int i = tl; i < nc; i += 256) {
-        const double ki = ekey[i];
-        int rank = 0;
-        for (int j = 0; j < nc; ++j) {
-          const double kj = ekey[j];
-          rank += (kj < ki) | ((kj == ki) & (j < i));
-        }
-        spos[rank] = i;
-        sxv[rank] = X[i >> 1];
-      }
-    __syncthreads();
-  } else {
-  if (act)
-    for (int i = tl; i < n2; i += 256) {
-      const double ri = (R && i < nc) ? R[i >> 1] : range;
-      const double k = (i < nc) ? ((i & 1) ? X[i >> 1] + ri : X[i >> 1] - ri) : INFINITY;
-      ekey[i] = (k != k) ? INFINITY : k;
-      epos[i] = i;
-    }
-  // A stage whose partner distance j is at most 64 only exchanges inside blocks of 128 consecutive endpoints, and a
-  // block belongs to one wave in every stage (pair t -> thread t mod 256): those stages need no workgroup barrier — a
-  // wave's LDS operations complete in program order — only the stages that cross blocks (j > 64) and the one after such
-  // a stage do.  6 barriers instead of 45 at 512 endpoints, where the barrier (three axes, twelve waves, one compute
-  // unit) was most of a stage's time.
-  bool crossed = true;  // (the keys were written by other waves)
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (crossed || j > 64) __syncthreads();
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      crossed = j > 64;
-      if (act) {
-        for (int t = tl; t < (n2 >> 1); t += 256) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
-          const double ka = ekey[i], kb = ekey[ixj];
-          const int pa = epos[i], pb = epos[ixj];
-          const bool a_gt_b = (ka > kb) | ((ka == kb) & (pa > pb));
-          const bool up = ((i & k) == 0);
-          if (a_gt_b == up) {
-            ekey[i] = kb;
-            ekey[ixj] = ka;
-            epos[i] = pb;
-            epos[ixj] = pa;
+    for (int B = 1; B < n2; B <<= 1) {
+      // (branch-free lower bound over the partner block — a power of two — and two endpoints of a thread side by side: the
+      // reads of a step are independent, and a step is what the round's time is made of)
+      auto place = [&](int i, int lo, double k, int pp) __attribute__((always_inline)) {
+        const int pair_base = i & ~(2 * B - 1), own = i & (B - 1);
+        k1[pair_base + own + lo] = k;
+        p1[pair_base + own + lo] = pp;
+      };
+      if (act)
+        for (int i = tl; i < n2; i += 512) {
+          const int ia = i, ib = i + 256;
+          const bool two = ib < n2;
+          const double ka = k0[ia], kb = two ? k0[ib] : 0.0;
+          const int pa = p0[ia], pb = two ? p0[ib] : 0;
+          const int parta = (ia & ~(2 * B - 1)) + ((ia & B) ? 0 : B), partb = two ? (ib & ~(2 * B - 1)) + ((ib & B) ? 0 : B) : parta;
+          int la = 0, lb = 0;
+          for (int h = B >> 1; h >= 1; h >>= 1) {
+            const double kma = k0[parta + la + h - 1], kmb = k0[partb + lb + h - 1];
+            const int pma = p0[parta + la + h - 1], pmb = p0[partb + lb + h - 1];
+            la += ((kma < ka) | ((kma == ka) & (pma < pa))) ? h : 0;
+            lb += ((kmb < kb) | ((kmb == kb) & (pmb < pb))) ? h : 0;
           }
+          {
+            const double kma = k0[parta + la], kmb = k0[partb + lb];
+            const int pma = p0[parta + la], pmb = p0[partb + lb];
+            la += ((kma < ka) | ((kma == ka) & (pma < pa))) ? 1 : 0;
+            lb += ((kmb < kb) | ((kmb == kb) & (pmb < pb))) ? 1 : 0;
+          }
+          place(ia, la, ka, pa);
+          if (two) place(ib, lb, kb, pb);
         }
+      __syncthreads();
+      double* tk = k0;
+      k0 = k1;
+      k1 = tk;
+      int* tp = p0;
+      p0 = p1;
+      p1 = tp;
+    }
+    if (act)
+      for (int i = tl; i < nc; i += 256) {
+        const int p = p0[i];
+        spos[i] = p;
+        sxv[i] = X[p >> 1];
       }
-    }
-  }
-  __syncthreads();
-  if (act)
-    for (int i = tl; i < nc; i += 256) {
-      const int p = epos[i];
-      spos[i] = p;
-      sxv[i] = X[p >> 1];
-    }
   }
   COTE_TICK(0)
   if (act && tl == 64 * ((sw + 1) & 3)) {  // sum of N ranges in the reference's order (:660), off the serial wave
