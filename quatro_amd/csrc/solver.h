@@ -37,6 +37,11 @@ struct SolverBufs {
   int* picks_buf = nullptr;  // [CLIQUE_BATCH][L] greedy picks of every start of the current batch
   SolverState* st = nullptr;
   qtr_result* res = nullptr;
+  // [Lcap + 1] doubles: [0] the COTE range the table was made for, [n] = that range added up n times in sequence (the
+  // reference's sum of N ranges, include/quatro.hpp:660, for every N: the host lays the table down when the range changes
+  // — solver_enqueue* — so that k_finalize need not run the chain of N dependent additions); range_rg: the host's copy of [0]
+  double* range_pre = nullptr;
+  mutable double range_rg = -1.0;
   int* mail = nullptr;  // device view of the slot's pinned host mailbox (frontend.h MAIL_*), or null
   int mail_seq = 0;     // sequence number the next k_finalize / k_clique_only publishes
 };
@@ -64,6 +69,7 @@ struct SolverView {
   // (qtr_max_clique).  Readers go through solver_degree().
   const unsigned char* degp;
   int Lp;
+  const double* range_pre;  // SolverBufs::range_pre
 };
 struct SolverArgs {
   SolverView one;

@@ -2961,8 +2961,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
       s_cost = costg;
       s_iters = itersg;
     }
-  } else if (wave == 1 && lane == 0) {
-    // (idle while wave 0 runs GNC) COTE needs the sum of its N ranges in the reference's sequential order (:660) — N is only
+  } else if (wave == 1 && lane == 0 && !(A.range_pre && A.range_pre[0] == prm.cote_noise_bound * sqrt(prm.cbar2))) {
+    // (only without the host's table of these sums, SolverBufs::range_pre; idle while wave 0 runs GNC) COTE needs the sum of its N ranges in the reference's sequential order (:660) — N is only
     // known after the rotation inliers, so the sums for EVERY n are laid down now: a chain of M additions that used to sit
     // on COTE's critical path (2 us at 250 members).  Behind the GNC arrays in LDS when there is room, else in scratch.
     const double rg = prm.cote_noise_bound * sqrt(prm.cbar2);
@@ -3023,7 +3023,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   if (tid == 0) {
     const double* pre = use_lds && (size_t)8 * M * sizeof(double) <= (size_t)FIN_LDS_BYTES ? fin_lds + 7 * (size_t)M
                                                                                             : A.f64 + 68 * (size_t)L;
-    s_range_sum = N > 0 ? pre[N - 1] : 0.0;
+    const bool table = A.range_pre && A.range_pre[0] == prm.cote_noise_bound * sqrt(prm.cbar2);
+    s_range_sum = N > 0 ? (table ? A.range_pre[N] : pre[N - 1]) : 0.0;
   }
   int* sel = A.i32;  // N selected vertex ids
   for (int i = tid; i < N; i += nthr) sel[i] = use_rot ? A.clique[A.rot_inl[i]] : A.clique[i];
@@ -3196,6 +3197,7 @@ size_t solver_scratch_bytes(int Lcap) {
   b += 24 * (size_t)Lcap * 4;           // i32
   b += W * 8 + 4096;
   b += (size_t)CLIQUE_BATCH * Lcap * 4;  // picks_buf
+  b += ((size_t)Lcap + 2) * 8 + 256;     // range_pre
   return b;
 }
 
@@ -3224,6 +3226,8 @@ void solver_carve(SolverBufs& B, void* base, int Lcap) {
   B.i32 = (int*)take(24 * (size_t)Lcap * 4);
   B.member_bits = (u64*)take(W * 8);
   B.picks_buf = (int*)take((size_t)CLIQUE_BATCH * Lcap * 4);
+  B.range_pre = (double*)take(((size_t)Lcap + 2) * 8);
+  B.range_rg = -1.0;
   B.st = (SolverState*)take(sizeof(SolverState));
   B.res = (qtr_result*)take(sizeof(qtr_result));
 }
@@ -3262,6 +3266,7 @@ static SolverView make_solver_view(const SolverBufs& B, const float4* src, const
   V.res = B.res;
   V.mail = B.mail;
   V.seq = B.mail_seq;
+  V.range_pre = (B.range_rg > 0.0) ? B.range_pre : nullptr;
   return V;
 }
 // one pair in the kernel arguments, or a group through the stage
@@ -3556,6 +3561,24 @@ hipError_t clique_only_finish(const SolverBufs& B, int L, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// the table of SolverBufs::range_pre for the range of `prm`, laid down when the range differs from the one it holds (the
+// buffers are idle then: a slot runs one call at a time).  Host arithmetic = device arithmetic (IEEE additions, a correctly
+// rounded square root); k_finalize still compares [0] with its own range and runs the chain itself if they differ.
+static hipError_t ensure_range_table(const SolverBufs& B, const qtr_params& prm) {
+  const double rg = prm.cote_noise_bound * sqrt(prm.cbar2);
+  if (!B.range_pre || !(rg > 0.0) || B.range_rg == rg) return hipSuccess;
+  std::vector<double> t((size_t)B.Lcap + 1);
+  t[0] = rg;
+  double r = 0;
+  for (int n = 1; n <= B.Lcap; ++n) {
+    r += rg;
+    t[(size_t)n] = r;
+  }
+  const hipError_t e = hipMemcpy(B.range_pre, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) B.range_rg = rg;
+  return e;
+}
+
 // The whole back end of the G pairs of `views` on `stream` (L known on the host).  The clique heuristic normally
 // terminates after the first two batches (see k_clique_batch); the host checks `done` with the result record.
 static hipError_t solver_launch(const SolverView* views, int G, const qtr_params& prm, ViewStage* stage,
@@ -3600,6 +3623,8 @@ hipError_t solver_enqueue(const SolverBufs& B, const float4* src, const float4* 
                           hipStream_t stream, int* pinned_state /* unused */, hipEvent_t ev_graph, hipEvent_t ev_clique,
                           bool reset_done) {
   (void)pinned_state;
+  const hipError_t e = ensure_range_table(B, prm);
+  if (e != hipSuccess) return e;
   const SolverView V = make_solver_view(B, src, tgt, L);
   return solver_launch(&V, 1, prm, nullptr, stream, ev_graph, ev_clique, reset_done);
 }
@@ -3616,7 +3641,11 @@ hipError_t solver_reset_enqueue(const SolverBufs& B, hipStream_t stream) {
 hipError_t solver_enqueue_group(SolverBufs* const* B, int G, const float4* const* src, const float4* const* tgt,
                                 const int* L, const qtr_params& prm, ViewStage* stage, hipStream_t stream) {
   std::vector<SolverView> v((size_t)G);
-  for (int g = 0; g < G; ++g) v[g] = make_solver_view(*B[g], src[g], tgt[g], L[g]);
+  for (int g = 0; g < G; ++g) {
+    const hipError_t e = ensure_range_table(*B[g], prm);
+    if (e != hipSuccess) return e;
+    v[g] = make_solver_view(*B[g], src[g], tgt[g], L[g]);
+  }
   return solver_launch(v.data(), G, prm, stage, stream, nullptr, nullptr);
 }
 
