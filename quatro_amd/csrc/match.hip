@@ -910,8 +910,6 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   const u32 frag = (u32)half * 32u + (u32)col;
   const int ntiles = D.nb_pad / 32;
-  const int per = (ntiles + gridDim.y - 1) / gridDim.y;
-  const int t0 = blockIdx.y * per, t1 = min(ntiles, t0 + per);
   const h8* __restrict__ baseH = (const h8*)D.baseH;
   const h8* __restrict__ queryH = (const h8*)D.queryH;
   const int* __restrict__ qcol = V.recheck_q;  // listed row -> its row of the query table (k_nn_finish)
@@ -919,7 +917,13 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
   const int qgroups = (nrows + 127) / 128;
-  for (int qg = blockIdx.x; qg < qgroups; qg += gridDim.x) {
+  // work items = (group of 128 listed rows) x (slice of the base tiles); the launch's workgroups are dealt over them with
+  // as many slices per group as there are workgroups for it: a hundred listed rows (direction 1 of a scan pair: ONE
+  // group) then take one tile per workgroup — one round trip — instead of nine behind one another in 64 of 512 workgroups
+  const int nwg = gridDim.x * gridDim.y, wid = blockIdx.y * gridDim.x + blockIdx.x;
+  const int nsl = max(1, min(ntiles, nwg / qgroups)), per = (ntiles + nsl - 1) / nsl;
+  for (int item = wid; item < qgroups * nsl; item += nwg) {
+    const int qg = item / nsl, t0 = (item - qg * nsl) * per, t1 = min(ntiles, t0 + per);
     __syncthreads();
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
