@@ -1138,12 +1138,18 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
       // the peeling workgroup runs instead.  Whatever else keeps the verdict away: 250 ms.
       else if ((polls & 15) == 15) {
         const unsigned long long waited = wall_clock64() - t_start;  // (per thread: the vote makes the decision uniform)
-        if (wg_any(waited > 25000000ull || (waited > 200000ull && tid < NWG && v1 == 0u))) verdict = 3;
+        // ... or somebody else has given up (its mark will never come: without this word the workgroups that did not see
+        // the version-0 neighbour in time — it became resident a moment later — waited out the 250 ms)
+        const bool abandoned = tid == 0 && hca_load_u32((const unsigned*)V.perm + HCA_CTL_FAILED) != 0u;
+        if (wg_any(abandoned || waited > 25000000ull || (waited > 200000ull && tid < NWG && v1 == 0u))) verdict = 3;
       } else __builtin_amdgcn_s_sleep(16);
     }
     v0_valid = false;
     if (verdict == 2) finished = true;
-    if (verdict == 3) break;
+    if (verdict == 3) {
+      if (tid == 0) __hip_atomic_store((unsigned*)V.perm + HCA_CTL_FAILED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
   }
   if (tid == 0) {
     if (!finished) V.perm[HCA_CTL_FAILED] = 1;
