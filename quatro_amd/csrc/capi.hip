@@ -1420,7 +1420,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
 static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out,
-                        bool init_done = false) {
+                        bool init_done = false, bool prep_done = false) {
   flush_nn_totals(s);
   // (an event pair attached to a launch costs ~5 us of queue time on either side of it: a caller that only wants the
   // average duration of the launches — the bench's roofline — has every n-th match timed, qtr_set_nn_event_stride)
@@ -1429,7 +1429,7 @@ static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_fronte
   s.nn_timed_last = (s.fb.nn_events && s.fb.nn_engine != 0) ? 1 : 0;
   s.nn_pending = s.nn_timed_last;
   s.fb.mail_seq = ++s.seq;
-  QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream, init_done));
+  QTR_HIP_TRY(h, match_enqueue(s.fb, ns, nt, *fp, s.stream, init_done, prep_done));
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
   *L_out = s.mail[MAIL_MATCH + MC_NCORR];
   if (*L_out < 0) {  // a multi-workgroup compaction of the tail gave up waiting for a predecessor's count (match.hip)
@@ -1603,19 +1603,20 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
     if (h->long_lists) QTR_TRY(ensure_long_arenas(h, s));
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists));
+    // (k2_fpfh also does the matcher's per-descriptor preparation: norms, hashes, duplicate table — see frontend.hip)
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists, true));
     if (!mean_first) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
-    QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2));
+    QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2, false));
     if (for_solver) QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
-  rc = match_device(h, s, ns, nt, fp, &L, true);
+  rc = match_device(h, s, ns, nt, fp, &L, true, true);
   if (rc != QTR_OK) return rc;
   if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY]) {
     snprintf(h->err, sizeof(h->err), "radius-neighbour lists longer than %d entries (longest %d / %d) exceed the long-list "
@@ -2070,13 +2071,13 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     if (ln.long_lists)
       for (int g : ln.active) QTR_TRY(ensure_long_arenas(h, h->slots[ln.first_slot + g]));
     QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream,
-                                      ln.long_lists));
+                                      ln.long_lists, true));
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, lead.ev[5], 0));
     for (int g : ln.active) {
       Slot& s = h->slots[ln.first_slot + g];
       s.fb.mail_seq = ++s.seq;
     }
-    QTR_HIP_TRY(h, match_enqueue_group(F.data(), G, n2.data(), &J.fp, seeds.data(), &ln.stage, lead.stream));
+    QTR_HIP_TRY(h, match_enqueue_group(F.data(), G, n2.data(), &J.fp, seeds.data(), &ln.stage, lead.stream, true));
     ln.phase = 2;
     return QTR_OK;
   }

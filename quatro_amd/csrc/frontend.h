@@ -95,6 +95,12 @@ struct CloudView {
   float4* spts;
   int* ranges;
   float* mean;
+  // the matcher's per-descriptor preparation at the end of k2_fpfh (whole-path chains; null / 0: k_desc_prep does it):
+  // |d|^2, the hash and the row's entry in the duplicate table, which k2_normals cleared earlier in the chain
+  float* norms;
+  u64* dd_hash;
+  u64* dd_table;
+  int dd_mask;
 };
 struct Clouds2 {
   CloudView c[2];        // up to two clouds travel in the kernel arguments ...
@@ -223,12 +229,16 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 // origin_known: the clouds are the voxel centroids voxelize_enqueue just produced in the same CloudBufs (its bounding box
 // is still there and serves as the neighbour grid's origin)
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known, bool long_lists);
+                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep = false);
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
 // init_done: match_init_enqueue already ran for this pair (same ns, nt, fp) — the whole-path driver issues it beside the
 // FPFH chain, which takes one launch off the critical path
-hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done = false);
-hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st);
+// prep_done: the clouds' k2_fpfh did k_desc_prep's work (fpfh_enqueue* with desc_prep) — then the init may not clear the
+// duplicate tables (k2_normals did, before they were filled)
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done = false,
+                         bool prep_done = false);
+hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st,
+                              bool clear_tables = true);
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
 
 // The same stages for G pairs at once (qtr_submit_batch): one launch chain, the views of all pairs in device memory
@@ -237,9 +247,9 @@ hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* cons
                                   ViewStage* stage, hipStream_t st);
 hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st);
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st, bool long_lists);
+                              hipStream_t st, bool long_lists, bool desc_prep = false);
 hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
-                               const unsigned long long* seeds, ViewStage* stage, hipStream_t st);
+                               const unsigned long long* seeds, ViewStage* stage, hipStream_t st, bool prep_done = false);
 
 // shared small kernels (defined in frontend.hip)
 hipError_t exclusive_scan_i32(const int* in, int* out, int n, hipStream_t st);  // out has n+1 entries

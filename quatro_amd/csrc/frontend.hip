@@ -1158,15 +1158,59 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
 // representable in binary64 (2816 < 2^12, 24 + 12 + 17 = 53), so ANY summation order gives the reference's bits: the
 // threads then keep private binary64 sums and add them up at the end.  Otherwise (not seen on lidar data; covered by a
 // test) one thread per block redoes the sum in the reference's order.
+// The matcher's preparation of one descriptor (k_desc_prep restated for the end of k2_fpfh): |d|^2 as a binary64 sum rounded
+// once, the 64-bit hash, and the row's entry in the duplicate table — slot sequence from the low hash bits, tag = high 32
+// bits, value = lowest row with that tag.
+// The hash is a SUM of per-component mixes (then one more mix): the 33 threads that hold a descriptor's components in
+// k2_fpfh each add theirs to a word in LDS — as a chain over the components (round 2's form) it was 500 dependent
+// instructions of one thread per descriptor.
+__device__ __forceinline__ u64 desc_mix64(u64 x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ u64 desc_hash_term(float v, int k) {
+  return desc_mix64(((u64)__float_as_uint(v) | ((u64)(k + 1) << 32)) * 0x9E3779B97F4A7C15ULL);
+}
+__device__ __forceinline__ u64 desc_hash33(const float* d) {
+  u64 h = 0;
+  for (int k = 0; k < 33; ++k) h += desc_hash_term(d[k], k);
+  return desc_mix64(h);
+}
+__device__ __forceinline__ void desc_table_insert(u64* __restrict__ table, int mask, u64 h, int i) {
+  const u64 tag = h & 0xffffffff00000000ULL;
+  u32 slot = (u32)h & (u32)mask;
+  for (int probe = 0; probe <= mask; ++probe) {
+    // (load first: claiming the slot with the CAS straight away saves a round trip on an empty slot but was measured
+    // slower — thousands of identical descriptors then queue on one word)
+    u64 cur = table[slot];
+    if (cur == ~0ULL) {
+      const u64 old = atomicCAS(&table[slot], ~0ULL, tag | (u32)i);
+      if (old == ~0ULL) break;
+      cur = old;
+    }
+    if ((cur & 0xffffffff00000000ULL) == tag) {
+      // entries only ever decrease, so a (possibly stale) value that is already <= i makes the atomic redundant
+      if ((u32)cur > (u32)i) atomicMin(&table[slot], tag | (u32)i);
+      break;
+    }
+    slot = (slot + 1) & (u32)mask;
+  }
+}
 #define FPFH_PB 7
 #define FPFH_CHUNK 32
 __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
-                                             const NbrLists NL, float* __restrict__ fpfh) {
+                                             const NbrLists NL, float* __restrict__ fpfh, float* __restrict__ norms,
+                                             u64* __restrict__ hashes, u64* __restrict__ table, int mask) {
   __shared__ int s_idx[FPFH_PB][FPFH_CHUNK];
   __shared__ float s_w[FPFH_PB][FPFH_CHUNK];  // 1 / d^2, or 0 for an entry the reference skips (d^2 == 0)
   __shared__ int s_k[FPFH_PB];
   __shared__ double s_part[FPFH_PB][33];
   __shared__ float s_vmin[FPFH_PB][33], s_vmax[FPFH_PB][33];
+  __shared__ u64 s_hsum[FPFH_PB];
   const int tid = threadIdx.x, i0 = blockIdx.x * FPFH_PB;
   if (i0 >= n) return;
   const int np = min(FPFH_PB, n - i0);
@@ -1174,6 +1218,7 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
   const bool owner = pi < np;
   const int lp = tid >> 5, lq = tid & 31;          // staging role: (point, entry of the chunk); 7 x 32 = 224 threads
   if (tid < FPFH_PB) s_k[tid] = (tid < np) ? max(nbr_cnt[i0 + tid], 0) : 0;
+  if (tid < FPFH_PB) s_hsum[tid] = 0;  // (the descriptors' hashes, see the end)
   __syncthreads();
   int kmax = 0;
 #pragma unroll
@@ -1223,7 +1268,8 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
     s_vmax[pi][b] = vmax;
   }
   __syncthreads();
-  if (!owner) return;
+  __shared__ float s_out[FPFH_PB][33];
+  if (owner) {
   const int blk = b / 11;
   double sum = 0.0;
   float lo = INFINITY, hi = 0.f;
@@ -1257,7 +1303,26 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
     }
   }
   if (sum != 0) sum = 100.0 / sum;
-  fpfh[(size_t)(i0 + pi) * 33 + b] = h * (float)sum;
+  const float out = h * (float)sum;
+  fpfh[(size_t)(i0 + pi) * 33 + b] = out;
+  s_out[pi][b] = out;
+  if (table) atomicAdd(&s_hsum[pi], desc_hash_term(out, b));
+  }
+  if (!table) return;  // (uniform)
+  // the matcher's preparation of the workgroup's descriptors, one thread each: the launch of its own that this used to be
+  // (k_desc_prep, 19 us at 16 - 18 k descriptors per cloud) re-read them and paid the table's round trips on the critical
+  // path; here they hide behind the other workgroups
+  __syncthreads();
+  if (tid < np) {
+    const float* v = s_out[tid];
+    double acc = 0.0;
+    for (int k = 0; k < 33; ++k) acc += (double)v[k] * (double)v[k];
+    const int i = i0 + tid;
+    norms[i] = (float)acc;
+    const u64 hh = desc_mix64(s_hsum[tid]);  // (= desc_hash33(v))
+    hashes[i] = hh;
+    desc_table_insert(table, mask, hh, i);
+  }
 }
 
 // Matcher::normalizePoints mean (reference src/teaser_utils/feature_matcher.cc:27-36): a plain
@@ -1440,6 +1505,9 @@ __global__ __launch_bounds__(1024) void k2_nbr_scan(ViewExt<CloudView> x, Clouds
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_normals(ViewExt<CloudView> x, Clouds2 a, float rn2) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  // (the clean slate of the duplicate table k2_fpfh fills two launches on, when it does the matcher's preparation)
+  if (C.dd_table)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e <= C.dd_mask; e += gridDim.x * 256) C.dd_table[e] = ~0ULL;
   d_normals(C.vox, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, rn2, C.normals);
 }
 template <bool EXT>
@@ -1450,7 +1518,8 @@ __global__ __launch_bounds__(256) void k2_spfh(ViewExt<CloudView> x, Clouds2 a) 
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_fpfh(C.spfh, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, C.fpfh);
+  d_fpfh(C.spfh, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, C.fpfh, C.norms, C.dd_hash,
+         C.dd_table, C.dd_mask);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_seq_mean(ViewExt<CloudView> x, Clouds2 a) {
@@ -1645,11 +1714,20 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
 // long_lists: also launch k2_neighbors_big, which serves the points with more than QTR_KMAX neighbours inside r_fpfh.
 // Voxel-grid centroids at the demo's leaf never have that many, so the whole-path drivers leave it out (one launch
 // fewer on the chain) and check CNT_NBR_OVERFLOW afterwards: if it is set the stage is run again with long_lists.
+static void view_desc_prep(CloudView& v, CloudBufs& C, int dd_slots) {
+  v.norms = C.norms;
+  v.dd_hash = C.dd_hash;
+  v.dd_table = C.dd_table;
+  v.dd_mask = dd_slots - 1;
+}
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known, bool long_lists) {
+                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep) {
   (void)hipGetLastError();
   CloudView v[2];
-  for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
+  for (int c = 0; c < nc; ++c) {
+    v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
+    if (desc_prep) view_desc_prep(v[c], F.cloud[first + c], F.dd_slots);
+  }
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
@@ -1657,11 +1735,14 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   return hipGetLastError();
 }
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st, bool long_lists) {
+                              hipStream_t st, bool long_lists, bool desc_prep) {
   (void)hipGetLastError();
   std::vector<CloudView> v((size_t)2 * G);
   for (int g = 0; g < G; ++g)
-    for (int c = 0; c < 2; ++c) v[2 * g + c] = make_view(F[g]->cloud[c], nullptr, 0, n[2 * g + c], nullptr, nullptr, 0);
+    for (int c = 0; c < 2; ++c) {
+      v[2 * g + c] = make_view(F[g]->cloud[c], nullptr, 0, n[2 * g + c], nullptr, nullptr, 0);
+      if (desc_prep) view_desc_prep(v[2 * g + c], F[g]->cloud[c], F[g]->dd_slots);
+    }
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;

@@ -143,15 +143,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NN_MAXSPLIT 32
 #define NN_NORM_SCALE (1.0 - 141.0 * 5.9604644775390625e-08)
 
-__device__ __forceinline__ u64 desc_hash(const float* d) {
-  u64 h = 0x9E3779B97F4A7C15ULL;
-  for (int k = 0; k < 33; ++k) {
-    h ^= (u64)__float_as_uint(d[k]) + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
-    h *= 0xff51afd7ed558ccdULL;
-    h ^= h >> 33;
-  }
-  return h;
-}
+__device__ __forceinline__ u64 desc_hash(const float* d) { return desc_hash33(d); }  // (frontend.hip: k2_fpfh computes the same)
 
 // the 256 rows of a workgroup, row-major table -> LDS: 33 coalesced loads per thread, all in flight before the first LDS
 // store (as a plain loop the compiler waits for every load: 33 round trips, 8 us of a 15 us kernel)
@@ -1155,7 +1147,7 @@ __device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* 
 }
 
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one) {
+__global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one, int clear_tables) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
@@ -1167,10 +1159,11 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
   for (int i = gid; i < V.ns; i += gsz) V.tgt_of_src[i] = -1;
   for (int i = gid; i < V.n_small; i += gsz) V.best_small[i] = ~0ULL;
   for (int i = gid; i < V.n_large; i += gsz) V.best_large[i] = ~0ULL;
-  for (int i = gid; i <= V.dd_mask; i += gsz) {
-    V.table_i[i] = ~0ULL;
-    V.table_j[i] = ~0ULL;
-  }
+  if (clear_tables)  // (0: the FPFH chain cleared and filled them — frontend.hip, desc_prep)
+    for (int i = gid; i <= V.dd_mask; i += gsz) {
+      V.table_i[i] = ~0ULL;
+      V.table_j[i] = ~0ULL;
+    }
   for (int i = gid; i < 2 * TAIL_MAXWG; i += gsz) V.scan[i] = 0;  // look-back words of k_cross_multi / k_pairs_multi
 }
 
@@ -1984,7 +1977,7 @@ static MatchView make_match_view(FrontBufs& F, int ns, int nt, const qtr_fronten
 // Enqueues the matcher for the pairs of `views` (G of them; one travels in the kernel arguments).  ev: optional
 // brackets of the two k_nn_mfma launches (single pair only).
 static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int n_cu, ViewStage* stage,
-                               hipStream_t st, hipEvent_t const* ev, bool init_done = false) {
+                               hipStream_t st, hipEvent_t const* ev, bool init_done = false, bool prep_done = false) {
   MatchArgs a;
   a.one = views[0];
   a.ext = nullptr;
@@ -2002,7 +1995,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     any_tuple = any_tuple || views[g].tuple;
   }
   const dim3 B256(256);
-  if (!init_done) LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st);
+  if (!init_done)
+    LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st, prep_done ? 0 : 1);
   // K5: NN of every small-cloud descriptor in the large cloud, then of the HIT rows of the large cloud in the small
   // one (the reference asks the latter lazily, feature_matcher.cc:113-122; the mutual test only reads hit rows)
 #ifdef QTR_TEST_ENGINES
@@ -2034,7 +2028,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     (void)nn_engine;
     constexpr bool f16 = true;
 #endif
-    LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, f16 ? 0 : 2);
+    // (the f16 engine needs nothing of k_desc_prep but the norms, hashes and duplicate table: k2_fpfh left them)
+    if (!(prep_done && f16)) LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, f16 ? 0 : 2);
     if (f16) {  // operand tables with the duplicates hidden, straight from the descriptors
       LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
     }
@@ -2152,25 +2147,26 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   return hipGetLastError();
 }
 
-hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st) {
+hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool clear_tables) {
   (void)hipGetLastError();
   MatchArgs a;
   a.one = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
   a.ext = nullptr;
-  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(a.one.n_large, a.one.dd_mask + 1)), 1, 1), dim3(256), 0, st);
+  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(a.one.n_large, a.one.dd_mask + 1)), 1, 1), dim3(256), 0, st, clear_tables ? 1 : 0);
   return hipGetLastError();
 }
-hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done) {
+hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done,
+                         bool prep_done) {
   (void)hipGetLastError();
   const MatchView V = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
   const bool fused_tail = V.crosscheck && V.n_large <= 32768 && ns <= 32768;
   F.gathered = fused_tail && F.m_src != nullptr;
   const bool evs = F.nn_events != 0;
-  return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr, init_done);
+  return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr, init_done, prep_done);
 }
 
 hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
-                               const unsigned long long* seeds, ViewStage* stage, hipStream_t st) {
+                               const unsigned long long* seeds, ViewStage* stage, hipStream_t st, bool prep_done) {
   (void)hipGetLastError();
   std::vector<MatchView> v((size_t)G);
   int max_large = 1, max_ns = 1;
@@ -2181,7 +2177,7 @@ hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const q
   }
   const bool fused_tail = fp->use_crosscheck && max_large <= 32768 && max_ns <= 32768;  // (as match_launch decides)
   for (int g = 0; g < G; ++g) F[g]->gathered = fused_tail && F[g]->m_src != nullptr;
-  return match_launch(v.data(), G, F[0]->nn_engine, F[0]->n_cu, stage, st, nullptr);
+  return match_launch(v.data(), G, F[0]->nn_engine, F[0]->n_cu, stage, st, nullptr, false, prep_done);
 }
 
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st) {
