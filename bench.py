@@ -516,15 +516,19 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, comp
     else:
         out.update(scan)
     hung = False
-    if world > 1 and cdev is not None:  # the gather that closes configs[3]: through the library's own RCCL path
+    # the gather that closes configs[3]: through the library's own RCCL path.  (QTR_BENCH_ONE_DEVICE: real RCCL refuses
+    # two ranks on one device, so the hook's ranks take this path only when QTR_RCCL_LIB names a transport double —
+    # tests/test_gpu_multi.py — and the unique id then travels over gloo on host tensors.)
+    if world > 1 and (cdev is not None or os.environ.get("QTR_RCCL_LIB")):
         g = {"path": "qtr_comm_init + qtr_gather_results_v (RCCL via the C ABI, dlopen)"}
         src_results = results if composite else results2
+        udev = cdev if cdev is not None else torch.device("cpu")
 
         def lib_gather():
             try:
-                uid = torch.zeros(128, dtype=torch.uint8, device=cdev)
+                uid = torch.zeros(128, dtype=torch.uint8, device=udev)
                 if rank == 0:
-                    uid = torch.frombuffer(bytearray(ql.comm_unique_id()), dtype=torch.uint8).to(cdev)
+                    uid = torch.frombuffer(bytearray(ql.comm_unique_id()), dtype=torch.uint8).to(udev)
                 dist.broadcast(uid, 0)
                 hb.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
                 n_loc = len(ids)
@@ -563,18 +567,22 @@ def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
       mutual_nn   the 16-18 k-voxel pool pairs with use_tuple_test = 0 (reference feature_matcher.cc:187-247 skipped):
                   every mutual nearest-neighbour pair, L ~ 2 k
       no_cross    use_crosscheck = 0 as well (:124-181: corres_ij + corres_ji, de-duplicated): L ~ n_s + n_hit ~ 20 k
-      dense       BASELINE configs[4] end to end: two independently sampled 50 000-point clouds, a leaf so small that
-                  the voxel grid would overflow int32 (pcl::VoxelGrid then passes the cloud through — "no voxel
-                  downsample"), FPFH, matching with cross check and tuple test (L ~ 1.1 k) and the back end
+      dense       BASELINE configs[4] end to end: two INDEPENDENT 50 000-point samplings of one structured scene
+                  (synth.dense_scene_pair), a leaf so small that the voxel grid would overflow int32 (pcl::VoxelGrid then
+                  passes the cloud through — "no voxel downsample"), FPFH, matching with cross check and tuple test
+                  (L ~ 2.1 k) and the back end: a registration that LANDS (clique ~160, centimetres from the truth)
+      dense_mutual  the same with use_tuple_test = 0: every mutual nearest-neighbour pair of the 50 k x 50 k search goes
+                  into the back end — L ~ 14 k of the matcher's own correspondences (configs[4]'s "~20 k corr")
     (parity of each against the oracle: tests/test_gpu_baseline_sizes.py)."""
     hc = ql.Handle(device_index, max_points=131072, max_voxels=65536, max_corr=32768)
     res = ql.Result()
     out = {}
-    a, b, Td = synth.dense_pair(50000)
+    a, b, Td = synth.dense_scene_pair(50000)
     dense = {"src": torch.from_numpy(a).to(dev), "tgt": torch.from_numpy(b).to(dev), "Tgt": Td}
     cases = [("mutual_nn", dict(use_tuple_test=0), pool, 12),
              ("no_cross", dict(use_crosscheck=0, use_tuple_test=0), pool, 8),
-             ("dense", dict(voxel_size=0.001), [dense], 4)]
+             ("dense", dict(voxel_size=0.001), [dense], 6),
+             ("dense_mutual", dict(voxel_size=0.001, use_tuple_test=0), [dense], 6)]
     hc.set_stage_events(False)
     hc.set_nn_event_stride(0)
     for name, kw, items, n in cases:
@@ -697,15 +705,90 @@ def solver_leg(args, torch, ql, synth, h, prm, dev, L):
                             "frac": (gb / gk / 1e9 / HBM_PEAK_GBS) if gk > 0 else 0.0}}
 
 
+def nn_roofline_two(n_rows1, n_rows2, n_cols1, n_cols2, ms_dir1, ms_dir2):
+    """roofline of the two nearest-neighbour launches of ONE match, each priced with ITS OWN rows: direction 1 evaluates
+    n_rows1 x n_cols1 entries (every row of the smaller cloud against the larger one), direction 2 n_rows2 x n_cols2 (only
+    the rows of the larger cloud some row of the smaller one chose, feature_matcher.cc:113-122).  The leading fields are
+    the two launches together (entries of both / time of both)."""
+    e1, e2 = float(n_rows1) * n_cols1, float(n_rows2) * n_cols2
+    r = nn_roofline((e1 + e2) / 2.0, 1e-3 * (ms_dir1 + ms_dir2) / 2.0)
+    d1, d2 = nn_roofline(e1, 1e-3 * ms_dir1), nn_roofline(e2, 1e-3 * ms_dir2)
+    r["accounting"] = "each launch priced with its own rows x columns; leading fields = both launches together"
+    r["direction1"] = {"rows": int(n_rows1), "cols": int(n_cols1), "launch_ms": ms_dir1, "achieved": d1["achieved"], "frac": d1["frac"]}
+    r["direction2"] = {"rows": int(n_rows2), "cols": int(n_cols2), "launch_ms": ms_dir2, "achieved": d2["achieved"], "frac": d2["frac"]}
+    return r
+
+
 def dense_legs(args, torch, ql, synth, prm, dev, device_index):
-    """BASELINE configs[4]: dense mode — 50 k-point clouds without voxel down-sampling through FPFH + matching (the NN
-    contraction at 50 k x 50 k = 1.65e11 FLOP per direction) and the solver at L = 20 000 (50 MB bit matrix)."""
+    """BASELINE configs[4]: dense mode — 50 k-point clouds, no voxel down-sampling, ~20 k correspondences.
+      dense_step_leg      configs[4] as ONE step and ONE call (qtr_register_pair_corr): the front end of two 50 000-point
+                          scans of one structured scene (synth.dense_scene_pair; the voxel grid passes them through, as
+                          pcl::VoxelGrid does when the leaf would overflow its index) + the back end on 20 000 given
+                          correspondences (2 % planted) — the dense analogue of the headline's composite step
+      dense_solver_leg    the back end alone at L = 20 000 (50 MB bit matrix)
+      dense_frontend_leg  FPFH + matching alone on the same clouds (qtr_fpfh x2 + qtr_match)
+    (the data-CONNECTED dense registrations — the matcher's own 2 k / 14 k correspondences into the back end — are
+    connected_leg.dense / dense_mutual)."""
     out = {}
     hd = ql.Handle(device_index, max_points=65536, max_voxels=65536, max_corr=24576)
     res = ql.Result()
     L = 20000
-    s, t, _, _ = synth.correspondences(L, 0.02, seed=7, noise=0.1)
+    s, t, Tc, planted = synth.correspondences(L, 0.02, seed=7, noise=0.1)
     sd, td = torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)
+    n_pts = 50000
+    a, b, Td = synth.dense_scene_pair(n_pts)
+    cl = [torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)]
+    fpd = ql.default_frontend_params(voxel_size=0.001, seed=1)
+
+    # ---- configs[4] as one step
+    def dstep():
+        rc = hd.register_pair_corr_dev(cl[0].data_ptr(), n_pts, cl[1].data_ptr(), n_pts, fpd, sd.data_ptr(), td.data_ptr(), L,
+                                       prm, res)
+        if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
+            raise ql.QuatroHipError(rc, hd.last_error())
+    hd.set_stage_events(True)
+    hd.set_nn_event_stride(1)
+    dstep()   # (the first call on a handle also sizes its lazily allocated arenas)
+    dstep()
+    st = dict(hd.stage_times())
+    n_hit = int(hd.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[7])
+    T = np.array(res.T[:]).reshape(4, 4)
+    yaw_gt, yaw = float(np.arctan2(Tc[1, 0], Tc[0, 0])), float(np.arctan2(T[1, 0], T[0, 0]))
+    rec = {"n_src": int(res.n_src), "n_tgt": int(res.n_tgt), "n_corr": int(res.n_corr), "n_hit": n_hit,
+           "n_clique": int(res.n_clique), "n_final": int(res.n_final), "valid": bool(res.valid),
+           "rot_err_vs_gt_rad": abs(float(np.arctan2(np.sin(yaw - yaw_gt), np.cos(yaw - yaw_gt)))),
+           "trans_err_vs_gt_m": float(np.linalg.norm(T[:3, 3] - Tc[:3, 3]))}
+    hd.set_stage_events(False)
+    hd.set_nn_event_stride(0)
+    dstep()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dstep()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms_step = 1e3 * el / reps
+    ab, af = algorithmic_work(n_pts, n_pts, rec["n_src"], rec["n_tgt"], L, rec["n_clique"])
+    af += 66.0 * n_hit * min(rec["n_src"], rec["n_tgt"])   # (both directions: at 50 k the second one is not small change)
+    roof = nn_roofline_two(min(rec["n_src"], rec["n_tgt"]), n_hit, max(rec["n_src"], rec["n_tgt"]),
+                           min(rec["n_src"], rec["n_tgt"]), st["nn_dir1"], st["nn_dir2"]) if st["nn_dir1"] > 0 else None
+    f16_ms = 1e3 * (af / F32_FLOP_PER_ENTRY * F16_FLOP_PER_ENTRY) / (F16_PEAK_TFLOPS * 1e12)
+    hbm_ms = 1e3 * ab / (HBM_PEAK_GBS * 1e9)
+    if roof is not None:
+        roof["end_to_end"] = {"algorithmic_gflop_per_registration": af / 1e9, "algorithmic_mbytes_per_registration": ab / 1e6,
+                              "mfma_bound_ms": 1e3 * af / (FP32_PEAK_TFLOPS * 1e12), "mfma_f16_bound_ms": f16_ms,
+                              "hbm_bound_ms": hbm_ms, "ms_per_step": ms_step,
+                              "frac": max(1e3 * af / (FP32_PEAK_TFLOPS * 1e12), hbm_ms) / ms_step,
+                              "frac_on_f16_pipe": max(f16_ms, hbm_ms) / ms_step}
+    out["dense_step_leg"] = {
+        "what": f"BASELINE configs[4] as ONE call (qtr_register_pair_corr): front end of two {n_pts}-point scans (no voxel "
+                f"down-sampling) + back end on {L} given correspondences",
+        "value": reps / el, "unit": "registrations/s", "ms_per_step": ms_step, "steps": reps, "record": rec,
+        "stage_ms": {k: round(float(v), 4) for k, v in st.items() if k != "nn_launches"}, "roofline": roof}
+
+    # ---- the back end alone
+    hd.set_stage_events(True)
     hd.solve_dev(sd.data_ptr(), td.data_ptr(), L, prm, res)
     torch.cuda.synchronize()
     n = 5
@@ -723,15 +806,15 @@ def dense_legs(args, torch, ql, synth, prm, dev, device_index):
         "value": n / el, "unit": "solves/s", "ms_per_solve": 1e3 * el / n, "n_clique": int(res.n_clique),
         "roofline": {"kernel": "k_graph_build", "bound": "hbm", "algorithmic_bytes": gb, "stage_ms": 1e3 * gk,
                      "achieved": gb / gk / 1e9 if gk > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (gb / gk / 1e9 / HBM_PEAK_GBS) if gk > 0 else 0.0}}
-    # front end at 50 k points per cloud, no voxel grid: qtr_fpfh + qtr_match on device-resident arrays
-    n_pts = 50000
-    a, b, _ = synth.dense_pair(n_pts)
-    cl = [torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)]
+                     "frac": (gb / gk / 1e9 / HBM_PEAK_GBS) if gk > 0 else 0.0,
+                     "note": "the kernel is bound by its vector-instruction count, not by HBM (profiles/r*_graph_sq.txt): "
+                             "L^2/2 predicates per launch is the unit that matters"}}
+    # ---- the front end alone at 50 k points per cloud, no voxel grid: qtr_fpfh + qtr_match on device-resident arrays
     desc = [torch.zeros((n_pts, 33), dtype=torch.float32, device=dev) for _ in range(2)]
     fp = ql.default_frontend_params(seed=1)
     corr = torch.zeros((n_pts, 2), dtype=torch.int32, device=dev)
     Lout = C.c_int()
+    hd.set_nn_event_stride(1)
 
     def fe_once():
         f_ms = 0.0
@@ -750,19 +833,21 @@ def dense_legs(args, torch, ql, synth, prm, dev, device_index):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 3
-    nn_ms, nn_l, f_acc, m_acc = 0.0, 0, 0.0, 0.0
+    d1_ms, d2_ms, f_acc, m_acc = 0.0, 0.0, 0.0, 0.0
     for _ in range(reps):
         f_ms, st = fe_once()
-        nn_ms += st["nn_kernel"]
-        nn_l += st["nn_launches"]
+        d1_ms += st["nn_dir1"]
+        d2_ms += st["nn_dir2"]
         f_acc += f_ms
         m_acc += st["match"]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    n_hit = int(hd.debug_fetch(ql.DBG_MATCH_STATS, np.int32)[7])
     out["dense_frontend_leg"] = {
         "what": f"FPFH + reciprocal matching of two {n_pts}-point clouds, no voxel down-sampling",
         "ms_per_pair": 1e3 * el / reps, "fpfh_ms": f_acc / reps, "match_ms": m_acc / reps, "n_corr": int(Lout.value),
-        "roofline": nn_roofline(float(n_pts) * n_pts, 1e-3 * nn_ms / max(nn_l, 1)) if nn_ms > 0 else None}
+        "n_hit": n_hit,
+        "roofline": nn_roofline_two(n_pts, n_hit, n_pts, n_pts, d1_ms / reps, d2_ms / reps) if d1_ms > 0 else None}
     hd.close()
     return out
 

@@ -148,6 +148,8 @@ typedef struct qtr_stage_times {
   float nn_kernel;  /* sum of the nearest-neighbour kernel launches of the last match (events on the launch stream) */
   int nn_launches;
   float graph_kernel; /* k_graph_build alone */
+  float nn_dir1, nn_dir2; /* the two launches behind nn_kernel: every row of the smaller cloud against the larger one, and the
+                             rows of the larger cloud that were chosen against the smaller one (feature_matcher.cc:113-122) */
 } qtr_stage_times;
 
 QTR_API int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);

@@ -2,8 +2,10 @@
 // Host-side orchestration only: arenas, stream slots, staging copies, kernel sequencing.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -94,12 +96,17 @@ struct qtr_handle {
   bool pre_on = false;      // qtr_set_batch_preprocess: the batched entry takes RAW sweeps (ground removal + range-image
   qtr_pw_params pre_pw;     // segmentation in front of the voxel grid)
   qtr_ip_params pre_ip;
-  bool long_lists = false;  // some cloud of the whole-path entry points had a point with more than QTR_KMAX neighbours:
-                            // from then on their FPFH chains include k2_neighbors_big (see front_device)
+  std::atomic<bool> long_lists{false};  // some cloud of the whole-path entry points had a point with more than QTR_KMAX
+                            // neighbours: from then on their FPFH chains include k2_neighbors_big (see front_device); written
+                            // by whichever slot call meets such a cloud first (calls from several threads)
+  std::atomic<int> n_callers{0};  // distinct host threads that have run a back-end chain on this handle (InFlight)
+  unsigned long long uid = 0;     // process-unique id of this handle (a thread remembers the handle it registered with)
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   int nn_event_stride = 1;  // every n-th match of a slot carries the nearest-neighbour event pairs (0: none)
   char err[512];
 };
+
+static std::atomic<unsigned long long> g_handle_uid{0};
 
 #define QTR_TRY(expr)                  \
   do {                                 \
@@ -451,6 +458,7 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   if (!h) return QTR_ERR_CAPACITY;
   h->err[0] = 0;
   h->device = device;
+  h->uid = g_handle_uid.fetch_add(1, std::memory_order_relaxed) + 1;
   {
     const char* hw = getenv("QTR_HOST_WAIT");
     h->spin_wait = (hw && strcmp(hw, "block") == 0) ? 0 : 1;
@@ -497,6 +505,8 @@ static void fill_nn_times(Slot& s) {
       hipEventElapsedTime(&b, s.fb.ev_nn[2], s.fb.ev_nn[3]) == hipSuccess) {
     s.times.nn_kernel = a + b;
     s.times.nn_launches = 2;
+    s.times.nn_dir1 = a;
+    s.times.nn_dir2 = b;
   }
 }
 
@@ -617,9 +627,9 @@ static void compute_times(Slot& s) {
 static int ensure_long_arenas(qtr_handle* h, Slot& s) {
   for (int c = 0; c < 2; ++c) {
     CloudBufs& cb = s.fb.cloud[c];
-    if (cb.nbr_big_idx && cb.nbr_big_d2) continue;
-    QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_idx, (size_t)h->lim.max_long_neighbors * 4));
-    QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_d2, (size_t)h->lim.max_long_neighbors * 4));
+    // (each pointer on its own: a failed second allocation must not make the next call allocate the first one again)
+    if (!cb.nbr_big_idx) QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_idx, (size_t)h->lim.max_long_neighbors * 4));
+    if (!cb.nbr_big_d2) QTR_HIP_TRY(h, hipMalloc((void**)&cb.nbr_big_d2, (size_t)h->lim.max_long_neighbors * 4));
     cb.nbr_big_cap = h->lim.max_long_neighbors;
   }
   return QTR_OK;
@@ -714,11 +724,27 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
   return QTR_OK;
 }
 
+// k_hcore_async's workgroups of one chain have to be resident together, so chains that may overlap must not ask for more
+// than the compute units between them.  Who may overlap is decided by WHO CALLS, not by what happens to be in flight at
+// the moment of the call (round 4 looked at the in-flight count: the first of several threads took the whole device and
+// the others' launches were only partly resident until a residency timeout sent them to the peeling fallback): every
+// host thread registers with the handle on its first back-end call, and from the moment a second thread has registered
+// every chain takes 1 / min(threads, slots) of the units.  The one chain that may be in flight with a full share at that
+// moment is waited for once.  A single-threaded caller never pays anything.  (QTR_DBG_CORE and the floor statistics
+// st[22] / st[29] depend on timing either way: the floor is decided by what has been published 200 us into the launch.)
 struct InFlight {
   qtr_handle* h;
   explicit InFlight(qtr_handle* h_) : h(h_) {
-    const int others = h->solves_in_flight.fetch_add(1, std::memory_order_acq_rel);
-    solver_set_hca_share(others > 0 ? (int)h->slots.size() : 1);
+    static thread_local unsigned long long t_registered_with = 0;
+    if (t_registered_with != h->uid) {
+      t_registered_with = h->uid;
+      if (h->n_callers.fetch_add(1, std::memory_order_acq_rel) == 1)  // the second thread: let a full-share chain drain
+        for (int spins = 0; h->solves_in_flight.load(std::memory_order_acquire) > 0 && spins < 2000000; ++spins)
+          std::this_thread::yield();
+    }
+    h->solves_in_flight.fetch_add(1, std::memory_order_acq_rel);
+    const int callers = h->n_callers.load(std::memory_order_acquire);
+    solver_set_hca_share(std::max(1, std::min(callers, (int)h->slots.size())));
   }
   ~InFlight() { h->solves_in_flight.fetch_sub(1, std::memory_order_acq_rel); }
 };
@@ -1420,7 +1446,7 @@ int qtr_fpfh(qtr_handle* h, int slot, const float* xyz4, int n, float r_normal, 
 
 // Matching on device-resident clouds/descriptors held in fb.cloud[0] (source) and fb.cloud[1] (target).
 static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_frontend_params* fp, int* L_out,
-                        bool init_done = false, bool prep_done = false) {
+                        bool init_done = false, bool prep_done = false, bool tolerate_tail = false) {
   flush_nn_totals(s);
   // (an event pair attached to a launch costs ~5 us of queue time on either side of it: a caller that only wants the
   // average duration of the launches — the bench's roofline — has every n-th match timed, qtr_set_nn_event_stride)
@@ -1433,6 +1459,7 @@ static int match_device(qtr_handle* h, Slot& s, int ns, int nt, const qtr_fronte
   QTR_TRY(wait_mail(h, s, MAIL_SEQ_MATCH, s.seq));  // k_corr_compact2 left the counters in the mailbox
   *L_out = s.mail[MAIL_MATCH + MC_NCORR];
   if (*L_out < 0) {  // a multi-workgroup compaction of the tail gave up waiting for a predecessor's count (match.hip)
+    if (tolerate_tail) return QTR_OK;  // (nobody reads the matcher's list: the caller reports -1 as the matched count)
     *L_out = 0;
     (void)hipStreamSynchronize(s.stream);
     snprintf(h->err, sizeof(h->err), "matcher tail: look-back timed out (no correspondences were written)");
@@ -1492,7 +1519,11 @@ int qtr_match(qtr_handle* h, int slot, const float* xyz4_s, int n_s, const float
 // `for_solver` the solver's clean slate is enqueued beside the FPFH chain (qtr_register_pair).  An error return leaves
 // nothing in flight that still reads the caller's scans.
 static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, const float* tgt_raw4, int Pt,
-                        const qtr_frontend_params* fp, int mem, bool for_solver, int* ns_out, int* nt_out, int* L_out) {
+                        const qtr_frontend_params* fp, int mem, bool for_solver, int* ns_out, int* nt_out, int* L_out,
+                        bool corr_given = false) {
+  // corr_given: the back end will run on the CALLER's correspondences — the matcher's list is only counted (*L_out; -1 when
+  // its tail gave up), so neither a list longer than max_corr nor a tail failure fails the registration, and the matched
+  // clouds are not gathered.
   int rc = QTR_OK;
   if (fp->normal_radius > fp->fpfh_radius) {
     snprintf(h->err, sizeof(h->err), "[FPFHManager]: Normal should be lower than fpfh_radius!!!!");
@@ -1616,7 +1647,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
   }
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[6], s.stream));
   int L = 0;
-  rc = match_device(h, s, ns, nt, fp, &L, true, true);
+  rc = match_device(h, s, ns, nt, fp, &L, true, true, corr_given);
   if (rc != QTR_OK) return rc;
   if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY]) {
     snprintf(h->err, sizeof(h->err), "radius-neighbour lists longer than %d entries (longest %d / %d) exceed the long-list "
@@ -1629,9 +1660,10 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     // the demo's leaf never have that many, so the launch is left out until a cloud needs it): descriptors and matches
     // of this call are not usable.  From now on the handle's chains include it; this pair goes round again.
     h->long_lists = true;
-    return front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, for_solver, ns_out, nt_out, L_out);
+    return front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, for_solver, ns_out, nt_out, L_out, corr_given);
   }
   *L_out = L;
+  if (corr_given) return QTR_OK;
   s.last_L = L;
   if (L > h->lim.max_corr) {
     snprintf(h->err, sizeof(h->err), "L=%d exceeds max_corr=%d", L, h->lim.max_corr);
@@ -1650,7 +1682,7 @@ static int register_pair_impl(qtr_handle* h, Slot& s, const float* src_raw4, int
                               int* final_inliers, int cap, int mem_in, int mem_out, const float4* corr_src,
                               const float4* corr_tgt, int n_corr) {
   int L = 0;
-  int rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem_in, true, &res->n_src, &res->n_tgt, &L);
+  int rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem_in, true, &res->n_src, &res->n_tgt, &L, n_corr >= 0);
   res->n_corr = L;
   if (rc != QTR_OK) return res->status = rc;
   if (n_corr >= 0) {
@@ -1698,8 +1730,8 @@ int qtr_register_pair_corr(qtr_handle* h, int slot, const float* src_raw4, int P
     return res->status = QTR_ERR_CAPACITY;
   }
   int Lm = 0;
-  rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, true, &res->n_src, &res->n_tgt, &Lm);
-  if (n_matched) *n_matched = Lm;
+  rc = front_device(h, s, src_raw4, Ps, tgt_raw4, Pt, fp, mem, true, &res->n_src, &res->n_tgt, &Lm, true);
+  if (n_matched) *n_matched = Lm;  // (-1: the matcher's tail gave up — its list is not used here)
   res->n_corr = n_corr;
   if (rc != QTR_OK) return res->status = rc;
   const float4 *cs = (const float4*)corr_src4, *ct = (const float4*)corr_tgt4;
@@ -2096,12 +2128,14 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       const bool given = pair_has_corr(pd);  // the back end runs on the caller's correspondences, not the matcher's
       const int Lm = s.mail[MAIL_MATCH + MC_NCORR];
       if (!given) r.n_corr = Lm;
-      if (Lm < 0) {  // the tail's look-back timed out (match.hip): nothing usable was written for this pair
+      if (Lm < 0 && !given) {  // the tail's look-back timed out (match.hip): nothing usable was written for this pair
         r.n_corr = 0;
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_HIP);
         continue;
       }
-      if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY] || Lm > h->lim.max_corr) {
+      // (a pair that brought its correspondences does not read the matcher's list: its length is no reason to fail it)
+      if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY] ||
+          (!given && Lm > h->lim.max_corr)) {
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_CAPACITY);
         continue;
       }
@@ -2131,7 +2165,7 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
           // front end first, then the caller's correspondences into the (now free) matched-cloud buffers, then the back end
           int L1 = 0;
           rc1 = front_device(h, s, (const float*)ln.raw_s[g], ln.Ps[g], (const float*)ln.raw_t[g], ln.Pt[g], &f1,
-                             QTR_MEM_DEVICE, true, &r.n_src, &r.n_tgt, &L1);
+                             QTR_MEM_DEVICE, true, &r.n_src, &r.n_tgt, &L1, true);
           if (rc1 == QTR_OK) {
             if (pd.n_corr > 0) {
               QTR_HIP_TRY(h, hipMemcpyAsync(s.m_src, pd.src_corr4, (size_t)pd.n_corr * 16, hipMemcpyHostToDevice, s.stream));
@@ -2156,7 +2190,7 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
         ++J.done;
         continue;
       }
-      QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, Lm, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail
+      if (!given) QTR_HIP_TRY(h, gather_matched_enqueue(s.fb, Lm, s.m_src, s.m_tgt, lead.stream));  // no-op after the fused tail
       if (given) {
         if (J.mem == QTR_MEM_HOST) {  // behind the matching chain on the lane's stream: the matched clouds are not needed
           if (pd.n_corr > 0) {

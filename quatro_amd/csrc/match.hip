@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
 __device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* s_red /* [5] LDS */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) __hip_atomic_store(words + w, total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int sum = 0;
+  int sum = 0, missing = 0;
   for (int u = tid; u < w; u += 256) {
     int v = 0;
     for (unsigned polls = 0; polls < (1u << 22); ++polls) {  // (bounded: a word that never appears cannot hang the device)
@@ -1135,15 +1135,17 @@ __device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* 
       if (v != 0) break;
       __builtin_amdgcn_s_sleep(2);
     }
-    if (v == 0) sum -= (1 << 28);  // (counts stay far below 2^26: one missing word makes the total negative)
+    missing |= (v == 0);  // (kept apart from the sum: any number of missing words is one flag, never an overflow)
     sum += max(v - 1, 0);
   }
-  sum = wave_sum_i32(sum);
+  sum = wave_sum_i32(sum);  // (a wave's sum stays far below 2^31: bit 31 of its word is free for the wave's flag)
+  const u32 word = (u32)sum | (__ballot(missing) ? 0x80000000u : 0u);
   __syncthreads();  // (s_red may still be read from an earlier use)
-  if (lane == 0) s_red[wave] = sum;
+  if (lane == 0) s_red[wave] = (int)word;
   __syncthreads();
-  const int before = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  return before < 0 ? -1 : before;
+  const u32 w0 = (u32)s_red[0], w1 = (u32)s_red[1], w2 = (u32)s_red[2], w3 = (u32)s_red[3];
+  if ((w0 | w1 | w2 | w3) & 0x80000000u) return -1;
+  return (int)(((w0 & 0x7fffffffu) + (w1 & 0x7fffffffu)) + ((w2 & 0x7fffffffu) + (w3 & 0x7fffffffu)));
 }
 
 template <bool EXT>

@@ -63,7 +63,8 @@ class PairDesc(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = ([(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total",
-                                          "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
+                                          "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float),
+                                                           ("nn_dir1", C.c_float), ("nn_dir2", C.c_float)])
 
 
 class PwParams(C.Structure):

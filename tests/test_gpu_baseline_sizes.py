@@ -704,3 +704,61 @@ def test_batch_long_list_fallback_with_given_correspondences_and_preprocessed_in
     assert np.array_equal(got[1]["T"], whole["T"])
     if host_mem:
         assert np.array_equal(got[0]["clique"], back["clique"]) and np.array_equal(got[1]["clique"], whole["clique"])
+
+
+# ---- BASELINE configs[4] as ONE registration (round 5) ----------------------------------------------------------------
+DENSE_LIMITS = dict(max_points=65536, max_voxels=65536, max_corr=24576)
+
+
+@pytest.fixture(scope="module")
+def dense_scene(qo16):
+    """Two independent 50 000-point samplings of one structured scene + the oracle's descriptors of both (shared by the
+    dense tests below: ~2 s of FPFH and one 50 k x 50 k brute-force matcher run per flag combination on the CPU side)."""
+    a, b, T = synth.dense_scene_pair(50000)
+    assert np.array_equal(qo16.voxelize(a, 0.001), a) and np.array_equal(qo16.voxelize(b, 0.001), b)  # pass-through
+    return {"a": a, "b": b, "T": T, "da": qo16.fpfh(a, 0.5, 0.75)[2], "db": qo16.fpfh(b, 0.5, 0.75)[2]}
+
+
+def test_dense_step_front_end_of_50k_clouds_and_back_end_on_20000_correspondences_in_one_call(qo16, dense_scene):
+    """configs[4] as the bench's dense_step_leg runs it: ONE qtr_register_pair_corr call — the front end of two
+    50 000-point clouds (no voxel down-sampling) and the back end on 20 000 given correspondences — against the oracle's
+    front end (voxel counts, the matcher's own count) and the oracle's solve of the same correspondences."""
+    d = dense_scene
+    c = synth.correspondences(20000, 0.02, seed=7, noise=0.1)
+    fp = ql.default_frontend_params(voxel_size=0.001, seed=1)
+    h = ql.Handle(0, **DENSE_LIMITS)
+    try:
+        g = h.register_pair_corr(d["a"], d["b"], c[0], c[1], fp)
+        g2 = h.register_pair_corr(d["a"], d["b"], c[0], c[1], fp)   # (a second call on warm arenas: the same record)
+    finally:
+        h.close()
+    corr = qo16.match(d["a"], d["da"], d["b"], d["db"], True, True, 0.95, 1)
+    assert (g["n_src"], g["n_tgt"], g["n_matched"], g["L"]) == (50000, 50000, corr.shape[0], 20000)
+    o = qo16.solve(c[0], c[1])
+    _same(g, o)
+    assert set(c[3]).issubset(set(g["clique"])) and g["valid"]
+    assert np.array_equal(g2["clique"], g["clique"]) and np.array_equal(g2["T"], g["T"])
+
+
+@pytest.mark.parametrize("tuple_test,lo,hi", [(1, 1500, 3000), (0, 11000, 17000)])
+def test_dense_scene_registers_through_the_whole_path_entry_and_matches_oracle(qo16, dense_scene, tuple_test, lo, hi):
+    """configs[4] DATA-CONNECTED: qtr_register_pair on two independent 50 000-point samplings of one structured scene (no
+    point of one cloud is a moved copy of a point of the other), the matcher's own correspondences into the back end —
+    L ~ 2.1 k with the tuple test, L ~ 14 k without it (every mutual nearest-neighbour pair of the 50 k x 50 k search).
+    The registration LANDS (final inliers, centimetres / 1e-3 rad from the truth) and every output equals the oracle's."""
+    d = dense_scene
+    fp = ql.default_frontend_params(voxel_size=0.001, use_tuple_test=tuple_test, seed=1)
+    h = ql.Handle(0, **DENSE_LIMITS)
+    try:
+        g = h.register_pair(d["a"], d["b"], fp)
+    finally:
+        h.close()
+    corr = qo16.match(d["a"], d["da"], d["b"], d["db"], True, bool(tuple_test), 0.95, 1)
+    assert lo < corr.shape[0] < hi, corr.shape
+    assert (g["n_src"], g["n_tgt"], g["L"]) == (50000, 50000, corr.shape[0])
+    o = qo16.solve(d["a"][corr[:, 0]], d["b"][corr[:, 1]])
+    _same(g, o)
+    assert g["valid"] and g["clique"].size > 100 and g["final_inliers"].size > 50
+    dy = _yaw(g["T"]) - _yaw(d["T"])
+    assert abs(np.arctan2(np.sin(dy), np.cos(dy))) < 2e-3            # the scene's sampling noise, not the tolerance of _same
+    assert np.linalg.norm(g["T"][:3, 3] - d["T"][:3, 3]) < 0.1
