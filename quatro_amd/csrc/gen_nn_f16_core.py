@@ -2,22 +2,37 @@
 """gen_nn_f16_core.py — writes nn_f16_core.inc: the hand-scheduled inner loop of k_nn_f16 (match.hip) as one inline-asm
 block with a fixed register map.       python gen_nn_f16_core.py > nn_f16_core.inc
 
-Why by hand: the loop needs 28 x v_mfma_f32_32x32x16_f16 per 32-row tile with the 3-VALU-per-value top-2 fold of the
-PREVIOUS tile issued in their shadow, two accumulator sets in architectural VGPRs (the fold must read them without
-v_accvgpr_read) and the 112 dwords of stationary query fragments in AGPRs (MFMA reads them in place).  The compiler's
-register allocation put the accumulators in AGPRs and re-packed the f16 fragments with v_perm; the schedule is the whole
-point of the kernel, so it is written out.  Timing of this schedule in isolation: tests/probe/gen_probe3.py.
+Why by hand: the loop needs 28 x v_mfma_f32_32x32x16_f16 per 32-row tile with the top-2 fold of the PREVIOUS tile issued
+in their shadow, two accumulator sets in architectural VGPRs (the fold must read them without v_accvgpr_read) and the
+112 dwords of stationary query fragments in AGPRs (MFMA reads them in place).  The compiler's register allocation put
+the accumulators in AGPRs and re-packed the f16 fragments with v_perm; the schedule is the whole point of the kernel, so
+it is written out.  Timing of the round-2 schedule in isolation: tests/probe/gen_probe3.py.
+
+The fold (round 5).  One wave per SIMD hides about five single-issue instructions behind a v_mfma_f32_32x32x16 (32
+clocks of matrix pipe = 8 issue slots; MI355X_MICROARCH.md), i.e. ~140 per tile of 28 MFMAs; rounds 2-4 folded every
+value with three instructions (row index packed into the low mantissa bits, v_med3, v_min: 209 per tile with the
+per-tile bookkeeping) and ran at 1186 clocks per tile against 896 of matrix pipe.  Now the lane's running (best,
+second best) takes the 16 values of a column block two at a time:
+    t  = med3(best, x, y)        the second smallest of the three
+    best = min3(best, x, y)
+    second = min3(second, t, t') once per two pairs
+— five instructions per FOUR values, 89 per tile with the bookkeeping: the loop is bound by the matrix pipe.  (Invariant:
+second >= best; the two smallest of {best, second, x, y} are min3(best, x, y) and min(second, med3(best, x, y)).)  No
+index travels with a value any more: the lane only notes the TILE in which its best last changed (best is written
+ping-pong into two register sets, one compare per column block and tile), so a partial result names 16 candidate rows
+— the lane's rows of that tile — and k_nn_finish_f16 picks the one with the smallest EXACT distance (match.hip).
 
 Register map (per lane)
   a[0:111]    query fragments: q[c][m] = a[(7c+m)*4 .. +3]      (c = column block 0..3, m = MFMA 0..6)
   v[64:127]   accumulator set A (16 per column block), v[128:191] set B
   v[192:219]  base tile buffer 0 (7 fragments of 4 dwords), v[220:247] buffer 1
-  v20-23 best, v24-27 second, v28-31 best before the tile, v32-35 tile of the best, v36 temp, v38 tile being folded,
+  v20-23 / v28-31 best (ping-pong: the fold of set A reads 20.. and writes 28.., the fold of set B the other way),
+  v24-27 second, v32-35 tile of the best, v36 v37 temporaries, v38 tile being folded,
   v39 lane byte offset inside a chunk pair, v40 = v39 + 4096
-  s[40:41] base-table cursor (next tile to load), s[44:45] query table, s42 tiles left to start, s43 pack mask
+  s[40:41] base-table cursor (next tile to load), s[44:45] query table, s42 tiles left to start, s[46:53] compare masks
 Wait states that the assembler will not insert for us (gfx940/950): a VALU read of an MFMA result needs the MFMA to
-be 11 wait states old (8-pass) — every fold starts behind two MFMAs of the next tile; v_cmp -> v_cndmask through VCC
-needs 2 (s_nop 1).
+be 11 wait states old (8-pass) — every fold starts behind two MFMAs of the next tile; a v_cmp's mask is read by its
+v_cndmask three instructions later.
 """
 
 TILE_BYTES = 14 * 32 * 16  # 7168: one tile of either operand table
@@ -45,77 +60,93 @@ def mfma(dst, c, j, buf):
     return "v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (acc, vr(MBUF[buf] + 4 * j, 4), q, "0" if j == 0 else acc)
 
 
-def fold_value(src, c, r):
-    a = ACC[src] + 16 * c + r
-    return ["v_and_or_b32 v36, v%d, s43, %d" % (a, r), "v_med3_f32 v%d, v%d, v%d, v36" % (24 + c, 20 + c, 24 + c),
-            "v_min_f32 v%d, v%d, v36" % (20 + c, 20 + c)]
+BEST = {"A": (20, 28), "B": (28, 20)}  # the fold of a set reads the running best from the first bank, writes the second
 
 
-def fold_tail(c):
-    return ["v_cmp_neq_f32 vcc, v%d, v%d" % (20 + c, 28 + c), "s_nop 1", "v_cndmask_b32 v%d, v%d, v38, vcc" % (32 + c, 32 + c),
-            "v_mov_b32 v%d, v%d" % (28 + c, 20 + c)]
-
-
-def fold_groups(src):
-    """the fold of one accumulator set as a list of small instruction groups (one value each, tails after r = 15)"""
-    G = []
+def fold_ops(src):
+    """the fold of one accumulator set as a flat list of instructions (see the module docstring)"""
+    pin, pout = BEST[src]
+    ops = []
     for c in range(4):
-        for r in range(16):
-            g = fold_value(src, c, r)
-            if r == 15:
-                g += fold_tail(c)
-            G.append(g)
-    G.append(["v_add_u32 v38, 1, v38"])
-    return G
+        x = ["v%d" % (ACC[src] + 16 * c + r) for r in range(16)]
+        cur, out, sec = "v%d" % (pin + c), "v%d" % (pout + c), "v%d" % (24 + c)
+        for q in range(4):
+            r = 4 * q
+            ops.append("v_med3_f32 v36, %s, %s, %s" % (cur, x[r], x[r + 1]))
+            ops.append("v_min3_f32 %s, %s, %s, %s" % (out, cur, x[r], x[r + 1]))
+            cur = out
+            ops.append("v_med3_f32 v37, %s, %s, %s" % (cur, x[r + 2], x[r + 3]))
+            ops.append("v_min3_f32 %s, %s, %s, %s" % (out, cur, x[r + 2], x[r + 3]))
+            ops.append("v_min3_f32 %s, %s, v36, v37" % (sec, sec))
+    for c in range(4):  # did the best change in this tile?  (mask in an SGPR pair, read three instructions later)
+        ops.append("v_cmp_neq_f32_e64 s[%d:%d], v%d, v%d" % (46 + 2 * c, 47 + 2 * c, pout + c, pin + c))
+    for c in range(4):
+        ops.append("v_cndmask_b32_e64 v%d, v%d, v38, s[%d:%d]" % (32 + c, 32 + c, 46 + 2 * c, 47 + 2 * c))
+    ops.append("v_add_u32 v38, 1, v38")
+    return ops
 
 
 def phase(dst, buf, fold_src):
-    """28 MFMAs of the tile in buffer buf into set dst; the fold of set fold_src (or None) dealt between them, starting
-    behind the second MFMA"""
+    """28 MFMAs of the tile in buffer buf into set dst; the fold of set fold_src (or None) dealt evenly between them,
+    starting behind the second MFMA"""
     L = []
-    G = fold_groups(fold_src) if fold_src else []
-    gi = 0
-    n = 0
+    G = fold_ops(fold_src) if fold_src else []
+    gaps, gi, n = 26, 0, 0
     for j in range(7):
         for c in range(4):
             L.append(mfma(dst, c, j, buf))
             n += 1
-            if n >= 2:
-                take = 3 if n % 2 == 0 else 2  # 13 x 3 + 13 x 2 = the 65 groups, spread over MFMAs 2..27
-                for _ in range(take):
-                    if gi < len(G):
-                        L += G[gi]
-                        gi += 1
-    while gi < len(G):
-        L += G[gi]
-        gi += 1
+            if n >= 2 and n - 2 < gaps:
+                upto = (len(G) * (n - 1) + gaps - 1) // gaps
+                L += G[gi:upto]
+                gi = max(gi, upto)
+    L += G[gi:]
     return L
 
 
-def fold_only(src):
-    L = ["s_nop 15"]
-    for g in fold_groups(src):
-        L += g
+def first_phase():
+    """tile 0 into set A, column block by column block: a block's MFMAs start as soon as ITS query fragments have landed
+    (the loads were issued q0, tile 0, q1, q2, q3, tile 1: 42 in flight), not when all 28 have"""
+    L = []
+    for c in range(4):
+        L.append("s_waitcnt vmcnt(%d)" % (28 - 7 * c))
+        for j in range(7):
+            L.append(mfma("A", c, j, 0))
+    return L
+
+
+def fold_only(src, move_best):
+    L = ["s_nop 15"] + fold_ops(src)
+    if move_best:  # the results are read from v20-23
+        L += ["v_mov_b32 v%d, v%d" % (20 + c, 28 + c) for c in range(4)]
     return L
 
 
 asm = []
 A = asm.append
-# ---- prologue
-asm += ["s_mov_b32 s40, %[blo]", "s_mov_b32 s41, %[bhi]", "s_mov_b32 s44, %[qlo]", "s_mov_b32 s45, %[qhi]", "s_mov_b32 s42, %[nt]",
-        "s_mov_b32 s43, 0xfffffff0", "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_mov_b32 v38, %[t0]"]
-for c in range(4):  # query fragments straight into AGPRs; the lane's row of column block c starts at byte %[qc] of the table
-    asm.append("v_add_u32 v36, 0x1000, %%[q%d]" % c)
+
+
+def query_loads(c):
+    L = ["v_add_u32 v36, 0x1000, %%[q%d]" % c]
     for m in range(7):
         va, off = ("%%[q%d]" % c, 1024 * m) if m < 4 else ("v36", 1024 * (m - 4))
-        asm.append("global_load_dwordx4 a[%d:%d], %s, s[44:45] offset:%d" % ((7 * c + m) * 4, (7 * c + m) * 4 + 3, va, off))
+        L.append("global_load_dwordx4 a[%d:%d], %s, s[44:45] offset:%d" % ((7 * c + m) * 4, (7 * c + m) * 4 + 3, va, off))
+    return L
+
+
+# ---- prologue
+asm += ["s_mov_b32 s40, %[blo]", "s_mov_b32 s41, %[bhi]", "s_mov_b32 s44, %[qlo]", "s_mov_b32 s45, %[qhi]", "s_mov_b32 s42, %[nt]",
+        "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_mov_b32 v38, %[t0]"]
+# query fragments straight into AGPRs; the lane's row of column block c starts at byte %[qc] of the table
+asm += query_loads(0)
+asm += load_tile(0)  # tile 0 of the slice
+for c in range(1, 4):
+    asm += query_loads(c)
+asm += load_tile(1)  # tile 1 (the tables are padded by two tiles: prefetching past the slice is harmless)
 for c in range(4):
     asm += ["v_mov_b32 v%d, 0x7f800000" % (20 + c), "v_mov_b32 v%d, 0x7f800000" % (24 + c), "v_mov_b32 v%d, 0x7f800000" % (28 + c),
             "v_mov_b32 v%d, -1" % (32 + c)]
-asm += load_tile(0)  # tile 0 of the slice
-asm += load_tile(1)  # tile 1 (the tables are padded by two tiles: prefetching past the slice is harmless)
-asm += ["s_waitcnt vmcnt(7)"]
-asm += phase("A", 0, None)
+asm += first_phase()
 asm += ["s_sub_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 0", "s_cbranch_scc1 L_f16_tailA_%="]
 A("L_f16_loop_%=:")
 # A holds an unfolded tile, buffer 1 holds (or is receiving) the next one
@@ -128,22 +159,22 @@ asm += ["s_waitcnt vmcnt(7)"]
 asm += phase("A", 0, "B")
 asm += ["s_sub_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 0", "s_cbranch_scc0 L_f16_loop_%="]
 A("L_f16_tailA_%=:")
-asm += fold_only("A")
+asm += fold_only("A", True)
 A("s_branch L_f16_done_%=")
 A("L_f16_tailB_%=:")
-asm += fold_only("B")
+asm += fold_only("B", False)
 A("L_f16_done_%=:")
 asm += ["s_waitcnt vmcnt(0)"]
 for c in range(4):
     asm += ["v_mov_b32 %%[b1%d], v%d" % (c, 20 + c), "v_mov_b32 %%[b2%d], v%d" % (c, 24 + c), "v_mov_b32 %%[it%d], v%d" % (c, 32 + c)]
 
 clob = ['"v%d"' % i for i in list(range(20, 41)) + list(range(64, 248))] + ['"a%d"' % i for i in range(112)]
-clob += ['"s40"', '"s41"', '"s42"', '"s43"', '"s44"', '"s45"', '"vcc"', '"scc"', '"memory"']
+clob += ['"s%d"' % i for i in (40, 41, 42, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53)] + ['"vcc"', '"scc"', '"memory"']
 
 print("// generated by gen_nn_f16_core.py — do not edit (see that file for the register map and the schedule)")
 print("// One item of k_nn_f16: 4 x 32 query columns of this wave (the lane's row of column block c starts at byte qoff[c] of")
 print("// the query table: any row, so a list of rows needs no gathered copy) against `ntiles` base tiles starting at `base`;")
-print("// running best / second best (scaled, row index packed in the low mantissa bits) and the tile of the best, per block.")
+print("// running best / second best (scaled) and the tile in which the best last changed, per column block.")
 print("__device__ __forceinline__ void nn_f16_core(const uint4* query, const u32 (&qoff)[4], const uint4* base, int ntiles, int t_begin,")
 print("                                            u32 frag_bytes,")
 print("                                            float (&b1)[4], float (&b2)[4], int (&it1)[4]) {")

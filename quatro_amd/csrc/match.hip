@@ -337,6 +337,15 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
 // Evaluated by wave 0 of every workgroup (of this kernel and of k_nn_finish, which has to find the same slicing) from
 // the device-side query counts of all pairs; results in LDS.  Written as a macro on purpose: the kernel-argument
 // structs must not travel by reference (see ViewExt).
+// a / b for a < 2^22, b >= 1: a float quotient and one correction step each way instead of the ~40-instruction integer
+// division (the work-item arithmetic of the nearest-neighbour kernels sits in front of their first load)
+__device__ __forceinline__ u32 fast_udiv(u32 a, u32 b) {
+  if (a >> 22) return a / b;
+  u32 q = (u32)((float)a * __frcp_rn((float)b));
+  if (q * b > a) --q;
+  if ((q + 1) * b <= a) ++q;
+  return q;
+}
 #define NN_MAXG 64
 #define NN_PLAN(G_, dir_, X_)                                                                                   \
   __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG], s_nq[NN_MAXG];                              \
@@ -345,21 +354,21 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
     int qb_ = 0, nt_ = 1, nq_ = 0;                                                                              \
     if (g_ < (G_)) {                                                                                            \
       const MatchView& P_ = EXT ? x.ext[g_] : one;                                                              \
-      nq_ = P_.mcounts[P_.d[dir_].nq_slot];                                                                     \
+      nq_ = (dir_) == 0 ? P_.n_small : P_.mcounts[P_.d[dir_].nq_slot]; /* (direction 0: no load to wait for) */ \
       qb_ = (nq_ + NN_QPB - 1) / NN_QPB;                                                                        \
       nt_ = P_.d[dir_].nb_pad / 32;                                                                             \
     }                                                                                                           \
     const int S_ = wave_sum_i32(qb_), W_ = wave_sum_i32(qb_ * nt_);                                             \
     int sp_;                                                                                                    \
     if (S_ <= (X_)) {                                                                                           \
-      sp_ = (X_) / max(S_, 1);                                                                                  \
+      sp_ = (int)fast_udiv((u32)(X_), (u32)max(S_, 1));                                                         \
     } else {                                                                                                    \
-      const int T_ = max(64, (W_ + (X_) * 8 - 1) / ((X_) * 8));                                                 \
-      sp_ = (nt_ + T_ - 1) / T_;                                                                                \
+      const int T_ = max(64, (int)fast_udiv((u32)(W_ + (X_) * 8 - 1), (u32)((X_) * 8)));                        \
+      sp_ = (int)fast_udiv((u32)(nt_ + T_ - 1), (u32)T_);                                                       \
     }                                                                                                           \
     sp_ = max(1, min(min(sp_, NN_MAXSPLIT), nt_));                                                              \
-    const int tps_ = (nt_ + sp_ - 1) / sp_;                                                                     \
-    sp_ = (nt_ + tps_ - 1) / tps_;                                                                              \
+    const int tps_ = (int)fast_udiv((u32)(nt_ + sp_ - 1), (u32)sp_);                                            \
+    sp_ = (int)fast_udiv((u32)(nt_ + tps_ - 1), (u32)tps_);                                                     \
     int tot_;                                                                                                   \
     const int ex_ = wave_excl_scan_i32(qb_ * sp_, &tot_);                                                       \
     if (g_ < (G_)) {                                                                                            \
@@ -661,6 +670,8 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
   NN_STAMP(0)
   NN_PLAN(G, dir, (int)gridDim.x)
   NN_STAMP(1)
+  // the slicing the plan decided, for k_nn_finish_f16 (which then needs neither the plan nor its barrier)
+  if (blockIdx.x == 0 && threadIdx.x < G) (EXT ? x.ext[threadIdx.x] : one).mcounts[MC_NSPLIT0 + dir] = s_ns[threadIdx.x];
   __shared__ int s_item;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -693,25 +704,34 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     const int nsplit = s_ns[g], tps = s_tps[g];
     NnPartial* __restrict__ partial = V.partial;
     const int local = cell - s_off[g];
-    int qb = local / nsplit, slice = local - qb * nsplit;
+    int qb, slice;
     if (dealt) {
-      const int nqb = total / nsplit, qh = (nqb + 1) >> 1, sq = (nsplit + 3) >> 2;
-      int rem = cell;
+      // (which rectangle: subtractions; ONE division — the eight of the unrolled form were a microsecond of every launch)
+      const int sq = (nsplit + 3) >> 2;
+      const int nqb = (int)fast_udiv((u32)total, (u32)nsplit), qh = (nqb + 1) >> 1;
+      int rem = cell, q0 = 0, s0 = 0, cols = 1;
       bool found = false;
 #pragma unroll
       for (int A = 0; A < 2; ++A) {
         const int rows = A == 0 ? qh : nqb - qh;
 #pragma unroll
         for (int B = 0; B < 4; ++B) {
-          const int cols = min(sq, max(0, nsplit - B * sq)), cells = rows * cols;
+          const int cl = min(sq, max(0, nsplit - B * sq)), cells = rows * cl;
           if (!found && rem < cells) {
-            qb = A * qh + rem / cols;
-            slice = B * sq + rem % cols;
+            q0 = A * qh;
+            s0 = B * sq;
+            cols = cl;
             found = true;
           }
           if (!found) rem -= cells;
         }
       }
+      const int qd = (int)fast_udiv((u32)rem, (u32)cols);
+      qb = q0 + qd;
+      slice = s0 + rem - qd * cols;
+    } else {
+      qb = (int)fast_udiv((u32)local, (u32)nsplit);
+      slice = local - qb * nsplit;
     }
     const int qbase = (qb * 4 + wave) * NN_QPW + col;
     const int t_begin = slice * tps, t_end = min(ntiles, t_begin + tps);
@@ -744,20 +764,21 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // decode the best's row, then merge the two lanes (half 0 / half 1) that own the same query column
-      const int r = (int)(__float_as_uint(b1[c]) & 15u);
-      int row = (it1[c] < 0) ? -1 : (it1[c] * 32 + 4 * half + (r & 3) + 8 * (r >> 2));
+      // merge the two lanes (half 0 / half 1) that own the same query column.  No row index travels with a value: a
+      // lane knows the TILE its best came from, i.e. 16 candidate rows — rows 8 g + 4 half + {0..3}, g = 0..3, of that
+      // tile — and k_nn_finish_f16 picks the candidate with the smallest exact distance.  i1 = 2 * tile + half.
+      int cand = (it1[c] < 0) ? -1 : (it1[c] * 2 + half);
       const float ob1 = __shfl_xor(b1[c], 32, 64), ob2 = __shfl_xor(b2[c], 32, 64);
-      const int orow = __shfl_xor(row, 32, 64);
-      const bool take = (ob1 < b1[c]) || (ob1 == b1[c] && orow >= 0 && (row < 0 || orow < row));
+      const int ocand = __shfl_xor(cand, 32, 64);
+      const bool take = (ob1 < b1[c]) || (cand < 0 && ocand >= 0);  // (a tie leaves second == best: never certified)
       const float nb2 = fminf(fminf(b2[c], ob2), take ? b1[c] : ob1);
       const float nb1 = take ? ob1 : b1[c];
-      row = take ? orow : row;
+      cand = take ? ocand : cand;
       if (half == 0) {
         NnPartial p;
         p.b1 = nb1 * NNH_UNSCALE;  // exact (power of two): the finish works in unscaled units
         p.b2 = nb2 * NNH_UNSCALE;
-        p.i1 = row;
+        p.i1 = cand;
         p.pad = 0;
         partial[(size_t)(qbase + 32 * c) * nsplit + slice] = p;
       }
@@ -864,6 +885,183 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
     }
   }
   QTR_STAMP(STAMP_NN_FINISH, 2)
+}
+
+// The f16 engine's finish (round 5).  k_nn_f16 no longer carries a row index with a value (its fold is 1.25 instructions
+// per value instead of three: gen_nn_f16_core.py): a partial record names the TILE and lane half its best came from,
+// i.e. 16 candidate rows — rows 8 g + 4 half + {0..3}, g = 0..3, of that tile: four aligned runs of four consecutive
+// rows, 4 x 528 bytes of the row-major descriptor table.  Per query: (1) the slices' records are merged (best, second,
+// candidate code of the best); (2) the 16 candidates get the EXACT flann::L2 distance — 16 lanes per query, the rows
+// staged through LDS with 16-byte loads — and the smallest (lowest row on a tie) is the query's row i1; (3) the
+// certification of the header comment, with the LARGEST |b|^2 among the candidates in the bound.  Why that is sound:
+// let r* be the row whose filter value is the best (unknown here, one of the candidates).  The bound grows with |b|^2,
+// so passing it with the candidates' maximum implies passing it with |b(r*)|^2, hence r* is the exact arg-min of the
+// whole cloud (lowest index on an exact tie: a tie partner's filter value would lie inside the gap) and therefore of the
+// candidates: i1 = r*.  A query that does not pass goes to k_recheck_filter as before, its threshold computed with the
+// same maximum (a larger threshold only lets more pairs through to the exact evaluation).  Pad rows of the last tile
+// are not candidates; a hidden duplicate among them has the distance of its lower-indexed original and loses the tie.
+// 64 queries per workgroup of 256 threads; grid (ceil(nq_max / 64), 1, pairs).
+#define NN_FINH_Q 64
+#define NN_FINH_THREADS 1024
+#define NN_FINH_PITCH 528  // floats per query of the candidate stage: 16 rows x 33 (half-wave conflict-free: 528 = 16 mod 32)
+#define NN_FINH_LDS (NN_FINH_Q * (NN_FINH_PITCH + 36) * 4)
+// 64 queries per workgroup of 1024 threads — sixteen waves, FOUR queries per wave, sixteen lanes per query, so that the
+// kernel is one round trip for the records, one for the candidate rows and one pass of arithmetic (a first version
+// walked four passes per wave behind one another: 23 us per launch whatever the cloud); the stage takes 135 KB of LDS:
+// one workgroup per compute unit.  grid (ceil(nq_max / 64), 1, pairs)
+template <bool EXT>
+__global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<MatchView> x, MatchView one, int dir, float cadd) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [64][528] candidate rows, then [64][36] query rows
+  __shared__ float s_b1[NN_FINH_Q], s_b2[NN_FINH_Q], s_nbmax[NN_FINH_Q], s_na[NN_FINH_Q];
+  __shared__ int s_row[NN_FINH_Q], s_i1[NN_FINH_Q];
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const NnDir& D = V.d[dir];
+  const int nq = V.mcounts[D.nq_slot];
+  if ((int)blockIdx.x * NN_FINH_Q >= nq) return;
+  QTR_STAMP(STAMP_NN_FINISH, 0)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nsplit = V.mcounts[MC_NSPLIT0 + dir];  // (k_nn_f16 left it there)
+  const float* __restrict__ A = D.A;
+  const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
+  const int nb = D.nb;
+  const int qj = lane >> 4, k = lane & 15;   // the lane's query of the wave's four, and its candidate
+  const int ql = wave * 4 + qj;              // ... of the workgroup's 64
+  const int q = blockIdx.x * NN_FINH_Q + ql;
+  // ---- (1) sixteen lanes per query merge the slices' records (at most NN_MAXSPLIT = 32: two per lane)
+  float b1 = INFINITY, b2 = INFINITY;
+  int cand = -1, row = 0;
+  float na = 0.f;
+  if (q < nq) {
+    const NnPartial* __restrict__ pr = V.partial + (size_t)q * nsplit;
+    const NnPartial p0 = pr[min(k, nsplit - 1)], p1 = pr[min(k + 16, nsplit - 1)];
+    if (k == 0) {
+      row = D.qmap ? D.qmap[q] : q;
+      na = D.qnorm[row];  // (the f16 engine's query tables are the cloud's own: by row)
+    }
+    if (k < nsplit) {
+      b1 = p0.b1;
+      b2 = p0.b2;
+      cand = p0.i1;
+    }
+    if (k + 16 < nsplit) {
+      const bool take = (p1.b1 < b1) || (cand < 0 && p1.i1 >= 0);
+      b2 = fminf(fminf(b2, p1.b2), take ? b1 : p1.b1);
+      b1 = take ? p1.b1 : b1;
+      cand = take ? p1.i1 : cand;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m <= 8; m <<= 1) {  // (a butterfly: all sixteen lanes end up with the merged record)
+    const float ob1 = __shfl_xor(b1, m, 64), ob2 = __shfl_xor(b2, m, 64);
+    const int oc = __shfl_xor(cand, m, 64);
+    const bool take = (ob1 < b1) || (ob1 == b1 && oc > cand) || (cand < 0 && oc >= 0);
+    b2 = fminf(fminf(b2, ob2), take ? b1 : ob1);
+    b1 = take ? ob1 : b1;
+    cand = take ? oc : cand;
+  }
+  row = __shfl(row, lane & 48, 64);
+  QTR_STAMP(STAMP_NN_FINISH, 1)
+  // ---- (2) exact distances of the wave's 4 x 16 candidates, the rows staged through the wave's own part of LDS
+  float* rows = s_dyn + (size_t)wave * 4 * NN_FINH_PITCH;
+  float* qv = s_dyn + (size_t)NN_FINH_Q * NN_FINH_PITCH + (size_t)wave * 4 * 36;
+  const bool aligned = (((uintptr_t)B) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {  // 4 queries x 4 runs x 33 pieces of 16 bytes
+    const int idx = lane + 64 * i;
+    const int sj = min(idx / 132, 3), e = idx - sj * 132, g = e / 33, ee = e - g * 33;
+    const int cj = __shfl(cand, sj * 16, 64);  // (all lanes take part in the shuffle)
+    if (idx < 4 * 132 && cj >= 0) {
+      const int row0 = (cj >> 1) * 32 + 8 * g + 4 * (cj & 1);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aligned && row0 + 4 <= nb) {
+        v = *(const float4*)(B + (size_t)row0 * 33 + 4 * ee);
+      } else {  // the cloud's last rows, or a caller's table that is not 16-byte aligned
+        const size_t f0 = (size_t)row0 * 33 + 4 * ee, fend = (size_t)nb * 33;
+        v.x = f0 < fend ? B[f0] : 0.f;
+        v.y = f0 + 1 < fend ? B[f0 + 1] : 0.f;
+        v.z = f0 + 2 < fend ? B[f0 + 2] : 0.f;
+        v.w = f0 + 3 < fend ? B[f0 + 3] : 0.f;
+      }
+      *(float4*)(rows + sj * NN_FINH_PITCH + g * 132 + 4 * ee) = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // the four query rows
+    const int idx = lane + 64 * i;
+    const int sj = min(idx / 33, 3), e = idx - sj * 33;
+    const int rj = __shfl(row, sj * 16, 64);
+    if (idx < 4 * 33) qv[sj * 36 + e] = A[(size_t)rj * 33 + e];
+  }
+  // (the stage is the wave's own: LDS operations of one wave complete in order, nothing to wait for but the compiler)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {
+    const int brow = (cand >> 1) * 32 + 8 * (k >> 2) + 4 * (cand & 1) + (k & 3);
+    const bool ok = cand >= 0 && brow < nb;
+    const float* __restrict__ a = qv + qj * 36;
+    const float* __restrict__ b = rows + qj * NN_FINH_PITCH + k * 33;
+    float result = 0.f;  // flann::L2 accumulation order (recheck_exact_pair)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
+                  d3 = a[4 * g + 3] - b[4 * g + 3];
+      result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    const float dt = a[32] - b[32];
+    result += dt * dt;
+    u64 key = (ok && result == result) ? (((u64)__float_as_uint(result) << 32) | (u32)brow) : ~0ULL;
+    float nbm = ok ? D.bnorm[brow] : 0.f;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const u64 ok2 = ((u64)(u32)__shfl_xor((int)(key >> 32), m, 64) << 32) | (u32)__shfl_xor((int)(u32)key, m, 64);
+      key = ok2 < key ? ok2 : key;
+      nbm = fmaxf(nbm, __shfl_xor(nbm, m, 64));
+    }
+    if (k == 0) {
+      s_i1[ql] = (key == ~0ULL) ? -1 : (int)(u32)key;
+      s_nbmax[ql] = nbm;
+      s_b1[ql] = b1;
+      s_b2[ql] = b2;
+      s_row[ql] = row;
+      s_na[ql] = na;
+    }
+  }
+  __syncthreads();
+  QTR_STAMP(STAMP_NN_FINISH, 2)
+  // ---- (3) certification and the ordered append of the listed rows: one thread per query (wave 0)
+  if (wave != 0) return;
+  {
+    const int t = blockIdx.x * NN_FINH_Q + lane;
+    const bool valid = t < nq;
+    const float c1 = s_b1[lane], c2 = s_b2[lane];
+    int i1 = s_i1[lane];
+    const int crow = s_row[lane];
+    const float cna = valid ? s_na[lane] : 0.f;
+    const float nb1 = (i1 >= 0) ? s_nbmax[lane] : 0.f;
+    const float u = 5.9604645e-08f;
+    const float d1 = fmaxf(cna + c1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
+    const float d2 = (c2 < INFINITY) ? fmaxf(cna + c2, 0.f) + 1.0f : d1;
+    const float gap = u * (144.0f * cna + 280.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;
+    const bool unsafe = V.mcounts[MC_UNSAFE] != 0;  // descriptor values outside the f16 engine's range: everything is re-checked
+    if (unsafe) i1 = -1;
+    const bool certified = i1 >= 0 && (c2 == INFINITY || c2 - c1 > gap);
+    const bool listed = valid && !certified;
+    if (valid) D.best[crow] = certified ? (u64)(u32)i1 : ~0ULL;
+    const u64 bal = __ballot(listed);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(V.mcounts + D.rc_slot, __popcll(bal));  // one atomic per workgroup
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (listed) {
+      const int slot = base + __popcll(bal & lanemask_lt());
+      V.recheck_rows[slot] = crow;
+      // a base row whose approximate (lower-bound) value exceeds this cannot be the exact arg-min; +inf when the slice
+      // merge found nothing
+      const float thr = (i1 >= 0) ? c1 + u * (144.0f * cna + 280.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
+      V.recheck_thr[slot] = thr;
+      V.recheck_q[slot] = crow;  // where k_recheck_filter finds the row's f16 query fragments (row of D.queryH)
+    }
+  }
 }
 
 // Re-check of the listed rows (f16 engine): the matrix pipe again.  A listed row's exact arg-min is among the base rows
@@ -2068,8 +2266,13 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
 #endif
         if (e1) (void)hipEventRecord(e1, st);
       }
-      LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir, X,
-                G, f16 ? 800.0f : 0.0f, f16 ? 1 : 0);
+      if (f16)
+        LAUNCH_MV(k_nn_finish_f16, a, dim3((nq_max + NN_FINH_Q - 1) / NN_FINH_Q, 1, G), dim3(NN_FINH_THREADS), NN_FINH_LDS, st, dir,
+                  800.0f);
+#ifdef QTR_TEST_ENGINES
+      else LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir,
+                     X, G, 0.0f, 0);
+#endif
       // (single pair: 8 x 64 workgroups = the 512 the device holds at two per compute unit — one round)
       if (f16) LAUNCH_MV(k_recheck_filter, a, dim3(8, G > 1 ? 16 : 64, G), B256, 0, st, dir);
       // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
@@ -2193,6 +2396,9 @@ hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_
 // CROSS_LDS_BYTES when both nearest-neighbour tables fit
 hipError_t match_init_attributes() {
   hipError_t e;
+  // k_nn_finish_f16 stages 64 queries x 16 candidate rows: more than the 64 KB a kernel gets without asking
+  if ((e = hipFuncSetAttribute((const void*)k_nn_finish_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NN_FINH_LDS)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)k_nn_finish_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NN_FINH_LDS)) != hipSuccess) return e;
 #ifdef QTR_TEST_ENGINES  // (the one-workgroup tails: comparison engines)
   if ((e = hipFuncSetAttribute((const void*)k_cross_fused<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)k_cross_fused<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CROSS_LDS_BYTES)) != hipSuccess) return e;
@@ -2205,8 +2411,6 @@ hipError_t match_init_attributes() {
     return e;
   SET_LDS2(k_pairs_fused)
 #undef SET_LDS2
-#else
-  (void)e;
 #endif
   return hipSuccess;
 }
