@@ -666,7 +666,7 @@ extern "C" int qtr_debug_stamps(unsigned long long* out) {  // [QTR_STAMP_KERNEL
 #define NN_STAMP(i)
 #endif
 template <bool EXT>
-__global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G) {
+__global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G, int la) {
   NN_STAMP(0)
   NN_PLAN(G, dir, (int)gridDim.x)
   NN_STAMP(1)
@@ -688,7 +688,9 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     // base (8 x (Q + B / 8) of L2 fill: 33 MB for direction 0's 7.6 MB of tables).  Instead the (query block, slice)
     // grid is cut into 2 x 4 rectangles, enumerated rectangle by rectangle, and XCD x takes the x-th eighth of that
     // enumeration (workgroup 8 j + x its j-th cell): every XCD then meets about half of the query blocks and a quarter
-    // of the base, 8 x (Q / 2 + B / 4).
+    // of the base, 8 x (Q / 2 + B / 4).  (Round 5: 4 x 2 — a quarter of the query blocks, half of the base — measured a
+    // microsecond faster per launch: the launch opens with every workgroup fetching its 114 KB of query fragments at
+    // once, and four instead of two of the eight workgroups that share a query block then share an L2.)
     const bool dealt = G == 1 && total <= (int)gridDim.x && (gridDim.x & 7) == 0;
     int cell = item;
     if (dealt) {
@@ -707,24 +709,24 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     int qb, slice;
     if (dealt) {
       // (which rectangle: subtractions; ONE division — the eight of the unrolled form were a microsecond of every launch)
-      const int sq = (nsplit + 3) >> 2;
-      const int nqb = (int)fast_udiv((u32)total, (u32)nsplit), qh = (nqb + 1) >> 1;
+      // (2^la x 2^(3-la) rectangles; la = 1 is the 2 x 4 cut described above)
+      const int lb = 3 - la;
+      const int nqb = (int)fast_udiv((u32)total, (u32)nsplit);
+      const int qh = (nqb + (1 << la) - 1) >> la, sq = (nsplit + (1 << lb) - 1) >> lb;
       int rem = cell, q0 = 0, s0 = 0, cols = 1;
       bool found = false;
 #pragma unroll
-      for (int A = 0; A < 2; ++A) {
-        const int rows = A == 0 ? qh : nqb - qh;
-#pragma unroll
-        for (int B = 0; B < 4; ++B) {
-          const int cl = min(sq, max(0, nsplit - B * sq)), cells = rows * cl;
-          if (!found && rem < cells) {
-            q0 = A * qh;
-            s0 = B * sq;
-            cols = cl;
-            found = true;
-          }
-          if (!found) rem -= cells;
+      for (int r = 0; r < 8; ++r) {
+        const int A = r >> lb, B = r & ((1 << lb) - 1);
+        const int rows = min(qh, max(0, nqb - A * qh));
+        const int cl = min(sq, max(0, nsplit - B * sq)), cells = rows * cl;
+        if (!found && rem < cells) {
+          q0 = A * qh;
+          s0 = B * sq;
+          cols = cl;
+          found = true;
         }
+        if (!found) rem -= cells;
       }
       const int qd = (int)fast_udiv((u32)rem, (u32)cols);
       qb = q0 + qd;
@@ -921,6 +923,7 @@ __global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<Match
   QTR_STAMP(STAMP_NN_FINISH, 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nsplit = V.mcounts[MC_NSPLIT0 + dir];  // (k_nn_f16 left it there)
+  const bool unsafe = V.mcounts[MC_UNSAFE] != 0;   // descriptor values outside the f16 engine's range: everything is re-checked
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
@@ -962,45 +965,49 @@ __global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<Match
   row = __shfl(row, lane & 48, 64);
   QTR_STAMP(STAMP_NN_FINISH, 1)
   // ---- (2) exact distances of the wave's 4 x 16 candidates, the rows staged through the wave's own part of LDS
-  float* rows = s_dyn + (size_t)wave * 4 * NN_FINH_PITCH;
-  float* qv = s_dyn + (size_t)NN_FINH_Q * NN_FINH_PITCH + (size_t)wave * 4 * 36;
+  const int brow = (cand >> 1) * 32 + 8 * (k >> 2) + 4 * (cand & 1) + (k & 3);
+  const bool ok = cand >= 0 && brow < nb;
+  float nbm = ok ? D.bnorm[brow] : 0.f;  // (issued with the staging loads: one round trip for both)
+  float* rows = s_dyn + (size_t)wave * 4 * NN_FINH_PITCH + qj * NN_FINH_PITCH;  // the lane's query: its 16 x 33 floats
+  float* qv = s_dyn + (size_t)NN_FINH_Q * NN_FINH_PITCH + (size_t)(wave * 4 + qj) * 36;
   const bool aligned = (((uintptr_t)B) & 15) == 0;
+  // the sixteen lanes of a query stage ITS four runs of 33 sixteen-byte pieces (132 pieces: nine per lane, the last
+  // round a quarter full) — no index leaves the lane group, and piece -> (run, offset) is three compares
+  if (cand >= 0) {
+    const int tile_row = (cand >> 1) * 32 + 4 * (cand & 1);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {  // 4 queries x 4 runs x 33 pieces of 16 bytes
-    const int idx = lane + 64 * i;
-    const int sj = min(idx / 132, 3), e = idx - sj * 132, g = e / 33, ee = e - g * 33;
-    const int cj = __shfl(cand, sj * 16, 64);  // (all lanes take part in the shuffle)
-    if (idx < 4 * 132 && cj >= 0) {
-      const int row0 = (cj >> 1) * 32 + 8 * g + 4 * (cj & 1);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (aligned && row0 + 4 <= nb) {
-        v = *(const float4*)(B + (size_t)row0 * 33 + 4 * ee);
-      } else {  // the cloud's last rows, or a caller's table that is not 16-byte aligned
-        const size_t f0 = (size_t)row0 * 33 + 4 * ee, fend = (size_t)nb * 33;
-        v.x = f0 < fend ? B[f0] : 0.f;
-        v.y = f0 + 1 < fend ? B[f0 + 1] : 0.f;
-        v.z = f0 + 2 < fend ? B[f0 + 2] : 0.f;
-        v.w = f0 + 3 < fend ? B[f0 + 3] : 0.f;
+    for (int i = 0; i < 9; ++i) {
+      const int pc = k + 16 * i;
+      if (pc < 132) {
+        const int g = (pc >= 33) + (pc >= 66) + (pc >= 99), ee = pc - 33 * g;
+        const int row0 = tile_row + 8 * g;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aligned && row0 + 4 <= nb) {
+          v = *(const float4*)(B + (size_t)row0 * 33 + 4 * ee);
+        } else {  // the cloud's last rows, or a caller's table that is not 16-byte aligned
+          const size_t f0 = (size_t)row0 * 33 + 4 * ee, fend = (size_t)nb * 33;
+          v.x = f0 < fend ? B[f0] : 0.f;
+          v.y = f0 + 1 < fend ? B[f0 + 1] : 0.f;
+          v.z = f0 + 2 < fend ? B[f0 + 2] : 0.f;
+          v.w = f0 + 3 < fend ? B[f0 + 3] : 0.f;
+        }
+        *(float4*)(rows + 4 * pc) = v;
       }
-      *(float4*)(rows + sj * NN_FINH_PITCH + g * 132 + 4 * ee) = v;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {  // the four query rows
-    const int idx = lane + 64 * i;
-    const int sj = min(idx / 33, 3), e = idx - sj * 33;
-    const int rj = __shfl(row, sj * 16, 64);
-    if (idx < 4 * 33) qv[sj * 36 + e] = A[(size_t)rj * 33 + e];
+  {  // the query's own row
+    const float* __restrict__ ar = A + (size_t)row * 33;
+    qv[k] = ar[k];
+    qv[k + 16] = ar[k + 16];
+    if (k == 0) qv[32] = ar[32];
   }
   // (the stage is the wave's own: LDS operations of one wave complete in order, nothing to wait for but the compiler)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   {
-    const int brow = (cand >> 1) * 32 + 8 * (k >> 2) + 4 * (cand & 1) + (k & 3);
-    const bool ok = cand >= 0 && brow < nb;
-    const float* __restrict__ a = qv + qj * 36;
-    const float* __restrict__ b = rows + qj * NN_FINH_PITCH + k * 33;
+    const float* __restrict__ a = qv;
+    const float* __restrict__ b = rows + k * 33;
     float result = 0.f;  // flann::L2 accumulation order (recheck_exact_pair)
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -1011,7 +1018,6 @@ __global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<Match
     const float dt = a[32] - b[32];
     result += dt * dt;
     u64 key = (ok && result == result) ? (((u64)__float_as_uint(result) << 32) | (u32)brow) : ~0ULL;
-    float nbm = ok ? D.bnorm[brow] : 0.f;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) {
       const u64 ok2 = ((u64)(u32)__shfl_xor((int)(key >> 32), m, 64) << 32) | (u32)__shfl_xor((int)(u32)key, m, 64);
@@ -1043,7 +1049,6 @@ __global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<Match
     const float d1 = fmaxf(cna + c1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
     const float d2 = (c2 < INFINITY) ? fmaxf(cna + c2, 0.f) + 1.0f : d1;
     const float gap = u * (144.0f * cna + 280.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;
-    const bool unsafe = V.mcounts[MC_UNSAFE] != 0;  // descriptor values outside the f16 engine's range: everything is re-checked
     if (unsafe) i1 = -1;
     const bool certified = i1 >= 0 && (c2 == INFINITY || c2 - c1 > gap);
     const bool listed = valid && !certified;
@@ -2247,6 +2252,11 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       return (e && atoi(e) == 2) ? 2 : 1;
     }();
     const int X = n_cu * wgs_per_cu;
+    // how a single pair's (query block, slice) grid is cut into the eight XCDs' rectangles: 2^la x 2^(3-la)
+    static const int nn_deal = [] {
+      const char* e = QTR_ENGINE_ENV("QTR_NN_DEAL");
+      return (e && atoi(e) >= 0 && atoi(e) <= 3) ? atoi(e) : 2;  // (4 x 2: same-box sweep, gpurun_out/r5e/deal.txt)
+    }();
     // QTR_NN_EVENTS=record: bracket the launch with two hipEventRecord calls instead of attaching the events to it
     static const bool attach_events = [] {
       const char* e = QTR_ENGINE_ENV("QTR_NN_EVENTS");
@@ -2254,13 +2264,13 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     }();
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
       if (e0 && e1 && attach_events) {
-        if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
+        if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G, nn_deal);
 #ifdef QTR_TEST_ENGINES
         else LAUNCH_MV_EV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
 #endif
       } else {
         if (e0) (void)hipEventRecord(e0, st);
-        if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G);
+        if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G, nn_deal);
 #ifdef QTR_TEST_ENGINES
         else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
 #endif

@@ -2228,6 +2228,147 @@ __global__ __launch_bounds__(64) void k_clique_scan(ViewExt<SolverView> x, Solve
   d_clique_scan(V, next_batch);
 }
 
+// The rest of the heuristic in ONE round (round 5).  On a graph whose bulk has core numbers ABOVE the largest clique
+// (use_crosscheck = 0 at L ~ 20 k: mean degree 775, bulk cores ~400, clique 345) the test K > mc never cuts anything
+// and pmc_heu tries every vertex as a start: 20 rounds of CLIQUE_BATCH starts, each as long as its longest descent
+// (a chain of ~345 dependent row reads, ~230 us) plus a host check — 5 ms.  The replay is exact whatever bound the
+// descents were started with (k_clique_batch_lds's comment: a descent that strays below the current bound cannot return
+// more than that bound), so ALL remaining starts can be speculated at once with the bound of this moment: k_clique_sweep
+// runs them grid-strided (sizes only — a pick list per start would be L x L ints), d_clique_scan_all replays the
+// sequential acceptance over all of them and re-runs the descent of the few starts it accepts to get their members
+// (same start, same bound: the same picks).
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_clique_sweep(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int* __restrict__ Kp = V.Kp;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  const SolverState* __restrict__ st = V.st;
+  if (st->done) return;
+  int* __restrict__ gsz = V.gsz;
+  const int lane = qk_lane();
+  const int pos = st->pos, mc0 = st->mc, t0 = st->t0;
+  const int nwaves = gridDim.x * 4;
+  for (int wid = blockIdx.x * 4 + (threadIdx.x >> 6); wid <= pos; wid += nwaves) {
+    const int r = pos - wid;
+    int g = 0;
+    if (Kp[r] > mc0) g = greedy_dispatch(adjP, W, r, t0, lane, nullptr);
+    if (lane == 0) gsz[wid] = g;
+  }
+}
+#define CSA_THREADS 1024
+#define CSA_LIST 256
+template <bool EXT>
+__global__ __launch_bounds__(CSA_THREADS) void k_clique_scan_all(ViewExt<SolverView> x, SolverView one) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const u64* __restrict__ adjP = V.adjP;
+  const int* __restrict__ Kp = V.Kp;
+  const int L = V.L, W = V.W;
+  if (L <= 0) return;
+  SolverState* __restrict__ st = V.st;
+  const int* __restrict__ gsz = V.gsz;
+  int* __restrict__ best_picks = V.picks;
+  if (st->done) return;
+  const int lane = qk_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pos = st->pos, B = pos + 1, ub = st->ub, cf = st->core_floor, t_sweep = st->t0, mc0 = st->mc;
+  // A start can only be accepted if its descent beat the bound the sweep started from: sixteen waves list those (in
+  // order, a contiguous range of starts each) and one wave replays the few that are left — walking all the starts 64 at
+  // a time was 320 dependent round trips, 170 us at 20 k starts.  A range with more than CSA_LIST of them is walked whole.
+  __shared__ int s_list[CSA_THREADS / 64][CSA_LIST];
+  __shared__ int s_cnt[CSA_THREADS / 64];
+  const int chunk = (((B + CSA_THREADS / 64 - 1) / (CSA_THREADS / 64)) + 63) & ~63;
+  {
+    const int lo = wave * chunk, hi = min(B, lo + chunk);
+    int cnt = 0;
+    for (int base = lo; base < hi; base += 64) {
+      const int wid = base + lane;
+      const bool c = wid < hi && Kp[pos - wid] > mc0 && gsz[wid] > mc0;
+      const u64 bal = __ballot(c);
+      if (c) {
+        const int at = cnt + __popcll(bal & lanemask_lt());
+        if (at < CSA_LIST) s_list[wave][at] = wid;
+      }
+      cnt += __popcll(bal);
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  int mc = mc0, t = st->t0, best = st->best_r, tainted = st->tainted;
+  bool full = false;
+  for (int seg = 0; seg < CSA_THREADS / 64 && !full; ++seg) {
+    const int n_listed = s_cnt[seg];
+    const bool listed = n_listed <= CSA_LIST;
+    const int seg_lo = seg * chunk, seg_n = listed ? n_listed : max(0, min(B, seg_lo + chunk) - seg_lo);
+    int cursor = 0;
+    while (cursor < seg_n) {
+      const int idx = cursor + lane;
+      const int wid = idx < seg_n ? (listed ? s_list[seg][idx] : seg_lo + idx) : 0;
+      const int r = pos - wid;
+      const bool cand = (idx < seg_n) && (Kp[r] > mc) && (gsz[wid] > mc);
+      const u64 bal = __ballot(cand);
+      if (!bal) {
+        cursor += 64;
+        continue;
+      }
+      const int first = __ffsll((long long)bal) - 1;
+      const int wsel = __builtin_amdgcn_readlane(wid, first);
+      const int rsel = pos - wsel;
+      // |P| = #{u in N(v) : K[u] > mc} = popcount of row bits at ranks >= t
+      int cnt = 0;
+      for (int w = lane; w < W; w += 64) {
+        u64 xw = adjP[(size_t)rsel * W + w];
+        const int lo = w * 64;
+        if (lo + 63 < t)
+          xw = 0;
+        else if (lo < t)
+          xw &= ~((1ULL << (t - lo)) - 1ULL);
+        cnt += __popcll(xw);
+      }
+      cnt = wave_sum_i32(cnt);
+      if (cnt > mc) {
+        mc = gsz[wsel];
+        best = rsel;
+        (void)greedy_dispatch(adjP, W, rsel, t_sweep, lane, best_picks);  // the sweep's descent once more, members kept
+        int lo = 0, hi = L;  // t = first rank with Kp > mc (Kp is non-decreasing in rank)
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (Kp[mid] > mc)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        t = lo;
+        if (mc >= ub) {
+          full = true;
+          break;
+        }
+      } else if (cf > 0) {
+        tainted = 1;  // (see k_rank_sort: under an injected bound this rule may not be what turns a start down)
+      }
+      cursor += first + 1;
+    }
+  }
+  int done = 1;  // every start has been replayed
+  if (cf > 0 && (best < 0 || tainted)) {  // nothing this search can vouch for: again, with exact core numbers
+    done = 0;
+    mc = 0;
+    best = -1;
+    if (lane == 0) st->redo_cores = 1;
+  }
+  if (lane == 0) {
+    st->tainted = tainted;
+    st->mc = mc;
+    st->best_r = best;
+    st->t0 = t;
+    st->pos = -1;
+    st->done = done;
+    st->batch = CLIQUE_BATCH;
+    st->rounds += 1;
+  }
+}
+
 // KCORE_HEU shortcut (reference src/graph.cc:67-82, including its shifted indexing): decided on device.
 // Writes the member bitset directly; st->mc = clique size, st->best_r = -2 marks "bitset already built".
 template <bool EXT>
@@ -2871,6 +3012,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(ViewExt<SolverView> x,
   }
   const int mc = st->mc;
   const long long t_fin0 = clock64();
+  if (L > 0 && !st->done) {
+    // the clique search is not through (solver_continue will run its remaining starts and launch this kernel again):
+    // nothing to estimate from yet — the state goes to the host, which only looks at `done` / `redo_cores` (on the
+    // 20 k-correspondence graphs of use_crosscheck = 0 this estimate from a provisional clique took 110 us)
+    if (tid == 0) {
+      res->n_clique = 0;
+      res->valid = 0;
+      res->status = QTR_OK;
+    }
+    __syncthreads();
+    export_result(A.mail, res, st, A.seq);
+    return;
+  }
 
   clique_members(st, A.member_bits, A.picks, A.perm, A.clique, W, &s_M);
   const int M = s_M;
@@ -3508,8 +3662,9 @@ hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4*
       LAUNCH_SV(k_solver_reset, a, dim3(1, 1, 1), dim3(64), 0, stream, 1);
       clique_stage_launch(a, 1, L, QTR_INLIER_PMC_HEU, 0.0, stream, false, false, true);
     } else {
-      LAUNCH_SV(k_clique_batch, a, dim3(CLIQUE_BATCH / 4, 1, 1), dim3(256), 0, stream);
-      LAUNCH_SV(k_clique_scan, a, dim3(1, 1, 1), dim3(64), 0, stream, CLIQUE_BATCH);
+      // every remaining start in one speculated round (see k_clique_sweep)
+      LAUNCH_SV(k_clique_sweep, a, dim3(max(1, min((L + 3) / 4, 2048)), 1, 1), dim3(256), 0, stream);
+      LAUNCH_SV(k_clique_scan_all, a, dim3(1, 1, 1), dim3(CSA_THREADS), 0, stream);
     }
     if ((e = hipMemcpyAsync(pinned_state, B.st, sizeof(SolverState), hipMemcpyDeviceToHost, stream)) != hipSuccess)
       return e;
