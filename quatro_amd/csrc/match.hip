@@ -1070,18 +1070,25 @@ __global__ __launch_bounds__(NN_FINH_THREADS) void k_nn_finish_f16(ViewExt<Match
 }
 
 // Re-check of the listed rows (f16 engine): the matrix pipe again.  A listed row's exact arg-min is among the base rows
-// whose filter value is at most the row's threshold (k_nn_finish: the leader's value plus twice the rounding bound) —
+// whose filter value is at most the row's threshold (k_nn_finish_f16: the leader's value plus twice the rounding bound) —
 // two or three near-ties, typically — so the listed rows go through the same 7-MFMA chain once more, this time
 // comparing every entry with the row's threshold; the (row, base row) pairs that are not ABOVE it (a NaN entry — possible
-// when the descriptors are outside the filter's range — passes) are buffered in LDS and get the exact flann::L2
-// evaluation by the same workgroup.  A workgroup takes 128 listed rows (32 per wave) and a slice of the base tiles
-// (fragments of the next tile prefetched).  If more pairs pass than the buffer holds (an infinite threshold: no leader,
-// MC_UNSAFE; clouds of near-identical rows) the workgroup walks its tiles a second time and evaluates every passing
-// pair on the spot, so the kernel is complete whatever passes — in the limit an exact scan of every pair.
-// grid (query groups, slices, pairs).
-#define RC_CAP 2048
-__device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, const float* __restrict__ b, u64* best, int base_row) {
-  float result = 0.f;
+// when the descriptors are outside the filter's range — passes) get the exact flann::L2 evaluation.  A workgroup takes
+// 128 listed rows (32 per wave) and a slice of the base tiles (fragments of the next tiles prefetched).
+// Round 5: every WAVE collects its passing pairs in a list of its own (LDS, 512 entries) and evaluates the list DENSELY
+// — 64 pairs at a time, one per lane, the 32 listed rows' descriptors staged in LDS once, the running minimum of every
+// listed row in LDS, ONE global atomic per row and item at the end — whenever it fills, and when the slice is through.
+// Dense un-voxelised clouds are what this is for: 40 % of the rows of a 50 000-point scan of flat surfaces are listed
+// (near-identical descriptors), each with 500 - 2000 base rows under its threshold, 15 million pairs per direction.  The
+// round-4 form evaluated a pair where it turned up (a sparse loop over the 16 entries of every lane: a tenth of the lanes
+// busy) with a global 64-bit atomic each, or — up to 2048 pairs per workgroup — from one workgroup-wide list behind a
+// barrier: 1.0 ms per direction there, 0.2 now; the voxelised scans (a thousand listed rows, two or three pairs each)
+// never fill a list and pay one vote per tile for it.  A tile that ALONE holds more pairs than a list (an infinite
+// threshold: no leader, MC_UNSAFE) is evaluated where it stands, so the kernel is complete whatever passes — in the limit
+// an exact scan of every pair.   grid (query groups, slices, pairs).
+#define RCW_CAP 512
+__device__ __forceinline__ float recheck_exact_dist(const float* __restrict__ a, const float* __restrict__ b) {
+  float result = 0.f;  // flann::L2's accumulation order
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const float d0 = a[4 * g] - b[4 * g], d1 = a[4 * g + 1] - b[4 * g + 1], d2 = a[4 * g + 2] - b[4 * g + 2],
@@ -1090,6 +1097,10 @@ __device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, 
   }
   const float dt = a[32] - b[32];
   result += dt * dt;
+  return result;
+}
+__device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, const float* __restrict__ b, u64* best, int base_row) {
+  const float result = recheck_exact_dist(a, b);
   if (result == result) atomicMin(best, ((u64)__float_as_uint(result) << 32) | (u32)base_row);  // (NaN never wins)
 }
 template <bool EXT>
@@ -1100,14 +1111,15 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   if (nrows <= 0) return;
 #define RC_STAMP(pt) if (dir == 0) { QTR_STAMP(STAMP_RECHECK, pt) } else { QTR_STAMP(STAMP_RECHECK1, pt) }
   RC_STAMP(0)
-  __shared__ int s_n;
-  __shared__ int2 s_cand[RC_CAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  __shared__ u32 s_wc[4][RCW_CAP];   // per wave: passing pairs, (listed row of the wave's 32) << 20 | base row
+  __shared__ u64 s_wbest[4][32];     // per wave: packed (exact distance bits << 32 | base row) minimum of each listed row
+  __shared__ float s_a[4][32][33];   // per wave: the descriptors of its listed rows (staged when the first list is evaluated)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, half = lane >> 5;
   const u32 frag = (u32)half * 32u + (u32)col;
   const int ntiles = D.nb_pad / 32;
   const h8* __restrict__ baseH = (const h8*)D.baseH;
   const h8* __restrict__ queryH = (const h8*)D.queryH;
-  const int* __restrict__ qcol = V.recheck_q;  // listed row -> its row of the query table (k_nn_finish)
+  const int* __restrict__ qcol = V.recheck_q;  // listed row -> its row of the query table (k_nn_finish_f16)
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
@@ -1117,85 +1129,157 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   // group) then take one tile per workgroup — one round trip — instead of nine behind one another in 64 of 512 workgroups
   const int nwg = gridDim.x * gridDim.y, wid = blockIdx.y * gridDim.x + blockIdx.x;
   const int nsl = max(1, min(ntiles, nwg / qgroups)), per = (ntiles + nsl - 1) / nsl;
+  u32* __restrict__ wc = &s_wc[wave][0];
+  u64* __restrict__ wbest = &s_wbest[wave][0];
   for (int item = wid; item < qgroups * nsl; item += nwg) {
     const int qg = item / nsl, t0 = (item - qg * nsl) * per, t1 = min(ntiles, t0 + per);
-    __syncthreads();
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
     const int qtile = qg * 4 + wave;
     const int slot = qtile * 32 + col;
     h8 q[7], m0[7], m1[7], m2[7];
     {
-      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is buffered)
+      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is listed)
 #pragma unroll
       for (int m = 0; m < 7; ++m) q[m] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + half) * 32 + (qc & 31)];
     }
     const bool live = slot < nrows;
     const float thr = live ? V.recheck_thr[slot] * (NNH_S * NNH_S) : 0.f;
     const int my_row = live ? V.recheck_rows[slot] : 0;
+    if (lane < 32) wbest[lane] = ~0ULL;
+    int wn = 0;             // (uniform) pairs in the wave's list
+    bool a_staged = false;  // (uniform)
+    // the wave's list, densely: lane e takes pair e
+    auto drain = [&]() __attribute__((always_inline)) {
+      if (!a_staged && wn <= 64) {
+        // a handful of pairs (the voxelised scans: two or three per listed row over the whole sweep): one pair per lane,
+        // both rows straight from the tables — staging the wave's 32 descriptors for them cost more than the evaluation
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u32 en = lane < wn ? wc[lane] : 0u;
+        const int c = (int)(en >> 20), brow = (int)(en & 0xfffffu);
+        const int rc = __shfl(my_row, c, 64);  // (lanes 0..31 hold the wave's listed rows)
+        if (lane < wn && brow < nb) {
+          const float result = recheck_exact_dist(A + (size_t)rc * 33, B + (size_t)brow * 33);
+          if (result == result) atomicMin(&wbest[c], ((u64)__float_as_uint(result) << 32) | (u32)brow);  // (NaN never wins)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wn = 0;
+        return;
+      }
+      if (!a_staged) {
+        a_staged = true;
+        for (int i = lane; i < 32 * 33; i += 64) {
+          const int c = i / 33, e = i - c * 33, sl = qtile * 32 + c;
+          s_a[wave][c][e] = (sl < nrows) ? A[(size_t)V.recheck_rows[sl] * 33 + e] : 0.f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the list and the stage are the wave's own: LDS operations of
+      __builtin_amdgcn_wave_barrier();                        // one wave complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = lane; e < wn; e += 64) {
+        const u32 en = wc[e];
+        const int c = (int)(en >> 20), brow = (int)(en & 0xfffffu);
+        if (brow < nb) {  // (not a pad row of the last tile)
+          const float result = recheck_exact_dist(&s_a[wave][c][0], B + (size_t)brow * 33);
+          if (result == result) atomicMin(&wbest[c], ((u64)__float_as_uint(result) << 32) | (u32)brow);  // (NaN never wins)
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      wn = 0;
+    };
     auto load = [&](h8 (&m)[7], int t) __attribute__((always_inline)) {
       t = min(t, ntiles + 1);  // (the table is padded by two tiles: running ahead of the slice is harmless)
 #pragma unroll
       for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];
     };
-    auto tile = [&](const h8 (&m)[7], int t, auto direct_tag) __attribute__((always_inline)) {
-      constexpr bool direct = decltype(direct_tag)::value;  // (two specialised copies: no run-time flag in the hot loop)
+    // which of the lane's 16 entries of tile t pass: sixteen compares into a mask
+    auto tile_mask = [&](const h8 (&m)[7]) __attribute__((always_inline)) -> u32 {
       f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
-      // which of the lane's 16 entries pass (two or three per listed row over the whole sweep): sixteen compares into a
-      // mask and ONE branch, instead of a compare and a branch per entry
       u32 pass = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pass |= !(acc[r] > thr) ? (1u << r) : 0u;
-      if (!live) pass = 0;
+      return live ? pass : 0u;
+    };
+    auto append = [&](u32 pass, int t, int at) __attribute__((always_inline)) {
       while (pass) {
         const int r = __ffs((int)pass) - 1;
         pass &= pass - 1;
-        const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (direct) {
-          if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
-        } else {
-          const int pos = atomicAdd(&s_n, 1);
-          if (pos < RC_CAP) s_cand[pos] = make_int2(slot, brow);
-        }
-      }
-    };
-    // three tiles in flight: a workgroup's slice is a handful of tiles and every one of them is an L2 round trip
-    auto sweep = [&](auto direct) __attribute__((always_inline)) {
-      if (t0 < t1) {
-        load(m0, t0);
-        load(m1, t0 + 1);
-      }
-      for (int t = t0; t < t1; t += 3) {
-        load(m2, t + 2);
-        tile(m0, t, direct);
-        if (t + 1 < t1) {
-          load(m0, t + 3);
-          tile(m1, t + 1, direct);
-        }
-        if (t + 2 < t1) {
-          load(m1, t + 4);
-          tile(m2, t + 2, direct);
-        }
+        wc[at++] = ((u32)col << 20) | (u32)(t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
       }
     };
     RC_STAMP(1)
-    sweep(std::false_type{});
-    RC_STAMP(2)
-    __syncthreads();
-    RC_STAMP(3)
-    const int n = s_n;
-    if (n <= RC_CAP) {
-      // exact distance of every buffered pair, folded into the row's packed (distance, base row) minimum
-      for (int e = threadIdx.x; e < n; e += 256) {
-        const int2 c = s_cand[e];
-        if (c.y >= nb) continue;  // a pad row of the last tile
-        const int row = V.recheck_rows[c.x];
-        recheck_exact_pair(A + (size_t)row * 33, B + (size_t)c.y * 33, &D.best[row], c.y);
+    // ---- the sweep as the voxelised scans need it: three tiles in flight (a workgroup's slice is a handful of tiles and
+    // every one of them is an L2 round trip), the few passing pairs appended to the list; a list that would overflow ends it
+    int ovf = -1;  // (uniform) the tile whose pairs did not fit
+    auto hot = [&](const h8 (&m)[7], int t) __attribute__((always_inline)) {
+      const u32 pass = tile_mask(m);
+      if (__ballot(pass != 0) == 0) return;  // ONE vote of the wave on "anything at all"
+      int tot = 0;
+      const int at = wave_excl_scan_i32(__popc(pass), &tot);
+      if (wn + tot > RCW_CAP) {
+        ovf = t;
+        return;
       }
-    } else {
-      sweep(std::true_type{});  // (uniform: n is the workgroup's count)
+      append(pass, t, wn + at);
+      wn += tot;
+    };
+    if (t0 < t1) {
+      load(m0, t0);
+      load(m1, t0 + 1);
+    }
+    for (int t = t0; t < t1 && ovf < 0; t += 3) {
+      load(m2, t + 2);
+      hot(m0, t);
+      if (ovf < 0 && t + 1 < t1) {
+        load(m0, t + 3);
+        hot(m1, t + 1);
+      }
+      if (ovf < 0 && t + 2 < t1) {
+        load(m1, t + 4);
+        hot(m2, t + 2);
+      }
+    }
+    RC_STAMP(2)
+    if (wn > 0) drain();
+    // ---- ... and as the dense clouds need it, from the tile that overflowed on: one tile ahead, the list evaluated
+    // whenever the next tile's pairs would not fit (and when the slice is through)
+    if (ovf >= 0) {
+      load(m0, ovf);
+      for (int t = ovf; t <= t1; ++t) {
+        u32 pass = 0;
+        int tot = 0, at = 0;
+        if (t < t1) {
+          load(m1, t + 1);
+          pass = tile_mask(m0);
+          at = wave_excl_scan_i32(__popc(pass), &tot);
+        }
+        if (t == t1 || wn + tot > RCW_CAP) {
+          if (wn > 0) drain();
+          if (t == t1) break;
+        }
+        if (tot > RCW_CAP) {  // more than a list holds in ONE tile (infinite thresholds): evaluated where they stand
+          while (pass) {
+            const int r = __ffs((int)pass) - 1;
+            pass &= pass - 1;
+            const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
+          }
+        } else if (tot > 0) {
+          append(pass, t, wn + at);
+          wn += tot;
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m0[j] = m1[j];
+      }
+    }
+    RC_STAMP(3)
+    if (lane < 32) {  // (lanes 0..31 hold the wave's 32 listed rows: slot, my_row)
+      const u64 b = wbest[lane];
+      if (live && b != ~0ULL) atomicMin(&D.best[my_row], b);
     }
     RC_STAMP(4)
   }

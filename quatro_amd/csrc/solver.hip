@@ -3628,6 +3628,10 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
       // Rounds 0 and 1 are enqueued unconditionally: the heuristic nearly always terminates within them (the
       // first start finds the large clique, the second batch only confirms that no start can beat it).  The
       // host checks `done` once, together with the result record; solver_continue() handles the rare rest.
+      // (Round 5 measured leaving round 1 to solver_continue: the headline's planted clique is settled by round 0 and
+      // saves the 4.7 us dispatch, but a matcher's own correspondences — use_tuple_test = 0, L = 2104, clique 87 — need
+      // round 1 and paid a host round trip for it, 0.637 -> 0.680 ms, and at L = 20 k the sweep then started from a
+      // small bound and re-ran a long descent per accepted start: 3.3 -> 3.7 ms.  Kept unconditional.)
       if (lds_rows)
         LAUNCH_SV(k_clique_batch_lds, a, dim3(BATCH / 4, 1, G), dim3(256), cl_lds, stream, 0);
       else
