@@ -18,18 +18,22 @@ second best) takes the 16 values of a column block two at a time:
     second = min3(second, t, t') once per two pairs
 — five instructions per FOUR values, 89 per tile with the bookkeeping: the loop is bound by the matrix pipe.  (Invariant:
 second >= best; the two smallest of {best, second, x, y} are min3(best, x, y) and min(second, med3(best, x, y)).)  No
-index travels with a value any more: the lane only notes the TILE in which its best last changed (best is written
-ping-pong into two register sets, one compare per column block and tile), so a partial result names 16 candidate rows
-— the lane's rows of that tile — and k_nn_finish_f16 picks the one with the smallest EXACT distance (match.hip).
+index travels with a value any more: the lane notes the tile and QUAD of accumulator registers (four consecutive rows
+of the base cloud) in which its best last changed — the running best moves through five registers per column block
+(in, three temporaries, out; in / out ping-pong between two banks from tile to tile), one compare and one conditional
+move per quad, 116 instructions per tile all told (131 issue slots with loads and loop control: still inside the ~140 the
+matrix pipe hides) — so a partial result names 4 candidate rows, one aligned 528-byte run of the row-major descriptor
+table, and k_nn_finish_f16 picks the one with the smallest EXACT distance (match.hip).
 
 Register map (per lane)
   a[0:111]    query fragments: q[c][m] = a[(7c+m)*4 .. +3]      (c = column block 0..3, m = MFMA 0..6)
   v[64:127]   accumulator set A (16 per column block), v[128:191] set B
   v[192:219]  base tile buffer 0 (7 fragments of 4 dwords), v[220:247] buffer 1
   v20-23 / v28-31 best (ping-pong: the fold of set A reads 20.. and writes 28.., the fold of set B the other way),
-  v24-27 second, v32-35 tile of the best, v36 v37 temporaries, v38 tile being folded,
+  v24-27 second, v32-35 4 * tile + quad of the best, v36 v37 temporaries, v41-43 the best between quads,
+  v44-47 4 * (tile being folded) + quad,
   v39 lane byte offset inside a chunk pair, v40 = v39 + 4096
-  s[40:41] base-table cursor (next tile to load), s[44:45] query table, s42 tiles left to start, s[46:53] compare masks
+  s[40:41] base-table cursor (next tile to load), s[44:45] query table, s42 tiles left to start, s[46:61] compare masks
 Wait states that the assembler will not insert for us (gfx940/950): a VALU read of an MFMA result needs the MFMA to
 be 11 wait states old (8-pass) — every fold starts behind two MFMAs of the next tile; a v_cmp's mask is read by its
 v_cndmask three instructions later.
@@ -63,26 +67,37 @@ def mfma(dst, c, j, buf):
 BEST = {"A": (20, 28), "B": (28, 20)}  # the fold of a set reads the running best from the first bank, writes the second
 
 
+TMP = [41, 42, 43]   # the running best between the four quads of a column block (in -> T0 -> T1 -> T2 -> out)
+TQ = [44, 45, 46, 47]  # 4 * tile + quad of the tile being folded
+
+
 def fold_ops(src):
     """the fold of one accumulator set as a flat list of instructions (see the module docstring)"""
     pin, pout = BEST[src]
     ops = []
+    pending = None  # the v_cndmask of the previous quad: issued a quad later than its v_cmp (the mask travels in SGPRs)
+    n = 0
     for c in range(4):
         x = ["v%d" % (ACC[src] + 16 * c + r) for r in range(16)]
-        cur, out, sec = "v%d" % (pin + c), "v%d" % (pout + c), "v%d" % (24 + c)
+        sec = "v%d" % (24 + c)
+        stage = ["v%d" % (pin + c)] + ["v%d" % t for t in TMP] + ["v%d" % (pout + c)]
         for q in range(4):
             r = 4 * q
+            cur, out = stage[q], stage[q + 1]
             ops.append("v_med3_f32 v36, %s, %s, %s" % (cur, x[r], x[r + 1]))
             ops.append("v_min3_f32 %s, %s, %s, %s" % (out, cur, x[r], x[r + 1]))
-            cur = out
-            ops.append("v_med3_f32 v37, %s, %s, %s" % (cur, x[r + 2], x[r + 3]))
-            ops.append("v_min3_f32 %s, %s, %s, %s" % (out, cur, x[r + 2], x[r + 3]))
+            ops.append("v_med3_f32 v37, %s, %s, %s" % (out, x[r + 2], x[r + 3]))
+            ops.append("v_min3_f32 %s, %s, %s, %s" % (out, out, x[r + 2], x[r + 3]))
             ops.append("v_min3_f32 %s, %s, v36, v37" % (sec, sec))
-    for c in range(4):  # did the best change in this tile?  (mask in an SGPR pair, read three instructions later)
-        ops.append("v_cmp_neq_f32_e64 s[%d:%d], v%d, v%d" % (46 + 2 * c, 47 + 2 * c, pout + c, pin + c))
-    for c in range(4):
-        ops.append("v_cndmask_b32_e64 v%d, v%d, v38, s[%d:%d]" % (32 + c, 32 + c, 46 + 2 * c, 47 + 2 * c))
-    ops.append("v_add_u32 v38, 1, v38")
+            sp = 46 + 2 * (n % 8)
+            n += 1
+            # did the best change in this QUAD (rows 8 q + 4 half + {0..3} of the tile)?
+            ops.append("v_cmp_neq_f32_e64 s[%d:%d], %s, %s" % (sp, sp + 1, out, cur))
+            if pending:
+                ops.append(pending)
+            pending = "v_cndmask_b32_e64 v%d, v%d, v%d, s[%d:%d]" % (32 + c, 32 + c, TQ[q], sp, sp + 1)
+    ops += ["v_nop", "v_nop", pending]
+    ops += ["v_add_u32 v%d, 4, v%d" % (t, t) for t in TQ]
     return ops
 
 
@@ -136,7 +151,8 @@ def query_loads(c):
 
 # ---- prologue
 asm += ["s_mov_b32 s40, %[blo]", "s_mov_b32 s41, %[bhi]", "s_mov_b32 s44, %[qlo]", "s_mov_b32 s45, %[qhi]", "s_mov_b32 s42, %[nt]",
-        "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_mov_b32 v38, %[t0]"]
+        "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_lshlrev_b32 v44, 2, %[t0v]", "v_add_u32 v45, 1, v44",
+        "v_add_u32 v46, 2, v44", "v_add_u32 v47, 3, v44"]
 # query fragments straight into AGPRs; the lane's row of column block c starts at byte %[qc] of the table
 asm += query_loads(0)
 asm += load_tile(0)  # tile 0 of the slice
@@ -168,8 +184,8 @@ asm += ["s_waitcnt vmcnt(0)"]
 for c in range(4):
     asm += ["v_mov_b32 %%[b1%d], v%d" % (c, 20 + c), "v_mov_b32 %%[b2%d], v%d" % (c, 24 + c), "v_mov_b32 %%[it%d], v%d" % (c, 32 + c)]
 
-clob = ['"v%d"' % i for i in list(range(20, 41)) + list(range(64, 248))] + ['"a%d"' % i for i in range(112)]
-clob += ['"s%d"' % i for i in (40, 41, 42, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53)] + ['"vcc"', '"scc"', '"memory"']
+clob = ['"v%d"' % i for i in list(range(20, 48)) + list(range(64, 248))] + ['"a%d"' % i for i in range(112)]
+clob += ['"s%d"' % i for i in [40, 41, 42, 44, 45] + list(range(46, 62))] + ['"vcc"', '"scc"', '"memory"']
 
 print("// generated by gen_nn_f16_core.py — do not edit (see that file for the register map and the schedule)")
 print("// One item of k_nn_f16: 4 x 32 query columns of this wave (the lane's row of column block c starts at byte qoff[c] of")
@@ -186,7 +202,7 @@ for a in asm:
     print('      "%s\\n"' % a)
 outs = ", ".join('[b1%d] "=&v"(b1[%d]), [b2%d] "=&v"(b2[%d]), [it%d] "=&v"(it1[%d])' % (c, c, c, c, c, c) for c in range(4))
 print("      : %s" % outs)
-print('      : [qlo] "s"(qlo), [qhi] "s"(qhi), [blo] "s"(blo), [bhi] "s"(bhi), [nt] "s"(nt), [t0] "s"(t0), [frag] "v"(frag_bytes),')
+print('      : [qlo] "s"(qlo), [qhi] "s"(qhi), [blo] "s"(blo), [bhi] "s"(bhi), [nt] "s"(nt), [t0v] "v"(t0), [frag] "v"(frag_bytes),')
 print('        [q0] "v"(qoff[0]), [q1] "v"(qoff[1]), [q2] "v"(qoff[2]), [q3] "v"(qoff[3])')
 print("      : %s);" % ", ".join(clob))
 print("}")
