@@ -4,8 +4,12 @@ import sqlite3
 import sys
 
 db = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = sqlite3.connect(db)
+# steps: a number, or "auto" = the registrations the trace holds (every registration opens with one k2_minmax launch)
+steps = 0
+if len(sys.argv) > 2:
+    steps = (c.execute("select count(*) from kernels where name like 'void k2_minmax%'").fetchone()[0]
+             if sys.argv[2] == "auto" else int(sys.argv[2]))
 rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                  "from kernels group by name order by 3 desc").fetchall()
 tot = sum(r[2] for r in rows)
