@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   __shared__ u32 s_wc[4][RCW_CAP];   // per wave: passing pairs, (listed row of the wave's 32) << 20 | base row
   __shared__ u64 s_wbest[4][32];     // per wave: packed (exact distance bits << 32 | base row) minimum of each listed row
   __shared__ float s_a[4][32][33];   // per wave: the descriptors of its listed rows (staged when the first list is evaluated)
+  __shared__ int s_wctl[4][4];       // per wave: the list's reservation counter and overflow marks (see the sweep)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, half = lane >> 5;
   const u32 frag = (u32)half * 32u + (u32)col;
   const int ntiles = D.nb_pad / 32;
@@ -1214,36 +1215,50 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
     RC_STAMP(1)
     // ---- the sweep as the voxelised scans need it: three tiles in flight (a workgroup's slice is a handful of tiles and
     // every one of them is an L2 round trip), the few passing pairs appended to the list; a list that would overflow ends it
-    int ovf = -1;  // (uniform) the tile whose pairs did not fit
+    // (a lane with pairs reserves their places with ONE LDS atomic — no vote, no scan on the path of the tiles that hold
+    // nothing; the first reservation that does not fit marks its tile, and what was reserved before it is a prefix of
+    // the list: reservations only grow)
+    int* __restrict__ wctl = &s_wctl[wave][0];  // [0] places reserved, [1] first tile that did not fit, [2] entries that did
+    if (lane == 0) {
+      wctl[0] = 0;
+      wctl[1] = 0x7fffffff;
+      wctl[2] = 0x7fffffff;
+    }
     auto hot = [&](const h8 (&m)[7], int t) __attribute__((always_inline)) {
       const u32 pass = tile_mask(m);
-      if (__ballot(pass != 0) == 0) return;  // ONE vote of the wave on "anything at all"
-      int tot = 0;
-      const int at = wave_excl_scan_i32(__popc(pass), &tot);
-      if (wn + tot > RCW_CAP) {
-        ovf = t;
-        return;
+      if (pass) {
+        const int cnt = __popc(pass), at = atomicAdd(&wctl[0], cnt);
+        if (at + cnt <= RCW_CAP) {
+          append(pass, t, at);
+        } else {
+          atomicMin(&wctl[1], t);
+          atomicMin(&wctl[2], at);
+        }
       }
-      append(pass, t, wn + at);
-      wn += tot;
     };
     if (t0 < t1) {
       load(m0, t0);
       load(m1, t0 + 1);
     }
-    for (int t = t0; t < t1 && ovf < 0; t += 3) {
+    for (int t = t0; t < t1; t += 3) {
       load(m2, t + 2);
       hot(m0, t);
-      if (ovf < 0 && t + 1 < t1) {
+      if (t + 1 < t1) {
         load(m0, t + 3);
         hot(m1, t + 1);
       }
-      if (ovf < 0 && t + 2 < t1) {
+      if (t + 2 < t1) {
         load(m1, t + 4);
         hot(m2, t + 2);
       }
+      if (__builtin_amdgcn_readfirstlane(wctl[1]) != 0x7fffffff) break;  // a list overflowed: the dense loop takes over
     }
     RC_STAMP(2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ovf = (wctl[1] != 0x7fffffff) ? __builtin_amdgcn_readfirstlane(wctl[1]) : -1;  // (uniform) first tile whose pairs did not fit
+    wn = __builtin_amdgcn_readfirstlane(min(min(wctl[0], wctl[2]), RCW_CAP));
     if (wn > 0) drain();
     // ---- ... and as the dense clouds need it, from the tile that overflowed on: one tile ahead, the list evaluated
     // whenever the next tile's pairs would not fit (and when the slice is through)
