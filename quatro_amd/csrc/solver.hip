@@ -140,7 +140,7 @@ __device__ __forceinline__ void wave_transpose64(u32& lo, u32& hi, int lane) {
 #define GB2_THREADS 256
 #define GB_TILES_MAX_L 8192  // up to here the tile kernel (k_graph_build_tiles, below) builds the graph
 template <bool EXT>
-__global__ __launch_bounds__(GB2_THREADS, 8) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta,
+__global__ __launch_bounds__(GB2_THREADS, EXT ? 7 : 8) void k_graph_build(ViewExt<SolverView> x, SolverView one, double beta,
                                                                 float margin, int prep) {
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L, Wb = V.Wb;
