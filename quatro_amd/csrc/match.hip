@@ -647,7 +647,6 @@ __global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, Match
 // loop is the hand-scheduled block of nn_f16_core.inc (generated by gen_nn_f16_core.py: register map, schedule and the
 // wait states it has to respect are documented there).  ~250 VGPRs + 112 AGPRs: one workgroup per compute unit.
 #include "nn_f16_core.inc"
-#include "nn_f16_core_packed.inc"  // the batched launches (EXT): row index packed into the values, see its generator
 // -DQTR_NN_TIMING (diagnostic build, tests/probe/nn_stamps.py): thread 0 of every workgroup records the shader clock and
 // the 100 MHz wall clock at five points of its first item
 #ifdef QTR_NN_TIMING
@@ -755,12 +754,8 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
           qoff[c] = ((u32)((row >> 5) * NNH_CHUNKS + half) * 32u + (u32)(row & 31)) * 16u;
         }
       }
-      if (EXT)
-        nn_f16_core_packed(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
-                           ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
-      else
-        nn_f16_core(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
-                    ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
+      nn_f16_core(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
+                  ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
     NN_STAMP(3)
     } else {
 #pragma unroll
@@ -775,14 +770,10 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
       // lane knows the tile and the quad of accumulator registers its best came from, i.e. 4 candidate rows — rows
       // 8 quad + 4 half + {0..3} of that tile — and k_nn_finish_f16 picks the candidate with the smallest exact
       // distance.  i1 = 2 * (4 tile + quad) + half.
-      // (EXT — a group of pairs — runs the packed-index loop: the record then names the row itself and k_nn_finish reads
-      // it; ties go to the lower row there)
-      const int r = (int)(__float_as_uint(b1[c]) & 15u);
-      int cand = (it1[c] < 0) ? -1 : EXT ? (it1[c] * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) : (it1[c] * 2 + half);
+      int cand = (it1[c] < 0) ? -1 : (it1[c] * 2 + half);
       const float ob1 = __shfl_xor(b1[c], 32, 64), ob2 = __shfl_xor(b2[c], 32, 64);
       const int ocand = __shfl_xor(cand, 32, 64);
-      const bool take = (ob1 < b1[c]) || (cand < 0 && ocand >= 0) ||
-                        (EXT && ob1 == b1[c] && ocand >= 0 && ocand < cand);  // (index-free: a tie leaves second == best)
+      const bool take = (ob1 < b1[c]) || (cand < 0 && ocand >= 0);  // (a tie leaves second == best: never certified)
       const float nb2 = fminf(fminf(b2[c], ob2), take ? b1[c] : ob1);
       const float nb1 = take ? ob1 : b1[c];
       cand = take ? ocand : cand;
@@ -900,7 +891,7 @@ __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView>
 }
 
 __device__ __forceinline__ float recheck_exact_dist(const float* __restrict__ a, const float* __restrict__ b);  // (below)
-// The f16 engine's finish (round 5; single registrations — a group of pairs keeps the packed-index loop and k_nn_finish).
+// The f16 engine's finish (round 5).
 // k_nn_f16 no longer carries a row index with a value (its fold is ~1.8 instructions per value instead of 3.3:
 // gen_nn_f16_core.py): a partial record names the tile, the QUAD of accumulator registers and the lane half its best came
 // from, i.e. 4 candidate rows — rows 8 quad + 4 half + {0..3} of that tile: ONE aligned run of 528 bytes of the row-major
@@ -915,7 +906,8 @@ __device__ __forceinline__ float recheck_exact_dist(const float* __restrict__ a,
 // through to the exact evaluation).  Pad rows of the last tile are not candidates; a hidden duplicate among them has the
 // distance of its lower-indexed original and loses the tie.
 // (First form of the round: the TILE only, 16 candidates and 2.1 KB of LDS per query — 64 queries filled a compute unit,
-// 11 us per launch single, half a millisecond for a group of sixteen pairs.)
+// 11 us per launch single, half a millisecond for a group of sixteen pairs: 5138 against 5407 batched registrations/s
+// for the packed-index loop of rounds 2-4.  With four candidates the batched path gains too: 5620 against 5560.)
 // 64 queries per workgroup of 256 threads, four lanes per query; grid (ceil(nq_max / 64), 1, pairs).
 #define NN_FINH_Q 64
 #define NN_FINH_PITCH 132  // floats per query of the candidate stage: 4 rows x 33
@@ -2375,12 +2367,11 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
 #endif
         if (e1) (void)hipEventRecord(e1, st);
       }
-      // (a group of pairs ran the packed-index loop: its records name rows, the round-4 finish reads them)
-      if (f16 && !a.ext)
-        LAUNCH_MV(k_nn_finish_f16, a, dim3((nq_max + NN_FINH_Q - 1) / NN_FINH_Q, 1, G), B256, 0, st, dir, 800.0f);
-      else
-        LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir,
-                  X, G, f16 ? 800.0f : 0.0f, f16 ? 1 : 0);
+      if (f16) LAUNCH_MV(k_nn_finish_f16, a, dim3((nq_max + NN_FINH_Q - 1) / NN_FINH_Q, 1, G), B256, 0, st, dir, 800.0f);
+#ifdef QTR_TEST_ENGINES
+      else LAUNCH_MV(k_nn_finish, a, dim3((nq_max + NN_FIN_THREADS - 1) / NN_FIN_THREADS, 1, G), dim3(NN_FIN_THREADS), 0, st, dir,
+                     X, G, 0.0f, 0);
+#endif
       // (single pair: 8 x 64 workgroups = the 512 the device holds at two per compute unit — one round)
       if (f16) LAUNCH_MV(k_recheck_filter, a, dim3(8, G > 1 ? 16 : 64, G), B256, 0, st, dir);
       // (row group, span slice) workgroups: a group's span is a few per cent of the base cloud
