@@ -142,6 +142,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NN_QPB 512    // queries per workgroup (4 waves)
 #define NN_MAXSPLIT 32
 #define NN_NORM_SCALE (1.0 - 141.0 * 5.9604644775390625e-08)
+#define NNH_NORM_SCALE (1.0 - 56.0 * 5.9604644775390625e-08)  // the f16-split tables' own (round 5, see the f16 engine's bound)
 
 __device__ __forceinline__ u64 desc_hash(const float* d) { return desc_hash33(d); }  // (frontend.hip: k2_fpfh computes the same)
 
@@ -516,7 +517,18 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 //   + 8u (33 + |a|^2) + 4u (33 + |b|^2)   subnormal second halves: 2^-14 (sum|q^| + sum|b^|) / S^2, |x| <= (1 + x^2)/2
 //   <= 69u |a|^2 + 114u |b|^2 + 396u
 // against 66u |a|^2 + 132u |b|^2 of the f32 chain: the same certification inequality holds with + 800u on the right-hand
-// side (k_nn_finish).  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
+// side (k_nn_finish; rounds 2-4).
+// Round 5: the fold no longer packs anything into the values (gen_nn_f16_core.py), so the third line is gone:
+//     E <= 37u |a|^2 + 50u |b|^2 + 396u,
+// and the tables' norm row is scaled down by 56u instead of the f32 chain's 141u (NNH_NORM_SCALE; it only has to cover
+// the |b|^2 term of E): nb' <= |b|^2 (1 - 56u), nb' >= |b|^2 (1 - 58u).  As in the f32 derivation above, for EVERY base
+// row   d(a,b) >= |a|^2~ + v - 38u |a|^2 - 396u   (the |b|^2 part of the error is inside the scaling), for the winner
+//     d(a,b1) <= |a|^2~ + v1 + 38u |a|^2 + 108u |b1|^2 + 396u,   and the exact-order float evaluation obeys |d_ex - d| <= 37u d:
+// the approximate winner is the exact arg-min whenever
+//     v2 - v1 > u (76 |a|^2 + 108 |b1|^2 + 40 (d~1 + d~2) + 800)     (k_nn_finish_f16, 1 % slack on top)
+// — 2.3 x tighter than the inequality the f32 chain needs, which is what the listed rows of dense clouds (thousands of
+// near-identical descriptors with |b|^2 = 30000) were waiting for.  The re-check's threshold follows: v1 + u (76 |a|^2 +
+// 108 |b1|^2 + 80 d~1 + 800).  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
 // -256 x) and every |b|^2 < 65000 (f16 range of the norm pieces); a pair that violates them (not an FPFH descriptor:
 // those are bounded by 100) sets MC_UNSAFE and k_nn_finish sends all of its rows to the exact re-check.
 // Hidden / pad rows carry 3 x 65504 in the norm slots (196512 > any real nb').
@@ -577,7 +589,7 @@ __device__ __forceinline__ void d_half_tables(const float* __restrict__ desc, in
   bool hide = false;
   if (i < n) {
     bad = bad || !((float)acc < 65000.0f);
-    nbp = __double2float_rd(acc * NN_NORM_SCALE);
+    nbp = __double2float_rd(acc * NNH_NORM_SCALE);
     const u64 h = hashes[i];
     const u64 tag = h & 0xffffffff00000000ULL;
     u32 slot = (u32)h & (u32)mask;
@@ -1040,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
     const float u = 5.9604645e-08f;
     const float d1 = fmaxf(cna + c1, 0.f) + 1.0f;  // d~ of the leader (|a|^2 is not inside b1)
     const float d2 = (c2 < INFINITY) ? fmaxf(cna + c2, 0.f) + 1.0f : d1;
-    const float gap = u * (144.0f * cna + 280.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;
+    const float gap = u * (76.0f * cna + 108.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;  // (the f16 engine's own bound, round 5)
     if (unsafe) i1 = -1;
     const bool certified = i1 >= 0 && (c2 == INFINITY || c2 - c1 > gap);
     const bool listed = valid && !certified;
@@ -1054,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
       V.recheck_rows[slot] = crow;
       // a base row whose approximate (lower-bound) value exceeds this cannot be the exact arg-min; +inf when the slice
       // merge found nothing
-      const float thr = (i1 >= 0) ? c1 + u * (144.0f * cna + 280.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
+      const float thr = (i1 >= 0) ? c1 + u * (76.0f * cna + 108.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
       V.recheck_thr[slot] = thr;
       V.recheck_q[slot] = crow;  // where k_recheck_filter finds the row's f16 query fragments (row of D.queryH)
     }
