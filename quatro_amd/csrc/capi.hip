@@ -735,9 +735,11 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
 struct InFlight {
   qtr_handle* h;
   explicit InFlight(qtr_handle* h_) : h(h_) {
-    static thread_local unsigned long long t_registered_with = 0;
-    if (t_registered_with != h->uid) {
-      t_registered_with = h->uid;
+    // (the handles this thread has registered with: a thread that works with several handles in turn is ONE caller of each)
+    static thread_local std::vector<unsigned long long> t_registered;
+    if (std::find(t_registered.begin(), t_registered.end(), h->uid) == t_registered.end()) {
+      if (t_registered.size() >= 64) t_registered.erase(t_registered.begin());  // (handles come and go: keep the list short)
+      t_registered.push_back(h->uid);
       if (h->n_callers.fetch_add(1, std::memory_order_acq_rel) == 1)  // the second thread: let a full-share chain drain
         for (int spins = 0; h->solves_in_flight.load(std::memory_order_acquire) > 0 && spins < 2000000; ++spins)
           std::this_thread::yield();
