@@ -148,8 +148,6 @@ typedef struct qtr_stage_times {
   float nn_kernel;  /* sum of the nearest-neighbour kernel launches of the last match (events on the launch stream) */
   int nn_launches;
   float graph_kernel; /* k_graph_build alone */
-  float nn_dir1, nn_dir2; /* the two launches behind nn_kernel: every row of the smaller cloud against the larger one, and the
-                             rows of the larger cloud that were chosen against the smaller one (feature_matcher.cc:113-122) */
 } qtr_stage_times;
 
 QTR_API int qtr_create(int device, const qtr_limits* limits /* NULL = defaults */, qtr_handle** out);
@@ -394,6 +392,11 @@ QTR_API int qtr_get_stage_times(qtr_handle* h, int slot, qtr_stage_times* out);
 QTR_API int qtr_set_stage_events(qtr_handle* h, int on);
 QTR_API int qtr_set_nn_event_stride(qtr_handle* h, int every);
 QTR_API int qtr_get_nn_totals(qtr_handle* h, int slot, double* total_ms, long long* launches, int reset);
+/* The two launches behind qtr_stage_times.nn_kernel apart, milliseconds (0 when the last match carried no events): every
+ * row of the smaller cloud against the larger one, and the rows of the larger cloud that were chosen against the smaller
+ * one — the two FLANN searches of teaser::Matcher::advancedMatching (src/teaser_utils/feature_matcher.cc:100-122).  A
+ * call of its own rather than two more fields: qtr_stage_times keeps its size for callers built against earlier headers. */
+QTR_API int qtr_get_nn_dir_times(qtr_handle* h, int slot, float* dir1_ms, float* dir2_ms);
 
 /* Inspection of intermediates of the LAST call on a slot (tests / parity debugging).  Copies up to
  * `bytes` bytes to host memory `dst`; returns the number of bytes the item holds, or <0 on error. */

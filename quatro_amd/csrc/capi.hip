@@ -46,6 +46,7 @@ struct Slot {
   int nn_pending = 0;            // the nearest-neighbour events of the last match have not been added to the totals yet
   int nn_timed_last = 0;         // the last match had its event pairs attached (qtr_set_nn_event_stride)
   long long n_matches = 0;       // matches this slot has run
+  float nn_dir_ms[2] = {0, 0};   // qtr_get_nn_dir_times: the two launches of the last timed match apart
   double nn_total_ms = 0;        // qtr_get_nn_totals
   long long nn_total_launches = 0;
   qtr_stage_times times = {};
@@ -500,13 +501,14 @@ static void flush_nn_totals(Slot& s) {
 
 static void fill_nn_times(Slot& s) {
   float a = 0, b = 0;
+  s.nn_dir_ms[0] = s.nn_dir_ms[1] = 0.f;
   if (!s.nn_timed_last) return;  // (the fields keep their zeros)
   if (hipEventElapsedTime(&a, s.fb.ev_nn[0], s.fb.ev_nn[1]) == hipSuccess &&
       hipEventElapsedTime(&b, s.fb.ev_nn[2], s.fb.ev_nn[3]) == hipSuccess) {
     s.times.nn_kernel = a + b;
     s.times.nn_launches = 2;
-    s.times.nn_dir1 = a;
-    s.times.nn_dir2 = b;
+    s.nn_dir_ms[0] = a;
+    s.nn_dir_ms[1] = b;
   }
 }
 
@@ -1317,6 +1319,18 @@ int qtr_set_nn_event_stride(qtr_handle* h, int every) {
   if (!h || every < 0) return QTR_ERR_BAD_ARG;
   h->nn_event_stride = every;
   for (auto& s : h->slots) s.n_matches = 0;  // the next match of every slot is a timed one
+  return QTR_OK;
+}
+
+int qtr_get_nn_dir_times(qtr_handle* h, int slot, float* dir1_ms, float* dir2_ms) {
+  Slot* sp = get_slot(h, slot);
+  if (!sp) return QTR_ERR_BAD_ARG;
+  if (sp->times_pending) {  // (the events of the last call are read on demand, like qtr_get_stage_times does)
+    qtr_stage_times t;
+    (void)qtr_get_stage_times(h, slot, &t);
+  }
+  if (dir1_ms) *dir1_ms = sp->nn_dir_ms[0];
+  if (dir2_ms) *dir2_ms = sp->nn_dir_ms[1];
   return QTR_OK;
 }
 

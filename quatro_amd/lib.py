@@ -63,8 +63,7 @@ class PairDesc(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = ([(n, C.c_float) for n in ("voxelize", "fpfh", "match", "graph", "clique", "solve", "total",
-                                          "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float),
-                                                           ("nn_dir1", C.c_float), ("nn_dir2", C.c_float)])
+                                          "nn_kernel")] + [("nn_launches", C.c_int), ("graph_kernel", C.c_float)])
 
 
 class PwParams(C.Structure):
@@ -87,7 +86,7 @@ EXPORTS = [
     "qtr_create", "qtr_destroy", "qtr_last_error", "qtr_default_limits", "qtr_default_params", "qtr_demo_params",
     "qtr_default_frontend_params", "qtr_num_slots", "qtr_slot_stream", "qtr_voxelize", "qtr_fpfh", "qtr_match",
     "qtr_solve", "qtr_max_clique", "qtr_compute_tims", "qtr_scale_mask", "qtr_gnc_rotation2d",
-    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_register_pair_corr", "qtr_feature_pair", "qtr_get_stage_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
+    "qtr_cote_estimate", "qtr_cote_estimate_ranges", "qtr_ip_default_params", "qtr_segment_cloud", "qtr_pw_default_params", "qtr_patchwork", "qtr_gnc_rotation3d", "qtr_exact_stats", "qtr_read_kitti_bin", "qtr_write_pcd_xyz", "qtr_read_pcd_xyz", "qtr_register_pair", "qtr_register_pair_corr", "qtr_feature_pair", "qtr_get_stage_times", "qtr_get_nn_dir_times", "qtr_set_stage_events", "qtr_set_nn_event_stride", "qtr_get_nn_totals", "qtr_debug_fetch", "qtr_debug_math", "qtr_submit_batch", "qtr_wait", "qtr_set_batch_preprocess", "qtr_comm_unique_id", "qtr_comm_init", "qtr_gather_results", "qtr_gather_results_v", "qtr_comm_destroy",
 ]
 
 _lib = None
@@ -197,6 +196,7 @@ def load(path: str | None = None):
                                      C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.qtr_set_batch_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
+    lib.qtr_get_nn_dir_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_set_nn_event_stride.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
@@ -681,7 +681,11 @@ class Handle:
     def stage_times(self, slot: int = 0) -> dict:
         t = StageTimes()
         self._lib.qtr_get_stage_times(self._h, slot, C.byref(t))
-        return {n: getattr(t, n) for n, _ in StageTimes._fields_}
+        out = {n: getattr(t, n) for n, _ in StageTimes._fields_}
+        d1, d2 = C.c_float(), C.c_float()
+        self._lib.qtr_get_nn_dir_times(self._h, slot, C.byref(d1), C.byref(d2))
+        out["nn_dir1"], out["nn_dir2"] = d1.value, d2.value  # the two nearest-neighbour launches behind nn_kernel apart
+        return out
 
     def debug_fetch(self, what: int, dtype, slot: int = 0) -> np.ndarray:
         nbytes = self._lib.qtr_debug_fetch(self._h, slot, what, None, 0)
