@@ -1386,6 +1386,10 @@ int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, 
   QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   int n = s.pinned_i32[CNT_NVOX];
+  if (n < 0) {  // (see front_device)
+    snprintf(h->err, sizeof(h->err), "voxel grid: look-back timed out");
+    return QTR_ERR_HIP;
+  }
   const bool passthrough = s.pinned_i32[CNT_VOX_OVERFLOW] != 0;
   const float4* d_out = cb.vox;
   if (passthrough) {  // PCL: "Leaf size is too small" -> output = input
@@ -1606,6 +1610,10 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     }
   }
   int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+  if (ns < 0 || nt < 0) {  // k2_vox_centroids: a tile never published its count (bounded look-back): nothing usable was written
+    snprintf(h->err, sizeof(h->err), "voxel grid: look-back timed out");
+    return fail_drained(QTR_ERR_HIP);
+  }
   {
     // pcl::VoxelGrid::applyFilter: "Leaf size is too small for the input dataset. Integer indices would overflow" ->
     // output = input.  So does `voxelize` of the reference (include/quatro.hpp:49-68 calls it unconditionally), and the
@@ -1656,8 +1664,9 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
-    QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2, false));
-    if (for_solver) QTR_HIP_TRY(h, solver_reset_enqueue(s.sb, s.stream2));
+    // (the solver's clean slate rides in the matcher's: one launch fewer beside the FPFH chain)
+    QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2, false, for_solver ? (int*)s.sb.st : nullptr,
+                                      (int)(sizeof(SolverState) / 4)));
     QTR_HIP_TRY(h, hipEventRecord(s.ev[5], s.stream2));
     QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream, s.ev[5], 0));
   }
@@ -2080,6 +2089,10 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       Slot& s = h->slots[ln.first_slot + g];
       qtr_result& r = J.results[ln.first_pair + g];
       int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+      if (ns < 0 || nt < 0) {  // the centroid kernel's look-back timed out for this pair (see front_device)
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_HIP);
+        continue;
+      }
       // (a grid that would overflow int32 passes its cloud through, as pcl::VoxelGrid does: see front_device)
       const bool pass_s = s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] != 0, pass_t = s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] != 0;
       if (pass_s) ns = ln.Ps[g];

@@ -136,6 +136,38 @@ __device__ __forceinline__ float wave_sum64_f32(float v) {  // qm_sum64_fold_f a
 }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << qk_lane()) - 1ULL; }
 
+// Ordered multi-workgroup compactions (the matcher's tail: k_cross_multi, k_pairs_multi; the voxel grid's centroids): every
+// workgroup publishes the number
+// of entries it keeps in its own word (count + 1; k_match_init zeroes the words) and reads its predecessors' words as
+// they appear — device-scope relaxed atomics, no chain: a workgroup only ever waits for counts, which every workgroup
+// publishes before it waits for anything, and workgroups are dispatched in index order.  Returns the number of entries
+// in front of workgroup w, or -1 when a predecessor's word never appeared (bounded wait): the caller then writes NOTHING
+// (its offsets would be wrong) and the failure travels to the host in the counters (MC_TAILERR -> MC_NCORR = -1).
+__device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* s_red /* [5] LDS */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) __hip_atomic_store(words + w, total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int sum = 0, missing = 0;
+  for (int u = tid; u < w; u += 256) {
+    int v = 0;
+    for (unsigned polls = 0; polls < (1u << 22); ++polls) {  // (bounded: a word that never appears cannot hang the device)
+      v = __hip_atomic_load(words + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    missing |= (v == 0);  // (kept apart from the sum: any number of missing words is one flag, never an overflow)
+    sum += max(v - 1, 0);
+  }
+  sum = wave_sum_i32(sum);  // (a wave's sum stays far below 2^31: bit 31 of its word is free for the wave's flag)
+  const u32 word = (u32)sum | (__ballot(missing) ? 0x80000000u : 0u);
+  __syncthreads();  // (s_red may still be read from an earlier use)
+  if (lane == 0) s_red[wave] = (int)word;
+  __syncthreads();
+  const u32 w0 = (u32)s_red[0], w1 = (u32)s_red[1], w2 = (u32)s_red[2], w3 = (u32)s_red[3];
+  if ((w0 | w1 | w2 | w3) & 0x80000000u) return -1;
+  return (int)(((w0 & 0x7fffffffu) + (w1 & 0x7fffffffu)) + ((w2 & 0x7fffffffu) + (w3 & 0x7fffffffu)));
+}
+
+
 // Views of a batched launch that live in device memory reach the kernels through this small by-value struct (NOT a
 // bare pointer parameter and NOT a member of a large argument struct): with this shape the compiler's kernel-argument
 // promotion also marks the pointers LOADED from the view as global-memory pointers; in the other two shapes every

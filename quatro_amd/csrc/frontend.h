@@ -42,6 +42,7 @@ struct CloudBufs {
   u64* keys_a = nullptr;       // [max_points] sort ping
   u64* keys_b = nullptr;       // [max_points] sort pong
   u32* hist = nullptr;         // radix histograms / block counters
+  int* vox_look = nullptr;     // one look-back word per 1024-point tile of the voxel grid's centroid kernel
   int* nbr_cnt = nullptr;      // [max_voxels]
   int* nbr_off = nullptr;      // [max_voxels+1] CSR view (exclusive scan of nbr_cnt) for inspection
   int* nbr_idx = nullptr;      // [max_voxels][QTR_KMAX]   (strided) ... compacted copy lives in nbr_idx_c
@@ -86,6 +87,7 @@ struct CloudView {
   int seq;             // ... and that number
   int* blkcnt;
   int* blkoff;
+  int* vox_look;
   int* nbr_cnt;
   int* nbr_off;
   int* nbr_idx;
@@ -239,7 +241,7 @@ hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done = false,
                          bool prep_done = false);
 hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st,
-                              bool clear_tables = true);
+                              bool clear_tables, int* zero_words = nullptr, int n_zero = 0);  // zero_words: n_zero ints the launch clears for the caller
 hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_tgt, hipStream_t st);
 
 // The same stages for G pairs at once (qtr_submit_batch): one launch chain, the views of all pairs in device memory

@@ -365,41 +365,10 @@ __device__ __forceinline__ void vox_grid_counts(const VoxGrid& g, int* __restric
 }
 
 // heads per 1024-element block
-__device__ __forceinline__ void d_vox_headcount(const u64* __restrict__ keys, int P, int* __restrict__ blkcnt) {
-  __shared__ int s;
-  if ((long long)blockIdx.x * 1024 >= P) return;
-  if (threadIdx.x == 0) s = 0;
-  __syncthreads();
-  int c = 0;
-  const int base = blockIdx.x * 1024;
-  {
-    u32 cur[4], prev[4];  // (eight loads in flight, then the comparisons)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = min(base + q * 256 + (int)threadIdx.x, P - 1);
-      cur[q] = (u32)(keys[i] >> 32);
-      prev[q] = (u32)(keys[max(i - 1, 0)] >> 32);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = base + q * 256 + (int)threadIdx.x;
-      if (i < P) c += (i == 0) || (cur[q] != prev[q]);
-    }
-  }
-  c = wave_sum_i32(c);
-  if (qk_lane() == 0) atomicAdd(&s, c);
-  __syncthreads();
-  if (threadIdx.x == 0) blkcnt[blockIdx.x] = s;
-}
-
-// centroid per voxel: the head element of each run sums its run sequentially (float, sorted order).
-// A workgroup stages its 1024 sorted elements plus a 512-element halo (cell id + xyz, gathered through
-// the sorted index) in LDS with coalesced loads, so the dependent float additions of a run are fed from
-// LDS instead of one HBM/L2 round trip per element; only runs longer than the halo touch global memory.
 #define VOX_TILE 1024
 #define VOX_HALO 512
 __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
-                                                       int P, const int* __restrict__ blkcnt, float4* __restrict__ out,
+                                                       int P, int* __restrict__ look, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts,
                                                        int* __restrict__ mail, int* __restrict__ mail_seq_slot,
                                                        int seq) {
@@ -410,33 +379,6 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   const int lane = qk_lane(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * VOX_TILE;
   QTR_STAMP(STAMP_CENTROIDS, 0)
-  // first output slot of this tile and the voxel count of the cloud, from the per-tile head counts (a scan launch of its
-  // own between the count and this kernel cost more than every workgroup adding up a few hundred integers)
-  __shared__ int s_before[4], s_all[4];
-  int running, total;
-  {
-    int before = 0, all = 0;
-    for (int t = threadIdx.x; t < nblk; t += 256) {
-      const int c = blkcnt[t];
-      all += c;
-      before += (t < (int)blockIdx.x) ? c : 0;
-    }
-    before = wave_sum_i32(before);
-    all = wave_sum_i32(all);
-    if (lane == 0) {
-      s_before[wave] = before;
-      s_all[wave] = all;
-    }
-    __syncthreads();
-    running = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-    total = s_all[0] + s_all[1] + s_all[2] + s_all[3];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[CNT_NVOX] = total;
-  if (mail && blockIdx.x == 0 && threadIdx.x < 16) {  // this is the last voxelise kernel: hand the counters to the host
-    mail_store_line(mail, threadIdx.x, (threadIdx.x == CNT_NVOX) ? total : counts[threadIdx.x], seq);
-    __threadfence_system();
-    if (threadIdx.x == 0) *mail_seq_slot = seq;
-  }
   {
     // two rounds of independent loads (keys, then the gathered points) instead of six dependent pairs
     constexpr int NLD = (VOX_TILE + VOX_HALO) / 256;
@@ -462,6 +404,37 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
   QTR_STAMP(STAMP_CENTROIDS, 1)
   if (threadIdx.x == 0) s_p[0].w = __uint_as_float((base > 0) ? (u32)(keys[base - 1] >> 32) : 0xffffffffu);
   __syncthreads();
+  // first output slot of this tile and the voxel count of the cloud: the tile's own run heads are counted from the window
+  // that has just landed in LDS, published, and the counts of the tiles in front are added up as they appear
+  // (tail_lookback; until round 5 a launch of its own — k2_vox_headcount — counted the heads first and every workgroup
+  // of this kernel added up its table: 4.7 us + a dispatch on the chain).  The LAST tile knows the total and hands the
+  // counters to the host.
+  __shared__ int s_hc[4], s_red[5];
+  int running, total = 0;
+  {
+    int c = 0;
+#pragma unroll
+    for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
+      const int t = t0 + threadIdx.x, i = base + t;
+      c += ((i < P) && (i == 0 || __float_as_uint(s_p[t + 1].w) != __float_as_uint(s_p[t].w))) ? 1 : 0;
+    }
+    c = wave_sum_i32(c);
+    if (lane == 0) s_hc[wave] = c;
+    __syncthreads();
+    const int mine = (s_hc[0] + s_hc[1]) + (s_hc[2] + s_hc[3]);
+    running = tail_lookback(look, (int)blockIdx.x, mine, s_red);
+    total = running + mine;
+  }
+  if ((int)blockIdx.x == nblk - 1) {  // this is the last voxelise kernel: the last tile hands the counters to the host
+    if (running < 0) total = -1;      // (a tile in front never published its count: the host refuses the cloud)
+    if (threadIdx.x == 0) counts[CNT_NVOX] = total;
+    if (mail && threadIdx.x < 16) {
+      mail_store_line(mail, threadIdx.x, (threadIdx.x == CNT_NVOX) ? total : counts[threadIdx.x], seq);
+      __threadfence_system();
+      if (threadIdx.x == 0) *mail_seq_slot = seq;
+    }
+  }
+  if (running < 0) return;  // (no writes at unknown offsets)
   QTR_STAMP(STAMP_CENTROIDS, 2)
   for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
     const int t = t0 + threadIdx.x;
@@ -1430,6 +1403,7 @@ __global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds
   } else {
     const VoxGrid g = vox_grid(s_mm, side);
     if (blockIdx.x == 0 && threadIdx.x == 0) vox_grid_counts(g, C.counts);
+    if (threadIdx.x == 0) C.vox_look[blockIdx.x] = 0;  // k2_vox_centroids' look-back words ("not published yet"), one per tile
     const float4* __restrict__ pts = C.raw;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return vox_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
   }
@@ -1459,16 +1433,10 @@ __device__ __forceinline__ int sorted_src(const CloudView& C, int passes, int ad
   return done & 1;
 }
 template <bool EXT>
-__global__ __launch_bounds__(256) void k2_vox_headcount(ViewExt<CloudView> x, Clouds2 a, int src) {
-  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  if (src < 0) src = sorted_src(C, -src, 1);  // (-src = passes launched)
-  d_vox_headcount(keys_src(C, src), C.P, C.blkcnt);
-}
-template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   if (src < 0) src = sorted_src(C, -src, 1);
-  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.blkcnt, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
+  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.vox_look, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
                   C.mail_seq_slot, C.seq);
 }
 template <bool EXT>
@@ -1555,6 +1523,7 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n, int* m
   v.mail_seq_slot = mail_seq_slot;
   v.seq = seq;
   v.blkcnt = (int*)C.hist;
+  v.vox_look = C.vox_look;
   v.blkoff = v.blkcnt + (P + 1023) / 1024 + 8;
   v.nbr_cnt = C.nbr_cnt;
   v.nbr_off = C.nbr_off;
@@ -1619,7 +1588,6 @@ static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipSt
   LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 0, 1);
   const int where = radix_sort2(S, 0, 8 * passes, st, true, true, leaf, mm_parts);  // (a pass above the keys' bits returns at once)
   const int nblk = (S.maxP + 1023) / 1024;
-  LAUNCH_CV(k2_vox_headcount, S.a, dim3(nblk, nc), dim3(256), 0, st, where);
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
@@ -1762,6 +1730,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * (16 + 16 + 132 + 132);   // vox, normals, spfh, fpfh
   per_cloud += 2 * (size_t)max_points * 8;                   // keys
   per_cloud += (size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4 + 65536;  // hist
+  per_cloud += (size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4 + 256;               // vox_look
   per_cloud += (size_t)max_voxels * 4 * 2 + 64;              // nbr_cnt, nbr_off
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
@@ -1800,6 +1769,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.keys_a = (u64*)take((size_t)max_points * 8);
     C.keys_b = (u64*)take((size_t)max_points * 8);
     C.hist = (u32*)take((size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4);
+    C.vox_look = (int*)take((size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4);
     C.nbr_cnt = (int*)take((size_t)max_voxels * 4);
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);

@@ -1424,40 +1424,15 @@ __global__ __launch_bounds__(256, 2) void k_nn_exact_rows(ViewExt<MatchView> x, 
 
 // one launch instead of a handful of memsets/fills: counters, tuple-test flags, source->target table, NN tables,
 // dedup tables.  grid (g, 1, pairs)
-// Multi-workgroup compactions of the matcher's tail (k_cross_multi, k_pairs_multi): every workgroup publishes the number
-// of entries it keeps in its own word (count + 1; k_match_init zeroes the words) and reads its predecessors' words as
-// they appear — device-scope relaxed atomics, no chain: a workgroup only ever waits for counts, which every workgroup
-// publishes before it waits for anything, and workgroups are dispatched in index order.  Returns the number of entries
-// in front of workgroup w, or -1 when a predecessor's word never appeared (bounded wait): the caller then writes NOTHING
-// (its offsets would be wrong) and the failure travels to the host in the counters (MC_TAILERR -> MC_NCORR = -1).
-__device__ __forceinline__ int tail_lookback(int* words, int w, int total, int* s_red /* [5] LDS */) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) __hip_atomic_store(words + w, total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int sum = 0, missing = 0;
-  for (int u = tid; u < w; u += 256) {
-    int v = 0;
-    for (unsigned polls = 0; polls < (1u << 22); ++polls) {  // (bounded: a word that never appears cannot hang the device)
-      v = __hip_atomic_load(words + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v != 0) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    missing |= (v == 0);  // (kept apart from the sum: any number of missing words is one flag, never an overflow)
-    sum += max(v - 1, 0);
-  }
-  sum = wave_sum_i32(sum);  // (a wave's sum stays far below 2^31: bit 31 of its word is free for the wave's flag)
-  const u32 word = (u32)sum | (__ballot(missing) ? 0x80000000u : 0u);
-  __syncthreads();  // (s_red may still be read from an earlier use)
-  if (lane == 0) s_red[wave] = (int)word;
-  __syncthreads();
-  const u32 w0 = (u32)s_red[0], w1 = (u32)s_red[1], w2 = (u32)s_red[2], w3 = (u32)s_red[3];
-  if ((w0 | w1 | w2 | w3) & 0x80000000u) return -1;
-  return (int)(((w0 & 0x7fffffffu) + (w1 & 0x7fffffffu)) + ((w2 & 0x7fffffffu) + (w3 & 0x7fffffffu)));
-}
-
+// (tail_lookback — the look-back over per-workgroup counts the multi-workgroup compactions of the tail use — lives in common.h)
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one, int clear_tables) {
+__global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchView one, int clear_tables, int* zero_words,
+                                                    int n_zero) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  // (a caller's own clean slate rides along: the whole-path driver's solver state — a 4.6 us launch of its own until round 5)
+  if (zero_words && blockIdx.x == gridDim.x - 1 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0;
   if (gid < 16) V.mcounts[gid] = (gid == MC_SWAPPED) ? V.swapped : (gid == MC_NQ0) ? V.n_small : 0;
   const int pv = V.tuple ? 0 : 1;
   const int np = V.crosscheck ? V.n_small : V.n_small + V.n_large;
@@ -2304,7 +2279,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   }
   const dim3 B256(256);
   if (!init_done)
-    LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st, prep_done ? 0 : 1);
+    LAUNCH_MV(k_match_init, a, dim3(grid_for(max(max_large, views[0].dd_mask + 1)), 1, G), B256, 0, st, prep_done ? 0 : 1, (int*)nullptr, 0);
   // K5: NN of every small-cloud descriptor in the large cloud, then of the HIT rows of the large cloud in the small
   // one (the reference asks the latter lazily, feature_matcher.cc:113-122; the mutual test only reads hit rows)
 #ifdef QTR_TEST_ENGINES
@@ -2463,12 +2438,13 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   return hipGetLastError();
 }
 
-hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool clear_tables) {
+hipError_t match_init_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool clear_tables,
+                              int* zero_words, int n_zero) {
   (void)hipGetLastError();
   MatchArgs a;
   a.one = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
   a.ext = nullptr;
-  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(a.one.n_large, a.one.dd_mask + 1)), 1, 1), dim3(256), 0, st, clear_tables ? 1 : 0);
+  LAUNCH_MV(k_match_init, a, dim3(grid_for(max(a.one.n_large, a.one.dd_mask + 1)), 1, 1), dim3(256), 0, st, clear_tables ? 1 : 0, zero_words, n_zero);
   return hipGetLastError();
 }
 hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params& fp, hipStream_t st, bool init_done,

@@ -196,7 +196,8 @@ def load(path: str | None = None):
                                      C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.qtr_set_batch_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qtr_get_stage_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(StageTimes)]
-    lib.qtr_get_nn_dir_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if hasattr(lib, "qtr_get_nn_dir_times"):
+        lib.qtr_get_nn_dir_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.qtr_set_stage_events.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_set_nn_event_stride.argtypes = [C.c_void_p, C.c_int]
     lib.qtr_get_nn_totals.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
@@ -683,7 +684,8 @@ class Handle:
         self._lib.qtr_get_stage_times(self._h, slot, C.byref(t))
         out = {n: getattr(t, n) for n, _ in StageTimes._fields_}
         d1, d2 = C.c_float(), C.c_float()
-        self._lib.qtr_get_nn_dir_times(self._h, slot, C.byref(d1), C.byref(d2))
+        if hasattr(self._lib, "qtr_get_nn_dir_times"):  # (QTR_LIB may name an older build of the library: A/B runs)
+            self._lib.qtr_get_nn_dir_times(self._h, slot, C.byref(d1), C.byref(d2))
         out["nn_dir1"], out["nn_dir2"] = d1.value, d2.value  # the two nearest-neighbour launches behind nn_kernel apart
         return out
 
