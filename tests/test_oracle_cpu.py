@@ -1235,3 +1235,21 @@ def test_shared_math_header_against_an_independent_libm(qo):
         d = np.where((got == 0) & (want == 0), 0, d)
         assert d.max() <= 1, (name, int(d.max()))
         assert (d > 0).mean() <= 1e-6, (name, int((d > 0).sum()))
+
+
+def test_dense_scene_pair_is_deterministic_and_what_its_docstring_says():
+    """synth.dense_scene_pair (BASELINE configs[4]'s registering input): same seed, same clouds; the two clouds share no
+    sample point (independent samplings of one scene); the surface density puts a few dozen neighbours inside r = 0.75 m
+    and none of the neighbour lists overflows QTR_KMAX = 256; tgt ~ T @ src as SURFACES (nearest-surface distance after
+    un-doing T stays within the sampling spacing)."""
+    import scipy.spatial as sp
+    n = 6000
+    a, b, T = synth.dense_scene_pair(n, seed=11)
+    a2, b2, T2 = synth.dense_scene_pair(n, seed=11)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2) and np.array_equal(T, T2)
+    assert a.shape == (n, 4) and a.dtype == np.float32 and np.all(a[:, 3] == 0)
+    back = (b[:, :3].astype(np.float64) - T[:3, 3]) @ T[:3, :3]          # T^-1 applied to the target
+    d, _ = sp.cKDTree(a[:, :3]).query(back)
+    assert np.median(d) > 0.02 and np.percentile(d, 99) < 1.0           # different sample points of the same surfaces
+    cnt = sp.cKDTree(a[:, :3]).query_ball_point(a[:, :3], 0.75, return_length=True)
+    assert 15 < np.median(cnt) < 60 and cnt.max() < 256
