@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
 //     handful of items costs as much as a full one;
 //   * many (a group of pairs): items of ~1/8 of a workgroup's share, handed out through an atomic counter, so that
 //     pairs of different size and the ragged last round cost a few per cent instead of a third of the launch.
-// Evaluated by wave 0 of every workgroup (of this kernel and of k_nn_finish, which has to find the same slicing) from
+// Evaluated by wave 0 of every workgroup (of this kernel and of the f32 engine's k_nn_finish, which has to find the same
+// slicing; k_nn_f16 leaves its slicing in the counter line for k_nn_finish_f16) from
 // the device-side query counts of all pairs; results in LDS.  Written as a macro on purpose: the kernel-argument
 // structs must not travel by reference (see ViewExt).
 // a / b for a < 2^22, b >= 1: a float quotient and one correction step each way instead of the ~40-instruction integer
@@ -506,14 +507,15 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 // (the second alternative covers a subnormal x2, whether or not the hardware flushes it), S = 128 for base rows, -2S for
 // queries, and a.b ~ sum (b1 q1 + b2 q1 + b1 q2): 3 x 33 products, plus three slots that carry nb' = c1 + c2 + c3 (f16
 // pieces) against the constant S^2 = 16384: K = 102, padded to 112 = 7 MFMAs per accumulator instead of 17 at half the
-// issue time — 896 clocks of matrix work per tile instead of 4352, with the 3-VALU-per-value fold riding under it.
+// issue time — 896 clocks of matrix work per tile instead of 4352, with the top-2 fold riding under it (rounds 2-4: three
+// vector instructions per value; round 5: ~1.8, see gen_nn_f16_core.py).
 // Every product of two f16 numbers is exact in f32; the accumulation inside and across the 7 MFMAs was measured at
 // <= 5.5 u sum|terms| on adversarial exponents (3.0 u on histogram-like data; same probe) and is budgeted at 16 u.
 //
 // Rounding bound, unscaled (u = 2^-24):  |V / S^2 - (nb' - 2 a.b)| <=
 //     12.1u (|a|^2 + |b|^2)   dropped products b2 q2, db q, b dq (3 x 2^-22 |b^ q^| each, Cauchy-Schwarz)
 //   + 16.1u (|a|^2 + 2|b|^2)  accumulation, sum|terms| / S^2 <= nb' + 2|a||b| (1 + 2^-10)
-//   + 32u   (|a|^2 + 2|b|^2)  the accumulator-register index in the four low mantissa bits
+//   + 32u   (|a|^2 + 2|b|^2)  the accumulator-register index in the four low mantissa bits (rounds 2-4 only, see below)
 //   + 8u (33 + |a|^2) + 4u (33 + |b|^2)   subnormal second halves: 2^-14 (sum|q^| + sum|b^|) / S^2, |x| <= (1 + x^2)/2
 //   <= 69u |a|^2 + 114u |b|^2 + 396u
 // against 66u |a|^2 + 132u |b|^2 of the f32 chain: the same certification inequality holds with + 800u on the right-hand
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 // near-identical descriptors with |b|^2 = 30000) were waiting for.  The re-check's threshold follows: v1 + u (76 |a|^2 +
 // 108 |b1|^2 + 80 d~1 + 800).  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
 // -256 x) and every |b|^2 < 65000 (f16 range of the norm pieces); a pair that violates them (not an FPFH descriptor:
-// those are bounded by 100) sets MC_UNSAFE and k_nn_finish sends all of its rows to the exact re-check.
+// those are bounded by 100) sets MC_UNSAFE and k_nn_finish_f16 sends all of its rows to the exact re-check.
 // Hidden / pad rows carry 3 x 65504 in the norm slots (196512 > any real nb').
 //
 // Operand layout (both operands): 32 rows form a tile; a row's 112 halves are cut into 14 chunks of 8 (chunk 2m+g is
@@ -810,8 +812,9 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
   }
 }
 
-// Merge the per-slice partials and decide each query: certified (see the header comment) or listed for the exact
-// re-check.  X = gridDim.x of the k_nn_mfma launch it follows.  grid (ceil(nq_max/256), 1, pairs).
+// The f32 MFMA engine's finish (test build: the product's f16 engine has k_nn_finish_f16 below).  Merge the per-slice
+// partials and decide each query: certified (see the header comment) or listed for the exact re-check.  X = gridDim.x of
+// the k_nn_mfma launch it follows.  grid (ceil(nq_max/512), 1, pairs).
 #define NN_FIN_THREADS 512
 template <bool EXT>
 __global__ __launch_bounds__(NN_FIN_THREADS) void k_nn_finish(ViewExt<MatchView> x, MatchView one, int dir, int X, int G,
