@@ -20,7 +20,7 @@ enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW =
 // for the rows of the larger cloud that some row of the smaller cloud points at); MC_HIDDEN_I / _J: descriptor rows
 // hidden from the base tables because a lower row holds the bit-identical descriptor
 enum { MC_NCORR = 0, MC_HIDDEN_I = 1, MC_HIDDEN_J = 2, MC_NCROSS = 3, MC_NTUPLE = 4, MC_SWAPPED = 5, MC_NQ0 = 6, MC_NHIT = 7,
-       MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_NSPLIT0 = 10, MC_NSPLIT1 = 11 /* slices per query block of the two k_nn_f16 launches */,
+       MC_RECHECK0 = 8, MC_RECHECK1 = 9, MC_NSPLIT0 = 10, MC_NSPLIT1 = 11 /* plan words of the two k_nn_f16 launches: slices per query block | base tiles per slice << 8 */,
        MC_UNSAFE = 12,
        MC_TAILERR = 13 /* a multi-workgroup compaction of the tail gave up waiting for a predecessor's count */ };
 

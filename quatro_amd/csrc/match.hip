@@ -340,17 +340,45 @@ __global__ __launch_bounds__(256) void k_norm_gather(ViewExt<MatchView> x, Match
 // the device-side query counts of all pairs; results in LDS.  Written as a macro on purpose: the kernel-argument
 // structs must not travel by reference (see ViewExt).
 // a / b for a < 2^22, b >= 1: a float quotient and one correction step each way instead of the ~40-instruction integer
-// division (the work-item arithmetic of the nearest-neighbour kernels sits in front of their first load)
-__device__ __forceinline__ u32 fast_udiv(u32 a, u32 b) {
-  if (a >> 22) return a / b;
-  u32 q = (u32)((float)a * __frcp_rn((float)b));
+// division (the work-item arithmetic of the nearest-neighbour kernels sits in front of their first load, and a kernel's
+// first pass over its code is paced by instruction fetch: every instruction less there is time).  v_rcp_f32 is good to
+// 1 ulp: the float quotient is within 0.75 of a / b, its truncation within one of the answer.
+__device__ __forceinline__ u32 fast_udiv_small(u32 a, u32 b) {
+  u32 q = (u32)((float)a * __builtin_amdgcn_rcpf((float)b));
   if (q * b > a) --q;
   if ((q + 1) * b <= a) ++q;
   return q;
 }
+__device__ __forceinline__ u32 fast_udiv(u32 a, u32 b) {
+  if (a >> 22) return a / b;
+  return fast_udiv_small(a, b);
+}
+// The plan of a single pair's k_nn_f16 launch (what NN_PLAN below computes for a group of pairs): slices per query block
+// and base tiles per slice, packed (slices | tiles << 8) as MC_NSPLITx holds them.  qb query blocks, nt base tiles, X
+// workgroups.  The host runs it for direction 0 (it knows both clouds' sizes), k_hit_compact for direction 1 (it has
+// just counted the hit rows): the search kernel then opens with two scalar loads instead of ~350 instructions.
+__host__ __device__ inline int nn_plan_single(int qb, int nt, int X) {
+  int sp;
+  if (qb <= X) {
+    sp = X / (qb > 1 ? qb : 1);
+  } else {
+    int T = (qb * nt + X * 8 - 1) / (X * 8);
+    if (T < 64) T = 64;
+    sp = (nt + T - 1) / T;
+  }
+  if (sp > NN_MAXSPLIT) sp = NN_MAXSPLIT;
+  if (sp > nt) sp = nt;
+  if (sp < 1) sp = 1;
+  const int tps = (nt + sp - 1) / sp;
+  sp = (nt + tps - 1) / tps;
+  return sp | (tps << 8);
+}
 #define NN_MAXG 64
-#define NN_PLAN(G_, dir_, X_)                                                                                   \
-  __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG], s_nq[NN_MAXG];                              \
+#define NN_PLAN_DECL __shared__ int s_off[NN_MAXG + 1], s_ns[NN_MAXG], s_tps[NN_MAXG], s_nq[NN_MAXG];
+#define NN_PLAN(G_, dir_, X_) \
+  NN_PLAN_DECL                \
+  NN_PLAN_BODY(G_, dir_, X_)
+#define NN_PLAN_BODY(G_, dir_, X_)                                                                              \
   if (threadIdx.x < 64) {                                                                                       \
     const int g_ = threadIdx.x;                                                                                 \
     int qb_ = 0, nt_ = 1, nq_ = 0;                                                                              \
@@ -680,17 +708,35 @@ extern "C" int qtr_debug_stamps(unsigned long long* out) {  // [QTR_STAMP_KERNEL
 #define NN_STAMP(i)
 #endif
 template <bool EXT>
-__global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G, int la) {
+__global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchView one, int dir, int G, int la, int plan) {
   NN_STAMP(0)
-  NN_PLAN(G, dir, (int)gridDim.x)
+  NN_PLAN_DECL
+  // A group of pairs plans in the kernel (NN_PLAN).  A single pair's plan is one word (see nn_plan_single): `plan` from
+  // the host (direction 0), or, plan < 0, the word k_hit_compact left beside its count of hit rows (direction 1).
+  int u_ns = 1, u_tps = 1, u_nq = 0, u_qb = 0;
+  if constexpr (EXT) {
+    NN_PLAN_BODY(G, dir, (int)gridDim.x)
+    // the slicing the plan decided, for k_nn_finish_f16 (which then needs neither the plan nor its barrier)
+    if (blockIdx.x == 0 && threadIdx.x < G) x.ext[threadIdx.x].mcounts[MC_NSPLIT0 + dir] = s_ns[threadIdx.x] | (s_tps[threadIdx.x] << 8);
+  } else {
+    int w = plan;
+    u_nq = one.n_small;
+    if (plan < 0) {
+      w = one.mcounts[MC_NSPLIT0 + dir];
+      u_nq = one.mcounts[one.d[dir].nq_slot];
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+      one.mcounts[MC_NSPLIT0 + dir] = w;
+    }
+    u_ns = w & 0xff;
+    u_tps = w >> 8;
+    u_qb = (u_nq + NN_QPB - 1) / NN_QPB;
+  }
   NN_STAMP(1)
-  // the slicing the plan decided, for k_nn_finish_f16 (which then needs neither the plan nor its barrier)
-  if (blockIdx.x == 0 && threadIdx.x < G) (EXT ? x.ext[threadIdx.x] : one).mcounts[MC_NSPLIT0 + dir] = s_ns[threadIdx.x];
   __shared__ int s_item;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   int* counter = (EXT ? x.ext[0].mcounts : one.mcounts) + 14 + dir;  // zeroed by k_match_init
-  const int total = s_off[G];
+  const int total = EXT ? s_off[G] : u_qb * u_ns;
   // the first item of a workgroup is its own index, later ones come from the counter (which therefore counts from
   // gridDim.x on): a launch with no more items than workgroups — every single-pair launch — never touches it, and nobody
   // waits for an atomic's round trip before the first load
@@ -705,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     // of the base, 8 x (Q / 2 + B / 4).  (Round 5: 4 x 2 — a quarter of the query blocks, half of the base — measured a
     // microsecond faster per launch: the launch opens with every workgroup fetching its 114 KB of query fragments at
     // once, and four instead of two of the eight workgroups that share a query block then share an L2.)
-    const bool dealt = G == 1 && total <= (int)gridDim.x && (gridDim.x & 7) == 0;
+    const bool dealt = !EXT && total <= (int)gridDim.x && (gridDim.x & 7) == 0;
     int cell = item;
     if (dealt) {
       const int per = (total + 7) >> 3, j = item >> 3;
@@ -713,19 +759,20 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
     }
     if (cell >= total) break;
     int g = 0;
-    while (g + 1 < G && cell >= s_off[g + 1]) ++g;
+    if constexpr (EXT)
+      while (g + 1 < G && cell >= s_off[g + 1]) ++g;
     const MatchView& V = EXT ? x.ext[g] : one;  // (inline on purpose: see ViewExt)
     const NnDir& D = V.d[dir];
     const int ntiles = D.nb_pad / 32;
-    const int nsplit = s_ns[g], tps = s_tps[g];
+    const int nsplit = EXT ? s_ns[g] : u_ns, tps = EXT ? s_tps[g] : u_tps;
     NnPartial* __restrict__ partial = V.partial;
-    const int local = cell - s_off[g];
+    const int local = EXT ? cell - s_off[g] : cell;
     int qb, slice;
     if (dealt) {
       // (which rectangle: subtractions; ONE division — the eight of the unrolled form were a microsecond of every launch)
       // (2^la x 2^(3-la) rectangles; la = 1 is the 2 x 4 cut described above)
       const int lb = 3 - la;
-      const int nqb = (int)fast_udiv((u32)total, (u32)nsplit);
+      const int nqb = u_qb;
       const int qh = (nqb + (1 << la) - 1) >> la, sq = (nsplit + (1 << lb) - 1) >> lb;
       int rem = cell, q0 = 0, s0 = 0, cols = 1;
       bool found = false;
@@ -742,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
         }
         if (!found) rem -= cells;
       }
-      const int qd = (int)fast_udiv((u32)rem, (u32)cols);
+      const int qd = (int)fast_udiv_small((u32)rem, (u32)cols);  // (rem < total <= gridDim.x)
       qb = q0 + qd;
       slice = s0 + rem - qd * cols;
     } else {
@@ -759,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
       // a list of rows needs no gathered copy of the table); columns past the list take row 0, nobody reads their result
       u32 qoff[4];
       {
-        const int nq = s_nq[g];  // (the plan read it)
+        const int nq = EXT ? s_nq[g] : u_nq;  // (the plan read it)
         const int* __restrict__ qmap = D.qmap;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -942,7 +989,7 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
   if ((int)blockIdx.x * NN_FINH_Q >= nq) return;
   QTR_STAMP(STAMP_NN_FINISH, 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nsplit = V.mcounts[MC_NSPLIT0 + dir];  // (k_nn_f16 left it there)
+  const int nsplit = V.mcounts[MC_NSPLIT0 + dir] & 0xff;  // (the plan word of the k_nn_f16 launch: slices | tiles per slice << 8)
   const bool unsafe = V.mcounts[MC_UNSAFE] != 0;   // descriptor values outside the f16 engine's range: everything is re-checked
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
@@ -1459,7 +1506,7 @@ __global__ __launch_bounds__(256) void k_match_init(ViewExt<MatchView> x, MatchV
 // tables by row.  bin_order = 0 — the f16 engine, whose re-check sweeps every tile — lists them by row.)
 // grid (1, 1, pairs), 1024 threads.
 template <bool EXT>
-__global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one, int bin_order) {
+__global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, MatchView one, int bin_order, int nn_X) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   extern __shared__ u32 hit_bits[];  // ceil(n_large / 32) words
   __shared__ int wsum[16];
@@ -1519,7 +1566,11 @@ __global__ __launch_bounds__(1024) void k_hit_compact(ViewExt<MatchView> x, Matc
       }
     }
   }
-  if (tid == 0) V.mcounts[MC_NHIT] = total;
+  if (tid == 0) {
+    V.mcounts[MC_NHIT] = total;
+    // (single pair, nn_X = workgroups of the k_nn_f16 launch that asks for these rows: its plan, see nn_plan_single)
+    if (nn_X > 0) V.mcounts[MC_NSPLIT1] = nn_plan_single((total + NN_QPB - 1) / NN_QPB, V.d[1].nb_pad / 32, nn_X);
+  }
   QTR_STAMP(STAMP_HIT_COMPACT, 2)
 }
 
@@ -2301,7 +2352,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     if (ev && ev[0]) (void)hipEventRecord(ev[0], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_small + 255) / 256, nsplit(max_small, max_large), G), B256, 0, st, 0);
     if (ev && ev[1]) (void)hipEventRecord(ev[1], st);
-    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, 1);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, 1, 0);
     if (ev && ev[2]) (void)hipEventRecord(ev[2], st);
     LAUNCH_MV(k_nn_exact, a, dim3((max_large + 255) / 256, nsplit(max_large, max_small), G), B256, 0, st, 1);
     if (ev && ev[3]) (void)hipEventRecord(ev[3], st);
@@ -2344,14 +2395,16 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
       return !(e && strcmp(e, "record") == 0);
     }();
     auto run_dir = [&](int dir, int nq_max, int nb_max, hipEvent_t e0, hipEvent_t e1) {
+      // a single pair's plan: direction 0 here, direction 1 by k_hit_compact (see nn_plan_single)
+      const int plan = (G == 1 && dir == 0) ? nn_plan_single((views[0].n_small + NN_QPB - 1) / NN_QPB, views[0].d[0].nb_pad / 32, X) : -1;
       if (e0 && e1 && attach_events) {
-        if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G, nn_deal);
+        if (f16) LAUNCH_MV_EV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G, nn_deal, plan);
 #ifdef QTR_TEST_ENGINES
         else LAUNCH_MV_EV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, e0, e1, dir, G);
 #endif
       } else {
         if (e0) (void)hipEventRecord(e0, st);
-        if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G, nn_deal);
+        if (f16) LAUNCH_MV(k_nn_f16, a, dim3(X, 1, 1), B256, 0, st, dir, G, nn_deal, plan);
 #ifdef QTR_TEST_ENGINES
         else LAUNCH_MV(k_nn_mfma, a, dim3(X, 1, 1), B256, 0, st, dir, G);
 #endif
@@ -2379,7 +2432,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
 #endif
     };
     run_dir(0, max_small, max_large, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, f16 ? 0 : 1);
+    LAUNCH_MV(k_hit_compact, a, dim3(1, 1, G), dim3(1024), (size_t)((max_large + 31) / 32) * 4, st, f16 ? 0 : 1,
+              (f16 && G == 1) ? X : 0);
 #ifdef QTR_TEST_ENGINES
     if (!f16) LAUNCH_MV(k_hit_gather, a, dim3(max_pad / 256, 1, G), B256, 0, st, 1);  // (f16: the rows are read in place)
 #endif
