@@ -80,6 +80,7 @@ typedef float gb_f2 __attribute__((ext_vector_type(2)));
 #define HCA_CTL_ITERS 3    // [HCA_CTL_VER + w] version counters, [HCA_CTL_DONE + w] marks  (w < HCA_MAXWG)
 #define HCA_CTL_FLOOR 4    // [4] (floor << 1) | decided: values below the floor are not lowered any further,
 #define HCA_CTL_FROZE 5    // [5] some row was actually left alone for that reason
+#define HCA_CTL_FLOOR2 6   // [6] (floor << 1) | 1 from the scout workgroup (a clique it FOUND, see hca_scout): may arrive at any time
 #define HCA_FLOOR_MIN 8
 #define HCA_MAXWG 512      // (one workgroup per compute unit: 256 on this part)
 #define HCA_CTL_VER 64
@@ -758,6 +759,164 @@ __device__ __forceinline__ unsigned hca_load_u32(const unsigned* p) {
 __device__ __forceinline__ u64 hca_load_u64(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The scout: one more workgroup of a single pair's launch on a large graph (8192 < L <= 32768), which owns no rows and
+// takes no part in the termination protocol.  The floor H / 2 above is a bet on the degree sequence and stays away where
+// the h-index of the degrees does not stand clear of their mean — the generator's graphs with 2 % planted at L = 20000
+// (bulk: a 198-core with degrees up to 591; clique 400; fifty iterations, 380 us) among them.  A floor that is no bet on
+// the graph's shape: the size of a clique somebody has SEEN.  The scout takes the values as they stand once every degree
+// is published, keeps the (at most) HCA_SCOUT_M vertices with the largest ones, copies their sub-matrix into LDS (a wave
+// per row: the row staged, one ballot per 64 columns) and peels it — every round the alive vertices count their alive
+// neighbours, all of equal count n - 1 is a clique, otherwise those within an eighth of the range above the minimum go.
+// On the generator's graphs the planted clique is what is left after eight rounds (tests/probe/scout_sim.py: 1 - 3 %
+// planted at L = 10000 / 20000, from the degrees or after one to three iterations; nothing planted: no clique of sixteen,
+// no floor).  A clique of s vertices puts s - 1 - s / 8 into HCA_CTL_FLOOR2 (its members' core numbers are >= s - 1; the
+// eighth is slack for a search that finds a little less than the scout did).  The iterating workgroups look at that word
+// once per iteration and raise their floor: values already below it stop, whatever they were; values at or above it go on
+// to their exact core numbers (the argument at "the floor" in k_hcore_async does not ask WHEN a value below the floor
+// stopped, only that it is an upper bound below the floor).  k_rank_sort starts the search from the larger of the two
+// floors; a search that comes back empty-handed sends the stage round again without any floor, as before.
+#define HCA_SCOUT_M 768
+__device__ __forceinline__ void hca_scout(const u64* __restrict__ bm, int Wb, int W, int L, unsigned* ctl, const unsigned short* gvals,
+                          unsigned char* lds, size_t lds_bytes, unsigned* s_hist /* [HCA_THREADS], the kernel's */,
+                          unsigned long long t_start) {
+  constexpr int T = HCA_THREADS, MWX = HCA_SCOUT_M / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ unsigned short s_cand[HCA_SCOUT_M];
+  __shared__ u64 s_alive[MWX];
+  __shared__ int s_red[4][T / 64];
+  __shared__ int s_flag, s_m;
+  const int Lp = (L + 63) & ~63;
+  if ((size_t)2 * Lp > lds_bytes) return;
+  unsigned short* vals = (unsigned short*)lds;
+  // every vertex's degree (or what its owner has made of it since): snapshots until none is missing
+  while (true) {
+    bool open = false;
+    for (int i = tid; i < (Lp >> 2); i += T) {
+      const u64 nv = hca_load_u64((const u64*)gvals + i);
+      ((u64*)vals)[i] = nv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) open = open || (4 * i + k < L && ((nv >> (16 * k)) & 0xffffu) == 0xffffu);
+    }
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    if (__any(open) && lane == 0) atomicOr(&s_flag, 1);
+    if (tid == 0 && wall_clock64() - t_start > 20000ull) atomicOr(&s_flag, 2);  // (200 us: somebody is not resident)
+    __syncthreads();
+    const int fl = s_flag;
+    __syncthreads();
+    if (!(fl & 1)) break;
+    if (fl & 2) return;
+  }
+  // theta = the smallest value with at most HCA_SCOUT_M vertices at or above it (values clamped to T - 1: a graph whose
+  // top values are all beyond that has no use for a floor the scout could find)
+  s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < L; i += T) atomicAdd(&s_hist[min((int)vals[i], T - 1)], 1u);
+  __syncthreads();
+  int theta, m;
+  {
+    const int mine_h = (int)s_hist[tid];
+    int wtot = 0;
+    const int below_incl = wave_excl_scan_i32(mine_h, &wtot) + mine_h;
+    if (lane == 0) s_red[0][wave] = wtot;
+    __syncthreads();
+    int above = 0;
+#pragma unroll
+    for (int q = 0; q < T / 64; ++q) above += q > wave ? s_red[0][q] : 0;
+    const int cnt_ge = above + (wtot - below_incl) + mine_h;  // #{values >= tid}
+    const int t_ok = (tid >= 2 && cnt_ge <= HCA_SCOUT_M) ? tid : T;
+    const int wmin = wave_min_i32(t_ok);
+    __syncthreads();
+    if (lane == 0) s_red[1][wave] = wmin;
+    __syncthreads();
+    theta = T;
+#pragma unroll
+    for (int q = 0; q < T / 64; ++q) theta = min(theta, s_red[1][q]);
+    if (theta >= T - 1) return;
+    if (tid == theta) s_m = cnt_ge;
+    __syncthreads();
+    m = s_m;
+    if (m < 16) return;
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+  }
+  for (int i = tid; i < L; i += T)
+    if ((int)vals[i] >= theta) s_cand[atomicAdd(&s_m, 1)] = (unsigned short)i;
+  __syncthreads();  // (vals is spent: the sub-matrix takes its place)
+  const int MW = (m + 63) >> 6;
+  u64* sub = (u64*)lds;  // [m][MW]
+  const size_t sub_bytes = (((size_t)m * MW * 8) + 15) & ~(size_t)15;
+  if (sub_bytes + (size_t)(T / 64) * W * 8 > lds_bytes || W > 512) return;
+  {
+    u64* stage = (u64*)(lds + sub_bytes) + (size_t)wave * W;  // this wave's copy of one row of the graph
+    int cid[MWX];
+#pragma unroll
+    for (int k = 0; k < MWX; ++k) cid[k] = (64 * k + lane < m) ? (int)s_cand[64 * k + lane] : -1;
+    // (the next row's words are on their way — in registers — while this one's ballots run: a wave alone would otherwise
+    // sit out a memory round trip per row, 48 rows deep)
+    constexpr int WPL = 8;  // words of a row per lane: W <= 512
+    u64 nxt[WPL];
+    auto fetch = [&](int r) __attribute__((always_inline)) {
+      const u64* rowp = bm + (size_t)s_cand[r] * Wb;
+#pragma unroll
+      for (int q = 0; q < WPL; ++q) nxt[q] = (lane + 64 * q < W) ? rowp[lane + 64 * q] : 0ULL;
+    };
+    if (wave < m) fetch(wave);
+    for (int r = wave; r < m; r += T / 64) {
+#pragma unroll
+      for (int q = 0; q < WPL; ++q)
+        if (lane + 64 * q < W) stage[lane + 64 * q] = nxt[q];
+      if (r + T / 64 < m) fetch(r + T / 64);
+#pragma unroll
+      for (int k = 0; k < MWX; ++k)
+        if (k < MW) {
+          const bool bit = cid[k] >= 0 && ((stage[cid[k] >> 6] >> (cid[k] & 63)) & 1ULL) != 0;
+          const u64 wd = __ballot(bit);
+          if (lane == 0) sub[(size_t)r * MW + k] = wd;
+        }
+    }
+  }
+  bool alive = tid < m;
+  {
+    const u64 b = __ballot(alive);
+    if (lane == 0 && wave < MWX) s_alive[wave] = b;
+  }
+  __syncthreads();
+  int clique = 0;
+  for (int round = 0; round < 512; ++round) {
+    int d = 0;
+    if (alive)
+      for (int k = 0; k < MW; ++k) d += __popcll(sub[(size_t)tid * MW + k] & s_alive[k]);
+    const int wmn = wave_min_i32(alive ? d : 0x7fffffff), wmx = wave_max_i32(alive ? d : -1), wn = wave_sum_i32(alive ? 1 : 0);
+    if (lane == 0) {
+      s_red[0][wave] = wmn;
+      s_red[1][wave] = wmx;
+      s_red[2][wave] = wn;
+    }
+    __syncthreads();
+    int mn = 0x7fffffff, mx = -1, n = 0;
+#pragma unroll
+    for (int q = 0; q < T / 64; ++q) {
+      mn = min(mn, s_red[0][q]);
+      mx = max(mx, s_red[1][q]);
+      n += s_red[2][q];
+    }
+    if (n < 16) break;
+    if (mn == n - 1) {
+      clique = n;
+      break;
+    }
+    const int thr = mn + ((mx - mn) >> 3);
+    alive = alive && d > thr;
+    __syncthreads();  // (everybody has read the masks and the partial results of this round)
+    const u64 b = __ballot(alive);
+    if (lane == 0 && wave < MWX) s_alive[wave] = b;
+    __syncthreads();
+  }
+  const int f2 = clique - 1 - (clique >> 3);
+  if (clique >= 16 && f2 >= HCA_FLOOR_MIN && tid == 0)
+    __hip_atomic_store(ctl + HCA_CTL_FLOOR2, ((unsigned)f2 << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // (the clean slate for graphs that were handed in as bit matrices; k_graph_build prepares its own, see there)
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_hcore_async_init(ViewExt<SolverView> x, SolverView one) {
@@ -772,7 +931,9 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const int L = V.L, W = V.W;
   if (L <= 0) return;
-  const int NWG = gridDim.x, w = blockIdx.x;
+  // (allow_floor = 2: the last workgroup of the launch is the scout, see hca_scout)
+  const bool has_scout = allow_floor == 2;
+  const int NWG = (int)gridDim.x - (has_scout ? 1 : 0), w = blockIdx.x;
   const unsigned long long t_start = wall_clock64();
   const int R = (L + NWG - 1) / NWG, Rp = (R + 3) & ~3;
   const int r_lo = min(L, w * R), r_hi = min(L, r_lo + R), nown = r_hi - r_lo;
@@ -790,6 +951,11 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   int* mine = (int*)lp;  // [Rp] my rows' current values (what I stored last)
   lp += (size_t)4 * Rp;
   unsigned short* pool = (unsigned short*)lp;  // [pool_entries] neighbour ids of my rows, row after row
+  __shared__ unsigned s_hist[HCA_THREADS];
+  if (has_scout && w == NWG) {
+    hca_scout(bm, V.Wb, W, L, (unsigned*)V.perm, gvals, hca_lds, (size_t)(lp - hca_lds) + (size_t)2 * pool_entries, s_hist, t_start);
+    return;
+  }
   __shared__ unsigned s_sum[HCA_THREADS / 64];
   // "does any thread of the workgroup ...": ONE barrier per vote.  (__syncthreads_or / _and compile to three — the flag
   // is initialised, or-ed and read between barriers of its own — and an iteration takes two votes: six barriers of sixteen
@@ -851,7 +1017,6 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   __shared__ unsigned s_floor;
   __shared__ int s_froze;
   __shared__ int s_hcnt[2][HCA_THREADS / 64];
-  __shared__ unsigned s_hist[HCA_THREADS];
   if (tid == 0) s_froze = 0;  // (barriers follow before anybody evaluates a row)
   int my_floor = 0;            // (uniform)
   if (allow_floor) {
@@ -1125,8 +1290,14 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     }
     // (every load above has returned, so the value stores of the previous iteration — issued before them — have reached
     // the coherence point as well: only now may the version say so)
+    // (the scout's floor, if it has one by now: thread 0's load rides with the snapshot's, the vote's barrier hands it round)
+    if (has_scout && tid == 0) s_floor = hca_load_u32((const unsigned*)V.perm + HCA_CTL_FLOOR2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const bool any_moved = wg_any(moved);
+    if (has_scout) {
+      const unsigned f2 = __builtin_amdgcn_readfirstlane(s_floor);
+      if (f2 & 1u) my_floor = max(my_floor, (int)(f2 >> 1));
+    }
     if (bump && tid == 0) __hip_atomic_store(ver + w, ++myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bump = false;
     HCA_MARK(1);
@@ -1550,7 +1721,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
     __shared__ int s_red[2][RS_THREADS / 64];
     const int failed = V.perm[HCA_CTL_FAILED], iters = V.perm[HCA_CTL_ITERS];  // (perm is overwritten further down)
     // the floor counts only if some value was in fact left standing below it (and the iteration itself went through)
-    const int floor_w = V.perm[HCA_CTL_FLOOR], froze = V.perm[HCA_CTL_FROZE];
+    const int floor_w = V.perm[HCA_CTL_FLOOR], froze = V.perm[HCA_CTL_FROZE], floor2_w = V.perm[HCA_CTL_FLOOR2];
     int mx = 0, es = 0;
     if (!failed)
       for (int v = tid; v < L; v += RS_THREADS) {
@@ -1576,7 +1747,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
         st->ub = mx + 1;
         st->pad[0] = iters;  // statistics: iterations of the slowest workgroup
         s_nb = mx + 1;
-        s_cf = froze ? (floor_w >> 1) : 0;
+        s_cf = froze ? max(floor_w >> 1, floor2_w >> 1) : 0;  // (the bet's floor or the scout's: whatever anybody stopped below)
       } else {
         s_nb = st->max_core + 1;
         s_cf = 0;  // (the peeling workgroup's numbers are exact)
@@ -3565,6 +3736,26 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         // one resident workgroup per compute unit at most (they wait for one another); a group of pairs shares the device
         int nwg = min(min(hca_max_workgroups(), HCA_MAXWG), max(1, (L + 15) / 16));
         nwg = max(1, min(nwg, hca_max_workgroups() / t_hca_share));
+        static const bool no_floor = [] {  // (QTR_HCORE_FLOOR=0: comparison runs of the test build)
+          const char* e = QTR_ENGINE_ENV("QTR_HCORE_FLOOR");
+          return e && atoi(e) == 0;
+        }();
+        int allow_floor = (exact_cores || no_floor || mode == QTR_INLIER_KCORE_HEU) ? 0 : 1;
+        // a single pair's large graph: one more workgroup, the scout (hca_scout) — one of the resident set, so a launch that
+        // would fill the device gives it one of its places
+        static const bool no_scout = [] {  // (QTR_HCORE_SCOUT=0: comparison runs of the test build)
+          const char* e = QTR_ENGINE_ENV("QTR_HCORE_SCOUT");
+          return e && atoi(e) == 0;
+        }();
+        static const int scout_min_l = [] {  // (QTR_HCORE_SCOUT_MIN_L: the test build's sweeps run it on small graphs too)
+          const char* e = QTR_ENGINE_ENV("QTR_HCORE_SCOUT_MIN_L");
+          return e ? atoi(e) : 8192;
+        }();
+        const bool scout = allow_floor && !no_scout && G == 1 && L > scout_min_l && L <= 32768 && nwg >= 2;
+        if (scout) {
+          allow_floor = 2;
+          if (nwg + 1 > min(HCA_MAXWG, hca_max_workgroups() / t_hca_share)) nwg -= 1;
+        }
         if (G > 1) {
           // A group of pairs: an iteration of a workgroup is one snapshot round trip (~1.2 us, whatever it owns) plus its
           // rows (~0.6 us per sixteen), so the device does the most work per microsecond when ALL pairs of the launch are
@@ -3592,13 +3783,8 @@ static int clique_stage_launch(const SolverArgs& a, int G, int L, int mode, doub
         }
         const int pool_entries = (int)((lds_budget - fixed) / 2) & ~7;
         if (!hcore_prepared) LAUNCH_SV(k_hcore_async_init, a, dim3((max(L, 4096) + 255) / 256, 1, G), dim3(256), 0, stream);
-        static const bool no_floor = [] {  // (QTR_HCORE_FLOOR=0: comparison runs of the test build)
-          const char* e = QTR_ENGINE_ENV("QTR_HCORE_FLOOR");
-          return e && atoi(e) == 0;
-        }();
-        const int allow_floor = (exact_cores || no_floor || mode == QTR_INLIER_KCORE_HEU) ? 0 : 1;
-        LAUNCH_SV(k_hcore_async, a, dim3(nwg, 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream, pool_entries,
-                  allow_floor);
+        LAUNCH_SV(k_hcore_async, a, dim3(nwg + (scout ? 1 : 0), 1, G), dim3(HCA_THREADS), fixed + (size_t)2 * pool_entries, stream,
+                  pool_entries, allow_floor);
         after_async = true;
       }
 #ifdef QTR_TEST_ENGINES

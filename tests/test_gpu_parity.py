@@ -731,6 +731,55 @@ def test_clique_search_under_the_floor_sweep(hip, qo):
     assert ways["floor"] >= 10 and ways["second run"] >= 5, ways
 
 
+def test_scout_floor_on_large_graphs(hip, qo):
+    """Above 8192 vertices a single pair's k_hcore_async launch carries a scout workgroup (solver.hip: hca_scout) that
+    peels the sub-graph of the largest values down to a clique and publishes a floor below its size — no bet on the degree
+    sequence.  (a) the generator's correspondences with 2.5 % planted at L = 12 000 (h-index of the degrees 1.6 x their
+    mean: the bet stays away): the floor is the scout's, one run, clique / largest core / core numbers at or above the
+    floor the oracle's.  (b) nothing planted: no clique of sixteen to see, no floor.  (c) a graph handed in as a bit
+    matrix, a clique beside a dense block that is none."""
+    src, tgt, _, inl = synth.correspondences(12000, 0.025, 21, noise=0.05)
+    r, o = hip.solve(src, tgt), qo.solve(src, tgt)
+    st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+    bm_o = qo.build_graph(src, tgt, 0.3, 1.0)
+    assert st[22] == 0 and st[29] >= 200, (st[22], st[29])  # (the clique has 300 members: 300 - 1 - 37)
+    assert assert_cores(hip, qo.kcore(bm_o)[0]) == st[29]
+    assert r["max_core"] == o["max_core"] and r["n_edges"] == o["n_edges"]
+    _assert_same_solution(r, o)
+    src, tgt, _, _ = synth.correspondences(9000, 0.0, 22, noise=0.05)
+    r, o = hip.solve(src, tgt), qo.solve(src, tgt)
+    st = hip.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)
+    assert st[29] == 0, st[29]
+    assert_cores(hip, qo.kcore(qo.build_graph(src, tgt, 0.3, 1.0))[0])
+    _assert_same_solution(r, o)
+    L = 8600
+    rng = np.random.default_rng(9)
+    A = np.triu(rng.random((L, L), dtype=np.float32) < 0.006, 1)
+    blk = rng.choice(L, 400, replace=False)
+    A[np.ix_(blk, blk)] |= rng.random((400, 400)) < 0.5
+    mem = rng.choice(L, 120, replace=False)
+    A[np.ix_(mem, mem)] = True
+    bm = _bitmap_of(A)
+    core, _, mc = qo.kcore(bm)
+    got, max_core = hip.max_clique(bm, 1)
+    assert np.array_equal(got, qo.max_clique(bm, 1, 0.5)) and max_core == mc
+    assert_cores(hip, core)
+
+
+def test_scout_floor_sweep_on_small_graphs():
+    """The scout on the graphs of the floor's own sweep (dense blocks, cliques around the bet's floor, overlapping
+    near-cliques, a clique inside a block): tests/gpu_scout_sweep.py under the test-engine build, whose
+    QTR_HCORE_SCOUT_MIN_L lets the scout run below 8192 vertices; every case against the oracle."""
+    import subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, QTR_HCORE_SCOUT_MIN_L="1000", GRAFT_REPO_ROOT=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_scout_sweep.py"), "56"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0 and "SCOUT_SWEEP_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+    ways = eval(p.stdout.strip().splitlines()[-2].split("ways", 1)[1])
+    assert ways["scout"] >= 3, ways
+
+
 def test_max_clique_entry_hygiene_and_errors(hip, qo):
     bm, _ = _random_graph_bitmap(130, 0.2, 9, 10)
     ref, _ = hip.max_clique(bm, 1)
