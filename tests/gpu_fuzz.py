@@ -66,7 +66,7 @@ def same_solution(g, o):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["solve", "solve", "clique", "pair", "match", "match", "patchwork", "segment", "gnc3", "cote", "batch"])
+    kind = rng.choice(["solve", "solve", "clique", "pair", "match", "match", "patchwork", "segment", "gnc3", "cote", "batch", "scout"])
     n_cases += 1
     print(f"case {n_cases} {kind}", file=sys.stderr, flush=True)
     try:
@@ -165,6 +165,49 @@ while time.time() < t_end:
                     continue
                 if not np.array_equal(got, ref if mode != 2 else refs[(mode, thr)]):
                     report(kind, f"L={L} p={p} planted={planted} mode={mode} thr={thr}", f"{got.size} vs {ref.size}")
+        elif kind == "scout":
+            # graphs of more than 8192 vertices: a single pair's k_hcore_async launch carries the scout workgroup, whose
+            # floor (a clique it found among the largest values) must never show in the result — the generator's
+            # correspondences, and bit matrices with cliques / dense blocks / overlapping near-cliques in a sparse bulk
+            if rng.random() < 0.5:
+                L = int(rng.choice([8193, 9500, 12000]))
+                frac = float(rng.choice([0.0, 0.005, 0.01, 0.02, 0.04]))
+                noise = float(rng.choice([0.02, 0.1]))
+                src, tgt, _, _ = synth.correspondences(L, frac, seed=int(rng.integers(1 << 30)), noise=noise)
+                desc = f"L={L} frac={frac} noise={noise}"
+                g = h.solve(src, tgt, ql.demo_params())
+                o = qo.solve(src, tgt, qo.default_params())
+                w = same_solution(g, o)
+                if w:
+                    report(kind, desc, w)
+            else:
+                L = int(rng.choice([8200, 9000]))
+                p = float(rng.choice([0.003, 0.01, 0.02]))
+                A = np.triu(rng.random((L, L), dtype=np.float32) < p, 1)
+                desc = f"L={L} p={p}"
+                for _ in range(int(rng.integers(1, 4))):
+                    k = int(rng.choice([12, 20, 60, 150, 400]))
+                    mem = rng.choice(L, k, replace=False)
+                    q = float(rng.choice([1.0, 1.0, 0.97, 0.8, 0.5]))
+                    A[np.ix_(mem, mem)] |= rng.random((k, k)) < q
+                    desc += f" block({k}, {q})"
+                A = np.triu(A, 1)
+                A = A | A.T
+                bits = np.zeros((L, ((L + 63) // 64) * 64), dtype=np.uint8)
+                bits[:, :L] = A
+                bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, -1)
+                ref = np.sort(qo.max_clique(bm, 1, 0.5))
+                core, _, mc = qo.kcore(bm)
+                got, max_core = h.max_clique(bm, 1, 0.5)
+                if not np.array_equal(got, ref) or max_core != mc:
+                    report(kind, desc, f"{got.size} vs {ref.size}, largest core {max_core} vs {mc}")
+                elif not DRY:
+                    core = np.asarray(core)
+                    core_g = h.debug_fetch(ql.DBG_CORE, np.int32)[:L]
+                    floor = int(h.debug_fetch(ql.DBG_SOLVER_STATE, np.int32)[29])
+                    hi = core >= floor
+                    if not (np.array_equal(core_g[hi], core[hi]) and np.all(core_g[~hi] >= core[~hi]) and np.all(core_g[~hi] < floor)):
+                        report(kind, desc, f"core numbers under floor {floor}")
         elif kind == "pair":
             pid = int(rng.integers(0, 50))
             s, t, _ = synth.kitti64_pair(pid)
