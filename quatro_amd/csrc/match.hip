@@ -2181,6 +2181,19 @@ __global__ void k_gather_matched(const float4* __restrict__ vs, const float4* __
   }
 }
 
+// Which tail follows the two searches when the mutual test is on: the fused one (k_cross_multi, k_tuple, k_pairs_multi —
+// three launches; their look-backs have TAIL_MAXWG words, one per 512 rows) or the six-launch chain with its
+// single-workgroup scans (54 us each at 50 000 rows).  Until the end of round 5 the fused tail stopped at 32768 rows, the
+// limit of the one-workgroup kernels it had replaced (QTR_MATCH_TAIL=single, test build: still theirs).
+static_assert(CM_ROWS == 512 && PM_SRC == 512, "TAIL_MAXWG look-back words cover TAIL_MAXWG * 512 rows");
+static bool tail_is_fused(bool crosscheck, int max_large, int max_ns) {
+  static const bool tail_single = [] {
+    const char* e = QTR_ENGINE_ENV("QTR_MATCH_TAIL");
+    return e && strcmp(e, "single") == 0;
+  }();
+  const int lim = tail_single ? 32768 : TAIL_MAXWG * 512;
+  return crosscheck && max_large <= lim && max_ns <= lim;
+}
 static inline int grid_for(int n) {
   int g = (n + 255) / 256;
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -2441,7 +2454,7 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
   }
   // K6 cross-check -> pairs in ascending i
   const bool crosscheck = views[0].crosscheck != 0;
-  const bool fused_tail = crosscheck && max_large <= 32768 && max_ns <= 32768;
+  const bool fused_tail = tail_is_fused(crosscheck, max_large, max_ns);
   const bool fused16 = max_large <= 16384 && max_ns <= 16384;
   // the multi-workgroup compactions (QTR_MATCH_TAIL=single: the one-workgroup kernels of round 2, kept for comparison)
   static const bool tail_single = [] {
@@ -2508,7 +2521,7 @@ hipError_t match_enqueue(FrontBufs& F, int ns, int nt, const qtr_frontend_params
                          bool prep_done) {
   (void)hipGetLastError();
   const MatchView V = make_match_view(F, ns, nt, fp, (unsigned long long)fp.seed);
-  const bool fused_tail = V.crosscheck && V.n_large <= 32768 && ns <= 32768;
+  const bool fused_tail = tail_is_fused(V.crosscheck != 0, V.n_large, ns);
   F.gathered = fused_tail && F.m_src != nullptr;
   const bool evs = F.nn_events != 0;
   return match_launch(&V, 1, F.nn_engine, F.n_cu, nullptr, st, evs ? F.ev_nn : nullptr, init_done, prep_done);
@@ -2524,7 +2537,7 @@ hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const q
     max_large = max(max_large, v[g].n_large);
     max_ns = max(max_ns, v[g].ns);
   }
-  const bool fused_tail = fp->use_crosscheck && max_large <= 32768 && max_ns <= 32768;  // (as match_launch decides)
+  const bool fused_tail = tail_is_fused(fp->use_crosscheck != 0, max_large, max_ns);  // (as match_launch decides)
   for (int g = 0; g < G; ++g) F[g]->gathered = fused_tail && F[g]->m_src != nullptr;
   return match_launch(v.data(), G, F[0]->nn_engine, F[0]->n_cu, stage, st, nullptr, false, prep_done);
 }
