@@ -558,7 +558,8 @@ __global__ __launch_bounds__(256, 2) void k_nn_mfma(ViewExt<MatchView> x, MatchV
 //     v2 - v1 > u (76 |a|^2 + 108 |b1|^2 + 40 (d~1 + d~2) + 800)     (k_nn_finish_f16, 1 % slack on top)
 // — 2.3 x tighter than the inequality the f32 chain needs, which is what the listed rows of dense clouds (thousands of
 // near-identical descriptors with |b|^2 = 30000) were waiting for.  The re-check's threshold follows: v1 + u (76 |a|^2 +
-// 108 |b1|^2 + 80 d~1 + 800).  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
+// 108 |b1|^2 + 80 d~1 + 800).  (Both have an a-posteriori companion in k_nn_finish_f16, which knows the exact distance of
+// the candidate it chose: see "charges the leader's error as it is" there.)  Preconditions, checked per pair by k_half_tables: every |descriptor value| <= 255 (f16 range of
 // -256 x) and every |b|^2 < 65000 (f16 range of the norm pieces); a pair that violates them (not an FPFH descriptor:
 // those are bounded by 100) sets MC_UNSAFE and k_nn_finish_f16 sends all of its rows to the exact re-check.
 // Hidden / pad rows carry 3 x 65504 in the norm slots (196512 > any real nb').
@@ -977,7 +978,7 @@ template <bool EXT>
 __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, MatchView one, int dir, float cadd) {
   __shared__ __attribute__((aligned(16))) float s_rows[4][16][NN_FINH_PITCH];
   __shared__ float s_qv[4][16][36];
-  __shared__ float s_b1[NN_FINH_Q], s_b2[NN_FINH_Q], s_nbmax[NN_FINH_Q], s_na[NN_FINH_Q];
+  __shared__ float s_b1[NN_FINH_Q], s_b2[NN_FINH_Q], s_nbmax[NN_FINH_Q], s_na[NN_FINH_Q], s_e1[NN_FINH_Q];
   __shared__ int s_row[NN_FINH_Q], s_i1[NN_FINH_Q];
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   const NnDir& D = V.d[dir];
@@ -1081,6 +1082,7 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
     if (k == 0) {
       s_i1[ql] = (key == ~0ULL) ? -1 : (int)(u32)key;
       s_nbmax[ql] = nbm;
+      s_e1[ql] = __uint_as_float((u32)(key >> 32));  // the chosen candidate's exact distance (NaN pattern when there is none)
       s_b1[ql] = b1;
       s_b2[ql] = b2;
       s_row[ql] = row;
@@ -1104,7 +1106,19 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
     const float d2 = (c2 < INFINITY) ? fmaxf(cna + c2, 0.f) + 1.0f : d1;
     const float gap = u * (76.0f * cna + 108.0f * nb1 + 40.0f * (d1 + d2) + cadd) * 1.01f;  // (the f16 engine's own bound, round 5)
     if (unsafe) i1 = -1;
-    const bool certified = i1 >= 0 && (c2 == INFINITY || c2 - c1 > gap);
+    // The chosen candidate's EXACT distance e1 is known here, and with it a bound that charges the leader's error as it is
+    // instead of as it could be.  A base row b with d_ex(a,b) <= e1 has d(a,b) <= e1 (1 + 38u), and every base row obeys
+    // d(a,b) >= |a|^2~ + v - 38u |a|^2 - 396u (header comment), so its filter value is at most
+    //     T = e1 - |a|^2~ + u (38 |a|^2 + 38 e1 + 396)
+    // (42 / 42 / 400 and 2 % on top below: the three float roundings of the expression lose <= 2u (e1 + |a|^2)).  Hence:
+    // the second-best value of the whole cloud ABOVE T means every row but the leader r* is strictly farther than e1 in the
+    // exact evaluation — also the other candidates, so the chosen one IS r* and is the exact arg-min: certified, whatever
+    // the a-priori gap says.  And a listed row's re-check needs no base row above T.  With |b|^2 = 30000 the a-priori
+    // window above the leader's value is u (76 |a|^2 + 108 |b|^2 + ...), this one u (42 |a|^2 + ...) + the leader's actual
+    // error: what the near-identical descriptors of dense clouds were listed for, and evaluated for, shrinks accordingly.
+    const float e1 = s_e1[lane];
+    const float thr_e = (i1 >= 0) ? (e1 - cna) + u * (42.0f * cna + 42.0f * e1 + 0.5f * cadd) * 1.02f + 1e-30f : INFINITY;
+    const bool certified = i1 >= 0 && (c2 == INFINITY || c2 - c1 > gap || c2 > thr_e);
     const bool listed = valid && !certified;
     if (valid) D.best[crow] = certified ? (u64)(u32)i1 : ~0ULL;
     const u64 bal = __ballot(listed);
@@ -1116,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
       V.recheck_rows[slot] = crow;
       // a base row whose approximate (lower-bound) value exceeds this cannot be the exact arg-min; +inf when the slice
       // merge found nothing
-      const float thr = (i1 >= 0) ? c1 + u * (76.0f * cna + 108.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f : INFINITY;
+      const float thr = (i1 >= 0) ? fminf(c1 + u * (76.0f * cna + 108.0f * nb1 + 80.0f * d1 + cadd) * 1.02f + 1e-30f, thr_e) : INFINITY;
       V.recheck_thr[slot] = thr;
       V.recheck_q[slot] = crow;  // where k_recheck_filter finds the row's f16 query fragments (row of D.queryH)
     }
