@@ -51,24 +51,28 @@ def scout(adj, vals):
         alive &= d > thr
 
 
-L = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-fracs = [float(a) for a in sys.argv[2:]] or [0.02, 0.015, 0.01, 0.0]
-for fr in fracs:
-    src, tgt, _, _ = synth.correspondences(L, fr, seed=3, noise=0.05)
-    t0 = time.time()
-    bm = oracle.build_graph(src, tgt)
-    core = np.asarray(oracle.kcore(bm)[0] if isinstance(oracle.kcore(bm), tuple) else oracle.kcore(bm))
-    clique = oracle.max_clique(bm)
-    adj = unpack(np.asarray(bm).reshape(L, -1), L)
-    deg = adj.sum(axis=1).astype(np.int64)
-    vals = deg.copy()
-    for it in range(4):
-        res = scout(adj, vals)
-        s = res[0]
-        f2 = s - 1 - (s >> 3) if s >= 16 else 0
-        print(f"L {L} planted {fr}: after {it} iterations: scout clique {s} (theta {res[1]}, candidates {res[2]}, rounds {res[3] if len(res) > 3 else '-'}) floor {f2} | "
-              f"oracle clique {len(clique[0]) if isinstance(clique, tuple) else len(clique)} median core {int(np.median(core))} max core {int(core.max())} "
-              f"vertices with core >= floor {(core >= f2).sum() if f2 else L}", flush=True)
-        if it < 3:
-            vals = h_index_rows(adj, vals)
-    print(f"  ({time.time() - t0:.1f} s)")
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    fracs = [float(a) for a in sys.argv[2:]] or [0.02, 0.015, 0.01, 0.0]
+    for fr in fracs:
+        src, tgt, _, _ = synth.correspondences(L, fr, seed=3, noise=0.05)
+        t0 = time.time()
+        bm = oracle.build_graph(src, tgt)
+        core = np.asarray(oracle.kcore(bm)[0])
+        clique = oracle.max_clique(bm)
+        adj = unpack(np.asarray(bm).reshape(L, -1), L)
+        vals = adj.sum(axis=1).astype(np.int64)
+        for it in range(4):
+            res = scout(adj, vals)
+            s = res[0]
+            f2 = s - 1 - (s >> 3) if s >= 16 else 0
+            print(f"L {L} planted {fr}: after {it} iterations: scout clique {s} (theta {res[1]}, candidates {res[2]}, rounds "
+                  f"{res[3] if len(res) > 3 else '-'}) floor {f2} | oracle clique {len(clique)} median core {int(np.median(core))} "
+                  f"max core {int(core.max())} vertices with core >= floor {(core >= f2).sum() if f2 else L}", flush=True)
+            if it < 3:
+                vals = h_index_rows(adj, vals)
+        print(f"  ({time.time() - t0:.1f} s)")
+
+
+if __name__ == "__main__":
+    main()

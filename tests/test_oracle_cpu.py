@@ -1253,3 +1253,29 @@ def test_dense_scene_pair_is_deterministic_and_what_its_docstring_says():
     assert np.median(d) > 0.02 and np.percentile(d, 99) < 1.0           # different sample points of the same surfaces
     cnt = sp.cKDTree(a[:, :3]).query_ball_point(a[:, :3], 0.75, return_length=True)
     assert 15 < np.median(cnt) < 60 and cnt.max() < 256
+
+
+def test_scout_model_finds_the_generators_planted_cliques():
+    """The CPU model of k_hcore_async's scout workgroup (tests/probe/scout_sim.py; the kernel is solver.hip: hca_scout):
+    from the degrees alone, the min-degree peel of the 768 largest values' sub-graph ends on the planted clique — the
+    oracle's clique — and its floor s - 1 - s / 8 lies above the bulk's core numbers; nothing planted: nothing found."""
+    import importlib.util
+    import os
+    from oracle import oracle as qo
+    from quatro_amd import synth
+    spec = importlib.util.spec_from_file_location("scout_sim", os.path.join(os.path.dirname(__file__), "probe", "scout_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    for L, frac in ((6000, 0.03), (6000, 0.0)):
+        src, tgt, _, _ = synth.correspondences(L, frac, seed=5, noise=0.05)
+        bm = qo.build_graph(src, tgt)
+        adj = sim.unpack(np.asarray(bm).reshape(L, -1), L)
+        res = sim.scout(adj, adj.sum(axis=1).astype(np.int64))
+        if frac:
+            clique = np.asarray(qo.max_clique(bm))
+            core = np.asarray(qo.kcore(bm)[0])
+            assert res[0] == clique.size == int(round(L * frac))
+            assert res[0] - 1 - (res[0] >> 3) > np.median(core)
+        else:
+            assert res[0] == 0
+
