@@ -454,6 +454,14 @@ def main() -> None:
             out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE + WRITE_SIZE)"
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc[-1])
+        # ... and so do the matrix pipe's own counters (SQ_VALU_MFMA_BUSY_CYCLES against the waves' lifetime)
+        mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_mfma.json")))
+        if mf and NN_ENGINE != "mfma32":
+            with open(mf[-1]) as f:
+                mj = json.load(f)
+            if "k_nn_f16" in mj.get("kernel", ""):
+                out["roofline"]["mfma_busy"] = mj["mfma_busy_of_wave_lifetime"]
+                out["roofline"]["mfma_busy_source"] = "profiles/" + os.path.basename(mf[-1])
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample; also the parity check
     # (for N > 1 too: north_star wants the CPU path timed in the same run next to the multi-GPU numbers — rank 0's host)
