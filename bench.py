@@ -71,6 +71,17 @@ NN_ENGINE = os.environ.get("QTR_NN_ENGINE", "f16")  # f16 (default): k_nn_f16; m
 F16_FLOP_PER_ENTRY, F32_FLOP_PER_ENTRY = 204.0, 66.0
 
 
+def nn_kernel_sha():
+    """sha256[:16] over the nearest-neighbour kernel's text (the hand-scheduled loop, its generator, match.hip): what a
+    committed counter profile was collected on (profiles/summarize_pmc.py records it) against what this run executes."""
+    import hashlib
+    hh = hashlib.sha256()
+    for f in ("nn_f16_core.inc", "gen_nn_f16_core.py", "match.hip"):
+        with open(os.path.join(ROOT, "quatro_amd", "csrc", f), "rb") as fh:
+            hh.update(fh.read())
+    return hh.hexdigest()[:16]
+
+
 def nn_roofline(entries_per_launch, mean_launch_s):
     """roofline fields of the nearest-neighbour kernel for one launch of `entries_per_launch` distance-matrix entries"""
     f32_rate = F32_FLOP_PER_ENTRY * entries_per_launch / mean_launch_s / 1e12
@@ -454,14 +465,21 @@ def main() -> None:
             out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE + WRITE_SIZE)"
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc[-1])
+            # (a committed profile can go stale behind a kernel change: say which kernel text it was collected on)
+            out["roofline"]["traffic_kernel_sha"] = pj.get("kernel_source_sha", "unrecorded")
+            out["roofline"]["kernel_sha_now"] = nn_kernel_sha()
         # ... and so do the matrix pipe's own counters (SQ_VALU_MFMA_BUSY_CYCLES against the waves' lifetime)
         mf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_mfma.json")))
         if mf and NN_ENGINE != "mfma32":
             with open(mf[-1]) as f:
                 mj = json.load(f)
             if "k_nn_f16" in mj.get("kernel", ""):
-                out["roofline"]["mfma_busy"] = mj["mfma_busy_of_wave_lifetime"]
+                # NOT measured in this run (counters cannot be read in-process): a figure of the committed profile,
+                # named as such, with the kernel text it was collected on beside the one this run executes
+                out["roofline"]["mfma_busy_from_profile"] = mj["mfma_busy_of_wave_lifetime"]
                 out["roofline"]["mfma_busy_source"] = "profiles/" + os.path.basename(mf[-1])
+                out["roofline"]["mfma_busy_kernel_sha"] = mj.get("kernel_source_sha", "unrecorded")
+                out["roofline"]["kernel_sha_now"] = nn_kernel_sha()
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample; also the parity check
     # (for N > 1 too: north_star wants the CPU path timed in the same run next to the multi-GPU numbers — rank 0's host)
@@ -496,9 +514,13 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, comp
         t0 = time.perf_counter()
         results = hb.register_batch_dev(pairs, prm, corr=corr)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's own block, before it waits for the others
         if world > 1:
             dist.barrier()
-        return qdist.max_over_ranks(time.perf_counter() - t0, cdev), results
+        el = qdist.max_over_ranks(time.perf_counter() - t0, cdev)
+        per_rank.append(qdist.all_over_ranks(len(ids) / max(own, 1e-9), cdev))
+        return el, results
+    per_rank = []  # per run(): every rank's pairs/s on its own block (rank order)
     out = {"what": f"{B} pair ids, block-partitioned over {world} GPU(s), batched launch chains "
                    "(qtr_submit_batch / qtr_wait)", "pairs": B}
     if composite:
@@ -513,12 +535,14 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, comp
         out.update({"unit_of_work": f"front end of the scan pair (n ~ 16-18 k voxels per cloud) + back end on {LC} given "
                                     "correspondences per pair id — the headline step's unit, batched",
                     "n_corr": LC, "value": B / el, "unit": "registrations/s", "ms_per_pair": 1e3 * el / B,
-                    "identical_to_sequential": same})
+                    "identical_to_sequential": same, "per_rank_pairs_per_s": per_rank[-1],
+                    "pairs_per_rank": [qdist.shard_range(B, r_, world)[1] - qdist.shard_range(B, r_, world)[0]
+                                       for r_ in range(world)]})
     el2, results2 = run(False)
     same2 = all(bool(np.array_equal(r["T"], pool[i % len(pool)]["whole"]["T"])) for i, r in zip(ids, results2))
     scan = {"what": "the same ids on the scans alone: the matcher's own correspondences feed the back end",
             "n_corr": [int(p["L"]) for p in pool], "value": B / el2, "unit": "registrations/s",
-            "ms_per_pair": 1e3 * el2 / B, "identical_to_sequential": same2}
+            "ms_per_pair": 1e3 * el2 / B, "identical_to_sequential": same2, "per_rank_pairs_per_s": per_rank[-1]}
     if composite:
         out["scan_pairs"] = scan
     else:
@@ -534,6 +558,7 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, comp
 
         def lib_gather():
             try:
+                t_init = time.perf_counter()
                 uid = torch.zeros(128, dtype=torch.uint8, device=udev)
                 if rank == 0:
                     uid = torch.frombuffer(bytearray(ql.comm_unique_id()), dtype=torch.uint8).to(udev)
@@ -550,7 +575,9 @@ def batch_leg(args, torch, ql, h, pool, prm, dev, world, dist, qdist, cdev, comp
                 allr, counts, n_all = hb.gather_results_v(loc if n_loc else None, n_loc, world, B)
                 want = [qdist.shard_range(B, r_, world)[1] - qdist.shard_range(B, r_, world)[0] for r_ in range(world)]
                 g.update({"ok": bool(n_all == B and counts == want), "records": int(n_all),
-                          "seconds": time.perf_counter() - t0,
+                          "seconds": time.perf_counter() - t0,  # the collective alone (counts + padded records)
+                          "comm_init_seconds": t0 - t_init,  # unique id broadcast + ncclCommInitRank + packing the block
+                          "bytes_gathered": int(n_all) * C.sizeof(ql.Result),
                           "all_valid": bool(all(allr[i].valid for i in range(n_all)))})
             except Exception as e:  # the bench line must survive a site whose RCCL cannot be opened from the library
                 g.update({"ok": False, "error": repr(e)[:300]})

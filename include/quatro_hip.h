@@ -81,7 +81,7 @@ typedef struct qtr_handle qtr_handle;
 
 typedef struct qtr_limits {
   int max_points; /* raw points per cloud            (default 262144; reference loader caps at 250000) */
-  int max_voxels; /* down-sampled points per cloud   (default 65536) */
+  int max_voxels; /* down-sampled points per cloud   (default 65536; at most 2^20 - 32: qtr_create refuses more) */
   int max_corr;   /* correspondences into the solver (default 24576) */
   int n_slots;    /* independent stream slots        (default 1) */
   int max_long_neighbors; /* per cloud: total entries of the radius-neighbour lists that are LONGER than 256 entries

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -100,7 +102,15 @@ struct qtr_handle {
   std::atomic<bool> long_lists{false};  // some cloud of the whole-path entry points had a point with more than QTR_KMAX
                             // neighbours: from then on their FPFH chains include k2_neighbors_big (see front_device); written
                             // by whichever slot call meets such a cloud first (calls from several threads)
-  std::atomic<int> n_callers{0};  // distinct host threads that have run a back-end chain on this handle (InFlight)
+  // LIVE host threads that have run a back-end chain on this handle (InFlight): the block outlives the handle as long as a
+  // thread still holds it, so a thread that ends after qtr_destroy can still take itself off the count
+  struct Callers {
+    std::atomic<int> live{0};
+  };
+  std::shared_ptr<Callers> callers = std::make_shared<Callers>();
+  std::mutex share_mu;                 // guards share_val / share_gen
+  int share_val = 1, share_gen = 0;    // the share in force and how often it has changed
+  std::atomic<int> gen_inflight[4] = {};  // chains in flight per generation of the share (gen & 3)
   unsigned long long uid = 0;     // process-unique id of this handle (a thread remembers the handle it registered with)
   int stage_events = 1;  // QTR_STAGE_EVENTS=0: only the first/last event of a call are recorded (stage times read 0)
   int nn_event_stride = 1;  // every n-th match of a slot carries the nearest-neighbour event pairs (0: none)
@@ -472,7 +482,8 @@ int qtr_create(int device, const qtr_limits* limits, qtr_handle** out) {
   else
     qtr_default_limits(&h->lim);
   if (h->lim.max_points < 64 || h->lim.max_voxels < 64 || h->lim.max_corr < 64 || h->lim.n_slots < 1 ||
-      h->lim.max_corr > 32768 || h->lim.max_voxels > h->lim.max_points || h->lim.max_long_neighbors < 0) {
+      h->lim.max_corr > 32768 || h->lim.max_voxels > h->lim.max_points || h->lim.max_long_neighbors < 0 ||
+      h->lim.max_voxels > QTR_NN_MAX_ROWS) {  // (k_recheck_filter's lists pack a base row into 20 bits: match.hip)
     delete h;
     return QTR_ERR_BAD_ARG;
   }
@@ -731,26 +742,68 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
 // the moment of the call (round 4 looked at the in-flight count: the first of several threads took the whole device and
 // the others' launches were only partly resident until a residency timeout sent them to the peeling fallback): every
 // host thread registers with the handle on its first back-end call, and from the moment a second thread has registered
-// every chain takes 1 / min(threads, slots) of the units.  The one chain that may be in flight with a full share at that
-// moment is waited for once.  A single-threaded caller never pays anything.  (QTR_DBG_CORE and the floor statistics
+// every chain takes 1 / min(LIVE threads, slots) of the units: a thread leaves the count when it ends (a pool of short-lived
+// threads that run one at a time keeps the whole device), and whenever the share CHANGES — a third thread arriving, one
+// leaving — the chains enqueued under the old share are waited for once (1/2 + 1/2 + 1/3 would oversubscribe as surely as
+// 1 + 1/2).  A single-threaded caller never pays anything.  (QTR_DBG_CORE and the floor statistics
 // st[22] / st[29] depend on timing either way: the floor is decided by what has been published 200 us into the launch.)
+// (the handles a thread has registered with; its destructor — the thread's end — takes the thread off their counts)
+struct ThreadCallerList {
+  struct Entry {
+    unsigned long long uid;
+    std::shared_ptr<qtr_handle::Callers> c;
+  };
+  std::vector<Entry> e;
+  ~ThreadCallerList() {
+    for (Entry& x : e) x.c->live.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  void enter(qtr_handle* h) {
+    for (const Entry& x : e)
+      if (x.uid == h->uid) return;  // (a thread that works with several handles in turn is ONE caller of each, once)
+    if (e.size() >= 64) {  // handles come and go: keep the list short — drop the entries of destroyed handles first; if
+      size_t victim = 0;   // every one is alive the oldest goes AND leaves its handle's count (it re-registers if it returns)
+      for (size_t i = 0; i < e.size(); ++i)
+        if (e[i].c.use_count() == 1) {
+          victim = i;
+          break;
+        }
+      e[victim].c->live.fetch_sub(1, std::memory_order_acq_rel);
+      e.erase(e.begin() + (long)victim);
+    }
+    h->callers->live.fetch_add(1, std::memory_order_acq_rel);
+    e.push_back(Entry{h->uid, h->callers});
+  }
+};
+
 struct InFlight {
   qtr_handle* h;
+  int gen;
   explicit InFlight(qtr_handle* h_) : h(h_) {
-    // (the handles this thread has registered with: a thread that works with several handles in turn is ONE caller of each)
-    static thread_local std::vector<unsigned long long> t_registered;
-    if (std::find(t_registered.begin(), t_registered.end(), h->uid) == t_registered.end()) {
-      if (t_registered.size() >= 64) t_registered.erase(t_registered.begin());  // (handles come and go: keep the list short)
-      t_registered.push_back(h->uid);
-      if (h->n_callers.fetch_add(1, std::memory_order_acq_rel) == 1)  // the second thread: let a full-share chain drain
-        for (int spins = 0; h->solves_in_flight.load(std::memory_order_acquire) > 0 && spins < 2000000; ++spins)
-          std::this_thread::yield();
+    static thread_local ThreadCallerList t_callers;
+    t_callers.enter(h);
+    const int want = std::max(1, std::min(h->callers->live.load(std::memory_order_acquire), (int)h->slots.size()));
+    bool changed = false;
+    {
+      std::lock_guard<std::mutex> lk(h->share_mu);
+      if (want != h->share_val) {  // a thread came or went: chains enqueued under the old share drain before this one starts
+        h->share_val = want;
+        ++h->share_gen;
+        changed = true;
+      }
+      gen = h->share_gen;
+      h->gen_inflight[gen & 3].fetch_add(1, std::memory_order_acq_rel);
     }
     h->solves_in_flight.fetch_add(1, std::memory_order_acq_rel);
-    const int callers = h->n_callers.load(std::memory_order_acquire);
-    solver_set_hca_share(std::max(1, std::min(callers, (int)h->slots.size())));
+    if (changed)  // (bounded: a chain another thread never reads back must not hang this one; three generations back is every
+      for (int back = 1; back <= 3; ++back)  // chain that can still be in flight under an older share)
+        for (int spins = 0; h->gen_inflight[(gen - back) & 3].load(std::memory_order_acquire) > 0 && spins < 2000000; ++spins)
+          std::this_thread::yield();
+    solver_set_hca_share(want);
   }
-  ~InFlight() { h->solves_in_flight.fetch_sub(1, std::memory_order_acq_rel); }
+  ~InFlight() {
+    h->gen_inflight[gen & 3].fetch_sub(1, std::memory_order_acq_rel);
+    h->solves_in_flight.fetch_sub(1, std::memory_order_acq_rel);
+  }
 };
 
 // Runs the back end on device-resident matched clouds and brings the result record to the host.
@@ -1383,10 +1436,10 @@ int qtr_voxelize(qtr_handle* h, int slot, const float* xyz4, int P, float leaf, 
     QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 1, raws, Ps, leaf, s.stream));
   }
   QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
-  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+  QTR_HIP_TRY(h, hipMemcpyAsync(s.pinned_i32, cb.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
   QTR_HIP_TRY(h, hipStreamSynchronize(s.stream));
   int n = s.pinned_i32[CNT_NVOX];
-  if (n < 0) {  // (see front_device)
+  if (n < 0 || s.pinned_i32[CNT_VOX_TAILERR]) {  // (see front_device; the sticky word: ANY tile gave up, not only the last)
     snprintf(h->err, sizeof(h->err), "voxel grid: look-back timed out");
     return QTR_ERR_HIP;
   }
@@ -1674,6 +1727,12 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
   int L = 0;
   rc = match_device(h, s, ns, nt, fp, &L, true, true, corr_given);
   if (rc != QTR_OK) return rc;
+  if (s.mail[MAIL_CNT0 + CNT_VOX_TAILERR] || s.mail[MAIL_CNT1 + CNT_VOX_TAILERR]) {
+    // a MIDDLE tile of k2_vox_centroids gave up its look-back (its centroids were never written) although the last tile's
+    // came out whole and mailed a valid count: the counter lines the matcher's tail mails after that kernel carry the word
+    snprintf(h->err, sizeof(h->err), "voxel grid: look-back timed out in a tile (centroids incomplete)");
+    return QTR_ERR_HIP;
+  }
   if (s.mail[MAIL_CNT0 + CNT_NBR_CAPACITY] || s.mail[MAIL_CNT1 + CNT_NBR_CAPACITY]) {
     snprintf(h->err, sizeof(h->err), "radius-neighbour lists longer than %d entries (longest %d / %d) exceed the long-list "
              "arena: qtr_limits.max_long_neighbors is %d", QTR_KMAX, s.mail[MAIL_CNT0 + CNT_KMAX],
@@ -2159,6 +2218,10 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
       if (!given) r.n_corr = Lm;
       if (Lm < 0 && !given) {  // the tail's look-back timed out (match.hip): nothing usable was written for this pair
         r.n_corr = 0;
+        batch_fail_pair(h, ln.first_pair + g, QTR_ERR_HIP);
+        continue;
+      }
+      if (s.mail[MAIL_CNT0 + CNT_VOX_TAILERR] || s.mail[MAIL_CNT1 + CNT_VOX_TAILERR]) {  // (see front_device)
         batch_fail_pair(h, ln.first_pair + g, QTR_ERR_HIP);
         continue;
       }

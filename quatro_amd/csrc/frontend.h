@@ -9,9 +9,13 @@
 #define NORM_BINS 192       // bins of width 1 over sqrt(|descriptor|^2) (<= sqrt(3 * 100^2) = 173.3)
 
 // per-cloud device counters (CloudBufs::counts, 16 ints)
+// the largest cloud the matcher takes: k_recheck_filter's per-wave lists hold (listed column << 20 | base row) in 32 bits —
+// 20 bits of base row (padded to whole 32-row tiles), 12 of column; qtr_create refuses limits above it
+#define QTR_NN_MAX_ROWS ((1 << 20) - 32)
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5,
        CNT_SORT_BITS = 6 /* significant bits of the voxel sort's keys */,
-       CNT_NBR_ARENA = 7 /* entries of the long-list arena handed out */, CNT_NBR_CAPACITY = 8 /* ... it was too small */ };
+       CNT_NBR_ARENA = 7 /* entries of the long-list arena handed out */, CNT_NBR_CAPACITY = 8 /* ... it was too small */,
+       CNT_VOX_TAILERR = 9 /* sticky: SOME tile of k2_vox_centroids gave up its look-back and wrote no centroids */ };
 // CNT_NBR_OVERFLOW: some point of the cloud has more than QTR_KMAX neighbours (k2_neighbors_big has work to do);
 // CNT_KMAX: the longest such list
 // matcher device counters (FrontBufs::mcounts, 16 ints)

@@ -434,7 +434,14 @@ __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, co
       if (threadIdx.x == 0) *mail_seq_slot = seq;
     }
   }
-  if (running < 0) return;  // (no writes at unknown offsets)
+  if (running < 0) {
+    // no writes at unknown offsets — and the failure is STICKY: the last tile's own look-back may still come out whole
+    // (a slow predecessor can appear after a middle tile has given up on it but before the last tile does), so every tile
+    // that gives up raises a word of the counter line; it reaches the host with the counters the matcher's tail mails
+    // (after this kernel in stream order) and in qtr_voxelize's read-back — as the matcher's MC_TAILERR does
+    if (threadIdx.x == 0) __hip_atomic_store(counts + CNT_VOX_TAILERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   QTR_STAMP(STAMP_CENTROIDS, 2)
   for (int t0 = 0; t0 < VOX_TILE; t0 += 256) {
     const int t = t0 + threadIdx.x;

@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
       while (pass) {
         const int r = __ffs((int)pass) - 1;
         pass &= pass - 1;
-        wc[at++] = ((u32)col << 20) | (u32)(t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));
+        wc[at++] = ((u32)col << 20) | (u32)(t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));  // (row < 2^20: QTR_NN_MAX_ROWS)
       }
     };
     RC_STAMP(1)

@@ -3908,7 +3908,11 @@ hipError_t solver_continue(const SolverBufs& B, const float4* src, const float4*
       guard = 0;
       continue;
     }
-    if (++guard > (L / CLIQUE_BATCH) + 4) break;  // cannot happen: pos decreases by CLIQUE_BATCH per round
+    // The sweep + scan-all pair goes over EVERY remaining start in one round and ends with done = 1 (or redo_cores), and a
+    // second run of the stage is followed by at most one more sweep: a state that is still open after that is an internal
+    // error, and it is reported as one — k_finalize exports valid = 0 with status QTR_OK while the search is not through,
+    // which a caller could not tell from "no clique"
+    if (++guard > 3) return hipErrorUnknown;
   }
   if (src) launch_finalize(a, 1, prm, stream);
   return hipGetLastError();

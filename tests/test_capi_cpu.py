@@ -83,6 +83,18 @@ def test_defaults_match_reference_params(libpath):
         (0.3, 0.5, 0.75, 0.95)
 
 
+def test_create_refuses_limits_the_kernels_cannot_address(libpath):
+    """qtr_create checks its limits before it touches a device: k_recheck_filter's per-wave lists pack a base row into 20
+    bits (quatro_amd/csrc/match.hip, QTR_NN_MAX_ROWS), so a cloud of 2^20 rows would alias rows silently — refused."""
+    import ctypes
+    from quatro_amd import lib as ql
+    lib = ql.load()
+    for mv in (1 << 20, (1 << 20) - 31, 1 << 21):
+        lim = ql.Limits(1 << 22, mv, 8192, 1, 0)
+        h = ctypes.c_void_p()
+        assert lib.qtr_create(0, ctypes.byref(lim), ctypes.byref(h)) == ql.QTR_ERR_BAD_ARG and not h
+
+
 def test_no_cpu_fallback_when_library_missing(tmp_path, monkeypatch):
     from quatro_amd import lib as ql
     monkeypatch.setattr(ql, "_lib", None)

@@ -36,6 +36,8 @@ def _worker(rank, world, port, q):
                                          "final_inliers": np.arange(pid + 1), "L": 100 + pid, "n_rot_inliers": pid}))
     g = qd.gather_records(np.stack(recs))
     tmax = qd.max_over_ranks(1.0 + rank)
+    every = qd.all_over_ranks(10.0 + rank)  # (the per-rank figures of bench.py's sharded leg)
+    assert every == [10.0 + r for r in range(world)]
     if rank == 0:
         q.put((g, tmax))
     else:
