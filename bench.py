@@ -63,6 +63,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+L5K_LEAF = 0.07  # voxel leaf at which the pool's scan pairs yield 4.2-5.9 k mutual nearest neighbours (connected_leg.l5k)
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32) = FP32 vector peak
@@ -485,6 +486,34 @@ def main() -> None:
     # (for N > 1 too: north_star wants the CPU path timed in the same run next to the multi-GPU numbers — rank 0's host)
     if args.cpu_seconds > 0:
         out.update(cpu_baseline_leg(args, ql, h, pool, composite, LC, value, seg, pwl, raw0, legs, extra))
+    # ---- beside the composite headline: a REAL registration at the metric's L ~ 5 k — the front end's own 4.2-5.9 k
+    # correspondences into the back end, one qtr_register_pair call (connected_leg.l5k), with its own ms_per_registration
+    cl = out.get("connected_leg") or {}
+    kept = cl.pop("_l5k", None)
+    chk = out.pop("_l5k_check", None) or {}
+    if "l5k" in cl:
+        def brief(name):
+            c = cl[name]
+            d = {"ms_per_registration": c["ms_per_registration"], "value": c["value"], "unit": "registrations/s",
+                 "frontend_params": c["frontend_params"], "n_voxels": [[r["n_src"], r["n_tgt"]] for r in c["pairs"]],
+                 "n_corr": c["n_corr"], "n_clique": [r["n_clique"] for r in c["pairs"]],
+                 "n_final": [r["n_final"] for r in c["pairs"]], "valid": [r["valid"] for r in c["pairs"]],
+                 "rot_err_vs_gt_rad": [r["rot_err_vs_gt_rad"] for r in c["pairs"]],
+                 "trans_err_vs_gt_m": [r["trans_err_vs_gt_m"] for r in c["pairs"]]}
+            if name in chk:
+                k = chk[name]
+                d["oracle_check_first_pair"] = k
+                d["oracle_equal"] = bool(k["counts_equal"] and k["clique_bit_exact"] and k["final_inliers_bit_exact"] and
+                                         k["rot_err_rad"] <= 1e-4 and k["trans_err_m"] <= 1e-3)
+                d["cpu_port_registrations_per_s"] = 1.0 / k["cpu_port_seconds"]
+            return d
+        out["connected_l5k"] = dict(
+            what="ONE qtr_register_pair call per registration, the matcher's OWN correspondences into the back end at the "
+                 "metric's L ~ 5 k: the pool's 64-beam scan pairs at a %.2f m leaf, cross check without tuple test "
+                 "(reference feature_matcher.cc:113-181; examples/run_global_registration.cpp:206-246)" % L5K_LEAF,
+            **brief("l5k"))
+        if "l5k_dense18k" in cl:
+            out["connected_l5k"]["dense18k"] = brief("l5k_dense18k")
     print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)
@@ -608,16 +637,28 @@ def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
                   (L ~ 2.1 k) and the back end: a registration that LANDS (clique ~160, centimetres from the truth)
       dense_mutual  the same with use_tuple_test = 0: every mutual nearest-neighbour pair of the 50 k x 50 k search goes
                   into the back end — L ~ 14 k of the matcher's own correspondences (configs[4]'s "~20 k corr")
-    (parity of each against the oracle: tests/test_gpu_baseline_sizes.py)."""
+      l5k         THE METRIC'S SIZE, DATA-CONNECTED: the pool's 64-beam scan pairs at a 0.07 m leaf (n ~ 35-40 k voxels per
+                  cloud) with use_tuple_test = 0 — the front end's OWN output is L = 4.2-5.9 k mutual nearest neighbours
+                  (reference feature_matcher.cc:113-181), and the back end registers them: cliques of 400-2600, centimetres
+                  from the truth
+      l5k_dense18k  two independent 18 000-point samplings of the structured scene, no voxel step: n = 18 000 per cloud
+                  (the headline's n) and L = 4999 of the matcher's own
+    (parity of each against the oracle: tests/test_gpu_baseline_sizes.py; of l5k pair 0 and l5k_dense18k also in this run:
+    `connected_l5k.oracle_equal`)."""
     hc = ql.Handle(device_index, max_points=131072, max_voxels=65536, max_corr=32768)
     res = ql.Result()
     out = {}
     a, b, Td = synth.dense_scene_pair(50000)
     dense = {"src": torch.from_numpy(a).to(dev), "tgt": torch.from_numpy(b).to(dev), "Tgt": Td}
+    a18, b18, T18 = synth.dense_scene_pair(18000)
+    dense18 = {"src": torch.from_numpy(a18).to(dev), "tgt": torch.from_numpy(b18).to(dev), "Tgt": T18, "src_h": a18, "tgt_h": b18}
     cases = [("mutual_nn", dict(use_tuple_test=0), pool, 12),
              ("no_cross", dict(use_crosscheck=0, use_tuple_test=0), pool, 8),
              ("dense", dict(voxel_size=0.001), [dense], 6),
-             ("dense_mutual", dict(voxel_size=0.001, use_tuple_test=0), [dense], 6)]
+             ("dense_mutual", dict(voxel_size=0.001, use_tuple_test=0), [dense], 6),
+             ("l5k", dict(voxel_size=L5K_LEAF, use_tuple_test=0), pool, 12),
+             ("l5k_dense18k", dict(voxel_size=0.001, use_tuple_test=0), [dense18], 8)]
+    keep = []  # (name, item, frontend params, the registration's full record) of the L ~ 5 k cases: the CPU leg checks them
     hc.set_stage_events(False)
     hc.set_nn_event_stride(0)
     for name, kw, items, n in cases:
@@ -645,6 +686,9 @@ def connected_leg(args, torch, ql, synth, pool, prm, dev, device_index):
         el = time.perf_counter() - t0
         out[name] = {"frontend_params": kw, "value": n / el, "unit": "registrations/s", "ms_per_registration": 1e3 * el / n,
                      "n_corr": [r["n_corr"] for r in recs], "pairs": recs}
+        if name.startswith("l5k"):  # the first item's lists (host call: clique, final inliers, transform) for the oracle check
+            keep.append((name, items[0], fps[0], hc.register_pair(items[0]["src_h"], items[0]["tgt_h"], fps[0], prm)))
+    out["_l5k"] = keep
     hc.close()
     out["what"] = ("qtr_register_pair, one call per registration, the matcher's own correspondences into the back end "
                    "(no generator in between)")
@@ -1084,6 +1128,28 @@ def cpu_baseline_leg(args, ql, h, pool, composite, LC, value, seg, pwl, raw0, le
         return bool(ok)
     out["parity_vs_oracle"] = {"all_pool_pairs_ok": all(all_ok(e) for e in par), "pairs": par,
                                "tolerance": "integer outputs bit-exact; 1e-4 rad / 1e-3 m"}
+
+    # ---- the data-connected registrations at the metric's L ~ 5 k (connected_leg.l5k*): the oracle's stages composed the
+    # same way on the same scans — every output equal — and timed: the CPU port's rate on a REAL registration of that size
+    l5k = (extra.get("connected_leg") or {}).get("_l5k") or []
+    chk = {}
+    for name, it, f, g in l5k:
+        t1 = time.perf_counter()
+        vs, vt = qo.voxelize(it["src_h"], f.voxel_size), qo.voxelize(it["tgt_h"], f.voxel_size)
+        ds, dt = qo.fpfh(vs, f.normal_radius, f.fpfh_radius)[2], qo.fpfh(vt, f.normal_radius, f.fpfh_radius)[2]
+        corr = qo.match(vs, ds, vt, dt, bool(f.use_crosscheck), bool(f.use_tuple_test), f.tuple_scale, int(f.seed))
+        o = qo.solve(vs[corr[:, 0]], vt[corr[:, 1]])
+        cpu_s = time.perf_counter() - t1
+        re_, te_ = t_err(g["T"], o["T"])
+        chk[name] = {
+            "counts_equal": bool((g["n_src"], g["n_tgt"], g["L"]) == (vs.shape[0], vt.shape[0], corr.shape[0])),
+            "clique_bit_exact": bool(np.array_equal(g["clique"], o["clique"])),
+            "final_inliers_bit_exact": bool(np.array_equal(g["final_inliers"], o["final_inliers"])),
+            "transform_bit_exact": bool(np.array_equal(g["T"], o["T"])), "rot_err_rad": re_, "trans_err_m": te_,
+            "n_corr": int(corr.shape[0]), "n_clique": int(o["clique"].size), "n_final": int(o["final_inliers"].size),
+            "cpu_port_seconds": cpu_s, "cpu_port_threads": best_th}
+    if chk:
+        out["_l5k_check"] = chk
 
     # ---- the reference's OWN back-end text (oracle/_ref/libref_solver.so: computeTIMs with materialised TIMs,
     # solveForScale, teaser::Graph adjacency lists with find-before-insert, solveForRotation2D, COTE — cut out of

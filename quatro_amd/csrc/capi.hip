@@ -459,6 +459,26 @@ static int create_impl(qtr_handle* h) {
     QTR_HIP_TRY(h, hipHostMalloc((void**)&ln.stage.h, ln.stage.cap));
     QTR_HIP_TRY(h, hipMalloc((void**)&ln.stage.d, ln.stage.cap));
   }
+  // experiment knob (test build only): the lanes' launch streams on DISJOINT sets of compute
+  // units (hipExtStreamCreateWithCUMask; on this part bit k of the mask is compute unit k / 8 of XCD k % 8).
+  //   QTR_LANE_CU_MASK=halves   lane l of NL takes the l-th NL-th of every XCD's units
+  //   QTR_LANE_CU_MASK=xcd      lane l takes XCDs [8 l / NL, 8 (l + 1) / NL)
+  // measured and NOT adopted: profiles/r6_ab.txt
+  if (const char* e = QTR_ENGINE_ENV("QTR_LANE_CU_MASK")) {
+    for (int l = 0; l < NL && NL > 1; ++l) {
+      unsigned mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < 256; ++k) {
+        const int xcd = k % 8, cu = k / 8;
+        const bool mine = (strcmp(e, "xcd") == 0) ? (xcd * NL / 8 == l) : (cu * NL / 32 == l);
+        if (mine) mask[k >> 5] |= 1u << (k & 31);
+      }
+      Slot& lead = h->slots[h->lanes[l].first_slot];
+      (void)hipStreamDestroy(lead.stream);
+      (void)hipStreamDestroy(lead.stream2);
+      QTR_HIP_TRY(h, hipExtStreamCreateWithCUMask(&lead.stream, 8, mask));
+      QTR_HIP_TRY(h, hipExtStreamCreateWithCUMask(&lead.stream2, 8, mask));
+    }
+  }
   return QTR_OK;
 }
 

@@ -667,7 +667,32 @@ __device__ __forceinline__ void d_neighbors(const float4* __restrict__ pts, int 
     }
     return;
   }
-  int n2 = 8;  // (most lists are shorter than 32: 10 - 15 compare stages instead of the 21 a 64-key network needs)
+  if (k <= 64) {
+    // Up to 64 keys (every list of a voxelised scan: ~18 entries): sorted by RANK, no network.  A lane keeps its key in
+    // registers and counts the keys below it — the keys are read four at a time from LDS, every lane the same address (a
+    // broadcast), one 64-bit compare and one add-with-carry per key; keys are distinct (the index is part of them), so the
+    // counts are a permutation and the lane stores its entry at its rank.  The bitonic network this replaces for short
+    // lists spent 10 - 15 stages of (barrier, two LDS reads, compare, two conditional LDS writes) with a scalar loop around
+    // each: ~120 vector + ~180 scalar + ~60 LDS instructions per point against ~3 per key here (round 6, profiles/
+    // r6_pmc_fpfh.json: the kernel issues as many scalar as vector instructions and its SIMDs are 65 % busy).
+    __syncthreads();  // (one wave: the list in buf is complete)
+    const u64 mine = (lane < k) ? buf[lane] : ~0ULL;
+    __syncthreads();
+    if (lane < 4) buf[k + lane] = ~0ULL;  // (k + 3 < QTR_KMAX; a pad never counts: nothing is above it)
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < k; j += 4) {
+      const u64 a = buf[j], b = buf[j + 1], c = buf[j + 2], d = buf[j + 3];
+      rank += (int)(a < mine) + (int)(b < mine) + (int)(c < mine) + (int)(d < mine);
+    }
+    if (lane < k) {
+      nbr_idx[(size_t)i * QTR_KMAX + rank] = (int)(u32)mine;
+      nbr_d2[(size_t)i * QTR_KMAX + rank] = __uint_as_float((u32)(mine >> 32));
+    }
+    if (lane == 0) nbr_cnt[i] = k;
+    return;
+  }
+  int n2 = 128;  // (longer lists: the bitonic network in LDS)
   while (n2 < k) n2 <<= 1;
   for (int t = k + lane; t < n2; t += 64) buf[t] = ~0ULL;
   // bitonic sort of n2 (<= 256) packed keys in LDS: ascending (d2, index)
@@ -1028,7 +1053,33 @@ __device__ __forceinline__ bool spfh_swap_roles(float angle1, float angle2) {
   if (x1 <= 1.0f && x2 <= 1.0f && fabsf(x1 - x2) > 5e-7f) return x1 < x2;
   return qm_acosf(x1) > qm_acosf(x2);
 }
-__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f) {
+// The bin of f1 = atan2f(y, x) in the first 11-bin block — floor(11 (f1 + pi) / (2 pi)), evaluated by d_spfh in binary64 from
+// the ROUNDED binary32 angle, with d_pi = 1.0f / (2.0f * (float)M_PI) — decided WITHOUT the arc tangent (qm_atan2f: five
+// binary64 divisions and three square roots for one of eleven answers) wherever that is safe; -1 = "not sure": the caller
+// evaluates the function.  The bin boundaries in f1 are T_k = k / (11 d_pi) - pi, k = 1..10: T_5 < 0 < T_6, and T_k and
+// -T_(11-k) differ by at most 2.3e-7 (d_pi is a rounded 1 / 2 pi), so with A_j = pi - 2 pi j / 11 (j = 5..1: 0.2856 ... 2.5704)
+//     y >= 0:  bin = 5 + #{ j : |phi| >= A_j },      y < 0:  bin = 5 - #{ j : |phi| > A_j }
+// and |phi| is on the far side of A_j exactly when c_j = cos A_j |y| - sin A_j x = r sin(|phi| - A_j) is positive (both
+// angles in [0, pi]).  Sure means: every |c_j| exceeds 1e-6 (|x| + |y|) >= 1e-6 r — then |phi| is more than 1e-6 rad from
+// every A_j, against 1.2e-7 (f1 is the angle rounded to binary32: half an ulp below 4) + 2.3e-7 (T_k against A_j) +
+// 1.3e-7 (|x| + |y|) / r (binary32 rounding of c_j: two products, one difference, two rounded constants) — and the
+// rounded angle falls into the bin the true one does.  y = +-0 is left to the function (atan2f(-0, x < 0) = -pi rounds
+// BELOW -pi: bin 0, not 10), as is anything non-finite or vanishing (NaN compares false; inf - inf is NaN).
+__device__ __forceinline__ int spfh_bin_of_angle(float y, float x) {
+  const float ya = fabsf(y), s = ya + fabsf(x);
+  const float c0 = 0.95949297361449748f * ya - 0.2817325568414295f * x;   // A = 0.2855993321445265
+  const float c1 = 0.6548607339452851f * ya - 0.75574957435425827f * x;   // A = 0.8567979964335799
+  const float c2 = 0.14231483827328512f * ya - 0.98982144188093268f * x;  // A = 1.4279966607226333
+  const float c3 = -0.41541501300188632f * ya - 0.90963199535451844f * x; // A = 1.9991953250116865
+  const float c4 = -0.84125353283118109f * ya - 0.54064081745559778f * x; // A = 2.5703939893007397
+  const float lim = 1e-6f * s;
+  const float low = fminf(fminf(fminf(fabsf(c0), fabsf(c1)), fminf(fabsf(c2), fabsf(c3))), fabsf(c4));
+  if (!(low > lim) || !(s > 1e-30f) || !(s < 1e30f) || ya == 0.f) return -1;
+  const int m = (int)(c0 > 0.f) + (int)(c1 > 0.f) + (int)(c2 > 0.f) + (int)(c3 > 0.f) + (int)(c4 > 0.f);
+  return (y > 0.f) ? 5 + m : 5 - m;
+}
+// (f[0] is left to the caller: yx = the arc tangent's two arguments, see spfh_bin_of_angle)
+__device__ bool dev_pair_features(const float4& p1, const float4& nn1, const float4& p2, const float4& nn2, float* f, float* yx) {
   float dp[3] = {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
   const float f4 = sqrtf(dot4_sse(dp, dp));
   if (f4 == 0.0f) return false;
@@ -1064,7 +1115,8 @@ __device__ bool dev_pair_features(const float4& p1, const float4& nn1, const flo
   float w[3];
   dev_cross(n1c, v, w);
   f[1] = dot4_sse(v, n2c);
-  f[0] = qm_atan2f(dot4_sse(w, n2c), dot4_sse(n1c, n2c));
+  yx[0] = dot4_sse(w, n2c);
+  yx[1] = dot4_sse(n1c, n2c);
   f[2] = f3;
   return true;
 }
@@ -1110,11 +1162,14 @@ __device__ __forceinline__ void d_spfh(const float4* __restrict__ pts, const flo
     const int i = i0 + pi;
     const int j = nbr_list_idx(NL, i, s_k[pi])[t - s_off[pi]];
     if (j == i) continue;
-    float f[3];
-    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f)) continue;
-    // (deciding this bin from five cross products instead of the arc tangent was measured: same kernel time — it is
-    // the role swap's two arc cosines that cost, see spfh_swap_roles)
-    atomicAdd(&cnt[pi][bin11(11 * (((double)f[0] + M_PI) * (double)d_pi))], 1);
+    float f[3], yx[2];
+    if (!dev_pair_features(s_p[pi], s_n[pi], pts[j], normals[j], f, yx)) continue;
+    // (the first block's bin from five cross products instead of the arc tangent: round 2 measured "same kernel time" with
+    // the role swap's two arc cosines still in the loop; with those gone — spfh_swap_roles — the arc tangent was a third
+    // of the kernel's vector instructions, and the batched path is bound by their count: profiles/r6_pmc_fpfh.json)
+    int b1 = spfh_bin_of_angle(yx[0], yx[1]);
+    if (b1 < 0) b1 = bin11(11 * (((double)qm_atan2f(yx[0], yx[1]) + M_PI) * (double)d_pi));
+    atomicAdd(&cnt[pi][b1], 1);
     atomicAdd(&cnt[pi][11 + bin11(11 * (((double)f[1] + 1.0) * 0.5))], 1);
     atomicAdd(&cnt[pi][22 + bin11(11 * (((double)f[2] + 1.0) * 0.5))], 1);
   }
@@ -1185,8 +1240,9 @@ __device__ __forceinline__ void desc_table_insert(u64* __restrict__ table, int m
 __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, const int* __restrict__ nbr_cnt,
                                              const NbrLists NL, float* __restrict__ fpfh, float* __restrict__ norms,
                                              u64* __restrict__ hashes, u64* __restrict__ table, int mask) {
-  __shared__ int s_idx[FPFH_PB][FPFH_CHUNK];
-  __shared__ float s_w[FPFH_PB][FPFH_CHUNK];  // 1 / d^2, or 0 for an entry the reference skips (d^2 == 0)
+  // per staged entry: (byte offset of the neighbour's SPFH row, 1 / d^2 — or 0 for an entry the reference skips, d^2 == 0,
+  // and for the slots past the end of a list: row 0, weight 0)
+  __shared__ __attribute__((aligned(16))) uint2 s_ow[FPFH_PB][FPFH_CHUNK];
   __shared__ int s_k[FPFH_PB];
   __shared__ double s_part[FPFH_PB][33];
   __shared__ float s_vmin[FPFH_PB][33], s_vmax[FPFH_PB][33];
@@ -1204,20 +1260,28 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
 #pragma unroll
   for (int q = 0; q < FPFH_PB; ++q) kmax = max(kmax, s_k[q]);
   const int k = owner ? s_k[pi] : 0;
-  float h = 0.f, vmin = INFINITY, vmax = 0.f;
+  // The loop over a list's entries is BRANCH-FREE (round 6: the kernel's SIMDs were 68 % busy with ~20 instructions per
+  // value, eight of them the scalar bookkeeping of two guards — profiles/r6_pmc_fpfh.json).  A skipped entry (d^2 == 0)
+  // and a slot past the end of the list are staged with weight +0: x * 0 = +0 (an SPFH value is a finite non-negative
+  // sum of increments), and adding +0 changes neither the binary32 sum h (never -0) nor the binary64 one — the bits the
+  // guarded loop produced.  The extreme terms are tracked on the BIT PATTERNS (non-negative floats order like unsigned
+  // integers): the largest as an unsigned maximum, the smallest NON-ZERO one as the minimum of pattern - 1 (+0 wraps to
+  // 0xffffffff and never wins); a NaN's pattern lies above infinity's and sends the block to the reference order below.
+  float h = 0.f;
+  u32 vminb = 0xffffffffu, vmaxb = 0u;
   double part = 0.0;
+  const char* __restrict__ spfh_b = (const char*)spfh + 4 * b;  // (uniform base + a 32-bit byte offset per entry)
   for (int t0 = 0; t0 < kmax; t0 += FPFH_CHUNK) {
     __syncthreads();
     if (lp < FPFH_PB) {
-      int j = 0;
+      u32 off = 0;
       float w = 0.f;
       if (lp < np && t0 + lq < s_k[lp]) {
-        j = nbr_list_idx(NL, i0 + lp, s_k[lp])[t0 + lq];
+        off = (u32)nbr_list_idx(NL, i0 + lp, s_k[lp])[t0 + lq] * 132u;  // (max_voxels < 2^20 rows of 132 bytes)
         const float d2 = nbr_list_d2(NL, i0 + lp, s_k[lp])[t0 + lq];
         w = (d2 == 0) ? 0.f : 1.0f / d2;
       }
-      s_idx[lp][lq] = j;
-      s_w[lp][lq] = w;
+      s_ow[lp][lq] = make_uint2(off, __float_as_uint(w));
     }
     __syncthreads();
     if (owner) {
@@ -1225,27 +1289,29 @@ __device__ __forceinline__ void d_fpfh(const float* __restrict__ spfh, int n, co
       for (int q0 = 0; q0 < m; q0 += 16) {
         float x[16], w[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {  // sixteen independent gathers in flight (entries past m are staged as row 0, weight 0)
-          w[u] = s_w[pi][q0 + u];
-          x[u] = spfh[(size_t)s_idx[pi][q0 + u] * 33 + b];
+        for (int u = 0; u < 16; ++u) {  // sixteen independent gathers in flight
+          const uint2 ow = s_ow[pi][q0 + u];
+          w[u] = __uint_as_float(ow.y);
+          x[u] = *(const float*)(spfh_b + ow.x);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          if (q0 + u < m && w[u] != 0.f) {
-            const float val = x[u] * w[u];
-            h += val;
-            part += (double)val;
-            vmax = fmaxf(vmax, val);
-            vmin = (val > 0.f) ? fminf(vmin, val) : vmin;
-          }
+        for (int u = 0; u < 16; u += 2) {
+          const float v0 = x[u] * w[u], v1 = x[u + 1] * w[u + 1];
+          h += v0;
+          part += (double)v0;
+          h += v1;
+          part += (double)v1;
+          const u32 b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);
+          vmaxb = max(max(b0, b1), vmaxb);
+          vminb = min(min(b0 - 1u, b1 - 1u), vminb);
         }
       }
     }
   }
   if (owner) {
     s_part[pi][b] = part;
-    s_vmin[pi][b] = vmin;
-    s_vmax[pi][b] = vmax;
+    s_vmin[pi][b] = (vminb == 0xffffffffu) ? INFINITY : __uint_as_float(vminb + 1u);
+    s_vmax[pi][b] = __uint_as_float(vmaxb);
   }
   __syncthreads();
   __shared__ float s_out[FPFH_PB][33];

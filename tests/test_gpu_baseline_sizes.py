@@ -607,6 +607,46 @@ def test_connected_registration_without_tuple_test_on_the_bench_pool_matches_ora
     _same(g, o)
 
 
+@pytest.mark.parametrize("pid", [0, 1, 2, 3])
+def test_connected_registration_at_the_metrics_5k_correspondences_matches_oracle(qo16, pool16k, pid):
+    """The metric's size DATA-CONNECTED (bench.py connected_leg.l5k / `connected_l5k`): qtr_register_pair on a 64-beam scan
+    pair at a 0.07 m leaf (n ~ 35-40 k voxels per cloud) with cross check and without the tuple test — the front end's OWN
+    output is 4.2-5.9 k mutual nearest neighbours (reference src/teaser_utils/feature_matcher.cc:113-181), and ONE call
+    registers them (examples/run_global_registration.cpp:206-246).  Every output equals the oracle's stages composed the same
+    way; the registration lands inside the noise bound."""
+    s, t, Tgt = pool16k[pid]
+    h = ql.Handle(0, max_points=131072, max_voxels=65536, max_corr=8192)
+    try:
+        g = h.register_pair(s, t, ql.default_frontend_params(voxel_size=0.07, use_tuple_test=0, seed=pid))
+    finally:
+        h.close()
+    vs, vt, corr, o = _oracle_connected(qo16, s, t, 0.07, True, False, pid)
+    assert 4000 < corr.shape[0] < 6000, corr.shape
+    assert (g["n_src"], g["n_tgt"], g["L"]) == (vs.shape[0], vt.shape[0], corr.shape[0])
+    _same(g, o)
+    assert g["valid"] and g["clique"].size > 300 and g["final_inliers"].size > 300
+    dy = _yaw(g["T"]) - _yaw(Tgt)
+    assert abs(np.arctan2(np.sin(dy), np.cos(dy))) < 5e-3 and np.linalg.norm(g["T"][:3, 3] - Tgt[:3, 3]) < 0.3  # noise bound
+
+
+def test_connected_registration_of_18k_point_clouds_with_5k_correspondences_matches_oracle(qo16):
+    """The headline's n AND L from one input: two independent 18 000-point samplings of the structured scene (no voxel
+    step: the grid would overflow and passes the cloud through), use_tuple_test = 0 -> 4999 mutual nearest neighbours."""
+    a, b, Tgt = synth.dense_scene_pair(18000)
+    h = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=8192)
+    try:
+        g = h.register_pair(a, b, ql.default_frontend_params(voxel_size=0.001, use_tuple_test=0, seed=1))
+    finally:
+        h.close()
+    ds, dt = qo16.fpfh(a, 0.5, 0.75)[2], qo16.fpfh(b, 0.5, 0.75)[2]
+    corr = qo16.match(a, ds, b, dt, True, False, 0.95, 1)
+    assert 4500 < corr.shape[0] < 5500 and (g["n_src"], g["n_tgt"], g["L"]) == (18000, 18000, corr.shape[0])
+    _same(g, qo16.solve(a[corr[:, 0]], b[corr[:, 1]]))
+    assert g["valid"] and g["final_inliers"].size > 20
+    dy = _yaw(g["T"]) - _yaw(Tgt)
+    assert abs(np.arctan2(np.sin(dy), np.cos(dy))) < 5e-3 and np.linalg.norm(g["T"][:3, 3] - Tgt[:3, 3]) < 0.3
+
+
 def test_dense_mode_end_to_end_through_the_whole_path_entry_matches_oracle(qo16):
     """BASELINE configs[4] as ONE registration: two independently sampled 50 000-point clouds and a leaf so small that the
     voxel grid would overflow int32 — pcl::VoxelGrid passes the cloud through unchanged, and so does the reference's

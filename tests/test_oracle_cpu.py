@@ -1201,6 +1201,41 @@ def test_spfh_role_swap_shortcut_logic_against_the_oracle_arithmetic(qo):
     assert np.array_equal((x1 < x2)[fast].astype(np.float32), want[fast])
 
 
+def test_spfh_angle_bin_shortcut_logic_against_the_oracle_arithmetic(qo):
+    """numpy mirror (binary32, no contraction) of the device's shortcut for the first SPFH block's bin (frontend.hip:
+    spfh_bin_of_angle: five cross products against the boundary directions instead of atan2f) against the oracle's plain
+    arithmetic — qm_atan2f (qo_math 0), then floor(11 (f1 + pi) d_pi) in binary64 as pcl::computePointSPFHSignature does:
+    wherever the shortcut claims to be sure it must give that bin.  Inputs: uniform directions, directions within 4e-6 rad of
+    every boundary (both sides, also of the cut at +-pi and of 0), y = +-0, tiny and huge magnitudes."""
+    f32 = np.float32
+    rng = np.random.default_rng(6)
+    d_pi = float(f32(1.0) / (f32(2.0) * f32(np.pi)))
+    T = np.array([k / (11 * d_pi) - np.pi for k in range(0, 12)])
+    n = 400000
+    phi = np.concatenate([rng.uniform(-np.pi, np.pi, n),
+                          (T[rng.integers(0, 12, n)] + rng.uniform(-4e-6, 4e-6, n)),
+                          rng.uniform(-4e-6, 4e-6, n // 4), np.pi - rng.uniform(0, 4e-6, n // 4), -np.pi + rng.uniform(0, 4e-6, n // 4)])
+    r = np.exp(rng.uniform(np.log(1e-12), np.log(1e6), phi.size))
+    y, x = (r * np.sin(phi)).astype(f32), (r * np.cos(phi)).astype(f32)
+    y[:2000:4], y[1:2000:4] = f32(0.0), f32(-0.0)                      # atan2f(-0, x < 0) = -pi rounds below -pi: bin 0
+    f1 = qo.math_fn(0, y, x).astype(np.float64)
+    g = 11.0 * ((f1 + np.pi) * d_pi)
+    want = np.where(g != g, 0, np.clip(np.floor(g), 0, 10)).astype(np.int64)
+    ya, s = np.abs(y), np.abs(y) + np.abs(x)
+    C = [(0.95949297361449748, 0.2817325568414295), (0.6548607339452851, 0.75574957435425827),
+         (0.14231483827328512, 0.98982144188093268), (-0.41541501300188632, 0.90963199535451844),
+         (-0.84125353283118109, 0.54064081745559778)]
+    c = [f32(ca) * ya - f32(sa) * x for ca, sa in C]                   # (float32 products, float32 difference)
+    low = np.minimum.reduce([np.abs(v) for v in c])
+    sure = (low > f32(1e-6) * s) & (s > f32(1e-30)) & (s < f32(1e30)) & (ya != 0)
+    m = sum((v > 0).astype(np.int64) for v in c)
+    got = np.where(y > 0, 5 + m, 5 - m)
+    assert sure[2000:n].mean() > 0.9999 and sure.mean() > 0.4         # (uniform directions: practically always sure)
+    assert not sure[:2000:4].any() and not sure[1:2000:4].any()
+    assert np.array_equal(got[sure], want[sure])
+    assert set(np.unique(want[sure])) == set(range(11))
+
+
 def test_shared_math_header_against_an_independent_libm(qo):
     """include/qtr_math.h (atan2f / acosf / sinf / cosf) is compiled into BOTH the HIP library and the oracle, so their
     agreement is self-agreement; this pins the header itself against numpy's float64 functions rounded once to float32
