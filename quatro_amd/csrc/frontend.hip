@@ -557,6 +557,27 @@ __device__ __forceinline__ int lower_bound_hi(const u64* keys, int n, u32 k) {  
   return lo;
 }
 
+// the same for two keys at once, k0 <= k1: the two chains of dependent loads advance together (a fixed number of
+// halvings, no branch), so the pair costs the round trips of one — k2_ranges is nothing but these round trips (85 % of
+// its wave-cycles parked: profiles/r6_pmc_fpfh.json)
+__device__ __forceinline__ void lower_bound_hi2(const u64* __restrict__ keys, int n, u32 k0, u32 k1, int* r0, int* r1) {
+  if (n <= 0) {
+    *r0 = *r1 = 0;
+    return;
+  }
+  int b0 = 0, b1 = 0, len = n;
+  while (len > 1) {
+    const int half = len >> 1;
+    const u32 a0 = (u32)(keys[b0 + half - 1] >> 32), a1 = (u32)(keys[b1 + half - 1] >> 32);
+    b0 = (a0 < k0) ? b0 + half : b0;
+    b1 = (a1 < k1) ? b1 + half : b1;
+    len -= half;
+  }
+  const u32 a0 = (u32)(keys[b0] >> 32), a1 = (u32)(keys[b1] >> 32);
+  *r0 = b0 + ((a0 < k0) ? 1 : 0);
+  *r1 = b1 + ((a1 < k1) ? 1 : 0);
+}
+
 // points gathered into cell-sorted order (w carries the original index) so that candidate loads are
 // contiguous 16-byte reads instead of a dependent key -> point gather
 __device__ __forceinline__ void d_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted,
@@ -587,8 +608,7 @@ __device__ __forceinline__ void d_ranges(const float4* __restrict__ pts, int n, 
   int s = 0, e = 0;
   if (cy >= 0 && cy <= 255 && cz >= 0 && cz <= 255) {
     const u32 klo = cell_key(max(c[0] - 1, 0), cy, cz), khi = cell_key(min(c[0] + 1, 255), cy, cz);
-    s = lower_bound_hi(sorted, n, klo);
-    e = lower_bound_hi(sorted, n, khi + 1u);
+    lower_bound_hi2(sorted, n, klo, khi + 1u, &s, &e);
   }
   ranges[2 * g] = s;
   ranges[2 * g + 1] = e;

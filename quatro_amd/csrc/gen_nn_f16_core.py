@@ -39,7 +39,15 @@ be 11 wait states old (8-pass) — every fold starts behind two MFMAs of the nex
 v_cndmask three instructions later.
 """
 
+import sys
+
+LDS = "--lds" in sys.argv  # experiment (round 6, VERDICT item 4 ii): the base tile staged ONCE per workgroup through LDS —
+# every wave fetches two of the tile's eight 1 KB pieces with global_load_lds_dwordx4 (the eighth is the next tile's first:
+# it lands in a spare slot), a barrier, then seven ds_read_b128 per wave; three tiles in flight (fabric -> LDS two ahead,
+# LDS -> registers one ahead).  Measured against the register-direct loop in profiles/r6_ab.txt; nn_f16_core_lds.inc is what
+# this flag writes, built into the library only with -DQTR_NN_LDS_STAGE.
 TILE_BYTES = 14 * 32 * 16  # 7168: one tile of either operand table
+LBUF_BYTES = 8192          # an LDS buffer: the tile + the spare piece
 ACC = {"A": 64, "B": 128}
 MBUF = {0: 192, 1: 220}
 
@@ -56,6 +64,27 @@ def load_tile(buf):
         L.append("global_load_dwordx4 %s, %s, s[40:41] offset:%d" % (vr(MBUF[buf] + 4 * j, 4), va, off))
     L += ["s_add_u32 s40, s40, %d" % TILE_BYTES, "s_addc_u32 s41, s41, 0"]
     return L
+
+
+def dma_tile(lbuf):
+    """this wave's two pieces of the tile at the base cursor -> LDS buffer lbuf, then advance the cursor
+    (s36 / s37: LDS addresses of the wave's pieces in buffer 0, s38 / s39 in buffer 1; v48 / v49 their byte offsets)"""
+    a, b = (36, 37) if lbuf == 0 else (38, 39)
+    return ["s_mov_b32 m0, s%d" % a, "global_load_lds_dwordx4 v48, s[40:41]", "s_mov_b32 m0, s%d" % b,
+            "global_load_lds_dwordx4 v49, s[40:41]", "s_add_u32 s40, s40, %d" % TILE_BYTES, "s_addc_u32 s41, s41, 0"]
+
+
+def lds_to_regs(lbuf, buf):
+    """seven fragments of the tile in LDS buffer lbuf -> register buffer buf (v50 / v51: the lane's address in buffer 0 / 1)"""
+    va = "v50" if lbuf == 0 else "v51"
+    return ["ds_read_b128 %s, %s offset:%d" % (vr(MBUF[buf] + 4 * j, 4), va, 1024 * j) for j in range(7)]
+
+
+def top(p_next_buf):
+    """top of a phase that computes from register buffer 1 - p_next_buf: the tile after it goes LDS -> registers, the one after
+    that fabric -> LDS (into the LDS buffer the phase's own tile came from: every wave has read it, see the barrier)"""
+    nb = p_next_buf
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"] + lds_to_regs(nb, nb) + dma_tile(1 - nb)
 
 
 def mfma(dst, c, j, buf):
@@ -124,7 +153,8 @@ def first_phase():
     (the loads were issued q0, tile 0, q1, q2, q3, tile 1: 42 in flight), not when all 28 have"""
     L = []
     for c in range(4):
-        L.append("s_waitcnt vmcnt(%d)" % (28 - 7 * c))
+        # (LDS form: in flight behind q_c are the later query blocks and the two pieces of tile 2)
+        L.append("s_waitcnt vmcnt(%d)" % ((23 - 7 * c) if LDS else (28 - 7 * c)))
         for j in range(7):
             L.append(mfma("A", c, j, 0))
     return L
@@ -154,11 +184,22 @@ asm += ["s_mov_b32 s40, %[blo]", "s_mov_b32 s41, %[bhi]", "s_mov_b32 s44, %[qlo]
         "v_mov_b32 v39, %[frag]", "v_add_u32 v40, 0x1000, v39", "v_lshlrev_b32 v44, 2, %[t0v]", "v_add_u32 v45, 1, v44",
         "v_add_u32 v46, 2, v44", "v_add_u32 v47, 3, v44"]
 # query fragments straight into AGPRs; the lane's row of column block c starts at byte %[qc] of the table
-asm += query_loads(0)
-asm += load_tile(0)  # tile 0 of the slice
-for c in range(1, 4):
-    asm += query_loads(c)
-asm += load_tile(1)  # tile 1 (the tables are padded by two tiles: prefetching past the slice is harmless)
+if not LDS:
+    asm += query_loads(0)
+    asm += load_tile(0)  # tile 0 of the slice
+    for c in range(1, 4):
+        asm += query_loads(c)
+    asm += load_tile(1)  # tile 1 (the tables are padded by two tiles: prefetching past the slice is harmless)
+else:
+    asm += ["s_mov_b32 s36, %[l0]", "s_add_u32 s37, s36, 4096", "s_add_u32 s38, s36, %d" % LBUF_BYTES, "s_add_u32 s39, s37, %d" % LBUF_BYTES,
+            "v_mov_b32 v48, %[dma]", "v_add_u32 v49, 0x1000, v48", "v_mov_b32 v50, %[lrd]", "v_add_u32 v51, %d, v50" % LBUF_BYTES]
+    asm += dma_tile(0) + dma_tile(1)  # tiles 0 and 1 on their way to LDS before anything else
+    for c in range(4):
+        asm += query_loads(c)
+    asm += ["s_waitcnt vmcnt(28)", "s_barrier"]  # the four pieces this wave asked for have landed, and everybody's
+    asm += lds_to_regs(0, 0) + lds_to_regs(1, 1)
+    asm += ["s_waitcnt lgkmcnt(0)", "s_barrier"]  # every wave has tile 0 in registers: its LDS buffer is free
+    asm += dma_tile(0)  # tile 2
 for c in range(4):
     asm += ["v_mov_b32 v%d, 0x7f800000" % (20 + c), "v_mov_b32 v%d, 0x7f800000" % (24 + c), "v_mov_b32 v%d, 0x7f800000" % (28 + c),
             "v_mov_b32 v%d, -1" % (32 + c)]
@@ -166,12 +207,18 @@ asm += first_phase()
 asm += ["s_sub_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 0", "s_cbranch_scc1 L_f16_tailA_%="]
 A("L_f16_loop_%=:")
 # A holds an unfolded tile, buffer 1 holds (or is receiving) the next one
-asm += load_tile(0)
-asm += ["s_waitcnt vmcnt(7)"]
+if not LDS:
+    asm += load_tile(0)
+    asm += ["s_waitcnt vmcnt(7)"]
+else:
+    asm += top(0)  # tile (p + 1) LDS buffer 0 -> register buffer 0, tile (p + 2) -> LDS buffer 1
 asm += phase("B", 1, "A")
 asm += ["s_sub_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 0", "s_cbranch_scc1 L_f16_tailB_%="]
-asm += load_tile(1)
-asm += ["s_waitcnt vmcnt(7)"]
+if not LDS:
+    asm += load_tile(1)
+    asm += ["s_waitcnt vmcnt(7)"]
+else:
+    asm += top(1)
 asm += phase("A", 0, "B")
 asm += ["s_sub_u32 s42, s42, 1", "s_cmp_eq_u32 s42, 0", "s_cbranch_scc0 L_f16_loop_%="]
 A("L_f16_tailA_%=:")
@@ -186,23 +233,29 @@ for c in range(4):
 
 clob = ['"v%d"' % i for i in list(range(20, 48)) + list(range(64, 248))] + ['"a%d"' % i for i in range(112)]
 clob += ['"s%d"' % i for i in [40, 41, 42, 44, 45] + list(range(46, 62))] + ['"vcc"', '"scc"', '"memory"']
+if LDS:
+    clob += ['"s%d"' % i for i in (36, 37, 38, 39)] + ['"v%d"' % i for i in (48, 49, 50, 51)] + ['"m0"']
 
 print("// generated by gen_nn_f16_core.py — do not edit (see that file for the register map and the schedule)")
 print("// One item of k_nn_f16: 4 x 32 query columns of this wave (the lane's row of column block c starts at byte qoff[c] of")
 print("// the query table: any row, so a list of rows needs no gathered copy) against `ntiles` base tiles starting at `base`;")
 print("// running best / second best (scaled) and the tile in which the best last changed, per column block.")
-print("__device__ __forceinline__ void nn_f16_core(const uint4* query, const u32 (&qoff)[4], const uint4* base, int ntiles, int t_begin,")
-print("                                            u32 frag_bytes,")
+print("__device__ __forceinline__ void nn_f16_core%s(const uint4* query, const u32 (&qoff)[4], const uint4* base, int ntiles, int t_begin," % ("_lds" if LDS else ""))
+print("                                            u32 frag_bytes,%s" % (" u32 lds_base, int wave," if LDS else ""))
 print("                                            float (&b1)[4], float (&b2)[4], int (&it1)[4]) {")
 print("  const u32 qlo = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)query), qhi = __builtin_amdgcn_readfirstlane((u32)((uintptr_t)query >> 32));")
 print("  const u32 blo = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)base), bhi = __builtin_amdgcn_readfirstlane((u32)((uintptr_t)base >> 32));")
 print("  const int nt = __builtin_amdgcn_readfirstlane(ntiles), t0 = __builtin_amdgcn_readfirstlane(t_begin);")
+if LDS:
+    print("  // (LDS addresses: two buffers of 8 KB at lds_base; this wave's pieces are wave and wave + 4 of a tile's eight KB)")
+    print("  const u32 l0 = __builtin_amdgcn_readfirstlane(lds_base + 1024u * (u32)wave);")
+    print("  const u32 dma = frag_bytes + 1024u * (u32)wave, lrd = lds_base + frag_bytes;")
 print("  asm volatile(")
 for a in asm:
     print('      "%s\\n"' % a)
 outs = ", ".join('[b1%d] "=&v"(b1[%d]), [b2%d] "=&v"(b2[%d]), [it%d] "=&v"(it1[%d])' % (c, c, c, c, c, c) for c in range(4))
 print("      : %s" % outs)
 print('      : [qlo] "s"(qlo), [qhi] "s"(qhi), [blo] "s"(blo), [bhi] "s"(bhi), [nt] "s"(nt), [t0v] "v"(t0), [frag] "v"(frag_bytes),')
-print('        [q0] "v"(qoff[0]), [q1] "v"(qoff[1]), [q2] "v"(qoff[2]), [q3] "v"(qoff[3])')
+print('        [q0] "v"(qoff[0]), [q1] "v"(qoff[1]), [q2] "v"(qoff[2]), [q3] "v"(qoff[3])%s' % (', [l0] "s"(l0), [dma] "v"(dma), [lrd] "v"(lrd)' if LDS else ""))
 print("      : %s);" % ", ".join(clob))
 print("}")

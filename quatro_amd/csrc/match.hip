@@ -690,6 +690,9 @@ __global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, Match
 // loop is the hand-scheduled block of nn_f16_core.inc (generated by gen_nn_f16_core.py: register map, schedule and the
 // wait states it has to respect are documented there).  ~250 VGPRs + 112 AGPRs: one workgroup per compute unit.
 #include "nn_f16_core.inc"
+#ifdef QTR_NN_LDS_STAGE  // experiment build (tests/gpu_r6_nnlds.sh): the base tile staged through LDS, see gen_nn_f16_core.py --lds
+#include "nn_f16_core_lds.inc"
+#endif
 // -DQTR_NN_TIMING (diagnostic build, tests/probe/nn_stamps.py): thread 0 of every workgroup records the shader clock and
 // the 100 MHz wall clock at five points of its first item
 #ifdef QTR_NN_TIMING
@@ -816,8 +819,14 @@ __global__ __launch_bounds__(256, 1) void k_nn_f16(ViewExt<MatchView> x, MatchVi
           qoff[c] = ((u32)((row >> 5) * NNH_CHUNKS + half) * 32u + (u32)(row & 31)) * 16u;
         }
       }
+#ifdef QTR_NN_LDS_STAGE
+      __shared__ __attribute__((aligned(16))) uint4 s_nn_tiles[2 * 512];  // two 8 KB buffers
+      nn_f16_core_lds(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
+                      ((u32)half * 32u + (u32)col) * 16u, (u32)(uintptr_t)s_nn_tiles, wave, b1, b2, it1);
+#else
       nn_f16_core(D.queryH, qoff, D.baseH + (size_t)t_begin * (NNH_CHUNKS * 32), t_end - t_begin, t_begin,
                   ((u32)half * 32u + (u32)col) * 16u, b1, b2, it1);
+#endif
     NN_STAMP(3)
     } else {
 #pragma unroll
@@ -1141,20 +1150,26 @@ __global__ __launch_bounds__(256) void k_nn_finish_f16(ViewExt<MatchView> x, Mat
 // whose filter value is at most the row's threshold (k_nn_finish_f16: the leader's value plus twice the rounding bound) —
 // two or three near-ties, typically — so the listed rows go through the same 7-MFMA chain once more, this time
 // comparing every entry with the row's threshold; the (row, base row) pairs that are not ABOVE it (a NaN entry — possible
-// when the descriptors are outside the filter's range — passes) get the exact flann::L2 evaluation.  A workgroup takes
-// 128 listed rows (32 per wave) and a slice of the base tiles (fragments of the next tiles prefetched).
-// Round 5: every WAVE collects its passing pairs in a list of its own (LDS, 512 entries) and evaluates the list DENSELY
-// — 64 pairs at a time, one per lane, the 32 listed rows' descriptors staged in LDS once, the running minimum of every
-// listed row in LDS, ONE global atomic per row and item at the end — whenever it fills, and when the slice is through.
-// Dense un-voxelised clouds are what this is for: 40 % of the rows of a 50 000-point scan of flat surfaces are listed
-// (near-identical descriptors), each with 500 - 2000 base rows under its threshold, 15 million pairs per direction.  The
-// round-4 form evaluated a pair where it turned up (a sparse loop over the 16 entries of every lane: a tenth of the lanes
-// busy) with a global 64-bit atomic each, or — up to 2048 pairs per workgroup — from one workgroup-wide list behind a
-// barrier: 1.0 ms per direction there, 0.2 now; the voxelised scans (a thousand listed rows, two or three pairs each)
-// never fill a list and pay one vote per tile for it.  A tile that ALONE holds more pairs than a list (an infinite
-// threshold: no leader, MC_UNSAFE) is evaluated where it stands, so the kernel is complete whatever passes — in the limit
-// an exact scan of every pair.   grid (query groups, slices, pairs).
-#define RCW_CAP 512
+// when the descriptors are outside the filter's range — passes) get the exact flann::L2 evaluation.
+// Round 6: the unit of work is a WAVE with 128 listed rows — four column blocks of 32 stationary in registers, like the
+// main kernel's waves — and a slice of the base tiles; the waves of the launch are dealt over (row group, slice) items on
+// their own (nothing in here is shared between the waves of a workgroup).  Until then a wave held 32 rows: in-kernel
+// stamps (tests/probe/recheck_stamps.py) put a dense-mode launch at 1455 clocks per 32 x 32 tile — one dependent chain
+// of seven MFMAs per tile (224 clocks of matrix pipe) behind a base tile's L2 round trip, 4.7 % of the time in the exact
+// evaluation — 366 us per item with 16 445 listed rows; four independent chains per base tile amortise the tile's loads
+// and hide one another's latency.
+// Round 5: every wave collects its passing pairs in a list of its own (LDS) and evaluates the list DENSELY — 64 pairs at
+// a time, one per lane, straight from the descriptor tables (the running minimum of every listed row in LDS, ONE global
+// atomic per row and item at the end) — whenever it fills, and when the slice is through.  Dense un-voxelised clouds are
+// what this is for: a third of the rows of a 50 000-point scan of flat surfaces are listed (near-identical descriptors),
+// each with hundreds of base rows under its threshold.  The round-4 form evaluated a pair where it turned up (a sparse
+// loop over the 16 entries of every lane: a tenth of the lanes busy) with a global 64-bit atomic each; the voxelised
+// scans (a thousand listed rows, two or three pairs each) never fill a list.  A tile that ALONE holds more pairs than a
+// list (an infinite threshold: no leader, MC_UNSAFE) is evaluated where it stands, so the kernel is complete whatever
+// passes — in the limit an exact scan of every pair.   grid (x, y, pairs): x * y workgroups of four waves per pair.
+#define RCW_CAP 1024
+#define RC_QB 4            // column blocks of 32 listed rows per wave
+#define RC_ROWS (32 * RC_QB)
 __device__ __forceinline__ float recheck_exact_dist(const float* __restrict__ a, const float* __restrict__ b) {
   float result = 0.f;  // flann::L2's accumulation order
 #pragma unroll
@@ -1171,18 +1186,15 @@ __device__ __forceinline__ void recheck_exact_pair(const float* __restrict__ a, 
   const float result = recheck_exact_dist(a, b);
   if (result == result) atomicMin(best, ((u64)__float_as_uint(result) << 32) | (u32)base_row);  // (NaN never wins)
 }
-template <bool EXT>
-__global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
-  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  const NnDir& D = V.d[dir];
-  const int nrows = V.mcounts[D.rc_slot];
-  if (nrows <= 0) return;
 #define RC_STAMP(pt) if (dir == 0) { QTR_STAMP(STAMP_RECHECK, pt) } else { QTR_STAMP(STAMP_RECHECK1, pt) }
-  RC_STAMP(0)
-  __shared__ u32 s_wc[4][RCW_CAP];   // per wave: passing pairs, (listed row of the wave's 32) << 20 | base row
-  __shared__ u64 s_wbest[4][32];     // per wave: packed (exact distance bits << 32 | base row) minimum of each listed row
-  __shared__ float s_a[4][32][33];   // per wave: the descriptors of its listed rows (staged when the first list is evaluated)
-  __shared__ int s_wctl[4][4];       // per wave: the list's reservation counter and overflow marks (see the sweep)
+#define RC_SMALL_ROWS 2048  // up to here the one-block form
+// (the kernel's body for QB column blocks of 32 listed rows per wave: 4 is the throughput form — dense clouds, thousands of
+// listed rows —, 1 the latency form a scan pair's thousand rows take: with four blocks a wave of theirs has three tile visits
+// behind 28 KB of staged fragments and a launch took 12.4 us, with one block eleven visits behind 7 KB: 10.8)
+template <int QB>
+__device__ __forceinline__ void recheck_items(const MatchView& V, const NnDir& D, const int dir, const int nrows, u32 (&s_wc)[4][RCW_CAP],
+                                              u64 (&s_wbest)[4][32 * RC_QB], int (&s_wrow)[4][32 * RC_QB], int (&s_wctl)[4][4],
+                                              h8* __restrict__ s_q /* [column block][chunk pair][lane]: the group's fragments */) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, half = lane >> 5;
   const u32 frag = (u32)half * 32u + (u32)col;
   const int ntiles = D.nb_pad / 32;
@@ -1192,110 +1204,151 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
   const float* __restrict__ A = D.A;
   const float* __restrict__ B = dir ? V.fpfh_j : V.fpfh_i;
   const int nb = D.nb;
-  const int qgroups = (nrows + 127) / 128;
-  // work items = (group of 128 listed rows) x (slice of the base tiles); the launch's workgroups are dealt over them with
-  // as many slices per group as there are workgroups for it: a hundred listed rows (direction 1 of a scan pair: ONE
-  // group) then take one tile per workgroup — one round trip — instead of nine behind one another in 64 of 512 workgroups
+  const int qgroups = (nrows + (32 * QB) - 1) / (32 * QB);
+  // work items = (group of 128 listed rows) x (slice of the base tiles), dealt over the launch's workgroups with as many
+  // slices per group as there are workgroups for it; the four waves of a workgroup take a quarter of the slice each and
+  // share the group's 28 KB of query fragments through LDS — fetched ONCE per workgroup: with every wave fetching its own
+  // (the first round-6 form) a thousand listed rows cost 58 MB of fragment traffic per launch, 6 us of the headline's
+  // launch before its first MFMA.  A thousand listed rows (direction 1 of a scan pair: nine groups) then take three tiles
+  // per wave — one round trip — and the 16 k rows of a dense cloud a hundred.
   const int nwg = gridDim.x * gridDim.y, wid = blockIdx.y * gridDim.x + blockIdx.x;
-  const int nsl = max(1, min(ntiles, nwg / qgroups)), per = (ntiles + nsl - 1) / nsl;
+  const int nsl = max(1, min((ntiles + 3) / 4, nwg / qgroups)), per_wg = (ntiles + nsl - 1) / nsl, per = (per_wg + 3) / 4;
   u32* __restrict__ wc = &s_wc[wave][0];
   u64* __restrict__ wbest = &s_wbest[wave][0];
+  int* __restrict__ wrow = &s_wrow[wave][0];
+  int* __restrict__ wctl = &s_wctl[wave][0];  // [0] places reserved, [1] first tile that did not fit, [2] entries that did
   for (int item = wid; item < qgroups * nsl; item += nwg) {
-    const int qg = item / nsl, t0 = (item - qg * nsl) * per, t1 = min(ntiles, t0 + per);
-    const int qtile = qg * 4 + wave;
-    const int slot = qtile * 32 + col;
-    h8 q[7], m0[7], m1[7], m2[7];
-    {
-      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is listed)
+    const int qg = item / nsl, T0 = (item - qg * nsl) * per_wg, T1 = min(ntiles, T0 + per_wg);
+    const int t0 = T0 + wave * per, t1 = min(T1, t0 + per);
+    // everything that does not wait for the fragments goes out first: the wave's first base tile, its thresholds (one
+    // round trip beside the two of the fragment staging instead of behind them: a launch on a thousand listed rows is
+    // five dependent round trips and three tiles)
+    h8 m0[7], m1[7];
+    float thr[QB];
 #pragma unroll
-      for (int m = 0; m < 7; ++m) q[m] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + half) * 32 + (qc & 31)];
+    for (int j = 0; j < 7; ++j) m0[j] = baseH[((size_t)min(t0, ntiles + 1) * NNH_CHUNKS + 2 * j) * 32 + frag];
+#pragma unroll
+    for (int cb = 0; cb < QB; ++cb) {
+      const int slot = qg * (32 * QB) + cb * 32 + col;
+      thr[cb] = (slot < nrows) ? V.recheck_thr[slot] * (NNH_S * NNH_S) + 0.0f : 0.f;  // (+ 0: never -0, see tile_mask)
     }
-    const bool live = slot < nrows;
-    const float thr = live ? V.recheck_thr[slot] * (NNH_S * NNH_S) : 0.f;
-    const int my_row = live ? V.recheck_rows[slot] : 0;
-    if (lane < 32) wbest[lane] = ~0ULL;
-    int wn = 0;             // (uniform) pairs in the wave's list
-    bool a_staged = false;  // (uniform)
-    // the wave's list, densely: lane e takes pair e
+    __syncthreads();  // (the previous item's fragments have been read)
+    for (int e = threadIdx.x; e < QB * 7 * 64; e += 256) {
+      const int cb = e / (7 * 64), m = (e - cb * 7 * 64) >> 6, l = e & 63;
+      const int slot = qg * (32 * QB) + cb * 32 + (l & 31);
+      const int qc = (slot < nrows) ? qcol[slot] : 0;  // (rows past the list: any column; nothing of theirs is listed)
+      s_q[e] = queryH[((size_t)(qc >> 5) * NNH_CHUNKS + 2 * m + (l >> 5)) * 32 + (qc & 31)];
+    }
+    __syncthreads();
+    if (t0 < t1) {  // (uniform per wave: the last waves of a short slice have nothing)
+    h8 q[QB][7];
+    bool live[QB];
+#pragma unroll
+    for (int cb = 0; cb < QB; ++cb) {
+      const int slot = qg * (32 * QB) + cb * 32 + col;
+      live[cb] = slot < nrows;
+#pragma unroll
+      for (int m = 0; m < 7; ++m) q[cb][m] = s_q[(cb * 7 + m) * 64 + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the previous item's reads of the wave's LDS are through)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = lane; e < (32 * QB); e += 64) {
+      const int slot = qg * (32 * QB) + e;
+      wrow[e] = (slot < nrows) ? V.recheck_rows[slot] : -1;
+      wbest[e] = ~0ULL;
+    }
+    if (lane == 0) {
+      wctl[0] = 0;
+      wctl[1] = 0x7fffffff;
+      wctl[2] = 0x7fffffff;
+    }
+    int wn = 0;  // (uniform) pairs in the wave's list
+#ifdef QTR_NN_TIMING
+    long long rc_drain_clk = 0, rc_drain_pairs = 0, rc_drains = 0;  // (tests/probe/recheck_stamps.py: the exact evaluation's share)
+#define RC_DRAIN_T0 const long long rc_t0_ = clock64(); rc_drain_pairs += wn; ++rc_drains;
+#define RC_DRAIN_T1 rc_drain_clk += clock64() - rc_t0_;
+#else
+#define RC_DRAIN_T0
+#define RC_DRAIN_T1
+#endif
+    // the wave's list, densely: lane e takes pair e, both rows straight from the descriptor tables (a listed row's 132
+    // bytes are read by every pair it takes part in: they stay in the unit's cache)
     auto drain = [&]() __attribute__((always_inline)) {
-      if (!a_staged && wn <= 64) {
-        // a handful of pairs (the voxelised scans: two or three per listed row over the whole sweep): one pair per lane,
-        // both rows straight from the tables — staging the wave's 32 descriptors for them cost more than the evaluation
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const u32 en = lane < wn ? wc[lane] : 0u;
-        const int c = (int)(en >> 20), brow = (int)(en & 0xfffffu);
-        const int rc = __shfl(my_row, c, 64);  // (lanes 0..31 hold the wave's listed rows)
-        if (lane < wn && brow < nb) {
-          const float result = recheck_exact_dist(A + (size_t)rc * 33, B + (size_t)brow * 33);
-          if (result == result) atomicMin(&wbest[c], ((u64)__float_as_uint(result) << 32) | (u32)brow);  // (NaN never wins)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        wn = 0;
-        return;
-      }
-      if (!a_staged) {
-        a_staged = true;
-        for (int i = lane; i < 32 * 33; i += 64) {
-          const int c = i / 33, e = i - c * 33, sl = qtile * 32 + c;
-          s_a[wave][c][e] = (sl < nrows) ? A[(size_t)V.recheck_rows[sl] * 33 + e] : 0.f;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the list and the stage are the wave's own: LDS operations of
-      __builtin_amdgcn_wave_barrier();                        // one wave complete in order)
+      RC_DRAIN_T0
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the list is the wave's own: LDS operations of one wave
+      __builtin_amdgcn_wave_barrier();                        // complete in order)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       for (int e = lane; e < wn; e += 64) {
         const u32 en = wc[e];
         const int c = (int)(en >> 20), brow = (int)(en & 0xfffffu);
         if (brow < nb) {  // (not a pad row of the last tile)
-          const float result = recheck_exact_dist(&s_a[wave][c][0], B + (size_t)brow * 33);
+          const float result = recheck_exact_dist(A + (size_t)wrow[c] * 33, B + (size_t)brow * 33);
           if (result == result) atomicMin(&wbest[c], ((u64)__float_as_uint(result) << 32) | (u32)brow);  // (NaN never wins)
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       wn = 0;
+      RC_DRAIN_T1
     };
     auto load = [&](h8 (&m)[7], int t) __attribute__((always_inline)) {
       t = min(t, ntiles + 1);  // (the table is padded by two tiles: running ahead of the slice is harmless)
 #pragma unroll
       for (int j = 0; j < 7; ++j) m[j] = baseH[((size_t)t * NNH_CHUNKS + 2 * j) * 32 + frag];
     };
-    // which of the lane's 16 entries of tile t pass: sixteen compares into a mask
-    auto tile_mask = [&](const h8 (&m)[7]) __attribute__((always_inline)) -> u32 {
-      f32x16 acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // which of the lane's 4 x 16 entries of tile t pass: bit 16 cb + r.  Two column blocks' chains at a time (independent
+    // accumulators: the matrix pipe works on one while the other's result is still on its way)
+    auto tile_mask = [&](const h8 (&m)[7]) __attribute__((always_inline)) -> u64 {
+      u64 pass = 0;
+      const f32x16 zero16 = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      // "entry r is above the threshold" is the SIGN of thr - acc[r], shifted into the mask by one v_alignbit: two vector
+      // instructions per entry and no compare whose mask has to travel through a scalar register (the first form — compare,
+      // select, or — was 3.5 with its wait states and kept the sweep at 3280 clocks per visit against 896 of matrix pipe).
+      // acc = thr gives +0 (thr is never -0): not above.  A threshold of +inf (no leader; descriptors outside the filter's
+      // range, where an entry may be inf or NaN and inf - inf has no sign to speak of) passes everything without looking.
+      auto fails = [&](const f32x16& acc, float th) __attribute__((always_inline)) -> u32 {
+        u32 f = 0;  // bit 15 - r: entry r FAILS
 #pragma unroll
-      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[j], acc, 0, 0, 0);
-      u32 pass = 0;
+        for (int r = 0; r < 16; ++r) f = __builtin_amdgcn_alignbit(f, __float_as_uint(th - acc[r]), 31);
+        return (th == INFINITY) ? 0xffffu : (__brev(~f) >> 16);  // bit r: entry r passes
+      };
+      if constexpr (QB == 1) {
+        f32x16 acc = zero16;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pass |= !(acc[r] > thr) ? (1u << r) : 0u;
-      return live ? pass : 0u;
+        for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[0][j], acc, 0, 0, 0);
+        pass = live[0] ? (u64)fails(acc, thr[0]) : 0ULL;
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < QB; cb += 2) {
+          f32x16 acc0 = zero16, acc1 = zero16;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[cb][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(m[j], q[cb + 1][j], acc1, 0, 0, 0);
+          }
+          const u32 p0 = live[cb] ? fails(acc0, thr[cb]) : 0u, p1 = live[cb + 1] ? fails(acc1, thr[cb + 1]) : 0u;
+          pass |= (u64)(p0 | (p1 << 16)) << (16 * cb);
+        }
+      }
+      return pass;
     };
-    auto append = [&](u32 pass, int t, int at) __attribute__((always_inline)) {
+    auto append = [&](u64 pass, int t, int at) __attribute__((always_inline)) {
       while (pass) {
-        const int r = __ffs((int)pass) - 1;
+        const int e = __ffsll((unsigned long long)pass) - 1, cb = e >> 4, r = e & 15;
         pass &= pass - 1;
-        wc[at++] = ((u32)col << 20) | (u32)(t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));  // (row < 2^20: QTR_NN_MAX_ROWS)
+        wc[at++] = ((u32)(cb * 32 + col) << 20) | (u32)(t * 32 + 8 * (r >> 2) + 4 * half + (r & 3));  // (row < 2^20: QTR_NN_MAX_ROWS)
       }
     };
     RC_STAMP(1)
-    // ---- the sweep as the voxelised scans need it: three tiles in flight (a workgroup's slice is a handful of tiles and
-    // every one of them is an L2 round trip), the few passing pairs appended to the list; a list that would overflow ends it
-    // (a lane with pairs reserves their places with ONE LDS atomic — no vote, no scan on the path of the tiles that hold
-    // nothing; the first reservation that does not fit marks its tile, and what was reserved before it is a prefix of
+    // ---- the sweep as the voxelised scans need it: the few passing pairs appended to the list; a list that would overflow
+    // ends it (a lane with pairs reserves their places with ONE LDS atomic — no vote, no scan on the path of the tiles that
+    // hold nothing; the first reservation that does not fit marks its tile, and what was reserved before it is a prefix of
     // the list: reservations only grow)
-    int* __restrict__ wctl = &s_wctl[wave][0];  // [0] places reserved, [1] first tile that did not fit, [2] entries that did
-    if (lane == 0) {
-      wctl[0] = 0;
-      wctl[1] = 0x7fffffff;
-      wctl[2] = 0x7fffffff;
-    }
     auto hot = [&](const h8 (&m)[7], int t) __attribute__((always_inline)) {
-      const u32 pass = tile_mask(m);
+      const u64 pass = tile_mask(m);
       if (pass) {
-        const int cnt = __popc(pass), at = atomicAdd(&wctl[0], cnt);
+        const int cnt = __popcll(pass), at = atomicAdd(&wctl[0], cnt);
         if (at + cnt <= RCW_CAP) {
           append(pass, t, at);
         } else {
@@ -1304,20 +1357,12 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
         }
       }
     };
-    if (t0 < t1) {
-      load(m0, t0);
-      load(m1, t0 + 1);
-    }
-    for (int t = t0; t < t1; t += 3) {
-      load(m2, t + 2);
+    for (int t = t0; t < t1; t += 2) {  // (m0 holds tile t0 since the top of the item)
+      load(m1, t + 1);
       hot(m0, t);
       if (t + 1 < t1) {
-        load(m0, t + 3);
+        load(m0, t + 2);
         hot(m1, t + 1);
-      }
-      if (t + 2 < t1) {
-        load(m1, t + 4);
-        hot(m2, t + 2);
       }
       if (__builtin_amdgcn_readfirstlane(wctl[1]) != 0x7fffffff) break;  // a list overflowed: the dense loop takes over
     }
@@ -1333,12 +1378,12 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
     if (ovf >= 0) {
       load(m0, ovf);
       for (int t = ovf; t <= t1; ++t) {
-        u32 pass = 0;
+        u64 pass = 0;
         int tot = 0, at = 0;
         if (t < t1) {
           load(m1, t + 1);
           pass = tile_mask(m0);
-          at = wave_excl_scan_i32(__popc(pass), &tot);
+          at = wave_excl_scan_i32(__popcll(pass), &tot);
         }
         if (t == t1 || wn + tot > RCW_CAP) {
           if (wn > 0) drain();
@@ -1346,10 +1391,10 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
         }
         if (tot > RCW_CAP) {  // more than a list holds in ONE tile (infinite thresholds): evaluated where they stand
           while (pass) {
-            const int r = __ffs((int)pass) - 1;
+            const int e = __ffsll((unsigned long long)pass) - 1, cb = e >> 4, r = e & 15;
             pass &= pass - 1;
-            const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (brow < nb) recheck_exact_pair(A + (size_t)my_row * 33, B + (size_t)brow * 33, &D.best[my_row], brow);
+            const int brow = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3), row = wrow[cb * 32 + col];
+            if (brow < nb) recheck_exact_pair(A + (size_t)row * 33, B + (size_t)brow * 33, &D.best[row], brow);
           }
         } else if (tot > 0) {
           append(pass, t, wn + at);
@@ -1360,14 +1405,52 @@ __global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x,
       }
     }
     RC_STAMP(3)
-    if (lane < 32) {  // (lanes 0..31 hold the wave's 32 listed rows: slot, my_row)
-      const u64 b = wbest[lane];
-      if (live && b != ~0ULL) atomicMin(&D.best[my_row], b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int e = lane; e < (32 * QB); e += 64) {
+      const u64 b = wbest[e];
+      const int row = wrow[e];
+      if (row >= 0 && b != ~0ULL) atomicMin(&D.best[row], b);
     }
     RC_STAMP(4)
+#ifdef QTR_NN_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 32 && blockIdx.y == 0 && blockIdx.z == 0) {
+      unsigned long long(*g)[2] = g_stamp[dir == 0 ? STAMP_RECHECK : STAMP_RECHECK1][blockIdx.x];
+      g[5][0] = (unsigned long long)rc_drain_clk;
+      g[5][1] = (unsigned long long)rc_drain_pairs;
+      g[6][0] = (unsigned long long)rc_drains;
+      g[6][1] = (unsigned long long)(t1 - t0);
+      g[7][0] = (unsigned long long)nrows;
+      g[7][1] = (unsigned long long)(qgroups * nsl);
+    }
+#endif
+    }  // t0 < t1
   }
-#undef RC_STAMP
+#undef RC_DRAIN_T0
+#undef RC_DRAIN_T1
 }
+
+template <bool EXT>
+__global__ __launch_bounds__(256, 2) void k_recheck_filter(ViewExt<MatchView> x, MatchView one, int dir) {
+  const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const NnDir& D = V.d[dir];
+  const int nrows = V.mcounts[D.rc_slot];
+  if (nrows <= 0) return;
+  RC_STAMP(0)
+  __shared__ u32 s_wc[4][RCW_CAP];      // per wave: passing pairs, (listed row of the wave's 128) << 20 | base row
+  __shared__ u64 s_wbest[4][RC_ROWS];   // per wave: packed (exact distance bits << 32 | base row) minimum of each listed row
+  __shared__ int s_wrow[4][RC_ROWS];    // per wave: its listed rows (source / target row ids; -1 past the end of the list)
+  __shared__ int s_wctl[4][4];          // per wave: the list's reservation counter and overflow marks (see the sweep)
+  __shared__ __attribute__((aligned(16))) h8 s_q[RC_QB * 7 * 64];
+  if (nrows <= RC_SMALL_ROWS)
+    recheck_items<1>(V, D, dir, nrows, s_wc, s_wbest, s_wrow, s_wctl, s_q);
+  else
+    recheck_items<RC_QB>(V, D, dir, nrows, s_wc, s_wbest, s_wrow, s_wctl, s_q);
+}
+
+#undef RC_STAMP
 
 // exact re-decision of the listed rows (list length read on the device).  A workgroup takes EIGHT listed rows at a
 // time: their 33 values (and the -2x copies the approximate chain needs) sit in LDS, where every lane reads them with

@@ -310,6 +310,251 @@ __global__ __launch_bounds__(GB2_THREADS, EXT ? 7 : 8) void k_graph_build(ViewEx
   }
 }
 
+// K9+K10+K11 on the MATRIX PIPE (round 6; VERDICT rounds 3-5: "screen the predicate on the matrix pipe").  Same strips, same
+// outputs, same binary64 decision for whatever the screen leaves open — but the two squared TIM lengths of a 32 x 32 block of
+// pairs come out of two v_mfma_f32_32x32x16_f16 instead of 12 packed vector instructions per row of 64:
+//     R = p . p' - |p|^2 / 2 - |p'|^2 / 2 = -|p - p'|^2 / 2
+// with every coordinate (relative to correspondence 0: a translation changes no distance) split in two binary16 halves,
+// x = x1 + x2 + eps, |eps| <= 2^-22 |x|, and a = -|p|^2 / 2 likewise: K = 16 exactly —
+//     row operand    [x1 x1 x2 x2 | y1 y1 y2 y2 | z1 z1 z2 z2 | a1 a2 1 1]
+//     column operand [x1 x2 x1 x2 | y1 y2 y1 y2 | z1 z2 z1 z2 | 1 1 a1 a2]
+// (a binary16 x binary16 product is exact in binary32; the accumulation is the matrix unit's).  Error of R against the true
+// -|p - p'|^2 / 2 of the binary32 points, with M = |p|^2 + |p'|^2: the halves' truncation 2 x 2^-22 sum |x x'| <= 2^-22 M,
+// |p|^2 rounded to binary32 after three roundings <= 1.5 u M (u = 2^-24), its two-way split 2^-23 M, the origin subtraction
+// <= u M, the unit's accumulation <= 16 u sum |terms| <= 16.1 u M (the budget match.hip measured and uses: <= 5.5 u there) —
+// 27.6 u M; delta = 1.8e-6 (M_s + M_t) + 2e-6 bounds the error of BOTH D = R_s - R_t = (t - s) / 2 and P = -(R_s + R_t) =
+// (s + t) / 2, M_s / M_t the largest row norm + the largest column norm of the tile.  The predicate (s - t)^2 <= 2 beta^2
+// (s + t) - beta^4 is z = D^2 - beta^2 P + beta^4 / 4 <= 0, and z is off by <= 2 |D| delta + delta^2 + beta^2 delta + its own
+// rounding (<= 4u D^2 near the threshold: <= 0.07 x 2 |D| delta, since |D| <= M_s + M_t); a pair is decided by the screen
+// only when |z| > 2.2 |D| delta + 1.1 (beta^2 delta + delta^2) + 1e-7 and P > 0.505 beta^2 + delta (s + t > 1.01 beta^2: the
+// squared form is valid, as in the other two kernels); the rest — a band ~1e-4 of the pairs wide at +-50 m, TIMs shorter
+// than beta — and every pair of a tile whose norms leave binary16's range (or are not finite) gets pair_consistent(), the
+// reference expression in binary64: the bit matrix is identical to the other two kernels' (tests/gpu_graph_bench.py).
+// Per entry the vector unit still does: P, D, -beta^2 P + beta^4 / 4, z (four packed instructions per two entries), the
+// margin (one fma), |z| - margin (one), two sign-bit shifts, half a min3 for the short-TIM test: 6.5 — against 12 + 5.
+#define GBM_KDELTA 1.8e-6f
+typedef _Float16 gbm_h8 __attribute__((ext_vector_type(8)));
+typedef float gbm_f16x __attribute__((ext_vector_type(16)));
+struct GbmRec {
+  gbm_h8 lo, hi;  // K slots 0..7, 8..15
+};
+__device__ __forceinline__ void gbm_records(float x, float y, float z, GbmRec& row, GbmRec& colr, float& n_out) {
+  const _Float16 x1 = (_Float16)x, y1 = (_Float16)y, z1 = (_Float16)z;
+  const _Float16 x2 = (_Float16)(x - (float)x1), y2 = (_Float16)(y - (float)y1), z2 = (_Float16)(z - (float)z1);
+  const float n = x * x + (y * y + z * z);
+  const float a = -0.5f * n;
+  const _Float16 a1 = (_Float16)a, a2 = (_Float16)(a - (float)a1);
+  const _Float16 one = (_Float16)1.0f;
+  row.lo = gbm_h8{x1, x1, x2, x2, y1, y1, y2, y2};
+  row.hi = gbm_h8{z1, z1, z2, z2, a1, a2, one, one};
+  colr.lo = gbm_h8{x1, x2, x1, x2, y1, y2, y1, y2};
+  colr.hi = gbm_h8{z1, z2, z1, z2, one, one, a1, a2};
+  n_out = n;
+}
+__device__ __forceinline__ float gbm_wave_max(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+  return v;
+}
+template <bool EXT>
+__global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<SolverView> x, SolverView one, double beta, int prep) {
+  const SolverView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  const int L = V.L, Wb = V.Wb;
+  const int nb = (L + 63) >> 6;
+  if (prep) {  // chores of neighbouring launches, see k_graph_build_tiles
+    const int nthreads = gridDim.x * gridDim.y * GB2_THREADS;
+    const int gi = (blockIdx.y * gridDim.x + blockIdx.x) * GB2_THREADS + threadIdx.x;
+    if (prep & 1) {
+      for (int e = gi; e < (((L + 63) & ~63) >> 1); e += nthreads) ((unsigned*)V.Kp)[e] = 0xffffffffu;
+      for (int e = gi; e < HCA_CTL_DONE + HCA_MAXWG; e += nthreads) V.perm[e] = 0;
+    }
+    if ((prep & 2) && gi < (int)(sizeof(SolverState) / 4)) ((int*)V.st)[gi] = 0;
+  }
+  const int rb = blockIdx.y, C = blockIdx.x;
+  if (rb >= nb || 4 * C + 3 < rb || 4 * C >= nb) return;  // strips of the upper triangle only
+  const float4* __restrict__ src = V.src;
+  const float4* __restrict__ tgt = V.tgt;
+  u64* __restrict__ bm = V.bm;
+  unsigned char* __restrict__ degp = const_cast<unsigned char*>(V.degp);
+  const int Lp = V.Lp;
+  __shared__ __attribute__((aligned(16))) GbmRec s_rowrec[2][64];   // role "row" of the strip's 64 rows: [cloud][row]
+  __shared__ __attribute__((aligned(16))) GbmRec s_colrec[4][2][64];  // role "column" of every wave's 64 columns
+  __shared__ float s_rowpts[64][6];  // the rows' binary32 points, for the binary64 path
+  __shared__ float s_rown[2][64];    // the rows' squared norms (relative to the origin)
+  __shared__ __attribute__((aligned(16))) u64 rowbuf[64 * 4];  // [row][column tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = 4 * C + ct;
+  const float4 o_s = src[0], o_t = tgt[0];  // the origin: correspondence 0
+  if (tid < 128) {
+    const int cl = tid >> 6, r = tid & 63;
+    const int i = min(rb * 64 + r, L - 1);
+    const float4 p = cl ? tgt[i] : src[i];
+    const float4 o = cl ? o_t : o_s;
+    GbmRec rr, cc;
+    float n;
+    gbm_records(p.x - o.x, p.y - o.y, p.z - o.z, rr, cc, n);
+    s_rowrec[cl][r] = rr;
+    s_rown[cl][r] = n;
+    s_rowpts[r][3 * cl + 0] = p.x;
+    s_rowpts[r][3 * cl + 1] = p.y;
+    s_rowpts[r][3 * cl + 2] = p.z;
+  }
+  const int j = cb * 64 + lane;
+  const bool mine = cb < nb && cb >= rb;  // my tile exists and lies in the upper triangle
+  const bool jvalid = mine && j < L;
+  float ncol_s, ncol_t;
+  {
+    const int jj = max(0, min(j, L - 1));
+    const float4 a = src[jj], b = tgt[jj];
+    GbmRec rr, cs, ctg;
+    gbm_records(a.x - o_s.x, a.y - o_s.y, a.z - o_s.z, rr, cs, ncol_s);
+    gbm_records(b.x - o_t.x, b.y - o_t.y, b.z - o_t.z, rr, ctg, ncol_t);
+    s_colrec[ct][0][lane] = cs;
+    s_colrec[ct][1][lane] = ctg;
+  }
+  __syncthreads();
+  const int nrows = min(64, L - rb * 64);  // rows of the strip that exist
+  if (mine) {
+    const bool diag = rb == cb;
+    const int half = lane >> 5, c32 = lane & 31;
+    const float fb2 = (float)(beta * beta);
+    const double beta2 = beta * beta;
+    // the tile's error bound, and whether its norms stay inside binary16's range (else: nothing is decided by the screen)
+    const float ms = gbm_wave_max(s_rown[0][lane]) + gbm_wave_max(ncol_s), mt = gbm_wave_max(s_rown[1][lane]) + gbm_wave_max(ncol_t);
+    const bool safe = (ms < 1.0e5f) && (mt < 1.0e5f) && (beta > 0.01);  // (NaN compares false)
+    const float delta = GBM_KDELTA * (ms + mt) + 2e-6f;
+    const float m_a = 2.2f * delta, m_b = 1.1f * (fb2 * delta + delta * delta) + 1e-7f;
+    const float nb2 = -fb2, q4 = 0.25f * fb2 * fb2;
+    const u32 pmin_bits = __float_as_uint(0.505f * fb2 + delta);
+    // my two columns' binary32 points (column c32 of the left and of the right half of the tile), for the binary64 path
+    float cpt[2][6];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int jj = max(0, min(cb * 64 + 32 * ch + c32, L - 1));
+      const float4 a = src[jj], b = tgt[jj];
+      cpt[ch][0] = a.x;
+      cpt[ch][1] = a.y;
+      cpt[ch][2] = a.z;
+      cpt[ch][3] = b.x;
+      cpt[ch][4] = b.y;
+      cpt[ch][5] = b.z;
+    }
+    // operand fragments: lane l holds K slots 8 (l >> 5) .. + 7 of row / column (l & 31) of a 32-block
+    gbm_h8 fa[2][2], fbq[2][2];  // [cloud][row half] / [cloud][column half]
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const GbmRec& ra = s_rowrec[cl][32 * h2 + c32];
+        const GbmRec& rbq = s_colrec[ct][cl][32 * h2 + c32];
+        fa[cl][h2] = half ? ra.hi : ra.lo;
+        fbq[cl][h2] = half ? rbq.hi : rbq.lo;
+      }
+    u32 w[2][2];  // [row half][column half]: this lane's 16 decisions, bit r = entry r
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const gbm_f16x zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const gbm_f16x rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][rh], fbq[0][ch], zero, 0, 0, 0);
+        const gbm_f16x rt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][rh], fbq[1][ch], zero, 0, 0, 0);
+        u32 cacc = 0, sacc = 0;  // decision / "not sure" bits, entry 0 ends up in bit 15
+        int plo = 0x7fffffff;    // smallest P of the sixteen, as a bit pattern (a negative P is a negative integer)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const gb_f2 Rs = {rs[r], rs[r + 1]}, Rt = {rt[r], rt[r + 1]};
+          const gb_f2 P = -Rs - Rt, D = Rs - Rt;
+          const gb_f2 nG = __builtin_elementwise_fma(P, gb_f2{nb2, nb2}, gb_f2{q4, q4});
+          const gb_f2 z = __builtin_elementwise_fma(D, D, nG);  // <= 0: consistent
+          const float t0 = __builtin_fabsf(z.x) - __builtin_fmaf(__builtin_fabsf(D.x), m_a, m_b);  // < 0: not sure
+          const float t1 = __builtin_fabsf(z.y) - __builtin_fmaf(__builtin_fabsf(D.y), m_a, m_b);
+          cacc = __builtin_amdgcn_alignbit(cacc, __float_as_uint(z.x), 31);
+          cacc = __builtin_amdgcn_alignbit(cacc, __float_as_uint(z.y), 31);
+          sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(t0), 31);
+          sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(t1), 31);
+          plo = min(min((int)__float_as_uint(P.x), (int)__float_as_uint(P.y)), plo);
+        }
+        // entry r is row 32 rh + 8 (r >> 2) + 4 half + (r & 3), column 32 ch + c32; bits 15 - r so far
+        u32 dec = __brev(cacc) >> 16, pend = __brev(sacc) >> 16;
+        const bool some_short = plo <= (int)pmin_bits;  // a short TIM among the lane's sixteen (or its own vertex, on the diagonal)
+        if (__any(pend != 0 || some_short || !safe)) {  // rare: which entries exactly, then the reference expression for them
+          if (!safe) {
+            pend = 0xffffu;
+          } else if (some_short) {
+            const float pminf = __uint_as_float(pmin_bits);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pend |= !(-(rs[r] + rt[r]) > pminf) ? (1u << r) : 0u;
+          }
+          // never decided (their bits are cleared further down): rows past the end of the last block, a vertex paired with
+          // itself on the diagonal tile, columns past the end of the matrix
+          u32 live = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * rh + 8 * (r >> 2) + 4 * half + (r & 3);
+            const bool ok = row < nrows && !(diag && row == 32 * ch + c32);
+            live |= ok ? (1u << r) : 0u;
+          }
+          if (cb * 64 + 32 * ch + c32 >= L) live = 0;
+          pend &= live;
+          while (__any(pend != 0)) {
+            if (pend != 0) {
+              const int r = __ffs((int)pend) - 1;
+              const int row = 32 * rh + 8 * (r >> 2) + 4 * half + (r & 3);
+              const float* rp = s_rowpts[row];
+              const double ex_ = (double)cpt[ch][0] - (double)rp[0], ey = (double)cpt[ch][1] - (double)rp[1], ez = (double)cpt[ch][2] - (double)rp[2];
+              const double fx = (double)cpt[ch][3] - (double)rp[3], fy = (double)cpt[ch][4] - (double)rp[4], fz = (double)cpt[ch][5] - (double)rp[5];
+              const double s2 = ex_ * ex_ + (ey * ey + ez * ez);
+              const double t2 = fx * fx + (fy * fy + fz * fz);
+              const u32 bit = 1u << r;
+              dec = pair_consistent(s2, t2, beta, beta2) ? (dec | bit) : (dec & ~bit);
+              pend &= ~bit;
+            }
+          }
+        }
+        w[rh][ch] = dec;
+      }
+    }
+    // the lane's column words: nibble g of `dec` holds rows 8 g + 4 half + {0..3} of the 32-row half — spread to bit
+    // 8 g + 4 half, merged with the other half-wave's (the lane 32 away owns the same column, the other four rows of
+    // every eight); then lane L keeps column L of the tile: the left half's word in lanes 0..31, the right half's above
+    u64 colw;
+    {
+      u32 full[2][2];
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const u32 d = w[rh][ch];
+          u32 sp = (d & 0xfu) | ((d & 0xf0u) << 4) | ((d & 0xf00u) << 8) | ((d & 0xf000u) << 12);
+          sp <<= 4 * half;
+          full[rh][ch] = sp | (u32)__shfl_xor((int)sp, 32, 64);
+        }
+      const u32 lo = half ? full[0][1] : full[0][0], hi = half ? full[1][1] : full[1][0];
+      colw = ((u64)hi << 32) | lo;
+    }
+    if (nrows < 64) colw &= (1ULL << nrows) - 1ULL;  // rows past the end of the last block
+    if (diag) colw &= ~(1ULL << lane);                // a vertex is not its own neighbour
+    if (!jvalid) colw = 0;                             // columns past the end of the matrix
+    if (!diag && jvalid) {  // the transposed word (the lower triangle is never evaluated)
+      bm[(size_t)j * Wb + rb] = colw;
+      degp[(size_t)rb * Lp + j] = (unsigned char)__popcll(colw);
+    }
+    u32 lo = (u32)colw, hi = (u32)(colw >> 32);
+    wave_transpose64(lo, hi, lane);
+    rowbuf[lane * 4 + ct] = ((u64)hi << 32) | lo;  // lane r: the word of row rb * 64 + r (diagonal tile: both triangles)
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 2, wi = 4 * C + (tid & 3);
+    if (row < nrows && wi < nb && wi >= rb) {
+      const u64 wv = rowbuf[tid];
+      bm[(size_t)(rb * 64 + row) * Wb + wi] = wv;
+      degp[(size_t)wi * Lp + rb * 64 + row] = (unsigned char)__popcll(wv);
+    }
+  }
+}
+
 // The tile-per-workgroup kernel (rounds 2-3): four waves x 16 rows per tile, many short workgroups — the LATENCY form, used up
 // to GB_TILES_MAX_L correspondences (a registration graph of the metric size is a single wave of workgroups).
 template <bool EXT>
@@ -1789,93 +2034,90 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   const int NB = s_nb;  // core values 0 .. max_core
   const int cf = s_cf;  // t0 = the number of vertices with core number < cf
   if (cf >= NB && tid == 0) st->t0 = L;
-  if (NB > RS_BINS) {
-    if (cf > 0 && cf < NB) {
-      int below = 0;
-      for (int v = tid; v < L; v += RS_THREADS) below += core[v] < cf ? 1 : 0;
-      below = wave_sum_i32(below);
-      if (lane == 0 && below) atomicAdd(&st->t0, below);
-    }
-    // rare: rank = #{u : (core u, u) < (core v, v)}, tiles of the core array through LDS
-    int* tile = rs_lds;
-    for (int v0 = 0; v0 < L; v0 += RS_THREADS) {
-      const int v = v0 + tid;
-      const int c = v < L ? core[v] : 0;
-      int r = 0;
-      for (int base = 0; base < L; base += 4096) {
-        __syncthreads();
-        for (int t = tid; t < 4096; t += RS_THREADS) tile[t] = (base + t < L) ? core[base + t] : 0x7fffffff;
-        __syncthreads();
-        const int lim = min(4096, L - base);
-        for (int t = 0; t < lim; ++t) {
-          const int cu = tile[t], u = base + t;
-          r += (cu < c) || (cu == c && u < v);
-        }
-      }
-      if (v < L) {
-        perm[r] = v;
-        Kp[r] = c + 1;
-      }
-    }
-    return;
+  // Core numbers above RS_BINS - 2 (a clique of more than a thousand members: half of the correspondences of a scan pair
+  // registered against a near copy of itself are inliers — bench.py connected_leg.l5k) take TWO stable passes of the same
+  // counting sort, ten bits of the core number each (an LSD radix sort: the second pass walks the first one's sequence, kept
+  // in V.rankof); until round 6 they took a quadratic count in this one workgroup: 1.9 ms at L = 5910.
+  const int npass = NB > RS_BINS ? 2 : 1;
+  if (npass > 1 && cf > 0 && cf < NB) {  // t0 = the number of vertices below the floor (the one-pass form reads it off its offsets)
+    int below = 0;
+    for (int v = tid; v < L; v += RS_THREADS) below += core[v] < cf ? 1 : 0;
+    below = wave_sum_i32(below);
+    if (lane == 0 && below) atomicAdd(&st->t0, below);
   }
-  for (int i = tid; i < 16 * RS_BINS; i += RS_THREADS) rs_lds[i] = 0;
-  __syncthreads();
-  const int chunk = (((L + 15) / 16) + 63) & ~63;  // ids per wave, a multiple of 64
+  int* __restrict__ seq = V.rankof;  // (L ints; not in use before the permutation)
+  const int chunk = (((L + 15) / 16) + 63) & ~63;  // sequence positions per wave, a multiple of 64
   const int id0 = wave * chunk, id1 = min(L, id0 + chunk);
   int* mycnt = rs_lds + wave * RS_BINS;
-  for (int v = id0 + lane; v < id1; v += 64) atomicAdd(&mycnt[core[v]], 1);
-  __syncthreads();
-  // thread c: exclusive prefix over the waves for core value c, total of c
-  int total = 0;
-  if (tid < NB) {
+  for (int ps = 0; ps < npass; ++ps) {
+    const int shift = 10 * ps;
+    const bool from_seq = ps > 0, last = ps == npass - 1;
+    const int NBd = npass == 1 ? NB : (ps == 0 ? RS_BINS : ((NB - 1) >> 10) + 1);  // digit values of this pass
+    __syncthreads();
+    for (int i = tid; i < 16 * RS_BINS; i += RS_THREADS) rs_lds[i] = 0;
+    __syncthreads();
+    for (int p = id0 + lane; p < id1; p += 64) {
+      const int v = from_seq ? seq[p] : p;
+      atomicAdd(&mycnt[(core[v] >> shift) & (RS_BINS - 1)], 1);
+    }
+    __syncthreads();
+    // thread d: exclusive prefix over the waves for digit value d, total of d
+    int total = 0;
+    if (tid < NBd) {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const int n = rs_lds[w * RS_BINS + tid];
-      rs_lds[w * RS_BINS + tid] = total;
-      total += n;
+      for (int w = 0; w < 16; ++w) {
+        const int n = rs_lds[w * RS_BINS + tid];
+        rs_lds[w * RS_BINS + tid] = total;
+        total += n;
+      }
     }
-  }
-  // exclusive prefix of the totals over the core values (one per thread)
-  int wtot;
-  const int ex = wave_excl_scan_i32(total, &wtot);
-  if (lane == 0) s_wtot[wave] = wtot;
-  __syncthreads();
-  int wbase = 0;
-  for (int q = 0; q < wave; ++q) wbase += s_wtot[q];
-  if (tid < NB) {
-    const int start = wbase + ex;
-    if (cf > 0 && tid == cf) st->t0 = start;
+    // exclusive prefix of the totals over the digit values (one per thread)
+    int wtot;
+    const int ex = wave_excl_scan_i32(total, &wtot);
+    if (lane == 0) s_wtot[wave] = wtot;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < wave; ++q) wbase += s_wtot[q];
+    if (tid < NBd) {
+      const int start = wbase + ex;
+      if (npass == 1 && cf > 0 && tid == cf) st->t0 = start;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) rs_lds[w * RS_BINS + tid] += start;
-  }
-  __syncthreads();
-  // placement: lanes of equal core value rank among themselves in id order; the wave's running offsets are private
-  int nbits = 1;
-  while ((1 << nbits) < NB) ++nbits;
-  for (int v0 = id0; v0 < id1; v0 += 64) {
-    const int v = v0 + lane;
-    const bool valid = v < id1;
-    const int c = valid ? core[v] : -1;
-    // m = the lanes holding my core value, bit by bit of the value (a ballot per bit: ~3 instructions each, whatever the
-    // number of distinct values in the chunk — the loop over distinct values this replaces ran up to 64 times per chunk
-    // and was most of the kernel)
-    u64 m = __ballot(valid);
-    for (int bit = 0; bit < nbits; ++bit) {
-      const bool one = (c >> bit) & 1;
-      const u64 b = __ballot(valid && one);
-      m &= one ? b : ~b;
+      for (int w = 0; w < 16; ++w) rs_lds[w * RS_BINS + tid] += start;
     }
-    int pos = -1;
-    if (valid) {
-      const int off = mycnt[c];
-      pos = off + __popcll(m & lanemask_lt());
-      // (the wave's LDS operations complete in program order: every lane has read its offset before a leader moves it)
-      if ((m & lanemask_lt()) == 0) mycnt[c] = off + __popcll(m);
-      perm[pos] = v;
-      Kp[pos] = c + 1;
+    __syncthreads();
+    // placement: lanes of equal digit rank among themselves in sequence order; the wave's running offsets are private
+    int nbits = 1;
+    while ((1 << nbits) < NBd) ++nbits;
+    for (int p0 = id0; p0 < id1; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < id1;
+      const int v = valid ? (from_seq ? seq[p] : p) : 0;
+      const int c = valid ? core[v] : -1;
+      const int d = valid ? ((c >> shift) & (RS_BINS - 1)) : -1;
+      // m = the lanes holding my digit, bit by bit of the value (a ballot per bit: ~3 instructions each, whatever the
+      // number of distinct values in the chunk — the loop over distinct values this replaces ran up to 64 times per chunk
+      // and was most of the kernel)
+      u64 m = __ballot(valid);
+      for (int bit = 0; bit < nbits; ++bit) {
+        const bool one = (d >> bit) & 1;
+        const u64 b = __ballot(valid && one);
+        m &= one ? b : ~b;
+      }
+      if (valid) {
+        const int off = mycnt[d];
+        const int pos = off + __popcll(m & lanemask_lt());
+        // (the wave's LDS operations complete in program order: every lane has read its offset before a leader moves it)
+        if ((m & lanemask_lt()) == 0) mycnt[d] = off + __popcll(m);
+        if (last) {
+          perm[pos] = v;
+          Kp[pos] = c + 1;
+        } else {
+          seq[pos] = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next chunk reads what the leaders stored
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next chunk reads what the leaders stored
+    __threadfence_block();  // (the next pass reads seq[] written by other waves of this workgroup)
   }
 }
 
@@ -4001,9 +4243,14 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
       // at the matcher's L ~ 300: 10 us per registration in its favour).  Strips: 64 x 256 per workgroup, one wave per
       // tile — 30 % fewer vector instructions and sector-sized row stores, the higher throughput once the device is
       // full (L = 20000: 107 against 132 us).
-      bool tiles = L <= GB_TILES_MAX_L;
-      if (const char* e = QTR_ENGINE_ENV("QTR_GRAPH")) tiles = strcmp(e, "tiles") == 0;
-      if (tiles)
+      bool tiles = L <= GB_TILES_MAX_L, mfma = false;
+      if (const char* e = QTR_ENGINE_ENV("QTR_GRAPH")) {
+        tiles = strcmp(e, "tiles") == 0;
+        mfma = strcmp(e, "mfma") == 0;
+      }
+      if (mfma)
+        LAUNCH_SV(k_graph_build_mfma, a, dim3(nsb, nb, G), dim3(GB2_THREADS), 0, stream, beta, prep);
+      else if (tiles)
         LAUNCH_SV(k_graph_build_tiles, a, dim3(nb * (nb + 1) / 2, 1, G), dim3(256), 0, stream, beta, graph_margin(beta), prep);
       else  // (grid: column group x row block; the lower-left half returns at once)
         LAUNCH_SV(k_graph_build, a, dim3(nsb, nb, G), dim3(GB2_THREADS), 0, stream, beta, graph_margin(beta), prep);
