@@ -315,24 +315,26 @@ __global__ __launch_bounds__(GB2_THREADS, EXT ? 7 : 8) void k_graph_build(ViewEx
 // pairs come out of two v_mfma_f32_32x32x16_f16 instead of 12 packed vector instructions per row of 64:
 //     R = p . p' - |p|^2 / 2 - |p'|^2 / 2 = -|p - p'|^2 / 2
 // with every coordinate (relative to correspondence 0: a translation changes no distance) split in two binary16 halves,
-// x = x1 + x2 + eps, |eps| <= 2^-22 |x|, and a = -|p|^2 / 2 likewise: K = 16 exactly —
+// x = x1 + x2 + eps, |eps| <= 2^-22 |x| (4 u M in R), and a = -|p|^2 / 2 likewise (2 u M): K = 16 exactly —
 //     row operand    [x1 x1 x2 x2 | y1 y1 y2 y2 | z1 z1 z2 z2 | a1 a2 1 1]
 //     column operand [x1 x2 x1 x2 | y1 y2 y1 y2 | z1 z2 z1 z2 | 1 1 a1 a2]
 // (a binary16 x binary16 product is exact in binary32; the accumulation is the matrix unit's).  Error of R against the true
-// -|p - p'|^2 / 2 of the binary32 points, with M = |p|^2 + |p'|^2: the halves' truncation 2 x 2^-22 sum |x x'| <= 2^-22 M,
-// |p|^2 rounded to binary32 after three roundings <= 1.5 u M (u = 2^-24), its two-way split 2^-23 M, the origin subtraction
-// <= u M, the unit's accumulation <= 16 u sum |terms| <= 16.1 u M (the budget match.hip measured and uses: <= 5.5 u there) —
-// 27.6 u M; delta = 1.8e-6 (M_s + M_t) + 2e-6 bounds the error of BOTH D = R_s - R_t = (t - s) / 2 and P = -(R_s + R_t) =
+// -|P - P'|^2 / 2 of the given binary32 points, with M = |p|^2 + |p'|^2 and u = 2^-24: the halves' truncation (above),
+// |p|^2 rounded to binary32 after three roundings <= 1.5 u M, the origin subtraction
+// (|p - p'|^2 of the shifted binary32 points against |P - P'|^2 of the given ones) <= 3.5 u M, the unit's accumulation <= 16 u
+// sum |terms| <= 16.1 u M (the budget match.hip measured and uses: <= 5.5 u there) — 27.1 u M = 1.62e-6 M;
+// delta = 1.8e-6 (M_s + M_t) + 2e-6 bounds the error of BOTH D = R_s - R_t = (t - s) / 2 and P = -(R_s + R_t) =
 // (s + t) / 2, M_s / M_t the largest row norm + the largest column norm of the tile.  The predicate (s - t)^2 <= 2 beta^2
 // (s + t) - beta^4 is z = D^2 - beta^2 P + beta^4 / 4 <= 0, and z is off by <= 2 |D| delta + delta^2 + beta^2 delta + its own
 // rounding (<= 4u D^2 near the threshold: <= 0.07 x 2 |D| delta, since |D| <= M_s + M_t); a pair is decided by the screen
-// only when |z| > 2.2 |D| delta + 1.1 (beta^2 delta + delta^2) + 1e-7 and P > 0.505 beta^2 + delta (s + t > 1.01 beta^2: the
+// only when |z| > 2.4 |D| delta + 1.3 (beta^2 delta + delta^2) + u beta^4 + 1e-7 and P > 0.505 beta^2 + delta (s + t > 1.01 beta^2: the
 // squared form is valid, as in the other two kernels); the rest — a band ~1e-4 of the pairs wide at +-50 m, TIMs shorter
 // than beta — and every pair of a tile whose norms leave binary16's range (or are not finite) gets pair_consistent(), the
 // reference expression in binary64: the bit matrix is identical to the other two kernels' (tests/gpu_graph_bench.py).
 // Per entry the vector unit still does: P, D, -beta^2 P + beta^4 / 4, z (four packed instructions per two entries), the
 // margin (one fma), |z| - margin (one), two sign-bit shifts, half a min3 for the short-TIM test: 6.5 — against 12 + 5.
 #define GBM_KDELTA 1.8e-6f
+#define GBM_MIN_L 2048  // below: the tile kernel (one wave of short workgroups)
 typedef _Float16 gbm_h8 __attribute__((ext_vector_type(8)));
 typedef float gbm_f16x __attribute__((ext_vector_type(16)));
 struct GbmRec {
@@ -351,10 +353,10 @@ __device__ __forceinline__ void gbm_records(float x, float y, float z, GbmRec& r
   colr.hi = gbm_h8{z1, z2, z1, z2, one, one, a1, a2};
   n_out = n;
 }
+// (the largest of the wave's squared norms: non-negative floats order like their bit patterns; a NaN's pattern — sign bit
+// cleared — lies above infinity's and comes out as the maximum, which then fails every "< limit" test)
 __device__ __forceinline__ float gbm_wave_max(float v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
-  return v;
+  return __int_as_float(wave_max_i32(__float_as_int(__builtin_fabsf(v))));
 }
 template <bool EXT>
 __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<SolverView> x, SolverView one, double beta, int prep) {
@@ -380,7 +382,8 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
   __shared__ __attribute__((aligned(16))) GbmRec s_rowrec[2][64];   // role "row" of the strip's 64 rows: [cloud][row]
   __shared__ __attribute__((aligned(16))) GbmRec s_colrec[4][2][64];  // role "column" of every wave's 64 columns
   __shared__ float s_rowpts[64][6];  // the rows' binary32 points, for the binary64 path
-  __shared__ float s_rown[2][64];    // the rows' squared norms (relative to the origin)
+  __shared__ float s_colpts[4][64][6];  // ... and every wave's columns'
+  __shared__ float s_rowmax[2];      // the largest squared norm (relative to the origin) among the rows, per cloud
   __shared__ __attribute__((aligned(16))) u64 rowbuf[64 * 4];  // [row][column tile]
   const int tid = threadIdx.x, lane = tid & 63;
   const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,7 +398,8 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
     float n;
     gbm_records(p.x - o.x, p.y - o.y, p.z - o.z, rr, cc, n);
     s_rowrec[cl][r] = rr;
-    s_rown[cl][r] = n;
+    const float nmax = gbm_wave_max(n);  // (waves 0 and 1: one cloud each)
+    if (r == 0) s_rowmax[cl] = nmax;
     s_rowpts[r][3 * cl + 0] = p.x;
     s_rowpts[r][3 * cl + 1] = p.y;
     s_rowpts[r][3 * cl + 2] = p.z;
@@ -412,6 +416,13 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
     gbm_records(b.x - o_t.x, b.y - o_t.y, b.z - o_t.z, rr, ctg, ncol_t);
     s_colrec[ct][0][lane] = cs;
     s_colrec[ct][1][lane] = ctg;
+    float* cp = s_colpts[ct][lane];
+    cp[0] = a.x;
+    cp[1] = a.y;
+    cp[2] = a.z;
+    cp[3] = b.x;
+    cp[4] = b.y;
+    cp[5] = b.z;
   }
   __syncthreads();
   const int nrows = min(64, L - rb * 64);  // rows of the strip that exist
@@ -421,35 +432,25 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
     const float fb2 = (float)(beta * beta);
     const double beta2 = beta * beta;
     // the tile's error bound, and whether its norms stay inside binary16's range (else: nothing is decided by the screen)
-    const float ms = gbm_wave_max(s_rown[0][lane]) + gbm_wave_max(ncol_s), mt = gbm_wave_max(s_rown[1][lane]) + gbm_wave_max(ncol_t);
+    const float ms = s_rowmax[0] + gbm_wave_max(ncol_s), mt = s_rowmax[1] + gbm_wave_max(ncol_t);
     const bool safe = (ms < 1.0e5f) && (mt < 1.0e5f) && (beta > 0.01);  // (NaN compares false)
     const float delta = GBM_KDELTA * (ms + mt) + 2e-6f;
-    const float m_a = 2.2f * delta, m_b = 1.1f * (fb2 * delta + delta * delta) + 1e-7f;
     const float nb2 = -fb2, q4 = 0.25f * fb2 * fb2;
+    // (the margin: 2 |D| delta + beta^2 delta + delta^2 is z's error from D and P; on top of it the binary32 roundings of P,
+    // D, nG and z themselves — u |P|, u |D| -> 2u D^2 ~ 2u beta^2 P near the threshold, u (beta^2 P + beta^4 / 4), u |z| — are
+    // covered by 0.4 |D| delta + 0.3 beta^2 delta (>= 5.4e-7 beta^2 M against <= 3.2e-7 beta^2 M, since P <= M_s + M_t) and
+    // 4u beta^4 / 4)
+    const float m_a = 2.4f * delta, m_b = 1.3f * (fb2 * delta + delta * delta) + 2.4e-7f * q4 + 1e-7f;
     const u32 pmin_bits = __float_as_uint(0.505f * fb2 + delta);
-    // my two columns' binary32 points (column c32 of the left and of the right half of the tile), for the binary64 path
-    float cpt[2][6];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const int jj = max(0, min(cb * 64 + 32 * ch + c32, L - 1));
-      const float4 a = src[jj], b = tgt[jj];
-      cpt[ch][0] = a.x;
-      cpt[ch][1] = a.y;
-      cpt[ch][2] = a.z;
-      cpt[ch][3] = b.x;
-      cpt[ch][4] = b.y;
-      cpt[ch][5] = b.z;
-    }
     // operand fragments: lane l holds K slots 8 (l >> 5) .. + 7 of row / column (l & 31) of a 32-block
     gbm_h8 fa[2][2], fbq[2][2];  // [cloud][row half] / [cloud][column half]
 #pragma unroll
     for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
-        const GbmRec& ra = s_rowrec[cl][32 * h2 + c32];
-        const GbmRec& rbq = s_colrec[ct][cl][32 * h2 + c32];
-        fa[cl][h2] = half ? ra.hi : ra.lo;
-        fbq[cl][h2] = half ? rbq.hi : rbq.lo;
+        // (one 16-byte read each: the address picks the half)
+        fa[cl][h2] = *(const gbm_h8*)((const char*)&s_rowrec[cl][32 * h2 + c32] + 16 * half);
+        fbq[cl][h2] = *(const gbm_h8*)((const char*)&s_colrec[ct][cl][32 * h2 + c32] + 16 * half);
       }
     u32 w[2][2];  // [row half][column half]: this lane's 16 decisions, bit r = entry r
 #pragma unroll
@@ -502,8 +503,9 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
               const int r = __ffs((int)pend) - 1;
               const int row = 32 * rh + 8 * (r >> 2) + 4 * half + (r & 3);
               const float* rp = s_rowpts[row];
-              const double ex_ = (double)cpt[ch][0] - (double)rp[0], ey = (double)cpt[ch][1] - (double)rp[1], ez = (double)cpt[ch][2] - (double)rp[2];
-              const double fx = (double)cpt[ch][3] - (double)rp[3], fy = (double)cpt[ch][4] - (double)rp[4], fz = (double)cpt[ch][5] - (double)rp[5];
+              const float* cq = s_colpts[ct][32 * ch + c32];
+              const double ex_ = (double)cq[0] - (double)rp[0], ey = (double)cq[1] - (double)rp[1], ez = (double)cq[2] - (double)rp[2];
+              const double fx = (double)cq[3] - (double)rp[3], fy = (double)cq[4] - (double)rp[4], fz = (double)cq[5] - (double)rp[5];
               const double s2 = ex_ * ex_ + (ey * ey + ez * ez);
               const double t2 = fx * fx + (fy * fy + fz * fz);
               const u32 bit = 1u << r;
@@ -4243,7 +4245,10 @@ static hipError_t solver_launch(const SolverView* views, int G, const qtr_params
       // at the matcher's L ~ 300: 10 us per registration in its favour).  Strips: 64 x 256 per workgroup, one wave per
       // tile — 30 % fewer vector instructions and sector-sized row stores, the higher throughput once the device is
       // full (L = 20000: 107 against 132 us).
-      bool tiles = L <= GB_TILES_MAX_L, mfma = false;
+      // Round 6: from GBM_MIN_L correspondences on the squared lengths come off the matrix pipe (k_graph_build_mfma: 14.2 vector
+      // instructions per 64 predicates against the strips' 17.3 and the tiles' 24 — 92 against 110 us at L = 20000, 16 against
+      // 18.5 at L = 5000); the strips stay as the test build's comparison engine (QTR_GRAPH=strips).
+      bool mfma = L >= GBM_MIN_L, tiles = !mfma;
       if (const char* e = QTR_ENGINE_ENV("QTR_GRAPH")) {
         tiles = strcmp(e, "tiles") == 0;
         mfma = strcmp(e, "mfma") == 0;
