@@ -13,7 +13,8 @@ issued as ONE call — qtr_register_pair_corr:
 The step is a COMPOSITE because FPFH matching on synthetic scans does not produce 5000 correspondences for any
 physically plausible scene: the mutual-NN + tuple test keeps ~250-650 (DESIGN.md section 5 and
 tests/probe/synth_L_probe.py list what was tried: baselines from 0 to 10 m, porous / solid clutter, near facades, range
-noise down to 5 mm; only a jittered COPY of the same sweep gets there, and that is not a second scan).  So the back end
+noise down to 5 mm; only a jittered COPY of the same sweep gets there, and that is not a second scan; WITHOUT the tuple
+test a finer voxel leaf does: `connected_l5k` below registers the front end's own L ~ 5 k).  So the back end
 of the step is fed from the solver-only generator SURVEY.md section 8(d) defines for this configuration, not from the
 matcher's output; `--workload pair` times qtr_register_pair on the scan pair alone (the `whole_pair_leg`), and the
 `connected_leg` times registrations whose back end runs on thousands of the matcher's OWN correspondences.
@@ -46,6 +47,12 @@ Objects in the line next to the contract's keys:
   parity_vs_oracle — every pool pair: front end (counts, correspondence list, keypoints), back end (clique, rotation /
                   final inliers, transform), the timed entry point's own record and the scan pair's whole path against
                   the oracle.
+  connected_l5k — beside the composite headline: REAL registrations at the metric's L ~ 5 k, ONE qtr_register_pair call each, the
+                  front end's OWN 4.2-5.9 k correspondences into the back end (the pool's scan pairs at a 0.07 m leaf, cross
+                  check without tuple test; `dense18k`: two 18 000-point samplings of the structured scene, L = 4999), with
+                  their own ms_per_registration (and per pair: the cliques are 400 - 2600 members), errors against the ground
+                  truth, and — with --cpu-seconds > 0 — `oracle_equal`: pair 0's counts, clique, final inliers and transform
+                  against the oracle's stages composed the same way, whose time is `cpu_port_registrations_per_s`.
   repeat_regions — the timed region four more times after the contract's one: how noisy the box is.
   whole_pair_leg, connected_leg, solver_L5000_leg, batch256_leg (composite pairs; `scan_pairs` = the scans alone),
   raw_batch_leg (raw sweeps through Patchwork + range image + the rest, batched), cpp_driver_leg (the step from a

@@ -112,7 +112,8 @@ __device__ __forceinline__ void wave_transpose64(u32& lo, u32& hi, int lane) {
   }
 }
 
-// K9+K10+K11 (default): 64-row x 256-column STRIPS of the upper triangle, one workgroup of four waves each; wave ct owns
+// K9+K10+K11 as 64-row x 256-column STRIPS of the upper triangle (rounds 4-5: the kernel above GB_TILES_MAX_L correspondences;
+// since round 6 — k_graph_build_mfma below — the test build's comparison engine), one workgroup of four waves each; wave ct owns
 // the 64 x 64 tile (rb, 4 C + ct).  What changed against the tile-per-workgroup kernel (k_graph_build_tiles, kept as a
 // comparison engine) and why (tests/probe/issue_probe.hip and profiles/r4_graph_sq.txt have the numbers — the kernel is
 // bound by VECTOR INSTRUCTIONS: a SIMD retires one wave64 instruction in four clocks, the tile kernel spent 24 per row of
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(GB2_THREADS, 4) void k_graph_build_mfma(ViewExt<Sol
 }
 
 // The tile-per-workgroup kernel (rounds 2-3): four waves x 16 rows per tile, many short workgroups — the LATENCY form, used up
-// to GB_TILES_MAX_L correspondences (a registration graph of the metric size is a single wave of workgroups).
+// to GB_TILES_MAX_L correspondences in rounds 3-5 and below GBM_MIN_L since (a small graph is a single wave of workgroups).
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_graph_build_tiles(ViewExt<SolverView> x, SolverView one, double beta, float margin,
                                                      int prep) {
@@ -2753,7 +2754,7 @@ __global__ __launch_bounds__(CSA_THREADS) void k_clique_scan_all(ViewExt<SolverV
   __syncthreads();
   if (wave != 0) return;
   int mc = mc0, t = st->t0, best = st->best_r, tainted = st->tainted;
-  bool full = false;
+  bool full = false, accepted = false;
   for (int seg = 0; seg < CSA_THREADS / 64 && !full; ++seg) {
     const int n_listed = s_cnt[seg];
     const bool listed = n_listed <= CSA_LIST;
@@ -2787,7 +2788,7 @@ __global__ __launch_bounds__(CSA_THREADS) void k_clique_scan_all(ViewExt<SolverV
       if (cnt > mc) {
         mc = gsz[wsel];
         best = rsel;
-        (void)greedy_dispatch(adjP, W, rsel, t_sweep, lane, best_picks);  // the sweep's descent once more, members kept
+        accepted = true;  // (its members: after the replay, see below)
         int lo = 0, hi = L;  // t = first rank with Kp > mc (Kp is non-decreasing in rank)
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
@@ -2807,6 +2808,11 @@ __global__ __launch_bounds__(CSA_THREADS) void k_clique_scan_all(ViewExt<SolverV
       cursor += first + 1;
     }
   }
+  // The members of the LAST accepted start only: the sweep's descent once more (same start, same bound t_sweep: the same
+  // picks).  Until round 6 every accepted start re-ran its descent on the spot — a chain of |clique| dependent row ANDs by
+  // this one wave: four or five improvements on the way to a clique of 2639 members were 3.4 ms of this kernel
+  // (bench.py connected_leg.l5k); the replay itself needs sizes only.
+  if (accepted) (void)greedy_dispatch(adjP, W, best, t_sweep, lane, best_picks);
   int done = 1;  // every start has been replayed
   if (cf > 0 && (best < 0 || tainted)) {  // nothing this search can vouch for: again, with exact core numbers
     done = 0;
