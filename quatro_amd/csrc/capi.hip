@@ -422,6 +422,8 @@ static int create_impl(qtr_handle* h) {
       frontend_carve(s.fb, s.front_arena, h->lim.max_points, h->lim.max_voxels);
       for (int q = 0; q < 4; ++q) s.fb.ev_nn[q] = keep[q];
       s.fb.nn_events = h->stage_events;
+      // (the neighbour grid's cell counters start at zero and are left at zero by every chain that uses them: k2_cell_scan)
+      for (int c = 0; c < 2; ++c) QTR_HIP_TRY(h, hipMemset(s.fb.cloud[c].cell_cnt, 0, (size_t)(QTR_CELL_CAP + 4096) * 4));
     }
     // (the long-list arenas — lists of more than QTR_KMAX neighbours: 8 bytes x max_long_neighbors per cloud, 134 MB per
     // slot at the defaults — are allocated the first time a chain with k2_neighbors_big is enqueued: ensure_long_arenas)
@@ -755,6 +757,14 @@ static int exact_phase(qtr_handle* h, Slot& s, int L, const SolverState& hs, boo
   }
   *improved = true;
   return QTR_OK;
+}
+
+// the cells of the larger of a pair's two neighbour-search grids (CNT_NCELL words of the voxel stage's mail) when BOTH fit the
+// dense cell table of the FPFH chain, else 0 = sort packed cell keys (frontend.hip, d_cell_count)
+static int cell_table_cells(int ncell_s, int ncell_t) {
+  static const bool off = QTR_ENGINE_ENV("QTR_CELL_TABLE") != nullptr && atoi(QTR_ENGINE_ENV("QTR_CELL_TABLE")) == 0;
+  if (off || ncell_s <= 0 || ncell_t <= 0 || ncell_s > QTR_CELL_CAP || ncell_t > QTR_CELL_CAP) return 0;
+  return std::max(ncell_s, ncell_t);
 }
 
 // k_hcore_async's workgroups of one chain have to be resident together, so chains that may overlap must not ask for more
@@ -1657,7 +1667,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     for (int attempt = 0;; ++attempt) {
       const int launched = s.fb.vox_passes;
       s.fb.mail_seq = ++s.seq;
-      QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream, launched));
+      QTR_HIP_TRY(h, voxelize_enqueue(s.fb, 2, raws, Ps2, fp->voxel_size, s.stream, launched, fp->fpfh_radius * 1.001f));
       // block 0 of k2_vox_centroids publishes the counters while other blocks are still writing centroids: anything
       // that reads the centroids from another stream has to wait for the kernel itself
       QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
@@ -1732,7 +1742,8 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     }
     if (h->long_lists) QTR_TRY(ensure_long_arenas(h, s));
     // (k2_fpfh also does the matcher's per-descriptor preparation: norms, hashes, duplicate table — see frontend.hip)
-    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists, true));
+    QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists, true,
+                                cell_table_cells(s.mail[MAIL_VOX0 + CNT_NCELL], s.mail[MAIL_VOX1 + CNT_NCELL])));
     if (!mean_first) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
@@ -2142,7 +2153,7 @@ static int lane_start_chunk(qtr_handle* h, Lane& ln) {
   }
   if (ln.active.empty()) return lane_enqueue_solver(h, ln, {});  // no scans in this chunk (or nothing valid at all)
   QTR_HIP_TRY(h, voxelize_enqueue_group(F.data(), (int)F.size(), raws.data(), Ps.data(), J.fp.voxel_size, &ln.stage,
-                                        lead.stream));
+                                        lead.stream, J.fp.fpfh_radius * 1.001f));
   QTR_HIP_TRY(h, hipEventRecord(lead.ev_vox, lead.stream));
   ln.phase = 1;
   return QTR_OK;
@@ -2210,8 +2221,14 @@ static int lane_poll(qtr_handle* h, Lane& ln, bool* progress) {
     ln.long_lists = h->long_lists;
     if (ln.long_lists)
       for (int g : ln.active) QTR_TRY(ensure_long_arenas(h, h->slots[ln.first_slot + g]));
+    int max_ncell = 1;  // the largest neighbour grid of the group (0: some pair's does not fit the dense cell table)
+    for (int g : ln.active) {
+      const Slot& sg = h->slots[ln.first_slot + g];
+      const int nc2 = cell_table_cells(sg.mail[MAIL_VOX0 + CNT_NCELL], sg.mail[MAIL_VOX1 + CNT_NCELL]);
+      max_ncell = (max_ncell == 0 || nc2 == 0) ? 0 : std::max(max_ncell, nc2);
+    }
     QTR_HIP_TRY(h, fpfh_enqueue_group(F.data(), G, n2.data(), J.fp.normal_radius, J.fp.fpfh_radius, &ln.stage, lead.stream,
-                                      ln.long_lists, true));
+                                      ln.long_lists, true, max_ncell));
     QTR_HIP_TRY(h, hipStreamWaitEvent(lead.stream, lead.ev[5], 0));
     for (int g : ln.active) {
       Slot& s = h->slots[ln.first_slot + g];

@@ -15,7 +15,12 @@
 enum { CNT_NVOX = 0, CNT_VOX_OVERFLOW = 1, CNT_NBR_TOTAL = 2, CNT_NBR_OVERFLOW = 3, CNT_GRID_OVERFLOW = 4, CNT_KMAX = 5,
        CNT_SORT_BITS = 6 /* significant bits of the voxel sort's keys */,
        CNT_NBR_ARENA = 7 /* entries of the long-list arena handed out */, CNT_NBR_CAPACITY = 8 /* ... it was too small */,
-       CNT_VOX_TAILERR = 9 /* sticky: SOME tile of k2_vox_centroids gave up its look-back and wrote no centroids */ };
+       CNT_VOX_TAILERR = 9 /* sticky: SOME tile of k2_vox_centroids (or of k2_cell_scan) gave up its look-back */,
+       CNT_NCELL = 10 /* cells of the neighbour-search grid over this cloud's bounding box (voxel stage, for the cell side
+                         the caller named): up to QTR_CELL_CAP the FPFH chain places the points by a dense cell table */ };
+// the largest neighbour-search grid served by the dense cell table (k2_cell_count / _scan / _place); above it — 160 x 160 x 30 m
+// at 0.75 m cells is 1.8 M — the chain sorts packed cell keys as it did until round 6
+#define QTR_CELL_CAP (1 << 21)
 // CNT_NBR_OVERFLOW: some point of the cloud has more than QTR_KMAX neighbours (k2_neighbors_big has work to do);
 // CNT_KMAX: the longest such list
 // matcher device counters (FrontBufs::mcounts, 16 ints)
@@ -57,6 +62,8 @@ struct CloudBufs {
   float4* spts = nullptr;      // [max_voxels] points in cell-sorted order, w = original index
   float4* raw_sorted = nullptr; // [max_points] raw scan gathered into voxel-sorted order
   int* ranges = nullptr;       // [max_voxels][9][2] candidate key ranges
+  int* cell_cnt = nullptr;     // [QTR_CELL_CAP + 4096] points per cell of the neighbour-search grid: zero between uses (k2_cell_scan leaves it so)
+  int* cell_start = nullptr;   // [QTR_CELL_CAP + 4096] first place of every cell in spts (exclusive scan of cell_cnt)
   float* mean = nullptr;       // 4 floats: sequential float mean of the cloud (Matcher::normalizePoints)
   float* baseT = nullptr;      // [34][n_pad] k-major descriptors + |b|^2 row   (MFMA streamed operand)
   float* queryT = nullptr;     // [34][n_pad] -2*descriptor + ones row            (MFMA stationary operand)
@@ -101,6 +108,8 @@ struct CloudView {
   int nbr_big_cap;
   float4* spts;
   int* ranges;
+  int* cell_cnt;
+  int* cell_start;
   float* mean;
   // the matcher's per-descriptor preparation at the end of k2_fpfh (whole-path chains; null / 0: k_desc_prep does it):
   // |d|^2, the hash and the row's entry in the duplicate table, which k2_normals cleared earlier in the chain
@@ -230,13 +239,16 @@ hipError_t frontend_init_attributes();
 // voxel counts) are only known on the device: a caller that launches fewer than 4 must check them afterwards and run the
 // stage again with enough passes when ceil(bits / 8) exceeds what it launched (the output is then unsorted garbage inside
 // its bounds)
+// cell_side: the cell of the FPFH chain that follows (r_fpfh * 1.001), or 0 — the voxel stage then mails the neighbour grid's
+// cell count (CNT_NCELL) with its counters
 hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st,
-                            int passes = 4);
+                            int passes = 4, float cell_side = 0.f);
 hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st);
 // origin_known: the clouds are the voxel centroids voxelize_enqueue just produced in the same CloudBufs (its bounding box
 // is still there and serves as the neighbour grid's origin)
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep = false);
+                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep = false,
+                        int max_ncell = 0 /* > 0 (and <= QTR_CELL_CAP, origin_known): the dense cell table, see frontend.hip */);
 hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
 // init_done: match_init_enqueue already ran for this pair (same ns, nt, fp) — the whole-path driver issues it beside the
 // FPFH chain, which takes one launch off the critical path
@@ -251,10 +263,10 @@ hipError_t gather_matched_enqueue(FrontBufs& F, int L, float4* m_src, float4* m_
 // The same stages for G pairs at once (qtr_submit_batch): one launch chain, the views of all pairs in device memory
 // (pushed through `stage`).  F[g] is pair g's arena; raw / P / n hold two entries per pair (source, target).
 hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* const* raw, const int* P, float leaf,
-                                  ViewStage* stage, hipStream_t st);
+                                  ViewStage* stage, hipStream_t st, float cell_side = 0.f);
 hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st);
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st, bool long_lists, bool desc_prep = false);
+                              hipStream_t st, bool long_lists, bool desc_prep = false, int max_ncell = 0);
 hipError_t match_enqueue_group(FrontBufs* const* F, int G, const int* n, const qtr_frontend_params* fp,
                                const unsigned long long* seeds, ViewStage* stage, hipStream_t st, bool prep_done = false);
 

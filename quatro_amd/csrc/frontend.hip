@@ -578,6 +578,108 @@ __device__ __forceinline__ void lower_bound_hi2(const u64* __restrict__ keys, in
   *r1 = b1 + ((a1 < k1) ? 1 : 0);
 }
 
+// ---- the neighbour-search grid as a DENSE cell table (round 6).  Until then the voxel centroids were sorted by packed cell
+// keys (a key launch + three radix passes, 31 us of the single registration's chain) and every point found its nine key ranges
+// by binary search (k2_ranges: 11 us of dependent round trips).  Nothing downstream needs the ORDER inside a cell — the lists
+// are sorted by (d^2, index) afterwards — so a counting sort does: a point takes a place in its cell with one atomic
+// (k2_cell_count: the old value is its rank in the cell; a cell holds a handful of points, no hot address), the cells' counts
+// are scanned (k2_cell_scan: 2048 cells per workgroup, the workgroups' totals added up through tail_lookback; the counts are
+// left ZERO for the next registration), and a point's place is start[cell] + rank, its nine ranges two table reads each
+// (k2_cell_place).  The grid is the bounding box of the RAW cloud (the voxel stage left it in C.mm, as before) cut into cells of
+// the FPFH radius; the voxel stage mails its cell count (CNT_NCELL) with the voxel counts, and a chain whose grids exceed
+// QTR_CELL_CAP cells (or that has no voxel stage in front: qtr_fpfh) sorts keys as before.
+struct CellDims {
+  int nx, ny, nz;
+};
+__device__ __forceinline__ CellDims cell_dims(const u32* __restrict__ mm, float cell) {
+  const CellGrid g = cell_grid(mm, cell);
+  int c[3];
+  cell_of(g, make_float4(dec_f32(mm[3]), dec_f32(mm[4]), dec_f32(mm[5]), 0.f), c);
+  return CellDims{c[0] + 1, c[1] + 1, c[2] + 1};
+}
+#define CELL_SCAN_TILE 2048
+__device__ __forceinline__ void d_cell_count(const float4* __restrict__ pts, int n, const u32* __restrict__ mm, float cell,
+                                             int* __restrict__ cnt, u64* __restrict__ place, int* __restrict__ look) {
+  const CellDims d = cell_dims(mm, cell);
+  const CellGrid g = cell_grid(mm, cell);
+  const int ncell = d.nx * d.ny * d.nz;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // k2_cell_scan's look-back words ("not published yet")
+  for (int w = t; w < (ncell + CELL_SCAN_TILE) / CELL_SCAN_TILE + 1; w += gridDim.x * blockDim.x) look[w] = 0;
+  if (t >= n) return;
+  int c[3];
+  cell_of(g, pts[t], c);
+  const int lin = min(c[0], d.nx - 1) + d.nx * (min(c[1], d.ny - 1) + d.ny * min(c[2], d.nz - 1));
+  const int r = atomicAdd(&cnt[lin], 1);
+  place[t] = ((u64)(u32)lin << 32) | (u32)r;
+}
+// start[e] = number of points in cells below e, for e = 0 .. ncell (and beyond: the launch's last tile); cnt[] back to zero
+__device__ __forceinline__ void d_cell_scan(const u32* __restrict__ mm, float cell, int* __restrict__ cnt, int* __restrict__ start,
+                                            int* __restrict__ look, int* __restrict__ counts) {
+  const CellDims d = cell_dims(mm, cell);
+  const int ncell = d.nx * d.ny * d.nz;
+  const int nblk = (ncell + CELL_SCAN_TILE) / CELL_SCAN_TILE;  // covers entry ncell itself
+  if ((int)blockIdx.x >= nblk) return;
+  __shared__ int s_red[5], s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e0 = blockIdx.x * CELL_SCAN_TILE + tid * 8;
+  int4 a = *(const int4*)(cnt + e0), b = *(const int4*)(cnt + e0 + 4);  // (cells past the grid hold zero: nobody counted there)
+  const int4 z = make_int4(0, 0, 0, 0);
+  *(int4*)(cnt + e0) = z;
+  *(int4*)(cnt + e0 + 4) = z;
+  const int mine = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+  int wtot;
+  const int ex = wave_excl_scan_i32(mine, &wtot);
+  if (lane == 0) s_w[wave] = wtot;
+  __syncthreads();
+  const int total = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+  int before = tail_lookback(look, (int)blockIdx.x, total, s_red);
+  if (before < 0) {  // a predecessor's count never appeared (bounded wait): the chain's result is refused by the host
+    if (tid == 0) __hip_atomic_store(counts + CNT_VOX_TAILERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    before = 0;  // (places stay inside the arrays: every start is at most the cloud's size)
+  }
+  int run = before + ex;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  int4 sa, sb;
+  sa.x = run;
+  sa.y = sa.x + a.x;
+  sa.z = sa.y + a.y;
+  sa.w = sa.z + a.z;
+  sb.x = sa.w + a.w;
+  sb.y = sb.x + b.x;
+  sb.z = sb.y + b.y;
+  sb.w = sb.z + b.z;
+  *(int4*)(start + e0) = sa;
+  *(int4*)(start + e0 + 4) = sb;
+}
+// the points in cell order (w carries the original index), and the nine candidate ranges of every point
+__device__ __forceinline__ void d_cell_place(const float4* __restrict__ pts, int n, const u32* __restrict__ mm, float cell,
+                                             const int* __restrict__ start, const u64* __restrict__ place,
+                                             float4* __restrict__ spts, int* __restrict__ ranges) {
+  const CellDims d = cell_dims(mm, cell);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) {
+    const u64 pl = place[g];
+    float4 p = pts[g];
+    p.w = __uint_as_float((u32)g);
+    spts[start[(int)(pl >> 32)] + (int)(u32)pl] = p;
+  }
+  if (g >= n * 9) return;
+  const int i = g / 9, r = g - i * 9;
+  const CellGrid cg = cell_grid(mm, cell);
+  int c[3];
+  cell_of(cg, pts[i], c);
+  const int cx = min(c[0], d.nx - 1), cy = min(c[1], d.ny - 1) + (r % 3) - 1, cz = min(c[2], d.nz - 1) + (r / 3) - 1;
+  int s = 0, e = 0;
+  if (cy >= 0 && cy < d.ny && cz >= 0 && cz < d.nz) {
+    const int row = d.nx * (cy + d.ny * cz);
+    s = start[row + max(cx - 1, 0)];
+    e = start[row + min(cx + 1, d.nx - 1) + 1];
+  }
+  ranges[2 * g] = s;
+  ranges[2 * g + 1] = e;
+}
+
 // points gathered into cell-sorted order (w carries the original index) so that candidate loads are
 // contiguous 16-byte reads instead of a dependent key -> point gather
 __device__ __forceinline__ void d_sorted_points(const float4* __restrict__ pts, const u64* __restrict__ sorted,
@@ -1472,7 +1574,7 @@ __global__ __launch_bounds__(256) void k2_minmax(ViewExt<CloudView> x, Clouds2 a
 // mm_parts: records k2_minmax left for this cloud (0: C.mm already holds the box / origin to use)
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds2 a, int use_vox, int make_keys, float side,
-                                                    int mm_parts) {
+                                                    int mm_parts, float cell_side /* voxel stage: the FPFH chain's cell, or 0 */) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   const int n = use_vox ? C.n : C.P;
   const int nblk = (n + RADIX_TILE - 1) / RADIX_TILE;
@@ -1495,7 +1597,13 @@ __global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds
     d_radix_hist<8, RADIX_TILE>([&](int i) { return cell_sort_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
   } else {
     const VoxGrid g = vox_grid(s_mm, side);
-    if (blockIdx.x == 0 && threadIdx.x == 0) vox_grid_counts(g, C.counts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      vox_grid_counts(g, C.counts);
+      if (cell_side > 0.f) {  // cells of the neighbour-search grid over this box: the host picks the FPFH chain's form by it
+        const CellDims cd = cell_dims(s_mm, cell_side);
+        C.counts[CNT_NCELL] = cd.nx * cd.ny * cd.nz;  // (<= 2^24: 256 cells per axis)
+      }
+    }
     if (threadIdx.x == 0) C.vox_look[blockIdx.x] = 0;  // k2_vox_centroids' look-back words ("not published yet"), one per tile
     const float4* __restrict__ pts = C.raw;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return vox_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
@@ -1546,6 +1654,21 @@ __global__ __launch_bounds__(256) void k2_ranges(ViewExt<CloudView> x, Clouds2 a
     }
   }
   d_ranges(C.vox, C.n, sorted, C.mm, cell, C.ranges);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_cell_count(ViewExt<CloudView> x, Clouds2 a, float cell) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  d_cell_count(C.vox, C.n, C.mm, cell, C.cell_cnt, C.keys_a, (int*)C.hist);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_cell_scan(ViewExt<CloudView> x, Clouds2 a, float cell) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  d_cell_scan(C.mm, cell, C.cell_cnt, C.cell_start, (int*)C.hist, C.counts);
+}
+template <bool EXT>
+__global__ __launch_bounds__(256) void k2_cell_place(ViewExt<CloudView> x, Clouds2 a, float cell) {
+  const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
+  d_cell_place(C.vox, C.n, C.mm, cell, C.cell_start, C.keys_a, C.spts, C.ranges);
 }
 template <bool EXT>
 __global__ __launch_bounds__(64) void k2_neighbors(ViewExt<CloudView> x, Clouds2 a, float r2) {
@@ -1627,6 +1750,8 @@ static CloudView make_view(CloudBufs& C, const float4* raw, int P, int n, int* m
   v.nbr_big_cap = C.nbr_big_cap;
   v.spts = C.spts;
   v.ranges = C.ranges;
+  v.cell_cnt = C.cell_cnt;
+  v.cell_start = C.cell_start;
   v.mean = C.mean;
   return v;
 }
@@ -1660,13 +1785,13 @@ static hipError_t cloudset_finish(CloudSet& S, const CloudView* views, int nc, V
 // buffer is only known on the device (the return value is then minus the number of passes launched: consumers call
 // sorted_src())
 static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t st, bool adaptive = false, bool make_keys = false,
-                       float side = 0.f, int mm_parts = 0) {
+                       float side = 0.f, int mm_parts = 0, float cell_side = 0.f) {
   const int maxblk = ((use_vox ? S.maxn : S.maxP) + RADIX_TILE - 1) / RADIX_TILE;
   const int passes = key_bits / 8;
   // one launch makes the keys and the first pass's histogram; every scatter accumulates the next pass's histogram (see d_radix_hist).
   // A single-launch pass (tiles exchanging offsets through flags) needs device-scope fences, which on this multi-XCD
   // part cost more than the launch boundary.
-  LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side, mm_parts);
+  LAUNCH_CV(k2_keys_hist, S.a, dim3(max(maxblk, 1), S.nc), dim3(256), 0, st, use_vox, make_keys ? 1 : 0, side, mm_parts, cell_side);
   for (int p = 0; p < passes; ++p)
     LAUNCH_CV(k2_radix_scatter, S.a, dim3(maxblk, S.nc), dim3(256), 0, st, use_vox, p, p + 1 == passes ? 1 : 0, adaptive ? 1 : 0);
   return adaptive ? -passes : (passes & 1);
@@ -1674,19 +1799,19 @@ static int radix_sort2(const CloudSet& S, int use_vox, int key_bits, hipStream_t
 
 // passes: radix passes to launch (4 covers every grid pcl::VoxelGrid accepts; a grid below 2^24 cells needs 3 — see
 // voxelize_enqueue)
-static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st, int passes = 4) {
+static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipStream_t st, int passes = 4, float cell_side = 0.f) {
   const int nc = S.nc;
   const int g = min(1024, (S.maxP + 255) / 256);
   const int mm_parts = max(1, min(g, MM_MAX_PARTS));
   LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 0, 1);
-  const int where = radix_sort2(S, 0, 8 * passes, st, true, true, leaf, mm_parts);  // (a pass above the keys' bits returns at once)
+  const int where = radix_sort2(S, 0, 8 * passes, st, true, true, leaf, mm_parts, cell_side);  // (a pass above the keys' bits returns at once)
   const int nblk = (S.maxP + 1023) / 1024;
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
 // voxel-grid down-sampling of nc (1 or 2) raw clouds
 hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, const int* P, float leaf, hipStream_t st,
-                            int passes) {
+                            int passes, float cell_side) {
   (void)hipGetLastError();
   CloudView v[2];
   for (int c = 0; c < nc; ++c) {
@@ -1697,12 +1822,12 @@ hipError_t voxelize_enqueue(FrontBufs& F, int nc, const float4* const* raw, cons
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  voxelize_launch(S, leaf, F.max_voxels, st, min(4, max(1, passes)));
+  voxelize_launch(S, leaf, F.max_voxels, st, min(4, max(1, passes)), cell_side);
   return hipGetLastError();
 }
 
 hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* const* raw, const int* P, float leaf,
-                                  ViewStage* stage, hipStream_t st) {
+                                  ViewStage* stage, hipStream_t st, float cell_side) {
   (void)hipGetLastError();
   std::vector<CloudView> v((size_t)2 * G);
   for (int g = 0; g < G; ++g)
@@ -1714,7 +1839,7 @@ hipError_t voxelize_enqueue_group(FrontBufs* const* F, int G, const float4* cons
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  voxelize_launch(S, leaf, F[0]->max_voxels, st);
+  voxelize_launch(S, leaf, F[0]->max_voxels, st, 4, cell_side);
   return hipGetLastError();
 }
 
@@ -1750,7 +1875,7 @@ hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStag
 // stage whose centroids these are) — the neighbour grid only needs an origin at or below every point (cell_of clamps, so
 // a centroid that rounds an ulp below it is still in cell 0), which saves two launches of a latency-bound chain
 static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStream_t st, bool with_mean, bool origin_known,
-                        bool long_lists) {
+                        bool long_lists, int max_ncell = 0 /* > 0: every cloud's grid has at most that many cells: the dense cell table */) {
   const int nc = S.nc, maxn = S.maxn;
   const int g = min(1024, (maxn + 255) / 256);
   const float cell = r_fpfh * 1.001f;
@@ -1758,9 +1883,17 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   const float rn2 = (float)((double)r_normal * (double)r_normal);
   const int mm_parts = origin_known ? 0 : max(1, min(g, MM_MAX_PARTS));
   if (!origin_known) LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 1, 0);  // (keeps the counters)
-  const int where = radix_sort2(S, 1, 24, st, false, true, cell, mm_parts);
-  // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
-  LAUNCH_CV(k2_ranges, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell, where);
+  if (origin_known && max_ncell > 0 && max_ncell <= QTR_CELL_CAP) {
+    // the dense cell table (see d_cell_count): three short launches instead of a key launch, three radix passes and the
+    // binary searches
+    LAUNCH_CV(k2_cell_count, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, cell);
+    LAUNCH_CV(k2_cell_scan, S.a, dim3((max_ncell + CELL_SCAN_TILE) / CELL_SCAN_TILE, nc), dim3(256), 0, st, cell);
+    LAUNCH_CV(k2_cell_place, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell);
+  } else {
+    const int where = radix_sort2(S, 1, 24, st, false, true, cell, mm_parts);
+    // k2_ranges also gathers the points into cell-sorted order (its first n threads): one launch fewer
+    LAUNCH_CV(k2_ranges, S.a, dim3((9 * maxn + 255) / 256, nc), dim3(256), 0, st, cell, where);
+  }
   // (fusing the normals into k2_neighbors was tried: the eigen-solve then runs once per WAVE instead of once per
   // thread and the launch went from 21 + 14 us to 51 us)
   LAUNCH_CV(k2_neighbors, S.a, dim3(maxn, nc), dim3(64), 0, st, r2);
@@ -1782,7 +1915,7 @@ static void view_desc_prep(CloudView& v, CloudBufs& C, int dd_slots) {
   v.dd_mask = dd_slots - 1;
 }
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
-                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep) {
+                        bool with_mean, bool origin_known, bool long_lists, bool desc_prep, int max_ncell) {
   (void)hipGetLastError();
   CloudView v[2];
   for (int c = 0; c < nc; ++c) {
@@ -1792,11 +1925,11 @@ hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_n
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, with_mean, origin_known, long_lists);
+  fpfh_launch(S, r_normal, r_fpfh, st, with_mean, origin_known, long_lists, max_ncell);
   return hipGetLastError();
 }
 hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_normal, float r_fpfh, ViewStage* stage,
-                              hipStream_t st, bool long_lists, bool desc_prep) {
+                              hipStream_t st, bool long_lists, bool desc_prep, int max_ncell) {
   (void)hipGetLastError();
   std::vector<CloudView> v((size_t)2 * G);
   for (int g = 0; g < G; ++g)
@@ -1807,7 +1940,7 @@ hipError_t fpfh_enqueue_group(FrontBufs* const* F, int G, const int* n, float r_
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  fpfh_launch(S, r_normal, r_fpfh, st, false, true, long_lists);  // always behind voxelize_enqueue_group
+  fpfh_launch(S, r_normal, r_fpfh, st, false, true, long_lists, max_ncell);  // always behind voxelize_enqueue_group
   return hipGetLastError();
 }
 
@@ -1827,6 +1960,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * 4 * 2 + 64;              // nbr_cnt, nbr_off
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
+  per_cloud += 2 * (size_t)(QTR_CELL_CAP + 4096) * 4 + 512;  // cell_cnt, cell_start
   per_cloud += (size_t)max_points * 16 + 256;                // raw_sorted
   size_t shared = (size_t)max_voxels * 64 + 16384 + 2 * TAIL_MAXWG * 4;
   shared += (size_t)max_voxels * (4 + 4 + 4 + 8) + (size_t)max_voxels * 4 * 6 + 4096;  // doubled pair lists + nc_* (cross-check off)
@@ -1870,6 +2004,8 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.spts = (float4*)take((size_t)max_voxels * 16);
     C.raw_sorted = (float4*)take((size_t)max_points * 16);
     C.ranges = (int*)take((size_t)max_voxels * 18 * 4);
+    C.cell_cnt = (int*)take((size_t)(QTR_CELL_CAP + 4096) * 4);   // (zeroed once by the handle: create_impl)
+    C.cell_start = (int*)take((size_t)(QTR_CELL_CAP + 4096) * 4);
     const size_t vpad = ((size_t)max_voxels + 511) / 512 * 512;
     C.baseT = (float*)take(34 * vpad * 4);
     C.queryT = (float*)take(34 * vpad * 4);
