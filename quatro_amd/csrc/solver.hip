@@ -2052,11 +2052,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
   const int chunk = (((L + 15) / 16) + 63) & ~63;  // sequence positions per wave, a multiple of 64
   const int id0 = wave * chunk, id1 = min(L, id0 + chunk);
   int* mycnt = rs_lds + wave * RS_BINS;
-  for (int ps = 0; ps < npass; ++ps) {
-    const int shift = 10 * ps;
-    const bool from_seq = ps > 0, last = ps == npass - 1;
-    const int NBd = npass == 1 ? NB : (ps == 0 ? RS_BINS : ((NB - 1) >> 10) + 1);  // digit values of this pass
-    __syncthreads();
+  // (the one-pass case — every graph with core numbers below 1023 — is compiled on its own: no sequence array, no digit
+  // extraction, no barrier in front; as one loop over `npass` it cost that case 1.5 us of its 10)
+  auto pass = [&](auto single_tag, const int ps) __attribute__((always_inline)) {
+    constexpr bool SINGLE = decltype(single_tag)::value;
+    const int shift = SINGLE ? 0 : 10 * ps;
+    const bool from_seq = !SINGLE && ps > 0, last = SINGLE || ps == npass - 1;
+    const int NBd = SINGLE ? NB : (ps == 0 ? RS_BINS : ((NB - 1) >> 10) + 1);  // digit values of this pass
+    if (!SINGLE) __syncthreads();
     for (int i = tid; i < 16 * RS_BINS; i += RS_THREADS) rs_lds[i] = 0;
     __syncthreads();
     for (int p = id0 + lane; p < id1; p += 64) {
@@ -2120,7 +2123,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rank_sort(ViewExt<SolverView> x,
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next chunk reads what the leaders stored
     }
-    __threadfence_block();  // (the next pass reads seq[] written by other waves of this workgroup)
+    if (!SINGLE) __threadfence_block();  // (the next pass reads seq[] written by other waves of this workgroup)
+  };
+  if (npass == 1) {
+    pass(std::true_type{}, 0);
+  } else {
+    pass(std::false_type{}, 0);
+    pass(std::false_type{}, 1);
   }
 }
 

@@ -647,6 +647,42 @@ def test_connected_registration_of_18k_point_clouds_with_5k_correspondences_matc
     assert abs(np.arctan2(np.sin(dy), np.cos(dy))) < 5e-3 and np.linalg.norm(g["T"][:3, 3] - Tgt[:3, 3]) < 0.3
 
 
+def test_neighbour_grid_cell_counters_are_clean_after_a_refused_registration(pool16k):
+    """The FPFH chain's dense cell table is zero between uses: k2_cell_count fills it and k2_cell_scan leaves it zero
+    (frontend.hip).  Registrations that are REFUSED behind the voxel stage (more voxels than max_voxels), and grids of different
+    sizes on the same table, must leave nothing behind: the next registrations on the same handle equal a fresh handle's."""
+    s, t, _ = pool16k[2]
+    fp = ql.default_frontend_params(seed=2)
+    fresh = ql.Handle(0, **LIMITS)
+    try:
+        want = fresh.register_pair(s, t, fp)
+    finally:
+        fresh.close()
+    h = ql.Handle(0, max_points=131072, max_voxels=8192, max_corr=8192)
+    try:
+        with pytest.raises(ql.QuatroHipError) as e:
+            h.register_pair(s, t, fp)                       # ~16 k voxels per cloud: refused after the voxel stage
+        assert e.value.code == ql.QTR_ERR_CAPACITY
+        coarse = ql.default_frontend_params(voxel_size=0.6, seed=2)
+        a = h.register_pair(s, t, coarse)                   # fits: runs on the table the refused call left behind
+        with pytest.raises(ql.QuatroHipError):
+            h.register_pair(s, t, fp)
+        b = h.register_pair(s, t, coarse)
+    finally:
+        h.close()
+    h2 = ql.Handle(0, **LIMITS)
+    try:
+        c = h2.register_pair(s, t, coarse)
+        d = h2.register_pair(s, t, fp)                      # (and a second grid of another size on the same table)
+    finally:
+        h2.close()
+    for x in (a, b):
+        assert (x["n_src"], x["n_tgt"], x["L"]) == (c["n_src"], c["n_tgt"], c["L"])
+        assert np.array_equal(x["clique"], c["clique"]) and np.array_equal(x["T"], c["T"])
+    assert (d["n_src"], d["n_tgt"], d["L"]) == (want["n_src"], want["n_tgt"], want["L"])
+    assert np.array_equal(d["clique"], want["clique"]) and np.array_equal(d["T"], want["T"])
+
+
 def test_dense_mode_end_to_end_through_the_whole_path_entry_matches_oracle(qo16):
     """BASELINE configs[4] as ONE registration: two independently sampled 50 000-point clouds and a leaf so small that the
     voxel grid would overflow int32 — pcl::VoxelGrid passes the cloud through unchanged, and so does the reference's
