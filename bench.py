@@ -148,6 +148,7 @@ def main() -> None:
     ap.add_argument("--legs", default="pair,solver5k,batch,dense,connected,cpp,rawbatch,segment,patchwork",
                     help="comma list of the extra legs to run on rank 0 / all ranks (never part of `value`); "
                          "`refdense` adds the reference's own back-end text at L = 20000 on the CPU (minutes, > 16 GB)")
+    ap.add_argument("--no-pin", action="store_true", help="leave the process's CPU affinity alone (default: the GPU's NUMA-local cores)")
     ap.add_argument("--batch-pairs", type=int, default=256, help="pairs of the batch256 leg (BASELINE configs[2])")
     ap.add_argument("--sharded-pairs", type=int, default=4096, help="pair ids of the N>1 sharded leg (configs[3])")
     ap.add_argument("--batch-slots", type=int, default=32, help="stream slots of the batched legs (two lanes of half as many pairs)")
@@ -183,6 +184,9 @@ def main() -> None:
     from quatro_amd import dist as qdist
     from quatro_amd import lib as ql
     from quatro_amd import synth
+
+    # one process per GPU, on the cores of the GPU's NUMA node (every hand-over of the path crosses PCIe twice)
+    host_cpus = None if args.no_pin else qdist.pin_to_device_node(local_rank)
 
     LC = int(args.corr)
     h = ql.Handle(local_rank, max_points=131072, max_voxels=32768, max_corr=max(8192, LC + 64))
@@ -409,6 +413,7 @@ def main() -> None:
                       "n_corr": int(LC if composite else p["L"]), "n_corr_matcher": int(p["L"]), "n_hit": int(p["n_hit"]),
                       "n_clique": int(p["result"]["clique"].size)}
                      for p in pool],
+            "host_cpus": host_cpus or "unpinned",
             "records_gathered": 0 if gathered is None else int(gathered.shape[0]),
             "parallelism": f"pair ids [0,{world * args.steps}) block-partitioned over {world} GPU(s) ({args.steps} per rank), one "
                            "process per GPU, RCCL "

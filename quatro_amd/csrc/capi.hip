@@ -1671,6 +1671,14 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
       // block 0 of k2_vox_centroids publishes the counters while other blocks are still writing centroids: anything
       // that reads the centroids from another stream has to wait for the kernel itself
       QTR_HIP_TRY(h, hipEventRecord(s.ev_vox, s.stream));
+      // The matcher's sequential means (70 us of one dependent chain per cloud: as long as the whole FPFH chain since round
+      // 6's cuts) start right behind the centroids, on the second stream, with the voxel counts read on the device — not
+      // after the mail, the host's checks and the FPFH chain's ten launches.
+      {
+        const int on_device[2] = {-1, -1};
+        QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
+        QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, on_device, s.stream2, h->lim.max_voxels));
+      }
       // k2_vox_centroids leaves both clouds' counters in the mailbox
       if ((rc = wait_mail(h, s, MAIL_SEQ_VOX0, s.seq)) != QTR_OK || (rc = wait_mail(h, s, MAIL_SEQ_VOX1, s.seq)) != QTR_OK)
         return fail_drained(rc);
@@ -1693,6 +1701,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     }
   }
   int ns = s.mail[MAIL_VOX0 + CNT_NVOX], nt = s.mail[MAIL_VOX1 + CNT_NVOX];
+  bool passed_through = false;
   if (ns < 0 || nt < 0) {  // k2_vox_centroids: a tile never published its count (bounded look-back): nothing usable was written
     snprintf(h->err, sizeof(h->err), "voxel grid: look-back timed out");
     return fail_drained(QTR_ERR_HIP);
@@ -1703,6 +1712,7 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     // demo goes on with the cloud as it is — BASELINE's dense mode ("no voxel downsample") through the whole-path entry.
     const bool pass[2] = {s.mail[MAIL_VOX0 + CNT_VOX_OVERFLOW] != 0, s.mail[MAIL_VOX1 + CNT_VOX_OVERFLOW] != 0};
     if (pass[0] || pass[1]) {
+      passed_through = true;
       if ((pass[0] && Ps > h->lim.max_voxels) || (pass[1] && Pt > h->lim.max_voxels)) {
         snprintf(h->err, sizeof(h->err), "voxel grid would overflow int32 (leaf too small): the cloud passes through as it "
                  "is (pcl::VoxelGrid), and its %d / %d points exceed max_voxels=%d", Ps, Pt, h->lim.max_voxels);
@@ -1730,13 +1740,10 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
   if (h->stage_events) QTR_HIP_TRY(h, hipEventRecord(s.ev[1], s.stream));
   {
     const int n2[2] = {ns, nt};
-    // Beside the FPFH chain, on the second stream: the matcher's sequential means (70 us: the long pole over there), and
-    // the matcher's and the solver's clean slates (they depend on the voxel counts alone).  The device is idle until the
-    // FPFH chain's first launch arrives, so that chain goes first and the second stream's work after it; QTR_MEAN_FIRST=1
-    // issues the means before the chain (one launch of delay for the chain, ~20 us of head start for the means — for
-    // hosts slow enough that the second stream would otherwise finish last).
-    static const bool mean_first = QTR_ENGINE_ENV("QTR_MEAN_FIRST") != nullptr;
-    if (mean_first) {
+    // Beside the FPFH chain, on the second stream: the matcher's sequential means (already running: enqueued behind the
+    // voxel stage above; a cloud that passed through is summed again from the copy), and the matcher's and the solver's
+    // clean slates (they depend on the voxel counts alone).
+    if (passed_through) {
       QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
       QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
     }
@@ -1744,10 +1751,6 @@ static int front_device(qtr_handle* h, Slot& s, const float* src_raw4, int Ps, c
     // (k2_fpfh also does the matcher's per-descriptor preparation: norms, hashes, duplicate table — see frontend.hip)
     QTR_HIP_TRY(h, fpfh_enqueue(s.fb, 0, 2, n2, fp->normal_radius, fp->fpfh_radius, s.stream, false, true, h->long_lists, true,
                                 cell_table_cells(s.mail[MAIL_VOX0 + CNT_NCELL], s.mail[MAIL_VOX1 + CNT_NCELL])));
-    if (!mean_first) {
-      QTR_HIP_TRY(h, hipStreamWaitEvent(s.stream2, s.ev_vox, 0));
-      QTR_HIP_TRY(h, mean_enqueue(s.fb, 0, 2, n2, s.stream2));
-    }
     // (the solver's clean slate rides in the matcher's: one launch fewer beside the FPFH chain)
     QTR_HIP_TRY(h, match_init_enqueue(s.fb, ns, nt, *fp, s.stream2, false, for_solver ? (int*)s.sb.st : nullptr,
                                       (int)(sizeof(SolverState) / 4)));

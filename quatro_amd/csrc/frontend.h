@@ -249,7 +249,7 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 hipError_t fpfh_enqueue(FrontBufs& F, int first, int nc, const int* n, float r_normal, float r_fpfh, hipStream_t st,
                         bool with_mean, bool origin_known, bool long_lists, bool desc_prep = false,
                         int max_ncell = 0 /* > 0 (and <= QTR_CELL_CAP, origin_known): the dense cell table, see frontend.hip */);
-hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st);
+hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st, int cap = 0);
 // init_done: match_init_enqueue already ran for this pair (same ns, nt, fp) — the whole-path driver issues it beside the
 // FPFH chain, which takes one launch off the critical path
 // prep_done: the clouds' k2_fpfh did k_desc_prep's work (fpfh_enqueue* with desc_prep) — then the init may not clear the

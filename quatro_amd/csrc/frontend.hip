@@ -1706,9 +1706,17 @@ __global__ __launch_bounds__(256) void k2_fpfh(ViewExt<CloudView> x, Clouds2 a) 
          C.dd_table, C.dd_mask);
 }
 template <bool EXT>
-__global__ __launch_bounds__(256) void k2_seq_mean(ViewExt<CloudView> x, Clouds2 a) {
+__global__ __launch_bounds__(256) void k2_seq_mean(ViewExt<CloudView> x, Clouds2 a, int cap) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
-  d_seq_mean(C.vox, C.n, C.mean);
+  int n = C.n;
+  if (n < 0) {
+    // enqueued behind the voxel stage BEFORE the host has its counters (the whole-path driver: the 70 us chain starts while
+    // the host still waits for the mail instead of behind the FPFH chain's launches): the count is the device's own.  A cloud
+    // that passes through is copied by the host after the mail; its mean is enqueued again behind that copy.
+    if (C.counts[CNT_VOX_OVERFLOW] != 0) return;
+    n = min(max(C.counts[CNT_NVOX], 0), cap);
+  }
+  d_seq_mean(C.vox, n, C.mean);
 }
 __global__ __launch_bounds__(1024) void k_scan_i32_copy(const int* __restrict__ in, int* __restrict__ out, int n) {
   d_scan_i32_copy(in, out, n);
@@ -1850,13 +1858,14 @@ hipError_t set_count_enqueue(CloudBufs& C, int which, int value, hipStream_t st)
 
 // Matcher::normalizePoints means of nc clouds; independent of the FPFH chain, so the whole-path driver runs it
 // on the slot's second stream
-hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st) {
+// n[c] < 0: the cloud's voxel count is read on the device (at most `cap`; see k2_seq_mean)
+hipError_t mean_enqueue(FrontBufs& F, int first, int nc, const int* n, hipStream_t st, int cap) {
   CloudView v[2];
   for (int c = 0; c < nc; ++c) v[c] = make_view(F.cloud[first + c], nullptr, 0, n[c], nullptr, nullptr, 0);
   CloudSet S;
   hipError_t e = cloudset_finish(S, v, nc, nullptr, st);
   if (e != hipSuccess) return e;
-  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
+  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st, cap);
   return hipGetLastError();
 }
 hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStage* stage, hipStream_t st) {
@@ -1866,7 +1875,7 @@ hipError_t mean_enqueue_group(FrontBufs* const* F, int G, const int* n, ViewStag
   CloudSet S;
   hipError_t e = cloudset_finish(S, v.data(), 2 * G, stage, st);
   if (e != hipSuccess) return e;
-  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, 2 * G), dim3(256), 0, st);
+  LAUNCH_CV(k2_seq_mean, S.a, dim3(1, 2 * G), dim3(256), 0, st, 0);
   return hipGetLastError();
 }
 
@@ -1902,7 +1911,7 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   LAUNCH_CV(k2_normals, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, rn2);
   LAUNCH_CV(k2_spfh, S.a, dim3((maxn + SPFH_PB - 1) / SPFH_PB, nc), dim3(256), 0, st);
   LAUNCH_CV(k2_fpfh, S.a, dim3((maxn + FPFH_PB - 1) / FPFH_PB, nc), dim3(256), 0, st);
-  if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st);
+  if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st, 0);
 }
 
 // long_lists: also launch k2_neighbors_big, which serves the points with more than QTR_KMAX neighbours inside r_fpfh.

@@ -81,3 +81,38 @@ def all_over_ranks(value: float, device=None) -> list:
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]
+
+
+def parse_cpulist(text: str) -> list:
+    """'64-127,192-255' (sysfs local_cpulist) -> sorted list of CPU numbers; '' -> []."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def pin_to_device_node(device_index: int):
+    """Restrict this process to the CPU cores of the GPU's NUMA node (one process per GPU: every hand-over of the path — voxel
+    counts, matcher counts, the result — crosses PCIe twice, and from the other socket each costs a microsecond or two more:
+    profiles/r6_ab.txt section 14).  Returns the sysfs cpulist that was applied, or None when there is nothing to go by (no sysfs
+    entry, an affinity mask that already excludes those cores, a platform without sched_setaffinity)."""
+    import os
+
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as fh:
+            text = fh.read().strip()
+        want = set(parse_cpulist(text)) & set(os.sched_getaffinity(0))
+        if not want:
+            return None
+        os.sched_setaffinity(0, want)
+        return text
+    except Exception:  # (no GPU, no such attribute in this torch, no sysfs entry, ...): leave the affinity as it is
+        return None

@@ -110,3 +110,16 @@ def test_sharded_registrations_gather_on_rank0_gloo_world2():
         r = qo.solve(src, tgt)
         assert np.array_equal(g[pid, :16].reshape(4, 4), r["T"]) and g[pid, 18] == len(r["clique"])
         assert g[pid, 17] == 1.0 and np.abs(r["T"][:3, 3] - Tgt[:3, 3]).max() < 0.2
+
+
+def test_cpulist_parsing_and_pinning_without_a_gpu():
+    """bench.py pins each rank to its GPU's NUMA-local cores (sysfs local_cpulist); without a GPU nothing is changed."""
+    import os
+
+    from quatro_amd import dist as qd
+
+    assert qd.parse_cpulist("64-127,192-255") == list(range(64, 128)) + list(range(192, 256))
+    assert qd.parse_cpulist("3") == [3] and qd.parse_cpulist("") == [] and qd.parse_cpulist("0-1, 5\n") == [0, 1, 5]
+    before = os.sched_getaffinity(0)
+    assert qd.pin_to_device_node(0) is None
+    assert os.sched_getaffinity(0) == before
