@@ -1901,39 +1901,123 @@ __global__ __launch_bounds__(1024) void k_nc_scan(ViewExt<MatchView> x, MatchVie
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
   d_block_scan(which == 0 ? V.nc_cnt : V.nc_fill, which == 0 ? V.nc_off : V.scan, V.ns, [](int v) { return v; });
 }
-// every source sorts its (short) target list, drops repeats and leaves the distinct count in nc_fill
+// Every source sorts its target list, drops repeats and leaves the distinct count in nc_fill.  Almost every list is a
+// handful of entries (one thread, insertion sort) — but a list's length is the source's in-degree in the other cloud's
+// nearest-neighbour table, and a descriptor that many points of the other cloud are nearest to (flat ground: one pair of
+// the bench pool has a source with thousands of targets; identical descriptors: ALL of them) made that thread's
+// quadratic loop the registration's longest kernel by a factor of ten (13 ms, profiles/r6_ab.txt section 15).  Lists above
+// NC_SHORT entries are therefore left to the whole workgroup: the targets are indices below nt, so the list is laid down
+// as a bit set in LDS (NC_RANGE targets at a time) and read back in order — sorted and unique in O(k + nt / 32) — via a
+// scratch slice (cross_i: dead since k_nc_scatter) because a list longer than one range is still being read while its
+// head is written.
+#define NC_SHORT 32
+#define NC_RANGE 16384
+__device__ __forceinline__ int nc_unique_long(int* __restrict__ l, int* __restrict__ out, int k, int n_other,
+                                              u32* __restrict__ s_bits, int* __restrict__ s_wt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int u = 0;  // (workgroup-uniform)
+  for (int lo = 0; lo < n_other; lo += NC_RANGE) {
+    const int span = min(NC_RANGE, n_other - lo), words = (span + 31) >> 5;
+    for (int w = tid; w < words; w += 256) s_bits[w] = 0u;
+    __syncthreads();
+    for (int a = tid; a < k; a += 256) {
+      const int v = l[a] - lo;
+      if ((unsigned)v < (unsigned)span) atomicOr(&s_bits[v >> 5], 1u << (v & 31));
+    }
+    __syncthreads();
+    for (int w0 = 0; w0 < words; w0 += 256) {
+      const int w = w0 + tid;
+      u32 bits = (w < words) ? s_bits[w] : 0u;
+      int tot;
+      const int ex = wave_excl_scan_i32(__popc(bits), &tot);
+      if (lane == 0) s_wt[wave] = tot;
+      __syncthreads();
+      int pos = u + ex;
+      for (int q = 0; q < wave; ++q) pos += s_wt[q];
+      while (bits) {
+        out[pos++] = lo + (w << 5) + __ffs(bits) - 1;
+        bits &= bits - 1u;
+      }
+      u += (s_wt[0] + s_wt[1]) + (s_wt[2] + s_wt[3]);
+      __syncthreads();
+    }
+  }
+  for (int a = tid; a < u; a += 256) l[a] = out[a];  // (out was written by other threads: the loop's last barrier orders it)
+  return u;
+}
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_nc_unique(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < V.ns; s += gridDim.x * blockDim.x) {
-    int* l = V.nc_list + V.nc_off[s];
-    const int k = V.nc_cnt[s];
-    for (int a = 1; a < k; ++a) {  // insertion sort: lists are a handful of entries
-      const int v = l[a];
-      int b = a - 1;
-      while (b >= 0 && l[b] > v) {
-        l[b + 1] = l[b];
-        --b;
+  __shared__ u32 s_bits[NC_RANGE / 32];
+  __shared__ int s_long[256], s_nlong, s_wt[4];
+  const int ns = V.ns, nt = V.nt;
+  for (int base = blockIdx.x * 256; base < ns; base += gridDim.x * 256) {
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    const int s = base + (int)threadIdx.x;
+    if (s < ns) {
+      int* l = V.nc_list + V.nc_off[s];
+      const int k = V.nc_cnt[s];
+      if (k > NC_SHORT) {
+        s_long[atomicAdd(&s_nlong, 1)] = s;
+      } else {
+        for (int a = 1; a < k; ++a) {  // insertion sort: a handful of entries
+          const int v = l[a];
+          int b = a - 1;
+          while (b >= 0 && l[b] > v) {
+            l[b + 1] = l[b];
+            --b;
+          }
+          l[b + 1] = v;
+        }
+        int u = 0;
+        for (int a = 0; a < k; ++a)
+          if (a == 0 || l[a] != l[a - 1]) l[u++] = l[a];
+        V.nc_fill[s] = u;
       }
-      l[b + 1] = v;
     }
-    int u = 0;
-    for (int a = 0; a < k; ++a)
-      if (a == 0 || l[a] != l[a - 1]) l[u++] = l[a];
-    V.nc_fill[s] = u;
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int q = 0; q < nlong; ++q) {
+      const int sl = s_long[q], off = V.nc_off[sl];
+      const int u = nc_unique_long(V.nc_list + off, V.cross_i + off, V.nc_cnt[sl], nt, s_bits, s_wt);
+      if (threadIdx.x == 0) V.nc_fill[sl] = u;
+    }
+    __syncthreads();
   }
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_nc_emit(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
+  __shared__ int s_long[256], s_nlong;
   const int ns = V.ns;
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
-    const int u = V.nc_fill[s], o = V.scan[s];
-    const int* l = V.nc_list + V.nc_off[s];
-    for (int a = 0; a < u; ++a) {
-      V.corr[2 * (o + a)] = s;
-      V.corr[2 * (o + a) + 1] = l[a];
+  for (int base = blockIdx.x * 256; base < ns; base += gridDim.x * 256) {
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    const int s = base + (int)threadIdx.x;
+    if (s < ns) {
+      const int u = V.nc_fill[s], o = V.scan[s];
+      if (u > NC_SHORT) {
+        s_long[atomicAdd(&s_nlong, 1)] = s;  // (the workgroup writes a long list together)
+      } else {
+        const int* l = V.nc_list + V.nc_off[s];
+        for (int a = 0; a < u; ++a) {
+          V.corr[2 * (o + a)] = s;
+          V.corr[2 * (o + a) + 1] = l[a];
+        }
+      }
     }
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int q = 0; q < nlong; ++q) {
+      const int sl = s_long[q], u = V.nc_fill[sl], o = V.scan[sl];
+      const int* l = V.nc_list + V.nc_off[sl];
+      for (int a = threadIdx.x; a < u; a += 256) {
+        V.corr[2 * (o + a)] = sl;
+        V.corr[2 * (o + a) + 1] = l[a];
+      }
+    }
+    __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) V.mcounts[MC_NCORR] = V.scan[ns];
   if (V.mail && blockIdx.x == 0 && threadIdx.x < 48) match_mail(V, threadIdx.x, V.scan[ns], V.mcounts[MC_NTUPLE]);

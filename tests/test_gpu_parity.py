@@ -259,6 +259,57 @@ def test_match_matches_oracle(hip, qo, small_pair):
             assert np.array_equal(nc, qo.match(a, da, b, db, crosscheck=False, tuple_test=bool(tup), seed=seed))
 
 
+def test_match_without_crosscheck_sorts_hub_lists_like_the_oracle(qo):
+    """use_crosscheck = false (reference feature_matcher.cc:146-181: corres_ij + corres_ji, sorted, unique) when ONE descriptor is
+    the nearest neighbour of thousands of the other cloud's (flat ground does that to FPFH): the per-source target lists are
+    then thousands of entries long (k_nc_unique's workgroup path: a bit set per NC_RANGE = 16384 targets), here with either
+    cloud as the source, with targets on both sides of a range boundary, and with every descriptor identical (all of a cloud on one list)."""
+    rng = np.random.default_rng(77)
+    h = ql.Handle(0, max_points=32768, max_voxels=32768, max_corr=32768)
+
+    def cloud(n):
+        c = np.zeros((n, 4), dtype=np.float32)
+        c[:, :3] = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+        return c
+
+    def check(a, da, b, db, seed):
+        for tup in (0, 1):
+            got = h.match(a, da, b, db, ql.default_frontend_params(seed=seed, use_crosscheck=0, use_tuple_test=tup))
+            want = qo.match(a, da, b, db, crosscheck=False, tuple_test=bool(tup), seed=seed)
+            assert np.array_equal(got, want), (a.shape[0], b.shape[0], tup)
+            if tup == 0:
+                untested = want
+        return untested  # (the list before the tuple test thins it out)
+
+    try:
+        # (a list's entries are the SMALLER cloud's rows that are nearest to one row of the larger, source, cloud)
+        # 1400 rows of the smaller cloud nearest to row 5000 of the larger one; either cloud as the source
+        a, b = cloud(3000), cloud(6000)
+        da = rng.uniform(0, 100, (3000, 33)).astype(np.float32)
+        db = rng.uniform(0, 100, (6000, 33)).astype(np.float32)
+        da[100:1500] = db[5000] + rng.normal(0, 0.01, (1400, 33)).astype(np.float32)
+        check(a, da, b, db, 21)
+        w = check(b, db, a, da, 22)
+        assert np.count_nonzero(w[:, 0] == 5000) >= 1400
+        # 18 000 sources, 17 000 targets, 3000 of them (14 000 .. 16 999: across the bit set's range boundary) on one list
+        a, b = cloud(18000), cloud(17000)
+        da = rng.uniform(0, 100, (18000, 33)).astype(np.float32)
+        db = rng.uniform(0, 100, (17000, 33)).astype(np.float32)
+        db[14000:] = da[123] + rng.normal(0, 0.01, (3000, 33)).astype(np.float32)
+        w = check(a, da, b, db, 23)
+        on = w[w[:, 0] == 123, 1]
+        assert on.size >= 3000 and on.min() < 16384 < on.max()
+        # every descriptor of a cloud identical: all of the smaller cloud on one list
+        a, b = cloud(2000), cloud(3000)
+        da = np.tile(rng.uniform(0, 100, (1, 33)).astype(np.float32), (2000, 1))
+        db = np.tile(rng.uniform(0, 100, (1, 33)).astype(np.float32), (3000, 1))
+        check(a, da, b, db, 25)
+        w = check(b, db, a, da, 26)
+        assert np.bincount(w[:, 0]).max() >= 2000
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("name,order,cross,tup,seed", [("ab", "ab", 1, 1, 11), ("ba", "ba", 1, 1, 12),
                                                        ("ab_notuple", "ab", 1, 0, 15), ("ab_nocross", "ab", 0, 1, 13),
                                                        ("ba_nocross_notuple", "ba", 0, 0, 14)])
