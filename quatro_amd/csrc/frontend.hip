@@ -365,8 +365,14 @@ __device__ __forceinline__ void vox_grid_counts(const VoxGrid& g, int* __restric
 }
 
 // heads per 1024-element block
-#define VOX_TILE 1024
+// Points per workgroup of the centroid kernel.  One pair at a time the launch is a chain of latencies (keys -> gathered points ->
+// LDS -> look-back -> the runs' sums): 256-point tiles — 1024 workgroups on the two clouds of a scan pair instead of 256, four
+// per compute unit — take 7 us off it (profiles/r6_ab.txt section 16).  A tile reads its halo again (768 points for 256), which
+// the batched path, bound by instruction issue, pays for: it keeps 1024-point tiles.
+#define VOX_TILE_SINGLE 256
+#define VOX_TILE_BATCH 1024
 #define VOX_HALO 512
+template <int VOX_TILE>
 __device__ __forceinline__ void d_vox_centroids(const u64* __restrict__ keys, const float4* __restrict__ pts,
                                                        int P, int* __restrict__ look, float4* __restrict__ out,
                                                        int cap, int nblk, int* __restrict__ counts,
@@ -1604,7 +1610,8 @@ __global__ __launch_bounds__(256) void k2_keys_hist(ViewExt<CloudView> x, Clouds
         C.counts[CNT_NCELL] = cd.nx * cd.ny * cd.nz;  // (<= 2^24: 256 cells per axis)
       }
     }
-    if (threadIdx.x == 0) C.vox_look[blockIdx.x] = 0;  // k2_vox_centroids' look-back words ("not published yet"), one per tile
+    if (threadIdx.x < RADIX_TILE / VOX_TILE_SINGLE)  // k2_vox_centroids' look-back words ("not published yet"), one per tile
+      C.vox_look[blockIdx.x * (RADIX_TILE / VOX_TILE_SINGLE) + threadIdx.x] = 0;
     const float4* __restrict__ pts = C.raw;
     d_radix_hist<8, RADIX_TILE>([&](int i) { return vox_key(g, pts[i], i); }, C.keys_a, n, 32, C.hist, nblk);
   }
@@ -1637,8 +1644,9 @@ template <bool EXT>
 __global__ __launch_bounds__(256) void k2_vox_centroids(ViewExt<CloudView> x, Clouds2 a, int cap, int src) {
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   if (src < 0) src = sorted_src(C, -src, 1);
-  d_vox_centroids(keys_src(C, src), C.raw, C.P, C.vox_look, C.vox, cap, (C.P + 1023) / 1024, C.counts, C.mail,
-                  C.mail_seq_slot, C.seq);
+  constexpr int TILE = EXT ? VOX_TILE_BATCH : VOX_TILE_SINGLE;
+  d_vox_centroids<TILE>(keys_src(C, src), C.raw, C.P, C.vox_look, C.vox, cap, (C.P + TILE - 1) / TILE, C.counts, C.mail,
+                        C.mail_seq_slot, C.seq);
 }
 template <bool EXT>
 __global__ __launch_bounds__(256) void k2_ranges(ViewExt<CloudView> x, Clouds2 a, float cell, int src) {
@@ -1813,7 +1821,8 @@ static void voxelize_launch(const CloudSet& S, float leaf, int max_voxels, hipSt
   const int mm_parts = max(1, min(g, MM_MAX_PARTS));
   LAUNCH_CV(k2_minmax, S.a, dim3(mm_parts, nc), dim3(256), 0, st, 0, 1);
   const int where = radix_sort2(S, 0, 8 * passes, st, true, true, leaf, mm_parts, cell_side);  // (a pass above the keys' bits returns at once)
-  const int nblk = (S.maxP + 1023) / 1024;
+  const int tile = S.a.ext ? VOX_TILE_BATCH : VOX_TILE_SINGLE;  // (as the kernel's template argument picks it)
+  const int nblk = (S.maxP + tile - 1) / tile;
   LAUNCH_CV(k2_vox_centroids, S.a, dim3(nblk, nc), dim3(256), 0, st, max_voxels, where);
 }
 
@@ -1965,7 +1974,7 @@ size_t frontend_scratch_bytes(int max_points, int max_voxels) {
   per_cloud += (size_t)max_voxels * (16 + 16 + 132 + 132);   // vox, normals, spfh, fpfh
   per_cloud += 2 * (size_t)max_points * 8;                   // keys
   per_cloud += (size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4 + 65536;  // hist
-  per_cloud += (size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4 + 256;               // vox_look
+  per_cloud += (size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4 * (RADIX_TILE / VOX_TILE_SINGLE) + 256;  // vox_look
   per_cloud += (size_t)max_voxels * 4 * 2 + 64;              // nbr_cnt, nbr_off
   per_cloud += (size_t)max_voxels * QTR_KMAX * 8;            // nbr_idx, nbr_d2
   per_cloud += (size_t)max_voxels * (16 + 72) + 512;         // spts, ranges
@@ -2005,7 +2014,7 @@ void frontend_carve(FrontBufs& F, void* base, int max_points, int max_voxels) {
     C.keys_a = (u64*)take((size_t)max_points * 8);
     C.keys_b = (u64*)take((size_t)max_points * 8);
     C.hist = (u32*)take((size_t)(4096 * ((max_points + RADIX_TILE - 1) / RADIX_TILE) + 8192) * 4);
-    C.vox_look = (int*)take((size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4);
+    C.vox_look = (int*)take((size_t)((max_points + RADIX_TILE - 1) / RADIX_TILE + 64) * 4 * (RADIX_TILE / VOX_TILE_SINGLE));
     C.nbr_cnt = (int*)take((size_t)max_voxels * 4);
     C.nbr_off = (int*)take((size_t)(max_voxels + 1) * 4);
     C.nbr_idx = (int*)take((size_t)max_voxels * QTR_KMAX * 4);
