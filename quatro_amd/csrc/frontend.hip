@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(256) void k2_normals(ViewExt<CloudView> x, Clouds2 
   const CloudView& C = EXT ? x.ext[blockIdx.y] : a.c[blockIdx.y];  // (inline on purpose: see ViewExt)
   // (the clean slate of the duplicate table k2_fpfh fills two launches on, when it does the matcher's preparation)
   if (C.dd_table)
-    for (int e = blockIdx.x * 256 + threadIdx.x; e <= C.dd_mask; e += gridDim.x * 256) C.dd_table[e] = ~0ULL;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e <= C.dd_mask; e += gridDim.x * blockDim.x) C.dd_table[e] = ~0ULL;
   d_normals(C.vox, C.n, C.nbr_cnt, NbrLists{C.nbr_idx, C.nbr_d2, C.nbr_big_idx, C.nbr_big_d2}, rn2, C.normals);
 }
 template <bool EXT>
@@ -1917,7 +1917,12 @@ static void fpfh_launch(const CloudSet& S, float r_normal, float r_fpfh, hipStre
   LAUNCH_CV(k2_neighbors, S.a, dim3(maxn, nc), dim3(64), 0, st, r2);
   // lists of more than QTR_KMAX entries (one workgroup per such point; returns at once when the cloud has none)
   if (long_lists) LAUNCH_CV(k2_neighbors_big, S.a, dim3(maxn, nc), dim3(256), (size_t)NBIG_LDS_KEYS * 8, st, r2);
-  LAUNCH_CV(k2_normals, S.a, dim3((maxn + 255) / 256, nc), dim3(256), 0, st, rn2);
+  {
+    // a thread per point: one pair at a time 256-thread workgroups would fill 140 of the 256 compute units (section 17 of
+    // profiles/r6_ab.txt); the batched path has points enough
+    const int bs = S.a.ext ? 256 : 64;
+    LAUNCH_CV(k2_normals, S.a, dim3((maxn + bs - 1) / bs, nc), dim3(bs), 0, st, rn2);
+  }
   LAUNCH_CV(k2_spfh, S.a, dim3((maxn + SPFH_PB - 1) / SPFH_PB, nc), dim3(256), 0, st);
   LAUNCH_CV(k2_fpfh, S.a, dim3((maxn + FPFH_PB - 1) / FPFH_PB, nc), dim3(256), 0, st);
   if (with_mean) LAUNCH_CV(k2_seq_mean, S.a, dim3(1, nc), dim3(256), 0, st, 0);

@@ -148,16 +148,17 @@ __device__ __forceinline__ u64 desc_hash(const float* d) { return desc_hash33(d)
 
 // the 256 rows of a workgroup, row-major table -> LDS: 33 coalesced loads per thread, all in flight before the first LDS
 // store (as a plain loop the compiler waits for every load: 33 round trips, 8 us of a 15 us kernel)
+template <int ROWS = 256>  // (= threads of the workgroup)
 __device__ __forceinline__ void stage_rows(const float* __restrict__ desc, int row0, int n, float* s_rows) {
   const size_t base = (size_t)row0 * 33, lim = (size_t)n * 33;
   float t[33];
 #pragma unroll
   for (int k = 0; k < 33; ++k) {
-    const size_t e = base + (size_t)(k * 256 + threadIdx.x);
+    const size_t e = base + (size_t)(k * ROWS + threadIdx.x);
     t[k] = (e < lim) ? desc[e] : 0.f;
   }
 #pragma unroll
-  for (int k = 0; k < 33; ++k) s_rows[k * 256 + threadIdx.x] = t[k];
+  for (int k = 0; k < 33; ++k) s_rows[k * ROWS + threadIdx.x] = t[k];
 }
 
 // desc[n][33] -> baseT[34][n_pad] (row 33 = scaled |b|^2; pad rows get 1e30 so they never win) and
@@ -595,14 +596,15 @@ __device__ __forceinline__ _Float16 query_slot(const HalfRow& q, int s) {
 // representative looked up (a row that repeats a lower row bit for bit is hidden: norm slots 3 x 65504), the range
 // checks, and both operand tables written.  The engine has no other copy of the descriptors: the k-major f32 tables of
 // the other engines are not built.  grid (pad_large_max / 256, 2, pairs)
+template <int ROWS>
 __device__ __forceinline__ void d_half_tables(const float* __restrict__ desc, int n, int n_pad, const u64* __restrict__ hashes,
                                               const u64* __restrict__ table, int mask, int* __restrict__ hidden_count,
                                               uint4* __restrict__ baseH, uint4* __restrict__ queryH, int* __restrict__ unsafe,
-                                              float* s_rows /* LDS, 256 x 33 */) {
-  const int row0 = blockIdx.x * 256;
+                                              float* s_rows /* LDS, ROWS x 33 */) {
+  const int row0 = blockIdx.x * ROWS;
   if (row0 >= n_pad) return;
   QTR_STAMP(STAMP_HALF_TABLES, 0)
-  stage_rows(desc, row0, n, s_rows);
+  stage_rows<ROWS>(desc, row0, n, s_rows);
   __syncthreads();
   QTR_STAMP(STAMP_HALF_TABLES, 1)
   const int i = row0 + threadIdx.x;
@@ -672,15 +674,19 @@ __device__ __forceinline__ void d_half_tables(const float* __restrict__ desc, in
     ((h8*)queryH)[t0 + (size_t)ch * 32] = q8;
   }
 }
+#define HT_ROWS_SINGLE 64
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_half_tables(ViewExt<MatchView> x, MatchView one) {
   const MatchView& V = EXT ? x.ext[blockIdx.z] : one;  // (inline on purpose: see ViewExt)
-  __shared__ float s_rows[256 * 33];
+  // a thread per row: one pair at a time 256-row workgroups would fill 144 of the 256 compute units, so it runs as
+  // one-wave workgroups there (the host launches HT_ROWS_SINGLE threads); the batched path has rows enough
+  constexpr int ROWS = EXT ? 256 : HT_ROWS_SINGLE;
+  __shared__ float s_rows[ROWS * 33];
   if (blockIdx.y == 0)
-    d_half_tables(V.fpfh_i, V.n_large, V.pad_large, V.hash_i, V.table_i, V.dd_mask, V.mcounts + MC_HIDDEN_I, V.baseH_i, V.queryH_i,
+    d_half_tables<ROWS>(V.fpfh_i, V.n_large, V.pad_large, V.hash_i, V.table_i, V.dd_mask, V.mcounts + MC_HIDDEN_I, V.baseH_i, V.queryH_i,
                   V.mcounts + MC_UNSAFE, s_rows);
   else
-    d_half_tables(V.fpfh_j, V.n_small, V.pad_small, V.hash_j, V.table_j, V.dd_mask, V.mcounts + MC_HIDDEN_J, V.baseH_j, V.queryH_j,
+    d_half_tables<ROWS>(V.fpfh_j, V.n_small, V.pad_small, V.hash_j, V.table_j, V.dd_mask, V.mcounts + MC_HIDDEN_J, V.baseH_j, V.queryH_j,
                   V.mcounts + MC_UNSAFE, s_rows);
 }
 
@@ -2562,7 +2568,8 @@ static hipError_t match_launch(const MatchView* views, int G, int nn_engine, int
     // (the f16 engine needs nothing of k_desc_prep but the norms, hashes and duplicate table: k2_fpfh left them)
     if (!(prep_done && f16)) LAUNCH_MV(k_desc_prep, a, dim3(max_pad / 256, 2, G), B256, 0, st, f16 ? 0 : 2);
     if (f16) {  // operand tables with the duplicates hidden, straight from the descriptors
-      LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+      if (a.ext) LAUNCH_MV(k_half_tables, a, dim3(max_pad / 256, 2, G), B256, 0, st);
+      else LAUNCH_MV(k_half_tables, a, dim3(max_pad / HT_ROWS_SINGLE, 2, G), dim3(HT_ROWS_SINGLE), 0, st);
     }
 #ifdef QTR_TEST_ENGINES
     else {  // the norm-bin order serves the span re-check (k_nn_exact_rows); the f16 engine's filter sweeps every tile
