@@ -210,11 +210,15 @@ def main() -> None:
         if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
             raise ql.QuatroHipError(rc, handle.last_error())
 
+    for p in pool:  # (the device addresses once, not four torch calls per step)
+        p["ptrs"] = (p["src"].data_ptr(), int(p["src"].shape[0]), p["tgt"].data_ptr(), int(p["tgt"].shape[0]),
+                     p["cs"].data_ptr(), p["ct"].data_ptr())
+
     def step_composite_1(p, handle=h, r=res, slot=0):
         # voxelize x2 + FPFHManager::setFeaturePair on the scans, then Quatro::computeTransformation on the metric's ~5k
         # correspondences — one call through the C ABI, nothing between the two halves but the library's own hand-over
-        rc = handle.register_pair_corr_dev(p["src"].data_ptr(), p["src"].shape[0], p["tgt"].data_ptr(), p["tgt"].shape[0],
-                                           p["fp"], p["cs"].data_ptr(), p["ct"].data_ptr(), LC, prm, r, slot)
+        sp, sn, tp, tn, cs, ct = p["ptrs"]
+        rc = handle.register_pair_corr_dev(sp, sn, tp, tn, p["fp"], cs, ct, LC, prm, r, slot)
         if rc not in (ql.QTR_OK, ql.QTR_ERR_CLIQUE_TOO_SMALL):
             raise ql.QuatroHipError(rc, handle.last_error())
 
