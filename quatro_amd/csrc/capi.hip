@@ -406,9 +406,18 @@ static int create_impl(qtr_handle* h) {
   QTR_HIP_TRY(h, hipSetDevice(h->device));
   QTR_HIP_TRY(h, solver_init_attributes());
   QTR_HIP_TRY(h, frontend_init_attributes());
+  // A slot's second stream carries what must run BESIDE the first one's chain (the matcher's sequential means: 70 - 200 us of
+  // one workgroup per cloud).  HIP multiplexes a process's streams onto a few hardware queues, and two streams that land on
+  // the same one do not overlap: a handle created after another one (or after a framework's own streams) read the dense step
+  // at 2.11 instead of 1.93 ms for that reason alone — its FPFH stage was chain + means, 0.48 ms, not their maximum, 0.27
+  // (profiles/r6_ab.txt section 19).  Streams of different PRIORITY come from different queue pools, so the second stream
+  // is created at the highest priority: its few small kernels are also the ones that should never wait behind a chain.
+  int prio_least = 0, prio_greatest = 0;
+  QTR_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   for (auto& s : h->slots) {
     QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    if (prio_greatest != prio_least) QTR_HIP_TRY(h, hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, prio_greatest));
+    else QTR_HIP_TRY(h, hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
     for (auto& e : s.ev) QTR_HIP_TRY(h, hipEventCreate(&e));
     QTR_HIP_TRY(h, hipEventCreateWithFlags(&s.ev_vox, hipEventDisableTiming));
     for (auto& e : s.fb.ev_nn) QTR_HIP_TRY(h, hipEventCreate(&e));

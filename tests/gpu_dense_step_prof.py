@@ -15,6 +15,16 @@ from quatro_amd import synth  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = torch.device("cuda", 0)
+if os.environ.get("QTR_DENSE_PREALLOC"):  # (bench.py's situation: another handle and a pool of scans allocated first)
+    h0 = ql.Handle(0, max_points=131072, max_voxels=32768, max_corr=8192)
+    pool0 = [torch.zeros(130000, 4, device=dev) for _ in range(8)]
+    if os.environ.get("QTR_DENSE_PREALLOC") == "run":  # ... and used
+        s0, t0_, _ = synth.kitti64_pair_16k(0)
+        r0 = ql.Result()
+        sd0, td0 = torch.from_numpy(s0).to(dev), torch.from_numpy(t0_).to(dev)
+        for _ in range(50):
+            h0.register_pair_dev(sd0.data_ptr(), sd0.shape[0], td0.data_ptr(), td0.shape[0], ql.default_frontend_params(seed=0),
+                                 ql.demo_params(), r0)
 h = ql.Handle(0, max_points=65536, max_voxels=65536, max_corr=24576)
 prm = ql.demo_params()
 res = ql.Result()
@@ -38,4 +48,12 @@ for name, fn in (("dense_step", lambda: h.register_pair_corr_dev(ad.data_ptr(), 
     torch.cuda.synchronize()
     print(f"{name}: {1e3 * (time.perf_counter() - t0) / reps:.3f} ms per registration  n_corr {res.n_corr} clique {res.n_clique} "
           f"final {res.n_final} valid {res.valid}", flush=True)
+    if os.environ.get("QTR_DENSE_STAGES"):  # (one more call with the stage events on: where the time goes)
+        h.set_stage_events(True)
+        h.set_nn_event_stride(1)
+        fn()
+        fn()
+        print("  stages", {k: round(v, 4) for k, v in h.stage_times().items() if isinstance(v, float)}, flush=True)
+        h.set_stage_events(False)
+        h.set_nn_event_stride(0)
 h.close()
