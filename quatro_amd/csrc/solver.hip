@@ -1434,6 +1434,13 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
   bool bump = true;       // values were stored (set-up) or lowered in the previous iteration: ver[w] has to follow once they have landed
   bool v0_valid = false;  // v0 / E0 were read before the snapshot of THIS iteration (only then may it claim a fixed point)
   int iter = 0;
+  // Every row is evaluated at least once.  The other workgroups get that from their snapshot (it starts as "everything
+  // moved"); workgroup 0's first snapshot is the one the floor's degree histogram was taken from, and if no other workgroup
+  // ever lowers a value — every other vertex's degree IS its core number — nothing moves again and its rows kept their
+  // DEGREES: a vertex 0 of degree 2 between two leaves came out with core number 2 (tests/gpu_fuzz.py seed 72: a
+  // 64-correspondence pair in a batch group whose largest clique is an edge, the search then started from vertex 0
+  // instead of the reference's highest-ranked one; round 6)
+  bool first_pass = true;
   bool finished = false;
   __syncthreads();
 #ifdef QTR_HCA_PROF
@@ -1541,7 +1548,8 @@ __global__ __launch_bounds__(HCA_THREADS) void k_hcore_async(ViewExt<SolverView>
     // (the scout's floor, if it has one by now: thread 0's load rides with the snapshot's, the vote's barrier hands it round)
     if (has_scout && tid == 0) s_floor = hca_load_u32((const unsigned*)V.perm + HCA_CTL_FLOOR2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool any_moved = wg_any(moved);
+    const bool any_moved = wg_any(moved) || first_pass;
+    first_pass = false;
     if (has_scout) {
       const unsigned f2 = __builtin_amdgcn_readfirstlane(s_floor);
       if (f2 & 1u) my_floor = max(my_floor, (int)(f2 >> 1));

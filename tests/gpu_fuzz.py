@@ -122,6 +122,12 @@ while time.time() < t_end:
                     w = same_solution(dict(g, rot_inliers=None), o) if "clique" in g else f"status {g['status']}"
                     if w:
                         report(kind, desc + f" pair {i}", w)
+                        dump = os.environ.get("FUZZ_DUMP_DIR")
+                        if dump:  # the whole group, for a reproducer off the random stream
+                            np.savez(os.path.join(dump, f"fuzz_batch_seed{seed}_case{n_cases}_pair{i}.npz"), noise_bound=nb_, pair=i,
+                                     sizes=np.array(sizes), got_clique=g.get("clique", np.zeros(0, np.int32)),
+                                     want_clique=np.sort(o["clique"]),
+                                     **{f"src{j}": a_ for j, (a_, b_) in enumerate(sets)}, **{f"tgt{j}": b_ for j, (a_, b_) in enumerate(sets)})
         elif kind == "solve":
             L = int(rng.choice([2, 3, 5, 17, 64, 65, 300, 1281, 2000, 4097, 7000]))
             frac = float(rng.choice([0.0, 0.02, 0.1, 0.5, 0.9, 1.0]))

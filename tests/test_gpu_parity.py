@@ -686,6 +686,49 @@ def _random_graph_bitmap(L, p, seed, planted=0):
     return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W), A
 
 
+def test_core_numbers_when_only_the_first_rows_have_to_move(hip, qo):
+    """k_hcore_async evaluates every row at least once: workgroup 0's first snapshot is the one its floor was computed from,
+    and in a graph where every OTHER vertex's degree is its core number nothing ever moves again — vertex 0 (degree 2 or 5
+    between leaves) used to keep its degree as its core number, and the heuristic then started from it instead of from the
+    reference's highest-ranked vertex (found by tests/gpu_fuzz.py seed 72 on a 64-correspondence pair inside a batch group)."""
+    for L, edges in ((2000, [(0, 700), (0, 900), (1500, 1900)]),
+                     (3000, [(0, 10), (0, 1000), (0, 2000), (0, 2500), (0, 2999), (5, 6), (2400, 2800)]),
+                     (1500, [(1, 40), (1, 50), (1, 60), (2, 70), (2, 80), (1400, 1499)])):
+        A = np.zeros((L, L), dtype=bool)
+        for a, b in edges:
+            A[a, b] = A[b, a] = True
+        W = (L + 63) // 64
+        bits = np.zeros((L, W * 64), dtype=np.uint8)
+        bits[:, :L] = A
+        bm = np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W)
+        core, _, mc = qo.kcore(bm)
+        for mode, thr in ((1, 0.5), (2, 0.5)):
+            got, max_core = hip.max_clique(bm, mode, thr)
+            assert max_core == mc == 1
+            assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32)[:L], core), (L, mode)
+            assert np.array_equal(got, qo.max_clique(bm, mode, thr)), (L, mode)
+
+
+def test_batch_group_with_a_tiny_pair_whose_largest_clique_is_an_edge(qo):
+    """tests/golden/batch_tie_case*.npz: the two groups of tests/gpu_fuzz.py seed 72 (correspondence-only pair descriptors of
+    5000 / 64 / 300 / 300 / 2500 and 0 / 300 / 5000 / 64 / 9000 correspondences, noise bound 0.05) whose 64-correspondence
+    member came back with another edge than the oracle's: inside a group every pair runs the large pair's kernels."""
+    hb = ql.Handle(0, max_points=65536, max_voxels=32768, max_corr=12288, n_slots=8)
+    try:
+        for f in ("batch_tie_case2176.npz", "batch_tie_case5740.npz"):
+            d = np.load(os.path.join(G, f))
+            nb = float(d["noise_bound"])
+            sets = [(d[f"src{j}"], d[f"tgt{j}"]) for j in range(len(d["sizes"]))]
+            got = hb.register_batch([(None, None, 0, a, b) for a, b in sets], params=ql.demo_params(noise_bound=nb))
+            for j, (a, b) in enumerate(sets):
+                o = qo.solve(a, b, qo.default_params(noise_bound=nb))
+                assert np.array_equal(got[j]["clique"], np.sort(o["clique"])), (f, j)
+                if o["valid"]:
+                    assert np.array_equal(got[j]["T"], o["T"]), (f, j)
+    finally:
+        hb.close()
+
+
 @pytest.mark.parametrize("L,p,planted,seed", [(1, 0.0, 0, 0), (2, 1.0, 0, 0), (65, 0.3, 0, 1), (200, 0.05, 12, 2),
                                               (777, 0.02, 25, 3), (1500, 0.3, 40, 4), (3000, 0.01, 30, 5),
                                               (2600, 0.01, 1300, 6), (6000, 0.005, 2500, 7)])
