@@ -27,6 +27,9 @@ max-over-ranks of the contract.  For N > 1 the line also carries `sharded_leg`: 
 pair ids, each the headline's unit of work (scan pair + 5000 given correspondences), block-partitioned over the ranks,
 streamed through the batched entry points (strong scaling) and gathered through the LIBRARY's RCCL path
 (qtr_comm_init / qtr_gather_results_v).  Prints ONE JSON line on rank 0.
+Two things happen before the W warm-up steps and are named in `config`: the rank pins itself to the cores of its GPU's NUMA
+node (`host_cpus`; --no-pin) and registers the pool for a quarter of a second (`settle`; --settle-seconds 0: the device's
+clocks have to come back from the seconds of host-side set-up).  The timed region is the K steps and nothing else.
 
 Objects in the line next to the contract's keys:
   roofline      — dominant kernel k_nn_f16: the 33-D distance matrix nb' - 2 a.b evaluated on the f16 matrix pipe with
