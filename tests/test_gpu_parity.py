@@ -709,6 +709,42 @@ def test_core_numbers_when_only_the_first_rows_have_to_move(hip, qo):
             assert np.array_equal(got, qo.max_clique(bm, mode, thr)), (L, mode)
 
 
+def test_core_numbers_and_cliques_of_degenerate_graphs(hip, qo):
+    """Graphs the consistency test of real correspondences rarely builds, through qtr_max_clique above the size where
+    k_hcore_async takes over (1280): no edge at all, a perfect matching, a path (its h-index iteration is a chain of L / 2
+    dependent rounds: the bounded iteration gives up and the peeling workgroup takes over), a cycle, a star, a star whose
+    centre is the LAST vertex, two disjoint cliques of equal size — core numbers and the heuristic's clique against the oracle."""
+    def graph(L, edges):
+        A = np.zeros((L, L), dtype=bool)
+        e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+        A[e[:, 0], e[:, 1]] = True
+        A[e[:, 1], e[:, 0]] = True
+        W = (L + 63) // 64
+        bits = np.zeros((L, W * 64), dtype=np.uint8)
+        bits[:, :L] = A
+        return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(L, W)
+
+    L = 1600
+    k1, k2 = list(range(100, 112)), list(range(1500, 1512))
+    cases = {
+        "empty": [],
+        "matching": [(2 * i, 2 * i + 1) for i in range(L // 2)],
+        "path": [(i, i + 1) for i in range(L - 1)],
+        "cycle": [(i, (i + 1) % L) for i in range(L)],
+        "star": [(0, i) for i in range(1, L)],
+        "star_last": [(L - 1, i) for i in range(L - 1)],
+        "two_cliques": [(a, b) for k in (k1, k2) for a in k for b in k if a < b],
+    }
+    for name, edges in cases.items():
+        bm = graph(L, edges)
+        core, _, mc = qo.kcore(bm)
+        for mode, thr in ((1, 0.5), (2, 0.5)):
+            got, max_core = hip.max_clique(bm, mode, thr)
+            assert max_core == mc, (name, mode)
+            assert np.array_equal(hip.debug_fetch(ql.DBG_CORE, np.int32)[:L], core), (name, mode)
+            assert np.array_equal(got, qo.max_clique(bm, mode, thr)), (name, mode)
+
+
 def test_batch_group_with_a_tiny_pair_whose_largest_clique_is_an_edge(qo):
     """tests/golden/batch_tie_case*.npz: the two groups of tests/gpu_fuzz.py seed 72 (correspondence-only pair descriptors of
     5000 / 64 / 300 / 300 / 2500 and 0 / 300 / 5000 / 64 / 9000 correspondences, noise bound 0.05) whose 64-correspondence
